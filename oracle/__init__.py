@@ -1,0 +1,18 @@
+"""CPU oracle for the D3GA deform-and-rasterize hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``d3ga_amd/`` or ``compat/`` may import
+this package: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` do, and only as the checker.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * ``oracle.deform`` / ``oracle.camera`` -- PINNED against golden vectors captured
+    from the reference's own Python (``tools/gen_golden.py`` -> ``tests/golden/*.npz``).
+  * ``oracle.raster_torch`` / ``oracle/raster_c`` -- PARITY UNPINNED: the reference's
+    rasterizer (graphdeco-inria/diff-gaussian-rasterization, branch ``dr_aa``, SHA not
+    recorded in /root/reference/.gitmodules:9-12) is an un-vendored CUDA submodule with no
+    tests or golden vectors in the reference tree.  These restate the published 3DGS
+    algorithm (Kerbl et al. 2023) and are anchored on the reference's call site
+    (renderer.py:79-141) plus known-answer tests.
+  * ``oracle.bary`` -- convention pinned by submodules/tetrahedralize/include/tet/tetrahedron.h:46-101;
+    tetra_sampler.compute_bary itself is un-vendored (parity unpinned for out-of-cage points).
+"""

@@ -1,0 +1,120 @@
+"""ctypes front-end of the C oracle rasterizer (oracle/raster_c/raster_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  PARITY UNPINNED (no reference rasterizer source).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "..", "_build", "libraster_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "raster_oracle.c")
+    os.makedirs(os.path.dirname(_SO), exist_ok=True)
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-shared", "-fPIC", src, "-o", _SO, "-lm"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        L.ro_forward.restype = ctypes.c_void_p
+        L.ro_num_rendered.restype = ctypes.c_int64
+        L.ro_num_rendered.argtypes = [ctypes.c_void_p]
+        L.ro_free.argtypes = [ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Context:
+    def __init__(self, handle, keep):
+        self.handle = handle
+        self.keep = keep
+
+    def __del__(self):
+        try:
+            if self.handle and _lib is not None:
+                _lib.ro_free(ctypes.c_void_p(self.handle))
+        except Exception:
+            pass
+        self.handle = None
+
+
+def forward(means3D, opacities, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, W, H,
+            cov3D_precomp=None, scales=None, rotations=None, scale_modifier=1.0,
+            shs=None, colors_precomp=None, sh_degree=0):
+    """numpy in / numpy out.  Returns (color (3,H,W), radii (P,), invdepth (H,W), ctx)."""
+    L = lib()
+    means3D = _f(means3D)
+    P = means3D.shape[0]
+    opacities, bg = _f(opacities).reshape(-1), _f(bg)
+    viewmatrix, projmatrix, campos = _f(viewmatrix).reshape(-1), _f(projmatrix).reshape(-1), _f(campos)
+    cov3D_precomp, scales, rotations, shs, colors_precomp = map(_f, (cov3D_precomp, scales, rotations, shs,
+                                                                    colors_precomp))
+    M = shs.shape[1] if shs is not None else 0
+    color = np.zeros((3, H, W), np.float32)
+    radii = np.zeros(P, np.int32)
+    invd = np.zeros((H, W), np.float32)
+    h = L.ro_forward(ctypes.c_int(P), ctypes.c_int(M), ctypes.c_int(sh_degree), ctypes.c_int(W), ctypes.c_int(H),
+                     _p(means3D), _p(shs), _p(colors_precomp), _p(opacities), _p(scales), _p(rotations),
+                     ctypes.c_float(scale_modifier), _p(cov3D_precomp), _p(viewmatrix), _p(projmatrix), _p(campos),
+                     ctypes.c_float(tanfovx), ctypes.c_float(tanfovy), _p(bg), _p(color), _p(radii), _p(invd))
+    ctx = Context(h, dict(means3D=means3D, shs=shs, scales=scales, rotations=rotations, P=P, M=M, W=W, H=H,
+                          has_sh=shs is not None, from_sr=cov3D_precomp is None))
+    return color, radii, invd, ctx
+
+
+def num_rendered(ctx):
+    return int(lib().ro_num_rendered(ctypes.c_void_p(ctx.handle)))
+
+
+def tile_lists(ctx):
+    k = ctx.keep
+    tiles = ((k["W"] + 15) // 16) * ((k["H"] + 15) // 16)
+    D = num_rendered(ctx)
+    start = np.zeros(tiles + 1, np.int64)
+    pl = np.zeros(max(D, 1), np.int32)
+    lib().ro_get_tile_list(ctypes.c_void_p(ctx.handle), _p(start), _p(pl))
+    return start, pl[:D]
+
+
+def geom(ctx):
+    k = ctx.keep
+    P, W, H = k["P"], k["W"], k["H"]
+    depth = np.zeros(P, np.float32); xy = np.zeros((P, 2), np.float32); co = np.zeros((P, 4), np.float32)
+    rgb = np.zeros((P, 3), np.float32); nc = np.zeros((H, W), np.int32); fT = np.zeros((H, W), np.float32)
+    lib().ro_get_geom(ctypes.c_void_p(ctx.handle), _p(depth), _p(xy), _p(co), _p(rgb), _p(nc), _p(fT))
+    return dict(depth=depth, xy=xy, conic_o=co, rgb=rgb, n_contrib=nc, final_T=fT)
+
+
+def backward(ctx, dL_dpix):
+    """Returns dict of numpy grads: means3D, means2D(P,3), shs|colors, opacities(P,1), scales, rotations, cov3D."""
+    k = ctx.keep
+    P, M = k["P"], k["M"]
+    dL_dpix = _f(dL_dpix)
+    g = dict(means3D=np.zeros((P, 3), np.float32), means2D=np.zeros((P, 3), np.float32),
+             opacities=np.zeros((P, 1), np.float32), cov3D=np.zeros((P, 6), np.float32))
+    g["shs"] = np.zeros((P, M, 3), np.float32) if k["has_sh"] else None
+    g["colors"] = None if k["has_sh"] else np.zeros((P, 3), np.float32)
+    g["scales"] = np.zeros((P, 3), np.float32) if k["from_sr"] else None
+    g["rotations"] = np.zeros((P, 4), np.float32) if k["from_sr"] else None
+    lib().ro_backward(ctypes.c_void_p(ctx.handle), _p(k["means3D"]), _p(k["shs"]), _p(k["scales"]), _p(k["rotations"]),
+                      _p(dL_dpix), _p(g["means3D"]), _p(g["means2D"]), _p(g["shs"]), _p(g["colors"]),
+                      _p(g["opacities"]), _p(g["scales"]), _p(g["rotations"]), _p(g["cov3D"]))
+    return g
