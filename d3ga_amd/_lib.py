@@ -1,0 +1,94 @@
+"""ctypes binding of libd3ga_hip.so (include/d3ga.h).  Fails loudly when the library is absent."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "libd3ga_hip.so")
+_lib = None
+
+
+class D3GAError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _PATH
+
+
+class RasterParams(ctypes.Structure):
+    """struct d3ga_raster_params (include/d3ga.h)."""
+    _fields_ = [("P", ctypes.c_int32), ("M", ctypes.c_int32), ("sh_degree", ctypes.c_int32),
+                ("W", ctypes.c_int32), ("H", ctypes.c_int32),
+                ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
+                ("antialiasing", ctypes.c_int32), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32)]
+
+
+_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_prm = ctypes.POINTER(RasterParams)
+
+# name -> (argtypes, restype); the trailing _vp of every launch entry is the hipStream_t
+_SIGNATURES = {
+    "d3ga_version": ([], _i),
+    "d3ga_status_string": ([_i], ctypes.c_char_p),
+    "d3ga_lbs_cage_fwd": ([_i, _i] + [_vp] * 8 + [_vp], _i),
+    "d3ga_lbs_cage_bwd": ([_i, _i] + [_vp] * 6 + [_vp], _i),
+    "d3ga_cage_deform_fwd": ([_i] + [_vp] * 9 + [_vp], _i),
+    "d3ga_cage_deform_bwd": ([_i, _i] + [_vp] * 13 + [_vp], _i),
+    "d3ga_fem_energy_fwd": ([_i] + [_vp] * 4 + [_vp], _i),
+    "d3ga_fem_energy_bwd": ([_i, _i] + [_vp] * 5 + [_vp], _i),
+    "d3ga_raster_scratch_bytes": ([ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, ctypes.POINTER(_i64)], _i),
+    "d3ga_raster_preprocess": ([_prm] + [_vp] * 12 + [_i64, _vp, _vp], _i),
+    "d3ga_raster_bin_sort": ([_prm, _vp, _vp, _i64, _vp], _i),
+    "d3ga_raster_composite_fwd": ([_prm, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i),
+    "d3ga_raster_composite_bwd": ([_prm, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i),
+    "d3ga_raster_preprocess_bwd": ([_prm] + [_vp] * 18 + [_vp], _i),
+    "d3ga_raster_forward": ([_prm] + [_vp] * 14 + [_i64, _vp, _vp, _vp, _vp], _i),
+    "d3ga_raster_backward": ([_prm] + [_vp] * 11 + [_i64] + [_vp] * 11 + [_vp], _i),
+    "d3ga_raster_mark_visible": ([ctypes.c_int32, _vp, _vp, _vp, _vp], _i),
+    "d3ga_compute_bary": ([_i, _i] + [_vp] * 5 + [_vp], _i),
+    "d3ga_selftest_wave_sum": ([_i, _vp, _vp, _vp], _i),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib():
+    """The loaded library.  Raises D3GAError (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            raise D3GAError(
+                f"{_PATH} is missing: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or python d3ga_amd/csrc/build.py). "
+                "There is no CPU fallback for this path.")
+        import torch  # noqa: F401  -- loads PyTorch-ROCm's HIP runtime first so the process holds one runtime
+        L = ctypes.CDLL(_PATH)
+        for name, (args, res) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = res
+        if L.d3ga_version() != 100:
+            raise D3GAError(f"libd3ga_hip.so version {L.d3ga_version()} does not match the Python layer (100)")
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().d3ga_status_string(status)
+        raise D3GAError(f"{what} failed with status {status}: {msg.decode() if msg else '?'}")
+
+
+def stream_handle():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise D3GAError("d3ga_amd ops run on the GPU only (tensor on %s); there is no CPU fallback" % t.device)

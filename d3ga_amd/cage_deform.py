@@ -1,0 +1,138 @@
+"""Autograd ops of the cage side of the hot path: LBS of cage vertices, fused tet-cage deformation, FEM energy.
+
+Host-side mirror of the reference's per-frame tensor program:
+    lib/smplman.py:155-171        -> lbs_cage
+    models/cage_net.py:218-230    -> cage_deform      (replaces tetpoints[tetra_faces], compute_def_grad,
+                                                        J S J^T, strip_symmetric and the bary einsum)
+    lib/cage.py:349-361           -> fem_energy
+All three call hand-written gfx950 kernels through the C ABI (include/d3ga.h); GPU tensors only.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, dptr, require_cuda, stream_handle
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _i32c(t):
+    if t.dtype != torch.int32:
+        t = t.to(torch.int32)
+    return t.contiguous()
+
+
+class _CageDeform(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations):
+        require_cuda(tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations)
+        tetpoints, barys, canon_grad, scales, rotations = map(_f32c, (tetpoints, barys, canon_grad, scales, rotations))
+        P = barys.shape[0]
+        means = torch.empty((P, 3), dtype=torch.float32, device=barys.device)
+        cov6 = torch.empty((P, 6), dtype=torch.float32, device=barys.device)
+        check(_lib.lib().d3ga_cage_deform_fwd(P, dptr(tetpoints), dptr(tetras), dptr(tetra_id), dptr(barys),
+                                              dptr(canon_grad), dptr(scales), dptr(rotations), dptr(means),
+                                              dptr(cov6), stream_handle()), "d3ga_cage_deform_fwd")
+        ctx.save_for_backward(tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations)
+        return means, cov6
+
+    @staticmethod
+    def backward(ctx, g_means, g_cov6):
+        tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations = ctx.saved_tensors
+        P, V = barys.shape[0], tetpoints.shape[0]
+        dev = barys.device
+        g_means = torch.zeros((P, 3), device=dev) if g_means is None else _f32c(g_means)
+        g_cov6 = torch.zeros((P, 6), device=dev) if g_cov6 is None else _f32c(g_cov6)
+        need = ctx.needs_input_grad
+        g_tp = torch.empty((V, 3), dtype=torch.float32, device=dev) if need[0] else None
+        g_b = torch.empty((P, 4), dtype=torch.float32, device=dev) if need[3] else None
+        g_s = torch.empty((P, 3), dtype=torch.float32, device=dev) if need[5] else None
+        g_r = torch.empty((P, 4), dtype=torch.float32, device=dev) if need[6] else None
+        check(_lib.lib().d3ga_cage_deform_bwd(P, V, dptr(tetpoints), dptr(tetras), dptr(tetra_id), dptr(barys),
+                                              dptr(canon_grad), dptr(scales), dptr(rotations), dptr(g_means),
+                                              dptr(g_cov6), dptr(g_tp), dptr(g_b), dptr(g_s), dptr(g_r),
+                                              stream_handle()), "d3ga_cage_deform_bwd")
+        return g_tp, None, None, g_b, None, g_s, g_r
+
+
+def cage_deform(tetpoints, tetras, tetra_id, barys, canonical_gradient, scales, rotations):
+    """(tetpoints (V,3), tetras (T,4), tetra_id (P), barys (P,4), canonical_gradient (P,3,3), scales (P,3),
+    rotations (P,4) wxyz) -> (means3D (P,3), cov3D_precomp (P,6)); differentiable in tetpoints, barys, scales,
+    rotations.  Drop-in for models/cage_net.py:218-230.  Index tensors may be int64
+    (as the reference registers them, lib/cage.py:331-337); they are converted to int32 once per call --
+    pass int32 to avoid the copy."""
+    return _CageDeform.apply(tetpoints, _i32c(tetras), _i32c(tetra_id), barys, canonical_gradient, scales, rotations)
+
+
+class _LbsCage(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, template, delta, joint_mats, skin_idx, skin_w, Rh, Th):
+        require_cuda(template, delta, joint_mats, skin_idx, skin_w, Rh, Th)
+        template, delta, joint_mats, skin_w, Rh, Th = map(_f32c, (template, delta, joint_mats, skin_w, Rh, Th))
+        V, K = skin_w.shape
+        out = torch.empty((V, 3), dtype=torch.float32, device=template.device)
+        check(_lib.lib().d3ga_lbs_cage_fwd(V, K, dptr(template), dptr(delta), dptr(joint_mats), dptr(skin_idx),
+                                           dptr(skin_w), dptr(Rh), dptr(Th), dptr(out), stream_handle()),
+              "d3ga_lbs_cage_fwd")
+        ctx.save_for_backward(joint_mats, skin_idx, skin_w, Rh if Rh is not None else torch.empty(0, device=out.device))
+        ctx.has_Rh = Rh is not None
+        ctx.has_delta = delta is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        joint_mats, skin_idx, skin_w, Rh = ctx.saved_tensors
+        V, K = skin_w.shape
+        gd = torch.empty((V, 3), dtype=torch.float32, device=g.device)
+        check(_lib.lib().d3ga_lbs_cage_bwd(V, K, dptr(joint_mats), dptr(skin_idx), dptr(skin_w),
+                                           dptr(Rh if ctx.has_Rh else None), dptr(_f32c(g)), dptr(gd),
+                                           stream_handle()), "d3ga_lbs_cage_bwd")
+        g_t = gd if ctx.needs_input_grad[0] else None
+        g_d = gd if (ctx.has_delta and ctx.needs_input_grad[1]) else None
+        return g_t, g_d, None, None, None, None, None
+
+
+def lbs_cage(template, delta, joint_mats, skin_idx, skin_w, Rh=None, Th=None):
+    """K-sparse linear blend skinning of cage vertices: (sum_k w_k A[idx_k]) [v+delta;1], then .Rh^T + Th
+    (lib/smplman.py:155-171).  Differentiable in template and delta (the deformation_field output when
+    train.tet_offset_pre_lbs is on, models/cage_net.py:207-208); joint transforms are treated as constants."""
+    return _LbsCage.apply(template, delta, joint_mats, _i32c(skin_idx), skin_w, Rh, Th)
+
+
+class _FemEnergy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tetpoints, tetras, Dn_inv):
+        require_cuda(tetpoints, tetras, Dn_inv)
+        tetpoints, Dn_inv = _f32c(tetpoints), _f32c(Dn_inv)
+        T = tetras.shape[0]
+        e = torch.empty((T,), dtype=torch.float32, device=tetpoints.device)
+        check(_lib.lib().d3ga_fem_energy_fwd(T, dptr(tetpoints), dptr(tetras), dptr(Dn_inv), dptr(e), stream_handle()),
+              "d3ga_fem_energy_fwd")
+        ctx.save_for_backward(tetpoints, tetras, Dn_inv)
+        return e
+
+    @staticmethod
+    def backward(ctx, g):
+        tetpoints, tetras, Dn_inv = ctx.saved_tensors
+        T, V = tetras.shape[0], tetpoints.shape[0]
+        gt = torch.empty((V, 3), dtype=torch.float32, device=g.device)
+        check(_lib.lib().d3ga_fem_energy_bwd(T, V, dptr(tetpoints), dptr(tetras), dptr(Dn_inv), dptr(_f32c(g)),
+                                             dptr(gt), stream_handle()), "d3ga_fem_energy_bwd")
+        return gt, None, None
+
+
+def fem_energy(tetpoints, tetras, Dn_inv):
+    """Per-tet 0.5 (det F - 1)^2 + 0.5 (tr F^T F - 3), F = Ds Dn^-1 (lib/cage.py:349-361).  Returns (T,)."""
+    return _FemEnergy.apply(tetpoints, _i32c(tetras), Dn_inv)
+
+
+def canonical_gradient(canon_points, tetras, tetra_id):
+    """inv(Dm) per Gaussian (lib/cage.py:329); init-time, plain torch on whatever device the inputs live."""
+    c = canon_points[tetras.long()][tetra_id.long()]
+    Dm = torch.stack([c[:, 3] - c[:, 0], c[:, 2] - c[:, 0], c[:, 1] - c[:, 0]], dim=2)
+    return torch.linalg.inv(Dm)

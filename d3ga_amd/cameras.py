@@ -1,0 +1,84 @@
+"""Host-side camera set-up of the render boundary (mirrors lib/cameras.py:14-75 and
+utils/graphics_utils.py:41-75 of the reference).
+
+The reference rebuilds a `Camera` (two numpy 4x4 inversions, three small H2D copies) on every `render()` call,
+twice per training step.  Here the matrices of a (R, T, FoV) triple are computed once on the host in float64,
+rounded to float32 exactly where the reference rounds, uploaded once, and cached per device.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+ZNEAR, ZFAR = 0.01, 100.0          # lib/cameras.py:62-63
+
+
+def _view_matrix(R, T):
+    """float32 world->view matrix (graphics_utils.getWorld2View2 with translate=0, scale=1)."""
+    Rt = np.zeros((4, 4), dtype=np.float64)
+    Rt[:3, :3] = np.asarray(R, dtype=np.float64).T
+    Rt[:3, 3] = np.asarray(T, dtype=np.float64).reshape(3)
+    Rt[3, 3] = 1.0
+    c2w = np.linalg.inv(Rt)           # the reference inverts twice (camera-centre shift of zero in between)
+    return np.linalg.inv(c2w).astype(np.float32)
+
+
+def _projection_matrix(fovx, fovy, znear=ZNEAR, zfar=ZFAR):
+    """float32 perspective matrix with z in [0,1] and w = z_view (graphics_utils.getProjectionMatrix)."""
+    top = math.tan(fovy / 2) * znear
+    right = math.tan(fovx / 2) * znear
+    P = np.zeros((4, 4), dtype=np.float32)
+    P[0, 0] = 2.0 * znear / (2.0 * right)
+    P[1, 1] = 2.0 * znear / (2.0 * top)
+    P[3, 2] = 1.0
+    P[2, 2] = zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+class Camera:
+    """Same attribute names as the reference's Camera (world_view_transform, projection_matrix,
+    full_proj_transform, camera_center are float32 tensors in the transposed, row-vector layout)."""
+
+    def __init__(self, colmap_id, R, T, FoVx, FoVy, image_name=None, uid=None, width=None, height=None,
+                 data_device="cuda"):
+        self.uid, self.colmap_id, self.image_name = uid, colmap_id, image_name
+        self.R, self.T, self.FoVx, self.FoVy = R, T, float(FoVx), float(FoVy)
+        self.image_width, self.image_height = width, height
+        self.znear, self.zfar = ZNEAR, ZFAR
+        wv = _view_matrix(R, T).T.copy()
+        pr = _projection_matrix(self.FoVx, self.FoVy).T.copy()
+        full = wv @ pr
+        center = np.linalg.inv(wv)[3, :3].astype(np.float32)
+        packed = np.concatenate([wv.ravel(), pr.ravel(), full.ravel(), center]).astype(np.float32)
+        dev = torch.device(data_device)
+        buf = torch.from_numpy(packed).to(dev)                 # one H2D copy
+        self.world_view_transform = buf[0:16].view(4, 4)
+        self.projection_matrix = buf[16:32].view(4, 4)
+        self.full_proj_transform = buf[32:48].view(4, 4)
+        self.camera_center = buf[48:51]
+        self.tanfovx = math.tan(self.FoVx * 0.5)
+        self.tanfovy = math.tan(self.FoVy * 0.5)
+
+
+_cache = OrderedDict()
+_CACHE_MAX = 512
+
+
+def batch_to_camera(batch, device="cuda"):
+    """lib/cameras.py:14-26, cached on the camera's defining numbers."""
+    R = np.ascontiguousarray(np.asarray(batch["R"], dtype=np.float64))
+    T = np.ascontiguousarray(np.asarray(batch["T"], dtype=np.float64))
+    key = (R.tobytes(), T.tobytes(), float(batch["FoVx"]), float(batch["FoVy"]), str(device))
+    cam = _cache.get(key)
+    if cam is None:
+        cam = Camera(colmap_id=batch.get("camera_id"), R=R, T=T, FoVx=batch["FoVx"], FoVy=batch["FoVy"],
+                     image_name=f'{batch.get("frame_id")}_{batch.get("camera_id")}', uid=batch.get("frame_id"),
+                     width=batch.get("width"), height=batch.get("height"), data_device=device)
+        _cache[key] = cam
+        if len(_cache) > _CACHE_MAX:
+            _cache.popitem(last=False)
+    else:
+        _cache.move_to_end(key)
+    return cam

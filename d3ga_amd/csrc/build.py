@@ -1,0 +1,51 @@
+"""Build libd3ga_hip.so (gfx950) in-tree with hipcc.  Cross-compiles without a GPU."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["deform.hip", "raster_pre.hip", "raster_bin.hip", "raster_composite.hip", "raster_api.hip", "bary.hip"]
+HEADERS = ["d3ga_math.h", "d3ga_internal.h", "raster_pre_body.h", os.path.join("..", "..", "include", "d3ga.h")]
+OUT = os.path.join(HERE, "..", "libd3ga_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(HERE, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or _newer(o, [s] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _newer(OUT, objs):
+        # Link against the HIP runtime that PyTorch-ROCm itself loads (torch/lib/libamdhip64.so, SONAME without a
+        # version) so that the process holds ONE runtime: torch's streams, events and allocations are then valid
+        # in our launches.  /opt/rocm/lib stays on the runpath for hosts that load the library without torch.
+        import torch
+        tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+        cmd = ["g++", "-shared", "-fPIC"] + objs + ["-L" + tlib, "-lamdhip64", "-Wl,-rpath," + tlib,
+                                                    "-Wl,-rpath,/opt/rocm/lib", "-o", OUT]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return os.path.abspath(OUT)
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,104 @@
+// d3ga_internal.h -- scratch-buffer layout and launch helpers shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/d3ga.h"
+#include "d3ga_math.h"
+
+namespace d3ga {
+
+constexpr int kBlock = 256;
+
+static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
+
+// Per-Gaussian state written by the preprocess kernel (structure of arrays, 256-byte aligned sections).
+struct GeomBuf {
+    float *depth;       // P      view-space z
+    float2 *xy;         // P      pixel-space centre
+    float4 *conic_o;    // P      conic (a,b,c) + opacity
+    float4 *rgb_invd;   // P      colour + 1/depth
+    uint2 *rect;        // P      tile rectangle packed: x = minx | miny<<16, y = maxx | maxy<<16
+    uint8_t *clamped;   // P      bit c set: SH colour channel c was clamped at 0
+    float *cov3D;       // P*6    3D covariance actually used (precomputed copy or from scale/rotation)
+};
+static inline int64_t geom_bytes(int64_t P) {
+    return align256(4 * P) + align256(8 * P) + align256(16 * P) + align256(16 * P) + align256(8 * P) + align256(P) +
+           align256(24 * P);
+}
+static inline GeomBuf carve_geom(void *base, int64_t P) {
+    char *p = (char *)base;
+    GeomBuf g;
+    g.depth = (float *)p;     p += align256(4 * P);
+    g.xy = (float2 *)p;       p += align256(8 * P);
+    g.conic_o = (float4 *)p;  p += align256(16 * P);
+    g.rgb_invd = (float4 *)p; p += align256(16 * P);
+    g.rect = (uint2 *)p;      p += align256(8 * P);
+    g.clamped = (uint8_t *)p; p += align256(P);
+    g.cov3D = (float *)p;
+    return g;
+}
+
+// Binning state.
+struct BinBuf {
+    uint32_t *counters;     // 8  (D3GA_CNT_*)
+    uint32_t *tile_count;   // tiles
+    uint32_t *tile_start;   // tiles + 1   exclusive prefix of tile_count
+    uint32_t *tile_cursor;  // tiles
+    uint64_t *keys;         // d_capacity  (depth bits << 32 | gaussian index), grouped by tile
+    uint32_t *point_list;   // d_capacity  gaussian indices, per tile ascending (depth, index)
+};
+static inline int64_t bin_bytes(int64_t tiles, int64_t dcap) {
+    return 256 + align256(4 * tiles) + align256(4 * (tiles + 1)) + align256(4 * tiles) + align256(8 * dcap) +
+           align256(4 * dcap);
+}
+static inline BinBuf carve_bin(void *base, int64_t tiles, int64_t dcap) {
+    char *p = (char *)base;
+    BinBuf b;
+    b.counters = (uint32_t *)p;    p += 256;
+    b.tile_count = (uint32_t *)p;  p += align256(4 * tiles);
+    b.tile_start = (uint32_t *)p;  p += align256(4 * (tiles + 1));
+    b.tile_cursor = (uint32_t *)p; p += align256(4 * tiles);
+    b.keys = (uint64_t *)p;        p += align256(8 * dcap);
+    b.point_list = (uint32_t *)p;
+    return b;
+}
+
+struct ImgBuf {
+    float *final_T;        // H*W
+    uint32_t *n_contrib;   // H*W   1-based tile-list position of the last contributing Gaussian
+};
+static inline int64_t img_bytes(int64_t W, int64_t H) { return 2 * align256(4 * W * H); }
+static inline ImgBuf carve_img(void *base, int64_t W, int64_t H) {
+    ImgBuf i;
+    i.final_T = (float *)base;
+    i.n_contrib = (uint32_t *)((char *)base + align256(4 * W * H));
+    return i;
+}
+
+static inline int tiles_x(int W) { return (W + kTile - 1) / kTile; }
+static inline int tiles_y(int H) { return (H + kTile - 1) / kTile; }
+
+// launch check: returns hipError (>0) or 0; in debug mode also synchronises
+static inline int check_launch(hipStream_t s, int debug) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (debug) {
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+#define D3GA_TRY(expr)            \
+    do {                          \
+        int _st = (expr);         \
+        if (_st != 0) return _st; \
+    } while (0)
+#define D3GA_HIP(expr)                          \
+    do {                                        \
+        hipError_t _e = (expr);                 \
+        if (_e != hipSuccess) return (int)_e;   \
+    } while (0)
+
+}  // namespace d3ga

@@ -1,0 +1,251 @@
+// deform.hip -- cage-side kernels for gfx950: LBS of cage vertices (D0), fused tetrahedral-cage deformation of
+// Gaussians forward/backward (D1-D5, A1) and the FEM regulariser (D6).   SURVEY.md sec. 8a.
+//
+// All three are HBM-streaming, one thread per element, no LDS, no MFMA (no dense contraction on this path).
+// Cage vertices (V*12 B, a few hundred KB) and tets (T*16 B) are gathered through L2; the per-Gaussian streams
+// (tet id, barycentrics, canonical gradient, scale, rotation -> mean, covariance) are read/written once with
+// lane-contiguous addresses.  Gaussians are expected sorted by tet id (static during training), so the four
+// corner gathers of neighbouring lanes hit the same cache lines and the backward's vertex-gradient atomics
+// of a wavefront collapse onto few addresses.
+#include "d3ga_internal.h"
+
+namespace d3ga {
+
+__device__ __forceinline__ V3 load3(const float *p, int i) { return v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+
+// ---------------------------------------------------------------------------------------------------------
+// D0: v' = Rh (sum_k w_k A[idx_k]) [v + delta; 1] + Th
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void lbs_fwd_kernel(int V, int K, const float *__restrict__ tmpl,
+                                                         const float *__restrict__ delta,
+                                                         const float *__restrict__ A,
+                                                         const int32_t *__restrict__ idx, const float *__restrict__ w,
+                                                         const float *__restrict__ Rh, const float *__restrict__ Th,
+                                                         float *__restrict__ out) {
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= V) return;
+    V3 p = load3(tmpl, v);
+    if (delta) p = p + load3(delta, v);
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float wk = w[(size_t)v * K + k];
+        const float *a = A + 16 * (size_t)idx[(size_t)v * K + k];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] += wk * a[i];
+    }
+    V3 o = v3(T[0] * p.x + T[1] * p.y + T[2] * p.z + T[3], T[4] * p.x + T[5] * p.y + T[6] * p.z + T[7],
+              T[8] * p.x + T[9] * p.y + T[10] * p.z + T[11]);
+    if (Rh) o = v3(Rh[0] * o.x + Rh[1] * o.y + Rh[2] * o.z, Rh[3] * o.x + Rh[4] * o.y + Rh[5] * o.z,
+                   Rh[6] * o.x + Rh[7] * o.y + Rh[8] * o.z);
+    if (Th) o = o + v3(Th[0], Th[1], Th[2]);
+    out[3 * v] = o.x; out[3 * v + 1] = o.y; out[3 * v + 2] = o.z;
+}
+
+__global__ __launch_bounds__(kBlock) void lbs_bwd_kernel(int V, int K, const float *__restrict__ A,
+                                                         const int32_t *__restrict__ idx, const float *__restrict__ w,
+                                                         const float *__restrict__ Rh, const float *__restrict__ g,
+                                                         float *__restrict__ gdelta) {
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= V) return;
+    V3 go = load3(g, v);
+    if (Rh) go = v3(Rh[0] * go.x + Rh[3] * go.y + Rh[6] * go.z, Rh[1] * go.x + Rh[4] * go.y + Rh[7] * go.z,
+                    Rh[2] * go.x + Rh[5] * go.y + Rh[8] * go.z);
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float wk = w[(size_t)v * K + k];
+        const float *a = A + 16 * (size_t)idx[(size_t)v * K + k];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] += wk * a[i];
+    }
+    gdelta[3 * v] = T[0] * go.x + T[4] * go.y + T[8] * go.z;
+    gdelta[3 * v + 1] = T[1] * go.x + T[5] * go.y + T[9] * go.z;
+    gdelta[3 * v + 2] = T[2] * go.x + T[6] * go.y + T[10] * go.z;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// D1-D5
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_deform_in(int i, const float *__restrict__ tetpoints,
+                                               const int32_t *__restrict__ tetras, const int32_t *__restrict__ tetra_id,
+                                               const float *__restrict__ barys, const float *__restrict__ canon_grad,
+                                               const float *__restrict__ scales, const float *__restrict__ rots,
+                                               DeformIn &in, int4 &vid) {
+    const int t = tetra_id[i];
+    vid = reinterpret_cast<const int4 *>(tetras)[t];
+    in.x0 = load3(tetpoints, vid.x); in.x1 = load3(tetpoints, vid.y);
+    in.x2 = load3(tetpoints, vid.z); in.x3 = load3(tetpoints, vid.w);
+    const float4 b = reinterpret_cast<const float4 *>(barys)[i];
+    in.bary[0] = b.x; in.bary[1] = b.y; in.bary[2] = b.z; in.bary[3] = b.w;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) in.G.m[k] = canon_grad[9 * (size_t)i + k];
+    in.s[0] = scales[3 * (size_t)i]; in.s[1] = scales[3 * (size_t)i + 1]; in.s[2] = scales[3 * (size_t)i + 2];
+    const float4 q = reinterpret_cast<const float4 *>(rots)[i];
+    in.q[0] = q.x; in.q[1] = q.y; in.q[2] = q.z; in.q[3] = q.w;
+}
+
+__global__ __launch_bounds__(kBlock) void cage_deform_fwd_kernel(int P, const float *__restrict__ tetpoints,
+                                                                 const int32_t *__restrict__ tetras,
+                                                                 const int32_t *__restrict__ tetra_id,
+                                                                 const float *__restrict__ barys,
+                                                                 const float *__restrict__ canon_grad,
+                                                                 const float *__restrict__ scales,
+                                                                 const float *__restrict__ rots,
+                                                                 float *__restrict__ means, float *__restrict__ cov6) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    DeformIn in;
+    int4 vid;
+    load_deform_in(i, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rots, in, vid);
+    float m[3], c[6];
+    deform_fwd(in, m, c);
+    means[3 * (size_t)i] = m[0]; means[3 * (size_t)i + 1] = m[1]; means[3 * (size_t)i + 2] = m[2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov6[6 * (size_t)i + k] = c[k];
+}
+
+__device__ __forceinline__ void atomic_add3(float *base, int v, V3 g) {
+    atomicAdd(base + 3 * (size_t)v, g.x);
+    atomicAdd(base + 3 * (size_t)v + 1, g.y);
+    atomicAdd(base + 3 * (size_t)v + 2, g.z);
+}
+
+__global__ __launch_bounds__(kBlock) void cage_deform_bwd_kernel(
+    int P, const float *__restrict__ tetpoints, const int32_t *__restrict__ tetras, const int32_t *__restrict__ tetra_id,
+    const float *__restrict__ barys, const float *__restrict__ canon_grad, const float *__restrict__ scales,
+    const float *__restrict__ rots, const float *__restrict__ g_means, const float *__restrict__ g_cov6,
+    float *__restrict__ g_tetpoints, float *__restrict__ g_barys, float *__restrict__ g_scales,
+    float *__restrict__ g_rots) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    DeformIn in;
+    int4 vid;
+    load_deform_in(i, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rots, in, vid);
+    float gm[3] = {g_means[3 * (size_t)i], g_means[3 * (size_t)i + 1], g_means[3 * (size_t)i + 2]};
+    float gc[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gc[k] = g_cov6[6 * (size_t)i + k];
+    DeformGrad o;
+    deform_bwd(in, gm, gc, o);
+    if (g_barys) reinterpret_cast<float4 *>(g_barys)[i] = make_float4(o.gbary[0], o.gbary[1], o.gbary[2], o.gbary[3]);
+    if (g_scales) {
+        g_scales[3 * (size_t)i] = o.gs[0]; g_scales[3 * (size_t)i + 1] = o.gs[1]; g_scales[3 * (size_t)i + 2] = o.gs[2];
+    }
+    if (g_rots) reinterpret_cast<float4 *>(g_rots)[i] = make_float4(o.gq[0], o.gq[1], o.gq[2], o.gq[3]);
+    if (g_tetpoints) {
+        atomic_add3(g_tetpoints, vid.x, o.gx0); atomic_add3(g_tetpoints, vid.y, o.gx1);
+        atomic_add3(g_tetpoints, vid.z, o.gx2); atomic_add3(g_tetpoints, vid.w, o.gx3);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// D6
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void fem_fwd_kernel(int T, const float *__restrict__ tetpoints,
+                                                         const int32_t *__restrict__ tetras,
+                                                         const float *__restrict__ Dn_inv, float *__restrict__ energy) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= T) return;
+    const int4 vid = reinterpret_cast<const int4 *>(tetras)[t];
+    M3 D;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) D.m[k] = Dn_inv[9 * (size_t)t + k];
+    energy[t] = fem_energy_fwd(load3(tetpoints, vid.x), load3(tetpoints, vid.y), load3(tetpoints, vid.z),
+                               load3(tetpoints, vid.w), D);
+}
+__global__ __launch_bounds__(kBlock) void fem_bwd_kernel(int T, const float *__restrict__ tetpoints,
+                                                         const int32_t *__restrict__ tetras,
+                                                         const float *__restrict__ Dn_inv, const float *__restrict__ g,
+                                                         float *__restrict__ g_tetpoints) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= T) return;
+    const int4 vid = reinterpret_cast<const int4 *>(tetras)[t];
+    M3 D;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) D.m[k] = Dn_inv[9 * (size_t)t + k];
+    V3 gx[4];
+    fem_energy_bwd(load3(tetpoints, vid.x), load3(tetpoints, vid.y), load3(tetpoints, vid.z), load3(tetpoints, vid.w),
+                   D, g[t], gx);
+    atomic_add3(g_tetpoints, vid.x, gx[0]); atomic_add3(g_tetpoints, vid.y, gx[1]);
+    atomic_add3(g_tetpoints, vid.z, gx[2]); atomic_add3(g_tetpoints, vid.w, gx[3]);
+}
+
+}  // namespace d3ga
+
+using namespace d3ga;
+
+static inline int nblocks(int n) { return (n + kBlock - 1) / kBlock; }
+
+extern "C" int d3ga_lbs_cage_fwd(int V, int K, const float *tmpl, const float *delta, const float *joint_mats,
+                                 const int32_t *skin_idx, const float *skin_w, const float *Rh, const float *Th,
+                                 float *out, d3ga_stream_t stream) {
+    if (V < 0 || K <= 0) return D3GA_E_SIZE;
+    if (V == 0) return D3GA_OK;
+    if (!tmpl || !joint_mats || !skin_idx || !skin_w || !out) return D3GA_E_NULL;
+    hipLaunchKernelGGL(lbs_fwd_kernel, dim3(nblocks(V)), dim3(kBlock), 0, (hipStream_t)stream, V, K, tmpl, delta,
+                       joint_mats, skin_idx, skin_w, Rh, Th, out);
+    return check_launch((hipStream_t)stream, 0);
+}
+
+extern "C" int d3ga_lbs_cage_bwd(int V, int K, const float *joint_mats, const int32_t *skin_idx, const float *skin_w,
+                                 const float *Rh, const float *grad_out, float *grad_delta, d3ga_stream_t stream) {
+    if (V < 0 || K <= 0) return D3GA_E_SIZE;
+    if (V == 0) return D3GA_OK;
+    if (!joint_mats || !skin_idx || !skin_w || !grad_out || !grad_delta) return D3GA_E_NULL;
+    hipLaunchKernelGGL(lbs_bwd_kernel, dim3(nblocks(V)), dim3(kBlock), 0, (hipStream_t)stream, V, K, joint_mats,
+                       skin_idx, skin_w, Rh, grad_out, grad_delta);
+    return check_launch((hipStream_t)stream, 0);
+}
+
+extern "C" int d3ga_cage_deform_fwd(int P, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
+                                    const float *barys, const float *canon_grad, const float *scales,
+                                    const float *rots, float *means3D, float *cov6, d3ga_stream_t stream) {
+    if (P < 0) return D3GA_E_SIZE;
+    if (P == 0) return D3GA_OK;
+    if (!tetpoints || !tetras || !tetra_id || !barys || !canon_grad || !scales || !rots || !means3D || !cov6)
+        return D3GA_E_NULL;
+    hipLaunchKernelGGL(cage_deform_fwd_kernel, dim3(nblocks(P)), dim3(kBlock), 0, (hipStream_t)stream, P, tetpoints,
+                       tetras, tetra_id, barys, canon_grad, scales, rots, means3D, cov6);
+    return check_launch((hipStream_t)stream, 0);
+}
+
+extern "C" int d3ga_cage_deform_bwd(int P, int V, const float *tetpoints, const int32_t *tetras,
+                                    const int32_t *tetra_id, const float *barys, const float *canon_grad,
+                                    const float *scales, const float *rots, const float *g_means, const float *g_cov6,
+                                    float *g_tetpoints, float *g_barys, float *g_scales, float *g_rots,
+                                    d3ga_stream_t stream) {
+    if (P < 0 || V < 0) return D3GA_E_SIZE;
+    if (g_tetpoints && V > 0) D3GA_HIP(hipMemsetAsync(g_tetpoints, 0, sizeof(float) * 3 * (size_t)V, (hipStream_t)stream));
+    if (P == 0) return D3GA_OK;
+    if (!tetpoints || !tetras || !tetra_id || !barys || !canon_grad || !scales || !rots || !g_means || !g_cov6)
+        return D3GA_E_NULL;
+    hipLaunchKernelGGL(cage_deform_bwd_kernel, dim3(nblocks(P)), dim3(kBlock), 0, (hipStream_t)stream, P, tetpoints,
+                       tetras, tetra_id, barys, canon_grad, scales, rots, g_means, g_cov6, g_tetpoints, g_barys,
+                       g_scales, g_rots);
+    return check_launch((hipStream_t)stream, 0);
+}
+
+extern "C" int d3ga_fem_energy_fwd(int T, const float *tetpoints, const int32_t *tetras, const float *Dn_inv,
+                                   float *energy, d3ga_stream_t stream) {
+    if (T < 0) return D3GA_E_SIZE;
+    if (T == 0) return D3GA_OK;
+    if (!tetpoints || !tetras || !Dn_inv || !energy) return D3GA_E_NULL;
+    hipLaunchKernelGGL(fem_fwd_kernel, dim3(nblocks(T)), dim3(kBlock), 0, (hipStream_t)stream, T, tetpoints, tetras,
+                       Dn_inv, energy);
+    return check_launch((hipStream_t)stream, 0);
+}
+
+extern "C" int d3ga_fem_energy_bwd(int T, int V, const float *tetpoints, const int32_t *tetras, const float *Dn_inv,
+                                   const float *g_energy, float *g_tetpoints, d3ga_stream_t stream) {
+    if (T < 0 || V < 0) return D3GA_E_SIZE;
+    if (!g_tetpoints) return D3GA_E_NULL;
+    if (V > 0) D3GA_HIP(hipMemsetAsync(g_tetpoints, 0, sizeof(float) * 3 * (size_t)V, (hipStream_t)stream));
+    if (T == 0) return D3GA_OK;
+    if (!tetpoints || !tetras || !Dn_inv || !g_energy) return D3GA_E_NULL;
+    hipLaunchKernelGGL(fem_bwd_kernel, dim3(nblocks(T)), dim3(kBlock), 0, (hipStream_t)stream, T, tetpoints, tetras,
+                       Dn_inv, g_energy, g_tetpoints);
+    return check_launch((hipStream_t)stream, 0);
+}

@@ -1,0 +1,170 @@
+// raster_bin.hip -- binning and depth ordering for gfx950.
+//
+// Instead of one global 64-bit radix sort over all (tile, depth) duplicates (6 passes x 2 x 12 B per duplicate
+// of HBM traffic), the duplicates are first binned by tile with a counting sort (histogram in the preprocess
+// kernel -> exclusive scan -> atomic-cursor scatter: 8 B written per duplicate), and each tile's list is then
+// sorted by (depth, Gaussian index) entirely inside the LDS of one workgroup with a bitonic network
+// (8 B read + 4 B written per duplicate).  The 64-bit key (depth bits << 32 | index) makes the order total, so
+// the result does not depend on the order in which the atomics of the scatter pass landed.
+//
+//   tile_scan_kernel      one workgroup: exclusive prefix of the tile histogram, D, overflow flag
+//   tile_scatter_kernel   one thread per Gaussian: emit its key into every tile of its rectangle
+//   tile_sort_lds_kernel  one workgroup per tile: LDS bitonic sort (lists up to CAP entries)
+//   tile_sort_global_kernel  fallback for longer lists: same network on global memory
+#include "d3ga_internal.h"
+
+namespace d3ga {
+
+constexpr int kScanBlock = 1024;
+
+__global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(int tiles, const uint32_t *__restrict__ count,
+                                                               uint32_t *__restrict__ start,
+                                                               uint32_t *__restrict__ cursor,
+                                                               uint32_t *__restrict__ counters, uint64_t dcap) {
+    __shared__ uint32_t s_sum[kScanBlock];
+    __shared__ uint32_t s_max;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_max = 0;
+    const int per = (tiles + kScanBlock - 1) / kScanBlock;
+    const int b = min(tid * per, tiles), e = min(b + per, tiles);
+    uint32_t sum = 0, mx = 0;
+    for (int t = b; t < e; ++t) {
+        const uint32_t c = count[t];
+        sum += c;
+        mx = max(mx, c);
+    }
+    s_sum[tid] = sum;
+    __syncthreads();
+    atomicMax(&s_max, mx);
+    for (int off = 1; off < kScanBlock; off <<= 1) {
+        const uint32_t v = tid >= off ? s_sum[tid - off] : 0u;
+        __syncthreads();
+        s_sum[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[tid] - sum;
+    for (int t = b; t < e; ++t) {
+        start[t] = run;
+        cursor[t] = run;
+        run += count[t];
+    }
+    if (tid == kScanBlock - 1) {
+        const uint32_t total = s_sum[kScanBlock - 1];
+        start[tiles] = total;
+        counters[D3GA_CNT_D] = total;
+        counters[D3GA_CNT_OVERFLOW] = (uint64_t)total > dcap ? 1u : 0u;
+        counters[D3GA_CNT_MAXTILE] = s_max;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void tile_scatter_kernel(int P, int gx, const uint2 *__restrict__ rect,
+                                                              const float *__restrict__ depth,
+                                                              uint32_t *__restrict__ cursor, uint64_t *__restrict__ keys,
+                                                              uint64_t dcap) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    const uint2 rc = rect[i];
+    const int x0 = rc.x & 0xffffu, y0 = rc.x >> 16, x1 = rc.y & 0xffffu, y1 = rc.y >> 16;
+    if (x1 <= x0 || y1 <= y0) return;
+    const uint64_t key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
+    for (int ty = y0; ty < y1; ++ty)
+        for (int tx = x0; tx < x1; ++tx) {
+            const uint32_t pos = atomicAdd(&cursor[ty * gx + tx], 1u);
+            if (pos < dcap) keys[pos] = key;
+        }
+}
+
+// Bitonic network in its "flip / disperse" form: every compare-exchange moves the smaller key to the lower
+// address, so slots >= n behave as +infinity without being stored and n need not be a power of two.
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr k, int n, int tid, int nthreads) {
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    const int half = n2 >> 1;
+    for (int size = 2; size <= n2; size <<= 1) {
+        const int hs = size >> 1;
+        for (int i = tid; i < half; i += nthreads) {          // flip
+            const int blk = i / hs, off = i - blk * hs;
+            const int lo = blk * size + off, hi = blk * size + size - 1 - off;
+            if (hi < n) {
+                const uint64_t a = k[lo], b = k[hi];
+                if (b < a) { k[lo] = b; k[hi] = a; }
+            }
+        }
+        __syncthreads();
+        for (int j = hs >> 1; j >= 1; j >>= 1) {              // disperse
+            for (int i = tid; i < half; i += nthreads) {
+                const int blk = i / j, off = i - blk * j;
+                const int lo = blk * 2 * j + off, hi = lo + j;
+                if (hi < n) {
+                    const uint64_t a = k[lo], b = k[hi];
+                    if (b < a) { k[lo] = b; k[hi] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int BLOCK, int CAP>
+__global__ __launch_bounds__(BLOCK) void tile_sort_lds_kernel(const uint32_t *__restrict__ start,
+                                                              const uint64_t *__restrict__ keys,
+                                                              uint32_t *__restrict__ point_list, uint64_t dcap,
+                                                              int n_min) {
+    __shared__ uint64_t s_key[CAP];
+    const int tile = blockIdx.x;
+    const uint64_t b64 = min((uint64_t)start[tile], dcap), e64 = min((uint64_t)start[tile + 1], dcap);
+    const int n = (int)(e64 - b64);
+    if (n <= n_min || n > CAP) return;                 // another launch owns this tile
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += BLOCK) s_key[i] = keys[b64 + i];
+    __syncthreads();
+    bitonic_sort(s_key, n, tid, BLOCK);
+    for (int i = tid; i < n; i += BLOCK) point_list[b64 + i] = (uint32_t)s_key[i];
+}
+
+__global__ __launch_bounds__(1024) void tile_sort_global_kernel(const uint32_t *__restrict__ start, uint64_t *keys,
+                                                                uint32_t *__restrict__ point_list, uint64_t dcap,
+                                                                int n_min) {
+    const int tile = blockIdx.x;
+    const uint64_t b64 = min((uint64_t)start[tile], dcap), e64 = min((uint64_t)start[tile + 1], dcap);
+    const int n = (int)(e64 - b64);
+    if (n <= n_min) return;
+    const int tid = threadIdx.x;
+    bitonic_sort(keys + b64, n, tid, 1024);
+    for (int i = tid; i < n; i += 1024) point_list[b64 + i] = (uint32_t)keys[b64 + i];
+}
+
+}  // namespace d3ga
+
+using namespace d3ga;
+
+constexpr int kSortSmall = 2048;   // 16 KiB LDS, 256 threads
+constexpr int kSortLarge = 8192;   // 64 KiB LDS, 1024 threads
+
+extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, void *binning, int64_t d_capacity,
+                                    d3ga_stream_t stream) {
+    if (!prm || !geom || !binning) return D3GA_E_NULL;
+    if (prm->P < 0 || prm->W <= 0 || prm->H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = tiles_x(prm->W);
+    const int tiles = gx * tiles_y(prm->H);
+    BinBuf bin = carve_bin(binning, tiles, d_capacity);
+    GeomBuf g = carve_geom(geom, prm->P);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(kScanBlock), 0, s, tiles, bin.tile_count, bin.tile_start,
+                       bin.tile_cursor, bin.counters, (uint64_t)d_capacity);
+    D3GA_TRY(check_launch(s, prm->debug));
+    if (prm->P == 0 || d_capacity == 0) return D3GA_OK;
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, prm->P, gx, g.rect,
+                       g.depth, bin.tile_cursor, bin.keys, (uint64_t)d_capacity);
+    D3GA_TRY(check_launch(s, prm->debug));
+    hipLaunchKernelGGL((tile_sort_lds_kernel<256, kSortSmall>), dim3(tiles), dim3(256), 0, s, bin.tile_start, bin.keys,
+                       bin.point_list, (uint64_t)d_capacity, 0);
+    D3GA_TRY(check_launch(s, prm->debug));
+    hipLaunchKernelGGL((tile_sort_lds_kernel<1024, kSortLarge>), dim3(tiles), dim3(1024), 0, s, bin.tile_start, bin.keys,
+                       bin.point_list, (uint64_t)d_capacity, kSortSmall);
+    D3GA_TRY(check_launch(s, prm->debug));
+    hipLaunchKernelGGL(tile_sort_global_kernel, dim3(tiles), dim3(1024), 0, s, bin.tile_start, bin.keys, bin.point_list,
+                       (uint64_t)d_capacity, kSortLarge);
+    return check_launch(s, prm->debug);
+}

@@ -1,0 +1,138 @@
+// raster_pre_body.h -- per-Gaussian bodies of the preprocess forward / backward kernels, written as
+// host+device functions over plain pointers so that tests/hostcheck can run exactly this code on the CPU.
+#pragma once
+#include "../../include/d3ga.h"
+#include "d3ga_math.h"
+
+namespace d3ga {
+
+D3GA_HD V3 ld3(const float *p, size_t i) { return v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+
+struct PreOut {
+    Splat sp;
+    float c6[6];
+    float rgb[3];
+    float opacity;
+    uint8_t clampmask;
+};
+
+// R1 for Gaussian i.  Exactly one of (shs|colors_precomp), ((scales,rotations)|cov3D_precomp) is non-null.
+D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float *means3D, const float *shs,
+                              const float *colors_precomp, const float *opacities, const float *scales,
+                              const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                              const float *projmatrix, const float *campos) {
+    PreOut o;
+    const V3 mean = ld3(means3D, i);
+    if (cov3D_precomp) {
+        for (int k = 0; k < 6; ++k) o.c6[k] = cov3D_precomp[6 * (size_t)i + k];
+    } else {
+        const float s[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+        const float q[4] = {rotations[4 * (size_t)i], rotations[4 * (size_t)i + 1], rotations[4 * (size_t)i + 2],
+                            rotations[4 * (size_t)i + 3]};
+        cov3d_from_scale_rot(s, prm.scale_modifier, q, o.c6);
+    }
+    o.sp = project_gaussian(mean, o.c6, viewmatrix, projmatrix, prm.W, prm.H, prm.tanfovx, prm.tanfovy);
+    o.rgb[0] = o.rgb[1] = o.rgb[2] = 0.f;
+    o.clampmask = 0;
+    o.opacity = 0.f;
+    if (!o.sp.visible) return o;
+    o.opacity = opacities[i];
+    if (colors_precomp) {
+        o.rgb[0] = colors_precomp[3 * (size_t)i]; o.rgb[1] = colors_precomp[3 * (size_t)i + 1];
+        o.rgb[2] = colors_precomp[3 * (size_t)i + 2];
+    } else {
+        const V3 d = mean - v3(campos[0], campos[1], campos[2]);
+        const float inv = 1.0f / sqrtf(dot(d, d));
+        float B[16];
+        sh_basis(prm.sh_degree, d.x * inv, d.y * inv, d.z * inv, B);
+        const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
+        const float *sh = shs + (size_t)3 * prm.M * i;
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {       // fixed trip count: keeps B[] in registers
+            if (k < nb) {
+                acc[0] += B[k] * sh[3 * k]; acc[1] += B[k] * sh[3 * k + 1]; acc[2] += B[k] * sh[3 * k + 2];
+            }
+        }
+        for (int c = 0; c < 3; ++c) {
+            const float v = acc[c] + 0.5f;
+            if (v < 0.f) o.clampmask |= (uint8_t)(1u << c);
+            o.rgb[c] = fmaxf(v, 0.f);
+        }
+    }
+    return o;
+}
+
+// R6 for Gaussian i.  a[12] = accumulated screen-space gradients (layout: d3ga.h, d3ga_raster_composite_bwd);
+// all-zero and visible=false for culled Gaussians.  Output pointers may be null where not applicable.
+D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visible, const float *means3D,
+                                const float *shs, const float *scales, const float *rotations,
+                                const float *viewmatrix, const float *projmatrix, const float *campos,
+                                const float *c6, uint8_t clampmask, const float *a, float *dL_dmeans3D,
+                                float *dL_dmeans2D, float *dL_dopacity, float *dL_dsh, float *dL_dcolors,
+                                float *dL_dcov3D, float *dL_dscales, float *dL_drots) {
+    float gmean[3] = {0.f, 0.f, 0.f};
+    float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const V3 mean = ld3(means3D, i);
+    const int nbM = prm.M;
+    if (visible) {
+        cov2d_bwd(mean, c6, viewmatrix, prm.W, prm.H, prm.tanfovx, prm.tanfovy, a[3], a[4], a[5], g6, gmean);
+        project_bwd(mean, projmatrix, a[0], a[1], gmean);
+    }
+    if (dL_dsh) {
+        float *out = dL_dsh + (size_t)3 * nbM * i;
+        if (visible) {
+            const float gr[3] = {(clampmask & 1) ? 0.f : a[7], (clampmask & 2) ? 0.f : a[8],
+                                 (clampmask & 4) ? 0.f : a[9]};
+            const V3 d0 = mean - v3(campos[0], campos[1], campos[2]);
+            const float inv = 1.0f / sqrtf(dot(d0, d0));
+            const float x = d0.x * inv, y = d0.y * inv, z = d0.z * inv;
+            float B[16], Bx[16], By[16], Bz[16];
+            sh_basis(prm.sh_degree, x, y, z, B);
+            sh_basis_grad(prm.sh_degree, x, y, z, Bx, By, Bz);
+            const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
+            const float *sh = shs + (size_t)3 * nbM * i;
+            V3 gd = v3(0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {   // fixed trip count: keeps the basis arrays in registers
+                if (k < nb) {
+                    const float s0 = sh[3 * k], s1 = sh[3 * k + 1], s2 = sh[3 * k + 2];
+                    out[3 * k] = B[k] * gr[0]; out[3 * k + 1] = B[k] * gr[1]; out[3 * k + 2] = B[k] * gr[2];
+                    const float w = s0 * gr[0] + s1 * gr[1] + s2 * gr[2];
+                    gd.x += Bx[k] * w; gd.y += By[k] * w; gd.z += Bz[k] * w;
+                } else if (k < nbM) {
+                    out[3 * k] = 0.f; out[3 * k + 1] = 0.f; out[3 * k + 2] = 0.f;
+                }
+            }
+            const V3 gm = normalize_bwd(d0, gd);
+            gmean[0] += gm.x; gmean[1] += gm.y; gmean[2] += gm.z;
+        } else {
+            for (int k = 0; k < 3 * nbM; ++k) out[k] = 0.f;
+        }
+    }
+    if (dL_dcolors) {
+        dL_dcolors[3 * (size_t)i] = a[7]; dL_dcolors[3 * (size_t)i + 1] = a[8]; dL_dcolors[3 * (size_t)i + 2] = a[9];
+    }
+    dL_dmeans3D[3 * (size_t)i] = gmean[0]; dL_dmeans3D[3 * (size_t)i + 1] = gmean[1];
+    dL_dmeans3D[3 * (size_t)i + 2] = gmean[2];
+    if (dL_dmeans2D) {
+        dL_dmeans2D[3 * (size_t)i] = a[0]; dL_dmeans2D[3 * (size_t)i + 1] = a[1]; dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
+    }
+    if (dL_dopacity) dL_dopacity[i] = a[6];
+    if (dL_dcov3D) {
+        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = g6[k];
+    }
+    if (dL_dscales && dL_drots) {
+        float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+        if (visible) {
+            const float s[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+            const float q[4] = {rotations[4 * (size_t)i], rotations[4 * (size_t)i + 1], rotations[4 * (size_t)i + 2],
+                                rotations[4 * (size_t)i + 3]};
+            cov3d_from_scale_rot_bwd(s, prm.scale_modifier, q, g6, gs, gq);
+        }
+        for (int k = 0; k < 3; ++k) dL_dscales[3 * (size_t)i + k] = gs[k];
+        for (int k = 0; k < 4; ++k) dL_drots[4 * (size_t)i + k] = gq[k];
+    }
+}
+
+}  // namespace d3ga

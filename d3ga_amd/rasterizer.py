@@ -1,0 +1,186 @@
+"""Differentiable tile rasterizer with the operator surface of `diff_gaussian_rasterization` (branch dr_aa).
+
+Mirrors what renderer.py:13-16,79-93,130-141 of the reference imports and calls:
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix,
+                                  projmatrix, sh_degree, campos, prefiltered, debug, antialiasing)
+    GaussianRasterizer(raster_settings)(means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                                        rotations=None, cov3D_precomp=None) -> (color (3,H,W), radii (P,), invdepth (1,H,W))
+backed by the gfx950 kernels of libd3ga_hip.so (include/d3ga.h).  GPU tensors only, no CPU fallback.
+
+Scratch ("geomBuffer / binningBuffer / imgBuffer") is allocated from torch's caching allocator per call and kept
+alive in the autograd context.  The duplicate capacity of the binning lists is a per-device high-water mark; after
+the forward has been enqueued the 16-byte counter block is read back (the only host sync, the analogue of upstream
+reading `num_rendered`) and the call is repeated with a larger buffer in the rare case of overflow.  With
+``set_capacity_policy("static", n)`` nothing is read back (graph-capturable; caller checks `last_counters()`).
+"""
+import ctypes
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import RasterParams, check, dptr, require_cuda, stream_handle
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    antialiasing: bool = False
+
+
+# ------------------------------------------------------------------------------------------------------------
+# capacity policy for the binning lists
+# ------------------------------------------------------------------------------------------------------------
+_policy = {"mode": "auto", "static": 0}
+_hwm = {}            # device index -> high-water mark of D
+_last = {}           # device index -> binning tensor of the most recent forward (for last_counters)
+
+
+def set_capacity_policy(mode, capacity=0):
+    """"auto": read the duplicate count back after every forward and retry on overflow (default).
+    "static": use `capacity` duplicates, never synchronise; check `last_counters()["overflow"]` yourself."""
+    if mode not in ("auto", "static"):
+        raise ValueError(mode)
+    _policy["mode"] = mode
+    _policy["static"] = int(capacity)
+
+
+def last_counters(device=None):
+    """dict(D, overflow, max_tile, visible) of the most recent forward on `device` (synchronises)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    c = _last[dev][:32].view(torch.int32)[:4].cpu().tolist()
+    return {"D": c[0] & 0xFFFFFFFF, "overflow": bool(c[1]), "max_tile": c[2] & 0xFFFFFFFF, "visible": c[3]}
+
+
+def _scratch(P, W, H, cap, device):
+    sizes = (ctypes.c_int64 * 3)()
+    check(_lib.lib().d3ga_raster_scratch_bytes(P, W, H, cap, sizes), "d3ga_raster_scratch_bytes")
+    return [torch.empty(int(s), dtype=torch.uint8, device=device) for s in sizes]
+
+
+def _f32(t, device):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or t.device != device:
+        t = t.to(device=device, dtype=torch.float32)
+    return t.contiguous()
+
+
+def _empty_to_none(t):
+    return None if (t is None or t.numel() == 0) else t
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        s = raster_settings
+        require_cuda(means3D)
+        dev = means3D.device
+        sh, colors_precomp, scales, rotations, cov3Ds_precomp = map(
+            _empty_to_none, (sh, colors_precomp, scales, rotations, cov3Ds_precomp))
+        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp = (
+            _f32(t, dev) for t in (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
+        view, proj, campos, bg = (_f32(t, dev) for t in (s.viewmatrix, s.projmatrix, s.campos, s.bg))
+        P = means3D.shape[0]
+        H, W = int(s.image_height), int(s.image_width)
+        M = sh.shape[1] if sh is not None else 0
+        prm = RasterParams(P=P, M=M, sh_degree=int(s.sh_degree), W=W, H=H, tanfovx=float(s.tanfovx),
+                           tanfovy=float(s.tanfovy), scale_modifier=float(s.scale_modifier),
+                           antialiasing=int(bool(s.antialiasing)), prefiltered=int(bool(s.prefiltered)),
+                           debug=int(bool(s.debug)))
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        invdepth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        L = _lib.lib()
+        static = _policy["mode"] == "static"
+        cap = _policy["static"] if static else max(_hwm.get(dev.index, 0), 4 * P + 1024)
+        while True:
+            geom, binning, img = _scratch(P, W, H, cap, dev)
+            check(L.d3ga_raster_forward(ctypes.byref(prm), dptr(means3D), dptr(sh), dptr(colors_precomp),
+                                        dptr(opacities), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp),
+                                        dptr(view), dptr(proj), dptr(campos), dptr(bg), dptr(geom), dptr(binning),
+                                        dptr(img), cap, dptr(color), dptr(radii), dptr(invdepth), stream_handle()),
+                  "d3ga_raster_forward")
+            _last[dev.index] = binning
+            if static:
+                break
+            cnt = binning[:32].view(torch.int32)[:2].cpu().tolist()       # host sync (upstream: num_rendered)
+            D = cnt[0] & 0xFFFFFFFF
+            _hwm[dev.index] = max(_hwm.get(dev.index, 0), int(D * 1.25) + 1024)
+            if not cnt[1]:
+                break
+            cap = _hwm[dev.index]
+        ctx.prm = prm
+        ctx.cap = cap
+        ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img)
+        ctx.mark_non_differentiable(radii, invdepth)
+        return color, radii, invdepth
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii, _grad_invdepth):
+        means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img = ctx.saved_tensors
+        prm, dev, P = ctx.prm, means3D.device, means3D.shape[0]
+        grad_color = _f32(grad_color, dev)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        acc = new(P, 12)
+        g_means3D, g_means2D, g_opac = new(P, 3), new(P, 3), new(P, 1)
+        g_sh = new(P, prm.M, 3) if sh is not None else None
+        g_col = new(P, 3) if sh is None else None
+        from_sr = cov3Ds_precomp is None
+        g_cov = None if from_sr else new(P, 6)
+        g_scales = new(P, 3) if from_sr else None
+        g_rots = new(P, 4) if from_sr else None
+        check(_lib.lib().d3ga_raster_backward(
+            ctypes.byref(prm), dptr(means3D), dptr(sh), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp), dptr(view),
+            dptr(proj), dptr(campos), dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img), dptr(grad_color),
+            dptr(acc), dptr(g_means3D), dptr(g_means2D), dptr(g_opac), dptr(g_sh), dptr(g_col), dptr(g_cov),
+            dptr(g_scales), dptr(g_rots), stream_handle()), "d3ga_raster_backward")
+        return g_means3D, g_means2D, g_sh, g_col, g_opac, g_scales, g_rots, g_cov, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean (P,) mask: view-space z > 0.2 (upstream _C.mark_visible)."""
+        require_cuda(positions)
+        with torch.no_grad():
+            p = _f32(positions, positions.device)
+            view = _f32(self.raster_settings.viewmatrix, positions.device)
+            vis = torch.empty((p.shape[0],), dtype=torch.uint8, device=p.device)
+            check(_lib.lib().d3ga_raster_mark_visible(p.shape[0], dptr(p), dptr(view), dptr(vis), stream_handle()),
+                  "d3ga_raster_mark_visible")
+        return vis.bool()
+
+    def forward(self, means3D, means2D, opacities, shs: Optional[torch.Tensor] = None,
+                colors_precomp: Optional[torch.Tensor] = None, scales: Optional[torch.Tensor] = None,
+                rotations: Optional[torch.Tensor] = None, cov3D_precomp: Optional[torch.Tensor] = None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if self.raster_settings.antialiasing:
+            raise NotImplementedError("antialiasing=True is not implemented (the D3GA renderer passes False, renderer.py:92)")
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)

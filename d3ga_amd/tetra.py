@@ -1,0 +1,93 @@
+"""`tetra_sampler`-compatible container and point location (lib/cage.py:17,299-346 of the reference use
+`Tetra(path)`, `.points/.tetras/.triangles/.tetra_faces/.triangle_to_tetra`, `.gradient(x)`, `.get_triangles(v)`,
+`.n()` and `compute_bary(points, tetras (T,4,3), triangles, tri_to_tetra, cage)`).
+
+The original package (github.com/Zielon/sampler) is an un-vendored submodule; conventions that nothing in the
+reference pins are decided here and documented in DESIGN.md:
+  * `gradient` returns the edge vectors (v3-v0, v2-v0, v1-v0) as COLUMNS (the in-tree analogue lib/tet_mesh.py:88-94),
+    so that Ds @ inv(Dm) is the deformation gradient (a rigid cage rotation R gives J = R);
+  * a point outside every tet is assigned the tet with the largest minimum barycentric weight.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, dptr, require_cuda, stream_handle
+
+
+def read_medit_mesh(path):
+    """Minimal ASCII Medit .mesh reader: returns (vertices (V,3) f32, triangles (F,3) i64, tetrahedra (T,4) i64),
+    0-based.  (The reference reads the same file through meshio, lib/tet_mesh.py:18-32.)"""
+    with open(path, "r") as f:
+        tok = f.read().split()
+    out = {"Vertices": (3, np.float64), "Triangles": (3, np.int64), "Tetrahedra": (4, np.int64)}
+    data = {}
+    i = 0
+    while i < len(tok):
+        t = tok[i]
+        if t in out:
+            width, dt = out[t]
+            n = int(tok[i + 1])
+            raw = np.asarray(tok[i + 2:i + 2 + n * (width + 1)], dtype=np.float64).reshape(n, width + 1)
+            data[t] = raw[:, :width].astype(dt)
+            i += 2 + n * (width + 1)
+        elif t == "End":
+            break
+        else:
+            i += 1
+    verts = data.get("Vertices", np.zeros((0, 3))).astype(np.float32)
+    tris = data.get("Triangles", np.zeros((0, 3), np.int64)) - 1
+    tets = data.get("Tetrahedra", np.zeros((0, 4), np.int64)) - 1
+    return verts, tris, tets
+
+
+def boundary_triangles(tets):
+    """Faces that belong to exactly one tet, and the tet each belongs to."""
+    combos = np.array([[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 3]])
+    faces = tets[:, combos].reshape(-1, 3)
+    owner = np.repeat(np.arange(tets.shape[0]), 4)
+    key = np.sort(faces, axis=1)
+    _, inv, counts = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+    mask = counts[inv.reshape(-1)] == 1
+    return faces[mask], owner[mask]
+
+
+class Tetra:
+    def __init__(self, path=None, points=None, tetras=None, device="cuda"):
+        if path is not None:
+            v, tris, t = read_medit_mesh(path)
+        else:
+            v, t = np.asarray(points, np.float32), np.asarray(tetras, np.int64)
+        tri, owner = boundary_triangles(t)
+        dev = torch.device(device)
+        self.points = torch.from_numpy(v).to(dev)
+        self.tetras = torch.from_numpy(t).to(dev)
+        self.triangles = torch.from_numpy(tri).to(dev)
+        self.tetra_faces = torch.from_numpy(t[:, [[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 3]]].reshape(-1, 3)).to(dev)
+        self.triangle_to_tetra = torch.from_numpy(owner).to(dev)
+
+    def n(self):
+        return self.points.shape[0]
+
+    def gradient(self, x):
+        """(N,4,3) tet corners -> (N,3,3), columns (v3-v0, v2-v0, v1-v0)."""
+        return torch.stack([x[:, 3] - x[:, 0], x[:, 2] - x[:, 0], x[:, 1] - x[:, 0]], dim=2)
+
+    def get_triangles(self, vertices):
+        return vertices[self.triangles]
+
+
+def compute_bary(points, tetras, triangles=None, tri_to_tetra=None, cage=None):
+    """(points (P,3), tetras (T,4,3) corner coordinates, ...) -> (barys (P,4) f32, tetra_id (P,) int64, active (P,) bool).
+    `triangles`, `tri_to_tetra` and `cage` are accepted for signature compatibility (lib/cage.py:325-327); the
+    exhaustive GPU search needs none of them."""
+    require_cuda(points, tetras)
+    pts = points.detach().float().contiguous()
+    cor = tetras.detach().float().contiguous()
+    P, T = pts.shape[0], cor.shape[0]
+    barys = torch.empty((P, 4), dtype=torch.float32, device=pts.device)
+    tid = torch.empty((P,), dtype=torch.int32, device=pts.device)
+    act = torch.empty((P,), dtype=torch.uint8, device=pts.device)
+    check(_lib.lib().d3ga_compute_bary(P, T, dptr(pts), dptr(cor), dptr(barys), dptr(tid), dptr(act), stream_handle()),
+          "d3ga_compute_bary")
+    return barys, tid.long(), act.bool()

@@ -1,0 +1,173 @@
+/*
+ * d3ga.h -- C ABI of libd3ga_hip.so: the MI355X (gfx950) deform-and-rasterize hot path of D3GA.
+ *
+ * Every entry point is `extern "C"`, takes raw DEVICE pointers (unless marked host), element counts,
+ * scalar settings and a HIP stream, and returns an int status:
+ *      0  ok        <0  invalid argument (D3GA_E_*)        >0  a hipError_t from the runtime.
+ * No entry point throws, allocates persistent device memory, or synchronises the stream (except
+ * d3ga_compute_bary, an init-time call, and any call made with params.debug != 0, which synchronises and
+ * checks after every kernel).  All scratch is caller-owned; the library keeps no mutable global state,
+ * so it is re-entrant across devices and streams.  Tensors are dense, row-major, float32 unless stated;
+ * index tensors are int32.
+ *
+ * Each entry point cites the interface of the reference (facebookresearch/D3GA, paths relative to its root)
+ * that it replaces.  Rows refer to SURVEY.md sec. 8a.
+ */
+#ifndef D3GA_H
+#define D3GA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3GA_VERSION 100 /* 0.1.0 */
+
+#define D3GA_OK 0
+#define D3GA_E_NULL (-1)     /* required pointer is NULL */
+#define D3GA_E_SIZE (-2)     /* negative / inconsistent size */
+#define D3GA_E_CONFIG (-3)   /* unsupported combination (e.g. both shs and colors_precomp) */
+#define D3GA_E_CAPACITY (-4) /* scratch buffer too small */
+
+typedef void *d3ga_stream_t; /* hipStream_t */
+
+int d3ga_version(void);
+const char *d3ga_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * D0  Linear blend skinning of cage vertices (K-sparse weights).
+ * Replaces: lib/smplman.py:155-171 Smplman.deform  (T = W.A ; v' = T[v+delta;1] ; v'.Rh^T + Th) and
+ *           lbsmodel/body_model.py:208-234 LinearBlendSkinning.skinning (8-sparse form).
+ *   tmpl (V,3), delta (V,3)|NULL, joint_mats (J,4,4), skin_idx (V,K) int32, skin_w (V,K),
+ *   Rh (3,3)|NULL, Th (3)|NULL  ->  out (V,3).
+ * bwd: grad_out (V,3) -> grad_delta (V,3)  (= gradient w.r.t. the template offset / deformation_field output).
+ * ------------------------------------------------------------------------------------------------------- */
+int d3ga_lbs_cage_fwd(int V, int K, const float *tmpl, const float *delta, const float *joint_mats,
+                      const int32_t *skin_idx, const float *skin_w, const float *Rh, const float *Th, float *out,
+                      d3ga_stream_t stream);
+int d3ga_lbs_cage_bwd(int V, int K, const float *joint_mats, const int32_t *skin_idx, const float *skin_w,
+                      const float *Rh, const float *grad_out, float *grad_delta, d3ga_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * D1-D5  Fused tetrahedral-cage deformation.
+ * Replaces: models/cage_net.py:218-230 (tetpoints[tetra_faces], compute_def_grad, J S J^T, strip_symmetric,
+ *           einsum bary means) with lib/cage.py:339-342 and utils/general_utils.py:24-35,58-90.
+ *   tetpoints (V,3) posed cage vertices; tetras (T,4) int32; tetra_id (P) int32; barys (P,4) (= barys+delta_bary);
+ *   canon_grad (P,3,3) = inv(Dm) (lib/cage.py:329); scales (P,3) activated; rots (P,4) wxyz (normalised inside)
+ *   -> means3D (P,3), cov6 (P,6) in order xx,xy,xz,yy,yz,zz.
+ * bwd: g_means (P,3), g_cov6 (P,6) -> g_tetpoints (V,3) [zeroed by the call, then accumulated],
+ *      g_barys (P,4), g_scales (P,3), g_rots (P,4).  Any of the four outputs may be NULL (skipped).
+ * ------------------------------------------------------------------------------------------------------- */
+int d3ga_cage_deform_fwd(int P, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
+                         const float *barys, const float *canon_grad, const float *scales, const float *rots,
+                         float *means3D, float *cov6, d3ga_stream_t stream);
+int d3ga_cage_deform_bwd(int P, int V, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
+                         const float *barys, const float *canon_grad, const float *scales, const float *rots,
+                         const float *g_means, const float *g_cov6, float *g_tetpoints, float *g_barys,
+                         float *g_scales, float *g_rots, d3ga_stream_t stream);
+
+/* D6  FEM regulariser (lib/cage.py:349-361): per-tet energy 0.5(det F-1)^2 + 0.5(|F|_F^2-3), F = Ds Dn^-1.
+ *   fwd: energy (T).  bwd: g_energy (T) -> g_tetpoints (V,3) [zeroed by the call]. */
+int d3ga_fem_energy_fwd(int T, const float *tetpoints, const int32_t *tetras, const float *Dn_inv, float *energy,
+                        d3ga_stream_t stream);
+int d3ga_fem_energy_bwd(int T, int V, const float *tetpoints, const int32_t *tetras, const float *Dn_inv,
+                        const float *g_energy, float *g_tetpoints, d3ga_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * R1-R6  Tile rasterizer.  Replaces the un-vendored package `diff_gaussian_rasterization`
+ * (graphdeco-inria, branch dr_aa; /root/reference/.gitmodules:9-12) as called from renderer.py:79-141:
+ * _C.rasterize_gaussians / _C.rasterize_gaussians_backward / _C.mark_visible.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct d3ga_raster_params {
+    int32_t P;           /* number of Gaussians */
+    int32_t M;           /* SH coefficients per Gaussian in `shs` (stride), 0 if colors_precomp */
+    int32_t sh_degree;   /* active degree 0..3 */
+    int32_t W, H;        /* raster size (renderer.py:80-81) */
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    int32_t antialiasing; /* must be 0 (renderer.py:92) */
+    int32_t prefiltered;  /* accepted, ignored (renderer.py:90) */
+    int32_t debug;        /* !=0: synchronise + check after every kernel (renderer.py:91 passes 0) */
+} d3ga_raster_params;
+
+/* Byte sizes of the three caller-owned scratch buffers (the analogue of upstream's geomBuffer /
+ * binningBuffer / imgBuffer).  d_capacity = capacity in (tile,Gaussian) duplicates of the binning lists.
+ * sizes[0]=geom, sizes[1]=binning, sizes[2]=img.  Buffers must be 256-byte aligned. */
+int d3ga_raster_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t d_capacity, int64_t sizes[3]);
+
+/* The binning buffer starts with 8 uint32 counters the host may read back after the forward:
+ *   [0] D = duplicates required (sum of tiles touched)      [1] 1 if D > d_capacity (lists truncated: re-run)
+ *   [2] longest tile list                                    [3] number of visible Gaussians   [4..7] reserved */
+#define D3GA_CNT_D 0
+#define D3GA_CNT_OVERFLOW 1
+#define D3GA_CNT_MAXTILE 2
+#define D3GA_CNT_VISIBLE 3
+
+/* R1 per-Gaussian stage + tile histogram.  Exactly one of (shs | colors_precomp) and of
+ * ((scales,rotations) | cov3D_precomp) is non-NULL.  viewmatrix/projmatrix are the reference's transposed
+ * 4x4 matrices (lib/cameras.py:68-74), campos (3): all DEVICE pointers.  radii (P) int32 is an output. */
+int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float *means3D, const float *shs,
+                           const float *colors_precomp, const float *opacities, const float *scales,
+                           const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                           const float *projmatrix, const float *campos, void *geom, void *binning,
+                           int64_t d_capacity, int32_t *radii, d3ga_stream_t stream);
+/* R2+R3 tile offsets (scan), scatter of (depth,index) keys, per-tile sort in LDS. */
+int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, void *binning, int64_t d_capacity,
+                         d3ga_stream_t stream);
+/* R4 front-to-back compositing.  bg (3) device.  out_color (3,H,W); out_invdepth (H,W)|NULL. */
+int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
+                              int64_t d_capacity, void *img, float *out_color, float *out_invdepth,
+                              d3ga_stream_t stream);
+/* R5 back-to-front compositing backward.  dL_dpix (3,H,W).  Accumulates into acc (P,12) float, which the
+ * call zeroes first: [0..2] dL/dmean2D (x,y in NDC-scaled units, z unused), [3..5] dL/dconic (a, b/2, c),
+ * [6] dL/dopacity, [7..9] dL/dcolor, [10..11] pad. */
+int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
+                              int64_t d_capacity, const void *img, const float *dL_dpix, float *acc,
+                              d3ga_stream_t stream);
+/* R6 per-Gaussian backward.  Writes every element of the outputs (zeros for culled Gaussians):
+ * dL_dmeans3D (P,3), dL_dmeans2D (P,3), dL_dopacity (P,1), and dL_dsh (P,M,3) | dL_dcolors (P,3),
+ * dL_dcov3D (P,6) | (dL_dscales (P,3), dL_drots (P,4)). */
+int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const float *means3D, const float *shs,
+                               const float *scales, const float *rotations, const float *cov3D_precomp,
+                               const float *viewmatrix, const float *projmatrix, const float *campos,
+                               const void *geom, const float *acc, float *dL_dmeans3D, float *dL_dmeans2D,
+                               float *dL_dopacity, float *dL_dsh, float *dL_dcolors, float *dL_dcov3D,
+                               float *dL_dscales, float *dL_drots, d3ga_stream_t stream);
+
+/* Convenience: the whole forward / backward as one call (same stream, no synchronisation). */
+int d3ga_raster_forward(const d3ga_raster_params *prm, const float *means3D, const float *shs,
+                        const float *colors_precomp, const float *opacities, const float *scales,
+                        const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                        const float *projmatrix, const float *campos, const float *bg, void *geom, void *binning,
+                        void *img, int64_t d_capacity, float *out_color, int32_t *radii, float *out_invdepth,
+                        d3ga_stream_t stream);
+int d3ga_raster_backward(const d3ga_raster_params *prm, const float *means3D, const float *shs, const float *scales,
+                         const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                         const float *projmatrix, const float *campos, const float *bg, const void *geom,
+                         const void *binning, int64_t d_capacity, const void *img, const float *dL_dpix, float *acc,
+                         float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dsh,
+                         float *dL_dcolors, float *dL_dcov3D, float *dL_dscales, float *dL_drots,
+                         d3ga_stream_t stream);
+
+/* _C.mark_visible: visible[i] = 1 if view-space z > 0.2 (uint8 output). */
+int d3ga_raster_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, uint8_t *visible,
+                             d3ga_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Init-time point location.  Replaces tetra_sampler.compute_bary (lib/cage.py:325-327): for each point the
+ * containing tetrahedron (point-in-tet per submodules/tetrahedralize/include/tet/tetrahedron.h:46-71) and its
+ * barycentric weights (same header :77-101, order a,b,c,d); points outside every tet take the tet with the
+ * largest minimum barycentric weight (weights may be negative) and active[i] = 0.
+ *   points (P,3), tetra_corners (T,4,3) -> barys (P,4), tetra_id (P) int32, active (P) uint8.
+ * ------------------------------------------------------------------------------------------------------- */
+/* Test hook, not part of the drop-in surface: 64-lane DPP reduction used by the compositing backward. */
+int d3ga_selftest_wave_sum(int n, const float *in, float *out, d3ga_stream_t stream);
+
+int d3ga_compute_bary(int P, int T, const float *points, const float *tetra_corners, float *barys,
+                      int32_t *tetra_id, uint8_t *active, d3ga_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3GA_H */
