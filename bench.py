@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- fwd+bwd frames/s of the D3GA deform-and-rasterize hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" on a rank = one frame of the hot path over synthetic inputs already resident in HBM:
+    LBS of the cage (D0) -> cage_deform (D1-D5) -> render() (R1-R4, SH degree 3) -> L1 loss -> backward through the
+    rasterizer (R5-R6), the deform (A1) and the LBS, down to the avatar parameters
+    (cage-vertex offsets, barycentric offsets, scaling, rotation, opacity, SH).
+With N ranks every rank renders its own view of the same pose (camera sharding, weak scaling) and the parameter
+gradients are summed with one RCCL all-reduce per step.  value = frames of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  "roofline":     dominant compositing kernel vs the HBM roofline (algorithmic bytes of SURVEY.md sec. 8d / HIP-event time)
+  "cpu_baseline": the oracle (CPU port: torch deform + C rasterizer) timed on this box's host cores, baseline only.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable in a copy
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events in the timed region")
+    return ap.parse_args()
+
+
+class Frame:
+    """Avatar parameters + one camera, resident on the device."""
+
+    def __init__(self, wl_name, dev, view_index, n_views=8):
+        from d3ga_amd import synthetic as syn
+        from d3ga_amd.cage_deform import canonical_gradient
+        self.syn = syn
+        sc = syn.make_scene(wl_name)
+        self.wl = sc["workload"]
+        d = lambda t: t.to(dev)
+        self.canon, self.tetras, self.tetra_id = d(sc["canon_points"]), d(sc["tetras"]), d(sc["tetra_id"])
+        self.barys0 = d(sc["barys"])
+        self.joint_mats, self.skin_idx, self.skin_w = d(sc["joint_mats"]), d(sc["skin_idx"]), d(sc["skin_w"])
+        self.canon_grad = canonical_gradient(self.canon, self.tetras, self.tetra_id).contiguous()
+        P = self.barys0.shape[0]
+        par = lambda t: d(t).clone().requires_grad_(True)
+        self.params = {
+            "delta_node": par(sc["delta_node"]),
+            "delta_bary": torch.zeros(P, 4, device=dev, requires_grad=True),
+            "scaling": par(sc["scaling"]),
+            "rotation": par(sc["rotation"]),
+            "opacity": par(sc["opacity_logit"]),
+            # one contiguous SH buffer (features_dc | features_rest), instead of torch.cat per frame (cage_net.py:155-159)
+            "features": par(torch.cat([sc["features_dc"], sc["features_rest"]], 1)),
+        }
+        self.batch = syn.make_batch(self.wl.width, self.wl.height, azimuth=2 * math.pi * view_index / n_views,
+                                    camera_id=view_index)
+        self.bg = torch.ones(3, device=dev)
+        g = torch.Generator().manual_seed(100 + view_index)
+        self.target = torch.rand(3, self.wl.height, self.wl.width, generator=g).to(dev)
+        self.sh_degree = self.wl.sh_degree
+
+    def step(self):
+        from d3ga_amd.cage_deform import cage_deform, lbs_cage
+        from d3ga_amd.renderer import render
+        p = self.params
+        tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
+        means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0 + p["delta_bary"],
+                                  self.canon_grad, torch.exp(p["scaling"]), p["rotation"])
+        pkg = {"means3D": means, "cov3D_precomp": cov6, "opacities": torch.sigmoid(p["opacity"]),
+               "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
+        img = render(self.batch, pkg, self.bg)["render"]
+        loss = (img - self.target).abs().mean()
+        loss.backward()
+        return loss
+
+
+def cpu_baseline(wl_name, budget_s=20.0):
+    """The oracle (CPU port of the path) on this box's host cores: torch deform fwd+bwd + C rasterizer fwd+bwd."""
+    from d3ga_amd import synthetic as syn
+    from oracle import camera as oc
+    from oracle import deform as od
+    from oracle import raster_c as rc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sc = syn.make_scene(wl_name)
+    wl = sc["workload"]
+    b = syn.make_batch(wl.width, wl.height)
+    cam = oc.camera(b["R"], b["T"], b["FoVx"], b["FoVy"])
+    cg = od.canonical_gradient(sc["canon_points"], sc["tetras"].long(), sc["tetra_id"].long())
+    shs = torch.cat([sc["features_dc"], sc["features_rest"]], 1).numpy()
+    op = torch.sigmoid(sc["opacity_logit"]).numpy()
+    gpix = np.random.default_rng(0).normal(size=(3, b["height"], b["width"])).astype(np.float32)
+    bg = np.ones(3, np.float32)
+    times, deform_times = [], []
+    t_start = time.time()
+    while True:
+        t0 = time.time()
+        delta = sc["delta_node"].clone().requires_grad_(True)
+        scaling = sc["scaling"].clone().requires_grad_(True)
+        rot = sc["rotation"].clone().requires_grad_(True)
+        barys = sc["barys"].clone().requires_grad_(True)
+        tp = od.lbs_cage(sc["canon_points"], delta, sc["joint_mats"], sc["skin_idx"], sc["skin_w"])
+        means, cov6 = od.cage_deform(tp, sc["tetras"], sc["tetra_id"], barys, cg, torch.exp(scaling), rot)
+        t1 = time.time()
+        color, radii, _, ctx = rc.forward(means.detach().numpy(), op, bg, cam["world_view_transform"],
+                                          cam["full_proj_transform"], cam["camera_center"], cam["tanfovx"],
+                                          cam["tanfovy"], b["width"], b["height"], cov3D_precomp=cov6.detach().numpy(),
+                                          shs=shs, sh_degree=wl.sh_degree)
+        g = rc.backward(ctx, gpix)
+        t2 = time.time()
+        ((means * torch.from_numpy(g["means3D"])).sum() + (cov6 * torch.from_numpy(g["cov3D"])).sum()).backward()
+        t3 = time.time()
+        times.append(t3 - t0)
+        deform_times.append((t1 - t0) + (t3 - t2))
+        if time.time() - t_start > budget_s or len(times) >= 5:
+            break
+    best = min(times)
+    return {"value": round(1.0 / best, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} full frames of {wl.name} (oracle: torch CPU deform fwd+bwd + OpenMP C rasterizer fwd+bwd), best of {len(times)}",
+            "deform_only_frames_per_s": round(1.0 / min(deform_times), 3)}
+
+
+def main():
+    args = parse()
+    from d3ga_amd import dist as ddist
+    rank, local, world = ddist.init_process_group()
+    if world != max(args.gpus, 1):
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import d3ga_amd
+    d3ga_amd.lib()
+    from d3ga_amd import rasterizer as R
+
+    frame = Frame(args.workload, dev, view_index=rank % 8)
+    flat = ddist.FlatGrads(list(frame.params.values()))
+
+    def one_step():
+        flat.zero_()
+        frame.step()
+        flat.all_reduce_mean()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up (auto capacity: learns the duplicate count), then freeze the capacity: no host sync inside a frame
+    for _ in range(max(args.warmup, 2)):
+        one_step()
+    torch.cuda.synchronize()
+    cnt = R.last_counters()
+    R.set_capacity_policy("static", int(cnt["D"] * 1.25) + 4096)
+    one_step()
+    R.stage_timer.enabled = not args.no_stage_events
+    R.stage_timer.reset()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    R.stage_timer.enabled = False
+    cnt_end = R.last_counters()
+    assert not cnt_end["overflow"], "binning capacity overflowed inside the timed region: result invalid"
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        wl = frame.wl
+        P, W, H, D = wl.n_gaussians, frame.batch["width"], frame.batch["height"], cnt_end["D"]
+        M = frame.params["features"].shape[1]
+        stages = R.stage_timer.summary()
+        alg = {   # algorithmic bytes per launch
+            "preprocess": P * (88 + 12 * M),
+            "bin_sort": 36 * D + 8 * (math.ceil(W / 16) * math.ceil(H / 16)),
+            "composite_fwd": 40 * D + 20 * W * H,
+            "composite_bwd": 80 * D + 20 * W * H,
+            "preprocess_bwd": P * (140 + 40 + 12 * M),
+        }
+        kernels = {k: {"ms": round(ms, 4), "launches": n, "alg_bytes": alg[k],
+                       "achieved_GBs": round(alg[k] / (ms * 1e-3) / 1e9, 1),
+                       "frac_hbm_peak": round(alg[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                   for k, (n, ms) in stages.items() if k in alg}
+        roof = None
+        comp = [k for k in ("composite_bwd", "composite_fwd") if k in kernels]
+        if comp:
+            k = max(comp, key=lambda n: kernels[n]["ms"])
+            roof = {"kernel": k, "bound": "hbm", "achieved": kernels[k]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": kernels[k]["frac_hbm_peak"], "traffic": None,
+                    "alg_bytes_per_launch": alg[k], "avg_ms": kernels[k]["ms"]}
+        out = {
+            "metric": "fwd+bwd frames/sec @500k Gaussians 1920x1080" if args.workload == "C3" else f"fwd+bwd frames/sec ({wl.name})",
+            "value": round(world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl.name, "gaussians": P, "width": W, "height": H, "sh_degree": wl.sh_degree,
+                       "duplicates_D": D, "max_tile_list": cnt_end["max_tile"], "visible": cnt_end["visible"],
+                       "views_per_step": world, "parallelism": f"camera-sharded dp{world}",
+                       "grad_allreduce_bytes": flat.nbytes() if world > 1 else 0},
+            "roofline": roof, "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

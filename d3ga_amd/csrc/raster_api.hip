@@ -27,6 +27,28 @@ extern "C" int d3ga_raster_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_
     return D3GA_OK;
 }
 
+extern "C" int d3ga_raster_binning_layout(int32_t W, int32_t H, int64_t d_capacity, int64_t offsets[6]) {
+    if (!offsets) return D3GA_E_NULL;
+    if (W <= 0 || H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
+    char *base = (char *)nullptr + 256;   // any aligned non-null base; only differences are reported
+    const BinBuf b = carve_bin(base, (int64_t)tiles_x(W) * tiles_y(H), d_capacity > 0 ? d_capacity : 1);
+    offsets[0] = (char *)b.counters - base;
+    offsets[1] = (char *)b.tile_count - base;
+    offsets[2] = (char *)b.tile_start - base;
+    offsets[3] = (char *)b.tile_cursor - base;
+    offsets[4] = (char *)b.keys - base;
+    offsets[5] = (char *)b.point_list - base;
+    return D3GA_OK;
+}
+
+extern "C" int d3ga_raster_img_layout(int32_t W, int32_t H, int64_t offsets[2]) {
+    if (!offsets) return D3GA_E_NULL;
+    if (W <= 0 || H <= 0) return D3GA_E_SIZE;
+    offsets[0] = 0;
+    offsets[1] = align256(4 * (int64_t)W * H);
+    return D3GA_OK;
+}
+
 extern "C" int d3ga_raster_forward(const d3ga_raster_params *prm, const float *means3D, const float *shs,
                                    const float *colors_precomp, const float *opacities, const float *scales,
                                    const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
@@ -46,6 +68,8 @@ extern "C" int d3ga_raster_backward(const d3ga_raster_params *prm, const float *
                                     const void *img, const float *dL_dpix, float *acc, float *dL_dmeans3D,
                                     float *dL_dmeans2D, float *dL_dopacity, float *dL_dsh, float *dL_dcolors,
                                     float *dL_dcov3D, float *dL_dscales, float *dL_drots, d3ga_stream_t stream) {
+    if (prm && prm->P > 0 && acc)
+        D3GA_HIP(hipMemsetAsync(acc, 0, sizeof(float) * 12 * (size_t)prm->P, (hipStream_t)stream));
     D3GA_TRY(d3ga_raster_composite_bwd(prm, bg, geom, binning, d_capacity, img, dL_dpix, acc, stream));
     return d3ga_raster_preprocess_bwd(prm, means3D, shs, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                                       campos, geom, acc, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors,

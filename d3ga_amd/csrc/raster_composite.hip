@@ -232,11 +232,11 @@ extern "C" int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const fl
 extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const float *bg, const void *geom,
                                          const void *binning, int64_t d_capacity, const void *img,
                                          const float *dL_dpix, float *acc, d3ga_stream_t stream) {
-    if (!prm || !bg || !geom || !binning || !img || !dL_dpix || !acc) return D3GA_E_NULL;
+    if (!prm) return D3GA_E_NULL;
     if (prm->P < 0 || prm->W <= 0 || prm->H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
-    hipStream_t s = (hipStream_t)stream;
     if (prm->P == 0) return D3GA_OK;
-    D3GA_HIP(hipMemsetAsync(acc, 0, sizeof(float) * 12 * (size_t)prm->P, s));
+    if (!bg || !geom || !binning || !img || !dL_dpix || !acc) return D3GA_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
     const int gx = tiles_x(prm->W), gy = tiles_y(prm->H);
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);

@@ -44,7 +44,7 @@ class GaussianRasterizationSettings(NamedTuple):
 # ------------------------------------------------------------------------------------------------------------
 _policy = {"mode": "auto", "static": 0}
 _hwm = {}            # device index -> high-water mark of D
-_last = {}           # device index -> binning tensor of the most recent forward (for last_counters)
+_last = {}           # device index -> (binning tensor, capacity) of the most recent forward (for last_counters)
 
 
 def set_capacity_policy(mode, capacity=0):
@@ -59,8 +59,41 @@ def set_capacity_policy(mode, capacity=0):
 def last_counters(device=None):
     """dict(D, overflow, max_tile, visible) of the most recent forward on `device` (synchronises)."""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    c = _last[dev][:32].view(torch.int32)[:4].cpu().tolist()
+    c = _last[dev][0][:32].view(torch.int32)[:4].cpu().tolist()
     return {"D": c[0] & 0xFFFFFFFF, "overflow": bool(c[1]), "max_tile": c[2] & 0xFFFFFFFF, "visible": c[3]}
+
+
+class StageTimer:
+    """Optional per-stage HIP-event timing of the rasterizer (bench.py).  While enabled the forward/backward are
+    issued stage by stage through the C ABI (same kernels, same stream) with an event pair around each stage."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (stage, start_event, end_event)
+
+    def reset(self):
+        self.records = []
+
+    def stage(self, name, fn):
+        if not self.enabled:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()                  # on torch's current stream == the stream the kernels are launched on
+        r = fn()
+        b.record()
+        self.records.append((name, a, b))
+        return r
+
+    def summary(self):
+        """stage -> (launches, mean ms); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, a, b in self.records:
+            n, t = out.get(name, (0, 0.0))
+            out[name] = (n + 1, t + a.elapsed_time(b))
+        return {k: (n, t / n) for k, (n, t) in out.items()}
+
+
+stage_timer = StageTimer()
 
 
 def _scratch(P, W, H, cap, device):
@@ -108,12 +141,24 @@ class _RasterizeGaussians(torch.autograd.Function):
         cap = _policy["static"] if static else max(_hwm.get(dev.index, 0), 4 * P + 1024)
         while True:
             geom, binning, img = _scratch(P, W, H, cap, dev)
-            check(L.d3ga_raster_forward(ctypes.byref(prm), dptr(means3D), dptr(sh), dptr(colors_precomp),
-                                        dptr(opacities), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp),
-                                        dptr(view), dptr(proj), dptr(campos), dptr(bg), dptr(geom), dptr(binning),
-                                        dptr(img), cap, dptr(color), dptr(radii), dptr(invdepth), stream_handle()),
-                  "d3ga_raster_forward")
-            _last[dev.index] = binning
+            if stage_timer.enabled:
+                st, pp = stream_handle(), ctypes.byref(prm)
+                stage_timer.stage("preprocess", lambda: check(L.d3ga_raster_preprocess(
+                    pp, dptr(means3D), dptr(sh), dptr(colors_precomp), dptr(opacities), dptr(scales), dptr(rotations),
+                    dptr(cov3Ds_precomp), dptr(view), dptr(proj), dptr(campos), dptr(geom), dptr(binning), cap,
+                    dptr(radii), st), "d3ga_raster_preprocess"))
+                stage_timer.stage("bin_sort", lambda: check(L.d3ga_raster_bin_sort(
+                    pp, dptr(geom), dptr(binning), cap, st), "d3ga_raster_bin_sort"))
+                stage_timer.stage("composite_fwd", lambda: check(L.d3ga_raster_composite_fwd(
+                    pp, dptr(bg), dptr(geom), dptr(binning), cap, dptr(img), dptr(color), dptr(invdepth), st),
+                    "d3ga_raster_composite_fwd"))
+            else:
+                check(L.d3ga_raster_forward(ctypes.byref(prm), dptr(means3D), dptr(sh), dptr(colors_precomp),
+                                            dptr(opacities), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp),
+                                            dptr(view), dptr(proj), dptr(campos), dptr(bg), dptr(geom), dptr(binning),
+                                            dptr(img), cap, dptr(color), dptr(radii), dptr(invdepth), stream_handle()),
+                      "d3ga_raster_forward")
+            _last[dev.index] = (binning, cap)
             if static:
                 break
             cnt = binning[:32].view(torch.int32)[:2].cpu().tolist()       # host sync (upstream: num_rendered)
@@ -124,6 +169,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             cap = _hwm[dev.index]
         ctx.prm = prm
         ctx.cap = cap
+        ctx.has_means2D = means2D is not None
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img)
         ctx.mark_non_differentiable(radii, invdepth)
         return color, radii, invdepth
@@ -142,12 +188,24 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_cov = None if from_sr else new(P, 6)
         g_scales = new(P, 3) if from_sr else None
         g_rots = new(P, 4) if from_sr else None
-        check(_lib.lib().d3ga_raster_backward(
-            ctypes.byref(prm), dptr(means3D), dptr(sh), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp), dptr(view),
-            dptr(proj), dptr(campos), dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img), dptr(grad_color),
-            dptr(acc), dptr(g_means3D), dptr(g_means2D), dptr(g_opac), dptr(g_sh), dptr(g_col), dptr(g_cov),
-            dptr(g_scales), dptr(g_rots), stream_handle()), "d3ga_raster_backward")
-        return g_means3D, g_means2D, g_sh, g_col, g_opac, g_scales, g_rots, g_cov, None
+        L = _lib.lib()
+        if stage_timer.enabled:
+            st, pp = stream_handle(), ctypes.byref(prm)
+            acc.zero_()
+            stage_timer.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd(
+                pp, dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img), dptr(grad_color), dptr(acc), st),
+                "d3ga_raster_composite_bwd"))
+            stage_timer.stage("preprocess_bwd", lambda: check(L.d3ga_raster_preprocess_bwd(
+                pp, dptr(means3D), dptr(sh), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp), dptr(view), dptr(proj),
+                dptr(campos), dptr(geom), dptr(acc), dptr(g_means3D), dptr(g_means2D), dptr(g_opac), dptr(g_sh),
+                dptr(g_col), dptr(g_cov), dptr(g_scales), dptr(g_rots), st), "d3ga_raster_preprocess_bwd"))
+        else:
+            check(L.d3ga_raster_backward(
+                ctypes.byref(prm), dptr(means3D), dptr(sh), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp),
+                dptr(view), dptr(proj), dptr(campos), dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img),
+                dptr(grad_color), dptr(acc), dptr(g_means3D), dptr(g_means2D), dptr(g_opac), dptr(g_sh), dptr(g_col),
+                dptr(g_cov), dptr(g_scales), dptr(g_rots), stream_handle()), "d3ga_raster_backward")
+        return (g_means3D, g_means2D if ctx.has_means2D else None, g_sh, g_col, g_opac, g_scales, g_rots, g_cov, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -184,3 +242,23 @@ class GaussianRasterizer(nn.Module):
             raise NotImplementedError("antialiasing=True is not implemented (the D3GA renderer passes False, renderer.py:92)")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings)
+
+
+def last_tile_lists(W, H, device=None):
+    """tile_lists() of the most recent forward on `device`."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    binning, cap = _last[dev]
+    return tile_lists(binning, W, H, cap)
+
+
+def tile_lists(binning, W, H, d_capacity):
+    """(tile_start (tiles+1,) int64, point_list (D,) int64, keys (D,) int64) views decoded from a binning buffer
+    (inspection / tests; layout from d3ga_raster_binning_layout)."""
+    off = (ctypes.c_int64 * 6)()
+    check(_lib.lib().d3ga_raster_binning_layout(W, H, d_capacity, off), "d3ga_raster_binning_layout")
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    start = binning[off[2]:off[2] + 4 * (tiles + 1)].view(torch.int32).long() & 0xFFFFFFFF
+    D = min(int(start[-1]), d_capacity)
+    keys = binning[off[4]:off[4] + 8 * D].view(torch.int64)
+    plist = binning[off[5]:off[5] + 4 * D].view(torch.int32).long()
+    return start, plist, keys

