@@ -94,8 +94,10 @@ def cpu_baseline(wl_name, budget_s=20.0):
     from oracle import camera as oc
     from oracle import deform as od
     from oracle import raster_c as rc
-    cores = os.cpu_count() or 1
+    # threads actually used: capped -- on a 256-thread host torch's intra-op pool and libgomp oversubscribe badly
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
+    rc.set_threads(cores)
     sc = syn.make_scene(wl_name)
     wl = sc["workload"]
     b = syn.make_batch(wl.width, wl.height)

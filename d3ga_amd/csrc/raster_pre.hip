@@ -101,16 +101,16 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     D3GA_TRY(validate(prm));
     if (!geom || !binning || !viewmatrix || !projmatrix || !campos) return D3GA_E_NULL;
     if (d_capacity < 0) return D3GA_E_SIZE;
-    if ((shs != nullptr) == (colors_precomp != nullptr)) return D3GA_E_CONFIG;
-    const bool sr = scales != nullptr && rotations != nullptr;
-    if (sr == (cov3D_precomp != nullptr)) return D3GA_E_CONFIG;
-    if (shs && (prm->sh_degree + 1) * (prm->sh_degree + 1) > prm->M) return D3GA_E_CONFIG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t tiles = (int64_t)tiles_x(prm->W) * tiles_y(prm->H);
     BinBuf bin = carve_bin(binning, tiles, d_capacity);
     // counters + tile_count are adjacent: one memset
     D3GA_HIP(hipMemsetAsync(bin.counters, 0, 256 + align256(4 * tiles), s));
-    if (prm->P == 0) return D3GA_OK;
+    if (prm->P == 0) return D3GA_OK;          // empty scene: every per-Gaussian tensor is empty (NULL)
+    if ((shs != nullptr) == (colors_precomp != nullptr)) return D3GA_E_CONFIG;
+    const bool sr = scales != nullptr && rotations != nullptr;
+    if (sr == (cov3D_precomp != nullptr)) return D3GA_E_CONFIG;
+    if (shs && (prm->sh_degree + 1) * (prm->sh_degree + 1) > prm->M) return D3GA_E_CONFIG;
     if (!means3D || !opacities || !radii) return D3GA_E_NULL;
     GeomBuf g = carve_geom(geom, prm->P);
     hipLaunchKernelGGL(preprocess_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, *prm, means3D, shs,

@@ -121,8 +121,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         s = raster_settings
         require_cuda(means3D)
         dev = means3D.device
-        sh, colors_precomp, scales, rotations, cov3Ds_precomp = map(
-            _empty_to_none, (sh, colors_precomp, scales, rotations, cov3Ds_precomp))
+        if means3D.shape[0] > 0:      # upstream passes absent arguments as empty tensors
+            sh, colors_precomp, scales, rotations, cov3Ds_precomp = map(
+                _empty_to_none, (sh, colors_precomp, scales, rotations, cov3Ds_precomp))
         means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp = (
             _f32(t, dev) for t in (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
         view, proj, campos, bg = (_f32(t, dev) for t in (s.viewmatrix, s.projmatrix, s.campos, s.bg))

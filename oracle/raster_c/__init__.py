@@ -34,6 +34,14 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    lib().ro_set_threads(ctypes.c_int(int(n)))
+
+
+def max_threads():
+    return int(lib().ro_max_threads())
+
+
 def _f(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
 

@@ -137,6 +137,15 @@ static int kv_cmp(const void *a, const void *b) {
     return (x->idx > y->idx) - (x->idx < y->idx);
 }
 
+#ifdef _OPENMP
+#include <omp.h>
+void ro_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int ro_max_threads(void) { return omp_get_max_threads(); }
+#else
+void ro_set_threads(int n) { (void)n; }
+int ro_max_threads(void) { return 1; }
+#endif
+
 void ro_free(ro_ctx *c) {
     if (!c) return;
     free(c->depth); free(c->xy); free(c->conic_o); free(c->rgb); free(c->cov3D); free(c->radii);

@@ -1,0 +1,126 @@
+"""The two rasterizer oracles against each other and against known answers (parity for this stage is UNPINNED:
+the reference ships no rasterizer source, test or golden vector -- see oracle/__init__.py)."""
+import math
+
+import numpy as np
+import torch
+
+from oracle import raster_c as rc
+from oracle import raster_torch as rt
+from util import rel_err, scene_inputs
+
+
+def _np(t):
+    return np.ascontiguousarray(t.detach().numpy())
+
+
+def _both(inp, dt, deg, use_sh=True, from_sr=False, mod=1.0, seed=1):
+    cam = inp["cam"]
+    W, H = inp["W"], inp["H"]
+    bg = torch.tensor([1.0, 0.5, 0.2])
+    gpix = torch.randn(3, H, W, generator=torch.Generator().manual_seed(seed))
+    leaf = lambda t: t.to(dt).clone().requires_grad_(True)
+    m, o = leaf(inp["means3D"]), leaf(inp["opacities"])
+    kw, ckw, leaves = {}, {}, {"means3D": m, "opacities": o}
+    if use_sh:
+        sh = leaf(inp["shs"]); kw.update(shs=sh, sh_degree=deg); ckw.update(shs=_np(inp["shs"]), sh_degree=deg)
+        leaves["shs"] = sh
+    else:
+        col = leaf(inp["rgb"]); kw.update(colors_precomp=col); ckw.update(colors_precomp=_np(inp["rgb"]))
+        leaves["colors"] = col
+    if from_sr:
+        q = torch.nn.functional.normalize(inp["scene"]["rotation"]) * 0.9
+        s, r = leaf(inp["scales"]), leaf(q)
+        kw.update(scales=s, rotations=r, scale_modifier=mod)
+        ckw.update(scales=_np(inp["scales"]), rotations=_np(q), scale_modifier=mod)
+        leaves.update(scales=s, rotations=r)
+    else:
+        c6 = leaf(inp["cov6"]); kw.update(cov3D_precomp=c6); ckw.update(cov3D_precomp=_np(inp["cov6"]))
+        leaves["cov3D"] = c6
+    col_t, fT, nc, invd, pre = rt.rasterize(m, o, bg, inp["view"], inp["proj"], inp["campos"], cam["tanfovx"],
+                                            cam["tanfovy"], W, H, return_aux=True, **kw)
+    (col_t * gpix.to(dt)).sum().backward()
+    ccol, radii, cinv, ctx = rc.forward(_np(inp["means3D"]), _np(inp["opacities"]), _np(bg), cam["world_view_transform"],
+                                        cam["full_proj_transform"], cam["camera_center"], cam["tanfovx"], cam["tanfovy"],
+                                        W, H, **ckw)
+    g = rc.backward(ctx, _np(gpix))
+    geom = rc.geom(ctx)
+    assert np.array_equal(radii, _np(pre["radii"]))
+    assert rc.num_rendered(ctx) == int(pre["tiles_touched"].sum())
+    assert np.abs(ccol - _np(col_t)).max() < 2e-6
+    assert np.abs(cinv - _np(invd)).max() < 2e-5
+    assert (geom["n_contrib"] == _np(nc)).mean() > 0.9995
+    assert np.abs(geom["final_T"] - _np(fT)).max() < 2e-6
+    for k, leaf_t in leaves.items():
+        assert rel_err(g[k], _np(leaf_t.grad)) < 2e-5, k
+    return g
+
+
+def test_c_oracle_matches_autograd_oracle_sh_cov():
+    inp = scene_inputs("T0", scale_mult=3.0)
+    _both(inp, torch.float32, 3)
+    _both(inp, torch.float64, 3)
+    _both(inp, torch.float64, 1, seed=2)
+
+
+def test_c_oracle_matches_autograd_oracle_colors_scale_rot():
+    inp = scene_inputs("T0", scale_mult=3.0, azimuth=-0.7)
+    _both(inp, torch.float64, 0, use_sh=False, from_sr=True, mod=1.4)
+
+
+def test_c_oracle_matches_autograd_oracle_clamped_sh():
+    inp = scene_inputs("T0", scale_mult=3.0)
+    inp["shs"] = inp["shs"].clone()
+    inp["shs"][::3, 0, :] = -2.5
+    _both(inp, torch.float64, 2)
+
+
+def test_single_gaussian_known_answer():
+    """One isotropic Gaussian on the optical axis: pixel (x,y) gets alpha = o*exp(-r^2/(2 s^2)) with
+    s^2 = (f sigma/z)^2 + 0.3, colour = alpha*c + (1-alpha)*bg."""
+    W = H = 33
+    fov = 0.6
+    f = W / (2 * math.tan(fov / 2))
+    z, sigma, o = 4.0, 0.08, 0.7
+    view = torch.eye(4)
+    proj = torch.from_numpy(__import__("oracle.camera", fromlist=["projection"]).projection(0.01, 100.0, fov, fov).T.copy())
+    means = torch.tensor([[0.0, 0.0, z]])
+    cov = torch.tensor([[sigma ** 2, 0, 0, sigma ** 2, 0, sigma ** 2]])
+    color = torch.tensor([[0.2, 0.6, 0.9]])
+    bg = torch.tensor([0.1, 0.1, 0.1])
+    img, radii = rt.rasterize(means.double(), torch.tensor([[o]]).double(), bg, view, proj, torch.zeros(3), math.tan(fov / 2),
+                              math.tan(fov / 2), W, H, cov3D_precomp=cov.double(), colors_precomp=color.double())
+    s2 = (f * sigma / z) ** 2 + 0.3
+    assert int(radii[0]) == math.ceil(3 * math.sqrt(s2))
+    cx = cy = (W - 1) / 2            # ndc 0 -> pixel ((0+1)W-1)/2
+    for (x, y) in ((16, 16), (18, 16), (16, 20), (10, 12)):
+        r2 = (x - cx) ** 2 + (y - cy) ** 2
+        a = min(0.99, o * math.exp(-0.5 * r2 / s2))
+        if a < 1 / 255:
+            a = 0.0
+        expect = a * color[0].double() + (1 - a) * bg.double()
+        np.testing.assert_allclose(img[:, y, x].numpy(), expect.numpy(), atol=1e-9)
+
+
+def test_front_to_back_order_and_termination():
+    """Depth order decides who is in front; blending stops BEFORE the splat that would take T below 1e-4."""
+    W = H = 16
+    fov = 0.5
+    view = torch.eye(4)
+    from oracle.camera import projection
+    proj = torch.from_numpy(projection(0.01, 100.0, fov, fov).T.copy())
+    means = torch.tensor([[0.0, 0.0, 5.0], [0.0, 0.0, 3.0], [0.0, 0.0, 4.0]]).double()
+    cov = torch.tensor([[1.0, 0, 0, 1.0, 0, 1.0]]).repeat(3, 1).double()
+    col = torch.tensor([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]]).double()
+    op = torch.tensor([[1.0], [1.0], [0.9]]).double()      # red z=5, green z=3, blue z=4
+    img, _ = rt.rasterize(means, op, torch.zeros(3), view, proj, torch.zeros(3), math.tan(fov / 2), math.tan(fov / 2), W, H,
+                          cov3D_precomp=cov, colors_precomp=col)
+    px = img[:, 8, 8]
+    # order: green (alpha .99), blue (alpha .9) -> T = 1e-3; red (alpha .99) would give T = 1e-5 < 1e-4: not blended
+    f = W / (2 * math.tan(fov / 2))
+    a_blue = 0.9 * math.exp(-0.5 * (0.5 ** 2 + 0.5 ** 2) / ((f * 1.0 / 4.0) ** 2 + 0.3))   # centre is at pixel 7.5
+    np.testing.assert_allclose(px.numpy(), [0.0, 0.99, a_blue * 0.01], atol=1e-9)
+    c, _, _, ctx = rc.forward(means.numpy(), op.numpy(), np.zeros(3), view.numpy(), proj.numpy(), np.zeros(3),
+                              math.tan(fov / 2), math.tan(fov / 2), W, H, cov3D_precomp=cov.numpy(), colors_precomp=col.numpy())
+    np.testing.assert_allclose(c[:, 8, 8], [0.0, 0.99, a_blue * 0.01], atol=1e-6)
+    assert rc.geom(ctx)["n_contrib"][8, 8] == 2
