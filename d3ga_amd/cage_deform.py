@@ -21,10 +21,45 @@ def _f32c(t):
     return t.contiguous()
 
 
+_i32_cache = {}
+
+
 def _i32c(t):
-    if t.dtype != torch.int32:
-        t = t.to(torch.int32)
-    return t.contiguous()
+    """int32 contiguous view of an index buffer.  The reference registers int64 buffers (lib/cage.py:331-337); their
+    int32 copies are cached (keyed on storage + version, holding the source alive) so that per-frame calls neither
+    convert again nor defeat the adjacency cache below."""
+    if t.dtype == torch.int32 and t.is_contiguous():
+        return t
+    key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+    hit = _i32_cache.get(key)
+    if hit is None:
+        if len(_i32_cache) > 64:
+            _i32_cache.clear()
+        hit = (t, t.to(torch.int32).contiguous())
+        _i32_cache[key] = hit
+    return hit[1]
+
+
+_adjacency_cache = {}
+
+
+def vertex_adjacency(tetras, tetra_id, n_vertices):
+    """Static CSR adjacency vertex -> items (4*gaussian + corner) of a cage binding; built once and cached.
+    (tetra_id / tetras are buffers fixed at initialisation, lib/cage.py:331-337.)"""
+    key = (tetras.data_ptr(), tetra_id.data_ptr(), tetras._version, tetra_id._version, tetra_id.shape[0], n_vertices)
+    hit = _adjacency_cache.get(key)
+    if hit is None:
+        with torch.no_grad():
+            vid = tetras.long()[tetra_id.long()].reshape(-1)                    # (4P,) vertex of item 4*i + corner
+            order = torch.sort(vid, stable=True)[1]
+            counts = torch.bincount(vid, minlength=n_vertices)
+            start = torch.zeros(n_vertices + 1, dtype=torch.int64, device=vid.device)
+            start[1:] = torch.cumsum(counts, 0)
+            hit = (start.to(torch.int32).contiguous(), order.to(torch.int32).contiguous(), tetras, tetra_id)
+        if len(_adjacency_cache) > 64:
+            _adjacency_cache.clear()
+        _adjacency_cache[key] = hit          # holds tetras / tetra_id alive: their addresses cannot be recycled
+    return hit[0], hit[1]
 
 
 class _CageDeform(torch.autograd.Function):
@@ -53,10 +88,15 @@ class _CageDeform(torch.autograd.Function):
         g_b = torch.empty((P, 4), dtype=torch.float32, device=dev) if need[3] else None
         g_s = torch.empty((P, 3), dtype=torch.float32, device=dev) if need[5] else None
         g_r = torch.empty((P, 4), dtype=torch.float32, device=dev) if need[6] else None
+        vstart = vitems = corner = None
+        if need[0] and P > 0:
+            vstart, vitems = vertex_adjacency(tetras, tetra_id, V)
+            corner = torch.empty((P, 4, 3), dtype=torch.float32, device=dev)
         check(_lib.lib().d3ga_cage_deform_bwd(P, V, dptr(tetpoints), dptr(tetras), dptr(tetra_id), dptr(barys),
                                               dptr(canon_grad), dptr(scales), dptr(rotations), dptr(g_means),
                                               dptr(g_cov6), dptr(g_tp), dptr(g_b), dptr(g_s), dptr(g_r),
-                                              stream_handle()), "d3ga_cage_deform_bwd")
+                                              dptr(vstart), dptr(vitems), dptr(corner), stream_handle()),
+              "d3ga_cage_deform_bwd")
         return g_tp, None, None, g_b, None, g_s, g_r
 
 

@@ -76,6 +76,39 @@ static inline ImgBuf carve_img(void *base, int64_t W, int64_t H) {
     return i;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Block-cooperative tile window.  The Gaussians of one 256-thread block are spatially coherent (they are stored in
+// tet order), so the union of their tile rectangles is small.  Counting / slot reservation is done with LDS atomics
+// inside that bounding window and only ONE global atomic per (block, touched tile) leaves the CU, instead of one per
+// (Gaussian, tile) -- which serialises badly because neighbouring lanes hit the same few tile counters.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kWinTiles = 4096;   // LDS window capacity in tiles (16 KiB of u32); larger unions fall back to global atomics
+
+struct TileWindow {
+    int x0, y0, w, h;             // window origin and size in tiles; w*h == 0 -> nothing visible in the block
+    __device__ __forceinline__ int area() const { return w * h; }
+    __device__ __forceinline__ bool fits() const { return w * h <= kWinTiles; }
+};
+
+#ifdef __HIPCC__
+// s_box: 4 ints of LDS.  Every thread of the block must call this (contains barriers).
+__device__ __forceinline__ TileWindow block_tile_window(int *s_box, bool visible, int rx0, int ry0, int rx1, int ry1) {
+    if (threadIdx.x == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = 0; s_box[3] = 0; }
+    __syncthreads();
+    if (visible) {
+        atomicMin(&s_box[0], rx0); atomicMin(&s_box[1], ry0);
+        atomicMax(&s_box[2], rx1); atomicMax(&s_box[3], ry1);
+    }
+    __syncthreads();
+    TileWindow win;
+    win.x0 = s_box[0]; win.y0 = s_box[1];
+    win.w = s_box[2] > s_box[0] ? s_box[2] - s_box[0] : 0;
+    win.h = s_box[3] > s_box[1] ? s_box[3] - s_box[1] : 0;
+    if (win.w == 0 || win.h == 0) { win.w = 0; win.h = 0; }
+    return win;
+}
+#endif
+
 static inline int tiles_x(int W) { return (W + kTile - 1) / kTile; }
 static inline int tiles_y(int H) { return (H + kTile - 1) / kTile; }
 

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void cage_deform_bwd_kernel(
     const float *__restrict__ barys, const float *__restrict__ canon_grad, const float *__restrict__ scales,
     const float *__restrict__ rots, const float *__restrict__ g_means, const float *__restrict__ g_cov6,
     float *__restrict__ g_tetpoints, float *__restrict__ g_barys, float *__restrict__ g_scales,
-    float *__restrict__ g_rots) {
+    float *__restrict__ g_rots, float *__restrict__ corner_grads) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= P) return;
     DeformIn in;
@@ -135,10 +135,47 @@ __global__ __launch_bounds__(kBlock) void cage_deform_bwd_kernel(
         g_scales[3 * (size_t)i] = o.gs[0]; g_scales[3 * (size_t)i + 1] = o.gs[1]; g_scales[3 * (size_t)i + 2] = o.gs[2];
     }
     if (g_rots) reinterpret_cast<float4 *>(g_rots)[i] = make_float4(o.gq[0], o.gq[1], o.gq[2], o.gq[3]);
-    if (g_tetpoints) {
+    if (corner_grads) {            // deterministic path: per-corner gradients, summed per vertex by vertex_gather_kernel
+        float4 *c = reinterpret_cast<float4 *>(corner_grads + 12 * (size_t)i);
+        c[0] = make_float4(o.gx0.x, o.gx0.y, o.gx0.z, o.gx1.x);
+        c[1] = make_float4(o.gx1.y, o.gx1.z, o.gx2.x, o.gx2.y);
+        c[2] = make_float4(o.gx2.z, o.gx3.x, o.gx3.y, o.gx3.z);
+    } else if (g_tetpoints) {
         atomic_add3(g_tetpoints, vid.x, o.gx0); atomic_add3(g_tetpoints, vid.y, o.gx1);
         atomic_add3(g_tetpoints, vid.z, o.gx2); atomic_add3(g_tetpoints, vid.w, o.gx3);
     }
+}
+
+// 64-lane sum through DPP (see raster_composite.hip); result broadcast from lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_sum_(float v) {
+    v = dpp_add_<0xB1, 0xf>(v); v = dpp_add_<0x4E, 0xf>(v); v = dpp_add_<0x141, 0xf>(v); v = dpp_add_<0x140, 0xf>(v);
+    v = dpp_add_<0x142, 0xa>(v); v = dpp_add_<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// One wavefront per cage vertex: sums the corner gradients of every (Gaussian, corner) incident to the vertex.
+// vert_start (V+1) / vert_items (4P, item = 4*gaussian + corner) is the static CSR adjacency built once per cage.
+// No atomics, bit-reproducible.
+__global__ __launch_bounds__(kBlock) void vertex_gather_kernel(int V, const int32_t *__restrict__ vert_start,
+                                                               const int32_t *__restrict__ vert_items,
+                                                               const float *__restrict__ corner_grads,
+                                                               float *__restrict__ g_tetpoints) {
+    const int v = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (v >= V) return;                                       // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int b = vert_start[v], e = vert_start[v + 1];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int k = b + lane; k < e; k += 64) {
+        const float *c = corner_grads + 3 * (size_t)vert_items[k];
+        sx += c[0]; sy += c[1]; sz += c[2];
+    }
+    sx = wave_sum_(sx); sy = wave_sum_(sy); sz = wave_sum_(sz);
+    if (lane == 0) { g_tetpoints[3 * (size_t)v] = sx; g_tetpoints[3 * (size_t)v + 1] = sy; g_tetpoints[3 * (size_t)v + 2] = sz; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -216,16 +253,25 @@ extern "C" int d3ga_cage_deform_bwd(int P, int V, const float *tetpoints, const 
                                     const int32_t *tetra_id, const float *barys, const float *canon_grad,
                                     const float *scales, const float *rots, const float *g_means, const float *g_cov6,
                                     float *g_tetpoints, float *g_barys, float *g_scales, float *g_rots,
+                                    const int32_t *vert_start, const int32_t *vert_items, float *corner_grads,
                                     d3ga_stream_t stream) {
     if (P < 0 || V < 0) return D3GA_E_SIZE;
-    if (g_tetpoints && V > 0) D3GA_HIP(hipMemsetAsync(g_tetpoints, 0, sizeof(float) * 3 * (size_t)V, (hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    const bool csr = g_tetpoints && vert_start && vert_items && corner_grads;
+    if (g_tetpoints && V > 0 && (!csr || P == 0)) D3GA_HIP(hipMemsetAsync(g_tetpoints, 0, sizeof(float) * 3 * (size_t)V, s));
     if (P == 0) return D3GA_OK;
     if (!tetpoints || !tetras || !tetra_id || !barys || !canon_grad || !scales || !rots || !g_means || !g_cov6)
         return D3GA_E_NULL;
-    hipLaunchKernelGGL(cage_deform_bwd_kernel, dim3(nblocks(P)), dim3(kBlock), 0, (hipStream_t)stream, P, tetpoints,
-                       tetras, tetra_id, barys, canon_grad, scales, rots, g_means, g_cov6, g_tetpoints, g_barys,
-                       g_scales, g_rots);
-    return check_launch((hipStream_t)stream, 0);
+    hipLaunchKernelGGL(cage_deform_bwd_kernel, dim3(nblocks(P)), dim3(kBlock), 0, s, P, tetpoints, tetras, tetra_id,
+                       barys, canon_grad, scales, rots, g_means, g_cov6, g_tetpoints, g_barys, g_scales, g_rots,
+                       csr ? corner_grads : nullptr);
+    D3GA_TRY(check_launch(s, 0));
+    if (csr && V > 0) {
+        hipLaunchKernelGGL(vertex_gather_kernel, dim3((V + 3) / 4), dim3(kBlock), 0, s, V, vert_start, vert_items,
+                           corner_grads, g_tetpoints);
+        return check_launch(s, 0);
+    }
+    return D3GA_OK;
 }
 
 extern "C" int d3ga_fem_energy_fwd(int T, const float *tetpoints, const int32_t *tetras, const float *Dn_inv,

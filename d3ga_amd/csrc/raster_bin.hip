@@ -8,7 +8,8 @@
 // the result does not depend on the order in which the atomics of the scatter pass landed.
 //
 //   tile_scan_kernel      one workgroup: exclusive prefix of the tile histogram, D, overflow flag
-//   tile_scatter_kernel   one thread per Gaussian: emit its key into every tile of its rectangle
+//   tile_scatter_kernel   one thread per Gaussian: emit its key into every tile of its rectangle; slots are reserved
+//                         per (block, tile) through an LDS window (d3ga_internal.h: TileWindow)
 //   tile_sort_lds_kernel  one workgroup per tile: LDS bitonic sort (lists up to CAP entries)
 //   tile_sort_global_kernel  fallback for longer lists: same network on global memory
 #include "d3ga_internal.h"
@@ -61,17 +62,49 @@ __global__ __launch_bounds__(kBlock) void tile_scatter_kernel(int P, int gx, con
                                                               const float *__restrict__ depth,
                                                               uint32_t *__restrict__ cursor, uint64_t *__restrict__ keys,
                                                               uint64_t dcap) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= P) return;
-    const uint2 rc = rect[i];
-    const int x0 = rc.x & 0xffffu, y0 = rc.x >> 16, x1 = rc.y & 0xffffu, y1 = rc.y >> 16;
-    if (x1 <= x0 || y1 <= y0) return;
-    const uint64_t key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
-    for (int ty = y0; ty < y1; ++ty)
-        for (int tx = x0; tx < x1; ++tx) {
-            const uint32_t pos = atomicAdd(&cursor[ty * gx + tx], 1u);
-            if (pos < dcap) keys[pos] = key;
+    __shared__ int s_box[4];
+    __shared__ uint32_t s_cnt[kWinTiles];     // pass A: per-tile count of this block; pass C: running slot counter
+    __shared__ uint32_t s_base[kWinTiles];    // pass B: first slot reserved for this block in each tile's list
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kBlock + tid;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    uint64_t key = 0;
+    if (i < P) {
+        const uint2 rc = rect[i];
+        x0 = rc.x & 0xffffu; y0 = rc.x >> 16; x1 = rc.y & 0xffffu; y1 = rc.y >> 16;
+        key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
+    }
+    const bool visible = x1 > x0 && y1 > y0;
+    const TileWindow win = block_tile_window(s_box, visible, x0, y0, x1, y1);
+    const int area = win.area();
+    if (area == 0) return;                                   // uniform
+    if (win.fits()) {
+        for (int k = tid; k < area; k += kBlock) s_cnt[k] = 0;
+        __syncthreads();
+        if (visible)
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) atomicAdd(&s_cnt[(ty - win.y0) * win.w + (tx - win.x0)], 1u);
+        __syncthreads();
+        for (int k = tid; k < area; k += kBlock) {           // ONE global (returning) atomic per touched tile
+            const uint32_t c = s_cnt[k];
+            if (c) s_base[k] = atomicAdd(&cursor[(win.y0 + k / win.w) * gx + win.x0 + k % win.w], c);
+            s_cnt[k] = 0;
         }
+        __syncthreads();
+        if (visible)
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) {
+                    const int l = (ty - win.y0) * win.w + (tx - win.x0);
+                    const uint32_t pos = s_base[l] + atomicAdd(&s_cnt[l], 1u);
+                    if (pos < dcap) keys[pos] = key;
+                }
+    } else if (visible) {
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) {
+                const uint32_t pos = atomicAdd(&cursor[ty * gx + tx], 1u);
+                if (pos < dcap) keys[pos] = key;
+            }
+    }
 }
 
 // Bitonic network in its "flip / disperse" form: every compare-exchange moves the smaller key to the lower

@@ -8,10 +8,11 @@
 //
 // forward : front-to-back; a wavefront stops as soon as all 64 pixels are saturated (T < 1e-4), the workgroup
 //           stops loading when all four have.
-// backward: back-to-front starting at the deepest contributor of the tile; per-pixel partial derivatives are
-//           reduced across the wavefront with DPP row operations (no LDS traffic, no per-pixel atomics) and ONE
-//           lane issues the nine float atomics per (wavefront, Gaussian); wavefronts in which no pixel is touched
-//           by the Gaussian skip it after a single ballot.
+// backward: back-to-front starting at the deepest contributor of the tile; the nine per-pixel partial derivatives
+//           are reduced across the wavefront with interleaved DPP row operations (VALU only), the four wavefronts'
+//           totals meet in a per-entry LDS accumulator (ds_add_f32), and after each batch ONE thread per staged
+//           Gaussian issues the nine global float atomics -- 256x fewer than one per (pixel, Gaussian).  Wavefronts
+//           in which no pixel is touched by a Gaussian skip it after a single ballot.
 #include "d3ga_internal.h"
 
 namespace d3ga {
@@ -105,6 +106,27 @@ __global__ __launch_bounds__(kBlock) void composite_fwd_kernel(
     }
 }
 
+// Reduce NV values across the 64 lanes at once: the NV dependency chains are independent, so the scheduler
+// interleaves them and the DPP wait states of one chain are filled by the others.  Totals end up in every lane of
+// row 3 (lanes 48..63).
+template <int NV>
+__device__ __forceinline__ void wave_sum_multi(float (&v)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = dpp_add<0xB1, 0xf>(v[k]);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = dpp_add<0x4E, 0xf>(v[k]);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = dpp_add<0x141, 0xf>(v[k]);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = dpp_add<0x140, 0xf>(v[k]);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = dpp_add<0x142, 0xa>(v[k]);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = dpp_add<0x143, 0xc>(v[k]);
+}
+
+constexpr int kNG = 9;   // partial derivatives per (pixel, Gaussian): mean2D x,y | conic a,b/2,c | opacity | r,g,b
+
 __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
     int W, int H, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list, uint64_t dcap,
     const float2 *__restrict__ xy, const float4 *__restrict__ conic_o, const float4 *__restrict__ rgb_invd,
@@ -114,6 +136,7 @@ __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
     __shared__ float4 s_co[kBlock];
     __shared__ float4 s_rgb[kBlock];
     __shared__ uint32_t s_id[kBlock];
+    __shared__ float s_acc[kBlock * kNG];     // per staged entry: the tile's 9 partial sums (stride 9: conflict-free)
     __shared__ uint32_t s_maxlast;
     const int tid = threadIdx.x;
     const int tile = blockIdx.y * gridDim.x + blockIdx.x;
@@ -145,6 +168,7 @@ __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     const int lane = tid & 63;
+    const int slot = lane - 48;                            // lanes 48..56 publish value `slot` of the wave's totals
 
     // positions hi, hi-1, ... (1-based) in batches of 256, thread t stages position hi - t
     for (uint32_t hi = maxlast; hi > 0; hi = hi > kBlock ? hi - kBlock : 0) {
@@ -156,6 +180,8 @@ __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
             s_co[tid] = conic_o[g];
             s_rgb[tid] = rgb_invd[g];
         }
+#pragma unroll
+        for (int k = 0; k < kNG; ++k) s_acc[tid * kNG + k] = 0.f;
         __syncthreads();
         const int cnt = (int)min((uint32_t)kBlock, hi);
         for (int j = 0; j < cnt; ++j) {
@@ -166,7 +192,9 @@ __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
             float alpha = 0.f, G = 0.f;
             const bool hit = inside && pos <= last && splat_alpha(dx, dy, co.x, co.y, co.z, co.w, alpha, G);
             if (!__any(hit)) continue;                     // wave-uniform skip
-            float v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f, v_r = 0.f, v_g = 0.f, v_b = 0.f;
+            float v[kNG];
+#pragma unroll
+            for (int k = 0; k < kNG; ++k) v[k] = 0.f;
             if (hit) {
                 const float4 col = s_rgb[j];
                 T = T / (1.0f - alpha);
@@ -180,24 +208,34 @@ __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
                 dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
                 const float dL_dG = co.w * dL_dalpha;      // the 0.99 clamp passes the gradient through
                 const float gdx = G * dx, gdy = G * dy;
-                v_mx = dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;
-                v_my = dL_dG * (-gdy * co.z - gdx * co.y) * ddely_dy;
-                v_ca = -0.5f * gdx * dx * dL_dG;
-                v_cb = -0.5f * gdx * dy * dL_dG;            // half of dL/dB, doubled in the per-Gaussian backward
-                v_cc = -0.5f * gdy * dy * dL_dG;
-                v_op = G * dL_dalpha;
-                v_r = dch * g0; v_g = dch * g1; v_b = dch * g2;
+                v[0] = dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;
+                v[1] = dL_dG * (-gdy * co.z - gdx * co.y) * ddely_dy;
+                v[2] = -0.5f * gdx * dx * dL_dG;
+                v[3] = -0.5f * gdx * dy * dL_dG;            // half of dL/dB, doubled in the per-Gaussian backward
+                v[4] = -0.5f * gdy * dy * dL_dG;
+                v[5] = G * dL_dalpha;
+                v[6] = dch * g0; v[7] = dch * g1; v[8] = dch * g2;
             }
-            v_mx = wave_sum(v_mx); v_my = wave_sum(v_my);
-            v_ca = wave_sum(v_ca); v_cb = wave_sum(v_cb); v_cc = wave_sum(v_cc);
-            v_op = wave_sum(v_op);
-            v_r = wave_sum(v_r); v_g = wave_sum(v_g); v_b = wave_sum(v_b);
-            if (lane == 0) {
-                float *o = acc + 12 * (size_t)s_id[j];
-                atomicAdd(o + 0, v_mx); atomicAdd(o + 1, v_my);
-                atomicAdd(o + 3, v_ca); atomicAdd(o + 4, v_cb); atomicAdd(o + 5, v_cc);
-                atomicAdd(o + 6, v_op);
-                atomicAdd(o + 7, v_r); atomicAdd(o + 8, v_g); atomicAdd(o + 9, v_b);
+            wave_sum_multi<kNG>(v);
+            // lanes 48..56 each add one of the nine totals into the entry's LDS accumulator (ds_add_f32)
+            float mine = v[0];
+#pragma unroll
+            for (int k = 1; k < kNG; ++k) mine = (slot == k) ? v[k] : mine;
+            if (slot >= 0 && slot < kNG) atomicAdd(&s_acc[j * kNG + slot], mine);
+        }
+        __syncthreads();
+        // flush: one thread per staged entry, nine global atomics per (tile, Gaussian) that any pixel touched
+        if (tid < cnt) {
+            float r[kNG];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < kNG; ++k) { r[k] = s_acc[tid * kNG + k]; any |= (r[k] != 0.f); }
+            if (any) {
+                float *o = acc + 12 * (size_t)s_id[tid];
+                atomicAdd(o + 0, r[0]); atomicAdd(o + 1, r[1]);
+                atomicAdd(o + 3, r[2]); atomicAdd(o + 4, r[3]); atomicAdd(o + 5, r[4]);
+                atomicAdd(o + 6, r[5]);
+                atomicAdd(o + 7, r[6]); atomicAdd(o + 8, r[7]); atomicAdd(o + 9, r[8]);
             }
         }
     }

@@ -17,29 +17,53 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, const float *__restrict__ viewmatrix,
     const float *__restrict__ projmatrix, const float *__restrict__ campos, GeomBuf geom,
     uint32_t *__restrict__ tile_count, uint32_t *__restrict__ counters, int32_t *__restrict__ radii) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= prm.P) return;
-    const PreOut o = preprocess_one(prm, i, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                    viewmatrix, projmatrix, campos);
-    const Splat &sp = o.sp;
+    __shared__ int s_box[4];
+    __shared__ uint32_t s_cnt[kWinTiles];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kBlock + tid;
+    bool visible = false;
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    if (i < prm.P) {
+        const PreOut o = preprocess_one(prm, i, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                        cov3D_precomp, viewmatrix, projmatrix, campos);
+        const Splat &sp = o.sp;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) geom.cov3D[6 * (size_t)i + k] = o.c6[k];
-    radii[i] = sp.radius;
-    geom.depth[i] = sp.depth;
-    geom.xy[i] = make_float2(sp.px, sp.py);
-    // culled Gaussians keep an EMPTY rectangle: the scatter pass and the backward test visibility through it
-    geom.rect[i] = sp.visible ? make_uint2((uint32_t)sp.rect[0] | ((uint32_t)sp.rect[1] << 16),
-                                           (uint32_t)sp.rect[2] | ((uint32_t)sp.rect[3] << 16))
-                              : make_uint2(0u, 0u);
-    geom.conic_o[i] = make_float4(sp.conic[0], sp.conic[1], sp.conic[2], o.opacity);
-    geom.rgb_invd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], sp.visible ? 1.0f / sp.depth : 0.f);
-    geom.clamped[i] = o.clampmask;
-    if (!sp.visible) return;
-    // tile histogram (counting-sort pass 1); the scatter pass walks the same rectangle
+        for (int k = 0; k < 6; ++k) geom.cov3D[6 * (size_t)i + k] = o.c6[k];
+        radii[i] = sp.radius;
+        geom.depth[i] = sp.depth;
+        geom.xy[i] = make_float2(sp.px, sp.py);
+        // culled Gaussians keep an EMPTY rectangle: the scatter pass and the backward test visibility through it
+        geom.rect[i] = sp.visible ? make_uint2((uint32_t)sp.rect[0] | ((uint32_t)sp.rect[1] << 16),
+                                               (uint32_t)sp.rect[2] | ((uint32_t)sp.rect[3] << 16))
+                                  : make_uint2(0u, 0u);
+        geom.conic_o[i] = make_float4(sp.conic[0], sp.conic[1], sp.conic[2], o.opacity);
+        geom.rgb_invd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], sp.visible ? 1.0f / sp.depth : 0.f);
+        geom.clamped[i] = o.clampmask;
+        visible = sp.visible;
+        r0 = sp.rect[0]; r1 = sp.rect[1]; r2 = sp.rect[2]; r3 = sp.rect[3];
+    }
+    // ---- tile histogram (counting-sort pass 1) through the block's LDS window ----
     const int gx = (prm.W + kTile - 1) / kTile;
-    for (int ty = sp.rect[1]; ty < sp.rect[3]; ++ty)
-        for (int tx = sp.rect[0]; tx < sp.rect[2]; ++tx) atomicAdd(&tile_count[ty * gx + tx], 1u);
-    atomicAdd(&counters[D3GA_CNT_VISIBLE], 1u);
+    const TileWindow win = block_tile_window(s_box, visible, r0, r1, r2, r3);
+    const int nvis = __syncthreads_count(visible);
+    if (tid == 0 && nvis) atomicAdd(&counters[D3GA_CNT_VISIBLE], (uint32_t)nvis);
+    const int area = win.area();
+    if (area == 0) return;                                   // uniform
+    if (win.fits()) {
+        for (int k = tid; k < area; k += kBlock) s_cnt[k] = 0;
+        __syncthreads();
+        if (visible)
+            for (int ty = r1; ty < r3; ++ty)
+                for (int tx = r0; tx < r2; ++tx) atomicAdd(&s_cnt[(ty - win.y0) * win.w + (tx - win.x0)], 1u);
+        __syncthreads();
+        for (int k = tid; k < area; k += kBlock) {
+            const uint32_t c = s_cnt[k];
+            if (c) atomicAdd(&tile_count[(win.y0 + k / win.w) * gx + win.x0 + k % win.w], c);
+        }
+    } else if (visible) {                                    // huge footprints: straight to global memory
+        for (int ty = r1; ty < r3; ++ty)
+            for (int tx = r0; tx < r2; ++tx) atomicAdd(&tile_count[ty * gx + tx], 1u);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(

@@ -56,8 +56,12 @@ int d3ga_lbs_cage_bwd(int V, int K, const float *joint_mats, const int32_t *skin
  *   tetpoints (V,3) posed cage vertices; tetras (T,4) int32; tetra_id (P) int32; barys (P,4) (= barys+delta_bary);
  *   canon_grad (P,3,3) = inv(Dm) (lib/cage.py:329); scales (P,3) activated; rots (P,4) wxyz (normalised inside)
  *   -> means3D (P,3), cov6 (P,6) in order xx,xy,xz,yy,yz,zz.
- * bwd: g_means (P,3), g_cov6 (P,6) -> g_tetpoints (V,3) [zeroed by the call, then accumulated],
- *      g_barys (P,4), g_scales (P,3), g_rots (P,4).  Any of the four outputs may be NULL (skipped).
+ * bwd: g_means (P,3), g_cov6 (P,6) -> g_tetpoints (V,3), g_barys (P,4), g_scales (P,3), g_rots (P,4).  Any of the
+ *      four outputs may be NULL (skipped).  The vertex gradient is a scatter-add over 4 corners x P Gaussians:
+ *      - with the static adjacency of the cage given -- vert_start (V+1) int32, vert_items (4P) int32 listing, per
+ *        vertex, the items 4*gaussian+corner incident to it, plus corner_grads (P,4,3) float scratch -- it is
+ *        computed WITHOUT atomics (one wavefront per vertex gathers and sums; deterministic);
+ *      - with those three NULL it falls back to float atomics into g_tetpoints (zeroed by the call).
  * ------------------------------------------------------------------------------------------------------- */
 int d3ga_cage_deform_fwd(int P, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
                          const float *barys, const float *canon_grad, const float *scales, const float *rots,
@@ -65,7 +69,8 @@ int d3ga_cage_deform_fwd(int P, const float *tetpoints, const int32_t *tetras, c
 int d3ga_cage_deform_bwd(int P, int V, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
                          const float *barys, const float *canon_grad, const float *scales, const float *rots,
                          const float *g_means, const float *g_cov6, float *g_tetpoints, float *g_barys,
-                         float *g_scales, float *g_rots, d3ga_stream_t stream);
+                         float *g_scales, float *g_rots, const int32_t *vert_start, const int32_t *vert_items,
+                         float *corner_grads, d3ga_stream_t stream);
 
 /* D6  FEM regulariser (lib/cage.py:349-361): per-tet energy 0.5(det F-1)^2 + 0.5(|F|_F^2-3), F = Ds Dn^-1.
  *   fwd: energy (T).  bwd: g_energy (T) -> g_tetpoints (V,3) [zeroed by the call]. */
