@@ -151,10 +151,10 @@ def main():
     from d3ga_amd import rasterizer as R
 
     frame = Frame(args.workload, dev, view_index=rank % 8)
-    flat = ddist.FlatGrads(list(frame.params.values()))
+    flat = ddist.GradReducer(list(frame.params.values()))
 
     def one_step():
-        flat.zero_()
+        flat.zero()
         frame.step()
         flat.all_reduce_mean()
 

@@ -1,28 +1,34 @@
 // raster_composite.hip -- alpha compositing forward / backward for gfx950.
 //
-// One 256-thread workgroup per 16x16 tile = four 64-lane wavefronts, each owning an 8x8 pixel quadrant (a compact
-// footprint keeps the per-wavefront early-outs effective: a quadrant saturates, or falls outside a splat, sooner
-// than a 16x4 strip does).  The tile's depth-ordered list is staged through LDS 256 entries at a time: every
-// duplicate's 36 B record (xy, conic+opacity, rgb, 1/depth) is fetched from HBM/L2 once per tile with one
-// gathered load per lane and then broadcast-read from LDS by all lanes (same address => conflict-free).
+// Wavefront-autonomous design.  The unit of work is ONE 64-lane wavefront = one 8x8-pixel quadrant of a 16x16 tile
+// (workgroup = one wavefront: no LDS, no barriers, independent early-out, 4x finer load balancing than a workgroup
+// per tile).  A wavefront walks its tile's depth-ordered list 64 entries at a time:
+//   1. every lane gathers ONE entry's record (xy, conic+opacity, rgb+1/depth: three 8/16-byte loads) and tests it
+//      against the quadrant with a conservative bounding box of the alpha >= 1/255 ellipse -> one 64-bit ballot;
+//   2. the wavefront iterates over the set bits only; the entry's record is broadcast from its lane into SGPRs with
+//      v_readlane (scalar operands are free for the per-pixel VALU math: no LDS round trip in the dependency chain);
+//   3. forward: front-to-back blend, stop when all 64 pixels are saturated (T < 1e-4);
+//      backward: back-to-front from the quadrant's deepest contributor; the nine per-pixel partial derivatives are
+//      reduced across the wavefront with interleaved DPP row operations (VALU only) and lanes 48..56 issue ONE
+//      global_atomic_add_f32 instruction per (wavefront, Gaussian) -- 64x fewer atomics than one per pixel.
+// Culled entries provably contribute nothing (alpha < 1/255 on every pixel of the quadrant), so the result is
+// identical to walking the full tile list; list positions (n_contrib) are kept as positions in the FULL list.
 //
-// forward : front-to-back; a wavefront stops as soon as all 64 pixels are saturated (T < 1e-4), the workgroup
-//           stops loading when all four have.
-// backward: back-to-front starting at the deepest contributor of the tile; the nine per-pixel partial derivatives
-//           are reduced across the wavefront with interleaved DPP row operations (VALU only), the four wavefronts'
-//           totals meet in a per-entry LDS accumulator (ds_add_f32), and after each batch ONE thread per staged
-//           Gaussian issues the nine global float atomics -- 256x fewer than one per (pixel, Gaussian).  Wavefronts
-//           in which no pixel is touched by a Gaussian skip it after a single ballot.
+// Work -> XCD mapping: the dispatcher places block b on XCD b % 8 (observed, speed only).  Tile ROW r is processed
+// by XCD r % 8, so the four quadrants of a tile and its horizontal neighbours -- which share most of their
+// Gaussians -- gather their records through the same 4 MiB L2, while the image's heavy rows stay interleaved
+// across XCDs for balance.
 #include "d3ga_internal.h"
 
 namespace d3ga {
 
-// ---- wavefront (64 lanes) sum through DPP; result valid in lane 63, returned broadcast ----
+// ---- wavefront (64 lanes) reductions through DPP ----
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v) {
     const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
     return v + __int_as_float(t);
 }
+// single value; total broadcast to all lanes
 __device__ __forceinline__ float wave_sum(float v) {
     v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
     v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
@@ -32,83 +38,8 @@ __device__ __forceinline__ float wave_sum(float v) {
     v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> row 3 holds the total
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-
-__device__ __forceinline__ void pixel_of_thread(int tid, int &lx, int &ly) {
-    const int wave = tid >> 6, lane = tid & 63;
-    lx = ((wave & 1) << 3) | (lane & 7);
-    ly = ((wave >> 1) << 3) | (lane >> 3);
-}
-
-__global__ __launch_bounds__(kBlock) void composite_fwd_kernel(
-    int W, int H, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list, uint64_t dcap,
-    const float2 *__restrict__ xy, const float4 *__restrict__ conic_o, const float4 *__restrict__ rgb_invd,
-    const float *__restrict__ bg, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-    float *__restrict__ out_color, float *__restrict__ out_invdepth) {
-    __shared__ float2 s_xy[kBlock];
-    __shared__ float4 s_co[kBlock];
-    __shared__ float4 s_rgb[kBlock];
-    const int tid = threadIdx.x;
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-    int lx, ly;
-    pixel_of_thread(tid, lx, ly);
-    const int px = blockIdx.x * kTile + lx, py = blockIdx.y * kTile + ly;
-    const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
-    const uint32_t begin = (uint32_t)min((uint64_t)tile_start[tile], dcap);
-    const uint32_t end = (uint32_t)min((uint64_t)tile_start[tile + 1], dcap);
-
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    uint32_t contributor = 0, last = 0;
-    bool done = !inside;
-
-    for (uint32_t base = begin; base < end; base += kBlock) {
-        if (__syncthreads_and(done)) break;
-        if (base + tid < end) {
-            const uint32_t g = point_list[base + tid];
-            s_xy[tid] = xy[g];
-            s_co[tid] = conic_o[g];
-            s_rgb[tid] = rgb_invd[g];
-        }
-        __syncthreads();
-        const int cnt = (int)min((uint32_t)kBlock, end - base);
-        for (int j = 0; j < cnt; ++j) {
-            if (__all(done)) break;                       // wave-uniform
-            if (!done) {
-                ++contributor;
-                const float2 c = s_xy[j];
-                const float4 co = s_co[j];
-                float alpha, G;
-                if (splat_alpha(c.x - fx, c.y - fy, co.x, co.y, co.z, co.w, alpha, G)) {
-                    const float test_T = T * (1.0f - alpha);
-                    if (test_T < kTmin) {
-                        done = true;
-                    } else {
-                        const float4 col = s_rgb[j];
-                        const float w = alpha * T;
-                        C0 += col.x * w; C1 += col.y * w; C2 += col.z * w; Dp += col.w * w;
-                        T = test_T;
-                        last = contributor;
-                    }
-                }
-            }
-        }
-        // lanes that left the inner loop early (wave done) need no fix-up: they never look at contributor again
-    }
-    if (inside) {
-        const size_t pid = (size_t)py * W + px;
-        const size_t hw = (size_t)H * W;
-        final_T[pid] = T;
-        n_contrib[pid] = last;
-        out_color[pid] = C0 + T * bg[0];
-        out_color[hw + pid] = C1 + T * bg[1];
-        out_color[2 * hw + pid] = C2 + T * bg[2];
-        if (out_invdepth) out_invdepth[pid] = Dp;
-    }
-}
-
-// Reduce NV values across the 64 lanes at once: the NV dependency chains are independent, so the scheduler
-// interleaves them and the DPP wait states of one chain are filled by the others.  Totals end up in every lane of
-// row 3 (lanes 48..63).
+// NV values at once: the chains are independent, so the scheduler interleaves them and the DPP wait states of one
+// chain are filled by the others.  Totals end up in every lane of row 3 (lanes 48..63).
 template <int NV>
 __device__ __forceinline__ void wave_sum_multi(float (&v)[NV]) {
 #pragma unroll
@@ -124,92 +55,202 @@ __device__ __forceinline__ void wave_sum_multi(float (&v)[NV]) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = dpp_add<0x143, 0xc>(v[k]);
 }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+    return v;
+}
+__device__ __forceinline__ float bcast(float v, int lane) {   // lane is wave-uniform
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// ---- work item -> (tile, quadrant) with tile rows interleaved over the 8 XCDs ----
+struct Quad {
+    bool valid;
+    int tile, px, py;            // tile index, this lane's pixel
+    int qx0, qy0;                // quadrant origin in pixels
+};
+__device__ __forceinline__ Quad quad_of_block(int gx, int gy) {
+    Quad q;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int per_row = gx * 4;
+    const int k = slot / per_row, rem = slot - k * per_row;
+    const int ty = xcd + 8 * k, tx = rem >> 2, quad = rem & 3;
+    q.valid = ty < gy;
+    q.tile = ty * gx + tx;
+    q.qx0 = tx * kTile + ((quad & 1) << 3);
+    q.qy0 = ty * kTile + ((quad >> 1) << 3);
+    const int lane = threadIdx.x & 63;
+    q.px = q.qx0 + (lane & 7);
+    q.py = q.qy0 + (lane >> 3);
+    return q;
+}
+static inline int quad_grid(int gx, int gy) { return 8 * ((gy + 7) / 8) * gx * 4; }
+
+// Conservative test: can the Gaussian reach alpha >= 1/255 on any pixel of the quadrant [x0,x0+7]x[y0,y0+7]?
+// alpha = o*exp(-q/2) >= 1/255  <=>  q = A dx^2 + 2B dx dy + C dy^2 <= 2 ln(255 o) =: tau.  The ellipse q <= tau has the
+// axis-aligned half extents sqrt(tau*C/det), sqrt(tau*A/det); they are inflated by 0.1 % + 0.02 px against rounding.
+// Comparisons are written so that NaNs answer "relevant".
+__device__ __forceinline__ bool quad_relevant(float cx, float cy, float A, float B, float C, float o, float x0, float y0) {
+    if (o * 255.0f < 1.0f) return false;                  // o*G <= o < 1/255 for every G <= 1
+    const float tau = 2.0f * __logf(255.0f * o) * 1.001f + 1e-4f;
+    const float idet = 1.0f / (A * C - B * B);
+    const float hx = sqrtf(tau * C * idet) * 1.001f + 0.02f;
+    const float hy = sqrtf(tau * A * idet) * 1.001f + 0.02f;
+    return !(cx + hx < x0) && !(cx - hx > x0 + 7.0f) && !(cy + hy < y0) && !(cy - hy > y0 + 7.0f);
+}
+
+__global__ __launch_bounds__(64) void composite_fwd_kernel(
+    int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+    uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
+    const float4 *__restrict__ rgb_invd, const float *__restrict__ bg, float *__restrict__ final_T,
+    uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_invdepth) {
+    const Quad q = quad_of_block(gx, gy);
+    if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const bool inside = q.px < W && q.py < H;
+    const float fx = (float)q.px, fy = (float)q.py, x0 = (float)q.qx0, y0 = (float)q.qy0;
+    const uint32_t begin = (uint32_t)min((uint64_t)tile_start[q.tile], dcap);
+    const uint32_t end = (uint32_t)min((uint64_t)tile_start[q.tile + 1], dcap);
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    // software pipeline: the next batch's records are in flight while the current batch is blended
+    float2 nxy = make_float2(0.f, 0.f);
+    float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (begin + lane < end) {
+        const uint32_t g = point_list[begin + lane];
+        nxy = xy[g]; nco = conic_o[g]; nrgb = rgb_invd[g];
+    }
+    for (uint32_t base = begin; base < end; base += 64) {
+        const float2 cxy = nxy;
+        const float4 cco = nco, crgb = nrgb;
+        const bool have = base + lane < end;
+        const uint32_t nb = base + 64;
+        if (nb + lane < end) {
+            const uint32_t g = point_list[nb + lane];
+            nxy = xy[g]; nco = conic_o[g]; nrgb = rgb_invd[g];
+        }
+        unsigned long long mask = __ballot(have && quad_relevant(cxy.x, cxy.y, cco.x, cco.y, cco.z, cco.w, x0, y0));
+        while (mask) {
+            const int j = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const float ex = bcast(cxy.x, j), ey = bcast(cxy.y, j);
+            const float ea = bcast(cco.x, j), eb = bcast(cco.y, j), ec = bcast(cco.z, j), eo = bcast(cco.w, j);
+            float alpha, G;
+            const bool hit = !done && splat_alpha(ex - fx, ey - fy, ea, eb, ec, eo, alpha, G);
+            if (__any(hit)) {
+                const float r = bcast(crgb.x, j), g = bcast(crgb.y, j), b = bcast(crgb.z, j), d = bcast(crgb.w, j);
+                if (hit) {
+                    const float test_T = T * (1.0f - alpha);
+                    if (test_T < kTmin) {
+                        done = true;
+                    } else {
+                        const float w = alpha * T;
+                        C0 += r * w; C1 += g * w; C2 += b * w; Dp += d * w;
+                        T = test_T;
+                        last = base - begin + (uint32_t)j + 1u;   // 1-based position in the FULL tile list
+                    }
+                }
+                if (__all(done)) { mask = 0; base = end; }       // whole quadrant saturated
+            }
+        }
+    }
+    if (inside) {
+        const size_t pid = (size_t)q.py * W + q.px;
+        const size_t hw = (size_t)H * W;
+        final_T[pid] = T;
+        n_contrib[pid] = last;
+        out_color[pid] = C0 + T * bg[0];
+        out_color[hw + pid] = C1 + T * bg[1];
+        out_color[2 * hw + pid] = C2 + T * bg[2];
+        if (out_invdepth) out_invdepth[pid] = Dp;
+    }
+}
 
 constexpr int kNG = 9;   // partial derivatives per (pixel, Gaussian): mean2D x,y | conic a,b/2,c | opacity | r,g,b
 
-__global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
-    int W, int H, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list, uint64_t dcap,
-    const float2 *__restrict__ xy, const float4 *__restrict__ conic_o, const float4 *__restrict__ rgb_invd,
-    const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-    const float *__restrict__ dL_dpix, float *__restrict__ acc) {
-    __shared__ float2 s_xy[kBlock];
-    __shared__ float4 s_co[kBlock];
-    __shared__ float4 s_rgb[kBlock];
-    __shared__ uint32_t s_id[kBlock];
-    __shared__ float s_acc[kBlock * kNG];     // per staged entry: the tile's 9 partial sums (stride 9: conflict-free)
-    __shared__ uint32_t s_maxlast;
-    const int tid = threadIdx.x;
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-    int lx, ly;
-    pixel_of_thread(tid, lx, ly);
-    const int px = blockIdx.x * kTile + lx, py = blockIdx.y * kTile + ly;
-    const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
-    const uint32_t begin = (uint32_t)min((uint64_t)tile_start[tile], dcap);
-    const uint32_t end = (uint32_t)min((uint64_t)tile_start[tile + 1], dcap);
+__global__ __launch_bounds__(64) void composite_bwd_kernel(
+    int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+    uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
+    const float4 *__restrict__ rgb_invd, const float *__restrict__ bg, const float *__restrict__ final_T,
+    const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix, float *__restrict__ acc) {
+    const Quad q = quad_of_block(gx, gy);
+    if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const bool inside = q.px < W && q.py < H;
+    const float fx = (float)q.px, fy = (float)q.py, x0 = (float)q.qx0, y0 = (float)q.qy0;
+    const uint32_t begin = (uint32_t)min((uint64_t)tile_start[q.tile], dcap);
+    const uint32_t end = (uint32_t)min((uint64_t)tile_start[q.tile + 1], dcap);
     if (begin >= end) return;                              // uniform: empty tile
 
-    const size_t pid = (size_t)py * W + px;
+    const size_t pid = (size_t)q.py * W + q.px;
     const size_t hw = (size_t)H * W;
     const float T_final = inside ? final_T[pid] : 0.f;
     const uint32_t last = inside ? n_contrib[pid] : 0u;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (inside) { g0 = dL_dpix[pid]; g1 = dL_dpix[hw + pid]; g2 = dL_dpix[2 * hw + pid]; }
     const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
-
-    if (tid == 0) s_maxlast = 0;
-    __syncthreads();
-    atomicMax(&s_maxlast, last);
-    __syncthreads();
-    const uint32_t maxlast = s_maxlast;                    // deepest 1-based list position any pixel used
+    const uint32_t maxlast = wave_max_u32(last);           // deepest 1-based list position any pixel of the quadrant used
+    if (maxlast == 0) return;
 
     float T = T_final;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;                    // colour accumulated behind the current splat
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-    const int lane = tid & 63;
     const int slot = lane - 48;                            // lanes 48..56 publish value `slot` of the wave's totals
+    const int slot_off = slot < 2 ? slot : slot + 1;       // acc layout: 0,1 | 3,4,5 | 6 | 7,8,9
 
-    // positions hi, hi-1, ... (1-based) in batches of 256, thread t stages position hi - t
-    for (uint32_t hi = maxlast; hi > 0; hi = hi > kBlock ? hi - kBlock : 0) {
-        __syncthreads();
-        if ((uint32_t)tid < hi) {
-            const uint32_t g = point_list[begin + (hi - 1 - tid)];
-            s_id[tid] = g;
-            s_xy[tid] = xy[g];
-            s_co[tid] = conic_o[g];
-            s_rgb[tid] = rgb_invd[g];
+    // positions hi, hi-1, ... (1-based); lane l holds position hi - l, so ascending lanes = back-to-front
+    float2 nxy = make_float2(0.f, 0.f);
+    float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t nid = 0;
+    if ((uint32_t)lane < maxlast) {
+        nid = point_list[begin + (maxlast - 1 - lane)];
+        nxy = xy[nid]; nco = conic_o[nid]; nrgb = rgb_invd[nid];
+    }
+    for (uint32_t hi = maxlast; hi > 0; hi = hi > 64 ? hi - 64 : 0) {
+        const float2 cxy = nxy;
+        const float4 cco = nco, crgb = nrgb;
+        const uint32_t cid = nid;
+        const bool have = (uint32_t)lane < hi;
+        if (hi > 64 && (uint32_t)lane < hi - 64) {
+            nid = point_list[begin + (hi - 64 - 1 - lane)];
+            nxy = xy[nid]; nco = conic_o[nid]; nrgb = rgb_invd[nid];
         }
-#pragma unroll
-        for (int k = 0; k < kNG; ++k) s_acc[tid * kNG + k] = 0.f;
-        __syncthreads();
-        const int cnt = (int)min((uint32_t)kBlock, hi);
-        for (int j = 0; j < cnt; ++j) {
-            const uint32_t pos = hi - j;                   // 1-based position of this entry
-            const float2 c = s_xy[j];
-            const float4 co = s_co[j];
-            const float dx = c.x - fx, dy = c.y - fy;
+        unsigned long long mask = __ballot(have && quad_relevant(cxy.x, cxy.y, cco.x, cco.y, cco.z, cco.w, x0, y0));
+        while (mask) {
+            const int j = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const uint32_t pos = hi - (uint32_t)j;
+            const float ex = bcast(cxy.x, j), ey = bcast(cxy.y, j);
+            const float ea = bcast(cco.x, j), eb = bcast(cco.y, j), ec = bcast(cco.z, j), eo = bcast(cco.w, j);
+            const float dx = ex - fx, dy = ey - fy;
             float alpha = 0.f, G = 0.f;
-            const bool hit = inside && pos <= last && splat_alpha(dx, dy, co.x, co.y, co.z, co.w, alpha, G);
+            const bool hit = inside && pos <= last && splat_alpha(dx, dy, ea, eb, ec, eo, alpha, G);
             if (!__any(hit)) continue;                     // wave-uniform skip
+            const float cr = bcast(crgb.x, j), cg = bcast(crgb.y, j), cb = bcast(crgb.z, j);
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)cid, j);
             float v[kNG];
 #pragma unroll
             for (int k = 0; k < kNG; ++k) v[k] = 0.f;
             if (hit) {
-                const float4 col = s_rgb[j];
                 T = T / (1.0f - alpha);
                 const float dch = alpha * T;
                 a0 = last_alpha * lc0 + (1.f - last_alpha) * a0;
                 a1 = last_alpha * lc1 + (1.f - last_alpha) * a1;
                 a2 = last_alpha * lc2 + (1.f - last_alpha) * a2;
-                lc0 = col.x; lc1 = col.y; lc2 = col.z;
-                float dL_dalpha = ((col.x - a0) * g0 + (col.y - a1) * g1 + (col.z - a2) * g2) * T;
+                lc0 = cr; lc1 = cg; lc2 = cb;
+                float dL_dalpha = ((cr - a0) * g0 + (cg - a1) * g1 + (cb - a2) * g2) * T;
                 last_alpha = alpha;
                 dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                const float dL_dG = co.w * dL_dalpha;      // the 0.99 clamp passes the gradient through
+                const float dL_dG = eo * dL_dalpha;        // the 0.99 clamp passes the gradient through
                 const float gdx = G * dx, gdy = G * dy;
-                v[0] = dL_dG * (-gdx * co.x - gdy * co.y) * ddelx_dx;
-                v[1] = dL_dG * (-gdy * co.z - gdx * co.y) * ddely_dy;
+                v[0] = dL_dG * (-gdx * ea - gdy * eb) * ddelx_dx;
+                v[1] = dL_dG * (-gdy * ec - gdx * eb) * ddely_dy;
                 v[2] = -0.5f * gdx * dx * dL_dG;
                 v[3] = -0.5f * gdx * dy * dL_dG;            // half of dL/dB, doubled in the per-Gaussian backward
                 v[4] = -0.5f * gdy * dy * dL_dG;
@@ -217,34 +258,24 @@ __global__ __launch_bounds__(kBlock) void composite_bwd_kernel(
                 v[6] = dch * g0; v[7] = dch * g1; v[8] = dch * g2;
             }
             wave_sum_multi<kNG>(v);
-            // lanes 48..56 each add one of the nine totals into the entry's LDS accumulator (ds_add_f32)
             float mine = v[0];
 #pragma unroll
             for (int k = 1; k < kNG; ++k) mine = (slot == k) ? v[k] : mine;
-            if (slot >= 0 && slot < kNG) atomicAdd(&s_acc[j * kNG + slot], mine);
-        }
-        __syncthreads();
-        // flush: one thread per staged entry, nine global atomics per (tile, Gaussian) that any pixel touched
-        if (tid < cnt) {
-            float r[kNG];
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < kNG; ++k) { r[k] = s_acc[tid * kNG + k]; any |= (r[k] != 0.f); }
-            if (any) {
-                float *o = acc + 12 * (size_t)s_id[tid];
-                atomicAdd(o + 0, r[0]); atomicAdd(o + 1, r[1]);
-                atomicAdd(o + 3, r[2]); atomicAdd(o + 4, r[3]); atomicAdd(o + 5, r[4]);
-                atomicAdd(o + 6, r[5]);
-                atomicAdd(o + 7, r[6]); atomicAdd(o + 8, r[7]); atomicAdd(o + 9, r[8]);
-            }
+            if (slot >= 0 && slot < kNG) atomicAdd(acc + 12 * (size_t)gid + slot_off, mine);   // one instruction, 9 lanes
         }
     }
 }
 
-// self-test kernel for wave_sum (tests/): out[w] = sum over the wave's 64 inputs
+// self-test kernel for the DPP reductions (tests/): out[w] = sum over the wave's 64 inputs, or -1e30 when the
+// single-value and the multi-value forms disagree
 __global__ void wave_sum_selftest_kernel(const float *__restrict__ in, float *__restrict__ out) {
-    const float s = wave_sum(in[blockIdx.x * blockDim.x + threadIdx.x]);
-    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s;
+    const float x = in[blockIdx.x * blockDim.x + threadIdx.x];
+    float v[2] = {x, 2.0f * x};
+    wave_sum_multi<2>(v);
+    const float s = wave_sum(x);
+    const float m0 = bcast(v[0], 50), m1 = bcast(v[1], 63);
+    if ((threadIdx.x & 63) == 0)
+        out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = (m0 == s && m1 == 2.0f * s) ? s : -1e30f;
 }
 
 }  // namespace d3ga
@@ -261,9 +292,9 @@ extern "C" int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const fl
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
     const ImgBuf im = carve_img(img, prm->W, prm->H);
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3(gx, gy), dim3(kBlock), 0, s, prm->W, prm->H, bin.tile_start,
-                       bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib,
-                       out_color, out_invdepth);
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
+                       bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T,
+                       im.n_contrib, out_color, out_invdepth);
     return check_launch(s, prm->debug);
 }
 
@@ -279,13 +310,13 @@ extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const fl
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
     const ImgBuf im = carve_img(const_cast<void *>(img), prm->W, prm->H);
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3(gx, gy), dim3(kBlock), 0, s, prm->W, prm->H, bin.tile_start,
-                       bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib,
-                       dL_dpix, acc);
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
+                       bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T,
+                       im.n_contrib, dL_dpix, acc);
     return check_launch(s, prm->debug);
 }
 
-// test hook (not part of the drop-in surface): n multiple of 64, in (n) -> out (n/64)
+// test hook (not part of the drop-in surface): n multiple of 256, in (n) -> out (n/64)
 extern "C" int d3ga_selftest_wave_sum(int n, const float *in, float *out, d3ga_stream_t stream) {
     if (n <= 0 || (n % 256) != 0) return D3GA_E_SIZE;
     if (!in || !out) return D3GA_E_NULL;

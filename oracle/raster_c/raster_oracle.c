@@ -307,7 +307,10 @@ ro_ctx *ro_forward(int P, int M, int deg, int W, int H, const float *means3D, co
     return c;
 }
 
-static void atomic_addf(float *p, float v) {
+/* Per-Gaussian sums over pixels are accumulated in DOUBLE: the terms are the float32 values a tile splatter
+ * produces, but their sum is then independent of the summation order (the GPU sums them in a different order, and
+ * a float32 running sum over 10^3..10^4 signed terms carries ~1e-3 relative noise of its own). */
+static void atomic_addd(double *p, double v) {
 #pragma omp atomic
     *p += v;
 }
@@ -317,8 +320,10 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
                  const float *dL_dpix, float *dL_dmeans3D, float *dL_dmeans2D /*P,3*/, float *dL_dsh,
                  float *dL_dcolors, float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D) {
     int P = c->P, W = c->W, H = c->H, tiles = c->gx * c->gy;
-    float *dL_dconic = (float *)calloc((size_t)(P > 0 ? P : 1), 16);
-    float *dL_drgb = (float *)calloc((size_t)(P > 0 ? P : 1), 12);
+    double *dL_dconic = (double *)calloc((size_t)(P > 0 ? P : 1), 32);
+    double *dL_drgb = (double *)calloc((size_t)(P > 0 ? P : 1), 24);
+    double *dL_dm2 = (double *)calloc((size_t)(P > 0 ? P : 1), 16);
+    double *dL_dop = (double *)calloc((size_t)(P > 0 ? P : 1), 8);
     float *dL_dcov = dL_dcov3D ? dL_dcov3D : (float *)calloc((size_t)(P > 0 ? P : 1), 24);
 
 #pragma omp parallel for schedule(dynamic, 4)
@@ -351,7 +356,7 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
                         accum[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum[ch];
                         last_color[ch] = col;
                         dL_dalpha += (col - accum[ch]) * dLp[ch];
-                        atomic_addf(&dL_drgb[3 * g + ch], dch * dLp[ch]);
+                        atomic_addd(&dL_drgb[3 * g + ch], dch * dLp[ch]);
                     }
                     dL_dalpha *= T;
                     last_alpha = alpha;
@@ -360,16 +365,20 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
                     float gdx = G * dx, gdy = G * dy;
                     float dG_ddelx = -gdx * co[0] - gdy * co[1];
                     float dG_ddely = -gdy * co[2] - gdx * co[1];
-                    atomic_addf(&dL_dmeans2D[3 * g], dL_dG * dG_ddelx * 0.5f * W);
-                    atomic_addf(&dL_dmeans2D[3 * g + 1], dL_dG * dG_ddely * 0.5f * H);
-                    atomic_addf(&dL_dconic[4 * g], -0.5f * gdx * dx * dL_dG);
-                    atomic_addf(&dL_dconic[4 * g + 1], -0.5f * gdx * dy * dL_dG); /* HALF of dL/dB; doubled below */
-                    atomic_addf(&dL_dconic[4 * g + 3], -0.5f * gdy * dy * dL_dG);
-                    atomic_addf(&dL_dopacity[g], G * dL_dalpha);
+                    atomic_addd(&dL_dm2[2 * g], dL_dG * dG_ddelx * 0.5f * W);
+                    atomic_addd(&dL_dm2[2 * g + 1], dL_dG * dG_ddely * 0.5f * H);
+                    atomic_addd(&dL_dconic[4 * g], -0.5f * gdx * dx * dL_dG);
+                    atomic_addd(&dL_dconic[4 * g + 1], -0.5f * gdx * dy * dL_dG); /* HALF of dL/dB; doubled below */
+                    atomic_addd(&dL_dconic[4 * g + 3], -0.5f * gdy * dy * dL_dG);
+                    atomic_addd(&dL_dop[g], G * dL_dalpha);
                 }
             }
     }
 
+    for (int i = 0; i < P; i++) {
+        dL_dmeans2D[3 * i] = (float)dL_dm2[2 * i]; dL_dmeans2D[3 * i + 1] = (float)dL_dm2[2 * i + 1];
+        dL_dopacity[i] = (float)dL_dop[i];
+    }
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < P; i++) {
         if (!(c->radii[i] > 0)) continue;
@@ -388,7 +397,7 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
             float a = TS[0] * T[0] + TS[1] * T[1] + TS[2] * T[2] + 0.3f;
             float b = TS[0] * T[3] + TS[1] * T[4] + TS[2] * T[5];
             float cc = TS[3] * T[3] + TS[4] * T[4] + TS[5] * T[5] + 0.3f;
-            float dcx = dL_dconic[4 * i], dcy = dL_dconic[4 * i + 1], dcz = dL_dconic[4 * i + 3];
+            float dcx = (float)dL_dconic[4 * i], dcy = (float)dL_dconic[4 * i + 1], dcz = (float)dL_dconic[4 * i + 3];
             float denom = a * cc - b * b;
             float d2inv = 1.0f / ((denom * denom) + 0.0000001f);
             float dL_da = 0, dL_db = 0, dL_dc = 0;
@@ -452,7 +461,7 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
             float inv = 1.f / sqrtf(len2);
             float x = dir0[0] * inv, y = dir0[1] * inv, z = dir0[2] * inv;
             float dRGB[3];
-            for (int ch = 0; ch < 3; ch++) dRGB[ch] = c->clamped[3 * i + ch] ? 0.f : dL_drgb[3 * i + ch];
+            for (int ch = 0; ch < 3; ch++) dRGB[ch] = c->clamped[3 * i + ch] ? 0.f : (float)dL_drgb[3 * i + ch];
             float ddir[3] = {0, 0, 0}; /* dL/d(unit dir) */
             for (int ch = 0; ch < 3; ch++) {
 #define SHC(k) sh[3 * (k) + ch]
@@ -504,7 +513,7 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
             dmean[1] += (-vx * vy * ddir[0] + (len2 - vy * vy) * ddir[1] - vz * vy * ddir[2]) * inv3;
             dmean[2] += (-vx * vz * ddir[0] - vy * vz * ddir[1] + (len2 - vz * vz) * ddir[2]) * inv3;
         } else if (dL_dcolors) {
-            for (int ch = 0; ch < 3; ch++) dL_dcolors[3 * i + ch] = dL_drgb[3 * i + ch];
+            for (int ch = 0; ch < 3; ch++) dL_dcolors[3 * i + ch] = (float)dL_drgb[3 * i + ch];
         }
         for (int k = 0; k < 3; k++) dL_dmeans3D[3 * i + k] += dmean[k];
         /* ---- cov3D -> scale / rotation ---- */
@@ -548,6 +557,6 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
             dL_drots[4 * i] = dr; dL_drots[4 * i + 1] = dx_; dL_drots[4 * i + 2] = dy_; dL_drots[4 * i + 3] = dz_;
         }
     }
-    free(dL_dconic); free(dL_drgb);
+    free(dL_dconic); free(dL_drgb); free(dL_dm2); free(dL_dop);
     if (!dL_dcov3D) free(dL_dcov);
 }

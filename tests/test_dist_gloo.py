@@ -42,6 +42,14 @@ def _worker(rank, world, port, out):
     flat.buffer[:15] = float(rank + 1)
     flat.all_reduce_mean()
     ok = ok and torch.allclose(params[1].grad, torch.full((7,), 1.5)) and params[1].grad.data_ptr() == flat.buffer[15:].data_ptr()
+    # per-tensor reducer (the one bench.py uses)
+    red = dd.GradReducer(params)
+    red.zero()
+    assert all(p.grad is None for p in params)
+    for v in views:
+        sum(((v + 1.0) * p).sum() for p in params).backward()
+    red.all_reduce_mean()
+    ok = ok and all(torch.allclose(p.grad, torch.full_like(p, expect)) for p in params)
     out[rank] = bool(ok)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
