@@ -177,6 +177,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    t_host = time.perf_counter() - t0          # host time to ENQUEUE the K steps (diagnostic: host- vs GPU-bound)
     barrier()
     dt = time.perf_counter() - t0
     R.stage_timer.enabled = False
@@ -221,6 +222,7 @@ def main():
                        "views_per_step": world, "parallelism": f"camera-sharded dp{world}",
                        "grad_allreduce_bytes": flat.nbytes() if world > 1 else 0},
             "roofline": roof, "kernels": kernels,
+            "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 4),
         }
         if not args.no_cpu_baseline and world == 1:
             try:
