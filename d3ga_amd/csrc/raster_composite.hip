@@ -55,6 +55,53 @@ __device__ __forceinline__ void wave_sum_multi(float (&v)[NV]) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = dpp_add<0x143, 0xc>(v[k]);
 }
+// ---- nine values at once: reduce-scatter with the gfx950 lane-swap instructions ----
+// v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of the second; adding the two results
+// leaves the half-wave sums of the first value in lanes 0..31 and of the second in lanes 32..63 (2 instructions retire
+// one of two values).  v_permlane16_swap does the same for odd/even 16-lane rows.  Two levels take 8 values down to 2
+// registers whose four rows each hold a different value; four row-local DPP adds finish them.
+//   q0 rows 0..3 = totals of v[0], v[2], v[1], v[3]     q1 rows 0..3 = totals of v[4], v[6], v[5], v[7]
+//   r8 row 3     = total of v[8] (plain six-step chain)
+// 30 VALU instructions instead of 72 for nine independent six-step chains.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float swap32_add(float a, float b) {
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float swap16_add(float a, float b) {
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float row_sum16(float v) {       // every lane <- sum over its 16-lane row
+    v = dpp_add<0xB1, 0xf>(v); v = dpp_add<0x4E, 0xf>(v); v = dpp_add<0x141, 0xf>(v); v = dpp_add<0x140, 0xf>(v);
+    return v;
+}
+struct Reduced9 { float q0, q1, r8; };
+__device__ __forceinline__ Reduced9 wave_reduce9(const float (&v)[9]) {
+    Reduced9 r;
+    const float p0 = swap32_add(v[0], v[1]), p1 = swap32_add(v[2], v[3]);
+    const float p2 = swap32_add(v[4], v[5]), p3 = swap32_add(v[6], v[7]);
+    r.q0 = row_sum16(swap16_add(p0, p1));
+    r.q1 = row_sum16(swap16_add(p2, p3));
+    float t = row_sum16(v[8]);
+    t = dpp_add<0x142, 0xa>(t);
+    r.r8 = dpp_add<0x143, 0xc>(t);
+    return r;
+}
+// which of the nine totals does this lane publish?  (-1: none).  Lanes 0,16,32,48 -> q0; 1,17,33,49 -> q1; 50 -> r8.
+__device__ __forceinline__ int reduce9_value_of_lane(int lane) {
+    const int row = lane >> 4, c = lane & 15;
+    const int perm = (row == 1) ? 2 : (row == 2) ? 1 : row;           // rows hold values 0,2,1,3
+    if (c == 0) return perm;
+    if (c == 1) return 4 + perm;
+    if (lane == 50) return 8;
+    return -1;
+}
+__device__ __forceinline__ float reduce9_pick(const Reduced9 &r, int lane) {
+    const int c = lane & 15;
+    return c == 0 ? r.q0 : (c == 1 ? r.q1 : r.r8);
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
@@ -201,7 +248,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;                    // colour accumulated behind the current splat
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-    const int slot = lane - 48;                            // lanes 48..56 publish value `slot` of the wave's totals
+    const int slot = reduce9_value_of_lane(lane);          // which of the nine totals this lane publishes (-1: none)
     const int slot_off = slot < 2 ? slot : slot + 1;       // acc layout: 0,1 | 3,4,5 | 6 | 7,8,9
 
     // positions hi, hi-1, ... (1-based); lane l holds position hi - l, so ascending lanes = back-to-front
@@ -257,25 +304,30 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(
                 v[5] = G * dL_dalpha;
                 v[6] = dch * g0; v[7] = dch * g1; v[8] = dch * g2;
             }
-            wave_sum_multi<kNG>(v);
-            float mine = v[0];
-#pragma unroll
-            for (int k = 1; k < kNG; ++k) mine = (slot == k) ? v[k] : mine;
-            if (slot >= 0 && slot < kNG) atomicAdd(acc + 12 * (size_t)gid + slot_off, mine);   // one instruction, 9 lanes
+            const Reduced9 red = wave_reduce9(v);
+            if (slot >= 0) atomicAdd(acc + 12 * (size_t)gid + slot_off, reduce9_pick(red, lane));   // one instruction, 9 lanes
         }
     }
 }
 
-// self-test kernel for the DPP reductions (tests/): out[w] = sum over the wave's 64 inputs, or -1e30 when the
-// single-value and the multi-value forms disagree
+// self-test kernel for the cross-lane reductions (tests/).  Per wave w with inputs x[0..63]:
+//   out[10 w + k] = sum_l (k+1) x[l] + k   for k = 0..8, through wave_reduce9 and the lane mapping the backward uses;
+//   out[10 w + 9] = sum_l x[l]              through wave_sum / wave_sum_multi (or -1e30 if those two disagree).
 __global__ void wave_sum_selftest_kernel(const float *__restrict__ in, float *__restrict__ out) {
-    const float x = in[blockIdx.x * blockDim.x + threadIdx.x];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = gid >> 6;
+    const float x = in[gid];
+    float v9[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v9[k] = (float)(k + 1) * x + (float)k / 64.0f;
+    const Reduced9 red = wave_reduce9(v9);
+    const int slot = reduce9_value_of_lane(lane);
+    if (slot >= 0) out[10 * w + slot] = reduce9_pick(red, lane);
     float v[2] = {x, 2.0f * x};
     wave_sum_multi<2>(v);
     const float s = wave_sum(x);
     const float m0 = bcast(v[0], 50), m1 = bcast(v[1], 63);
-    if ((threadIdx.x & 63) == 0)
-        out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = (m0 == s && m1 == 2.0f * s) ? s : -1e30f;
+    if (lane == 0) out[10 * w + 9] = (m0 == s && m1 == 2.0f * s) ? s : -1e30f;
 }
 
 }  // namespace d3ga
@@ -316,7 +368,7 @@ extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const fl
     return check_launch(s, prm->debug);
 }
 
-// test hook (not part of the drop-in surface): n multiple of 256, in (n) -> out (n/64)
+// test hook (not part of the drop-in surface): n multiple of 256, in (n) -> out (10 * n/64)
 extern "C" int d3ga_selftest_wave_sum(int n, const float *in, float *out, d3ga_stream_t stream) {
     if (n <= 0 || (n % 256) != 0) return D3GA_E_SIZE;
     if (!in || !out) return D3GA_E_NULL;

@@ -3,13 +3,46 @@
 //   preprocess_kernel      project, EWA 2D covariance, conic, radius, tile rectangle, SH colour, tile histogram
 //   preprocess_bwd_kernel  conic/mean2D/colour/opacity gradients -> mean3D, cov3D | (scale, rotation), SH
 //
-// Both are HBM-streaming: one thread per Gaussian, every per-Gaussian array read/written once with
-// lane-contiguous addresses (algorithmic bytes per Gaussian: fwd 88 + 12 M).  The camera
-// matrices are wave-uniform and come through the scalar cache.  No LDS, no MFMA.
+// Both are HBM-streaming: one thread per Gaussian, every per-Gaussian array read/written once (algorithmic bytes per
+// Gaussian: fwd 88 + 12 M).  The wide (P,M,3) SH arrays go through per-wavefront LDS slabs so that
+// global accesses are 16 B per lane and lane-contiguous; the camera matrices are wave-uniform and come through the
+// scalar cache.  No MFMA.
 #include "d3ga_internal.h"
 #include "raster_pre_body.h"
 
 namespace d3ga {
+
+// ---------------------------------------------------------------------------------------------------------
+// SH staging.  shs / dL_dsh are (P, M, 3): 12*M bytes per Gaussian, so a thread-per-Gaussian access walks memory with
+// a 192-byte stride (M = 16) and every load instruction of a wavefront touches 64 different cache lines -- measured
+// 3.5x over-fetch.  Instead each wavefront moves the 64 rows it owns as ONE contiguous block with 16-byte-per-lane,
+// lane-contiguous accesses (1 KiB per instruction) through an LDS slab, and every lane then works on its own row in
+// LDS.  Rows are padded to 52 floats = 13 x 16 B (odd number of 16-byte slots -> conflict-free b128 row access).
+// Used when 3*M is a multiple of 4 floats (M = 4, 8, 12, 16; D3GA always has M = 16); otherwise rows are accessed
+// in global memory directly.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kShRow = 52;
+constexpr int kShSlab = 64 * kShRow;            // floats per wavefront
+constexpr size_t kShLdsBytes = (size_t)(kBlock / 64) * kShSlab * sizeof(float);   // 53,248 B per block
+
+__device__ __forceinline__ bool sh_staged(int M) { return M > 0 && (3 * M) % 4 == 0 && 3 * M <= 48; }
+
+// global (rows x 3M floats, contiguous) -> LDS slab; `rows` valid rows of this wavefront (<= 64)
+__device__ __forceinline__ void sh_slab_load(float *slab, const float *__restrict__ src, int rows, int M3, int lane) {
+    const int nvec = rows * M3 / 4;
+    for (int v = lane; v < nvec; v += 64) {
+        const float4 x = reinterpret_cast<const float4 *>(src)[v];
+        const int e = 4 * v, r = e / M3, c = e - r * M3;
+        *reinterpret_cast<float4 *>(slab + r * kShRow + c) = x;
+    }
+}
+__device__ __forceinline__ void sh_slab_store(const float *slab, float *__restrict__ dst, int rows, int M3, int lane) {
+    const int nvec = rows * M3 / 4;
+    for (int v = lane; v < nvec; v += 64) {
+        const int e = 4 * v, r = e / M3, c = e - r * M3;
+        reinterpret_cast<float4 *>(dst)[v] = *reinterpret_cast<const float4 *>(slab + r * kShRow + c);
+    }
+}
 
 __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     d3ga_raster_params prm, const float *__restrict__ means3D, const float *__restrict__ shs,
@@ -17,15 +50,31 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, const float *__restrict__ viewmatrix,
     const float *__restrict__ projmatrix, const float *__restrict__ campos, GeomBuf geom,
     uint32_t *__restrict__ tile_count, uint32_t *__restrict__ counters, int32_t *__restrict__ radii) {
+    // one dynamic LDS region, used first as the SH staging slabs and then (after a barrier) as the tile window
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_box[4];
-    __shared__ uint32_t s_cnt[kWinTiles];
-    const int tid = threadIdx.x;
+    float *s_sh = reinterpret_cast<float *>(smem);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * kBlock + tid;
+    const int M3 = 3 * prm.M;
+    const bool staged = shs != nullptr && sh_staged(prm.M);
+    float *slab = s_sh + wave * kShSlab;
+    if (staged) {
+        const int row0 = blockIdx.x * kBlock + wave * 64;           // first Gaussian of this wavefront
+        const int rows = min(64, prm.P - row0);
+        if (rows > 0) sh_slab_load(slab, shs + (size_t)M3 * row0, rows, M3, lane);
+        __syncthreads();
+    }
     bool visible = false;
     int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
     if (i < prm.P) {
-        const PreOut o = preprocess_one(prm, i, means3D, shs, colors_precomp, opacities, scales, rotations,
-                                        cov3D_precomp, viewmatrix, projmatrix, campos);
+        // two call sites so that each inlined copy sees ONE address space (ds_read vs global_load, never flat)
+        const PreOut o = staged ? preprocess_one(prm, i, means3D, slab + lane * kShRow, colors_precomp, opacities, scales,
+                                                 rotations, cov3D_precomp, viewmatrix, projmatrix, campos)
+                                : preprocess_one(prm, i, means3D, shs ? shs + (size_t)M3 * i : nullptr, colors_precomp,
+                                                 opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                                                 campos);
         const Splat &sp = o.sp;
 #pragma unroll
         for (int k = 0; k < 6; ++k) geom.cov3D[6 * (size_t)i + k] = o.c6[k];
@@ -44,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     }
     // ---- tile histogram (counting-sort pass 1) through the block's LDS window ----
     const int gx = (prm.W + kTile - 1) / kTile;
-    const TileWindow win = block_tile_window(s_box, visible, r0, r1, r2, r3);
+    const TileWindow win = block_tile_window(s_box, visible, r0, r1, r2, r3);   // barriers inside: slabs are dead now
     const int nvis = __syncthreads_count(visible);
     if (tid == 0 && nvis) atomicAdd(&counters[D3GA_CNT_VISIBLE], (uint32_t)nvis);
     const int area = win.area();
@@ -73,27 +122,52 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const float *__restrict__ acc, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
     float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors,
     float *__restrict__ dL_dcov3D, float *__restrict__ dL_dscales, float *__restrict__ dL_drots) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= prm.P) return;
-    const uint2 rc = geom.rect[i];
-    const bool visible = ((rc.y & 0xffffu) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.x >> 16));
-    float a[12], c6[6];
-    if (visible) {
-        const float4 *ap = reinterpret_cast<const float4 *>(acc + 12 * (size_t)i);
-        const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
-        a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
-        a[8] = a2.x; a[9] = a2.y; a[10] = a2.z; a[11] = a2.w;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c6[k] = geom.cov3D[6 * (size_t)i + k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) a[k] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c6[k] = 0.f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_sh = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * kBlock + tid;
+    const int M3 = 3 * prm.M;
+    const bool staged = dL_dsh != nullptr && sh_staged(prm.M);
+    const int row0 = blockIdx.x * kBlock + wave * 64;
+    const int rows = min(64, prm.P - row0);
+    float *slab = s_sh + wave * kShSlab;
+    if (staged) {
+        if (rows > 0) sh_slab_load(slab, shs + (size_t)M3 * row0, rows, M3, lane);
+        __syncthreads();
     }
-    preprocess_bwd_one(prm, i, visible, means3D, shs, scales, rotations, viewmatrix, projmatrix, campos, c6,
-                       geom.clamped[i], a, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors, dL_dcov3D,
-                       dL_dscales, dL_drots);
+    if (i < prm.P) {
+        const uint2 rc = geom.rect[i];
+        const bool visible = ((rc.y & 0xffffu) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.x >> 16));
+        float a[12], c6[6];
+        if (visible) {
+            const float4 *ap = reinterpret_cast<const float4 *>(acc + 12 * (size_t)i);
+            const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+            a[8] = a2.x; a[9] = a2.y; a[10] = a2.z; a[11] = a2.w;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c6[k] = geom.cov3D[6 * (size_t)i + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) a[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c6[k] = 0.f;
+        }
+        // two call sites so that each inlined copy sees ONE address space (LDS row vs global row, never flat);
+        // staged: the gradient row overwrites the coefficient row in place
+        if (staged)
+            preprocess_bwd_one(prm, i, visible, means3D, slab + lane * kShRow, scales, rotations, viewmatrix, projmatrix,
+                               campos, c6, geom.clamped[i], a, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
+                               slab + lane * kShRow, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots);
+        else
+            preprocess_bwd_one(prm, i, visible, means3D, dL_dsh ? shs + (size_t)M3 * i : nullptr, scales, rotations,
+                               viewmatrix, projmatrix, campos, c6, geom.clamped[i], a, dL_dmeans3D, dL_dmeans2D,
+                               dL_dopacity, dL_dsh ? dL_dsh + (size_t)M3 * i : nullptr, dL_dcolors, dL_dcov3D,
+                               dL_dscales, dL_drots);
+    }
+    if (staged) {
+        __syncthreads();
+        if (rows > 0) sh_slab_store(slab, dL_dsh + (size_t)M3 * row0, rows, M3, lane);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void mark_visible_kernel(int P, const float *__restrict__ means3D,
@@ -137,7 +211,8 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     if (shs && (prm->sh_degree + 1) * (prm->sh_degree + 1) > prm->M) return D3GA_E_CONFIG;
     if (!means3D || !opacities || !radii) return D3GA_E_NULL;
     GeomBuf g = carve_geom(geom, prm->P);
-    hipLaunchKernelGGL(preprocess_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, *prm, means3D, shs,
+    const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? kShLdsBytes : (size_t)kWinTiles * 4;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
                        colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, g,
                        bin.tile_count, bin.counters, radii);
     return check_launch(s, prm->debug);
@@ -158,7 +233,8 @@ extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const f
     if (dL_dscales && (!scales || !rotations)) return D3GA_E_NULL;
     hipStream_t s = (hipStream_t)stream;
     GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, *prm, means3D,
+    const size_t lds = (dL_dsh && prm->M > 0 && (3 * prm->M) % 4 == 0) ? kShLdsBytes : 0;
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D,
                        shs, scales, rotations, viewmatrix, projmatrix, campos, g, acc, dL_dmeans3D, dL_dmeans2D,
                        dL_dopacity, dL_dsh, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots);
     return check_launch(s, prm->debug);

@@ -16,8 +16,9 @@ struct PreOut {
     uint8_t clampmask;
 };
 
-// R1 for Gaussian i.  Exactly one of (shs|colors_precomp), ((scales,rotations)|cov3D_precomp) is non-null.
-D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float *means3D, const float *shs,
+// R1 for Gaussian i.  Exactly one of (sh_row|colors_precomp), ((scales,rotations)|cov3D_precomp) is non-null.
+// sh_row points at THIS Gaussian's 3*M SH floats (in global memory or in an LDS staging row).
+D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float *means3D, const float *sh_row,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
                               const float *projmatrix, const float *campos) {
@@ -46,7 +47,7 @@ D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float 
         float B[16];
         sh_basis(prm.sh_degree, d.x * inv, d.y * inv, d.z * inv, B);
         const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
-        const float *sh = shs + (size_t)3 * prm.M * i;
+        const float *sh = sh_row;
         float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 16; ++k) {       // fixed trip count: keeps B[] in registers
@@ -65,11 +66,12 @@ D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float 
 
 // R6 for Gaussian i.  a[12] = accumulated screen-space gradients (layout: d3ga.h, d3ga_raster_composite_bwd);
 // all-zero and visible=false for culled Gaussians.  Output pointers may be null where not applicable.
+// sh_row / dsh_row point at THIS Gaussian's 3*M floats (global memory or an LDS staging row; they may alias).
 D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visible, const float *means3D,
-                                const float *shs, const float *scales, const float *rotations,
+                                const float *sh_row, const float *scales, const float *rotations,
                                 const float *viewmatrix, const float *projmatrix, const float *campos,
                                 const float *c6, uint8_t clampmask, const float *a, float *dL_dmeans3D,
-                                float *dL_dmeans2D, float *dL_dopacity, float *dL_dsh, float *dL_dcolors,
+                                float *dL_dmeans2D, float *dL_dopacity, float *dsh_row, float *dL_dcolors,
                                 float *dL_dcov3D, float *dL_dscales, float *dL_drots) {
     float gmean[3] = {0.f, 0.f, 0.f};
     float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -79,8 +81,8 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
         cov2d_bwd(mean, c6, viewmatrix, prm.W, prm.H, prm.tanfovx, prm.tanfovy, a[3], a[4], a[5], g6, gmean);
         project_bwd(mean, projmatrix, a[0], a[1], gmean);
     }
-    if (dL_dsh) {
-        float *out = dL_dsh + (size_t)3 * nbM * i;
+    if (dsh_row) {
+        float *out = dsh_row;
         if (visible) {
             const float gr[3] = {(clampmask & 1) ? 0.f : a[7], (clampmask & 2) ? 0.f : a[8],
                                  (clampmask & 4) ? 0.f : a[9]};
@@ -91,7 +93,7 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
             sh_basis(prm.sh_degree, x, y, z, B);
             sh_basis_grad(prm.sh_degree, x, y, z, Bx, By, Bz);
             const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
-            const float *sh = shs + (size_t)3 * nbM * i;
+            const float *sh = sh_row;
             V3 gd = v3(0.f, 0.f, 0.f);
 #pragma unroll
             for (int k = 0; k < 16; ++k) {   // fixed trip count: keeps the basis arrays in registers

@@ -82,8 +82,8 @@ void hc_preprocess(const d3ga_raster_params *prm, const float *means3D, const fl
                    const float *view, const float *proj, const float *campos, float *depth, float *xy, float *conic_o,
                    float *rgb, int32_t *radii, int32_t *rect, uint8_t *clamped, float *cov3D) {
     for (int i = 0; i < prm->P; ++i) {
-        const PreOut o = preprocess_one(*prm, i, means3D, shs, colors, opacities, scales, rots, cov3D_precomp, view,
-                                        proj, campos);
+        const PreOut o = preprocess_one(*prm, i, means3D, shs ? shs + (size_t)3 * prm->M * i : nullptr, colors, opacities,
+                                        scales, rots, cov3D_precomp, view, proj, campos);
         depth[i] = o.sp.depth; xy[2 * i] = o.sp.px; xy[2 * i + 1] = o.sp.py;
         for (int k = 0; k < 3; ++k) conic_o[4 * i + k] = o.sp.conic[k];
         conic_o[4 * i + 3] = o.opacity;
@@ -103,9 +103,10 @@ void hc_preprocess_bwd(const d3ga_raster_params *prm, const float *means3D, cons
     const float zeros[12] = {0};
     for (int i = 0; i < prm->P; ++i) {
         const bool vis = radii[i] > 0;
-        preprocess_bwd_one(*prm, i, vis, means3D, shs, scales, rots, view, proj, campos, cov3D + 6 * (size_t)i,
-                           clamped[i], vis ? acc + 12 * (size_t)i : zeros, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
-                           dL_dsh, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots);
+        preprocess_bwd_one(*prm, i, vis, means3D, shs ? shs + (size_t)3 * prm->M * i : nullptr, scales, rots, view, proj,
+                           campos, cov3D + 6 * (size_t)i, clamped[i], vis ? acc + 12 * (size_t)i : zeros, dL_dmeans3D,
+                           dL_dmeans2D, dL_dopacity, dL_dsh ? dL_dsh + (size_t)3 * prm->M * i : nullptr, dL_dcolors,
+                           dL_dcov3D, dL_dscales, dL_drots);
     }
 }
 

@@ -26,11 +26,14 @@ def test_library_loaded_and_wave_sum():
     L = d3ga_amd.lib()
     assert L.d3ga_version() == 100
     x = torch.randn(256 * 8, device=DEV)
-    out = torch.empty(256 * 8 // 64, device=DEV)
+    out = torch.full((256 * 8 // 64, 10), float("nan"), device=DEV)
     check(L.d3ga_selftest_wave_sum(x.numel(), dptr(x), dptr(out), stream_handle()), "selftest")
     torch.cuda.synchronize()
-    ref = x.double().view(-1, 64).sum(1)
-    assert torch.allclose(out.double(), ref, atol=1e-4), (out[:4], ref[:4])
+    xs = x.double().view(-1, 64)
+    k = torch.arange(9, device=DEV, dtype=torch.float64)
+    ref9 = (k + 1)[None] * xs.sum(1, keepdim=True) + k[None]          # sum_l ((k+1) x_l + k/64)
+    assert torch.allclose(out[:, :9].double(), ref9, atol=1e-3), (out[0], ref9[0])
+    assert torch.allclose(out[:, 9].double(), xs.sum(1), atol=1e-4)
 
 
 def test_cage_deform_matches_reference_golden(golden):
