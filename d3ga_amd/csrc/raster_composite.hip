@@ -141,11 +141,21 @@ static inline int quad_grid(int gx, int gy) { return 8 * ((gy + 7) / 8) * gx * 4
 // Comparisons are written so that NaNs answer "relevant".
 __device__ __forceinline__ bool quad_relevant(float cx, float cy, float A, float B, float C, float o, float x0, float y0) {
     if (o * 255.0f < 1.0f) return false;                  // o*G <= o < 1/255 for every G <= 1
+    // hardware rcp / sqrt / log (1 ulp-ish) are fine here: the extents are inflated below
     const float tau = 2.0f * __logf(255.0f * o) * 1.001f + 1e-4f;
-    const float idet = 1.0f / (A * C - B * B);
-    const float hx = sqrtf(tau * C * idet) * 1.001f + 0.02f;
-    const float hy = sqrtf(tau * A * idet) * 1.001f + 0.02f;
+    const float idet = __builtin_amdgcn_rcpf(A * C - B * B);
+    const float hx = __builtin_amdgcn_sqrtf(tau * C * idet) * 1.001f + 0.02f;
+    const float hy = __builtin_amdgcn_sqrtf(tau * A * idet) * 1.001f + 0.02f;
     return !(cx + hx < x0) && !(cx - hx > x0 + 7.0f) && !(cy + hy < y0) && !(cy - hy > y0 + 7.0f);
+}
+
+// alpha of one splat on one pixel, branch-free: ok <=> the splat touches the pixel (power <= 0 and alpha >= 1/255)
+__device__ __forceinline__ void splat_eval(float dx, float dy, float ca, float cb, float cc, float o, float &alpha,
+                                           float &G, bool &ok) {
+    const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+    G = __expf(power);
+    alpha = fminf(kAlphaMax, o * G);
+    ok = (power <= 0.0f) && (alpha >= kAlphaMin);
 }
 
 __global__ __launch_bounds__(64) void composite_fwd_kernel(
@@ -182,28 +192,47 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
             nxy = xy[g]; nco = conic_o[g]; nrgb = rgb_invd[g];
         }
         unsigned long long mask = __ballot(have && quad_relevant(cxy.x, cxy.y, cco.x, cco.y, cco.z, cco.w, x0, y0));
+        // Two entries per iteration, straight-line code: the alpha evaluations (readlane broadcasts, quadratic form,
+        // exp) of the pair are independent and overlap; only the short T / done recurrence is serial.  No divergent
+        // branches -> no exec-mask juggling on the (single, shared) scalar unit.
         while (mask) {
-            const int j = __ffsll((long long)mask) - 1;
+            const int j0 = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
-            const float ex = bcast(cxy.x, j), ey = bcast(cxy.y, j);
-            const float ea = bcast(cco.x, j), eb = bcast(cco.y, j), ec = bcast(cco.z, j), eo = bcast(cco.w, j);
-            float alpha, G;
-            const bool hit = !done && splat_alpha(ex - fx, ey - fy, ea, eb, ec, eo, alpha, G);
-            if (__any(hit)) {
-                const float r = bcast(crgb.x, j), g = bcast(crgb.y, j), b = bcast(crgb.z, j), d = bcast(crgb.w, j);
-                if (hit) {
-                    const float test_T = T * (1.0f - alpha);
-                    if (test_T < kTmin) {
-                        done = true;
-                    } else {
-                        const float w = alpha * T;
-                        C0 += r * w; C1 += g * w; C2 += b * w; Dp += d * w;
-                        T = test_T;
-                        last = base - begin + (uint32_t)j + 1u;   // 1-based position in the FULL tile list
-                    }
-                }
-                if (__all(done)) { mask = 0; base = end; }       // whole quadrant saturated
+            const bool two = mask != 0;
+            const int j1 = two ? __ffsll((long long)mask) - 1 : j0;
+            mask &= mask - 1;                                              // no-op when mask is already 0
+            float al0, G0, al1, G1;
+            bool ok0, ok1;
+            splat_eval(bcast(cxy.x, j0) - fx, bcast(cxy.y, j0) - fy, bcast(cco.x, j0), bcast(cco.y, j0), bcast(cco.z, j0),
+                       bcast(cco.w, j0), al0, G0, ok0);
+            splat_eval(bcast(cxy.x, j1) - fx, bcast(cxy.y, j1) - fy, bcast(cco.x, j1), bcast(cco.y, j1), bcast(cco.z, j1),
+                       bcast(cco.w, j1), al1, G1, ok1);
+            ok1 = ok1 && two;
+            {   // entry j0
+                const bool act = ok0 && !done;
+                const float test_T = T * (1.0f - al0);
+                const bool sat = act && (test_T < kTmin);
+                const bool bl = act && !sat;
+                const float w = bl ? al0 * T : 0.f;
+                C0 += bcast(crgb.x, j0) * w; C1 += bcast(crgb.y, j0) * w; C2 += bcast(crgb.z, j0) * w;
+                Dp += bcast(crgb.w, j0) * w;
+                T = bl ? test_T : T;
+                last = bl ? (base - begin + (uint32_t)j0 + 1u) : last;   // 1-based position in the FULL tile list
+                done = done || sat;
             }
+            {   // entry j1
+                const bool act = ok1 && !done;
+                const float test_T = T * (1.0f - al1);
+                const bool sat = act && (test_T < kTmin);
+                const bool bl = act && !sat;
+                const float w = bl ? al1 * T : 0.f;
+                C0 += bcast(crgb.x, j1) * w; C1 += bcast(crgb.y, j1) * w; C2 += bcast(crgb.z, j1) * w;
+                Dp += bcast(crgb.w, j1) * w;
+                T = bl ? test_T : T;
+                last = bl ? (base - begin + (uint32_t)j1 + 1u) : last;
+                done = done || sat;
+            }
+            if (__all(done)) { mask = 0; base = end; }                     // whole quadrant saturated
         }
     }
     if (inside) {
@@ -251,6 +280,12 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(
     const int slot = reduce9_value_of_lane(lane);          // which of the nine totals this lane publishes (-1: none)
     const int slot_off = slot < 2 ? slot : slot + 1;       // acc layout: 0,1 | 3,4,5 | 6 | 7,8,9
 
+    float pend[kNG];                                       // partials of the entry awaiting its reduction
+#pragma unroll
+    for (int k = 0; k < kNG; ++k) pend[k] = 0.f;
+    uint32_t pend_gid = 0;
+    bool pend_any = false;
+
     // positions hi, hi-1, ... (1-based); lane l holds position hi - l, so ascending lanes = back-to-front
     float2 nxy = make_float2(0.f, 0.f);
     float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -269,44 +304,59 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(
             nxy = xy[nid]; nco = conic_o[nid]; nrgb = rgb_invd[nid];
         }
         unsigned long long mask = __ballot(have && quad_relevant(cxy.x, cxy.y, cco.x, cco.y, cco.z, cco.w, x0, y0));
+        // Straight-line, software-pipelined body: iteration j evaluates entry j's nine partial derivatives while the
+        // cross-lane reduction + atomic of entry j-1 (a long dependent chain that nothing else waits for) is issued
+        // in between -- one basic block, so the scheduler interleaves the two instruction streams.
         while (mask) {
             const int j = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
             const uint32_t pos = hi - (uint32_t)j;
-            const float ex = bcast(cxy.x, j), ey = bcast(cxy.y, j);
             const float ea = bcast(cco.x, j), eb = bcast(cco.y, j), ec = bcast(cco.z, j), eo = bcast(cco.w, j);
-            const float dx = ex - fx, dy = ey - fy;
-            float alpha = 0.f, G = 0.f;
-            const bool hit = inside && pos <= last && splat_alpha(dx, dy, ea, eb, ec, eo, alpha, G);
-            if (!__any(hit)) continue;                     // wave-uniform skip
+            const float dx = bcast(cxy.x, j) - fx, dy = bcast(cxy.y, j) - fy;
             const float cr = bcast(crgb.x, j), cg = bcast(crgb.y, j), cb = bcast(crgb.z, j);
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)cid, j);
+            float al, G;
+            bool ok;
+            splat_eval(dx, dy, ea, eb, ec, eo, al, G, ok);
+            const bool hit = ok && inside && pos <= last;
+            const bool any_hit = __any(hit);
+            const float alpha = hit ? al : 0.f;            // masked lanes: alpha = G = 0 -> all partials vanish
+            G = hit ? G : 0.f;
+            const float inv1ma = 1.0f / (1.0f - alpha);
+            T = T * inv1ma;
+            const float dch = alpha * T;
+            const float n0 = last_alpha * lc0 + (1.f - last_alpha) * a0;
+            const float n1 = last_alpha * lc1 + (1.f - last_alpha) * a1;
+            const float n2 = last_alpha * lc2 + (1.f - last_alpha) * a2;
+            a0 = hit ? n0 : a0; a1 = hit ? n1 : a1; a2 = hit ? n2 : a2;
+            lc0 = hit ? cr : lc0; lc1 = hit ? cg : lc1; lc2 = hit ? cb : lc2;
+            last_alpha = hit ? alpha : last_alpha;
+            float dL_dalpha = ((cr - a0) * g0 + (cg - a1) * g1 + (cb - a2) * g2) * T;
+            dL_dalpha += (-T_final * inv1ma) * bg_dot;
+            const float dL_dG = eo * dL_dalpha;            // the 0.99 clamp passes the gradient through
+            const float gdx = G * dx, gdy = G * dy;
             float v[kNG];
-#pragma unroll
-            for (int k = 0; k < kNG; ++k) v[k] = 0.f;
-            if (hit) {
-                T = T / (1.0f - alpha);
-                const float dch = alpha * T;
-                a0 = last_alpha * lc0 + (1.f - last_alpha) * a0;
-                a1 = last_alpha * lc1 + (1.f - last_alpha) * a1;
-                a2 = last_alpha * lc2 + (1.f - last_alpha) * a2;
-                lc0 = cr; lc1 = cg; lc2 = cb;
-                float dL_dalpha = ((cr - a0) * g0 + (cg - a1) * g1 + (cb - a2) * g2) * T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                const float dL_dG = eo * dL_dalpha;        // the 0.99 clamp passes the gradient through
-                const float gdx = G * dx, gdy = G * dy;
-                v[0] = dL_dG * (-gdx * ea - gdy * eb) * ddelx_dx;
-                v[1] = dL_dG * (-gdy * ec - gdx * eb) * ddely_dy;
-                v[2] = -0.5f * gdx * dx * dL_dG;
-                v[3] = -0.5f * gdx * dy * dL_dG;            // half of dL/dB, doubled in the per-Gaussian backward
-                v[4] = -0.5f * gdy * dy * dL_dG;
-                v[5] = G * dL_dalpha;
-                v[6] = dch * g0; v[7] = dch * g1; v[8] = dch * g2;
+            v[0] = dL_dG * (-gdx * ea - gdy * eb) * ddelx_dx;
+            v[1] = dL_dG * (-gdy * ec - gdx * eb) * ddely_dy;
+            v[2] = -0.5f * gdx * dx * dL_dG;
+            v[3] = -0.5f * gdx * dy * dL_dG;                // half of dL/dB, doubled in the per-Gaussian backward
+            v[4] = -0.5f * gdy * dy * dL_dG;
+            v[5] = G * dL_dalpha;
+            v[6] = dch * g0; v[7] = dch * g1; v[8] = dch * g2;
+            // ---- retire the previous entry (unconditionally reduced: keeps the body one basic block) ----
+            {
+                const Reduced9 red = wave_reduce9(pend);
+                if (slot >= 0 && pend_any) atomicAdd(acc + 12 * (size_t)pend_gid + slot_off, reduce9_pick(red, lane));
             }
-            const Reduced9 red = wave_reduce9(v);
-            if (slot >= 0) atomicAdd(acc + 12 * (size_t)gid + slot_off, reduce9_pick(red, lane));   // one instruction, 9 lanes
+#pragma unroll
+            for (int k = 0; k < kNG; ++k) pend[k] = v[k];
+            pend_gid = gid;
+            pend_any = any_hit;
         }
+    }
+    if (pend_any) {
+        const Reduced9 red = wave_reduce9(pend);
+        if (slot >= 0) atomicAdd(acc + 12 * (size_t)pend_gid + slot_off, reduce9_pick(red, lane));
     }
 }
 
