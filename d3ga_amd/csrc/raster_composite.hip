@@ -18,9 +18,13 @@
 // by XCD r % 8, so the four quadrants of a tile and its horizontal neighbours -- which share most of their
 // Gaussians -- gather their records through the same 4 MiB L2, while the image's heavy rows stay interleaved
 // across XCDs for balance.
+#include <stdlib.h>
+
 #include "d3ga_internal.h"
 
 namespace d3ga {
+
+constexpr int kDefaultCompositeVariant = 3;   // LDS slabs in both directions (measured: fwd -30 %, bwd -5 %)
 
 // ---- wavefront (64 lanes) reductions through DPP ----
 template <int CTRL, int ROW_MASK>
@@ -158,6 +162,7 @@ __device__ __forceinline__ void splat_eval(float dx, float dy, float ca, float c
     ok = (power <= 0.0f) && (alpha >= kAlphaMin);
 }
 
+template <bool LDS>
 __global__ __launch_bounds__(64) void composite_fwd_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
     uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
@@ -170,6 +175,12 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     const float fx = (float)q.px, fy = (float)q.py, x0 = (float)q.qx0, y0 = (float)q.qy0;
     const uint32_t begin = (uint32_t)min((uint64_t)tile_start[q.tile], dcap);
     const uint32_t end = (uint32_t)min((uint64_t)tile_start[q.tile + 1], dcap);
+
+    // LDS variant: the batch's records are parked in a wave-private LDS slab and each entry is fetched with three
+    // uniform-address (broadcast) ds_reads instead of ten v_readlane (which occupy the VALU).
+    __shared__ float2 s_xy[64];
+    __shared__ float4 s_co[64];
+    __shared__ float4 s_rgb[64];
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0;
@@ -192,6 +203,11 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
             nxy = xy[g]; nco = conic_o[g]; nrgb = rgb_invd[g];
         }
         unsigned long long mask = __ballot(have && quad_relevant(cxy.x, cxy.y, cco.x, cco.y, cco.z, cco.w, x0, y0));
+        if constexpr (LDS) {
+            __builtin_amdgcn_wave_barrier();              // previous batch's reads are done (program order)
+            s_xy[lane] = cxy; s_co[lane] = cco; s_rgb[lane] = crgb;
+            __builtin_amdgcn_wave_barrier();
+        }
         // Two entries per iteration, straight-line code: the alpha evaluations (readlane broadcasts, quadratic form,
         // exp) of the pair are independent and overlap; only the short T / done recurrence is serial.  No divergent
         // branches -> no exec-mask juggling on the (single, shared) scalar unit.
@@ -203,10 +219,21 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
             mask &= mask - 1;                                              // no-op when mask is already 0
             float al0, G0, al1, G1;
             bool ok0, ok1;
-            splat_eval(bcast(cxy.x, j0) - fx, bcast(cxy.y, j0) - fy, bcast(cco.x, j0), bcast(cco.y, j0), bcast(cco.z, j0),
-                       bcast(cco.w, j0), al0, G0, ok0);
-            splat_eval(bcast(cxy.x, j1) - fx, bcast(cxy.y, j1) - fy, bcast(cco.x, j1), bcast(cco.y, j1), bcast(cco.z, j1),
-                       bcast(cco.w, j1), al1, G1, ok1);
+            float2 e0xy, e1xy;
+            float4 e0co, e1co, e0rgb, e1rgb;
+            if constexpr (LDS) {
+                e0xy = s_xy[j0]; e0co = s_co[j0]; e0rgb = s_rgb[j0];
+                e1xy = s_xy[j1]; e1co = s_co[j1]; e1rgb = s_rgb[j1];
+            } else {
+                e0xy = make_float2(bcast(cxy.x, j0), bcast(cxy.y, j0));
+                e0co = make_float4(bcast(cco.x, j0), bcast(cco.y, j0), bcast(cco.z, j0), bcast(cco.w, j0));
+                e0rgb = make_float4(bcast(crgb.x, j0), bcast(crgb.y, j0), bcast(crgb.z, j0), bcast(crgb.w, j0));
+                e1xy = make_float2(bcast(cxy.x, j1), bcast(cxy.y, j1));
+                e1co = make_float4(bcast(cco.x, j1), bcast(cco.y, j1), bcast(cco.z, j1), bcast(cco.w, j1));
+                e1rgb = make_float4(bcast(crgb.x, j1), bcast(crgb.y, j1), bcast(crgb.z, j1), bcast(crgb.w, j1));
+            }
+            splat_eval(e0xy.x - fx, e0xy.y - fy, e0co.x, e0co.y, e0co.z, e0co.w, al0, G0, ok0);
+            splat_eval(e1xy.x - fx, e1xy.y - fy, e1co.x, e1co.y, e1co.z, e1co.w, al1, G1, ok1);
             ok1 = ok1 && two;
             {   // entry j0
                 const bool act = ok0 && !done;
@@ -214,8 +241,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
                 const bool sat = act && (test_T < kTmin);
                 const bool bl = act && !sat;
                 const float w = bl ? al0 * T : 0.f;
-                C0 += bcast(crgb.x, j0) * w; C1 += bcast(crgb.y, j0) * w; C2 += bcast(crgb.z, j0) * w;
-                Dp += bcast(crgb.w, j0) * w;
+                C0 += e0rgb.x * w; C1 += e0rgb.y * w; C2 += e0rgb.z * w; Dp += e0rgb.w * w;
                 T = bl ? test_T : T;
                 last = bl ? (base - begin + (uint32_t)j0 + 1u) : last;   // 1-based position in the FULL tile list
                 done = done || sat;
@@ -226,8 +252,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
                 const bool sat = act && (test_T < kTmin);
                 const bool bl = act && !sat;
                 const float w = bl ? al1 * T : 0.f;
-                C0 += bcast(crgb.x, j1) * w; C1 += bcast(crgb.y, j1) * w; C2 += bcast(crgb.z, j1) * w;
-                Dp += bcast(crgb.w, j1) * w;
+                C0 += e1rgb.x * w; C1 += e1rgb.y * w; C2 += e1rgb.z * w; Dp += e1rgb.w * w;
                 T = bl ? test_T : T;
                 last = bl ? (base - begin + (uint32_t)j1 + 1u) : last;
                 done = done || sat;
@@ -249,6 +274,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
 
 constexpr int kNG = 9;   // partial derivatives per (pixel, Gaussian): mean2D x,y | conic a,b/2,c | opacity | r,g,b
 
+template <bool LDS>
 __global__ __launch_bounds__(64) void composite_bwd_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
     uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
@@ -273,18 +299,17 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(
     const uint32_t maxlast = wave_max_u32(last);           // deepest 1-based list position any pixel of the quadrant used
     if (maxlast == 0) return;
 
+    __shared__ float2 s_xy[64];
+    __shared__ float4 s_co[64];
+    __shared__ float4 s_rgb[64];
+    __shared__ uint32_t s_id[64];
+
     float T = T_final;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;                    // colour accumulated behind the current splat
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     const int slot = reduce9_value_of_lane(lane);          // which of the nine totals this lane publishes (-1: none)
     const int slot_off = slot < 2 ? slot : slot + 1;       // acc layout: 0,1 | 3,4,5 | 6 | 7,8,9
-
-    float pend[kNG];                                       // partials of the entry awaiting its reduction
-#pragma unroll
-    for (int k = 0; k < kNG; ++k) pend[k] = 0.f;
-    uint32_t pend_gid = 0;
-    bool pend_any = false;
 
     // positions hi, hi-1, ... (1-based); lane l holds position hi - l, so ascending lanes = back-to-front
     float2 nxy = make_float2(0.f, 0.f);
@@ -304,59 +329,66 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(
             nxy = xy[nid]; nco = conic_o[nid]; nrgb = rgb_invd[nid];
         }
         unsigned long long mask = __ballot(have && quad_relevant(cxy.x, cxy.y, cco.x, cco.y, cco.z, cco.w, x0, y0));
-        // Straight-line, software-pipelined body: iteration j evaluates entry j's nine partial derivatives while the
-        // cross-lane reduction + atomic of entry j-1 (a long dependent chain that nothing else waits for) is issued
-        // in between -- one basic block, so the scheduler interleaves the two instruction streams.
+        if constexpr (LDS) {
+            __builtin_amdgcn_wave_barrier();
+            s_xy[lane] = cxy; s_co[lane] = cco; s_rgb[lane] = crgb; s_id[lane] = cid;
+            __builtin_amdgcn_wave_barrier();
+        }
         while (mask) {
             const int j = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
             const uint32_t pos = hi - (uint32_t)j;
-            const float ea = bcast(cco.x, j), eb = bcast(cco.y, j), ec = bcast(cco.z, j), eo = bcast(cco.w, j);
-            const float dx = bcast(cxy.x, j) - fx, dy = bcast(cxy.y, j) - fy;
-            const float cr = bcast(crgb.x, j), cg = bcast(crgb.y, j), cb = bcast(crgb.z, j);
-            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)cid, j);
-            float al, G;
-            bool ok;
-            splat_eval(dx, dy, ea, eb, ec, eo, al, G, ok);
-            const bool hit = ok && inside && pos <= last;
-            const bool any_hit = __any(hit);
-            const float alpha = hit ? al : 0.f;            // masked lanes: alpha = G = 0 -> all partials vanish
-            G = hit ? G : 0.f;
-            const float inv1ma = 1.0f / (1.0f - alpha);
-            T = T * inv1ma;
-            const float dch = alpha * T;
-            const float n0 = last_alpha * lc0 + (1.f - last_alpha) * a0;
-            const float n1 = last_alpha * lc1 + (1.f - last_alpha) * a1;
-            const float n2 = last_alpha * lc2 + (1.f - last_alpha) * a2;
-            a0 = hit ? n0 : a0; a1 = hit ? n1 : a1; a2 = hit ? n2 : a2;
-            lc0 = hit ? cr : lc0; lc1 = hit ? cg : lc1; lc2 = hit ? cb : lc2;
-            last_alpha = hit ? alpha : last_alpha;
-            float dL_dalpha = ((cr - a0) * g0 + (cg - a1) * g1 + (cb - a2) * g2) * T;
-            dL_dalpha += (-T_final * inv1ma) * bg_dot;
-            const float dL_dG = eo * dL_dalpha;            // the 0.99 clamp passes the gradient through
-            const float gdx = G * dx, gdy = G * dy;
-            float v[kNG];
-            v[0] = dL_dG * (-gdx * ea - gdy * eb) * ddelx_dx;
-            v[1] = dL_dG * (-gdy * ec - gdx * eb) * ddely_dy;
-            v[2] = -0.5f * gdx * dx * dL_dG;
-            v[3] = -0.5f * gdx * dy * dL_dG;                // half of dL/dB, doubled in the per-Gaussian backward
-            v[4] = -0.5f * gdy * dy * dL_dG;
-            v[5] = G * dL_dalpha;
-            v[6] = dch * g0; v[7] = dch * g1; v[8] = dch * g2;
-            // ---- retire the previous entry (unconditionally reduced: keeps the body one basic block) ----
-            {
-                const Reduced9 red = wave_reduce9(pend);
-                if (slot >= 0 && pend_any) atomicAdd(acc + 12 * (size_t)pend_gid + slot_off, reduce9_pick(red, lane));
+            float ex, ey, ea, eb, ec, eo;
+            if constexpr (LDS) {
+                const float2 t = s_xy[j]; const float4 u = s_co[j];
+                ex = t.x; ey = t.y; ea = u.x; eb = u.y; ec = u.z; eo = u.w;
+            } else {
+                ex = bcast(cxy.x, j); ey = bcast(cxy.y, j);
+                ea = bcast(cco.x, j); eb = bcast(cco.y, j); ec = bcast(cco.z, j); eo = bcast(cco.w, j);
             }
+            const float dx = ex - fx, dy = ey - fy;
+            float alpha = 0.f, G = 0.f;
+            const bool hit = inside && pos <= last && splat_alpha(dx, dy, ea, eb, ec, eo, alpha, G);
+            if (!__any(hit)) continue;                     // wave-uniform skip
+            float cr, cg, cb;
+            uint32_t gid;
+            if constexpr (LDS) {
+                const float4 t = s_rgb[j];
+                cr = t.x; cg = t.y; cb = t.z;
+                gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_id[j]);
+            } else {
+                cr = bcast(crgb.x, j); cg = bcast(crgb.y, j); cb = bcast(crgb.z, j);
+                gid = (uint32_t)__builtin_amdgcn_readlane((int)cid, j);
+            }
+            float v[kNG];
 #pragma unroll
-            for (int k = 0; k < kNG; ++k) pend[k] = v[k];
-            pend_gid = gid;
-            pend_any = any_hit;
+            for (int k = 0; k < kNG; ++k) v[k] = 0.f;
+            if (hit) {
+                // hardware reciprocal (1 ulp) instead of an IEEE division: the ~50-step running product stays within
+                // ~1e-5 relative of the forward's T, far inside the 1e-3 gradient bar
+                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+                T = T * inv1ma;
+                const float dch = alpha * T;
+                a0 = last_alpha * lc0 + (1.f - last_alpha) * a0;
+                a1 = last_alpha * lc1 + (1.f - last_alpha) * a1;
+                a2 = last_alpha * lc2 + (1.f - last_alpha) * a2;
+                lc0 = cr; lc1 = cg; lc2 = cb;
+                float dL_dalpha = ((cr - a0) * g0 + (cg - a1) * g1 + (cb - a2) * g2) * T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final * inv1ma) * bg_dot;
+                const float dL_dG = eo * dL_dalpha;        // the 0.99 clamp passes the gradient through
+                const float gdx = G * dx, gdy = G * dy;
+                v[0] = dL_dG * (-gdx * ea - gdy * eb) * ddelx_dx;
+                v[1] = dL_dG * (-gdy * ec - gdx * eb) * ddely_dy;
+                v[2] = -0.5f * gdx * dx * dL_dG;
+                v[3] = -0.5f * gdx * dy * dL_dG;            // half of dL/dB, doubled in the per-Gaussian backward
+                v[4] = -0.5f * gdy * dy * dL_dG;
+                v[5] = G * dL_dalpha;
+                v[6] = dch * g0; v[7] = dch * g1; v[8] = dch * g2;
+            }
+            const Reduced9 red = wave_reduce9(v);
+            if (slot >= 0) atomicAdd(acc + 12 * (size_t)gid + slot_off, reduce9_pick(red, lane));   // one instruction, 9 lanes
         }
-    }
-    if (pend_any) {
-        const Reduced9 red = wave_reduce9(pend);
-        if (slot >= 0) atomicAdd(acc + 12 * (size_t)pend_gid + slot_off, reduce9_pick(red, lane));
     }
 }
 
@@ -384,6 +416,16 @@ __global__ void wave_sum_selftest_kernel(const float *__restrict__ in, float *__
 
 using namespace d3ga;
 
+// Tuning knob (read once): D3GA_COMPOSITE_VARIANT bit 0 = forward, bit 1 = backward fetch entry records through a
+// wave-private LDS slab (1) instead of v_readlane broadcasts (0).
+static int composite_variant() {
+    static const int v = [] {
+        const char *e = getenv("D3GA_COMPOSITE_VARIANT");
+        return e ? atoi(e) : kDefaultCompositeVariant;
+    }();
+    return v;
+}
+
 extern "C" int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const float *bg, const void *geom,
                                          const void *binning, int64_t d_capacity, void *img, float *out_color,
                                          float *out_invdepth, d3ga_stream_t stream) {
@@ -394,9 +436,14 @@ extern "C" int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const fl
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
     const ImgBuf im = carve_img(img, prm->W, prm->H);
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
-                       bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T,
-                       im.n_contrib, out_color, out_invdepth);
+    if (composite_variant() & 1)
+        hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
+                           bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
+                           im.final_T, im.n_contrib, out_color, out_invdepth);
+    else
+        hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
+                           bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
+                           im.final_T, im.n_contrib, out_color, out_invdepth);
     return check_launch(s, prm->debug);
 }
 
@@ -412,9 +459,14 @@ extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const fl
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
     const ImgBuf im = carve_img(const_cast<void *>(img), prm->W, prm->H);
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
-                       bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T,
-                       im.n_contrib, dL_dpix, acc);
+    if (composite_variant() & 2)
+        hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
+                           bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
+                           im.final_T, im.n_contrib, dL_dpix, acc);
+    else
+        hipLaunchKernelGGL(composite_bwd_kernel<false>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
+                           bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
+                           im.final_T, im.n_contrib, dL_dpix, acc);
     return check_launch(s, prm->debug);
 }
 
