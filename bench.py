@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for tests)")
+    ap.add_argument("--single-device", action="store_true", help="testing only: all ranks share cuda:0")
     ap.add_argument("--no-graph", action="store_true",
                     help="time eager launches instead of replaying the captured hipGraph of one step")
     return ap.parse_args()
@@ -141,7 +143,9 @@ def cpu_baseline(wl_name, budget_s=20.0):
 def main():
     args = parse()
     from d3ga_amd import dist as ddist
-    rank, local, world = ddist.init_process_group()
+    if args.single_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, local, world = ddist.init_process_group(args.backend)
     if world != max(args.gpus, 1):
         if rank == 0:
             print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)

@@ -12,8 +12,12 @@ bg_colors = {"white": (1.0, 1.0, 1.0), "black": (0.0, 0.0, 0.0)}
 def paste(img, crop):
     """Undo the symmetric-FoV padding of lib/batch.py:186-198 (renderer.py:36-47)."""
     left_w, right_w, top_h, bottom_h, W, H = crop[0], crop[1], crop[2], crop[3], int(crop[4]), int(crop[5])
-    img = img[:, :, :W] if left_w > right_w else img[:, :, -W:]
-    img = img[:, :H, :] if top_h > bottom_h else img[:, -H:, :]
+    # identity crops (centred principal point) are skipped: a no-op slice still costs a zero-fill + copy of the whole
+    # image in its backward
+    if W < img.shape[2]:
+        img = img[:, :, :W] if left_w > right_w else img[:, :, -W:]
+    if H < img.shape[1]:
+        img = img[:, :H, :] if top_h > bottom_h else img[:, -H:, :]
     return img
 
 
