@@ -379,7 +379,8 @@ def test_baseline_configs_c2_c4_against_oracle(name, cx, cy):
     ((m * torch.from_numpy(og["means3D"]).double()).sum() + (c * torch.from_numpy(og["cov3D"]).double()).sum()).backward()
     for mine, ref, what in ((tp.grad, tp64.grad, "tetpoints"), (b.grad, b64.grad, "barys"), (s.grad, s64.grad, "scales"),
                             (r.grad, r64.grad, "rotations")):
-        ok, mx, frac = grad_close(_np(mine), _np(ref), outlier_frac=1e-4)
+        # a Gaussian on a flipped pixel feeds its 4 cage vertices: allow a few of the 24k vertices to move
+        ok, mx, frac = grad_close(_np(mine), _np(ref), outlier_frac=1e-3 if what == "tetpoints" else 1e-4)
         assert ok, (what, mx, frac)
 
 
@@ -408,6 +409,9 @@ def test_hipgraph_replay_equals_eager():
     img_e, loss_e = step()
     torch.cuda.synchronize()
     ref_tp, ref_sh, ref_img = tp.grad.clone(), sh.grad.clone(), img_e.detach().clone()
+    # PyTorch-ROCm 2.10 segfaults in capture_end() when a tensor that still carries the grad_fn of an EARLIER backward
+    # is alive while a backward is being captured (reproduced with pure torch ops): drop the eager results first
+    del img_e, loss_e
     cnt = R.last_counters()
     R.set_capacity_policy("static", int(cnt["D"] * 1.5) + 1024)
     try:
