@@ -254,12 +254,25 @@ def main():
                        "achieved_GBs": round(alg[k] / (ms * 1e-3) / 1e9, 1),
                        "frac_hbm_peak": round(alg[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                    for k, (n, ms) in stages.items() if k in alg}
+        # HBM traffic of the compositing kernels from the committed rocprofv3 --pmc passes of this same command
+        # (tools/gpu_pmc.sh -> profiles/*.json): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH doubled per the gfx950
+        # correction of MI355X_MICROARCH.md.  None when no PMC summary for this workload is present.
+        pmc_traffic = {}
+        try:
+            pj = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
+            if os.path.exists(pj):
+                for kname, c in json.load(open(pj)).items():
+                    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                        short = kname.split("::")[-1].split("_kernel")[0]
+                        pmc_traffic[short] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+        except Exception:
+            pmc_traffic = {}
         roof = None
         comp = [k for k in ("composite_bwd", "composite_fwd") if k in kernels]
         if comp:
             k = max(comp, key=lambda n: kernels[n]["ms"])
             roof = {"kernel": k, "bound": "hbm", "achieved": kernels[k]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kernels[k]["frac_hbm_peak"], "traffic": None,
+                    "unit": "GB/s", "frac": kernels[k]["frac_hbm_peak"], "traffic": pmc_traffic.get(k),
                     "alg_bytes_per_launch": alg[k], "avg_ms": kernels[k]["ms"]}
         out = {
             "metric": "fwd+bwd frames/sec @500k Gaussians 1920x1080" if args.workload == "C3" else f"fwd+bwd frames/sec ({wl.name})",

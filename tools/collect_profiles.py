@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries from gpurun_out/ (scratch) into profiles/ (tracked).  Usage: collect_profiles.py rNN [workload]"""
+import collections, csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+wl = sys.argv[2] if len(sys.argv) > 2 else "C3"
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+out = {}
+for name in ("fetch", "write", "sq", "lds", "grbm"):
+    f = os.path.join(ROOT, "gpurun_out", f"pmc_{name}", "pmc_counter_collection.csv")
+    if not os.path.exists(f):
+        continue
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in d.items():
+        out.setdefault(k, {}).update({c: round(sum(x) / len(x), 1) for c, x in v.items()})
+if out:
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"pmc_{wl}.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{wl}.json"), "w"), indent=1)
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", "prof", "*kernel_stats.csv")):
+    shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_bench_{wl}_kernel_stats.csv"))
+b = os.path.join(ROOT, "gpurun_out", "bench.log")
+if os.path.exists(b) and os.path.getsize(b) > 10:
+    shutil.copy(b, os.path.join(ROOT, "profiles", f"{tag}_bench_{wl}.json"))
+print(sorted(os.listdir(os.path.join(ROOT, "profiles"))))
