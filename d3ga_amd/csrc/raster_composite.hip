@@ -24,7 +24,7 @@
 
 namespace d3ga {
 
-constexpr int kDefaultCompositeVariant = 3;   // LDS slabs in both directions (measured: fwd -30 %, bwd -5 %)
+constexpr int kDefaultCompositeVariant = 15;  // row-segmented kernels with LDS slabs (measured at C3: fwd 248 -> 133 us, bwd 508 -> 376 us)
 
 // ---- wavefront (64 lanes) reductions through DPP ----
 template <int CTRL, int ROW_MASK>
@@ -392,6 +392,301 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(
     }
 }
 
+// =========================================================================================================
+// Row-segmented variant.  A wavefront still owns one 8x8 quadrant, but each of its four 16-lane DPP rows owns a 4x4
+// sub-block and walks ITS OWN culled list: per batch the 64 staged entries are tested against the four sub-blocks
+// (four ballots), compacted into four per-row index lists in LDS, and iteration i makes row r process the i-th
+// entry of list r.  A 4x4 block is touched by ~1.6x fewer list entries than an 8x8 quadrant (measured at C3: 160 vs
+// 251 iterations per quadrant), and the backward's cross-lane reduction shrinks to the four row-local DPP steps.
+// =========================================================================================================
+struct RowGeom {
+    int row, px, py;
+    float x0, y0;     // sub-block origin
+};
+__device__ __forceinline__ RowGeom row_geom(const Quad &q, int lane) {
+    RowGeom g;
+    g.row = lane >> 4;
+    const int l = lane & 15;
+    const int sx = q.qx0 + ((g.row & 1) << 2), sy = q.qy0 + ((g.row >> 1) << 2);
+    g.px = sx + (l & 3);
+    g.py = sy + (l >> 2);
+    g.x0 = (float)sx; g.y0 = (float)sy;
+    return g;
+}
+// half extents of the alpha >= 1/255 ellipse (inflated); negative hx marks "never visible"
+__device__ __forceinline__ void splat_extent(float A, float B, float C, float o, float &hx, float &hy) {
+    if (o * 255.0f < 1.0f) { hx = -1.0f; hy = -1.0f; return; }
+    const float tau = 2.0f * __logf(255.0f * o) * 1.001f + 1e-4f;
+    const float idet = __builtin_amdgcn_rcpf(A * C - B * B);
+    hx = __builtin_amdgcn_sqrtf(tau * C * idet) * 1.001f + 0.02f;
+    hy = __builtin_amdgcn_sqrtf(tau * A * idet) * 1.001f + 0.02f;
+}
+__device__ __forceinline__ bool block_hit(float cx, float cy, float hx, float hy, float x0, float y0, float ext) {
+    return !(hx < 0.0f) && !(cx + hx < x0) && !(cx - hx > x0 + ext) && !(cy + hy < y0) && !(cy - hy > y0 + ext);
+}
+__device__ __forceinline__ int lanes_below(unsigned long long m) {   // popcount of m restricted to lower lanes
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+__device__ __forceinline__ float row_max_f(float v) {
+    // not needed; kept for symmetry
+    return v;
+}
+__device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {       // every lane <- max over its 16-lane row
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); v = max(v, t);
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); v = max(v, t);
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true); v = max(v, t);
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true); v = max(v, t);
+    return v;
+}
+
+// builds the four per-row lists of one staged batch; returns the per-lane count of THIS lane's row and the trip count
+__device__ __forceinline__ int build_row_lists(uint8_t (*s_list)[64], bool r0, bool r1, bool r2, bool r3, int lane, int row,
+                                               int &trip) {
+    const unsigned long long m0 = __ballot(r0), m1 = __ballot(r1), m2 = __ballot(r2), m3 = __ballot(r3);
+    if (r0) s_list[0][lanes_below(m0)] = (uint8_t)lane;
+    if (r1) s_list[1][lanes_below(m1)] = (uint8_t)lane;
+    if (r2) s_list[2][lanes_below(m2)] = (uint8_t)lane;
+    if (r3) s_list[3][lanes_below(m3)] = (uint8_t)lane;
+    const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
+    trip = max(max(c0, c1), max(c2, c3));
+    return row == 0 ? c0 : (row == 1 ? c1 : (row == 2 ? c2 : c3));
+}
+
+__global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
+    int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+    uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
+    const float4 *__restrict__ rgb_invd, const float *__restrict__ bg, float *__restrict__ final_T,
+    uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_invdepth) {
+    const Quad q = quad_of_block(gx, gy);
+    if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const RowGeom rg = row_geom(q, lane);
+    const bool inside = rg.px < W && rg.py < H;
+    const float fx = (float)rg.px, fy = (float)rg.py;
+    const float bx0 = (float)q.qx0, by0 = (float)q.qy0;
+    const uint32_t begin = (uint32_t)min((uint64_t)tile_start[q.tile], dcap);
+    const uint32_t end = (uint32_t)min((uint64_t)tile_start[q.tile + 1], dcap);
+
+    __shared__ float2 s_xy[64];
+    __shared__ float4 s_co[64];
+    __shared__ float4 s_rgb[64];
+    __shared__ uint8_t s_list[4][64];
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    float2 nxy = make_float2(0.f, 0.f);
+    float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (begin + lane < end) {
+        const uint32_t g = point_list[begin + lane];
+        nxy = xy[g]; nco = conic_o[g]; nrgb = rgb_invd[g];
+    }
+    for (uint32_t base = begin; base < end; base += 64) {
+        const float2 cxy = nxy;
+        const float4 cco = nco, crgb = nrgb;
+        const bool have = base + lane < end;
+        const uint32_t nb = base + 64;
+        if (nb + lane < end) {
+            const uint32_t g = point_list[nb + lane];
+            nxy = xy[g]; nco = conic_o[g]; nrgb = rgb_invd[g];
+        }
+        float hx, hy;
+        splat_extent(cco.x, cco.y, cco.z, cco.w, hx, hy);
+        if (!have) hx = -1.0f;
+        __builtin_amdgcn_wave_barrier();                  // previous batch's LDS reads are done (program order)
+        s_xy[lane] = cxy; s_co[lane] = cco; s_rgb[lane] = crgb;
+        int trip;
+        const int my_cnt = build_row_lists(s_list, block_hit(cxy.x, cxy.y, hx, hy, bx0, by0, 3.0f),
+                                           block_hit(cxy.x, cxy.y, hx, hy, bx0 + 4.0f, by0, 3.0f),
+                                           block_hit(cxy.x, cxy.y, hx, hy, bx0, by0 + 4.0f, 3.0f),
+                                           block_hit(cxy.x, cxy.y, hx, hy, bx0 + 4.0f, by0 + 4.0f, 3.0f), lane, rg.row,
+                                           trip);
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < trip; i += 2) {
+            // two list positions per iteration, straight-line; rows whose list is exhausted idle (valid = false)
+            const bool v0 = i < my_cnt, v1 = i + 1 < my_cnt;
+            // (& 63: slots past a row's count hold stale bytes; they are only ever read with valid == false)
+            const int j0 = s_list[rg.row][i] & 63, j1 = s_list[rg.row][(i + 1) & 63] & 63;
+            const float2 e0xy = s_xy[j0], e1xy = s_xy[j1];
+            const float4 e0co = s_co[j0], e1co = s_co[j1];
+            const float4 e0rgb = s_rgb[j0], e1rgb = s_rgb[j1];
+            float al0, G0, al1, G1;
+            bool ok0, ok1;
+            splat_eval(e0xy.x - fx, e0xy.y - fy, e0co.x, e0co.y, e0co.z, e0co.w, al0, G0, ok0);
+            splat_eval(e1xy.x - fx, e1xy.y - fy, e1co.x, e1co.y, e1co.z, e1co.w, al1, G1, ok1);
+            {
+                const bool act = ok0 && v0 && !done;
+                const float test_T = T * (1.0f - al0);
+                const bool sat = act && (test_T < kTmin);
+                const bool bl = act && !sat;
+                const float w = bl ? al0 * T : 0.f;
+                C0 += e0rgb.x * w; C1 += e0rgb.y * w; C2 += e0rgb.z * w; Dp += e0rgb.w * w;
+                T = bl ? test_T : T;
+                last = bl ? (base - begin + (uint32_t)j0 + 1u) : last;   // 1-based position in the FULL tile list
+                done = done || sat;
+            }
+            {
+                const bool act = ok1 && v1 && !done;
+                const float test_T = T * (1.0f - al1);
+                const bool sat = act && (test_T < kTmin);
+                const bool bl = act && !sat;
+                const float w = bl ? al1 * T : 0.f;
+                C0 += e1rgb.x * w; C1 += e1rgb.y * w; C2 += e1rgb.z * w; Dp += e1rgb.w * w;
+                T = bl ? test_T : T;
+                last = bl ? (base - begin + (uint32_t)j1 + 1u) : last;
+                done = done || sat;
+            }
+            if (__all(done)) { i = trip; base = end; }     // whole quadrant saturated
+        }
+    }
+    if (inside) {
+        const size_t pid = (size_t)rg.py * W + rg.px;
+        const size_t hw = (size_t)H * W;
+        final_T[pid] = T;
+        n_contrib[pid] = last;
+        out_color[pid] = C0 + T * bg[0];
+        out_color[hw + pid] = C1 + T * bg[1];
+        out_color[2 * hw + pid] = C2 + T * bg[2];
+        if (out_invdepth) out_invdepth[pid] = Dp;
+    }
+}
+
+
+__global__ __launch_bounds__(64) void composite_bwd_rows_kernel(
+    int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+    uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
+    const float4 *__restrict__ rgb_invd, const float *__restrict__ bg, const float *__restrict__ final_T,
+    const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix, float *__restrict__ acc) {
+    const Quad q = quad_of_block(gx, gy);
+    if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const RowGeom rg = row_geom(q, lane);
+    const bool inside = rg.px < W && rg.py < H;
+    const float fx = (float)rg.px, fy = (float)rg.py;
+    const float bx0 = (float)q.qx0, by0 = (float)q.qy0;
+    const uint32_t begin = (uint32_t)min((uint64_t)tile_start[q.tile], dcap);
+    const uint32_t end = (uint32_t)min((uint64_t)tile_start[q.tile + 1], dcap);
+    if (begin >= end) return;                              // uniform: empty tile
+
+    const size_t pid = (size_t)rg.py * W + rg.px;
+    const size_t hw = (size_t)H * W;
+    const float T_final = inside ? final_T[pid] : 0.f;
+    const uint32_t last = inside ? n_contrib[pid] : 0u;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (inside) { g0 = dL_dpix[pid]; g1 = dL_dpix[hw + pid]; g2 = dL_dpix[2 * hw + pid]; }
+    const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    const uint32_t rowlast = row_max_u32(last);            // deepest position used inside this lane's 4x4 block
+    const uint32_t maxlast = wave_max_u32(rowlast);
+    if (maxlast == 0) return;
+    // every lane needs all four row limits for the per-block tests of ITS staged entry
+    const uint32_t rl0 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 0), rl1 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 16);
+    const uint32_t rl2 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 32), rl3 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 48);
+
+    __shared__ float2 s_xy[64];
+    __shared__ float4 s_co[64];
+    __shared__ float4 s_rgb[64];
+    __shared__ uint32_t s_id[64];
+    __shared__ uint8_t s_list[4][64];
+
+    float T = T_final;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    const int l16 = lane & 15;
+    const int slot_off = l16 < 2 ? l16 : l16 + 1;          // lanes 0..8 of each row publish value l16; acc layout 0,1|3,4,5|6|7,8,9
+
+    float2 nxy = make_float2(0.f, 0.f);
+    float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t nid = 0;
+    if ((uint32_t)lane < maxlast) {
+        nid = point_list[begin + (maxlast - 1 - lane)];
+        nxy = xy[nid]; nco = conic_o[nid]; nrgb = rgb_invd[nid];
+    }
+    for (uint32_t hi = maxlast; hi > 0; hi = hi > 64 ? hi - 64 : 0) {
+        const float2 cxy = nxy;
+        const float4 cco = nco, crgb = nrgb;
+        const uint32_t cid = nid;
+        const bool have = (uint32_t)lane < hi;
+        if (hi > 64 && (uint32_t)lane < hi - 64) {
+            nid = point_list[begin + (hi - 64 - 1 - lane)];
+            nxy = xy[nid]; nco = conic_o[nid]; nrgb = rgb_invd[nid];
+        }
+        float hx, hy;
+        splat_extent(cco.x, cco.y, cco.z, cco.w, hx, hy);
+        if (!have) hx = -1.0f;
+        const uint32_t mypos = hi - (uint32_t)lane;        // list position of the entry this lane staged
+        __builtin_amdgcn_wave_barrier();
+        s_xy[lane] = cxy; s_co[lane] = cco; s_rgb[lane] = crgb; s_id[lane] = cid;
+        int trip;
+        const int my_cnt = build_row_lists(
+            s_list, mypos <= rl0 && block_hit(cxy.x, cxy.y, hx, hy, bx0, by0, 3.0f),
+            mypos <= rl1 && block_hit(cxy.x, cxy.y, hx, hy, bx0 + 4.0f, by0, 3.0f),
+            mypos <= rl2 && block_hit(cxy.x, cxy.y, hx, hy, bx0, by0 + 4.0f, 3.0f),
+            mypos <= rl3 && block_hit(cxy.x, cxy.y, hx, hy, bx0 + 4.0f, by0 + 4.0f, 3.0f), lane, rg.row, trip);
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < trip; ++i) {
+            const bool valid = i < my_cnt;
+            const int j = s_list[rg.row][i] & 63;          // ascending staged lane = back-to-front (& 63: stale slots)
+            const uint32_t pos = hi - (uint32_t)j;
+            const float2 exy = s_xy[j];
+            const float4 eco = s_co[j];
+            const float dx = exy.x - fx, dy = exy.y - fy;
+            float al, G;
+            bool ok;
+            splat_eval(dx, dy, eco.x, eco.y, eco.z, eco.w, al, G, ok);
+            const bool hit = ok && valid && inside && pos <= last;
+            const unsigned long long hm = __ballot(hit);
+            if (hm == 0) continue;                         // wave-uniform skip
+            const float4 ergb = s_rgb[j];
+            const uint32_t gid = s_id[j];
+            // NOTE: keep this body in the kernel (no helper functions / lambdas over v[]): hipcc then turns the
+            // lane-indexed select below into a scratch-memory table lookup.  A divergent `if (hit)` block beats
+            // computing masked partials for every lane (measured 376 vs 410 us at C3).
+            float v[kNG];
+#pragma unroll
+            for (int k = 0; k < kNG; ++k) v[k] = 0.f;
+            if (hit) {
+                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - al);
+                T = T * inv1ma;
+                const float dch = al * T;
+                a0 = last_alpha * lc0 + (1.f - last_alpha) * a0;
+                a1 = last_alpha * lc1 + (1.f - last_alpha) * a1;
+                a2 = last_alpha * lc2 + (1.f - last_alpha) * a2;
+                lc0 = ergb.x; lc1 = ergb.y; lc2 = ergb.z;
+                float dL_dalpha = ((ergb.x - a0) * g0 + (ergb.y - a1) * g1 + (ergb.z - a2) * g2) * T;
+                last_alpha = al;
+                dL_dalpha += (-T_final * inv1ma) * bg_dot;
+                const float dL_dG = eco.w * dL_dalpha;     // the 0.99 clamp passes the gradient through
+                const float gdx = G * dx, gdy = G * dy;
+                v[0] = dL_dG * (-gdx * eco.x - gdy * eco.y) * ddelx_dx;
+                v[1] = dL_dG * (-gdy * eco.z - gdx * eco.y) * ddely_dy;
+                v[2] = -0.5f * gdx * dx * dL_dG;
+                v[3] = -0.5f * gdx * dy * dL_dG;            // half of dL/dB, doubled in the per-Gaussian backward
+                v[4] = -0.5f * gdy * dy * dL_dG;
+                v[5] = G * dL_dalpha;
+                v[6] = dch * g0; v[7] = dch * g1; v[8] = dch * g2;
+            }
+            // row-local reduction: every lane of a row ends up with the row's nine totals
+#pragma unroll
+            for (int k = 0; k < kNG; ++k) v[k] = dpp_add<0xB1, 0xf>(v[k]);
+#pragma unroll
+            for (int k = 0; k < kNG; ++k) v[k] = dpp_add<0x4E, 0xf>(v[k]);
+#pragma unroll
+            for (int k = 0; k < kNG; ++k) v[k] = dpp_add<0x141, 0xf>(v[k]);
+#pragma unroll
+            for (int k = 0; k < kNG; ++k) v[k] = dpp_add<0x140, 0xf>(v[k]);
+            float mine = v[0];
+#pragma unroll
+            for (int k = 1; k < kNG; ++k) mine = (l16 == k) ? v[k] : mine;
+            const bool row_any = ((hm >> (rg.row << 4)) & 0xffffull) != 0;
+            // lanes 0..8 of every row that was hit: one atomic instruction, up to 36 active lanes
+            if (l16 < kNG && row_any) atomicAdd(acc + 12 * (size_t)gid + slot_off, mine);
+        }
+    }
+}
+
 // self-test kernel for the cross-lane reductions (tests/).  Per wave w with inputs x[0..63]:
 //   out[10 w + k] = sum_l (k+1) x[l] + k   for k = 0..8, through wave_reduce9 and the lane mapping the backward uses;
 //   out[10 w + 9] = sum_l x[l]              through wave_sum / wave_sum_multi (or -1e30 if those two disagree).
@@ -417,7 +712,8 @@ __global__ void wave_sum_selftest_kernel(const float *__restrict__ in, float *__
 using namespace d3ga;
 
 // Tuning knob (read once): D3GA_COMPOSITE_VARIANT bit 0 = forward, bit 1 = backward fetch entry records through a
-// wave-private LDS slab (1) instead of v_readlane broadcasts (0).
+// wave-private LDS slab (1) instead of v_readlane broadcasts (0); bit 2 = forward, bit 3 = backward use the
+// row-segmented kernels (four 4x4 blocks per wavefront).
 static int composite_variant() {
     static const int v = [] {
         const char *e = getenv("D3GA_COMPOSITE_VARIANT");
@@ -436,7 +732,11 @@ extern "C" int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const fl
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
     const ImgBuf im = carve_img(img, prm->W, prm->H);
-    if (composite_variant() & 1)
+    if (composite_variant() & 4)
+        hipLaunchKernelGGL(composite_fwd_rows_kernel, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
+                           bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
+                           im.final_T, im.n_contrib, out_color, out_invdepth);
+    else if (composite_variant() & 1)
         hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
                            bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
                            im.final_T, im.n_contrib, out_color, out_invdepth);
@@ -459,7 +759,11 @@ extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const fl
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
     const ImgBuf im = carve_img(const_cast<void *>(img), prm->W, prm->H);
-    if (composite_variant() & 2)
+    if (composite_variant() & 8)
+        hipLaunchKernelGGL(composite_bwd_rows_kernel, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
+                           gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
+                           im.final_T, im.n_contrib, dL_dpix, acc);
+    else if (composite_variant() & 2)
         hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
                            bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
                            im.final_T, im.n_contrib, dL_dpix, acc);

@@ -1,16 +1,17 @@
 #!/bin/bash
-# A/B of composite variants inside one box: interleaved rounds
+# A/B of composite variants inside one box: interleaved rounds.  usage: gpu_ab.sh "3 7 11 15" [test_variant]
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+VARS=${1:-"3 15"}
 : > gpurun_out/ab.log
 for round in 1 2; do
- for v in 0 1 2 3; do
+ for v in $VARS; do
   echo "variant $v round $round" >> gpurun_out/ab.log
   D3GA_COMPOSITE_VARIANT=$v timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k:v['ms'] for k,v in d['kernels'].items()})" >> gpurun_out/ab.log
  done
 done
-D3GA_COMPOSITE_VARIANT=3 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 >> gpurun_out/ab.log
+if [ -n "$2" ]; then D3GA_COMPOSITE_VARIANT=$2 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 >> gpurun_out/ab.log; fi
 cat gpurun_out/ab.log
