@@ -10,8 +10,9 @@
 //   tile_scan_kernel      one workgroup: exclusive prefix of the tile histogram, D, overflow flag
 //   tile_scatter_kernel   one thread per Gaussian: emit its key into every tile of its rectangle; slots are reserved
 //                         per (block, tile) through an LDS window (d3ga_internal.h: TileWindow)
-//   tile_sort_lds_kernel  one workgroup per tile: LDS bitonic sort (lists up to CAP entries)
-//   tile_sort_global_kernel  fallback for longer lists: same network on global memory
+//   tile_sort_lds_kernel       one workgroup per tile: LDS bitonic sort, 8 keys per thread (lists up to 2048 entries)
+//   tile_sort_lds_list_kernel  longer lists (up to 8192): 64 KB LDS, persistent grid over a device-side work list
+//   tile_sort_global_list_kernel  fallback for even longer lists: same network on global memory
 #include "d3ga_internal.h"
 
 namespace d3ga {
@@ -21,7 +22,10 @@ constexpr int kScanBlock = 1024;
 __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(int tiles, const uint32_t *__restrict__ count,
                                                                uint32_t *__restrict__ start,
                                                                uint32_t *__restrict__ cursor,
-                                                               uint32_t *__restrict__ counters, uint64_t dcap) {
+                                                               uint32_t *__restrict__ counters, uint64_t dcap,
+                                                               uint32_t *__restrict__ big_tiles,
+                                                               uint32_t *__restrict__ huge_tiles, uint32_t n_small,
+                                                               uint32_t n_large) {
     __shared__ uint32_t s_sum[kScanBlock];
     __shared__ uint32_t s_max;
     const int tid = threadIdx.x;
@@ -45,9 +49,13 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(int tiles, const 
     }
     uint32_t run = s_sum[tid] - sum;
     for (int t = b; t < e; ++t) {
+        const uint32_t c = count[t];
         start[t] = run;
         cursor[t] = run;
-        run += count[t];
+        run += c;
+        // work lists for the long-list sort kernels (usually empty: those launches then cost one tiny grid)
+        if (c > n_large) huge_tiles[atomicAdd(&counters[D3GA_CNT_HUGE], 1u)] = (uint32_t)t;
+        else if (c > n_small) big_tiles[atomicAdd(&counters[D3GA_CNT_BIG], 1u)] = (uint32_t)t;
     }
     if (tid == kScanBlock - 1) {
         const uint32_t total = s_sum[kScanBlock - 1];
@@ -146,6 +154,9 @@ __device__ __forceinline__ void cmpex(uint64_t &a, uint64_t &b) {
     const uint64_t lo = min(a, b), hi = max(a, b);
     a = lo; b = hi;
 }
+// LDS index with one pad slot per 8 keys: a thread's 8 consecutive keys start 72 B apart, so the 16-byte row reads /
+// writes of the register phases hit distinct banks.
+#define PH(i) ((i) + ((i) >> 3))
 __device__ __forceinline__ void bitonic_sort_regs8(uint64_t *k, int n, int tid, int nthreads) {
     int n2 = 8;
     while (n2 < n) n2 <<= 1;
@@ -155,7 +166,7 @@ __device__ __forceinline__ void bitonic_sort_regs8(uint64_t *k, int n, int tid, 
     uint64_t r[8];
     if (act) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = (base + i < n) ? k[base + i] : ~0ull;
+        for (int i = 0; i < 8; ++i) r[i] = (base + i < n) ? k[PH(base + i)] : ~0ull;
         cmpex(r[0], r[1]); cmpex(r[2], r[3]); cmpex(r[4], r[5]); cmpex(r[6], r[7]);      // size 2
         cmpex(r[0], r[3]); cmpex(r[1], r[2]); cmpex(r[4], r[7]); cmpex(r[5], r[6]);      // size 4: flip
         cmpex(r[0], r[1]); cmpex(r[2], r[3]); cmpex(r[4], r[5]); cmpex(r[6], r[7]);      //         disperse 1
@@ -164,7 +175,7 @@ __device__ __forceinline__ void bitonic_sort_regs8(uint64_t *k, int n, int tid, 
         cmpex(r[0], r[1]); cmpex(r[2], r[3]); cmpex(r[4], r[5]); cmpex(r[6], r[7]);      //         disperse 1
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (base + i < n) k[base + i] = r[i];
+            if (base + i < n) k[PH(base + i)] = r[i];
     }
     __syncthreads();
     for (int size = 16; size <= n2; size <<= 1) {
@@ -173,8 +184,8 @@ __device__ __forceinline__ void bitonic_sort_regs8(uint64_t *k, int n, int tid, 
             const int blk = i / hs, off = i - blk * hs;
             const int lo = blk * size + off, hi = blk * size + size - 1 - off;
             if (hi < n) {
-                const uint64_t a = k[lo], b = k[hi];
-                if (b < a) { k[lo] = b; k[hi] = a; }
+                const uint64_t a = k[PH(lo)], b = k[PH(hi)];
+                if (b < a) { k[PH(lo)] = b; k[PH(hi)] = a; }
             }
         }
         __syncthreads();
@@ -183,54 +194,90 @@ __device__ __forceinline__ void bitonic_sort_regs8(uint64_t *k, int n, int tid, 
                 const int blk = i / j, off = i - blk * j;
                 const int lo = blk * 2 * j + off, hi = lo + j;
                 if (hi < n) {
-                    const uint64_t a = k[lo], b = k[hi];
-                    if (b < a) { k[lo] = b; k[hi] = a; }
+                    const uint64_t a = k[PH(lo)], b = k[PH(hi)];
+                    if (b < a) { k[PH(lo)] = b; k[PH(hi)] = a; }
                 }
             }
             __syncthreads();
         }
         if (act) {                                            // disperse 4, 2, 1 (registers)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = (base + i < n) ? k[base + i] : ~0ull;
+            for (int i = 0; i < 8; ++i) r[i] = (base + i < n) ? k[PH(base + i)] : ~0ull;
             cmpex(r[0], r[4]); cmpex(r[1], r[5]); cmpex(r[2], r[6]); cmpex(r[3], r[7]);
             cmpex(r[0], r[2]); cmpex(r[1], r[3]); cmpex(r[4], r[6]); cmpex(r[5], r[7]);
             cmpex(r[0], r[1]); cmpex(r[2], r[3]); cmpex(r[4], r[5]); cmpex(r[6], r[7]);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (base + i < n) k[base + i] = r[i];
+                if (base + i < n) k[PH(base + i)] = r[i];
         }
         __syncthreads();
     }
 }
+#undef PH
 
+template <int BLOCK, int CAP>
+__device__ __forceinline__ void sort_one_tile_lds(uint64_t *s_key, int tile, const uint32_t *__restrict__ start,
+                                                  const uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
+                                                  uint64_t dcap) {
+    constexpr bool kRegs = CAP <= 8 * BLOCK;
+    const uint64_t b64 = min((uint64_t)start[tile], dcap), e64 = min((uint64_t)start[tile + 1], dcap);
+    const int n = min((int)(e64 - b64), CAP);             // (lists are clamped only if the capacity overflowed)
+    const int tid = threadIdx.x;
+    if constexpr (kRegs) {
+        for (int i = tid; i < n; i += BLOCK) s_key[i + (i >> 3)] = keys[b64 + i];
+        __syncthreads();
+        bitonic_sort_regs8(s_key, n, tid, BLOCK);
+        for (int i = tid; i < n; i += BLOCK) point_list[b64 + i] = (uint32_t)s_key[i + (i >> 3)];
+    } else {
+        for (int i = tid; i < n; i += BLOCK) s_key[i] = keys[b64 + i];
+        __syncthreads();
+        bitonic_sort(s_key, n, tid, BLOCK);
+        for (int i = tid; i < n; i += BLOCK) point_list[b64 + i] = (uint32_t)s_key[i];
+    }
+}
+
+// one workgroup per tile; tiles with longer lists are left to the list-driven kernels below
 template <int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void tile_sort_lds_kernel(const uint32_t *__restrict__ start,
                                                               const uint64_t *__restrict__ keys,
-                                                              uint32_t *__restrict__ point_list, uint64_t dcap,
-                                                              int n_min) {
-    __shared__ uint64_t s_key[CAP];
+                                                              uint32_t *__restrict__ point_list, uint64_t dcap) {
+    constexpr bool kRegs = CAP <= 8 * BLOCK;
+    __shared__ uint64_t s_key[kRegs ? CAP + CAP / 8 : CAP];
     const int tile = blockIdx.x;
-    const uint64_t b64 = min((uint64_t)start[tile], dcap), e64 = min((uint64_t)start[tile + 1], dcap);
-    const int n = (int)(e64 - b64);
-    if (n <= n_min || n > CAP) return;                 // another launch owns this tile
-    const int tid = threadIdx.x;
-    for (int i = tid; i < n; i += BLOCK) s_key[i] = keys[b64 + i];
-    __syncthreads();
-    if constexpr (CAP <= 8 * BLOCK) bitonic_sort_regs8(s_key, n, tid, BLOCK);
-    else bitonic_sort(s_key, n, tid, BLOCK);
-    for (int i = tid; i < n; i += BLOCK) point_list[b64 + i] = (uint32_t)s_key[i];
+    const uint32_t n = start[tile + 1] - start[tile];
+    if (n == 0 || n > (uint32_t)CAP) return;
+    sort_one_tile_lds<BLOCK, CAP>(s_key, tile, start, keys, point_list, dcap);
 }
 
-__global__ __launch_bounds__(1024) void tile_sort_global_kernel(const uint32_t *__restrict__ start, uint64_t *keys,
-                                                                uint32_t *__restrict__ point_list, uint64_t dcap,
-                                                                int n_min) {
-    const int tile = blockIdx.x;
-    const uint64_t b64 = min((uint64_t)start[tile], dcap), e64 = min((uint64_t)start[tile + 1], dcap);
-    const int n = (int)(e64 - b64);
-    if (n <= n_min) return;
+// persistent grid over the work list written by tile_scan_kernel (tiles with CAP_SMALL < n <= CAP)
+template <int BLOCK, int CAP>
+__global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_t *__restrict__ start,
+                                                                   const uint64_t *__restrict__ keys,
+                                                                   uint32_t *__restrict__ point_list, uint64_t dcap,
+                                                                   const uint32_t *__restrict__ list,
+                                                                   const uint32_t *__restrict__ list_count) {
+    __shared__ uint64_t s_key[CAP];
+    const uint32_t count = *list_count;
+    for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+        __syncthreads();
+        sort_one_tile_lds<BLOCK, CAP>(s_key, (int)list[k], start, keys, point_list, dcap);
+    }
+}
+
+__global__ __launch_bounds__(1024) void tile_sort_global_list_kernel(const uint32_t *__restrict__ start, uint64_t *keys,
+                                                                     uint32_t *__restrict__ point_list, uint64_t dcap,
+                                                                     const uint32_t *__restrict__ list,
+                                                                     const uint32_t *__restrict__ list_count) {
+    const uint32_t count = *list_count;
     const int tid = threadIdx.x;
-    bitonic_sort(keys + b64, n, tid, 1024);
-    for (int i = tid; i < n; i += 1024) point_list[b64 + i] = (uint32_t)keys[b64 + i];
+    for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+        const int tile = (int)list[k];
+        const uint64_t b64 = min((uint64_t)start[tile], dcap), e64 = min((uint64_t)start[tile + 1], dcap);
+        const int n = (int)(e64 - b64);
+        __syncthreads();
+        bitonic_sort(keys + b64, n, tid, 1024);
+        for (int i = tid; i < n; i += 1024) point_list[b64 + i] = (uint32_t)keys[b64 + i];
+    }
 }
 
 }  // namespace d3ga
@@ -250,19 +297,22 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
     BinBuf bin = carve_bin(binning, tiles, d_capacity);
     GeomBuf g = carve_geom(geom, prm->P);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(kScanBlock), 0, s, tiles, bin.tile_count, bin.tile_start,
-                       bin.tile_cursor, bin.counters, (uint64_t)d_capacity);
+                       bin.tile_cursor, bin.counters, (uint64_t)d_capacity, bin.big_tiles, bin.huge_tiles,
+                       (uint32_t)kSortSmall, (uint32_t)kSortLarge);
     D3GA_TRY(check_launch(s, prm->debug));
     if (prm->P == 0 || d_capacity == 0) return D3GA_OK;
     hipLaunchKernelGGL(tile_scatter_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, prm->P, gx, g.rect,
                        g.depth, bin.tile_cursor, bin.keys, (uint64_t)d_capacity);
     D3GA_TRY(check_launch(s, prm->debug));
     hipLaunchKernelGGL((tile_sort_lds_kernel<256, kSortSmall>), dim3(tiles), dim3(256), 0, s, bin.tile_start, bin.keys,
-                       bin.point_list, (uint64_t)d_capacity, 0);
+                       bin.point_list, (uint64_t)d_capacity);
     D3GA_TRY(check_launch(s, prm->debug));
-    hipLaunchKernelGGL((tile_sort_lds_kernel<1024, kSortLarge>), dim3(tiles), dim3(1024), 0, s, bin.tile_start, bin.keys,
-                       bin.point_list, (uint64_t)d_capacity, kSortSmall);
+    // long lists: small persistent grids driven by the device-side work lists (empty for avatar-sized scenes)
+    const int lgrid = tiles < 256 ? tiles : 256;
+    hipLaunchKernelGGL((tile_sort_lds_list_kernel<1024, kSortLarge>), dim3(lgrid), dim3(1024), 0, s, bin.tile_start,
+                       bin.keys, bin.point_list, (uint64_t)d_capacity, bin.big_tiles, bin.counters + D3GA_CNT_BIG);
     D3GA_TRY(check_launch(s, prm->debug));
-    hipLaunchKernelGGL(tile_sort_global_kernel, dim3(tiles), dim3(1024), 0, s, bin.tile_start, bin.keys, bin.point_list,
-                       (uint64_t)d_capacity, kSortLarge);
+    hipLaunchKernelGGL(tile_sort_global_list_kernel, dim3(lgrid), dim3(1024), 0, s, bin.tile_start, bin.keys,
+                       bin.point_list, (uint64_t)d_capacity, bin.huge_tiles, bin.counters + D3GA_CNT_HUGE);
     return check_launch(s, prm->debug);
 }

@@ -458,3 +458,25 @@ def test_multi_view_gradient_sum_matches_sequential():
     sum(render(bt, pk(), bg)["render"].mean() for bt in batches).div(V).backward()
     mean_of_views = torch.stack(per_view).mean(0)
     assert rel_err(_np(sh.grad), _np(mean_of_views)) < 1e-5
+
+
+@pytest.mark.parametrize("name,scale_mult,min_longest", [("T1", 14.0, 2049), ("C1", 30.0, 8193)])
+def test_long_tile_lists_use_the_large_sort_paths(name, scale_mult, min_longest):
+    """Tiles with more than 2048 / 8192 entries go through the 64 KB-LDS and the global-memory sort kernels (driven by
+    device-side work lists); order and image must still match the oracle."""
+    from d3ga_amd import rasterizer as R
+    inp = scene_inputs(name, scale_mult=scale_mult)
+    bg = torch.tensor([0.0, 0.3, 0.6])
+    rast = R.GaussianRasterizer(_settings(inp, bg, 0))
+    with torch.no_grad():
+        color, radii, _ = rast(means3D=inp["means3D"].to(DEV), means2D=None, opacities=inp["opacities"].to(DEV),
+                               colors_precomp=inp["rgb"].to(DEV), cov3D_precomp=inp["cov6"].to(DEV))
+    cnt = R.last_counters()
+    assert cnt["max_tile"] >= min_longest, cnt
+    start, plist, _ = R.last_tile_lists(inp["W"], inp["H"])
+    ocolor, oradii, _, ctx, _ = _oracle(inp, bg, None, 0, use_sh=False)
+    ostart, olist = rc.tile_lists(ctx)
+    np.testing.assert_array_equal(_np(start), ostart)
+    np.testing.assert_array_equal(_np(plist), olist)
+    ok, mx, frac = image_close(_np(color), ocolor)
+    assert ok, (mx, frac)
