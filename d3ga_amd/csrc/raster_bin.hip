@@ -215,11 +215,10 @@ __device__ __forceinline__ void bitonic_sort_regs8(uint64_t *k, int n, int tid, 
 }
 #undef PH
 
-template <int BLOCK, int CAP>
+template <int BLOCK, int CAP, bool kRegs>
 __device__ __forceinline__ void sort_one_tile_lds(uint64_t *s_key, int tile, const uint32_t *__restrict__ start,
                                                   const uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
                                                   uint64_t dcap) {
-    constexpr bool kRegs = CAP <= 8 * BLOCK;
     const uint64_t b64 = min((uint64_t)start[tile], dcap), e64 = min((uint64_t)start[tile + 1], dcap);
     const int n = min((int)(e64 - b64), CAP);             // (lists are clamped only if the capacity overflowed)
     const int tid = threadIdx.x;
@@ -241,12 +240,12 @@ template <int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void tile_sort_lds_kernel(const uint32_t *__restrict__ start,
                                                               const uint64_t *__restrict__ keys,
                                                               uint32_t *__restrict__ point_list, uint64_t dcap) {
-    constexpr bool kRegs = CAP <= 8 * BLOCK;
-    __shared__ uint64_t s_key[kRegs ? CAP + CAP / 8 : CAP];
+    static_assert(CAP <= 8 * BLOCK, "8 keys per thread");
+    __shared__ uint64_t s_key[CAP + CAP / 8];             // padded layout of bitonic_sort_regs8
     const int tile = blockIdx.x;
     const uint32_t n = start[tile + 1] - start[tile];
     if (n == 0 || n > (uint32_t)CAP) return;
-    sort_one_tile_lds<BLOCK, CAP>(s_key, tile, start, keys, point_list, dcap);
+    sort_one_tile_lds<BLOCK, CAP, true>(s_key, tile, start, keys, point_list, dcap);
 }
 
 // persistent grid over the work list written by tile_scan_kernel (tiles with CAP_SMALL < n <= CAP)
@@ -260,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_
     const uint32_t count = *list_count;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
         __syncthreads();
-        sort_one_tile_lds<BLOCK, CAP>(s_key, (int)list[k], start, keys, point_list, dcap);
+        sort_one_tile_lds<BLOCK, CAP, false>(s_key, (int)list[k], start, keys, point_list, dcap);   // 64 KB: unpadded
     }
 }
 
