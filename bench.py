@@ -79,6 +79,7 @@ class Frame:
 
     def step(self):
         from d3ga_amd.cage_deform import cage_deform, lbs_cage
+        from d3ga_amd.losses import l1_loss
         from d3ga_amd.renderer import render
         p = self.params
         tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
@@ -87,7 +88,7 @@ class Frame:
         pkg = {"means3D": means, "cov3D_precomp": cov6, "opacities": torch.sigmoid(p["opacity"]),
                "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
         img = render(self.batch, pkg, self.bg)["render"]
-        loss = (img - self.target).abs().mean()
+        loss = l1_loss(img, self.target)              # fused mean |img - target| (utils/loss_utils.py:29)
         loss.backward()
         return loss
 

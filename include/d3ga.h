@@ -177,6 +177,14 @@ int d3ga_raster_mark_visible(int32_t P, const float *means3D, const float *viewm
  * largest minimum barycentric weight (weights may be negative) and active[i] = 0.
  *   points (P,3), tetra_corners (T,4,3) -> barys (P,4), tetra_id (P) int32, active (P) uint8.
  * ------------------------------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------------------------------
+ * Loss tail.  Replaces utils/loss_utils.py:29  l1_loss = |network_output - gt|.mean().
+ *   fwd: out[0] = mean |a - b| over n floats (out is zeroed by the call; float atomics across workgroups).
+ *   bwd: grad_a = g[0] * sign(a - b) / n   (g: device scalar).   a, b, grad_a 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------------- */
+int d3ga_l1_mean_fwd(int64_t n, const float *a, const float *b, float *out, d3ga_stream_t stream);
+int d3ga_l1_mean_bwd(int64_t n, const float *a, const float *b, const float *g, float *grad_a, d3ga_stream_t stream);
+
 /* Test hook, not part of the drop-in surface: the 64-lane reductions of the compositing backward.  n multiple of 256;
  * in (n) -> out (10*n/64): per wavefront w, out[10w+k] = sum_l ((k+1) in[l] + k/64) for k<9, out[10w+9] = sum_l in[l]. */
 int d3ga_selftest_wave_sum(int n, const float *in, float *out, d3ga_stream_t stream);

@@ -480,3 +480,18 @@ def test_long_tile_lists_use_the_large_sort_paths(name, scale_mult, min_longest)
     np.testing.assert_array_equal(_np(plist), olist)
     ok, mx, frac = image_close(_np(color), ocolor)
     assert ok, (mx, frac)
+
+
+def test_fused_l1_loss_matches_torch():
+    from d3ga_amd.losses import l1_loss
+    g = torch.Generator().manual_seed(21)
+    for shape in ((3, 1080, 1920), (3, 37, 53), (5,)):
+        a = torch.rand(shape, generator=g).to(DEV).requires_grad_(True)
+        b = torch.rand(shape, generator=g).to(DEV)
+        b.view(-1)[0] = a.detach().view(-1)[0]              # an exact tie: sign(0) = 0
+        loss = l1_loss(a, b)
+        ref = (a.detach().double() - b.double()).abs().mean()
+        assert abs(float(loss) - float(ref)) < 1e-6
+        (loss * 3.0).backward()
+        gref = 3.0 * torch.sign(a.detach() - b) / a.numel()
+        assert torch.allclose(a.grad, gref, atol=1e-12)
