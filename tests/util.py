@@ -13,7 +13,7 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-def scene_inputs(name="T0", seed=17, azimuth=0.4, scale_mult=1.0, cx=None, cy=None):
+def scene_inputs(name="T0", seed=17, azimuth=0.4, scale_mult=1.0, cx=None, cy=None, width=None, height=None):
     """CPU tensors for one frame: oracle-deformed Gaussians + camera of a synthetic workload."""
     sc = syn.make_scene(name, seed=seed)
     wl = sc["workload"]
@@ -21,7 +21,7 @@ def scene_inputs(name="T0", seed=17, azimuth=0.4, scale_mult=1.0, cx=None, cy=No
     cg = od.canonical_gradient(sc["canon_points"], sc["tetras"].long(), sc["tetra_id"].long())
     scales = torch.exp(sc["scaling"]) * scale_mult
     means, cov6 = od.cage_deform(tp, sc["tetras"], sc["tetra_id"], sc["barys"], cg, scales, sc["rotation"])
-    batch = syn.make_batch(wl.width, wl.height, azimuth=azimuth, cx=cx, cy=cy)
+    batch = syn.make_batch(width or wl.width, height or wl.height, azimuth=azimuth, cx=cx, cy=cy)
     cam = oc.camera(batch["R"], batch["T"], batch["FoVx"], batch["FoVy"])
     return dict(
         scene=sc, batch=batch, cam=cam, W=batch["width"], H=batch["height"],
