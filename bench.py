@@ -264,7 +264,7 @@ def main():
             if os.path.exists(pj):
                 for kname, c in json.load(open(pj)).items():
                     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                        short = kname.split("::")[-1].split("_kernel")[0]
+                        short = kname.split("::")[-1].split("_kernel")[0].replace("_rows", "")
                         pmc_traffic[short] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
         except Exception:
             pmc_traffic = {}
