@@ -47,12 +47,13 @@ struct BinBuf {
     uint32_t *tile_cursor;  // tiles
     uint64_t *keys;         // d_capacity  (depth bits << 32 | gaussian index), grouped by tile
     uint32_t *point_list;   // d_capacity  gaussian indices, per tile ascending (depth, index)
-    uint32_t *big_tiles;    // tiles       tiles whose list is too long for the small LDS sort (counters[4] entries)
-    uint32_t *huge_tiles;   // tiles       tiles whose list is too long for any LDS sort      (counters[5] entries)
+    uint32_t *big_tiles;    // tiles       tiles with 4097..8192 entries (counters[4] of them)
+    uint32_t *huge_tiles;   // tiles       tiles with more than 8192 entries: no LDS sort (counters[5])
+    uint32_t *mid_tiles;    // tiles       tiles with 2049..4096 entries (counters[6])
 };
 static inline int64_t bin_bytes(int64_t tiles, int64_t dcap) {
     return 256 + align256(4 * tiles) + align256(4 * (tiles + 1)) + align256(4 * tiles) + align256(8 * dcap) +
-           align256(4 * dcap) + 2 * align256(4 * tiles);
+           align256(4 * dcap) + 3 * align256(4 * tiles);
 }
 static inline BinBuf carve_bin(void *base, int64_t tiles, int64_t dcap) {
     char *p = (char *)base;
@@ -64,7 +65,8 @@ static inline BinBuf carve_bin(void *base, int64_t tiles, int64_t dcap) {
     b.keys = (uint64_t *)p;        p += align256(8 * dcap);
     b.point_list = (uint32_t *)p;  p += align256(4 * dcap);
     b.big_tiles = (uint32_t *)p;   p += align256(4 * tiles);
-    b.huge_tiles = (uint32_t *)p;
+    b.huge_tiles = (uint32_t *)p;  p += align256(4 * tiles);
+    b.mid_tiles = (uint32_t *)p;
     return b;
 }
 

@@ -24,8 +24,9 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(int tiles, const 
                                                                uint32_t *__restrict__ cursor,
                                                                uint32_t *__restrict__ counters, uint64_t dcap,
                                                                uint32_t *__restrict__ big_tiles,
-                                                               uint32_t *__restrict__ huge_tiles, uint32_t n_small,
-                                                               uint32_t n_large) {
+                                                               uint32_t *__restrict__ huge_tiles,
+                                                               uint32_t *__restrict__ mid_tiles, uint32_t n_small,
+                                                               uint32_t n_mid, uint32_t n_large) {
     __shared__ uint32_t s_sum[kScanBlock];
     __shared__ uint32_t s_max;
     const int tid = threadIdx.x;
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(int tiles, const 
         run += c;
         // work lists for the long-list sort kernels (usually empty: those launches then cost one tiny grid)
         if (c > n_large) huge_tiles[atomicAdd(&counters[D3GA_CNT_HUGE], 1u)] = (uint32_t)t;
-        else if (c > n_small) big_tiles[atomicAdd(&counters[D3GA_CNT_BIG], 1u)] = (uint32_t)t;
+        else if (c > n_mid) big_tiles[atomicAdd(&counters[D3GA_CNT_BIG], 1u)] = (uint32_t)t;
+        else if (c > n_small) mid_tiles[atomicAdd(&counters[D3GA_CNT_MID], 1u)] = (uint32_t)t;
     }
     if (tid == kScanBlock - 1) {
         const uint32_t total = s_sum[kScanBlock - 1];
@@ -248,18 +250,20 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_lds_kernel(const uint32_t *__
     sort_one_tile_lds<BLOCK, CAP, true>(s_key, tile, start, keys, point_list, dcap);
 }
 
-// persistent grid over the work list written by tile_scan_kernel (tiles with CAP_SMALL < n <= CAP)
+// persistent grid over a work list written by tile_scan_kernel (tiles whose list does not fit the kernel above);
+// dynamic LDS: CAP + CAP/8 keys in the padded register-phase layout (36 KB for 4096, 72 KB for 8192)
 template <int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_t *__restrict__ start,
                                                                    const uint64_t *__restrict__ keys,
                                                                    uint32_t *__restrict__ point_list, uint64_t dcap,
                                                                    const uint32_t *__restrict__ list,
                                                                    const uint32_t *__restrict__ list_count) {
-    __shared__ uint64_t s_key[CAP];
+    static_assert(CAP <= 8 * BLOCK, "8 keys per thread");
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_key_dyn[];
     const uint32_t count = *list_count;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
         __syncthreads();
-        sort_one_tile_lds<BLOCK, CAP, false>(s_key, (int)list[k], start, keys, point_list, dcap);   // 64 KB: unpadded
+        sort_one_tile_lds<BLOCK, CAP, true>(s_key_dyn, (int)list[k], start, keys, point_list, dcap);
     }
 }
 
@@ -283,8 +287,10 @@ __global__ __launch_bounds__(1024) void tile_sort_global_list_kernel(const uint3
 
 using namespace d3ga;
 
-constexpr int kSortSmall = 2048;   // 16 KiB LDS, 256 threads
-constexpr int kSortLarge = 8192;   // 64 KiB LDS, 1024 threads
+constexpr int kSortSmall = 2048;   // 18 KiB LDS, 256 threads, one workgroup per tile
+constexpr int kSortMid = 4096;     // 36 KiB LDS, 512 threads, list-driven
+constexpr int kSortLarge = 8192;   // 72 KiB LDS, 1024 threads, list-driven
+
 
 extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, void *binning, int64_t d_capacity,
                                     d3ga_stream_t stream) {
@@ -296,8 +302,8 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
     BinBuf bin = carve_bin(binning, tiles, d_capacity);
     GeomBuf g = carve_geom(geom, prm->P);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(kScanBlock), 0, s, tiles, bin.tile_count, bin.tile_start,
-                       bin.tile_cursor, bin.counters, (uint64_t)d_capacity, bin.big_tiles, bin.huge_tiles,
-                       (uint32_t)kSortSmall, (uint32_t)kSortLarge);
+                       bin.tile_cursor, bin.counters, (uint64_t)d_capacity, bin.big_tiles, bin.huge_tiles, bin.mid_tiles,
+                       (uint32_t)kSortSmall, (uint32_t)kSortMid, (uint32_t)kSortLarge);
     D3GA_TRY(check_launch(s, prm->debug));
     if (prm->P == 0 || d_capacity == 0) return D3GA_OK;
     hipLaunchKernelGGL(tile_scatter_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, prm->P, gx, g.rect,
@@ -306,12 +312,23 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
     hipLaunchKernelGGL((tile_sort_lds_kernel<256, kSortSmall>), dim3(tiles), dim3(256), 0, s, bin.tile_start, bin.keys,
                        bin.point_list, (uint64_t)d_capacity);
     D3GA_TRY(check_launch(s, prm->debug));
-    // long lists: small persistent grids driven by the device-side work lists (empty for avatar-sized scenes)
-    const int lgrid = tiles < 256 ? tiles : 256;
-    hipLaunchKernelGGL((tile_sort_lds_list_kernel<1024, kSortLarge>), dim3(lgrid), dim3(1024), 0, s, bin.tile_start,
-                       bin.keys, bin.point_list, (uint64_t)d_capacity, bin.big_tiles, bin.counters + D3GA_CNT_BIG);
+    // long lists: persistent grids driven by the device-side work lists (empty for avatar-sized scenes)
+    static const bool attrs_set = [] {   // > 64 KiB of dynamic LDS needs an explicit opt-in (once per process)
+        (void)hipFuncSetAttribute((const void *)tile_sort_lds_list_kernel<1024, kSortLarge>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (kSortLarge + kSortLarge / 8) * 8);
+        return true;
+    }();
+    (void)attrs_set;
+    const int lgrid = tiles < 1024 ? tiles : 1024;
+    hipLaunchKernelGGL((tile_sort_lds_list_kernel<512, kSortMid>), dim3(lgrid), dim3(512), (kSortMid + kSortMid / 8) * 8, s,
+                       bin.tile_start, bin.keys, bin.point_list, (uint64_t)d_capacity, bin.mid_tiles,
+                       bin.counters + D3GA_CNT_MID);
     D3GA_TRY(check_launch(s, prm->debug));
-    hipLaunchKernelGGL(tile_sort_global_list_kernel, dim3(lgrid), dim3(1024), 0, s, bin.tile_start, bin.keys,
+    hipLaunchKernelGGL((tile_sort_lds_list_kernel<1024, kSortLarge>), dim3(lgrid < 512 ? lgrid : 512), dim3(1024),
+                       (kSortLarge + kSortLarge / 8) * 8, s, bin.tile_start, bin.keys, bin.point_list,
+                       (uint64_t)d_capacity, bin.big_tiles, bin.counters + D3GA_CNT_BIG);
+    D3GA_TRY(check_launch(s, prm->debug));
+    hipLaunchKernelGGL(tile_sort_global_list_kernel, dim3(lgrid < 256 ? lgrid : 256), dim3(1024), 0, s, bin.tile_start, bin.keys,
                        bin.point_list, (uint64_t)d_capacity, bin.huge_tiles, bin.counters + D3GA_CNT_HUGE);
     return check_launch(s, prm->debug);
 }

@@ -112,13 +112,14 @@ int d3ga_raster_img_layout(int32_t W, int32_t H, int64_t offsets[2]);
 /* The binning buffer starts with 8 uint32 counters the host may read back after the forward:
  *   [0] D = duplicates required (sum of tiles touched)      [1] 1 if D > d_capacity (lists truncated: re-run)
  *   [2] longest tile list                                    [3] number of visible Gaussians
- *   [4] tiles with > 2048 entries   [5] tiles with > 8192 entries   [6..7] reserved */
+ *   [4] tiles with 4097..8192 entries   [5] tiles with > 8192 entries   [6] tiles with 2049..4096 entries   [7] reserved */
 #define D3GA_CNT_D 0
 #define D3GA_CNT_OVERFLOW 1
 #define D3GA_CNT_MAXTILE 2
 #define D3GA_CNT_VISIBLE 3
-#define D3GA_CNT_BIG 4  /* tiles with more than 2048 entries (sorted by the large-LDS kernel) */
+#define D3GA_CNT_BIG 4  /* tiles with 4097..8192 entries (72 KB-LDS sort kernel) */
 #define D3GA_CNT_HUGE 5 /* tiles with more than 8192 entries (sorted in global memory) */
+#define D3GA_CNT_MID 6  /* tiles with 2049..4096 entries (36 KB-LDS sort kernel) */
 
 /* R1 per-Gaussian stage + tile histogram.  Exactly one of (shs | colors_precomp) and of
  * ((scales,rotations) | cov3D_precomp) is non-NULL.  viewmatrix/projmatrix are the reference's transposed
