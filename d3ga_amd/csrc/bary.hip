@@ -65,3 +65,60 @@ extern "C" int d3ga_compute_bary(int P, int T, const float *points, const float 
                        points, tetra_corners, barys, tetra_id, active);
     return check_launch((hipStream_t)stream, 1);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Init-time scale seed: mean squared distance of every point to its 3 nearest neighbours.
+// Replaces simple_knn._C.distCUDA2 (models/mesh_net.py:22,66) and the pytorch3d form used for cages,
+// knn_points(p, p, K=4)[0][0, :, 1:].mean(-1) (models/cage_net.py:66).  Exhaustive, points streamed through LDS.
+// ---------------------------------------------------------------------------------------------------------
+namespace d3ga {
+
+__global__ __launch_bounds__(kBlock) void knn3_mean_dist2_kernel(int P, const float *__restrict__ points,
+                                                                 float *__restrict__ out) {
+    __shared__ float s_p[kBlock * 3];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kBlock + tid;
+    const bool live = i < P;
+    V3 p = v3(0.f, 0.f, 0.f);
+    if (live) p = v3(points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2]);
+    float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;       // three smallest squared distances, ascending
+    for (int base = 0; base < P; base += kBlock) {
+        const int cnt = min(kBlock, P - base);
+        __syncthreads();
+        for (int k = tid; k < cnt * 3; k += kBlock) s_p[k] = points[(size_t)base * 3 + k];
+        __syncthreads();
+        if (!live) continue;
+        for (int j = 0; j < cnt; ++j) {
+            if (base + j == i) continue;                      // the point itself
+            const float dx = s_p[3 * j] - p.x, dy = s_p[3 * j + 1] - p.y, dz = s_p[3 * j + 2] - p.z;
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d < d2) {
+                if (d < d1) {
+                    d2 = d1;
+                    if (d < d0) { d1 = d0; d0 = d; } else { d1 = d; }
+                } else {
+                    d2 = d;
+                }
+            }
+        }
+    }
+    if (live) {
+        // fewer than 3 other points: average what exists (0 for a single point)
+        float sum = 0.f; int n = 0;
+        if (d0 < INFINITY) { sum += d0; ++n; }
+        if (d1 < INFINITY) { sum += d1; ++n; }
+        if (d2 < INFINITY) { sum += d2; ++n; }
+        out[i] = n ? sum / (float)n : 0.f;
+    }
+}
+
+}  // namespace d3ga
+
+extern "C" int d3ga_knn3_mean_dist2(int P, const float *points, float *out, d3ga_stream_t stream) {
+    if (P < 0) return D3GA_E_SIZE;
+    if (P == 0) return D3GA_OK;
+    if (!points || !out) return D3GA_E_NULL;
+    hipLaunchKernelGGL(d3ga::knn3_mean_dist2_kernel, dim3((P + d3ga::kBlock - 1) / d3ga::kBlock), dim3(d3ga::kBlock), 0,
+                       (hipStream_t)stream, P, points, out);
+    return d3ga::check_launch((hipStream_t)stream, 0);
+}

@@ -1,18 +1,22 @@
 // raster_composite.hip -- alpha compositing forward / backward for gfx950.
 //
 // Wavefront-autonomous design.  The unit of work is ONE 64-lane wavefront = one 8x8-pixel quadrant of a 16x16 tile
-// (workgroup = one wavefront: no LDS, no barriers, independent early-out, 4x finer load balancing than a workgroup
-// per tile).  A wavefront walks its tile's depth-ordered list 64 entries at a time:
-//   1. every lane gathers ONE entry's record (xy, conic+opacity, rgb+1/depth: three 8/16-byte loads) and tests it
-//      against the quadrant with a conservative bounding box of the alpha >= 1/255 ellipse -> one 64-bit ballot;
-//   2. the wavefront iterates over the set bits only; the entry's record is broadcast from its lane into SGPRs with
-//      v_readlane (scalar operands are free for the per-pixel VALU math: no LDS round trip in the dependency chain);
-//   3. forward: front-to-back blend, stop when all 64 pixels are saturated (T < 1e-4);
-//      backward: back-to-front from the quadrant's deepest contributor; the nine per-pixel partial derivatives are
-//      reduced across the wavefront with interleaved DPP row operations (VALU only) and lanes 48..56 issue ONE
-//      global_atomic_add_f32 instruction per (wavefront, Gaussian) -- 64x fewer atomics than one per pixel.
-// Culled entries provably contribute nothing (alpha < 1/255 on every pixel of the quadrant), so the result is
-// identical to walking the full tile list; list positions (n_contrib) are kept as positions in the FULL list.
+// (workgroup = one wavefront: no barriers, independent early-out, 4x finer load balancing than a workgroup per
+// tile).  A wavefront walks its tile's depth-ordered list 64 entries at a time:
+//   1. every lane gathers ONE entry's record (xy, conic+opacity, rgb+1/depth: three 8/16-byte loads), parks it in a
+//      wave-private LDS slab and tests it with a conservative bounding box of the alpha >= 1/255 ellipse;
+//   2. DEFAULT ("rows" kernels): each of the four 16-lane DPP rows owns a 4x4 sub-block; the batch is tested against
+//      the four sub-blocks (four ballots) and compacted into four per-row index lists in LDS; iteration i makes row r
+//      process the i-th entry of its own list (records fetched with per-row broadcast ds_reads).
+//      ALTERNATIVE (64-lane kernels, D3GA_COMPOSITE_VARIANT): one ballot per batch, all 64 lanes visit the set bits;
+//      records come from the LDS slab or from v_readlane broadcasts;
+//   3. forward: straight-line front-to-back blend, two list positions per iteration, stop when all 64 pixels are
+//      saturated (T < 1e-4);
+//      backward: back-to-front from the deepest contributor; the nine per-pixel partial derivatives are reduced inside
+//      the row with four DPP steps (VALU only) and lanes 0..8 of every hit row issue ONE global_atomic_add_f32
+//      instruction per iteration (64-lane variant: v_permlane32/16_swap reduce-scatter, 9 lanes publish).
+// Culled entries provably contribute nothing (alpha < 1/255 on every pixel of the block), so the result is identical
+// to walking the full tile list; list positions (n_contrib) are kept as positions in the FULL list.
 //
 // Work -> XCD mapping: the dispatcher places block b on XCD b % 8 (observed, speed only).  Tile ROW r is processed
 // by XCD r % 8, so the four quadrants of a tile and its horizontal neighbours -- which share most of their
@@ -426,10 +430,6 @@ __device__ __forceinline__ bool block_hit(float cx, float cy, float hx, float hy
 }
 __device__ __forceinline__ int lanes_below(unsigned long long m) {   // popcount of m restricted to lower lanes
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-}
-__device__ __forceinline__ float row_max_f(float v) {
-    // not needed; kept for symmetry
-    return v;
 }
 __device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {       // every lane <- max over its 16-lane row
     uint32_t t;

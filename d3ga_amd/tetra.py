@@ -91,3 +91,35 @@ def compute_bary(points, tetras, triangles=None, tri_to_tetra=None, cage=None):
     check(_lib.lib().d3ga_compute_bary(P, T, dptr(pts), dptr(cor), dptr(barys), dptr(tid), dptr(act), stream_handle()),
           "d3ga_compute_bary")
     return barys, tid.long(), act.bool()
+
+
+def knn_mean_dist2(points):
+    """(P,3) -> (P,) mean squared distance to the 3 nearest neighbours: `simple_knn._C.distCUDA2(points)`
+    (models/mesh_net.py:66) == `knn_points(p[None], p[None], K=4)[0][0, :, 1:].mean(-1)` (models/cage_net.py:66)."""
+    require_cuda(points)
+    pts = points.detach().float().contiguous()
+    out = torch.empty((pts.shape[0],), dtype=torch.float32, device=pts.device)
+    check(_lib.lib().d3ga_knn3_mean_dist2(pts.shape[0], dptr(pts), dptr(out), stream_handle()), "d3ga_knn3_mean_dist2")
+    return out
+
+
+distCUDA2 = knn_mean_dist2
+
+
+def gaussian_ply_columns(features_dc, features_rest, scaling, rotation):
+    """Column names of the 3DGS-style PLY export (models/cage_net.py:111-122 describe_ply)."""
+    cols = ["x", "y", "z", "nx", "ny", "nz"]
+    cols += [f"f_dc_{i}" for i in range(features_dc.shape[1] * features_dc.shape[2])]
+    cols += [f"f_rest_{i}" for i in range(features_rest.shape[1] * features_rest.shape[2])]
+    cols.append("opacity")
+    cols += [f"scale_{i}" for i in range(scaling.shape[1])]
+    cols += [f"rot_{i}" for i in range(rotation.shape[1])]
+    return cols
+
+
+def gaussian_ply_arrays(features_dc, features_rest, opacities, scaling, rotation):
+    """(f_dc, f_rest, opacities, scale, rotation) numpy blocks in the layout of models/cage_net.py:124-132 get_ply."""
+    f_dc = features_dc.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy()
+    f_rest = features_rest.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy()
+    return (f_dc, f_rest, opacities.detach().cpu().numpy(), scaling.detach().cpu().numpy(),
+            rotation.detach().cpu().numpy())

@@ -193,6 +193,11 @@ int d3ga_selftest_wave_sum(int n, const float *in, float *out, d3ga_stream_t str
 int d3ga_compute_bary(int P, int T, const float *points, const float *tetra_corners, float *barys,
                       int32_t *tetra_id, uint8_t *active, d3ga_stream_t stream);
 
+/* Init-time scale seed.  Replaces simple_knn._C.distCUDA2 (models/mesh_net.py:22,66) and
+ * pytorch3d knn_points(p, p, K=4)[0][0,:,1:].mean(-1) (models/cage_net.py:66): out[i] = mean squared distance of
+ * point i to its 3 nearest other points.  points (P,3) -> out (P).  Exhaustive O(P^2). */
+int d3ga_knn3_mean_dist2(int P, const float *points, float *out, d3ga_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -517,3 +517,15 @@ def test_screen_filling_splats_exceed_the_lds_tile_window():
     np.testing.assert_array_equal(_np(plist), olist)
     ok, mx, frac = image_close(_np(color), ocolor)
     assert ok, (mx, frac)
+
+
+def test_knn_mean_dist2_matches_bruteforce():
+    from d3ga_amd.tetra import knn_mean_dist2
+    g = torch.Generator().manual_seed(12)
+    pts = torch.randn(1500, 3, generator=g)
+    d = torch.cdist(pts.double(), pts.double()) ** 2
+    d.fill_diagonal_(float("inf"))
+    ref = d.topk(3, largest=False).values.mean(1)
+    out = knn_mean_dist2(pts.to(DEV))
+    np.testing.assert_allclose(_np(out), ref.numpy(), rtol=1e-4, atol=1e-7)
+    assert float(knn_mean_dist2(pts[:1].to(DEV))[0]) == 0.0
