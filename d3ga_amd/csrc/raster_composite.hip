@@ -28,7 +28,7 @@
 
 namespace d3ga {
 
-constexpr int kDefaultCompositeVariant = 15;  // row-segmented kernels with LDS slabs (measured at C3: fwd 248 -> 133 us, bwd 508 -> 376 us)
+constexpr int kDefaultCompositeVariant = 31;  // row-segmented kernels with LDS slabs (measured at C3: fwd 248 -> 133 us, bwd 508 -> 376 us)
 
 // ---- wavefront (64 lanes) reductions through DPP ----
 template <int CTRL, int ROW_MASK>
@@ -554,6 +554,7 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
 }
 
 
+template <bool LDSACC>
 __global__ __launch_bounds__(64) void composite_bwd_rows_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
     uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
@@ -589,6 +590,10 @@ __global__ __launch_bounds__(64) void composite_bwd_rows_kernel(
     __shared__ float4 s_rgb[64];
     __shared__ uint32_t s_id[64];
     __shared__ uint8_t s_list[4][64];
+    // LDSACC: per-batch accumulator of the wavefront -- the four rows' totals for a staged entry meet here (ds_add_f32)
+    // and ONE lane per entry flushes them with nine global atomics at the end of the batch: the same Gaussian is
+    // usually hit by several rows of the quadrant, so the memory-side atomic requests roughly halve
+    __shared__ float s_acc[LDSACC ? 64 * kNG : 1];
 
     float T = T_final;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -596,6 +601,8 @@ __global__ __launch_bounds__(64) void composite_bwd_rows_kernel(
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     const int l16 = lane & 15;
     const int slot_off = l16 < 2 ? l16 : l16 + 1;          // lanes 0..8 of each row publish value l16; acc layout 0,1|3,4,5|6|7,8,9
+    const int fq = lane / 9, fk = lane - 9 * fq;           // LDSACC flush: lane -> (entry within a group of 7, value)
+    const int fk_off = fk < 2 ? fk : fk + 1;
 
     float2 nxy = make_float2(0.f, 0.f);
     float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -619,6 +626,10 @@ __global__ __launch_bounds__(64) void composite_bwd_rows_kernel(
         const uint32_t mypos = hi - (uint32_t)lane;        // list position of the entry this lane staged
         __builtin_amdgcn_wave_barrier();
         s_xy[lane] = cxy; s_co[lane] = cco; s_rgb[lane] = crgb; s_id[lane] = cid;
+        if constexpr (LDSACC) {
+#pragma unroll
+            for (int k = 0; k < kNG; ++k) s_acc[lane * kNG + k] = 0.f;
+        }
         int trip;
         const int my_cnt = build_row_lists(
             s_list, mypos <= rl0 && block_hit(cxy.x, cxy.y, hx, hy, bx0, by0, 3.0f),
@@ -682,7 +693,23 @@ __global__ __launch_bounds__(64) void composite_bwd_rows_kernel(
             for (int k = 1; k < kNG; ++k) mine = (l16 == k) ? v[k] : mine;
             const bool row_any = ((hm >> (rg.row << 4)) & 0xffffull) != 0;
             // lanes 0..8 of every row that was hit: one atomic instruction, up to 36 active lanes
-            if (l16 < kNG && row_any) atomicAdd(acc + 12 * (size_t)gid + slot_off, mine);
+            if constexpr (LDSACC) {
+                if (l16 < kNG && row_any) atomicAdd(&s_acc[j * kNG + l16], mine);          // ds_add_f32
+            } else {
+                if (l16 < kNG && row_any) atomicAdd(acc + 12 * (size_t)gid + slot_off, mine);
+            }
+        }
+        if constexpr (LDSACC) {
+            __builtin_amdgcn_wave_barrier();
+            // flush: nine consecutive lanes publish one staged entry (36 contiguous bytes = 2 memory-side requests,
+            // like the direct path), seven entries per instruction
+            for (int e0 = 0; e0 < 64; e0 += 7) {
+                const int e = e0 + fq;
+                if (fq < 7 && e < 64) {
+                    const float val = s_acc[e * kNG + fk];
+                    if (val != 0.f) atomicAdd(acc + 12 * (size_t)s_id[e] + fk_off, val);
+                }
+            }
         }
     }
 }
@@ -713,7 +740,8 @@ using namespace d3ga;
 
 // Tuning knob (read once): D3GA_COMPOSITE_VARIANT bit 0 = forward, bit 1 = backward fetch entry records through a
 // wave-private LDS slab (1) instead of v_readlane broadcasts (0); bit 2 = forward, bit 3 = backward use the
-// row-segmented kernels (four 4x4 blocks per wavefront).
+// row-segmented kernels (four 4x4 blocks per wavefront); bit 4 (with bit 3) = backward accumulates a batch in LDS
+// before the global atomics.
 static int composite_variant() {
     static const int v = [] {
         const char *e = getenv("D3GA_COMPOSITE_VARIANT");
@@ -759,8 +787,12 @@ extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const fl
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
     const ImgBuf im = carve_img(const_cast<void *>(img), prm->W, prm->H);
-    if (composite_variant() & 8)
-        hipLaunchKernelGGL(composite_bwd_rows_kernel, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
+    if ((composite_variant() & 24) == 24)
+        hipLaunchKernelGGL(composite_bwd_rows_kernel<true>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
+                           gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
+                           im.final_T, im.n_contrib, dL_dpix, acc);
+    else if (composite_variant() & 8)
+        hipLaunchKernelGGL(composite_bwd_rows_kernel<false>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
                            gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
                            im.final_T, im.n_contrib, dL_dpix, acc);
     else if (composite_variant() & 2)
