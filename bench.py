@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for tests)")
     ap.add_argument("--single-device", action="store_true", help="testing only: all ranks share cuda:0")
+    ap.add_argument("--reduce", choices=("cut", "params"), default="cut",
+                    help="N>1 gradient exchange: 'cut' = summed at the rasterizer's inputs with the SH gradient in factored "
+                         "form (dist.ViewShardedGrads); 'params' = one all-reduce per parameter tensor (dist.GradReducer)")
     ap.add_argument("--no-graph", action="store_true",
                     help="time eager launches instead of replaying the captured hipGraph of one step")
     return ap.parse_args()
@@ -76,6 +79,7 @@ class Frame:
         g = torch.Generator().manual_seed(100 + view_index)
         self.target = torch.rand(3, self.wl.height, self.wl.width, generator=g).to(dev)
         self.sh_degree = self.wl.sh_degree
+        self.grad_sync = None          # d3ga_amd.dist.ViewShardedGrads when the views are sharded over ranks
 
     def step(self):
         from d3ga_amd.cage_deform import cage_deform, lbs_cage
@@ -87,7 +91,7 @@ class Frame:
                                   self.canon_grad, torch.exp(p["scaling"]), p["rotation"])
         pkg = {"means3D": means, "cov3D_precomp": cov6, "opacities": torch.sigmoid(p["opacity"]),
                "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
-        img = render(self.batch, pkg, self.bg)["render"]
+        img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
         loss = l1_loss(img, self.target)              # fused mean |img - target| (utils/loss_utils.py:29)
         loss.backward()
         return loss
@@ -159,11 +163,18 @@ def main():
 
     frame = Frame(args.workload, dev, view_index=rank % 8)
     flat = ddist.GradReducer(list(frame.params.values()))
+    cut = world > 1 and args.reduce == "cut"
+    if cut:
+        frame.grad_sync = ddist.ViewShardedGrads()        # gradients leave the rasterizer already averaged over the ranks
+
+    def reduce_params():
+        if not cut:
+            flat.all_reduce_mean()
 
     def one_step():
         flat.zero()
         frame.step()
-        flat.all_reduce_mean()
+        reduce_params()
 
     def barrier():
         if world > 1:
@@ -209,7 +220,7 @@ def main():
         else:
             flat.zero()
             frame.step()
-        flat.all_reduce_mean()
+        reduce_params()
 
     for _ in range(3):
         timed_step()
@@ -283,7 +294,10 @@ def main():
             "config": {"workload": wl.name, "gaussians": P, "width": W, "height": H, "sh_degree": wl.sh_degree,
                        "duplicates_D": D, "max_tile_list": cnt_end["max_tile"], "visible": cnt_end["visible"],
                        "views_per_step": world, "parallelism": f"camera-sharded dp{world}",
-                       "grad_allreduce_bytes": flat.nbytes() if world > 1 else 0},
+                       "grad_exchange": ("none" if world == 1 else "cut: all-reduce of the rasterizer-input gradients + "
+                                         "all-gather of the factored SH gradient" if cut else "per-parameter all-reduce"),
+                       "grad_exchange_bytes_per_rank": (0 if world == 1 else frame.grad_sync.bytes_last if cut
+                                                        else flat.nbytes())},
             "roofline": roof, "kernels": kernels,
             "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 4),
             "launch_mode": "hipGraph replay of one captured step" if graph is not None else "eager",

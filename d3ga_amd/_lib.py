@@ -47,6 +47,7 @@ _SIGNATURES = {
     "d3ga_raster_forward": ([_prm] + [_vp] * 14 + [_i64, _vp, _vp, _vp, _vp], _i),
     "d3ga_raster_backward": ([_prm] + [_vp] * 11 + [_i64] + [_vp] * 11 + [_vp], _i),
     "d3ga_raster_mark_visible": ([ctypes.c_int32, _vp, _vp, _vp, _vp], _i),
+    "d3ga_sh_grad_from_views": ([ctypes.c_int32] * 4 + [_vp, _vp, _i64, _vp, _i64, ctypes.c_float, _vp, _vp], _i),
     "d3ga_compute_bary": ([_i, _i] + [_vp] * 5 + [_vp], _i),
     "d3ga_selftest_wave_sum": ([_i, _vp, _vp, _vp], _i),
     "d3ga_knn3_mean_dist2": ([_i, _vp, _vp, _vp], _i),

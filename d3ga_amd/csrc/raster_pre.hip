@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * kBlock + tid;
     const int M3 = 3 * prm.M;
-    const bool staged = dL_dsh != nullptr && sh_staged(prm.M);
+    const bool staged = shs != nullptr && sh_staged(prm.M);      // dL_dsh may be null (factored SH gradient)
     const int row0 = blockIdx.x * kBlock + wave * 64;
     const int rows = min(64, prm.P - row0);
     float *slab = s_sh + wave * kShSlab;
@@ -157,12 +157,65 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
         if (staged)
             preprocess_bwd_one(prm, i, visible, means3D, slab + lane * kShRow, scales, rotations, viewmatrix, projmatrix,
                                campos, c6, geom.clamped[i], a, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
-                               slab + lane * kShRow, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots);
+                               dL_dsh ? slab + lane * kShRow : nullptr, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots);
         else
-            preprocess_bwd_one(prm, i, visible, means3D, dL_dsh ? shs + (size_t)M3 * i : nullptr, scales, rotations,
+            preprocess_bwd_one(prm, i, visible, means3D, shs ? shs + (size_t)M3 * i : nullptr, scales, rotations,
                                viewmatrix, projmatrix, campos, c6, geom.clamped[i], a, dL_dmeans3D, dL_dmeans2D,
                                dL_dopacity, dL_dsh ? dL_dsh + (size_t)M3 * i : nullptr, dL_dcolors, dL_dcov3D,
                                dL_dscales, dL_drots);
+    }
+    if (staged && dL_dsh) {
+        __syncthreads();
+        if (rows > 0) sh_slab_store(slab, dL_dsh + (size_t)M3 * row0, rows, M3, lane);
+    }
+}
+
+// View-sharded training: the SH gradient of one view is rank-1 per Gaussian,
+//   dL/dsh[i][k][c] = basis_k(normalize(mean_i - campos_v)) * g_v[i][c],      g_v = clamp-masked dL/dcolour,
+// so the ranks exchange the (P,3) factor g_v (all-gather) instead of summing (P,M,3) blocks (all-reduce) and every rank
+// rebuilds   dL_dsh = scale * sum_v basis(dir_v) (x) g_v   here.  One thread per Gaussian, 48 accumulators in
+// registers, rows leave through the per-wavefront LDS slab (16 B/lane contiguous stores).
+__global__ __launch_bounds__(kBlock) void sh_grad_from_views_kernel(
+    int P, int M, int sh_degree, int n_views, const float *__restrict__ means3D, const float *__restrict__ g_views,
+    int64_t g_stride, const float *__restrict__ campos_views, int64_t campos_stride, float scale,
+    float *__restrict__ dL_dsh) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_sh = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * kBlock + tid;
+    const int M3 = 3 * M;
+    const bool staged = sh_staged(M);
+    const int row0 = blockIdx.x * kBlock + wave * 64;
+    const int rows = min(64, P - row0);
+    float *slab = s_sh + wave * kShSlab;
+    if (i < P) {
+        float out[48];
+#pragma unroll
+        for (int k = 0; k < 48; ++k) out[k] = 0.f;
+        const V3 mean = ld3(means3D, i);
+        const int nb = (sh_degree + 1) * (sh_degree + 1);
+        for (int v = 0; v < n_views; ++v) {
+            const float *g = g_views + v * g_stride + 3 * (size_t)i;
+            const float g0 = g[0], g1 = g[1], g2 = g[2];
+            if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;        // culled / invisible / clamped in this view
+            const float *cp = campos_views + v * campos_stride;
+            const V3 d0 = mean - v3(cp[0], cp[1], cp[2]);
+            const float inv = 1.0f / sqrtf(dot(d0, d0));
+            float B[16];
+            sh_basis(sh_degree, d0.x * inv, d0.y * inv, d0.z * inv, B);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < nb) {
+                    out[3 * k] += B[k] * g0; out[3 * k + 1] += B[k] * g1; out[3 * k + 2] += B[k] * g2;
+                }
+        }
+        float *row = staged ? slab + lane * kShRow : nullptr;
+#pragma unroll
+        for (int k = 0; k < 48; ++k)
+            if (k < M3) {
+                if (staged) row[k] = out[k] * scale;
+                else dL_dsh[(size_t)M3 * i + k] = out[k] * scale;
+            }
     }
     if (staged) {
         __syncthreads();
@@ -229,15 +282,30 @@ extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const f
     if (prm->P == 0) return D3GA_OK;
     if (!means3D || !viewmatrix || !projmatrix || !campos || !geom || !acc || !dL_dmeans3D) return D3GA_E_NULL;
     if (dL_dsh && !shs) return D3GA_E_NULL;
+    if (shs && !dL_dsh && !dL_dcolors) return D3GA_E_NULL;        // SH path: full block or factored (P,3) output
     if ((dL_dscales != nullptr) != (dL_drots != nullptr)) return D3GA_E_CONFIG;
     if (dL_dscales && (!scales || !rotations)) return D3GA_E_NULL;
     hipStream_t s = (hipStream_t)stream;
     GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
-    const size_t lds = (dL_dsh && prm->M > 0 && (3 * prm->M) % 4 == 0) ? kShLdsBytes : 0;
+    const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? kShLdsBytes : 0;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D,
                        shs, scales, rotations, viewmatrix, projmatrix, campos, g, acc, dL_dmeans3D, dL_dmeans2D,
                        dL_dopacity, dL_dsh, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots);
     return check_launch(s, prm->debug);
+}
+
+extern "C" int d3ga_sh_grad_from_views(int32_t P, int32_t M, int32_t sh_degree, int32_t n_views, const float *means3D,
+                                       const float *g_views, int64_t g_stride, const float *campos_views,
+                                       int64_t campos_stride, float scale, float *dL_dsh, d3ga_stream_t stream) {
+    if (P < 0 || M < 1 || M > 16 || n_views < 0) return D3GA_E_SIZE;
+    if (sh_degree < 0 || sh_degree > 3 || (sh_degree + 1) * (sh_degree + 1) > M) return D3GA_E_CONFIG;
+    if (P == 0) return D3GA_OK;
+    if (!means3D || !dL_dsh || (n_views > 0 && (!g_views || !campos_views))) return D3GA_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = ((3 * M) % 4 == 0) ? kShLdsBytes : 0;
+    hipLaunchKernelGGL(sh_grad_from_views_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, P, M, sh_degree,
+                       n_views, means3D, g_views, g_stride, campos_views, campos_stride, scale, dL_dsh);
+    return check_launch(s, 0);
 }
 
 extern "C" int d3ga_raster_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, uint8_t *visible,

@@ -81,7 +81,10 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
         cov2d_bwd(mean, c6, viewmatrix, prm.W, prm.H, prm.tanfovx, prm.tanfovy, a[3], a[4], a[5], g6, gmean);
         project_bwd(mean, projmatrix, a[0], a[1], gmean);
     }
-    if (dsh_row) {
+    // SH colour path (sh_row != null).  dsh_row == null selects the FACTORED output used by the view-sharded gradient
+    // exchange (d3ga_sh_grad_from_views): the clamp-masked dL/dcolour is written to dL_dcolors instead of the rank-1
+    // (basis x dL/dcolour) SH block; the view-direction term of dL/dmean is computed either way.
+    if (sh_row) {
         float *out = dsh_row;
         if (visible) {
             const float gr[3] = {(clampmask & 1) ? 0.f : a[7], (clampmask & 2) ? 0.f : a[8],
@@ -99,20 +102,25 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
             for (int k = 0; k < 16; ++k) {   // fixed trip count: keeps the basis arrays in registers
                 if (k < nb) {
                     const float s0 = sh[3 * k], s1 = sh[3 * k + 1], s2 = sh[3 * k + 2];
-                    out[3 * k] = B[k] * gr[0]; out[3 * k + 1] = B[k] * gr[1]; out[3 * k + 2] = B[k] * gr[2];
+                    if (out) { out[3 * k] = B[k] * gr[0]; out[3 * k + 1] = B[k] * gr[1]; out[3 * k + 2] = B[k] * gr[2]; }
                     const float w = s0 * gr[0] + s1 * gr[1] + s2 * gr[2];
                     gd.x += Bx[k] * w; gd.y += By[k] * w; gd.z += Bz[k] * w;
-                } else if (k < nbM) {
+                } else if (k < nbM && out) {
                     out[3 * k] = 0.f; out[3 * k + 1] = 0.f; out[3 * k + 2] = 0.f;
                 }
             }
             const V3 gm = normalize_bwd(d0, gd);
             gmean[0] += gm.x; gmean[1] += gm.y; gmean[2] += gm.z;
+            if (dL_dcolors) {
+                dL_dcolors[3 * (size_t)i] = gr[0]; dL_dcolors[3 * (size_t)i + 1] = gr[1]; dL_dcolors[3 * (size_t)i + 2] = gr[2];
+            }
         } else {
-            for (int k = 0; k < 3 * nbM; ++k) out[k] = 0.f;
+            if (out) for (int k = 0; k < 3 * nbM; ++k) out[k] = 0.f;
+            if (dL_dcolors) {
+                dL_dcolors[3 * (size_t)i] = 0.f; dL_dcolors[3 * (size_t)i + 1] = 0.f; dL_dcolors[3 * (size_t)i + 2] = 0.f;
+            }
         }
-    }
-    if (dL_dcolors) {
+    } else if (dL_dcolors) {
         dL_dcolors[3 * (size_t)i] = a[7]; dL_dcolors[3 * (size_t)i + 1] = a[8]; dL_dcolors[3 * (size_t)i + 2] = a[9];
     }
     dL_dmeans3D[3 * (size_t)i] = gmean[0]; dL_dmeans3D[3 * (size_t)i + 1] = gmean[1];

@@ -117,7 +117,7 @@ def _empty_to_none(t):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, grad_sync=None):
         s = raster_settings
         require_cuda(means3D)
         dev = means3D.device
@@ -171,6 +171,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.prm = prm
         ctx.cap = cap
         ctx.has_means2D = means2D is not None
+        ctx.grad_sync = grad_sync if (grad_sync is not None and grad_sync.world > 1 and P > 0) else None
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img)
         ctx.mark_non_differentiable(radii, invdepth)
         return color, radii, invdepth
@@ -182,13 +183,35 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_color = _f32(grad_color, dev)
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         acc = new(P, 12)
-        g_means3D, g_means2D, g_opac = new(P, 3), new(P, 3), new(P, 1)
-        g_sh = new(P, prm.M, 3) if sh is not None else None
-        g_col = new(P, 3) if sh is None else None
         from_sr = cov3Ds_precomp is None
-        g_cov = None if from_sr else new(P, 6)
-        g_scales = new(P, 3) if from_sr else None
-        g_rots = new(P, 4) if from_sr else None
+        sync = ctx.grad_sync
+        if sync is None:
+            g_means3D, g_means2D, g_opac = new(P, 3), new(P, 3), new(P, 1)
+            g_sh = new(P, prm.M, 3) if sh is not None else None
+            g_col = new(P, 3) if sh is None else None
+            g_cov = None if from_sr else new(P, 6)
+            g_scales = new(P, 3) if from_sr else None
+            g_rots = new(P, 4) if from_sr else None
+        else:
+            # view-sharded training: every gradient that leaves this op is summed over the ranks HERE, at the narrowest
+            # cut of the graph (d3ga_amd/dist.py:ViewShardedGrads) -- one planar buffer for the all-reduce, and for the SH
+            # path the (P,3) factor of the rank-1 SH gradient (+ this view's camera position as row P) for the all-gather
+            g_means2D = new(P, 3)
+            widths = [3, 1] + ([3, 4] if from_sr else [6]) + ([3] if sh is None else [])
+            flat = new(P * sum(widths))
+            parts, off = [], 0
+            for w in widths:
+                parts.append(flat[off:off + P * w].view(P, w))
+                off += P * w
+            g_means3D, g_opac = parts[0], parts[1]
+            g_scales, g_rots = (parts[2], parts[3]) if from_sr else (None, None)
+            g_cov = None if from_sr else parts[2]
+            g_sh = None
+            if sh is None:
+                g_col, factor = parts[-1], None
+            else:
+                factor = new(P + 1, 3)
+                g_col = factor[:P]
         L = _lib.lib()
         if stage_timer.enabled:
             st, pp = stream_handle(), ctypes.byref(prm)
@@ -206,19 +229,34 @@ class _RasterizeGaussians(torch.autograd.Function):
                 dptr(view), dptr(proj), dptr(campos), dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img),
                 dptr(grad_color), dptr(acc), dptr(g_means3D), dptr(g_means2D), dptr(g_opac), dptr(g_sh), dptr(g_col),
                 dptr(g_cov), dptr(g_scales), dptr(g_rots), stream_handle()), "d3ga_raster_backward")
-        return (g_means3D, g_means2D if ctx.has_means2D else None, g_sh, g_col, g_opac, g_scales, g_rots, g_cov, None)
+        if sync is not None:
+            if factor is not None:
+                factor[P].copy_(campos.reshape(3))
+            gathered = sync.exchange(flat, factor)         # flat: summed (averaged) in place; gathered: (world, P+1, 3)
+            if factor is not None:
+                g_sh = new(P, prm.M, 3)
+                check(L.d3ga_sh_grad_from_views(P, prm.M, prm.sh_degree, sync.world, dptr(means3D), dptr(gathered),
+                                                3 * (P + 1), dptr(gathered[0, P]), 3 * (P + 1), sync.scale, dptr(g_sh),
+                                                stream_handle()), "d3ga_sh_grad_from_views")
+                g_col = None
+        return (g_means3D, g_means2D if ctx.has_means2D else None, g_sh, g_col, g_opac, g_scales, g_rots, g_cov, None,
+                None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, grad_sync=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, grad_sync)
 
 
 class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings):
+    """`grad_sync` (optional, not in upstream): a d3ga_amd.dist.ViewShardedGrads -- the gradients returned by the
+    backward are then already summed/averaged over the ranks of the group (each rank renders its own camera)."""
+
+    def __init__(self, raster_settings, grad_sync=None):
         super().__init__()
         self.raster_settings = raster_settings
+        self.grad_sync = grad_sync
 
     def markVisible(self, positions):
         """Boolean (P,) mask: view-space z > 0.2 (upstream _C.mark_visible)."""
@@ -242,7 +280,7 @@ class GaussianRasterizer(nn.Module):
         if self.raster_settings.antialiasing:
             raise NotImplementedError("antialiasing=True is not implemented (the D3GA renderer passes False, renderer.py:92)")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   self.raster_settings)
+                                   self.raster_settings, self.grad_sync)
 
 
 def last_tile_lists(W, H, device=None):

@@ -21,7 +21,8 @@ def paste(img, crop):
     return img
 
 
-def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_bg=True, fast=False, detach=[]):
+def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_bg=True, fast=False, detach=[],
+           grad_sync=None):
     means3D = pkg["means3D"]
     cam = batch_to_camera(batch, device=means3D.device)
     crop = batch["crop"]
@@ -71,6 +72,8 @@ def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_
         pass
 
     rasterizer = GaussianRasterizer(raster_settings=settings)
+    if grad_sync is not None:                       # extension over upstream's constructor: set only when asked for
+        rasterizer.grad_sync = grad_sync
     if measure_time:
         torch.cuda.synchronize()
     rendered = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,

@@ -144,7 +144,9 @@ int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const float *bg, co
                               d3ga_stream_t stream);
 /* R6 per-Gaussian backward.  Writes every element of the outputs (zeros for culled Gaussians):
  * dL_dmeans3D (P,3), dL_dmeans2D (P,3), dL_dopacity (P,1), and dL_dsh (P,M,3) | dL_dcolors (P,3),
- * dL_dcov3D (P,6) | (dL_dscales (P,3), dL_drots (P,4)). */
+ * dL_dcov3D (P,6) | (dL_dscales (P,3), dL_drots (P,4)).
+ * SH path with dL_dsh == NULL and dL_dcolors != NULL: FACTORED SH gradient -- dL_dcolors receives the clamp-masked
+ * dL/dcolour (the (P,3) factor of the rank-1 SH gradient, see d3ga_sh_grad_from_views); dL/dmeans3D is complete. */
 int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const float *means3D, const float *shs,
                                const float *scales, const float *rotations, const float *cov3D_precomp,
                                const float *viewmatrix, const float *projmatrix, const float *campos,
@@ -166,6 +168,15 @@ int d3ga_raster_backward(const d3ga_raster_params *prm, const float *means3D, co
                          float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dsh,
                          float *dL_dcolors, float *dL_dcov3D, float *dL_dscales, float *dL_drots,
                          d3ga_stream_t stream);
+
+/* View-sharded training (no reference counterpart: the reference trains on one GPU).  Per view v
+ * the SH gradient is rank-1 per Gaussian: dL/dsh[i][k][c] = Y_k(normalize(means3D[i] - campos_v)) * g_v[i][c] with g_v the
+ * factored output of d3ga_raster_preprocess_bwd.  Rebuilds  dL_dsh (P,M,3) = scale * sum_v Y(dir_v) (x) g_v  from the
+ * gathered factors: g_views + v*g_stride -> (P,3) floats of view v, campos_views + v*campos_stride -> 3 floats
+ * (strides in floats).  Coefficients k >= (sh_degree+1)^2 get 0. */
+int d3ga_sh_grad_from_views(int32_t P, int32_t M, int32_t sh_degree, int32_t n_views, const float *means3D,
+                            const float *g_views, int64_t g_stride, const float *campos_views, int64_t campos_stride,
+                            float scale, float *dL_dsh, d3ga_stream_t stream);
 
 /* _C.mark_visible: visible[i] = 1 if view-space z > 0.2 (uint8 output). */
 int d3ga_raster_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, uint8_t *visible,
