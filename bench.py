@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--reduce", choices=("cut", "params"), default="cut",
                     help="N>1 gradient exchange: 'cut' = summed at the rasterizer's inputs with the SH gradient in factored "
                          "form (dist.ViewShardedGrads); 'params' = one all-reduce per parameter tensor (dist.GradReducer)")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the 2-render training-step variant")
     ap.add_argument("--no-graph", action="store_true",
                     help="time eager launches instead of replaying the captured hipGraph of one step")
     return ap.parse_args()
@@ -95,6 +96,83 @@ class Frame:
         loss = l1_loss(img, self.target)              # fused mean |img - target| (utils/loss_utils.py:29)
         loss.backward()
         return loss
+
+
+    def train_step(self):
+        """The reference's training step renders twice (models/trainer.py:102-110): RGB, then a silhouette pass with a
+        constant per-Gaussian colour on a black background; both feed an L1 term (train.py:190-193)."""
+        from d3ga_amd.cage_deform import cage_deform, lbs_cage
+        from d3ga_amd.losses import l1_loss
+        from d3ga_amd.renderer import render
+        p = self.params
+        if not hasattr(self, "sil_rgb"):
+            P = self.barys0.shape[0]
+            self.sil_rgb = torch.ones(P, 3, device=self.bg.device)
+            self.sil_target = (self.target.mean(0, keepdim=True) > 0.5).float().expand(3, -1, -1).contiguous()
+            self.bg0 = torch.zeros_like(self.bg)
+        tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
+        means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0 + p["delta_bary"],
+                                  self.canon_grad, torch.exp(p["scaling"]), p["rotation"])
+        pkg = {"means3D": means, "cov3D_precomp": cov6, "opacities": torch.sigmoid(p["opacity"]),
+               "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
+        img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
+        sil = render(self.batch, pkg, self.bg0, colors_precomp=self.sil_rgb, grad_sync=self.grad_sync)["render"]
+        loss = l1_loss(img, self.target) + l1_loss(sil, self.sil_target)
+        loss.backward()
+        return loss
+
+
+def measured_copy_gbs(dev, nbytes=1 << 30, reps=10):
+    """Device-to-device copy rate (read + write bytes / time): the practical HBM ceiling quoted beside the 8 TB/s peak."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def deform_gpu_comparison(frame, reps=50):
+    """Like-for-like for the fused deform kernels: the reference's unfused tensor program
+    (oracle/deform.py, the restatement of cage_net.py:213-230) run by ATen on the SAME GPU, against
+    d3ga_lbs_cage + d3ga_cage_deform, forward + backward each.  Baseline leg only."""
+    from d3ga_amd.cage_deform import cage_deform, lbs_cage
+    from oracle import deform as od
+    p = frame.params
+    tetras, tetra_id = frame.tetras.long(), frame.tetra_id.long()
+
+    def fused():
+        tp = lbs_cage(frame.canon, p["delta_node"], frame.joint_mats, frame.skin_idx, frame.skin_w)
+        m, c = cage_deform(tp, frame.tetras, frame.tetra_id, frame.barys0 + p["delta_bary"], frame.canon_grad,
+                           torch.exp(p["scaling"]), p["rotation"])
+        (m.sum() + c.sum()).backward()
+
+    def unfused():
+        tp = od.lbs_cage(frame.canon, p["delta_node"], frame.joint_mats, frame.skin_idx.long(), frame.skin_w)
+        m, c = od.cage_deform(tp, tetras, tetra_id, frame.barys0 + p["delta_bary"], frame.canon_grad,
+                              torch.exp(p["scaling"]), p["rotation"])
+        (m.sum() + c.sum()).backward()
+
+    res = {}
+    for name, fn in (("fused_hip_ms", fused), ("unfused_torch_gpu_ms", unfused)):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = round(e0.elapsed_time(e1) / reps, 4)
+    for q in p.values():
+        q.grad = None
+    return res
 
 
 def cpu_baseline(wl_name, budget_s=20.0):
@@ -245,6 +323,24 @@ def main():
         torch.cuda.synchronize()
         R.stage_timer.enabled = False
 
+    # the reference-faithful training step (RGB + silhouette render), reported beside the headline frame
+    train = None
+    if world == 1 and not args.no_train_step:
+        for _ in range(3):
+            flat.zero()
+            frame.train_step()
+        assert not R.last_counters()["overflow"]
+        torch.cuda.synchronize()
+        n_ts = max(5, args.steps // 2)
+        t1 = time.perf_counter()
+        for _ in range(n_ts):
+            flat.zero()
+            frame.train_step()
+        torch.cuda.synchronize()
+        train = {"renders_per_step": 2, "steps": n_ts, "launch_mode": "eager",
+                 "ms_per_step": round(1e3 * (time.perf_counter() - t1) / n_ts, 4)}
+        train["steps_per_s"] = round(1e3 / train["ms_per_step"], 2)
+
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -303,9 +399,18 @@ def main():
             "launch_mode": "hipGraph replay of one captured step" if graph is not None else "eager",
             "stage_events": "separate eager pass, same K steps" if graph is not None else "none" if args.no_stage_events else "separate eager pass",
         }
+        if train is not None:
+            out["training_step"] = train
+        if roof is not None:
+            try:
+                roof["measured_copy_GBs"] = round(measured_copy_gbs(dev), 1)
+            except Exception as e:
+                roof["measured_copy_GBs"] = None
         if not args.no_cpu_baseline and world == 1:
             try:
+                same_gpu = deform_gpu_comparison(frame)          # before the CPU leg: the GPU is still at full clocks
                 out["cpu_baseline"] = cpu_baseline(args.workload)
+                out["cpu_baseline"]["deform_same_gpu"] = same_gpu
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
