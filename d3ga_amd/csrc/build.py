@@ -9,6 +9,10 @@ HEADERS = ["d3ga_math.h", "d3ga_internal.h", "raster_pre_body.h", os.path.join("
 OUT = os.path.join(HERE, "..", "libd3ga_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
+if os.environ.get("D3GA_DIAG"):            # diagnostic build (loop statistics, tools/diag_bwd.py); never the shipped one
+    FLAGS.append("-DD3GA_DIAG")
+    if os.environ.get("D3GA_DIAG") == "counters":
+        FLAGS.append("-DD3GA_DIAG_COUNTERS")
 
 
 def _newer(target, deps):

@@ -28,7 +28,9 @@
 
 namespace d3ga {
 
-constexpr int kDefaultCompositeVariant = 31;  // row-segmented kernels with LDS slabs (measured at C3: fwd 248 -> 133 us, bwd 508 -> 376 us)
+// D3GA_COMPOSITE_VARIANT (A/B knob, tools/gpu_ab.sh): bit 0 fwd LDS slab, bit 1 bwd LDS slab (64-lane kernels); bit 2 fwd
+// row-segmented, bit 3 bwd row-segmented, bit 4 (with 3) bwd third generation (composite_bwd_rows3_kernel).
+constexpr int kDefaultCompositeVariant = 31;  // measured at C3: fwd 248 -> 133 us, bwd 508 -> 376 (rows) -> 337 us (rows3)
 
 // ---- wavefront (64 lanes) reductions through DPP ----
 template <int CTRL, int ROW_MASK>
@@ -127,7 +129,13 @@ struct Quad {
 };
 __device__ __forceinline__ Quad quad_of_block(int gx, int gy) {
     Quad q;
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+#ifdef D3GA_DIAG
+    {   // diagnostic build: a grid launched k times too large runs every quadrant k times (throughput vs balance test)
+        const int n = 8 * ((gy + 7) / 8) * gx * 4;
+        b = b % n;
+    }
+#endif
     const int xcd = b & 7, slot = b >> 3;
     const int per_row = gx * 4;
     const int k = slot / per_row, rem = slot - k * per_row;
@@ -554,7 +562,208 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
 }
 
 
-template <bool LDSACC>
+// ---------------------------------------------------------------------------------------------------------
+// Backward, third generation of the row-segmented kernel.  Same work decomposition as composite_bwd_rows_kernel; what
+// changed is the instruction stream of the inner loop (the kernel is VALU-issue bound):
+//  * RAW MOMENTS: with w = o*G*dL/dalpha the five geometric gradients are linear in  S = sum w*{dx, dy, dx^2, dx*dy,
+//    dy^2}; the per-entry constants (conic, -1/2, the NDC scale) are applied ONCE per entry when the batch accumulator
+//    is flushed instead of once per (pixel, entry)  -> 10 instead of 22 multiplies in the hit body;
+//  * TRANSPOSED REDUCTION: two quad_perm butterflies (18 DPP adds) leave quad sums in all four lanes of a quad; lane t
+//    of every quad then keeps values {t, 4+t, 8} only, and two row_ror steps (t-preserving: rotate by 4, by 8) finish
+//    them -> 18 + 6 selects + 6 DPP adds + 2 selects = 32 instructions instead of 53, and lane k of the row ends up
+//    with total k, exactly where the ds_add_f32 of the batch accumulator wants it;
+//  * ONE LDS RECORD per staged entry (48 B: conic+opacity | rgb+id | xy) and an accumulator with the same 48 B stride:
+//    the per-row lists hold the BYTE OFFSET j*48 (u16), so one ds_read_u16 yields the address of everything.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kRecBytes = 48;
+#ifdef D3GA_DIAG
+__device__ unsigned long long g_diag[8];     // diagnostic build only (tools/diag_bwd.py): loop statistics of the kernel below
+#endif
+__global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
+    int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+    uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
+    const float4 *__restrict__ rgb_invd, const float *__restrict__ bg, const float *__restrict__ final_T,
+    const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix, float *__restrict__ acc) {
+    const Quad q = quad_of_block(gx, gy);
+    if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const RowGeom rg = row_geom(q, lane);
+    const bool inside = rg.px < W && rg.py < H;
+    const float fx = (float)rg.px, fy = (float)rg.py;
+    const float bx0 = (float)q.qx0, by0 = (float)q.qy0;
+    const uint32_t begin = (uint32_t)min((uint64_t)tile_start[q.tile], dcap);
+    const uint32_t end = (uint32_t)min((uint64_t)tile_start[q.tile + 1], dcap);
+    if (begin >= end) return;                              // uniform: empty tile
+
+    const size_t pid = (size_t)rg.py * W + rg.px;
+    const size_t hw = (size_t)H * W;
+    const float T_final = inside ? final_T[pid] : 0.f;
+    const uint32_t last = inside ? n_contrib[pid] : 0u;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (inside) { g0 = dL_dpix[pid]; g1 = dL_dpix[hw + pid]; g2 = dL_dpix[2 * hw + pid]; }
+    const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    const uint32_t rowlast = row_max_u32(last);            // deepest position used inside this lane's 4x4 block
+    const uint32_t maxlast = wave_max_u32(rowlast);
+    if (maxlast == 0) return;
+    const uint32_t rl0 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 0), rl1 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 16);
+    const uint32_t rl2 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 32), rl3 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 48);
+
+    __shared__ __attribute__((aligned(16))) char s_rec[64 * kRecBytes];      // [0,16) conic+o  [16,32) rgb,id  [32,40) xy
+    __shared__ __attribute__((aligned(16))) char s_accb[64 * kRecBytes];     // nine float sums per staged entry (+3 pad)
+    __shared__ uint16_t s_list[4][64];                                       // byte offsets j*48
+    s_list[0][lane] = 0; s_list[1][lane] = 0; s_list[2][lane] = 0; s_list[3][lane] = 0;   // stale slots stay in range
+
+#ifdef D3GA_DIAG_COUNTERS
+    unsigned d_batches = 0, d_iter = 0, d_hit = 0, d_lanes = 0, d_rows = 0, d_ent = 0, d_staged = 0;
+#endif
+    float T = T_final;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    const int l16 = lane & 15, t4 = lane & 3;
+    const bool t_is0 = t4 == 0, t_is1 = t4 == 1, t_is2 = t4 == 2;
+    const bool l_lt4 = l16 < 4, l_lt8 = l16 < 8, l_lt9 = l16 < kNG;
+    const uint32_t my_off = (uint32_t)lane * kRecBytes;
+    const uint32_t l16x4 = (uint32_t)l16 * 4u;
+    const int fq = lane / 9, fk = lane - 9 * fq;           // flush: lane -> (entry within a group of 7, value)
+    const int fk_off = fk < 2 ? fk : fk + 1;               // acc layout 0,1 | 3,4,5 | 6 | 7,8,9
+
+    float2 nxy = make_float2(0.f, 0.f);
+    float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t nid = 0;
+    if ((uint32_t)lane < maxlast) {
+        nid = point_list[begin + (maxlast - 1 - lane)];
+        nxy = xy[nid]; nco = conic_o[nid]; nrgb = rgb_invd[nid];
+    }
+    for (uint32_t hi = maxlast; hi > 0; hi = hi > 64 ? hi - 64 : 0) {
+        const float2 cxy = nxy;
+        const float4 cco = nco;
+        float4 crgb = nrgb;
+        crgb.w = __uint_as_float(nid);
+        const bool have = (uint32_t)lane < hi;
+        if (hi > 64 && (uint32_t)lane < hi - 64) {
+            nid = point_list[begin + (hi - 64 - 1 - lane)];
+            nxy = xy[nid]; nco = conic_o[nid]; nrgb = rgb_invd[nid];
+        }
+        float hx, hy;
+        splat_extent(cco.x, cco.y, cco.z, cco.w, hx, hy);
+        if (!have) hx = -1.0f;
+        const uint32_t mypos = hi - (uint32_t)lane;        // list position of the entry this lane staged
+        // pos = hi - j <= last   <=>   j*48 >= 48*(hi - last): one compare on the list's byte offset
+        const uint32_t off_min = hi > last ? (hi - last) * kRecBytes : 0u;
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<float4 *>(s_rec + my_off) = cco;
+        *reinterpret_cast<float4 *>(s_rec + my_off + 16) = crgb;
+        *reinterpret_cast<float2 *>(s_rec + my_off + 32) = cxy;
+        {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(s_accb + my_off) = z;
+            *reinterpret_cast<float4 *>(s_accb + my_off + 16) = z;
+            *reinterpret_cast<float4 *>(s_accb + my_off + 32) = z;
+        }
+        const bool r0 = mypos <= rl0 && block_hit(cxy.x, cxy.y, hx, hy, bx0, by0, 3.0f);
+        const bool r1 = mypos <= rl1 && block_hit(cxy.x, cxy.y, hx, hy, bx0 + 4.0f, by0, 3.0f);
+        const bool r2 = mypos <= rl2 && block_hit(cxy.x, cxy.y, hx, hy, bx0, by0 + 4.0f, 3.0f);
+        const bool r3 = mypos <= rl3 && block_hit(cxy.x, cxy.y, hx, hy, bx0 + 4.0f, by0 + 4.0f, 3.0f);
+        const unsigned long long m0 = __ballot(r0), m1 = __ballot(r1), m2 = __ballot(r2), m3 = __ballot(r3);
+        if (r0) s_list[0][lanes_below(m0)] = (uint16_t)my_off;
+        if (r1) s_list[1][lanes_below(m1)] = (uint16_t)my_off;
+        if (r2) s_list[2][lanes_below(m2)] = (uint16_t)my_off;
+        if (r3) s_list[3][lanes_below(m3)] = (uint16_t)my_off;
+        const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
+        const int trip = max(max(c0, c1), max(c2, c3));                     // wave-uniform (scalar)
+        const int my_cnt = rg.row == 0 ? c0 : (rg.row == 1 ? c1 : (rg.row == 2 ? c2 : c3));
+#ifdef D3GA_DIAG_COUNTERS
+        d_batches += 1; d_iter += trip; d_ent += c0 + c1 + c2 + c3; d_staged += min(hi, 64u);
+#endif
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < trip; ++i) {
+            const uint32_t off = s_list[rg.row][i];        // ascending staged lane = back-to-front
+            const float4 eco = *reinterpret_cast<const float4 *>(s_rec + off);
+            const float2 exy = *reinterpret_cast<const float2 *>(s_rec + off + 32);
+            const float dx = exy.x - fx, dy = exy.y - fy;
+            float al, G;
+            bool ok;
+            splat_eval(dx, dy, eco.x, eco.y, eco.z, eco.w, al, G, ok);
+            const bool hit = ok && (i < my_cnt) && inside && off >= off_min;
+            const unsigned long long hm = __ballot(hit);
+            if (hm == 0) continue;                         // wave-uniform skip
+#ifdef D3GA_DIAG_COUNTERS
+            d_hit += 1; d_lanes += __popcll(hm);
+            d_rows += ((hm & 0xffffull) != 0) + ((hm & 0xffff0000ull) != 0) + ((hm & 0xffff00000000ull) != 0) + ((hm >> 48) != 0);
+#endif
+            const float4 ergb = *reinterpret_cast<const float4 *>(s_rec + off + 16);
+            // NOTE: keep this body in the kernel (no helper functions / lambdas over m[]): hipcc then turns the
+            // lane-indexed selects below into a scratch-memory table lookup.
+            float m[kNG];
+#pragma unroll
+            for (int k = 0; k < kNG; ++k) m[k] = 0.f;
+            if (hit) {
+                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - al);
+                T = T * inv1ma;
+                const float dch = al * T;
+                a0 = last_alpha * lc0 + (1.f - last_alpha) * a0;
+                a1 = last_alpha * lc1 + (1.f - last_alpha) * a1;
+                a2 = last_alpha * lc2 + (1.f - last_alpha) * a2;
+                lc0 = ergb.x; lc1 = ergb.y; lc2 = ergb.z;
+                float dL_dalpha = ((ergb.x - a0) * g0 + (ergb.y - a1) * g1 + (ergb.z - a2) * g2) * T;
+                last_alpha = al;
+                dL_dalpha += (-T_final * inv1ma) * bg_dot;
+                const float gop = G * dL_dalpha;           // dL/dopacity term
+                const float w = eco.w * gop;               // o * G * dL/dalpha   (the 0.99 clamp passes the gradient)
+                const float wx = w * dx, wy = w * dy;
+                m[0] = wx; m[1] = wy; m[2] = wx * dx; m[3] = wx * dy; m[4] = wy * dy;
+                m[5] = gop;
+                m[6] = dch * g0; m[7] = dch * g1; m[8] = dch * g2;
+            }
+#pragma unroll
+            for (int k = 0; k < kNG; ++k) m[k] = dpp_add<0xB1, 0xf>(m[k]);      // quad_perm [1,0,3,2]
+#pragma unroll
+            for (int k = 0; k < kNG; ++k) m[k] = dpp_add<0x4E, 0xf>(m[k]);      // quad_perm [2,3,0,1]: quad sums
+            float s0 = t_is0 ? m[0] : (t_is1 ? m[1] : (t_is2 ? m[2] : m[3]));
+            float s1 = t_is0 ? m[4] : (t_is1 ? m[5] : (t_is2 ? m[6] : m[7]));
+            float s2 = m[8];
+            s0 = dpp_add<0x124, 0xf>(s0); s1 = dpp_add<0x124, 0xf>(s1); s2 = dpp_add<0x124, 0xf>(s2);   // row_ror:4
+            s0 = dpp_add<0x128, 0xf>(s0); s1 = dpp_add<0x128, 0xf>(s1); s2 = dpp_add<0x128, 0xf>(s2);   // row_ror:8
+            const float mine = l_lt4 ? s0 : (l_lt8 ? s1 : s2);              // lane k of the row: total of value k
+            const bool row_any = ((hm >> (rg.row << 4)) & 0xffffull) != 0;
+            if (l_lt9 && row_any) atomicAdd(reinterpret_cast<float *>(s_accb + off + l16x4), mine);   // ds_add_f32
+        }
+        __builtin_amdgcn_wave_barrier();
+        // flush: nine consecutive lanes publish one staged entry (36 contiguous bytes = 2 memory-side requests), seven
+        // entries per instruction; the per-entry constants of the raw moments are applied here
+#pragma unroll 1
+        for (int e0 = 0; e0 < 64; e0 += 7) {
+            const int e = e0 + fq;
+            if (fq < 7 && e < 64) {
+                const float *sa = reinterpret_cast<const float *>(s_accb + e * kRecBytes);
+                const float S = sa[fk];
+                if (S != 0.f || fk < 2) {
+                    const float4 co = *reinterpret_cast<const float4 *>(s_rec + e * kRecBytes);
+                    const float O = sa[fk ^ 1];
+                    float val = S;
+                    if (fk == 0) val = -(co.x * S + co.y * O) * ddelx_dx;
+                    else if (fk == 1) val = -(co.z * S + co.y * O) * ddely_dy;
+                    else if (fk < 5) val = -0.5f * S;
+                    if (val != 0.f) {
+                        const uint32_t gid = __float_as_uint(*reinterpret_cast<const float *>(s_rec + e * kRecBytes + 28));
+                        atomicAdd(acc + 12 * (size_t)gid + fk_off, val);
+                    }
+                }
+            }
+        }
+    }
+#ifdef D3GA_DIAG_COUNTERS
+    if (lane == 0) {
+        atomicAdd(&g_diag[0], 1ull); atomicAdd(&g_diag[1], (unsigned long long)d_batches);
+        atomicAdd(&g_diag[2], (unsigned long long)d_iter); atomicAdd(&g_diag[3], (unsigned long long)d_hit);
+        atomicAdd(&g_diag[4], (unsigned long long)d_lanes); atomicAdd(&g_diag[5], (unsigned long long)d_rows);
+        atomicAdd(&g_diag[6], (unsigned long long)d_ent); atomicMax(&g_diag[7], (unsigned long long)d_iter);
+        (void)d_staged;
+    }
+#endif
+}
+
 __global__ __launch_bounds__(64) void composite_bwd_rows_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
     uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
@@ -590,10 +799,6 @@ __global__ __launch_bounds__(64) void composite_bwd_rows_kernel(
     __shared__ float4 s_rgb[64];
     __shared__ uint32_t s_id[64];
     __shared__ uint8_t s_list[4][64];
-    // LDSACC: per-batch accumulator of the wavefront -- the four rows' totals for a staged entry meet here (ds_add_f32)
-    // and ONE lane per entry flushes them with nine global atomics at the end of the batch: the same Gaussian is
-    // usually hit by several rows of the quadrant, so the memory-side atomic requests roughly halve
-    __shared__ float s_acc[LDSACC ? 64 * kNG : 1];
 
     float T = T_final;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -601,8 +806,6 @@ __global__ __launch_bounds__(64) void composite_bwd_rows_kernel(
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     const int l16 = lane & 15;
     const int slot_off = l16 < 2 ? l16 : l16 + 1;          // lanes 0..8 of each row publish value l16; acc layout 0,1|3,4,5|6|7,8,9
-    const int fq = lane / 9, fk = lane - 9 * fq;           // LDSACC flush: lane -> (entry within a group of 7, value)
-    const int fk_off = fk < 2 ? fk : fk + 1;
 
     float2 nxy = make_float2(0.f, 0.f);
     float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -626,10 +829,6 @@ __global__ __launch_bounds__(64) void composite_bwd_rows_kernel(
         const uint32_t mypos = hi - (uint32_t)lane;        // list position of the entry this lane staged
         __builtin_amdgcn_wave_barrier();
         s_xy[lane] = cxy; s_co[lane] = cco; s_rgb[lane] = crgb; s_id[lane] = cid;
-        if constexpr (LDSACC) {
-#pragma unroll
-            for (int k = 0; k < kNG; ++k) s_acc[lane * kNG + k] = 0.f;
-        }
         int trip;
         const int my_cnt = build_row_lists(
             s_list, mypos <= rl0 && block_hit(cxy.x, cxy.y, hx, hy, bx0, by0, 3.0f),
@@ -693,23 +892,7 @@ __global__ __launch_bounds__(64) void composite_bwd_rows_kernel(
             for (int k = 1; k < kNG; ++k) mine = (l16 == k) ? v[k] : mine;
             const bool row_any = ((hm >> (rg.row << 4)) & 0xffffull) != 0;
             // lanes 0..8 of every row that was hit: one atomic instruction, up to 36 active lanes
-            if constexpr (LDSACC) {
-                if (l16 < kNG && row_any) atomicAdd(&s_acc[j * kNG + l16], mine);          // ds_add_f32
-            } else {
-                if (l16 < kNG && row_any) atomicAdd(acc + 12 * (size_t)gid + slot_off, mine);
-            }
-        }
-        if constexpr (LDSACC) {
-            __builtin_amdgcn_wave_barrier();
-            // flush: nine consecutive lanes publish one staged entry (36 contiguous bytes = 2 memory-side requests,
-            // like the direct path), seven entries per instruction
-            for (int e0 = 0; e0 < 64; e0 += 7) {
-                const int e = e0 + fq;
-                if (fq < 7 && e < 64) {
-                    const float val = s_acc[e * kNG + fk];
-                    if (val != 0.f) atomicAdd(acc + 12 * (size_t)s_id[e] + fk_off, val);
-                }
-            }
+            if (l16 < kNG && row_any) atomicAdd(acc + 12 * (size_t)gid + slot_off, mine);
         }
     }
 }
@@ -775,6 +958,17 @@ extern "C" int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const fl
     return check_launch(s, prm->debug);
 }
 
+#ifdef D3GA_DIAG
+extern "C" int d3ga_diag_read(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
 extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const float *bg, const void *geom,
                                          const void *binning, int64_t d_capacity, const void *img,
                                          const float *dL_dpix, float *acc, d3ga_stream_t stream) {
@@ -787,12 +981,20 @@ extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const fl
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
     const ImgBuf im = carve_img(const_cast<void *>(img), prm->W, prm->H);
+#ifdef D3GA_DIAG
+    if (composite_variant() & 512) {
+        hipLaunchKernelGGL(composite_bwd_rows3_kernel, dim3(2 * quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
+                           gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
+                           im.final_T, im.n_contrib, dL_dpix, acc);
+        return check_launch(s, prm->debug);
+    }
+#endif
     if ((composite_variant() & 24) == 24)
-        hipLaunchKernelGGL(composite_bwd_rows_kernel<true>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
+        hipLaunchKernelGGL(composite_bwd_rows3_kernel, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
                            gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
                            im.final_T, im.n_contrib, dL_dpix, acc);
     else if (composite_variant() & 8)
-        hipLaunchKernelGGL(composite_bwd_rows_kernel<false>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
+        hipLaunchKernelGGL(composite_bwd_rows_kernel, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
                            gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
                            im.final_T, im.n_contrib, dL_dpix, acc);
     else if (composite_variant() & 2)

@@ -8,7 +8,7 @@ VARS=${1:-"3 15"}
 for round in 1 2; do
  for v in $VARS; do
   echo "variant $v round $round" >> gpurun_out/ab.log
-  D3GA_COMPOSITE_VARIANT=$v timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "
+  D3GA_COMPOSITE_VARIANT=$v timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-train-step 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k:v['ms'] for k,v in d['kernels'].items()})" >> gpurun_out/ab.log
  done
