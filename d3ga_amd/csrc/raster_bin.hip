@@ -27,9 +27,9 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(int tiles, const 
                                                                uint32_t *__restrict__ huge_tiles,
                                                                uint32_t *__restrict__ mid_tiles, uint32_t n_small,
                                                                uint32_t n_mid, uint32_t n_large) {
-    __shared__ uint32_t s_sum[kScanBlock];
+    __shared__ uint32_t s_wave[kScanBlock / 64];
     __shared__ uint32_t s_max;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_max = 0;
     const int per = (tiles + kScanBlock - 1) / kScanBlock;
     const int b = min(tid * per, tiles), e = min(b + per, tiles);
@@ -39,16 +39,26 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(int tiles, const 
         sum += c;
         mx = max(mx, c);
     }
-    s_sum[tid] = sum;
-    __syncthreads();
-    atomicMax(&s_max, mx);
-    for (int off = 1; off < kScanBlock; off <<= 1) {
-        const uint32_t v = tid >= off ? s_sum[tid - off] : 0u;
-        __syncthreads();
-        s_sum[tid] += v;
-        __syncthreads();
+    // block-wide exclusive prefix: wavefront scan (6 shuffle steps) + 16 wavefront totals through LDS
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
     }
-    uint32_t run = s_sum[tid] - sum;
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (lane == 0) atomicMax(&s_max, mx);
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kScanBlock / 64; ++w) {
+        const uint32_t v = s_wave[w];
+        wbase += w < wave ? v : 0u;
+        total += v;
+    }
+    __syncthreads();
+    uint32_t run = wbase + incl - sum;
     for (int t = b; t < e; ++t) {
         const uint32_t c = count[t];
         start[t] = run;
@@ -60,7 +70,6 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(int tiles, const 
         else if (c > n_small) mid_tiles[atomicAdd(&counters[D3GA_CNT_MID], 1u)] = (uint32_t)t;
     }
     if (tid == kScanBlock - 1) {
-        const uint32_t total = s_sum[kScanBlock - 1];
         start[tiles] = total;
         counters[D3GA_CNT_D] = total;
         counters[D3GA_CNT_OVERFLOW] = (uint64_t)total > dcap ? 1u : 0u;
@@ -124,21 +133,22 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr k, int n, int tid, int nthre
     int n2 = 1;
     while (n2 < n) n2 <<= 1;
     const int half = n2 >> 1;
-    for (int size = 2; size <= n2; size <<= 1) {
+    // (sizes and distances are powers of two: shifts, not integer divisions -- a 32-bit division costs ~40 instructions)
+    for (int size = 2, lsz = 1; size <= n2; size <<= 1, ++lsz) {
         const int hs = size >> 1;
         for (int i = tid; i < half; i += nthreads) {          // flip
-            const int blk = i / hs, off = i - blk * hs;
-            const int lo = blk * size + off, hi = blk * size + size - 1 - off;
+            const int blk = i >> (lsz - 1), off = i & (hs - 1);
+            const int lo = (blk << lsz) + off, hi = (blk << lsz) + size - 1 - off;
             if (hi < n) {
                 const uint64_t a = k[lo], b = k[hi];
                 if (b < a) { k[lo] = b; k[hi] = a; }
             }
         }
         __syncthreads();
-        for (int j = hs >> 1; j >= 1; j >>= 1) {              // disperse
+        for (int j = hs >> 1, lj = lsz - 2; j >= 1; j >>= 1, --lj) {   // disperse
             for (int i = tid; i < half; i += nthreads) {
-                const int blk = i / j, off = i - blk * j;
-                const int lo = blk * 2 * j + off, hi = lo + j;
+                const int blk = i >> lj, off = i & (j - 1);
+                const int lo = (blk << (lj + 1)) + off, hi = lo + j;
                 if (hi < n) {
                     const uint64_t a = k[lo], b = k[hi];
                     if (b < a) { k[lo] = b; k[hi] = a; }
@@ -180,21 +190,21 @@ __device__ __forceinline__ void bitonic_sort_regs8(uint64_t *k, int n, int tid, 
             if (base + i < n) k[PH(base + i)] = r[i];
     }
     __syncthreads();
-    for (int size = 16; size <= n2; size <<= 1) {
+    for (int size = 16, lsz = 4; size <= n2; size <<= 1, ++lsz) {
         const int hs = size >> 1;
         for (int i = tid; i < half; i += nthreads) {          // flip (LDS)
-            const int blk = i / hs, off = i - blk * hs;
-            const int lo = blk * size + off, hi = blk * size + size - 1 - off;
+            const int blk = i >> (lsz - 1), off = i & (hs - 1);
+            const int lo = (blk << lsz) + off, hi = (blk << lsz) + size - 1 - off;
             if (hi < n) {
                 const uint64_t a = k[PH(lo)], b = k[PH(hi)];
                 if (b < a) { k[PH(lo)] = b; k[PH(hi)] = a; }
             }
         }
         __syncthreads();
-        for (int j = hs >> 1; j >= 8; j >>= 1) {              // disperse, distance >= 8 (LDS)
+        for (int j = hs >> 1, lj = lsz - 2; j >= 8; j >>= 1, --lj) {   // disperse, distance >= 8 (LDS)
             for (int i = tid; i < half; i += nthreads) {
-                const int blk = i / j, off = i - blk * j;
-                const int lo = blk * 2 * j + off, hi = lo + j;
+                const int blk = i >> lj, off = i & (j - 1);
+                const int lo = (blk << (lj + 1)) + off, hi = lo + j;
                 if (hi < n) {
                     const uint64_t a = k[PH(lo)], b = k[PH(hi)];
                     if (b < a) { k[PH(lo)] = b; k[PH(hi)] = a; }

@@ -16,12 +16,30 @@ struct PreOut {
     uint8_t clampmask;
 };
 
-// R1 for Gaussian i.  Exactly one of (sh_row|colors_precomp), ((scales,rotations)|cov3D_precomp) is non-null.
-// sh_row points at THIS Gaussian's 3*M SH floats (in global memory or in an LDS staging row).
+// SH basis of Gaussian i's view direction (the direction is normalize(mean - campos), as in R1)
+D3GA_HD void sh_view_basis(const d3ga_raster_params &prm, const float *means3D, int i, const float *campos, float B[16]) {
+    const V3 d = ld3(means3D, i) - v3(campos[0], campos[1], campos[2]);
+    const float inv = 1.0f / sqrtf(dot(d, d));
+    sh_basis(prm.sh_degree, d.x * inv, d.y * inv, d.z * inv, B);
+}
+// acc[c] += sum_{k in [k0, k1)} B[k] * coeff[k][c];  `part` points at coefficient k0 of the row (3 floats per coefficient)
+D3GA_HD void sh_accumulate(const float B[16], const float *part, int k0, int k1, int nb, float acc[3]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {           // fixed trip count: keeps B[] in registers
+        if (k >= k0 && k < k1 && k < nb) {
+            const float *c = part + 3 * (k - k0);
+            acc[0] += B[k] * c[0]; acc[1] += B[k] * c[1]; acc[2] += B[k] * c[2];
+        }
+    }
+}
+
+// R1 for Gaussian i.  Exactly one of (sh_row|sh_acc|colors_precomp), ((scales,rotations)|cov3D_precomp) is non-null.
+// sh_row points at THIS Gaussian's 3*M SH floats (in global memory or in an LDS staging row); alternatively sh_acc
+// holds the already evaluated sum_k Y_k(dir) * coeff_k (3 floats, see sh_view_basis / sh_accumulate).
 D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float *means3D, const float *sh_row,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
-                              const float *projmatrix, const float *campos) {
+                              const float *projmatrix, const float *campos, const float *sh_acc = nullptr) {
     PreOut o;
     const V3 mean = ld3(means3D, i);
     if (cov3D_precomp) {
@@ -42,18 +60,13 @@ D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float 
         o.rgb[0] = colors_precomp[3 * (size_t)i]; o.rgb[1] = colors_precomp[3 * (size_t)i + 1];
         o.rgb[2] = colors_precomp[3 * (size_t)i + 2];
     } else {
-        const V3 d = mean - v3(campos[0], campos[1], campos[2]);
-        const float inv = 1.0f / sqrtf(dot(d, d));
-        float B[16];
-        sh_basis(prm.sh_degree, d.x * inv, d.y * inv, d.z * inv, B);
-        const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
-        const float *sh = sh_row;
         float acc[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {       // fixed trip count: keeps B[] in registers
-            if (k < nb) {
-                acc[0] += B[k] * sh[3 * k]; acc[1] += B[k] * sh[3 * k + 1]; acc[2] += B[k] * sh[3 * k + 2];
-            }
+        if (sh_acc) {
+            acc[0] = sh_acc[0]; acc[1] = sh_acc[1]; acc[2] = sh_acc[2];
+        } else {
+            float B[16];
+            sh_view_basis(prm, means3D, i, campos, B);
+            sh_accumulate(B, sh_row, 0, 16, (prm.sh_degree + 1) * (prm.sh_degree + 1), acc);
         }
         for (int c = 0; c < 3; ++c) {
             const float v = acc[c] + 0.5f;
