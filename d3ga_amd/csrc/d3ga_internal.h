@@ -94,6 +94,12 @@ struct TileWindow {
     int x0, y0, w, h;             // window origin and size in tiles; w*h == 0 -> nothing visible in the block
     __device__ __forceinline__ int area() const { return w * h; }
     __device__ __forceinline__ bool fits() const { return w * h <= kWinTiles; }
+    // window slot k -> global tile index (exact for k < 4096: the fractional part of (k + 0.5) / w is >= 0.5 / w away from
+    // an integer, the float error is < 5e-4 / w; a 32-bit integer division costs ~40 instructions)
+    __device__ __forceinline__ int tile_of(int k, int gx, float inv_w) const {
+        const int r = (int)(((float)k + 0.5f) * inv_w);
+        return (y0 + r) * gx + x0 + (k - r * w);
+    }
 };
 
 #ifdef __HIPCC__
@@ -101,9 +107,17 @@ struct TileWindow {
 __device__ __forceinline__ TileWindow block_tile_window(int *s_box, bool visible, int rx0, int ry0, int rx1, int ry1) {
     if (threadIdx.x == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = 0; s_box[3] = 0; }
     __syncthreads();
-    if (visible) {
-        atomicMin(&s_box[0], rx0); atomicMin(&s_box[1], ry0);
-        atomicMax(&s_box[2], rx1); atomicMax(&s_box[3], ry1);
+    // wavefront-level min/max first (butterfly shuffles), then ONE lane per wavefront touches the four LDS words:
+    // 256 same-address LDS atomics per word serialise
+    int bx0 = visible ? rx0 : 0x7fffffff, by0 = visible ? ry0 : 0x7fffffff, bx1 = visible ? rx1 : 0, by1 = visible ? ry1 : 0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, off)); by0 = min(by0, __shfl_xor(by0, off));
+        bx1 = max(bx1, __shfl_xor(bx1, off)); by1 = max(by1, __shfl_xor(by1, off));
+    }
+    if ((threadIdx.x & 63) == 0 && bx1 > 0) {
+        atomicMin(&s_box[0], bx0); atomicMin(&s_box[1], by0);
+        atomicMax(&s_box[2], bx1); atomicMax(&s_box[3], by1);
     }
     __syncthreads();
     TileWindow win;

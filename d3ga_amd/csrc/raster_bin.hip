@@ -104,9 +104,10 @@ __global__ __launch_bounds__(kBlock) void tile_scatter_kernel(int P, int gx, con
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx) atomicAdd(&s_cnt[(ty - win.y0) * win.w + (tx - win.x0)], 1u);
         __syncthreads();
+        const float inv_w = 1.0f / (float)win.w;
         for (int k = tid; k < area; k += kBlock) {           // ONE global (returning) atomic per touched tile
             const uint32_t c = s_cnt[k];
-            if (c) s_base[k] = atomicAdd(&cursor[(win.y0 + k / win.w) * gx + win.x0 + k % win.w], c);
+            if (c) s_base[k] = atomicAdd(&cursor[win.tile_of(k, gx, inv_w)], c);
             s_cnt[k] = 0;
         }
         __syncthreads();

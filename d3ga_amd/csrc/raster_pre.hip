@@ -107,6 +107,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     }
     bool visible = false;
     int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+#ifdef D3GA_DIAG
+    if (prm.debug & 0x200) { if (acc[0] == 12345.f) radii[0] = 1; return; }     // diag: SH staging only
+#endif
     if (i < prm.P) {
         // two call sites so that each inlined copy sees ONE address space (registers vs global_load, never flat)
         const PreOut o = staged ? preprocess_one(prm, i, means3D, nullptr, colors_precomp, opacities, scales, rotations,
@@ -130,6 +133,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
         visible = sp.visible;
         r0 = sp.rect[0]; r1 = sp.rect[1]; r2 = sp.rect[2]; r3 = sp.rect[3];
     }
+#ifdef D3GA_DIAG
+    if (prm.debug & 0x100) return;                                              // diag: no histogram
+#endif
     // ---- tile histogram (counting-sort pass 1) through the block's LDS window ----
     const int gx = (prm.W + kTile - 1) / kTile;
     const TileWindow win = block_tile_window(s_box, visible, r0, r1, r2, r3);   // barriers inside: slabs are dead now
@@ -144,9 +150,10 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
             for (int ty = r1; ty < r3; ++ty)
                 for (int tx = r0; tx < r2; ++tx) atomicAdd(&s_cnt[(ty - win.y0) * win.w + (tx - win.x0)], 1u);
         __syncthreads();
+        const float inv_w = 1.0f / (float)win.w;
         for (int k = tid; k < area; k += kBlock) {
             const uint32_t c = s_cnt[k];
-            if (c) atomicAdd(&tile_count[(win.y0 + k / win.w) * gx + win.x0 + k % win.w], c);
+            if (c) atomicAdd(&tile_count[win.tile_of(k, gx, inv_w)], c);
         }
     } else if (visible) {                                    // huge footprints: straight to global memory
         for (int ty = r1; ty < r3; ++ty)
@@ -308,7 +315,7 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     hipLaunchKernelGGL(preprocess_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
                        colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, g,
                        bin.tile_count, bin.counters, radii);
-    return check_launch(s, prm->debug);
+    return check_launch(s, prm->debug & 0xff);
 }
 
 extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const float *means3D, const float *shs,
