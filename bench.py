@@ -88,8 +88,9 @@ class Frame:
         from d3ga_amd.renderer import render
         p = self.params
         tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
-        means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0 + p["delta_bary"],
-                                  self.canon_grad, torch.exp(p["scaling"]), p["rotation"])
+        # canon_barys = barys + delta_bary, scales = exp(scaling) (cage_net.py:213-214): fused into the deform kernels
+        means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad, p["scaling"],
+                                  p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp")
         pkg = {"means3D": means, "cov3D_precomp": cov6, "opacities": torch.sigmoid(p["opacity"]),
                "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
         img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
@@ -111,8 +112,8 @@ class Frame:
             self.sil_target = (self.target.mean(0, keepdim=True) > 0.5).float().expand(3, -1, -1).contiguous()
             self.bg0 = torch.zeros_like(self.bg)
         tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
-        means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0 + p["delta_bary"],
-                                  self.canon_grad, torch.exp(p["scaling"]), p["rotation"])
+        means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad, p["scaling"],
+                                  p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp")
         pkg = {"means3D": means, "cov3D_precomp": cov6, "opacities": torch.sigmoid(p["opacity"]),
                "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
         img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
@@ -148,8 +149,8 @@ def deform_gpu_comparison(frame, reps=50):
 
     def fused():
         tp = lbs_cage(frame.canon, p["delta_node"], frame.joint_mats, frame.skin_idx, frame.skin_w)
-        m, c = cage_deform(tp, frame.tetras, frame.tetra_id, frame.barys0 + p["delta_bary"], frame.canon_grad,
-                           torch.exp(p["scaling"]), p["rotation"])
+        m, c = cage_deform(tp, frame.tetras, frame.tetra_id, frame.barys0, frame.canon_grad, p["scaling"], p["rotation"],
+                           delta_barys=p["delta_bary"], scale_activation="exp")
         (m.sum() + c.sum()).backward()
 
     def unfused():

@@ -64,49 +64,64 @@ def vertex_adjacency(tetras, tetra_id, n_vertices):
 
 class _CageDeform(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations):
+    def forward(ctx, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations, delta_barys, flags):
         require_cuda(tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations)
-        tetpoints, barys, canon_grad, scales, rotations = map(_f32c, (tetpoints, barys, canon_grad, scales, rotations))
+        tetpoints, barys, canon_grad, scales, rotations, delta_barys = map(
+            _f32c, (tetpoints, barys, canon_grad, scales, rotations, delta_barys))
         P = barys.shape[0]
         means = torch.empty((P, 3), dtype=torch.float32, device=barys.device)
         cov6 = torch.empty((P, 6), dtype=torch.float32, device=barys.device)
-        check(_lib.lib().d3ga_cage_deform_fwd(P, dptr(tetpoints), dptr(tetras), dptr(tetra_id), dptr(barys),
-                                              dptr(canon_grad), dptr(scales), dptr(rotations), dptr(means),
-                                              dptr(cov6), stream_handle()), "d3ga_cage_deform_fwd")
-        ctx.save_for_backward(tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations)
+        check(_lib.lib().d3ga_cage_deform_fwd_ex(P, dptr(tetpoints), dptr(tetras), dptr(tetra_id), dptr(barys),
+                                                 dptr(canon_grad), dptr(scales), dptr(rotations), dptr(delta_barys),
+                                                 flags, dptr(means), dptr(cov6), stream_handle()),
+              "d3ga_cage_deform_fwd_ex")
+        ctx.flags = flags
+        ctx.has_delta = delta_barys is not None
+        ctx.save_for_backward(tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations,
+                              delta_barys if delta_barys is not None else torch.empty(0, device=barys.device))
         return means, cov6
 
     @staticmethod
     def backward(ctx, g_means, g_cov6):
-        tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations = ctx.saved_tensors
+        tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations, delta_barys = ctx.saved_tensors
+        if not ctx.has_delta:
+            delta_barys = None
         P, V = barys.shape[0], tetpoints.shape[0]
         dev = barys.device
         g_means = torch.zeros((P, 3), device=dev) if g_means is None else _f32c(g_means)
         g_cov6 = torch.zeros((P, 6), device=dev) if g_cov6 is None else _f32c(g_cov6)
         need = ctx.needs_input_grad
         g_tp = torch.empty((V, 3), dtype=torch.float32, device=dev) if need[0] else None
-        g_b = torch.empty((P, 4), dtype=torch.float32, device=dev) if need[3] else None
+        g_b = torch.empty((P, 4), dtype=torch.float32, device=dev) if (need[3] or need[7]) else None
         g_s = torch.empty((P, 3), dtype=torch.float32, device=dev) if need[5] else None
         g_r = torch.empty((P, 4), dtype=torch.float32, device=dev) if need[6] else None
         vstart = vitems = corner = None
         if need[0] and P > 0:
             vstart, vitems = vertex_adjacency(tetras, tetra_id, V)
             corner = torch.empty((P, 4, 3), dtype=torch.float32, device=dev)
-        check(_lib.lib().d3ga_cage_deform_bwd(P, V, dptr(tetpoints), dptr(tetras), dptr(tetra_id), dptr(barys),
-                                              dptr(canon_grad), dptr(scales), dptr(rotations), dptr(g_means),
-                                              dptr(g_cov6), dptr(g_tp), dptr(g_b), dptr(g_s), dptr(g_r),
-                                              dptr(vstart), dptr(vitems), dptr(corner), stream_handle()),
-              "d3ga_cage_deform_bwd")
-        return g_tp, None, None, g_b, None, g_s, g_r
+        check(_lib.lib().d3ga_cage_deform_bwd_ex(P, V, dptr(tetpoints), dptr(tetras), dptr(tetra_id), dptr(barys),
+                                                 dptr(canon_grad), dptr(scales), dptr(rotations), dptr(delta_barys),
+                                                 ctx.flags, dptr(g_means), dptr(g_cov6), dptr(g_tp), dptr(g_b),
+                                                 dptr(g_s), dptr(g_r), dptr(vstart), dptr(vitems), dptr(corner),
+                                                 stream_handle()), "d3ga_cage_deform_bwd_ex")
+        return (g_tp, None, None, g_b if need[3] else None, None, g_s, g_r, g_b if need[7] else None, None)
 
 
-def cage_deform(tetpoints, tetras, tetra_id, barys, canonical_gradient, scales, rotations):
+def cage_deform(tetpoints, tetras, tetra_id, barys, canonical_gradient, scales, rotations, delta_barys=None,
+                scale_activation=None):
     """(tetpoints (V,3), tetras (T,4), tetra_id (P), barys (P,4), canonical_gradient (P,3,3), scales (P,3),
     rotations (P,4) wxyz) -> (means3D (P,3), cov3D_precomp (P,6)); differentiable in tetpoints, barys, scales,
     rotations.  Drop-in for models/cage_net.py:218-230.  Index tensors may be int64
     (as the reference registers them, lib/cage.py:331-337); they are converted to int32 once per call --
-    pass int32 to avoid the copy."""
-    return _CageDeform.apply(tetpoints, _i32c(tetras), _i32c(tetra_id), barys, canonical_gradient, scales, rotations)
+    pass int32 to avoid the copy.
+
+    Optional fusion of the two activations in front of the op (models/cage_net.py:213-214):
+    `delta_barys` (P,4) is added to `barys` inside the kernel (differentiable), and `scale_activation="exp"` makes
+    `scales` the raw log-scales (`scaling + delta`), with exp applied on load and the chain rule in the backward."""
+    if scale_activation not in (None, "exp"):
+        raise ValueError(f"scale_activation must be None or 'exp', got {scale_activation!r}")
+    return _CageDeform.apply(tetpoints, _i32c(tetras), _i32c(tetra_id), barys, canonical_gradient, scales, rotations,
+                             delta_barys, 1 if scale_activation == "exp" else 0)
 
 
 class _LbsCage(torch.autograd.Function):

@@ -73,16 +73,24 @@ __device__ __forceinline__ void load_deform_in(int i, const float *__restrict__ 
                                                const int32_t *__restrict__ tetras, const int32_t *__restrict__ tetra_id,
                                                const float *__restrict__ barys, const float *__restrict__ canon_grad,
                                                const float *__restrict__ scales, const float *__restrict__ rots,
-                                               DeformIn &in, int4 &vid) {
+                                               const float *__restrict__ delta_barys, int flags, DeformIn &in,
+                                               int4 &vid) {
     const int t = tetra_id[i];
     vid = reinterpret_cast<const int4 *>(tetras)[t];
     in.x0 = load3(tetpoints, vid.x); in.x1 = load3(tetpoints, vid.y);
     in.x2 = load3(tetpoints, vid.z); in.x3 = load3(tetpoints, vid.w);
     const float4 b = reinterpret_cast<const float4 *>(barys)[i];
     in.bary[0] = b.x; in.bary[1] = b.y; in.bary[2] = b.z; in.bary[3] = b.w;
+    if (delta_barys) {                       // canon_barys = barys + delta_bary (models/cage_net.py:213), fused
+        const float4 d = reinterpret_cast<const float4 *>(delta_barys)[i];
+        in.bary[0] += d.x; in.bary[1] += d.y; in.bary[2] += d.z; in.bary[3] += d.w;
+    }
 #pragma unroll
     for (int k = 0; k < 9; ++k) in.G.m[k] = canon_grad[9 * (size_t)i + k];
     in.s[0] = scales[3 * (size_t)i]; in.s[1] = scales[3 * (size_t)i + 1]; in.s[2] = scales[3 * (size_t)i + 2];
+    if (flags & D3GA_DEFORM_LOG_SCALES) {    // scales = exp(scaling) (models/cage_net.py:214), fused
+        in.s[0] = expf(in.s[0]); in.s[1] = expf(in.s[1]); in.s[2] = expf(in.s[2]);
+    }
     const float4 q = reinterpret_cast<const float4 *>(rots)[i];
     in.q[0] = q.x; in.q[1] = q.y; in.q[2] = q.z; in.q[3] = q.w;
 }
@@ -94,12 +102,13 @@ __global__ __launch_bounds__(kBlock) void cage_deform_fwd_kernel(int P, const fl
                                                                  const float *__restrict__ canon_grad,
                                                                  const float *__restrict__ scales,
                                                                  const float *__restrict__ rots,
+                                                                 const float *__restrict__ delta_barys, int flags,
                                                                  float *__restrict__ means, float *__restrict__ cov6) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= P) return;
     DeformIn in;
     int4 vid;
-    load_deform_in(i, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rots, in, vid);
+    load_deform_in(i, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rots, delta_barys, flags, in, vid);
     float m[3], c[6];
     deform_fwd(in, m, c);
     means[3 * (size_t)i] = m[0]; means[3 * (size_t)i + 1] = m[1]; means[3 * (size_t)i + 2] = m[2];
@@ -116,14 +125,15 @@ __device__ __forceinline__ void atomic_add3(float *base, int v, V3 g) {
 __global__ __launch_bounds__(kBlock) void cage_deform_bwd_kernel(
     int P, const float *__restrict__ tetpoints, const int32_t *__restrict__ tetras, const int32_t *__restrict__ tetra_id,
     const float *__restrict__ barys, const float *__restrict__ canon_grad, const float *__restrict__ scales,
-    const float *__restrict__ rots, const float *__restrict__ g_means, const float *__restrict__ g_cov6,
+    const float *__restrict__ rots, const float *__restrict__ delta_barys, int flags,
+    const float *__restrict__ g_means, const float *__restrict__ g_cov6,
     float *__restrict__ g_tetpoints, float *__restrict__ g_barys, float *__restrict__ g_scales,
     float *__restrict__ g_rots, float *__restrict__ corner_grads) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= P) return;
     DeformIn in;
     int4 vid;
-    load_deform_in(i, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rots, in, vid);
+    load_deform_in(i, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rots, delta_barys, flags, in, vid);
     float gm[3] = {g_means[3 * (size_t)i], g_means[3 * (size_t)i + 1], g_means[3 * (size_t)i + 2]};
     float gc[6];
 #pragma unroll
@@ -132,6 +142,9 @@ __global__ __launch_bounds__(kBlock) void cage_deform_bwd_kernel(
     deform_bwd(in, gm, gc, o);
     if (g_barys) reinterpret_cast<float4 *>(g_barys)[i] = make_float4(o.gbary[0], o.gbary[1], o.gbary[2], o.gbary[3]);
     if (g_scales) {
+        if (flags & D3GA_DEFORM_LOG_SCALES) {    // d/d(log s) = s * d/ds
+            o.gs[0] *= in.s[0]; o.gs[1] *= in.s[1]; o.gs[2] *= in.s[2];
+        }
         g_scales[3 * (size_t)i] = o.gs[0]; g_scales[3 * (size_t)i + 1] = o.gs[1]; g_scales[3 * (size_t)i + 2] = o.gs[2];
     }
     if (g_rots) reinterpret_cast<float4 *>(g_rots)[i] = make_float4(o.gq[0], o.gq[1], o.gq[2], o.gq[3]);
@@ -237,16 +250,51 @@ extern "C" int d3ga_lbs_cage_bwd(int V, int K, const float *joint_mats, const in
     return check_launch((hipStream_t)stream, 0);
 }
 
-extern "C" int d3ga_cage_deform_fwd(int P, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
-                                    const float *barys, const float *canon_grad, const float *scales,
-                                    const float *rots, float *means3D, float *cov6, d3ga_stream_t stream) {
+extern "C" int d3ga_cage_deform_fwd_ex(int P, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
+                                       const float *barys, const float *canon_grad, const float *scales,
+                                       const float *rots, const float *delta_barys, int32_t flags, float *means3D,
+                                       float *cov6, d3ga_stream_t stream) {
+    if (flags & ~D3GA_DEFORM_LOG_SCALES) return D3GA_E_CONFIG;
     if (P < 0) return D3GA_E_SIZE;
     if (P == 0) return D3GA_OK;
     if (!tetpoints || !tetras || !tetra_id || !barys || !canon_grad || !scales || !rots || !means3D || !cov6)
         return D3GA_E_NULL;
     hipLaunchKernelGGL(cage_deform_fwd_kernel, dim3(nblocks(P)), dim3(kBlock), 0, (hipStream_t)stream, P, tetpoints,
-                       tetras, tetra_id, barys, canon_grad, scales, rots, means3D, cov6);
+                       tetras, tetra_id, barys, canon_grad, scales, rots, delta_barys, (int)flags, means3D, cov6);
     return check_launch((hipStream_t)stream, 0);
+}
+
+extern "C" int d3ga_cage_deform_fwd(int P, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
+                                    const float *barys, const float *canon_grad, const float *scales,
+                                    const float *rots, float *means3D, float *cov6, d3ga_stream_t stream) {
+    return d3ga_cage_deform_fwd_ex(P, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rots, nullptr, 0, means3D,
+                                   cov6, stream);
+}
+
+extern "C" int d3ga_cage_deform_bwd_ex(int P, int V, const float *tetpoints, const int32_t *tetras,
+                                       const int32_t *tetra_id, const float *barys, const float *canon_grad,
+                                       const float *scales, const float *rots, const float *delta_barys, int32_t flags,
+                                       const float *g_means, const float *g_cov6, float *g_tetpoints, float *g_barys,
+                                       float *g_scales, float *g_rots, const int32_t *vert_start,
+                                       const int32_t *vert_items, float *corner_grads, d3ga_stream_t stream) {
+    if (P < 0 || V < 0) return D3GA_E_SIZE;
+    if (flags & ~D3GA_DEFORM_LOG_SCALES) return D3GA_E_CONFIG;
+    hipStream_t s = (hipStream_t)stream;
+    const bool csr = g_tetpoints && vert_start && vert_items && corner_grads;
+    if (g_tetpoints && V > 0 && (!csr || P == 0)) D3GA_HIP(hipMemsetAsync(g_tetpoints, 0, sizeof(float) * 3 * (size_t)V, s));
+    if (P == 0) return D3GA_OK;
+    if (!tetpoints || !tetras || !tetra_id || !barys || !canon_grad || !scales || !rots || !g_means || !g_cov6)
+        return D3GA_E_NULL;
+    hipLaunchKernelGGL(cage_deform_bwd_kernel, dim3(nblocks(P)), dim3(kBlock), 0, s, P, tetpoints, tetras, tetra_id,
+                       barys, canon_grad, scales, rots, delta_barys, (int)flags, g_means, g_cov6, g_tetpoints, g_barys,
+                       g_scales, g_rots, csr ? corner_grads : nullptr);
+    D3GA_TRY(check_launch(s, 0));
+    if (csr && V > 0) {
+        hipLaunchKernelGGL(vertex_gather_kernel, dim3((V + 3) / 4), dim3(kBlock), 0, s, V, vert_start, vert_items,
+                           corner_grads, g_tetpoints);
+        return check_launch(s, 0);
+    }
+    return D3GA_OK;
 }
 
 extern "C" int d3ga_cage_deform_bwd(int P, int V, const float *tetpoints, const int32_t *tetras,
@@ -255,23 +303,9 @@ extern "C" int d3ga_cage_deform_bwd(int P, int V, const float *tetpoints, const 
                                     float *g_tetpoints, float *g_barys, float *g_scales, float *g_rots,
                                     const int32_t *vert_start, const int32_t *vert_items, float *corner_grads,
                                     d3ga_stream_t stream) {
-    if (P < 0 || V < 0) return D3GA_E_SIZE;
-    hipStream_t s = (hipStream_t)stream;
-    const bool csr = g_tetpoints && vert_start && vert_items && corner_grads;
-    if (g_tetpoints && V > 0 && (!csr || P == 0)) D3GA_HIP(hipMemsetAsync(g_tetpoints, 0, sizeof(float) * 3 * (size_t)V, s));
-    if (P == 0) return D3GA_OK;
-    if (!tetpoints || !tetras || !tetra_id || !barys || !canon_grad || !scales || !rots || !g_means || !g_cov6)
-        return D3GA_E_NULL;
-    hipLaunchKernelGGL(cage_deform_bwd_kernel, dim3(nblocks(P)), dim3(kBlock), 0, s, P, tetpoints, tetras, tetra_id,
-                       barys, canon_grad, scales, rots, g_means, g_cov6, g_tetpoints, g_barys, g_scales, g_rots,
-                       csr ? corner_grads : nullptr);
-    D3GA_TRY(check_launch(s, 0));
-    if (csr && V > 0) {
-        hipLaunchKernelGGL(vertex_gather_kernel, dim3((V + 3) / 4), dim3(kBlock), 0, s, V, vert_start, vert_items,
-                           corner_grads, g_tetpoints);
-        return check_launch(s, 0);
-    }
-    return D3GA_OK;
+    return d3ga_cage_deform_bwd_ex(P, V, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rots, nullptr, 0, g_means,
+                                   g_cov6, g_tetpoints, g_barys, g_scales, g_rots, vert_start, vert_items, corner_grads,
+                                   stream);
 }
 
 extern "C" int d3ga_fem_energy_fwd(int T, const float *tetpoints, const int32_t *tetras, const float *Dn_inv,

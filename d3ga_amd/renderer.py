@@ -9,6 +9,19 @@ from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 bg_colors = {"white": (1.0, 1.0, 1.0), "black": (0.0, 0.0, 0.0)}
 
 
+_zeros = {}
+
+
+def _zero_leaf(like):
+    key = (like.device, tuple(like.shape))
+    z = _zeros.get(key)
+    if z is None:
+        if len(_zeros) > 16:
+            _zeros.clear()
+        z = _zeros[key] = torch.zeros(like.shape, dtype=torch.float32, device=like.device)
+    return z.detach().requires_grad_(True)
+
+
 def paste(img, crop):
     """Undo the symmetric-FoV padding of lib/batch.py:186-198 (renderer.py:36-47)."""
     left_w, right_w, top_h, bottom_h, W, H = crop[0], crop[1], crop[2], crop[3], int(crop[4]), int(crop[5])
@@ -64,8 +77,9 @@ def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_
     else:
         shs = None
 
-    # screen-space points: a zero tensor whose .grad receives dL/d(mean2D) (renderer.py:122-128)
-    means2D = torch.zeros_like(means3D, requires_grad=True)
+    # screen-space points: a zero tensor whose .grad receives dL/d(mean2D) (renderer.py:122-128).  A fresh leaf over a
+    # cached block of zeros: no fill kernel per render (the rasterizer never reads or writes its values)
+    means2D = _zero_leaf(means3D)
     try:
         means2D.retain_grad()
     except Exception:

@@ -63,6 +63,7 @@ int d3ga_lbs_cage_bwd(int V, int K, const float *joint_mats, const int32_t *skin
  *        computed WITHOUT atomics (one wavefront per vertex gathers and sums; deterministic);
  *      - with those three NULL it falls back to float atomics into g_tetpoints (zeroed by the call).
  * ------------------------------------------------------------------------------------------------------- */
+#define D3GA_DEFORM_LOG_SCALES 1 /* `scales` holds log-scales: exp() applied inside, g_scales is d/d(log-scale) */
 int d3ga_cage_deform_fwd(int P, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
                          const float *barys, const float *canon_grad, const float *scales, const float *rots,
                          float *means3D, float *cov6, d3ga_stream_t stream);
@@ -71,6 +72,17 @@ int d3ga_cage_deform_bwd(int P, int V, const float *tetpoints, const int32_t *te
                          const float *g_means, const float *g_cov6, float *g_tetpoints, float *g_barys,
                          float *g_scales, float *g_rots, const int32_t *vert_start, const int32_t *vert_items,
                          float *corner_grads, d3ga_stream_t stream);
+/* Same ops with the two activations of models/cage_net.py:213-214 fused: delta_barys (P,4) or NULL is added to barys
+ * (g_barys is then the gradient of both), and flags & D3GA_DEFORM_LOG_SCALES applies scales = exp(.) on load. */
+int d3ga_cage_deform_fwd_ex(int P, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
+                            const float *barys, const float *canon_grad, const float *scales, const float *rots,
+                            const float *delta_barys, int32_t flags, float *means3D, float *cov6, d3ga_stream_t stream);
+int d3ga_cage_deform_bwd_ex(int P, int V, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
+                            const float *barys, const float *canon_grad, const float *scales, const float *rots,
+                            const float *delta_barys, int32_t flags, const float *g_means, const float *g_cov6,
+                            float *g_tetpoints, float *g_barys, float *g_scales, float *g_rots,
+                            const int32_t *vert_start, const int32_t *vert_items, float *corner_grads,
+                            d3ga_stream_t stream);
 
 /* D6  FEM regulariser (lib/cage.py:349-361): per-tet energy 0.5(det F-1)^2 + 0.5(|F|_F^2-3), F = Ds Dn^-1.
  *   fwd: energy (T).  bwd: g_energy (T) -> g_tetpoints (V,3) [zeroed by the call]. */

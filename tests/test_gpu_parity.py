@@ -529,3 +529,31 @@ def test_knn_mean_dist2_matches_bruteforce():
     out = knn_mean_dist2(pts.to(DEV))
     np.testing.assert_allclose(_np(out), ref.numpy(), rtol=1e-4, atol=1e-7)
     assert float(knn_mean_dist2(pts[:1].to(DEV))[0]) == 0.0
+
+
+def test_cage_deform_fused_activations_equal_the_unfused_composition():
+    """delta_barys / scale_activation="exp" (cage_net.py:213-214 fused into the kernels) against the same op fed with
+    barys + delta and exp(scaling) computed by ATen: values and all parameter gradients."""
+    from d3ga_amd.cage_deform import cage_deform
+    inp = scene_inputs("T1")
+    sc = inp["scene"]
+    g = torch.Generator().manual_seed(3)
+    tp = inp["tetpoints"].to(DEV)
+    tetras, tid, cg = sc["tetras"].to(DEV), sc["tetra_id"].to(DEV), inp["canon_grad"].to(DEV)
+    barys = sc["barys"].to(DEV)
+    P = barys.shape[0]
+    wm, wc = torch.randn(P, 3, generator=g).to(DEV), torch.randn(P, 6, generator=g).to(DEV)
+    res = []
+    for fused in (False, True):
+        tpl = tp.clone().requires_grad_(True)
+        delta = (0.01 * torch.randn(P, 4, generator=torch.Generator().manual_seed(4))).to(DEV).requires_grad_(True)
+        scaling = sc["scaling"].to(DEV).clone().requires_grad_(True)
+        rot = sc["rotation"].to(DEV).clone().requires_grad_(True)
+        if fused:
+            m, c = cage_deform(tpl, tetras, tid, barys, cg, scaling, rot, delta_barys=delta, scale_activation="exp")
+        else:
+            m, c = cage_deform(tpl, tetras, tid, barys + delta, cg, torch.exp(scaling), rot)
+        ((m * wm).sum() + (c * wc).sum()).backward()
+        res.append([m, c, tpl.grad, delta.grad, scaling.grad, rot.grad])
+    for a, b in zip(*res):
+        assert rel_err(_np(b), _np(a)) < 2e-6
