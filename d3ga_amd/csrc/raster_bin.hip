@@ -12,7 +12,7 @@
 //                         per (block, tile) through an LDS window (d3ga_internal.h: TileWindow)
 //   tile_sort_lds_kernel       one workgroup per tile: LDS bitonic sort, 8 keys per thread (lists up to 2048 entries)
 //   tile_sort_lds_list_kernel  longer lists (up to 8192): 64 KB LDS, persistent grid over a device-side work list
-//   tile_sort_global_list_kernel  fallback for even longer lists: same network on global memory
+//                              (+ in the same launch: even longer lists, same network on global memory)
 #include "d3ga_internal.h"
 
 namespace d3ga {
@@ -27,52 +27,81 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(int tiles, const 
                                                                uint32_t *__restrict__ huge_tiles,
                                                                uint32_t *__restrict__ mid_tiles, uint32_t n_small,
                                                                uint32_t n_mid, uint32_t n_large) {
+    // The histogram is staged through LDS in chunks of 8 tiles per thread: lane-contiguous global loads/stores with all of
+    // a thread's requests in flight at once (a thread-strided read of 8 values is 8 dependent L2 round trips), then each
+    // thread scans its 8 consecutive values from LDS (two 16-byte reads) and a wavefront scan + 16 LDS totals finish it.
+    constexpr int kPer = 8, kChunk = kPer * kScanBlock;
+    __shared__ __attribute__((aligned(16))) uint32_t s_c[kChunk];
     __shared__ uint32_t s_wave[kScanBlock / 64];
     __shared__ uint32_t s_max;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_max = 0;
-    const int per = (tiles + kScanBlock - 1) / kScanBlock;
-    const int b = min(tid * per, tiles), e = min(b + per, tiles);
-    uint32_t sum = 0, mx = 0;
-    for (int t = b; t < e; ++t) {
-        const uint32_t c = count[t];
-        sum += c;
-        mx = max(mx, c);
-    }
-    // block-wide exclusive prefix: wavefront scan (6 shuffle steps) + 16 wavefront totals through LDS
-    uint32_t incl = sum;
+    uint32_t carry = 0, mx = 0;
+    for (int c0 = 0; c0 < tiles; c0 += kChunk) {
+        __syncthreads();                                   // previous chunk's LDS reads are done
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off);
-        if (lane >= off) incl += v;
-        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+        for (int k = 0; k < kPer; ++k) {
+            const int t = c0 + k * kScanBlock + tid;
+            s_c[k * kScanBlock + tid] = t < tiles ? count[t] : 0u;
+        }
+        __syncthreads();
+        uint32_t c[kPer];
+        {
+            const uint4 lo = reinterpret_cast<const uint4 *>(s_c)[2 * tid], hi = reinterpret_cast<const uint4 *>(s_c)[2 * tid + 1];
+            c[0] = lo.x; c[1] = lo.y; c[2] = lo.z; c[3] = lo.w; c[4] = hi.x; c[5] = hi.y; c[6] = hi.z; c[7] = hi.w;
+        }
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) { sum += c[k]; mx = max(mx, c[k]); }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kScanBlock / 64; ++w) {
+            const uint32_t v = s_wave[w];
+            wbase += w < wave ? v : 0u;
+            total += v;
+        }
+        uint32_t run = carry + wbase + incl - sum;
+        uint32_t e[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            e[k] = run;
+            run += c[k];
+            // work lists for the long-list sort kernels (usually empty: those launches then cost one tiny grid)
+            const int t = c0 + kPer * tid + k;
+            if (c[k] > n_large) huge_tiles[atomicAdd(&counters[D3GA_CNT_HUGE], 1u)] = (uint32_t)t;
+            else if (c[k] > n_mid) big_tiles[atomicAdd(&counters[D3GA_CNT_BIG], 1u)] = (uint32_t)t;
+            else if (c[k] > n_small) mid_tiles[atomicAdd(&counters[D3GA_CNT_MID], 1u)] = (uint32_t)t;
+        }
+        reinterpret_cast<uint4 *>(s_c)[2 * tid] = make_uint4(e[0], e[1], e[2], e[3]);
+        reinterpret_cast<uint4 *>(s_c)[2 * tid + 1] = make_uint4(e[4], e[5], e[6], e[7]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int t = c0 + k * kScanBlock + tid;
+            if (t < tiles) {
+                const uint32_t v = s_c[k * kScanBlock + tid];
+                start[t] = v;
+                cursor[t] = v;
+            }
+        }
+        carry += total;
     }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
     if (lane == 0) atomicMax(&s_max, mx);
-    uint32_t wbase = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kScanBlock / 64; ++w) {
-        const uint32_t v = s_wave[w];
-        wbase += w < wave ? v : 0u;
-        total += v;
-    }
     __syncthreads();
-    uint32_t run = wbase + incl - sum;
-    for (int t = b; t < e; ++t) {
-        const uint32_t c = count[t];
-        start[t] = run;
-        cursor[t] = run;
-        run += c;
-        // work lists for the long-list sort kernels (usually empty: those launches then cost one tiny grid)
-        if (c > n_large) huge_tiles[atomicAdd(&counters[D3GA_CNT_HUGE], 1u)] = (uint32_t)t;
-        else if (c > n_mid) big_tiles[atomicAdd(&counters[D3GA_CNT_BIG], 1u)] = (uint32_t)t;
-        else if (c > n_small) mid_tiles[atomicAdd(&counters[D3GA_CNT_MID], 1u)] = (uint32_t)t;
-    }
-    if (tid == kScanBlock - 1) {
-        start[tiles] = total;
-        counters[D3GA_CNT_D] = total;
-        counters[D3GA_CNT_OVERFLOW] = (uint64_t)total > dcap ? 1u : 0u;
+    if (tid == 0) {
+        start[tiles] = carry;
+        counters[D3GA_CNT_D] = carry;
+        counters[D3GA_CNT_OVERFLOW] = (uint64_t)carry > dcap ? 1u : 0u;
         counters[D3GA_CNT_MAXTILE] = s_max;
     }
 }
@@ -268,7 +297,10 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_
                                                                    const uint64_t *__restrict__ keys,
                                                                    uint32_t *__restrict__ point_list, uint64_t dcap,
                                                                    const uint32_t *__restrict__ list,
-                                                                   const uint32_t *__restrict__ list_count) {
+                                                                   const uint32_t *__restrict__ list_count,
+                                                                   uint64_t *__restrict__ keys_rw,
+                                                                   const uint32_t *__restrict__ huge_list,
+                                                                   const uint32_t *__restrict__ huge_count) {
     static_assert(CAP <= 8 * BLOCK, "8 keys per thread");
     extern __shared__ __attribute__((aligned(16))) uint64_t s_key_dyn[];
     const uint32_t count = *list_count;
@@ -276,21 +308,19 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_
         __syncthreads();
         sort_one_tile_lds<BLOCK, CAP, true>(s_key_dyn, (int)list[k], start, keys, point_list, dcap);
     }
-}
-
-__global__ __launch_bounds__(1024) void tile_sort_global_list_kernel(const uint32_t *__restrict__ start, uint64_t *keys,
-                                                                     uint32_t *__restrict__ point_list, uint64_t dcap,
-                                                                     const uint32_t *__restrict__ list,
-                                                                     const uint32_t *__restrict__ list_count) {
-    const uint32_t count = *list_count;
-    const int tid = threadIdx.x;
-    for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
-        const int tile = (int)list[k];
-        const uint64_t b64 = min((uint64_t)start[tile], dcap), e64 = min((uint64_t)start[tile + 1], dcap);
-        const int n = (int)(e64 - b64);
-        __syncthreads();
-        bitonic_sort(keys + b64, n, tid, 1024);
-        for (int i = tid; i < n; i += 1024) point_list[b64 + i] = (uint32_t)keys[b64 + i];
+    // lists that do not fit any LDS class (huge_list != null: same launch, saves a near-empty grid per frame):
+    // the same network on global memory
+    if (huge_list) {
+        const uint32_t hcount = *huge_count;
+        const int tid = threadIdx.x;
+        for (uint32_t k = blockIdx.x; k < hcount; k += gridDim.x) {
+            const int tile = (int)huge_list[k];
+            const uint64_t b64 = min((uint64_t)start[tile], dcap), e64 = min((uint64_t)start[tile + 1], dcap);
+            const int n = (int)(e64 - b64);
+            __syncthreads();
+            bitonic_sort(keys_rw + b64, n, tid, BLOCK);
+            for (int i = tid; i < n; i += BLOCK) point_list[b64 + i] = (uint32_t)keys_rw[b64 + i];
+        }
     }
 }
 
@@ -333,13 +363,12 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
     const int lgrid = tiles < 1024 ? tiles : 1024;
     hipLaunchKernelGGL((tile_sort_lds_list_kernel<512, kSortMid>), dim3(lgrid), dim3(512), (kSortMid + kSortMid / 8) * 8, s,
                        bin.tile_start, bin.keys, bin.point_list, (uint64_t)d_capacity, bin.mid_tiles,
-                       bin.counters + D3GA_CNT_MID);
+                       bin.counters + D3GA_CNT_MID, (uint64_t *)nullptr, (const uint32_t *)nullptr,
+                       (const uint32_t *)nullptr);
     D3GA_TRY(check_launch(s, prm->debug));
     hipLaunchKernelGGL((tile_sort_lds_list_kernel<1024, kSortLarge>), dim3(lgrid < 512 ? lgrid : 512), dim3(1024),
                        (kSortLarge + kSortLarge / 8) * 8, s, bin.tile_start, bin.keys, bin.point_list,
-                       (uint64_t)d_capacity, bin.big_tiles, bin.counters + D3GA_CNT_BIG);
-    D3GA_TRY(check_launch(s, prm->debug));
-    hipLaunchKernelGGL(tile_sort_global_list_kernel, dim3(lgrid < 256 ? lgrid : 256), dim3(1024), 0, s, bin.tile_start, bin.keys,
-                       bin.point_list, (uint64_t)d_capacity, bin.huge_tiles, bin.counters + D3GA_CNT_HUGE);
+                       (uint64_t)d_capacity, bin.big_tiles, bin.counters + D3GA_CNT_BIG, bin.keys,
+                       (const uint32_t *)bin.huge_tiles, (const uint32_t *)(bin.counters + D3GA_CNT_HUGE));
     return check_launch(s, prm->debug);
 }
