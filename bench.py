@@ -18,6 +18,7 @@ import argparse
 import json
 import math
 import os
+import re
 import sys
 import time
 
@@ -372,7 +373,7 @@ def main():
             if os.path.exists(pj):
                 for kname, c in json.load(open(pj)).items():
                     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                        short = kname.split("::")[-1].split("_kernel")[0].replace("_rows", "")
+                        short = re.sub(r"_rows\d*", "", kname.split("::")[-1].split("_kernel")[0])
                         pmc_traffic[short] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
         except Exception:
             pmc_traffic = {}

@@ -44,21 +44,9 @@ __device__ __forceinline__ void sh_slab_store(const float *slab, float *__restri
     }
 }
 
-// half-row staging of the forward (see preprocess_kernel): rows of 3M/2 floats, padded to 28
-constexpr int kShHalfRow = 28;
-constexpr int kShHalfSlab = 64 * kShHalfRow;
-constexpr size_t kShHalfLdsBytes = (size_t)(kBlock / 64) * kShHalfSlab * sizeof(float);      // 28,672 B per block
-__device__ __forceinline__ bool sh_halves(int M) { return M > 0 && (3 * M) % 8 == 0 && 3 * M <= 48; }
-// global half rows (row stride M3 floats, `half` floats each) -> LDS slab rows of kShHalfRow floats
-__device__ __forceinline__ void sh_half_load(float *slab, const float *__restrict__ src, int rows, int M3, int half, int lane) {
-    const int vpr = half / 4;                       // float4 per half row
-    const int nvec = rows * vpr;
-    for (int v = lane; v < nvec; v += 64) {
-        const int r = v / vpr, c = v - r * vpr;
-        const float4 x = *reinterpret_cast<const float4 *>(src + (size_t)r * M3 + 4 * c);
-        *reinterpret_cast<float4 *>(slab + r * kShHalfRow + 4 * c) = x;
-    }
-}
+// forward staging (see preprocess_kernel): half of a wavefront's rows at a time
+constexpr int kShHalfSlab = 32 * kShRow;
+constexpr size_t kShHalfLdsBytes = (size_t)(kBlock / 64) * kShHalfSlab * sizeof(float);      // 26,624 B per block
 
 __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     d3ga_raster_params prm, const float *__restrict__ means3D, const float *__restrict__ shs,
@@ -74,35 +62,26 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * kBlock + tid;
     const int M3 = 3 * prm.M;
-    const bool staged = shs != nullptr && sh_halves(prm.M);
+    const bool staged = shs != nullptr && sh_staged(prm.M);
     float acc[3] = {0.f, 0.f, 0.f};
     if (staged) {
-        // SH colour in two half-row passes (coefficients 0..7, then 8..15): the slab of a wavefront is 64 x 28 floats =
-        // 7 KiB instead of 13 KiB, which lifts the kernel from 12 to 20 resident wavefronts per CU (it is a streaming
-        // kernel with long dependent chains: occupancy is what hides the HBM latency).  Only wavefront-private LDS
-        // is touched: no workgroup barrier, program order + wave_barrier suffice.
+        // SH colour in two passes over HALF THE ROWS of the wavefront (rows 0..31, then 32..63; full 192-byte rows, so
+        // every byte is fetched once): the slab of a wavefront is 32 x 52 floats = 6.5 KiB instead of 13 KiB, which
+        // lifts the kernel from 12 to 20 resident wavefronts per CU.  Only wavefront-private LDS is touched: no
+        // workgroup barrier, program order + wave_barrier suffice.
         float *slab = s_sh + wave * kShHalfSlab;
         const int row0 = blockIdx.x * kBlock + wave * 64;           // first Gaussian of this wavefront
         const int rows = min(64, prm.P - row0);
         const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
         float B[16];
         if (i < prm.P) sh_view_basis(prm, means3D, i, campos, B);
-        const int half = M3 / 2;                                    // floats per half row (24 for M = 16)
-#define D3GA_SH_PASS(H, K0, K1)                                                                                \
-    do {                                                                                                       \
-        __builtin_amdgcn_wave_barrier();                                                                       \
-        if (rows > 0) sh_half_load(slab, shs + (size_t)M3 * row0 + (H) * half, rows, M3, half, lane);          \
-        __builtin_amdgcn_wave_barrier();                                                                       \
-        if (i < prm.P) sh_accumulate(B, slab + lane * kShHalfRow, (K0), (K1), nb, acc);                        \
-    } while (0)
-        if (prm.M == 16) {                                          // D3GA's layout: constant coefficient ranges
-            D3GA_SH_PASS(0, 0, 8);
-            if (nb > 8) D3GA_SH_PASS(1, 8, 16);                     // degree <= 1 never reads the second half (uniform)
-        } else {
-            D3GA_SH_PASS(0, 0, prm.M / 2);
-            if (nb > prm.M / 2) D3GA_SH_PASS(1, prm.M / 2, prm.M);
+        for (int h = 0; h < 2; ++h) {
+            const int r = min(32, rows - 32 * h);
+            __builtin_amdgcn_wave_barrier();
+            if (r > 0) sh_slab_load(slab, shs + (size_t)M3 * (row0 + 32 * h), r, M3, lane);
+            __builtin_amdgcn_wave_barrier();
+            if (i < prm.P && (lane >> 5) == h) sh_accumulate(B, slab + (lane & 31) * kShRow, 0, 16, nb, acc);
         }
-#undef D3GA_SH_PASS
         __syncthreads();                                            // the region becomes the tile window below
     }
     bool visible = false;
@@ -311,7 +290,7 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     if (!means3D || !opacities || !radii) return D3GA_E_NULL;
     GeomBuf g = carve_geom(geom, prm->P);
     const size_t win = (size_t)kWinTiles * 4;
-    const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 8 == 0) ? (kShHalfLdsBytes > win ? kShHalfLdsBytes : win) : win;
+    const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? (kShHalfLdsBytes > win ? kShHalfLdsBytes : win) : win;
     hipLaunchKernelGGL(preprocess_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
                        colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, g,
                        bin.tile_count, bin.counters, radii);

@@ -24,4 +24,8 @@ for f in glob.glob(os.path.join(ROOT, "gpurun_out", "prof", "*kernel_stats.csv")
 b = os.path.join(ROOT, "gpurun_out", "bench.log")
 if os.path.exists(b) and os.path.getsize(b) > 10:
     shutil.copy(b, os.path.join(ROOT, "profiles", f"{tag}_bench_{wl}.json"))
+for other in ("C1", "C2", "C4", "C5"):
+    b = os.path.join(ROOT, "gpurun_out", f"bench_{other}.log")
+    if os.path.exists(b) and os.path.getsize(b) > 10:
+        shutil.copy(b, os.path.join(ROOT, "profiles", f"{tag}_bench_{other}.json"))
 print(sorted(os.listdir(os.path.join(ROOT, "profiles"))))

@@ -20,3 +20,7 @@ rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
 find gpurun_out/prof -name "*_kernel_trace.csv" -size +20M -delete
 timeout 900 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err
 cat gpurun_out/pytest_gpu.log | tail -2; cat gpurun_out/bench.log | cut -c1-600
+for wl in C1 C2 C4 C5; do
+  timeout 600 python bench.py --workload $wl --steps 30 --warmup 5 --no-cpu-baseline --no-train-step > gpurun_out/bench_$wl.log 2> gpurun_out/bench_$wl.err
+done
+tail -c 300 gpurun_out/bench_C5.log
