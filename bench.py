@@ -102,9 +102,10 @@ class Frame:
 
     def train_step(self):
         """The reference's training step renders twice (models/trainer.py:102-110): RGB, then a silhouette pass with a
-        constant per-Gaussian colour on a black background; both feed an L1 term (train.py:190-193)."""
+        constant per-Gaussian colour on a black background; losses as in train.py:190-193 (L1 + SSIM on RGB, L1 on the
+        silhouette)."""
         from d3ga_amd.cage_deform import cage_deform, lbs_cage
-        from d3ga_amd.losses import l1_loss
+        from d3ga_amd.losses import l1_loss, ssim
         from d3ga_amd.renderer import render
         p = self.params
         if not hasattr(self, "sil_rgb"):
@@ -119,7 +120,10 @@ class Frame:
                "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
         img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
         sil = render(self.batch, pkg, self.bg0, colors_precomp=self.sil_rgb, grad_sync=self.grad_sync)["render"]
-        loss = l1_loss(img, self.target) + l1_loss(sil, self.sil_target)
+        # train.py:190-193: (1 - lambda) L1 + lambda (1 - SSIM) on the RGB image, L1 on the silhouette
+        lam = 0.2
+        loss = ((1.0 - lam) * l1_loss(img, self.target) + lam * (1.0 - ssim(img, self.target))
+                + l1_loss(sil, self.sil_target))
         loss.backward()
         return loss
 
@@ -339,7 +343,8 @@ def main():
             flat.zero()
             frame.train_step()
         torch.cuda.synchronize()
-        train = {"renders_per_step": 2, "steps": n_ts, "launch_mode": "eager",
+        train = {"renders_per_step": 2, "losses": "0.8 L1 + 0.2 (1 - SSIM) on RGB, L1 on the silhouette", "steps": n_ts,
+                 "launch_mode": "eager",
                  "ms_per_step": round(1e3 * (time.perf_counter() - t1) / n_ts, 4)}
         train["steps_per_s"] = round(1e3 / train["ms_per_step"], 2)
 

@@ -55,6 +55,8 @@ _SIGNATURES = {
     "d3ga_knn3_mean_dist2": ([_i, _vp, _vp, _vp], _i),
     "d3ga_l1_mean_fwd": ([_i64, _vp, _vp, _vp, _vp], _i),
     "d3ga_l1_mean_bwd": ([_i64, _vp, _vp, _vp, _vp, _vp], _i),
+    "d3ga_ssim_fwd": ([ctypes.c_int32] * 3 + [_vp] * 6 + [_vp], _i),
+    "d3ga_ssim_bwd": ([ctypes.c_int32] * 3 + [_vp] * 7 + [_vp], _i),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -1,6 +1,9 @@
-// loss.hip -- fused L1 image loss ("loss tail"): mean |a - b| and its gradient.
-// Replaces utils/loss_utils.py:29 (l1_loss = torch.abs(network_output - gt).mean()), which autograd runs as six
-// full-image ATen kernels (sub, abs, mean, expand/div, sign, mul): here one streaming pass each way.
+// loss.hip -- the loss tail next to the render boundary.
+//   l1_mean_*   fused L1 image loss: mean |a - b| and its gradient.  Replaces utils/loss_utils.py:29
+//               (torch.abs(network_output - gt).mean()), which autograd runs as six full-image ATen kernels.
+//   ssim_*      fused 11x11 Gaussian-window SSIM (utils/loss_utils.py:46-86, called at train.py:192): the reference runs
+//               five depthwise conv2d (11x11, zero padding) plus ~15 elementwise kernels forward and their autograd
+//               backward; here one LDS-tiled separable pass each way.
 #include "d3ga_internal.h"
 
 namespace d3ga {
@@ -55,6 +58,146 @@ __global__ __launch_bounds__(kBlock) void l1_mean_bwd_kernel(int64_t n4, int64_t
         grad_a[i] = s * sgn(a[i] - b[i]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// SSIM.  ssim_map = (2 mu1 mu2 + C1)(2 s12 + C2) / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2)) with mu = w*x, s1 = w*x^2 - mu1^2,
+// s12 = w*xy - mu1 mu2 and w the 11x11 window gaussian(11, 1.5) (x) gaussian(11, 1.5) (utils/loss_utils.py:46-57),
+// zero padding of 5 (F.conv2d(..., padding=window_size // 2)).  The window is separable: a workgroup owns a 16x16
+// output tile of one channel, stages the (16+10)^2 halo of both images in LDS, convolves the five maps
+// (x, y, x^2, y^2, xy) horizontally into LDS and vertically into registers.  The forward also stores the three
+// partial derivatives the backward needs (d ssim / d(w*x), d(w*x^2), d(w*xy)); the backward convolves those three maps
+// with the same (symmetric) window:  dL/dx = w*Dm + 2 x (w*Dq1) + y (w*Dq12).
+// HBM traffic per pixel and channel: forward 8 B read + 12 B written, backward 20 B read + 4 B written.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSsimTile = 16, kSsimHalo = 5, kSsimIn = kSsimTile + 2 * kSsimHalo;     // 26
+__device__ __constant__ float c_ssim_w[11] = {1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f,
+                                              2.130055279e-01f, 2.660117149e-01f, 2.130055279e-01f, 1.093606874e-01f,
+                                              3.600077331e-02f, 7.598758209e-03f, 1.028380124e-03f};
+constexpr float kSsimC1 = 0.01f * 0.01f, kSsimC2 = 0.03f * 0.03f;
+
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(int C, int H, int W, int tiles_x, int tiles_y,
+                                                       const float *__restrict__ img1, const float *__restrict__ img2,
+                                                       float inv_n, float *__restrict__ out, float *__restrict__ Dm,
+                                                       float *__restrict__ Dq1, float *__restrict__ Dq12) {
+    __shared__ float s_x[kSsimIn][kSsimIn + 1], s_y[kSsimIn][kSsimIn + 1];
+    __shared__ float s_h[5][kSsimIn][kSsimTile + 1];
+    __shared__ float s_part[4];
+    const int tid = threadIdx.x, px = tid & 15, py = tid >> 4;
+    const int ntiles = C * tiles_x * tiles_y;
+    float w[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) w[k] = c_ssim_w[k];
+    float local = 0.f;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int c = t / (tiles_x * tiles_y), r = t - c * tiles_x * tiles_y;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const float *p1 = img1 + (size_t)c * H * W, *p2 = img2 + (size_t)c * H * W;
+        __syncthreads();                                   // previous tile's LDS reads are done
+        for (int idx = tid; idx < kSsimIn * kSsimIn; idx += 256) {
+            const int rr = idx / kSsimIn, cc = idx - rr * kSsimIn;
+            const int gy = ty * kSsimTile + rr - kSsimHalo, gx = tx * kSsimTile + cc - kSsimHalo;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            s_x[rr][cc] = in ? p1[(size_t)gy * W + gx] : 0.f;
+            s_y[rr][cc] = in ? p2[(size_t)gy * W + gx] : 0.f;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < kSsimIn * kSsimTile; idx += 256) {        // horizontal pass
+            const int rr = idx >> 4, cx = idx & 15;
+            float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float x = s_x[rr][cx + k], y = s_y[rr][cx + k], wk = w[k];
+                a += wk * x; b += wk * y; aa += wk * x * x; bb += wk * y * y; ab += wk * x * y;
+            }
+            s_h[0][rr][cx] = a; s_h[1][rr][cx] = b; s_h[2][rr][cx] = aa; s_h[3][rr][cx] = bb; s_h[4][rr][cx] = ab;
+        }
+        __syncthreads();
+        float mu1 = 0.f, mu2 = 0.f, q1 = 0.f, q2 = 0.f, q12 = 0.f;           // vertical pass
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float wk = w[k];
+            mu1 += wk * s_h[0][py + k][px]; mu2 += wk * s_h[1][py + k][px]; q1 += wk * s_h[2][py + k][px];
+            q2 += wk * s_h[3][py + k][px]; q12 += wk * s_h[4][py + k][px];
+        }
+        const int gy = ty * kSsimTile + py, gx = tx * kSsimTile + px;
+        if (gy < H && gx < W) {
+            const float s1 = q1 - mu1 * mu1, s2 = q2 - mu2 * mu2, s12 = q12 - mu1 * mu2;
+            const float A = 2.f * mu1 * mu2 + kSsimC1, B = 2.f * s12 + kSsimC2;
+            const float Dd = mu1 * mu1 + mu2 * mu2 + kSsimC1, E = s1 + s2 + kSsimC2;
+            const float iD = 1.0f / Dd, iE = 1.0f / E;
+            const float val = A * B * iD * iE;
+            local += val;
+            if (Dm) {
+                // partials w.r.t. the five convolved maps (s1, s12 depend on mu1 through -mu1^2, -mu1 mu2)
+                const float d_s1 = -val * iE;                              // d/d s1   (= d/d q1)
+                const float d_s12 = 2.f * A * iD * iE;                     // d/d s12  (= d/d q12)
+                const float d_mu1 = 2.f * mu2 * B * iD * iE - 2.f * mu1 * val * iD;
+                const size_t o = (size_t)c * H * W + (size_t)gy * W + gx;
+                Dm[o] = d_mu1 - 2.f * mu1 * d_s1 - mu2 * d_s12;
+                Dq1[o] = d_s1;
+                Dq12[o] = d_s12;
+            }
+        }
+    }
+    local = wave_sum_loss(local);
+    if ((tid & 63) == 0) s_part[tid >> 6] = local;
+    __syncthreads();
+    if (tid == 0) atomicAdd(out, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * inv_n);
+}
+
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(int C, int H, int W, int tiles_x, int tiles_y,
+                                                       const float *__restrict__ img1, const float *__restrict__ img2,
+                                                       const float *__restrict__ Dm, const float *__restrict__ Dq1,
+                                                       const float *__restrict__ Dq12, const float *__restrict__ g,
+                                                       float inv_n, float *__restrict__ grad1) {
+    __shared__ float s_in[3][kSsimIn][kSsimIn + 1];
+    __shared__ float s_h[3][kSsimIn][kSsimTile + 1];
+    const int tid = threadIdx.x, px = tid & 15, py = tid >> 4;
+    const int ntiles = C * tiles_x * tiles_y;
+    const float scale = g[0] * inv_n;
+    float w[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) w[k] = c_ssim_w[k];
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int c = t / (tiles_x * tiles_y), r = t - c * tiles_x * tiles_y;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const size_t plane = (size_t)c * H * W;
+        __syncthreads();
+        for (int idx = tid; idx < kSsimIn * kSsimIn; idx += 256) {
+            const int rr = idx / kSsimIn, cc = idx - rr * kSsimIn;
+            const int gy = ty * kSsimTile + rr - kSsimHalo, gx = tx * kSsimTile + cc - kSsimHalo;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const size_t o = plane + (size_t)gy * W + gx;
+            s_in[0][rr][cc] = in ? Dm[o] : 0.f;
+            s_in[1][rr][cc] = in ? Dq1[o] : 0.f;
+            s_in[2][rr][cc] = in ? Dq12[o] : 0.f;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < kSsimIn * kSsimTile; idx += 256) {
+            const int rr = idx >> 4, cx = idx & 15;
+            float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float wk = w[k];
+                a += wk * s_in[0][rr][cx + k]; b += wk * s_in[1][rr][cx + k]; d += wk * s_in[2][rr][cx + k];
+            }
+            s_h[0][rr][cx] = a; s_h[1][rr][cx] = b; s_h[2][rr][cx] = d;
+        }
+        __syncthreads();
+        float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float wk = w[k];
+            a += wk * s_h[0][py + k][px]; b += wk * s_h[1][py + k][px]; d += wk * s_h[2][py + k][px];
+        }
+        const int gy = ty * kSsimTile + py, gx = tx * kSsimTile + px;
+        if (gy < H && gx < W) {
+            const size_t o = plane + (size_t)gy * W + gx;
+            grad1[o] = scale * (a + 2.f * img1[o] * b + img2[o] * d);
+        }
+    }
+}
+
 }  // namespace d3ga
 
 using namespace d3ga;
@@ -86,5 +229,33 @@ extern "C" int d3ga_l1_mean_bwd(int64_t n, const float *a, const float *b, const
     const int64_t n4 = n / 4;
     hipLaunchKernelGGL(l1_mean_bwd_kernel, dim3(loss_grid(n4, 2048)), dim3(kBlock), 0, s, n4, n, a, b, g, 1.0f / (float)n,
                        grad_a);
+    return check_launch(s, 0);
+}
+
+static inline int ssim_grid(int ntiles, int cap) { return ntiles < 1 ? 1 : (ntiles > cap ? cap : ntiles); }
+
+extern "C" int d3ga_ssim_fwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *out,
+                             float *Dm, float *Dq1, float *Dq12, d3ga_stream_t stream) {
+    if (C <= 0 || H <= 0 || W <= 0) return D3GA_E_SIZE;
+    if (!img1 || !img2 || !out) return D3GA_E_NULL;
+    if ((Dm != nullptr) != (Dq1 != nullptr) || (Dm != nullptr) != (Dq12 != nullptr)) return D3GA_E_CONFIG;
+    hipStream_t s = (hipStream_t)stream;
+    D3GA_HIP(hipMemsetAsync(out, 0, sizeof(float), s));
+    const int tx = (W + kSsimTile - 1) / kSsimTile, ty = (H + kSsimTile - 1) / kSsimTile;
+    // persistent grid: every workgroup ends with ONE atomic on the result word (same-address atomics serialise)
+    hipLaunchKernelGGL(ssim_fwd_kernel, dim3(ssim_grid(C * tx * ty, 2048)), dim3(256), 0, s, C, H, W, tx, ty, img1, img2,
+                       1.0f / ((float)C * (float)H * (float)W), out, Dm, Dq1, Dq12);
+    return check_launch(s, 0);
+}
+
+extern "C" int d3ga_ssim_bwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, const float *Dm,
+                             const float *Dq1, const float *Dq12, const float *g, float *grad_img1,
+                             d3ga_stream_t stream) {
+    if (C <= 0 || H <= 0 || W <= 0) return D3GA_E_SIZE;
+    if (!img1 || !img2 || !Dm || !Dq1 || !Dq12 || !g || !grad_img1) return D3GA_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const int tx = (W + kSsimTile - 1) / kSsimTile, ty = (H + kSsimTile - 1) / kSsimTile;
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(ssim_grid(C * tx * ty, 8192)), dim3(256), 0, s, C, H, W, tx, ty, img1, img2,
+                       Dm, Dq1, Dq12, g, 1.0f / ((float)C * (float)H * (float)W), grad_img1);
     return check_launch(s, 0);
 }

@@ -1,7 +1,10 @@
-"""Loss tail next to the render boundary: fused L1 image loss.
+"""Loss tail next to the render boundary: fused L1 and SSIM image losses.
 
-Drop-in for `utils/loss_utils.py:29  l1_loss(network_output, gt) = torch.abs(network_output - gt).mean()` of the
-reference (used at train.py:190): one streaming HIP kernel forward, one backward, instead of six ATen kernels.
+Drop-ins for the reference's `utils/loss_utils.py`:
+    l1_loss(network_output, gt)                       :29   (train.py:190-191)
+    ssim(img1, img2, window_size=11, size_average=True) :59-86 (train.py:192)
+each one HIP kernel forward and one backward (the reference runs 6 resp. ~25 full-image ATen/MIOpen kernels per
+direction).  GPU tensors only.
 """
 import torch
 
@@ -34,3 +37,58 @@ class _L1Mean(torch.autograd.Function):
 def l1_loss(network_output, gt):
     """mean |network_output - gt| (utils/loss_utils.py:29).  GPU tensors only."""
     return _L1Mean.apply(network_output, gt)
+
+
+class _SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2):
+        require_cuda(img1, img2)
+        a = img1.float().contiguous()
+        b = img2.float().contiguous()
+        if a.shape != b.shape or a.dim() != 3:
+            raise ValueError(f"ssim: expected two (C,H,W) images of equal shape, got {tuple(a.shape)} / {tuple(b.shape)}")
+        C, H, W = a.shape
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        d = [torch.empty_like(a) for _ in range(3)] if ctx.needs_input_grad[0] else [None, None, None]
+        check(_lib.lib().d3ga_ssim_fwd(C, H, W, dptr(a), dptr(b), dptr(out), dptr(d[0]), dptr(d[1]), dptr(d[2]),
+                                       stream_handle()), "d3ga_ssim_fwd")
+        if need:
+            ctx.save_for_backward(a, b, *[t for t in d if t is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        a, b = saved[0], saved[1]
+        C, H, W = a.shape
+        g = g.float().contiguous()
+        L = _lib.lib()
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = torch.empty_like(a)
+            check(L.d3ga_ssim_bwd(C, H, W, dptr(a), dptr(b), dptr(saved[2]), dptr(saved[3]), dptr(saved[4]), dptr(g),
+                                  dptr(ga), stream_handle()), "d3ga_ssim_bwd")
+        if ctx.needs_input_grad[1]:                    # SSIM is symmetric: the same kernels with the images swapped
+            d = [torch.empty_like(a) for _ in range(3)]
+            tmp = torch.empty((), dtype=torch.float32, device=a.device)
+            check(L.d3ga_ssim_fwd(C, H, W, dptr(b), dptr(a), dptr(tmp), dptr(d[0]), dptr(d[1]), dptr(d[2]),
+                                  stream_handle()), "d3ga_ssim_fwd")
+            gb = torch.empty_like(a)
+            check(L.d3ga_ssim_bwd(C, H, W, dptr(b), dptr(a), dptr(d[0]), dptr(d[1]), dptr(d[2]), dptr(g), dptr(gb),
+                                  stream_handle()), "d3ga_ssim_bwd")
+        return ga, gb
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """Mean SSIM with the reference's 11x11 Gaussian window (sigma 1.5, zero padding), utils/loss_utils.py:59-86.
+    (C,H,W) images, or (N,C,H,W) batches (mean over the batch, or one value per image with size_average=False)."""
+    if window_size != 11:
+        raise NotImplementedError("ssim: only the reference's window_size=11 is implemented (train.py:192 uses the default)")
+    if img1.dim() == 3:
+        v = _SSIM.apply(img1, img2)
+        return v if size_average else v[None]
+    if img1.dim() != 4 or img1.shape != img2.shape:
+        raise ValueError(f"ssim: expected (C,H,W) or (N,C,H,W) inputs of equal shape, got {tuple(img1.shape)}")
+    per = torch.stack([_SSIM.apply(img1[n], img2[n]) for n in range(img1.shape[0])])
+    return per.mean() if size_average else per

@@ -209,6 +209,17 @@ int d3ga_raster_mark_visible(int32_t P, const float *means3D, const float *viewm
 int d3ga_l1_mean_fwd(int64_t n, const float *a, const float *b, float *out, d3ga_stream_t stream);
 int d3ga_l1_mean_bwd(int64_t n, const float *a, const float *b, const float *g, float *grad_a, d3ga_stream_t stream);
 
+/* 11x11 Gaussian-window SSIM, mean over all channels and pixels.  Replaces utils/loss_utils.py:46-86 (ssim / _ssim with
+ * window_size = 11, sigma = 1.5, zero padding 5, size_average = True; called at train.py:192).
+ *   fwd: img1, img2 (C,H,W) -> out[0] = mean ssim_map (zeroed by the call).  Dm, Dq1, Dq12: optional (C,H,W) outputs
+ *        (all three or none) holding d ssim_map / d(w*img1), d(w*img1^2), d(w*img1*img2) for the backward.
+ *   bwd: grad_img1 (C,H,W) = g[0]/(C*H*W) * ( w*Dm + 2 img1 (w*Dq1) + img2 (w*Dq12) ),  g: device scalar dL/d(mean).
+ * The gradient w.r.t. img2 is the same call with the two images swapped (SSIM is symmetric). */
+int d3ga_ssim_fwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *out, float *Dm,
+                  float *Dq1, float *Dq12, d3ga_stream_t stream);
+int d3ga_ssim_bwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, const float *Dm,
+                  const float *Dq1, const float *Dq12, const float *g, float *grad_img1, d3ga_stream_t stream);
+
 /* Test hook, not part of the drop-in surface: the 64-lane reductions of the compositing backward.  n multiple of 256;
  * in (n) -> out (10*n/64): per wavefront w, out[10w+k] = sum_l ((k+1) in[l] + k/64) for k<9, out[10w+9] = sum_l in[l]. */
 int d3ga_selftest_wave_sum(int n, const float *in, float *out, d3ga_stream_t stream);

@@ -625,3 +625,36 @@ def test_full_size_c5_properties_without_an_oracle():
     m.grad = None
     (run(c1, m)[0] * (-3.0 * gp)).sum().backward()
     assert rel_err(_np(m.grad), -3.0 * _np(g1)) < 1e-4
+
+
+def test_fused_ssim_matches_reference_goldens_and_oracle(golden):
+    """d3ga_ssim_{fwd,bwd} against (i) values and gradients of the reference's own ssim() (loss_cases.npz) and (ii) the
+    oracle at image sizes with ragged tile borders and at 1080p; gradient w.r.t. both images."""
+    from d3ga_amd.losses import ssim
+    from oracle import losses as ol
+    g = golden("loss_cases.npz")
+    for name in ("a", "b", "c"):
+        pred = torch.from_numpy(g[f"{name}_pred"]).to(DEV).requires_grad_(True)
+        gt = torch.from_numpy(g[f"{name}_gt"]).to(DEV)
+        v = ssim(pred, gt)
+        v.backward()
+        assert abs(float(v) - float(g[f"{name}_ssim"])) < 2e-6
+        assert rel_err(_np(pred.grad), g[f"{name}_ssim_grad"]) < 2e-5
+    gen = torch.Generator().manual_seed(9)
+    for (C, H, W) in ((3, 1080, 1920), (3, 5, 7), (2, 33, 16)):
+        b = torch.rand(C, H, W, generator=gen)
+        a = (b + 0.2 * torch.randn(C, H, W, generator=gen)).clamp(0, 1)
+        ac, bc = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        vo = ol.ssim(ac, bc)
+        (2.5 * vo).backward()
+        ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        vd = ssim(ad, bd)
+        (2.5 * vd).backward()
+        assert abs(float(vd) - float(vo)) < 5e-6, (C, H, W)
+        assert rel_err(_np(ad.grad), ac.grad.numpy()) < 5e-5, (C, H, W)
+        assert rel_err(_np(bd.grad), bc.grad.numpy()) < 5e-5, (C, H, W)
+    # batched form
+    x = torch.rand(2, 3, 20, 24, generator=gen)
+    y = torch.rand(2, 3, 20, 24, generator=gen)
+    np.testing.assert_allclose(_np(ssim(x.to(DEV), y.to(DEV), size_average=False)),
+                               ol.ssim(x, y, size_average=False).numpy(), atol=5e-6)

@@ -107,3 +107,19 @@ def test_rigid_cage_motion_property():
     S0 = od.unpack_sym6(c0)
     np.testing.assert_allclose(od.unpack_sym6(c1).numpy(), (R @ S0 @ R.T).numpy(), atol=1e-12)
     np.testing.assert_allclose(c0.numpy(), od.pack_sym6(od.covariance_from_scale_rot(scales, rots)).numpy(), atol=1e-12)
+
+
+def test_loss_oracle_matches_reference_losses(golden):
+    """oracle/losses.py against values and autograd gradients of the reference's own l1_loss / ssim
+    (utils/loss_utils.py:29,59-86), tests/golden/loss_cases.npz."""
+    import torch
+    from oracle import losses as ol
+    g = golden("loss_cases.npz")
+    for name in ("a", "b", "c"):
+        pred = torch.from_numpy(g[f"{name}_pred"]).requires_grad_(True)
+        gt = torch.from_numpy(g[f"{name}_gt"])
+        v = ol.ssim(pred, gt)
+        (gr,) = torch.autograd.grad(v, pred)
+        np.testing.assert_allclose(v.detach().numpy(), g[f"{name}_ssim"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(gr.numpy(), g[f"{name}_ssim_grad"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(ol.l1_loss(pred, gt).detach().numpy(), g[f"{name}_l1"], rtol=0, atol=1e-7)

@@ -339,6 +339,22 @@ def gen_lbs(smplman_mod):
              delta=delta.numpy(), Rh=Rh_mat.numpy(), Th=Th[0].numpy(), out=out[0].numpy())
 
 
+def gen_losses(loss_utils):
+    """utils/loss_utils.py: l1_loss (:29) and ssim (:59-86) of the reference on seeded images, values and autograd
+    gradients w.r.t. the first image (sizes chosen to cross tile borders of the HIP kernel: not multiples of 16)."""
+    g = torch.Generator().manual_seed(23)
+    out = {}
+    for name, (C, H, W) in {"a": (3, 37, 53), "b": (1, 16, 16), "c": (3, 64, 96)}.items():
+        gt = torch.rand(C, H, W, generator=g)
+        pred = (gt + 0.25 * torch.randn(C, H, W, generator=g)).clamp(0, 1).requires_grad_(True)
+        val = loss_utils.ssim(pred, gt)
+        (grad,) = torch.autograd.grad(val, pred)
+        l1 = loss_utils.l1_loss(pred, gt)
+        out.update({f"{name}_pred": pred.detach().numpy(), f"{name}_gt": gt.numpy(), f"{name}_ssim": val.detach().numpy(),
+                    f"{name}_ssim_grad": grad.numpy(), f"{name}_l1": l1.detach().numpy()})
+    np.savez(os.path.join(OUT, "loss_cases.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_harness()
@@ -356,6 +372,8 @@ def main():
     gen_deform(cn, CageBase, "deform_case1", n_cell=4, P=1000, seed=18, dtype=torch.float32, use_shs=False)
     gen_boundary(renderer)
     gen_sh(sh_utils)
+    import utils.loss_utils as loss_utils
+    gen_losses(loss_utils)
     gen_lbs(smplman_mod)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
