@@ -610,7 +610,7 @@ __global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
 
     __shared__ __attribute__((aligned(16))) char s_rec[64 * kRecBytes];      // [0,16) conic+o  [16,32) rgb,id  [32,40) xy
     __shared__ __attribute__((aligned(16))) char s_accb[64 * kRecBytes];     // nine float sums per staged entry (+3 pad)
-    __shared__ uint16_t s_list[4][64];                                       // byte offsets j*48
+    __shared__ uint16_t s_list[5][64];                                       // byte offsets j*48; [4] = union of the four rows
     s_list[0][lane] = 0; s_list[1][lane] = 0; s_list[2][lane] = 0; s_list[3][lane] = 0;   // stale slots stay in range
 
 #ifdef D3GA_DIAG_COUNTERS
@@ -670,6 +670,9 @@ __global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
         if (r1) s_list[1][lanes_below(m1)] = (uint16_t)my_off;
         if (r2) s_list[2][lanes_below(m2)] = (uint16_t)my_off;
         if (r3) s_list[3][lanes_below(m3)] = (uint16_t)my_off;
+        const unsigned long long mu = m0 | m1 | m2 | m3;                    // entries some row will visit: the only
+        if (r0 || r1 || r2 || r3) s_list[4][lanes_below(mu)] = (uint16_t)my_off;   // ones the flush has to look at
+        const int n_u = __popcll(mu);
         const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
         const int trip = max(max(c0, c1), max(c2, c3));                     // wave-uniform (scalar)
         const int my_cnt = rg.row == 0 ? c0 : (rg.row == 1 ? c1 : (rg.row == 2 ? c2 : c3));
@@ -730,23 +733,24 @@ __global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
             if (l_lt9 && row_any) atomicAdd(reinterpret_cast<float *>(s_accb + off + l16x4), mine);   // ds_add_f32
         }
         __builtin_amdgcn_wave_barrier();
-        // flush: nine consecutive lanes publish one staged entry (36 contiguous bytes = 2 memory-side requests), seven
+        // flush: nine consecutive lanes publish one visited entry (36 contiguous bytes = 2 memory-side requests), seven
         // entries per instruction; the per-entry constants of the raw moments are applied here
 #pragma unroll 1
-        for (int e0 = 0; e0 < 64; e0 += 7) {
-            const int e = e0 + fq;
-            if (fq < 7 && e < 64) {
-                const float *sa = reinterpret_cast<const float *>(s_accb + e * kRecBytes);
+        for (int e0 = 0; e0 < n_u; e0 += 7) {
+            const int idx = e0 + fq;
+            if (fq < 7 && idx < n_u) {
+                const uint32_t eoff = s_list[4][idx];
+                const float *sa = reinterpret_cast<const float *>(s_accb + eoff);
                 const float S = sa[fk];
                 if (S != 0.f || fk < 2) {
-                    const float4 co = *reinterpret_cast<const float4 *>(s_rec + e * kRecBytes);
+                    const float4 co = *reinterpret_cast<const float4 *>(s_rec + eoff);
                     const float O = sa[fk ^ 1];
                     float val = S;
                     if (fk == 0) val = -(co.x * S + co.y * O) * ddelx_dx;
                     else if (fk == 1) val = -(co.z * S + co.y * O) * ddely_dy;
                     else if (fk < 5) val = -0.5f * S;
                     if (val != 0.f) {
-                        const uint32_t gid = __float_as_uint(*reinterpret_cast<const float *>(s_rec + e * kRecBytes + 28));
+                        const uint32_t gid = __float_as_uint(*reinterpret_cast<const float *>(s_rec + eoff + 28));
                         atomicAdd(acc + 12 * (size_t)gid + fk_off, val);
                     }
                 }
