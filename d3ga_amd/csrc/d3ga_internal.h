@@ -50,10 +50,11 @@ struct BinBuf {
     uint32_t *big_tiles;    // tiles       tiles with 4097..8192 entries (counters[4] of them)
     uint32_t *huge_tiles;   // tiles       tiles with more than 8192 entries: no LDS sort (counters[5])
     uint32_t *mid_tiles;    // tiles       tiles with 2049..4096 entries (counters[6])
+    uint32_t *tile_order;   // tiles       tile indices by descending list length (work-ordered dispatch of compositing)
 };
 static inline int64_t bin_bytes(int64_t tiles, int64_t dcap) {
     return 256 + align256(4 * tiles) + align256(4 * (tiles + 1)) + align256(4 * tiles) + align256(8 * dcap) +
-           align256(4 * dcap) + 3 * align256(4 * tiles);
+           align256(4 * dcap) + 4 * align256(4 * tiles);
 }
 static inline BinBuf carve_bin(void *base, int64_t tiles, int64_t dcap) {
     char *p = (char *)base;
@@ -66,7 +67,8 @@ static inline BinBuf carve_bin(void *base, int64_t tiles, int64_t dcap) {
     b.point_list = (uint32_t *)p;  p += align256(4 * dcap);
     b.big_tiles = (uint32_t *)p;   p += align256(4 * tiles);
     b.huge_tiles = (uint32_t *)p;  p += align256(4 * tiles);
-    b.mid_tiles = (uint32_t *)p;
+    b.mid_tiles = (uint32_t *)p;   p += align256(4 * tiles);
+    b.tile_order = (uint32_t *)p;
     return b;
 }
 

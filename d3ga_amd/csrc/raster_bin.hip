@@ -106,6 +106,61 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(int tiles, const 
     }
 }
 
+// Work-ordered dispatch of the compositing kernels: tile indices by DESCENDING list length (bucket sort, 256 buckets
+// scaled to the longest list; order inside a bucket is arbitrary).  All active compositing wavefronts are resident at once
+// and the dispatcher deals workgroups round-robin, so dealing them in descending order of work gives every SIMD one
+// wavefront from each work quantile instead of a random handful.
+__global__ __launch_bounds__(kScanBlock) void tile_order_kernel(int tiles, const uint32_t *__restrict__ count,
+                                                                const uint32_t *__restrict__ counters,
+                                                                uint32_t *__restrict__ order) {
+    __shared__ uint32_t s_hist[256];                      // buckets 0..254: non-empty tiles, longest lists first
+    __shared__ uint32_t s_zero;                           // empty tiles (most of the image for an avatar): wavefront-
+    const int tid = threadIdx.x, lane = tid & 63;         // aggregated, thousands of same-address LDS atomics serialise
+    if (tid < 256) s_hist[tid] = 0;
+    if (tid == 0) s_zero = 0;
+    const uint32_t mx = counters[D3GA_CNT_MAXTILE];
+    const int shift = mx >= 255u ? (32 - __clz((int)mx) - 8 + 1) : 0;      // (count >> shift) < 255
+    __syncthreads();
+    const int rounds = (tiles + kScanBlock - 1) / kScanBlock;
+    for (int r = 0; r < rounds; ++r) {
+        const int t = r * kScanBlock + tid;
+        const uint32_t c = t < tiles ? count[t] : 0u;
+        const bool zero = t < tiles && c == 0u;
+        const unsigned long long zm = __ballot(zero);
+        if (lane == 0 && zm) atomicAdd(&s_zero, (uint32_t)__popcll(zm));
+        if (t < tiles && c) atomicAdd(&s_hist[254u - min(c >> shift, 254u)], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {                                       // exclusive prefix of the buckets: 4 per lane + wave scan
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = (4 * tid + k < 255) ? s_hist[4 * tid + k] : 0u; sum += v[k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off);
+            if (tid >= off) incl += u;
+        }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_hist[4 * tid + k] = run; run += v[k]; }   // [255] = number of non-empty tiles
+    }
+    __syncthreads();
+    if (tid == 0) s_zero = s_hist[255];                   // empty tiles follow the non-empty ones
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        const int t = r * kScanBlock + tid;
+        const uint32_t c = t < tiles ? count[t] : 0u;
+        const bool zero = t < tiles && c == 0u;
+        const unsigned long long zm = __ballot(zero);
+        uint32_t zbase = 0;
+        if (lane == 0 && zm) zbase = atomicAdd(&s_zero, (uint32_t)__popcll(zm));
+        zbase = (uint32_t)__shfl((int)zbase, 0);
+        if (zero) order[zbase + (uint32_t)__popcll(zm & ((1ull << lane) - 1ull))] = (uint32_t)t;
+        if (t < tiles && c) order[atomicAdd(&s_hist[254u - min(c >> shift, 254u)], 1u)] = (uint32_t)t;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void tile_scatter_kernel(int P, int gx, const uint2 *__restrict__ rect,
                                                               const float *__restrict__ depth,
                                                               uint32_t *__restrict__ cursor, uint64_t *__restrict__ keys,
@@ -345,6 +400,9 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(kScanBlock), 0, s, tiles, bin.tile_count, bin.tile_start,
                        bin.tile_cursor, bin.counters, (uint64_t)d_capacity, bin.big_tiles, bin.huge_tiles, bin.mid_tiles,
                        (uint32_t)kSortSmall, (uint32_t)kSortMid, (uint32_t)kSortLarge);
+    D3GA_TRY(check_launch(s, prm->debug));
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kScanBlock), 0, s, tiles, bin.tile_count, bin.counters,
+                       bin.tile_order);
     D3GA_TRY(check_launch(s, prm->debug));
     if (prm->P == 0 || d_capacity == 0) return D3GA_OK;
     hipLaunchKernelGGL(tile_scatter_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, prm->P, gx, g.rect,

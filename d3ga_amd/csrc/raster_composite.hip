@@ -29,8 +29,9 @@
 namespace d3ga {
 
 // D3GA_COMPOSITE_VARIANT (A/B knob, tools/gpu_ab.sh): bit 0 fwd LDS slab, bit 1 bwd LDS slab (64-lane kernels); bit 2 fwd
-// row-segmented, bit 3 bwd row-segmented, bit 4 (with 3) bwd third generation (composite_bwd_rows3_kernel).
-constexpr int kDefaultCompositeVariant = 31;  // measured at C3: fwd 248 -> 133 us, bwd 508 -> 376 (rows) -> 337 us (rows3)
+// row-segmented, bit 3 bwd row-segmented, bit 4 (with 3) bwd third generation (composite_bwd_rows3_kernel), bit 5 work-
+// ordered dispatch of the row-segmented kernels (tile_order).
+constexpr int kDefaultCompositeVariant = 63;  // measured at C3: fwd 248 -> 133 us, bwd 508 -> 376 (rows) -> 337 us (rows3)
 
 // ---- wavefront (64 lanes) reductions through DPP ----
 template <int CTRL, int ROW_MASK>
@@ -150,6 +151,23 @@ __device__ __forceinline__ Quad quad_of_block(int gx, int gy) {
     return q;
 }
 static inline int quad_grid(int gx, int gy) { return 8 * ((gy + 7) / 8) * gx * 4; }
+// Work-ordered mapping: tile rank k (tile_order: descending list length) -> blocks b, b+8, b+16, b+24 of one XCD (the four
+// quadrants of a tile keep sharing an L2), ranks dealt round-robin over the XCDs.
+__device__ __forceinline__ Quad quad_of_block_ordered(int gx, int tiles, const uint32_t *__restrict__ order) {
+    Quad q;
+    const int b = blockIdx.x;
+    const int k = (b & 7) + 8 * (b >> 5), quad = (b >> 3) & 3;
+    q.valid = k < tiles;
+    q.tile = q.valid ? (int)order[k] : 0;
+    const int ty = q.tile / gx, tx = q.tile - ty * gx;
+    q.qx0 = tx * kTile + ((quad & 1) << 3);
+    q.qy0 = ty * kTile + ((quad >> 1) << 3);
+    const int lane = threadIdx.x & 63;
+    q.px = q.qx0 + (lane & 7);
+    q.py = q.qy0 + (lane >> 3);
+    return q;
+}
+static inline int quad_grid_ordered(int tiles) { return 32 * ((tiles + 7) / 8); }
 
 // Conservative test: can the Gaussian reach alpha >= 1/255 on any pixel of the quadrant [x0,x0+7]x[y0,y0+7]?
 // alpha = o*exp(-q/2) >= 1/255  <=>  q = A dx^2 + 2B dx dy + C dy^2 <= 2 ln(255 o) =: tau.  The ellipse q <= tau has the
@@ -476,8 +494,9 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
     uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
     const float4 *__restrict__ rgb_invd, const float *__restrict__ bg, float *__restrict__ final_T,
-    uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_invdepth) {
-    const Quad q = quad_of_block(gx, gy);
+    uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_invdepth,
+    const uint32_t *__restrict__ tile_order) {
+    const Quad q = tile_order ? quad_of_block_ordered(gx, gx * gy, tile_order) : quad_of_block(gx, gy);
     if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
     const int lane = threadIdx.x & 63;
     const RowGeom rg = row_geom(q, lane);
@@ -591,8 +610,9 @@ __global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
     uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
     const float4 *__restrict__ rgb_invd, const float *__restrict__ bg, const float *__restrict__ final_T,
-    const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix, float *__restrict__ acc) {
-    const Quad q = quad_of_block(gx, gy);
+    const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix, float *__restrict__ acc,
+    const uint32_t *__restrict__ tile_order) {
+    const Quad q = tile_order ? quad_of_block_ordered(gx, gx * gy, tile_order) : quad_of_block(gx, gy);
     if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
     const int lane = threadIdx.x & 63;
     const RowGeom rg = row_geom(q, lane);
@@ -954,10 +974,13 @@ extern "C" int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const fl
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
     const ImgBuf im = carve_img(img, prm->W, prm->H);
-    if (composite_variant() & 4)
-        hipLaunchKernelGGL(composite_fwd_rows_kernel, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
-                           bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
-                           im.final_T, im.n_contrib, out_color, out_invdepth);
+    if (composite_variant() & 4) {
+        const bool ordered = (composite_variant() & 32) != 0;
+        hipLaunchKernelGGL(composite_fwd_rows_kernel, dim3(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy)),
+                           dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity,
+                           g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, out_color, out_invdepth,
+                           ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr);
+    }
     else if (composite_variant() & 1)
         hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
                            bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
@@ -1000,10 +1023,13 @@ extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const fl
         return check_launch(s, prm->debug);
     }
 #endif
-    if ((composite_variant() & 24) == 24)
-        hipLaunchKernelGGL(composite_bwd_rows3_kernel, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
-                           gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
-                           im.final_T, im.n_contrib, dL_dpix, acc);
+    if ((composite_variant() & 24) == 24) {
+        const bool ordered = (composite_variant() & 32) != 0;
+        hipLaunchKernelGGL(composite_bwd_rows3_kernel, dim3(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy)),
+                           dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity,
+                           g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc,
+                           ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr);
+    }
     else if (composite_variant() & 8)
         hipLaunchKernelGGL(composite_bwd_rows_kernel, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
                            gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
