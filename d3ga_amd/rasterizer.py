@@ -85,12 +85,18 @@ class StageTimer:
         return r
 
     def summary(self):
-        """stage -> (launches, mean ms); call after torch.cuda.synchronize()."""
-        out = {}
+        """stage -> (launches, mean ms); call after torch.cuda.synchronize().  An event pair also sees any gap in which the
+        GPU waited for the host between the two records (a Python GC pause inside one eager launch shows up as a
+        multi-millisecond "kernel"), so launches longer than 5x the stage's median are left out of the mean."""
+        per = {}
         for name, a, b in self.records:
-            n, t = out.get(name, (0, 0.0))
-            out[name] = (n + 1, t + a.elapsed_time(b))
-        return {k: (n, t / n) for k, (n, t) in out.items()}
+            per.setdefault(name, []).append(a.elapsed_time(b))
+        out = {}
+        for name, ts in per.items():
+            med = sorted(ts)[len(ts) // 2]
+            kept = [t for t in ts if t <= 5.0 * med] or ts
+            out[name] = (len(kept), sum(kept) / len(kept))
+        return out
 
 
 stage_timer = StageTimer()
