@@ -48,6 +48,32 @@ __device__ __forceinline__ void sh_slab_store(const float *slab, float *__restri
 constexpr int kShHalfSlab = 32 * kShRow;
 constexpr size_t kShHalfLdsBytes = (size_t)(kBlock / 64) * kShHalfSlab * sizeof(float);      // 26,624 B per block
 
+// sum_k Y_k(dir_i) * coeff_k of this thread's Gaussian, with the (P,M,3) block read through wavefront-private LDS.
+// SH colour in two passes over HALF THE ROWS of the wavefront (rows 0..31, then 32..63; full 192-byte rows, so every
+// byte is fetched once): the slab of a wavefront is 32 x 52 floats = 6.5 KiB instead of 13 KiB, which lifts the kernels
+// from 12 to 20 resident wavefronts per CU.  Only wavefront-private LDS is touched: no workgroup barrier, program order
+// + wave_barrier suffice.  Every thread of the block must call it (s_sh: kShHalfLdsBytes of LDS).
+__device__ __forceinline__ void staged_sh_colour(const d3ga_raster_params &prm, const float *__restrict__ means3D,
+                                                 const float *__restrict__ shs, const float *__restrict__ campos,
+                                                 float *s_sh, float acc[3]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * kBlock + tid;
+    const int M3 = 3 * prm.M;
+    float *slab = s_sh + wave * kShHalfSlab;
+    const int row0 = blockIdx.x * kBlock + wave * 64;           // first Gaussian of this wavefront
+    const int rows = min(64, prm.P - row0);
+    const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
+    float B[16];
+    if (i < prm.P) sh_view_basis(prm, means3D, i, campos, B);
+    for (int h = 0; h < 2; ++h) {
+        const int r = min(32, rows - 32 * h);
+        __builtin_amdgcn_wave_barrier();
+        if (r > 0) sh_slab_load(slab, shs + (size_t)M3 * (row0 + 32 * h), r, M3, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (i < prm.P && (lane >> 5) == h) sh_accumulate(B, slab + (lane & 31) * kShRow, 0, 16, nb, acc);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     d3ga_raster_params prm, const float *__restrict__ means3D, const float *__restrict__ shs,
     const float *__restrict__ colors_precomp, const float *__restrict__ opacities, const float *__restrict__ scales,
@@ -59,29 +85,13 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     __shared__ int s_box[4];
     float *s_sh = reinterpret_cast<float *>(smem);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int i = blockIdx.x * kBlock + tid;
     const int M3 = 3 * prm.M;
     const bool staged = shs != nullptr && sh_staged(prm.M);
     float acc[3] = {0.f, 0.f, 0.f};
     if (staged) {
-        // SH colour in two passes over HALF THE ROWS of the wavefront (rows 0..31, then 32..63; full 192-byte rows, so
-        // every byte is fetched once): the slab of a wavefront is 32 x 52 floats = 6.5 KiB instead of 13 KiB, which
-        // lifts the kernel from 12 to 20 resident wavefronts per CU.  Only wavefront-private LDS is touched: no
-        // workgroup barrier, program order + wave_barrier suffice.
-        float *slab = s_sh + wave * kShHalfSlab;
-        const int row0 = blockIdx.x * kBlock + wave * 64;           // first Gaussian of this wavefront
-        const int rows = min(64, prm.P - row0);
-        const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
-        float B[16];
-        if (i < prm.P) sh_view_basis(prm, means3D, i, campos, B);
-        for (int h = 0; h < 2; ++h) {
-            const int r = min(32, rows - 32 * h);
-            __builtin_amdgcn_wave_barrier();
-            if (r > 0) sh_slab_load(slab, shs + (size_t)M3 * (row0 + 32 * h), r, M3, lane);
-            __builtin_amdgcn_wave_barrier();
-            if (i < prm.P && (lane >> 5) == h) sh_accumulate(B, slab + (lane & 31) * kShRow, 0, 16, nb, acc);
-        }
+        staged_sh_colour(prm, means3D, shs, campos, s_sh, acc);
         __syncthreads();                                            // the region becomes the tile window below
     }
     bool visible = false;
@@ -138,6 +148,55 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
         for (int ty = r1; ty < r3; ++ty)
             for (int tx = r0; tx < r2; ++tx) atomicAdd(&tile_count[ty * gx + tx], 1u);
     }
+}
+
+// Second render of the SAME geometry with other colours (the reference's training step renders RGB and a silhouette
+// pass from one garment_pkg, models/trainer.py:102-110): copies the geometry records of `src` to `dst` and evaluates
+// only the colour (SH of this camera or colors_precomp) -- the projection, the tile histogram and the whole binning
+// stage of the second pass disappear; `dst` then shares the first pass's binning buffer.
+__global__ __launch_bounds__(kBlock) void recolor_kernel(d3ga_raster_params prm, const float *__restrict__ means3D,
+                                                         const float *__restrict__ shs,
+                                                         const float *__restrict__ colors_precomp,
+                                                         const float *__restrict__ campos, GeomBuf src, GeomBuf dst) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_sh = reinterpret_cast<float *>(smem);
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int M3 = 3 * prm.M;
+    const bool staged = shs != nullptr && sh_staged(prm.M);
+    float acc[3] = {0.f, 0.f, 0.f};
+    if (staged) staged_sh_colour(prm, means3D, shs, campos, s_sh, acc);
+    if (i >= prm.P) return;
+    const uint2 rc = src.rect[i];
+    const bool visible = ((rc.y & 0xffffu) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.x >> 16));
+    const float depth = src.depth[i];
+    dst.depth[i] = depth;
+    dst.xy[i] = src.xy[i];
+    dst.conic_o[i] = src.conic_o[i];
+    dst.rect[i] = rc;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dst.cov3D[6 * (size_t)i + k] = src.cov3D[6 * (size_t)i + k];
+    float rgb[3] = {0.f, 0.f, 0.f};
+    uint8_t mask = 0;
+    if (visible) {
+        if (colors_precomp) {
+            rgb[0] = colors_precomp[3 * (size_t)i]; rgb[1] = colors_precomp[3 * (size_t)i + 1];
+            rgb[2] = colors_precomp[3 * (size_t)i + 2];
+        } else {
+            if (!staged) {
+                float B[16];
+                sh_view_basis(prm, means3D, i, campos, B);
+                sh_accumulate(B, shs + (size_t)M3 * i, 0, 16, (prm.sh_degree + 1) * (prm.sh_degree + 1), acc);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = acc[c] + 0.5f;
+                if (v < 0.f) mask |= (uint8_t)(1u << c);
+                rgb[c] = fmaxf(v, 0.f);
+            }
+        }
+    }
+    dst.rgb_invd[i] = make_float4(rgb[0], rgb[1], rgb[2], visible ? 1.0f / depth : 0.f);
+    dst.clamped[i] = mask;
 }
 
 __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
@@ -294,6 +353,23 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     hipLaunchKernelGGL(preprocess_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
                        colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, g,
                        bin.tile_count, bin.counters, radii);
+    return check_launch(s, prm->debug & 0xff);
+}
+
+extern "C" int d3ga_raster_recolor(const d3ga_raster_params *prm, const float *means3D, const float *shs,
+                                   const float *colors_precomp, const float *campos, const void *geom_src,
+                                   void *geom_dst, d3ga_stream_t stream) {
+    D3GA_TRY(validate(prm));
+    if (prm->P == 0) return D3GA_OK;
+    if (!geom_src || !geom_dst || geom_src == geom_dst) return D3GA_E_NULL;
+    if ((shs != nullptr) == (colors_precomp != nullptr)) return D3GA_E_CONFIG;
+    if (shs && (!means3D || !campos)) return D3GA_E_NULL;
+    if (shs && (prm->sh_degree + 1) * (prm->sh_degree + 1) > prm->M) return D3GA_E_CONFIG;
+    hipStream_t s = (hipStream_t)stream;
+    const GeomBuf src = carve_geom(const_cast<void *>(geom_src), prm->P), dst = carve_geom(geom_dst, prm->P);
+    const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? kShHalfLdsBytes : 0;
+    hipLaunchKernelGGL(recolor_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
+                       colors_precomp, campos, src, dst);
     return check_launch(s, prm->debug & 0xff);
 }
 

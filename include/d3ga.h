@@ -154,6 +154,15 @@ int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const float *bg, co
 int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, const void *img, const float *dL_dpix, float *acc,
                               d3ga_stream_t stream);
+/* Re-render of the SAME geometry (same means3D / covariance / opacities / camera / image size) with other colours: the
+ * reference's training step renders an RGB and a silhouette pass from one package (models/trainer.py:102-110).
+ * Copies the geometry records of geom_src (a d3ga_raster_preprocess result) to geom_dst and evaluates only the colour
+ * (SH from this camera, or colors_precomp).  geom_dst is then used with the binning buffer of the first pass in
+ * d3ga_raster_composite_fwd / _bwd / _preprocess_bwd; the binning buffer is only read by those. */
+int d3ga_raster_recolor(const d3ga_raster_params *prm, const float *means3D, const float *shs,
+                        const float *colors_precomp, const float *campos, const void *geom_src, void *geom_dst,
+                        d3ga_stream_t stream);
+
 /* R6 per-Gaussian backward.  Writes every element of the outputs (zeros for culled Gaussians):
  * dL_dmeans3D (P,3), dL_dmeans2D (P,3), dL_dopacity (P,1), and dL_dsh (P,M,3) | dL_dcolors (P,3),
  * dL_dcov3D (P,6) | (dL_dscales (P,3), dL_drots (P,4)).

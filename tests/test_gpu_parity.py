@@ -658,3 +658,48 @@ def test_fused_ssim_matches_reference_goldens_and_oracle(golden):
     y = torch.rand(2, 3, 20, 24, generator=gen)
     np.testing.assert_allclose(_np(ssim(x.to(DEV), y.to(DEV), size_average=False)),
                                ol.ssim(x, y, size_average=False).numpy(), atol=5e-6)
+
+
+def test_geometry_reuse_between_rgb_and_silhouette_pass():
+    """The second render of the same package (models/trainer.py:102-110) reuses projection + binning of the first
+    (d3ga_raster_recolor).  It must give exactly the image and the gradients of a render without reuse, must not be used
+    when an input changed in place, and the first pass's backward must be unaffected."""
+    from d3ga_amd import rasterizer as R
+    inp = scene_inputs("T1", scale_mult=3.0)
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    st = _settings(inp, bg, 3)
+    rast = R.GaussianRasterizer(st)
+    gpix = torch.randn(3, inp["H"], inp["W"], generator=torch.Generator().manual_seed(4)).to(DEV)
+    sil = torch.rand(inp["means3D"].shape[0], 3, generator=torch.Generator().manual_seed(5)).to(DEV)
+
+    def two_passes(reuse):
+        R.set_geometry_reuse(reuse)
+        R.clear_geometry_cache()
+        means, cov, op, sh = (_cu(inp[k], True) for k in ("means3D", "cov6", "opacities", "shs"))
+        z = lambda: torch.zeros_like(means)
+        rgb, radii1, _ = rast(means3D=means, means2D=z(), opacities=op, shs=sh, cov3D_precomp=cov)
+        mask, radii2, _ = rast(means3D=means, means2D=z(), opacities=op, colors_precomp=sil, cov3D_precomp=cov)
+        ((rgb * gpix).sum() + 0.5 * (mask * gpix).sum()).backward()
+        return rgb, mask, radii1, radii2, means.grad, cov.grad, op.grad, sh.grad
+
+    try:
+        a = two_passes(False)
+        b = two_passes(True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        for x, y in zip(a[4:], b[4:]):
+            assert rel_err(_np(y), _np(x)) < 1e-5
+        # an in-place change of an input must miss the cache: result equals a fresh render of the new values
+        R.clear_geometry_cache()
+        means = inp["means3D"].to(DEV).clone()
+        cov, op = inp["cov6"].to(DEV), inp["opacities"].to(DEV)
+        z = lambda: torch.zeros_like(means)
+        rast(means3D=means, means2D=z(), opacities=op, colors_precomp=sil, cov3D_precomp=cov)
+        means.add_(0.05)
+        moved, _, _ = rast(means3D=means, means2D=z(), opacities=op, colors_precomp=sil, cov3D_precomp=cov)
+        R.set_geometry_reuse(False)
+        fresh, _, _ = rast(means3D=means.clone(), means2D=z(), opacities=op, colors_precomp=sil, cov3D_precomp=cov)
+        assert torch.equal(moved, fresh)
+    finally:
+        R.set_geometry_reuse(True)
+        R.clear_geometry_cache()
