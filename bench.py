@@ -105,7 +105,7 @@ class Frame:
         constant per-Gaussian colour on a black background; losses as in train.py:190-193 (L1 + SSIM on RGB, L1 on the
         silhouette)."""
         from d3ga_amd.cage_deform import cage_deform, lbs_cage
-        from d3ga_amd.losses import l1_loss, ssim
+        from d3ga_amd.losses import l1_loss, l1_ssim
         from d3ga_amd.renderer import render
         p = self.params
         if not hasattr(self, "sil_rgb"):
@@ -122,8 +122,8 @@ class Frame:
         sil = render(self.batch, pkg, self.bg0, colors_precomp=self.sil_rgb, grad_sync=self.grad_sync)["render"]
         # train.py:190-193: (1 - lambda) L1 + lambda (1 - SSIM) on the RGB image, L1 on the silhouette
         lam = 0.2
-        loss = ((1.0 - lam) * l1_loss(img, self.target) + lam * (1.0 - ssim(img, self.target))
-                + l1_loss(sil, self.sil_target))
+        rgb_l1, rgb_ssim = l1_ssim(img, self.target)          # one fused kernel each way
+        loss = (1.0 - lam) * rgb_l1 + lam * (1.0 - rgb_ssim) + l1_loss(sil, self.sil_target)
         loss.backward()
         return loss
 

@@ -58,6 +58,8 @@ _SIGNATURES = {
     "d3ga_l1_mean_bwd": ([_i64, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_ssim_fwd": ([ctypes.c_int32] * 3 + [_vp] * 6 + [_vp], _i),
     "d3ga_ssim_bwd": ([ctypes.c_int32] * 3 + [_vp] * 7 + [_vp], _i),
+    "d3ga_ssim_l1_fwd": ([ctypes.c_int32] * 3 + [_vp] * 7 + [_vp], _i),
+    "d3ga_ssim_l1_bwd": ([ctypes.c_int32] * 3 + [_vp] * 8 + [_vp], _i),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -78,16 +78,17 @@ constexpr float kSsimC1 = 0.01f * 0.01f, kSsimC2 = 0.03f * 0.03f;
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(int C, int H, int W, int tiles_x, int tiles_y,
                                                        const float *__restrict__ img1, const float *__restrict__ img2,
                                                        float inv_n, float *__restrict__ out, float *__restrict__ Dm,
-                                                       float *__restrict__ Dq1, float *__restrict__ Dq12) {
+                                                       float *__restrict__ Dq1, float *__restrict__ Dq12,
+                                                       float *__restrict__ out_l1) {
     __shared__ float s_x[kSsimIn][kSsimIn + 1], s_y[kSsimIn][kSsimIn + 1];
     __shared__ float s_h[5][kSsimIn][kSsimTile + 1];
-    __shared__ float s_part[4];
+    __shared__ float s_part[8];
     const int tid = threadIdx.x, px = tid & 15, py = tid >> 4;
     const int ntiles = C * tiles_x * tiles_y;
     float w[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) w[k] = c_ssim_w[k];
-    float local = 0.f;
+    float local = 0.f, local_l1 = 0.f;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int c = t / (tiles_x * tiles_y), r = t - c * tiles_x * tiles_y;
         const int ty = r / tiles_x, tx = r - ty * tiles_x;
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int C, int H, int W, int 
             const float iD = 1.0f / Dd, iE = 1.0f / E;
             const float val = A * B * iD * iE;
             local += val;
+            local_l1 += fabsf(s_x[py + kSsimHalo][px + kSsimHalo] - s_y[py + kSsimHalo][px + kSsimHalo]);   // fused L1
             if (Dm) {
                 // partials w.r.t. the five convolved maps (s1, s12 depend on mu1 through -mu1^2, -mu1 mu2)
                 const float d_s1 = -val * iE;                              // d/d s1   (= d/d q1)
@@ -140,21 +142,27 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int C, int H, int W, int 
         }
     }
     local = wave_sum_loss(local);
-    if ((tid & 63) == 0) s_part[tid >> 6] = local;
+    local_l1 = wave_sum_loss(local_l1);
+    if ((tid & 63) == 0) { s_part[tid >> 6] = local; s_part[4 + (tid >> 6)] = local_l1; }
     __syncthreads();
-    if (tid == 0) atomicAdd(out, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * inv_n);
+    if (tid == 0) {
+        atomicAdd(out, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * inv_n);
+        if (out_l1) atomicAdd(out_l1, (s_part[4] + s_part[5] + s_part[6] + s_part[7]) * inv_n);
+    }
 }
 
 __global__ __launch_bounds__(256) void ssim_bwd_kernel(int C, int H, int W, int tiles_x, int tiles_y,
                                                        const float *__restrict__ img1, const float *__restrict__ img2,
                                                        const float *__restrict__ Dm, const float *__restrict__ Dq1,
                                                        const float *__restrict__ Dq12, const float *__restrict__ g,
-                                                       float inv_n, float *__restrict__ grad1) {
+                                                       const float *__restrict__ g_l1, float inv_n,
+                                                       float *__restrict__ grad1) {
     __shared__ float s_in[3][kSsimIn][kSsimIn + 1];
     __shared__ float s_h[3][kSsimIn][kSsimTile + 1];
     const int tid = threadIdx.x, px = tid & 15, py = tid >> 4;
     const int ntiles = C * tiles_x * tiles_y;
     const float scale = g[0] * inv_n;
+    const float scale_l1 = g_l1 ? g_l1[0] * inv_n : 0.f;
     float w[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) w[k] = c_ssim_w[k];
@@ -193,7 +201,8 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int C, int H, int W, int 
         const int gy = ty * kSsimTile + py, gx = tx * kSsimTile + px;
         if (gy < H && gx < W) {
             const size_t o = plane + (size_t)gy * W + gx;
-            grad1[o] = scale * (a + 2.f * img1[o] * b + img2[o] * d);
+            const float x = img1[o], y = img2[o], df = x - y;
+            grad1[o] = scale * (a + 2.f * x * b + y * d) + scale_l1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
         }
     }
 }
@@ -234,28 +243,40 @@ extern "C" int d3ga_l1_mean_bwd(int64_t n, const float *a, const float *b, const
 
 static inline int ssim_grid(int ntiles, int cap) { return ntiles < 1 ? 1 : (ntiles > cap ? cap : ntiles); }
 
-extern "C" int d3ga_ssim_fwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *out,
-                             float *Dm, float *Dq1, float *Dq12, d3ga_stream_t stream) {
+extern "C" int d3ga_ssim_l1_fwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *out,
+                                float *Dm, float *Dq1, float *Dq12, float *out_l1, d3ga_stream_t stream) {
     if (C <= 0 || H <= 0 || W <= 0) return D3GA_E_SIZE;
     if (!img1 || !img2 || !out) return D3GA_E_NULL;
     if ((Dm != nullptr) != (Dq1 != nullptr) || (Dm != nullptr) != (Dq12 != nullptr)) return D3GA_E_CONFIG;
     hipStream_t s = (hipStream_t)stream;
     D3GA_HIP(hipMemsetAsync(out, 0, sizeof(float), s));
+    if (out_l1) D3GA_HIP(hipMemsetAsync(out_l1, 0, sizeof(float), s));
     const int tx = (W + kSsimTile - 1) / kSsimTile, ty = (H + kSsimTile - 1) / kSsimTile;
     // persistent grid: every workgroup ends with ONE atomic on the result word (same-address atomics serialise)
     hipLaunchKernelGGL(ssim_fwd_kernel, dim3(ssim_grid(C * tx * ty, 2048)), dim3(256), 0, s, C, H, W, tx, ty, img1, img2,
-                       1.0f / ((float)C * (float)H * (float)W), out, Dm, Dq1, Dq12);
+                       1.0f / ((float)C * (float)H * (float)W), out, Dm, Dq1, Dq12, out_l1);
+    return check_launch(s, 0);
+}
+
+extern "C" int d3ga_ssim_fwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *out,
+                             float *Dm, float *Dq1, float *Dq12, d3ga_stream_t stream) {
+    return d3ga_ssim_l1_fwd(C, H, W, img1, img2, out, Dm, Dq1, Dq12, nullptr, stream);
+}
+
+extern "C" int d3ga_ssim_l1_bwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, const float *Dm,
+                                const float *Dq1, const float *Dq12, const float *g, const float *g_l1,
+                                float *grad_img1, d3ga_stream_t stream) {
+    if (C <= 0 || H <= 0 || W <= 0) return D3GA_E_SIZE;
+    if (!img1 || !img2 || !Dm || !Dq1 || !Dq12 || !g || !grad_img1) return D3GA_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const int tx = (W + kSsimTile - 1) / kSsimTile, ty = (H + kSsimTile - 1) / kSsimTile;
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(ssim_grid(C * tx * ty, 8192)), dim3(256), 0, s, C, H, W, tx, ty, img1, img2,
+                       Dm, Dq1, Dq12, g, g_l1, 1.0f / ((float)C * (float)H * (float)W), grad_img1);
     return check_launch(s, 0);
 }
 
 extern "C" int d3ga_ssim_bwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, const float *Dm,
                              const float *Dq1, const float *Dq12, const float *g, float *grad_img1,
                              d3ga_stream_t stream) {
-    if (C <= 0 || H <= 0 || W <= 0) return D3GA_E_SIZE;
-    if (!img1 || !img2 || !Dm || !Dq1 || !Dq12 || !g || !grad_img1) return D3GA_E_NULL;
-    hipStream_t s = (hipStream_t)stream;
-    const int tx = (W + kSsimTile - 1) / kSsimTile, ty = (H + kSsimTile - 1) / kSsimTile;
-    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(ssim_grid(C * tx * ty, 8192)), dim3(256), 0, s, C, H, W, tx, ty, img1, img2,
-                       Dm, Dq1, Dq12, g, 1.0f / ((float)C * (float)H * (float)W), grad_img1);
-    return check_launch(s, 0);
+    return d3ga_ssim_l1_bwd(C, H, W, img1, img2, Dm, Dq1, Dq12, g, nullptr, grad_img1, stream);
 }

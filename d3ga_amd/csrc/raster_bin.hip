@@ -412,12 +412,16 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
                        bin.point_list, (uint64_t)d_capacity);
     D3GA_TRY(check_launch(s, prm->debug));
     // long lists: persistent grids driven by the device-side work lists (empty for avatar-sized scenes)
-    static const bool attrs_set = [] {   // > 64 KiB of dynamic LDS needs an explicit opt-in (once per process)
-        (void)hipFuncSetAttribute((const void *)tile_sort_lds_list_kernel<1024, kSortLarge>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (kSortLarge + kSortLarge / 8) * 8);
-        return true;
-    }();
-    (void)attrs_set;
+    {   // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (function attributes are per device)
+        static bool attr_set[64] = {};
+        int dev = 0;
+        D3GA_HIP(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            D3GA_HIP(hipFuncSetAttribute((const void *)tile_sort_lds_list_kernel<1024, kSortLarge>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (kSortLarge + kSortLarge / 8) * 8));
+            attr_set[dev] = true;
+        }
+    }
     const int lgrid = tiles < 1024 ? tiles : 1024;
     hipLaunchKernelGGL((tile_sort_lds_list_kernel<512, kSortMid>), dim3(lgrid), dim3(512), (kSortMid + kSortMid / 8) * 8, s,
                        bin.tile_start, bin.keys, bin.point_list, (uint64_t)d_capacity, bin.mid_tiles,

@@ -92,3 +92,36 @@ def ssim(img1, img2, window_size=11, size_average=True):
         raise ValueError(f"ssim: expected (C,H,W) or (N,C,H,W) inputs of equal shape, got {tuple(img1.shape)}")
     per = torch.stack([_SSIM.apply(img1[n], img2[n]) for n in range(img1.shape[0])])
     return per.mean() if size_average else per
+
+
+class _L1SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2):
+        require_cuda(img1, img2)
+        a = img1.float().contiguous()
+        b = img2.float().contiguous()
+        if a.shape != b.shape or a.dim() != 3:
+            raise ValueError(f"l1_ssim: expected two (C,H,W) images of equal shape, got {tuple(a.shape)} / {tuple(b.shape)}")
+        C, H, W = a.shape
+        out = torch.empty((2,), dtype=torch.float32, device=a.device)
+        d = [torch.empty_like(a) for _ in range(3)]
+        check(_lib.lib().d3ga_ssim_l1_fwd(C, H, W, dptr(a), dptr(b), dptr(out[1:]), dptr(d[0]), dptr(d[1]), dptr(d[2]),
+                                          dptr(out[:1]), stream_handle()), "d3ga_ssim_l1_fwd")
+        ctx.save_for_backward(a, b, *d)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim):
+        a, b, d0, d1, d2 = ctx.saved_tensors
+        C, H, W = a.shape
+        g = torch.stack([g_l1.float().reshape(()), g_ssim.float().reshape(())])
+        ga = torch.empty_like(a)
+        check(_lib.lib().d3ga_ssim_l1_bwd(C, H, W, dptr(a), dptr(b), dptr(d0), dptr(d1), dptr(d2), dptr(g[1:]),
+                                          dptr(g[:1]), dptr(ga), stream_handle()), "d3ga_ssim_l1_bwd")
+        return ga, None
+
+
+def l1_ssim(network_output, gt):
+    """(l1_loss(network_output, gt), ssim(network_output, gt)) from ONE kernel each way -- the pair train.py:190-193
+    combines as (1 - lambda) * l1 + lambda * (1 - ssim).  Differentiable in network_output only (gt is the target)."""
+    return _L1SSIM.apply(network_output, gt)

@@ -228,6 +228,13 @@ int d3ga_ssim_fwd(int32_t C, int32_t H, int32_t W, const float *img1, const floa
                   float *Dq1, float *Dq12, d3ga_stream_t stream);
 int d3ga_ssim_bwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, const float *Dm,
                   const float *Dq1, const float *Dq12, const float *g, float *grad_img1, d3ga_stream_t stream);
+/* The same two kernels with the L1 term of train.py:190-193 riding along (both losses read the same two images):
+ * out_l1[0] = mean |img1 - img2| (NULL: skipped); g_l1: device scalar dL/d(l1) (NULL: no L1 term in the gradient). */
+int d3ga_ssim_l1_fwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *out, float *Dm,
+                     float *Dq1, float *Dq12, float *out_l1, d3ga_stream_t stream);
+int d3ga_ssim_l1_bwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, const float *Dm,
+                     const float *Dq1, const float *Dq12, const float *g, const float *g_l1, float *grad_img1,
+                     d3ga_stream_t stream);
 
 /* Test hook, not part of the drop-in surface: the 64-lane reductions of the compositing backward.  n multiple of 256;
  * in (n) -> out (10*n/64): per wavefront w, out[10w+k] = sum_l ((k+1) in[l] + k/64) for k<9, out[10w+9] = sum_l in[l]. */

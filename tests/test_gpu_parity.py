@@ -653,6 +653,17 @@ def test_fused_ssim_matches_reference_goldens_and_oracle(golden):
         assert abs(float(vd) - float(vo)) < 5e-6, (C, H, W)
         assert rel_err(_np(ad.grad), ac.grad.numpy()) < 5e-5, (C, H, W)
         assert rel_err(_np(bd.grad), bc.grad.numpy()) < 5e-5, (C, H, W)
+    # fused L1 + SSIM pair (train.py:190-193) against the two separate oracles
+    from d3ga_amd.losses import l1_ssim
+    bb = torch.rand(3, 70, 45, generator=gen)
+    aa = (bb + 0.2 * torch.randn(3, 70, 45, generator=gen)).clamp(0, 1)
+    ac = aa.clone().requires_grad_(True)
+    (0.8 * ol.l1_loss(ac, bb) + 0.2 * (1.0 - ol.ssim(ac, bb))).backward()
+    ad = aa.to(DEV).requires_grad_(True)
+    l1v, sv = l1_ssim(ad, bb.to(DEV))
+    (0.8 * l1v + 0.2 * (1.0 - sv)).backward()
+    assert abs(float(l1v) - float(ol.l1_loss(aa, bb))) < 1e-6 and abs(float(sv) - float(ol.ssim(aa, bb))) < 5e-6
+    assert rel_err(_np(ad.grad), ac.grad.numpy()) < 5e-5
     # batched form
     x = torch.rand(2, 3, 20, 24, generator=gen)
     y = torch.rand(2, 3, 20, 24, generator=gen)
