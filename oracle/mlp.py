@@ -1,0 +1,39 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's field networks (models/mlp.py, utils/pos_encoder.py).
+
+Pinned: tests/golden/field_cases.npz holds weights, inputs, outputs and autograd gradients of the reference's own
+`CanonicalField` and `DeformationField` (tools/gen_golden.py imports /root/reference/models/mlp.py in the build container).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def embed(x, multires=7):
+    """utils/pos_encoder.py:13-66 with get_embedder(7): [x, sin(2^0 x), cos(2^0 x), ..., sin(2^6 x), cos(2^6 x)] -> 3 + 42."""
+    out = [x]
+    for freq in 2.0 ** torch.linspace(0.0, multires - 1, steps=multires):
+        out += [torch.sin(x * freq), torch.cos(x * freq)]
+    return torch.cat(out, -1)
+
+
+def field_mlp(z, hidden, out_w, out_b):
+    """The trunk every field shares (models/mlp.py:64-69,100-105): h = leaky_relu(W h + b, 0.1) for every layer of
+    `hidden` = [(W, b), ...], then the linear head."""
+    h = z
+    for w, b in hidden:
+        h = F.leaky_relu(F.linear(h, w, b), negative_slope=0.1)
+    return F.linear(h, out_w, out_b)
+
+
+def canonical_field(barys, rots, scales, pose, hidden, out_w, out_b, scale_bary=0.25, bary_size=4):
+    """models/mlp.py:94-110: z = [pose | rots | scales | barys] -> (tanh(pred[:, :4]) * scale_bary, pred[:, 4:8], pred[:, 8:])."""
+    P = barys.shape[0]
+    z = torch.cat([pose.expand(P, -1), rots, scales, barys], dim=1)
+    pred = field_mlp(z, hidden, out_w, out_b)
+    return torch.tanh(pred[:, :bary_size]) * scale_bary, pred[:, bary_size:bary_size + 4], pred[:, bary_size + 4:]
+
+
+def deformation_field(canonical, pose, hidden, out_w, out_b, scaling):
+    """models/mlp.py:58-71: z = [pose | embed_7(canonical)] -> tanh(pred) * scaling."""
+    P = canonical.shape[0]
+    z = torch.cat([pose.expand(P, -1), embed(canonical)], dim=1)
+    return torch.tanh(field_mlp(z, hidden, out_w, out_b)) * scaling

@@ -123,3 +123,33 @@ def test_loss_oracle_matches_reference_losses(golden):
         np.testing.assert_allclose(v.detach().numpy(), g[f"{name}_ssim"], rtol=0, atol=1e-7)
         np.testing.assert_allclose(gr.numpy(), g[f"{name}_ssim_grad"], rtol=0, atol=1e-9)
         np.testing.assert_allclose(ol.l1_loss(pred, gt).detach().numpy(), g[f"{name}_l1"], rtol=0, atol=1e-7)
+
+
+def _field_weights(g, prefix, n_hidden=4):
+    hidden = [(torch.from_numpy(g[f"{prefix}_w_network.{i}.weight"]), torch.from_numpy(g[f"{prefix}_w_network.{i}.bias"]))
+              for i in range(n_hidden)]
+    return hidden, torch.from_numpy(g[f"{prefix}_w_output.weight"]), torch.from_numpy(g[f"{prefix}_w_output.bias"])
+
+
+def test_field_oracle_matches_reference_fields(golden):
+    """oracle/mlp.py against outputs and autograd gradients of the reference's own CanonicalField / DeformationField
+    (models/mlp.py:39-110), tests/golden/field_cases.npz -- including the argument-order quirk of cage_net.py:199-204."""
+    from oracle import mlp as om
+    g = golden("field_cases.npz")
+    hidden, ow, ob = _field_weights(g, "cf")
+    leaf = lambda k: torch.from_numpy(g[k]).requires_grad_(True)
+    barys, rots, scales, pose = leaf("cf_barys"), leaf("cf_rots"), leaf("cf_scales"), leaf("cf_pose")
+    # the reference calls canonical_field(rotation, scales, barys, cond) against (barys, rots, scales, pose)
+    outs = om.canonical_field(rots, scales, barys, pose, hidden, ow, ob)
+    for o, k in zip(outs, ("cf_d_bary", "cf_d_rot", "cf_d_scale")):
+        np.testing.assert_allclose(o.detach().numpy(), g[k], rtol=1e-5, atol=1e-6)
+    grads = torch.autograd.grad(list(outs), [barys, rots, scales, pose], [torch.from_numpy(g[f"cf_up{i}"]) for i in range(3)])
+    for gr, k in zip(grads, ("cf_g_barys", "cf_g_rots", "cf_g_scales", "cf_g_pose")):
+        np.testing.assert_allclose(gr.numpy(), g[k], rtol=1e-4, atol=1e-6)
+    hidden, ow, ob = _field_weights(g, "df")
+    canon, pose = leaf("df_canon"), leaf("df_pose")
+    delta = om.deformation_field(canon, pose, hidden, ow, ob, scaling=0.07)
+    np.testing.assert_allclose(delta.detach().numpy(), g["df_delta"], rtol=1e-5, atol=1e-7)
+    gc, gp = torch.autograd.grad(delta, [canon, pose], torch.from_numpy(g["df_up"]))
+    np.testing.assert_allclose(gc.numpy(), g["df_g_canon"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(gp.numpy(), g["df_g_pose"], rtol=1e-4, atol=1e-6)

@@ -355,6 +355,61 @@ def gen_losses(loss_utils):
     np.savez(os.path.join(OUT, "loss_cases.npz"), **out)
 
 
+def gen_fields(mlp_mod):
+    """models/mlp.py: DeformationField (:39-71) and CanonicalField (:74-110) of the reference with the widths of
+    configs/actorshq_actor02.yml (n_nodes 128, n_layers 3): weights, inputs, outputs and autograd gradients w.r.t. the
+    per-row inputs, the pose vector and every weight, for a fixed upstream gradient."""
+    from types import SimpleNamespace as NS
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+
+        def get(self, k, d=None):
+            return dict.get(self, k, d)
+
+    config = Cfg(is_smpl_body=False, deform_mlp=Cfg(n_layers=3, n_nodes=128, scale=0.2),
+                 canon_mlp=Cfg(n_layers=3, n_nodes=128, scale_bary=0.25, scale_rot=0.25, scale_scale=0.25))
+    cage_config = Cfg(cage_name="body", node_scale=0.07)
+    torch.manual_seed(31)
+    out = {}
+    g = torch.Generator().manual_seed(32)
+    # --- CanonicalField: z = [pose(98) | rots(4) | scales(3) | barys(4)] -> 128 x (1+3) -> 11
+    cf = mlp_mod.CanonicalField(config, cage_config)
+    P = 300
+    barys = torch.rand(P, 4, generator=g).requires_grad_(True)
+    rots = torch.randn(P, 4, generator=g).requires_grad_(True)
+    scales = (0.1 * torch.randn(P, 3, generator=g)).requires_grad_(True)
+    pose = (0.3 * torch.randn(98, generator=g)).requires_grad_(True)
+    # called as (rot, scale, bary, cond) against the signature (barys, rots, scales, pose): cage_net.py:199-204
+    d_bary, d_rot, d_scale = cf(rots, scales, barys, pose)
+    up = [torch.randn(*t.shape, generator=g) for t in (d_bary, d_rot, d_scale)]
+    params = list(cf.parameters())
+    grads = torch.autograd.grad([d_bary, d_rot, d_scale], [barys, rots, scales, pose] + params, up)
+    out.update(cf_barys=barys.detach().numpy(), cf_rots=rots.detach().numpy(), cf_scales=scales.detach().numpy(),
+               cf_pose=pose.detach().numpy(), cf_d_bary=d_bary.detach().numpy(), cf_d_rot=d_rot.detach().numpy(),
+               cf_d_scale=d_scale.detach().numpy(), cf_up0=up[0].numpy(), cf_up1=up[1].numpy(), cf_up2=up[2].numpy(),
+               cf_g_barys=grads[0].numpy(), cf_g_rots=grads[1].numpy(), cf_g_scales=grads[2].numpy(),
+               cf_g_pose=grads[3].numpy())
+    for (name, prm), gr in zip(cf.named_parameters(), grads[4:]):
+        out[f"cf_w_{name}"] = prm.detach().numpy()
+        out[f"cf_gw_{name}"] = gr.numpy()
+    # --- DeformationField: z = [pose(98) | embed_7(canonical)(45)] -> 128 x (1+3) -> 3, tanh * node_scale
+    df = mlp_mod.DeformationField(config, cage_config)
+    V = 211
+    canon = torch.randn(V, 3, generator=g).requires_grad_(True)
+    pose2 = (0.3 * torch.randn(98, generator=g)).requires_grad_(True)
+    delta = df(canon, pose2)
+    up2 = torch.randn(V, 3, generator=g)
+    params = list(df.parameters())
+    grads = torch.autograd.grad(delta, [canon, pose2] + params, up2)
+    out.update(df_canon=canon.detach().numpy(), df_pose=pose2.detach().numpy(), df_delta=delta.detach().numpy(),
+               df_up=up2.numpy(), df_g_canon=grads[0].numpy(), df_g_pose=grads[1].numpy())
+    for (name, prm), gr in zip(df.named_parameters(), grads[2:]):
+        out[f"df_w_{name}"] = prm.detach().numpy()
+        out[f"df_gw_{name}"] = gr.numpy()
+    np.savez(os.path.join(OUT, "field_cases.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_harness()
@@ -374,6 +429,8 @@ def main():
     gen_sh(sh_utils)
     import utils.loss_utils as loss_utils
     gen_losses(loss_utils)
+    import models.mlp as mlp_mod
+    gen_fields(mlp_mod)
     gen_lbs(smplman_mod)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
