@@ -1,0 +1,141 @@
+"""Field networks of the reference (models/mlp.py) on the MI355X matrix cores.
+
+Every field of the reference is the same trunk -- ``z -> [Linear(128) + leaky_relu(0.1)] x (1 + n_layers) -> Linear`` --
+with ``z = [pose.expand(P, -1) | per-row features]`` (models/mlp.py:58-69, 94-105).  Here
+  * the broadcast part of the first layer is folded into its bias once per call (``W0[:, :n_pose] @ pose + b0``: a
+    128-vector instead of 98 of the 109 input columns for every one of the P rows),
+  * every dense layer is one launch of ``d3ga_mlp_linear`` (exact-f32 MFMA, bias + leaky_relu fused; the backward's
+    ``dY (.) lrelu'(Y)`` is fused into the operand load of the input-gradient GEMM),
+  * weight gradients are plain library GEMMs (``dPre^T @ X`` through hipBLASLt).
+Modules keep the reference's parameter names (``network.{i}.weight/bias``, ``output.weight/bias``): state dicts
+interchange.  GPU tensors only.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from ._lib import check, dptr, require_cuda, stream_handle
+
+_panels = {}
+
+
+def _panel(weight, transpose):
+    """Zero-padded weight panel the kernel stages in LDS: (2*ceil(K/2), 32*ceil(N/32)) with panel[k][n] = weight of input k
+    for output n.  transpose=True: forward (weight is (N,K) as in nn.Linear); False: input-gradient GEMM (contracts over
+    the layer's outputs: panel[k=n_layer][n=k_layer] = weight[n_layer][k_layer]).  Cached per (storage, version)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()), transpose)
+    hit = _panels.get(key)
+    if hit is None:
+        if len(_panels) > 64:
+            _panels.clear()
+        w = weight.detach()
+        src = w.t() if transpose else w                      # (K, N) in the kernel's sense
+        K, N = src.shape
+        p = torch.zeros((2 * ((K + 1) // 2), 32 * ((N + 31) // 32)), dtype=torch.float32, device=w.device)
+        p[:K, :N] = src
+        hit = (p, weight)                                     # holds the weight alive: its address cannot be recycled
+        _panels[key] = hit
+    return hit[0]
+
+
+class _LinearAct(torch.autograd.Function):
+    """y = act(x @ weight.T + bias), act(y) = y if y > 0 else slope * y  (slope = 1: plain linear layer)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope):
+        require_cuda(x, weight)
+        x = x.float().contiguous()
+        P, K = x.shape
+        N = weight.shape[0]
+        if weight.shape[1] != K or K > 128 or N > 128:
+            raise ValueError(f"linear_act: x (P,{K}) weight {tuple(weight.shape)}: need matching K <= 128 and N <= 128")
+        y = torch.empty((P, N), dtype=torch.float32, device=x.device)
+        b = None if bias is None else bias.float().contiguous()
+        check(_lib.lib().d3ga_mlp_linear(P, K, N, dptr(x), None, 0.0, None, dptr(_panel(weight, True)), dptr(b),
+                                         float(slope), dptr(y), stream_handle()), "d3ga_mlp_linear")
+        ctx.slope = float(slope)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        P, K = x.shape
+        N = weight.shape[0]
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        masked = ctx.slope != 1.0
+        dpre = torch.empty_like(dy) if masked else dy          # dY (.) act'(y): operand of the weight-gradient GEMM
+        dx = None
+        if need_x or masked:
+            dx = torch.empty((P, K), dtype=torch.float32, device=x.device)
+            check(_lib.lib().d3ga_mlp_linear(P, N, K, dptr(dy), dptr(y) if masked else None, ctx.slope,
+                                             dptr(dpre) if masked else None, dptr(_panel(weight, False)), None, 1.0,
+                                             dptr(dx), stream_handle()), "d3ga_mlp_linear")
+        dw = dpre.t().mm(x) if need_w else None                # plain library GEMM (hipBLASLt): a reduction over all rows
+        db = dpre.sum(0) if need_b else None
+        return (dx if need_x else None), dw, db, None
+
+
+def linear_act(x, weight, bias=None, negative_slope=1.0):
+    """``leaky_relu(F.linear(x, weight, bias), negative_slope)`` in one launch (negative_slope=1: no activation)."""
+    return _LinearAct.apply(x, weight, bias, negative_slope)
+
+
+class FieldMLP(nn.Module):
+    """The trunk shared by the reference's fields (models/mlp.py:50-69): ``n_layers + 1`` hidden layers of ``n_nodes`` with
+    leaky_relu(0.1) and a linear head; kaiming-leaky init, head weights scaled by 0.33 (models/mlp.py:17-20,55-57)."""
+
+    def __init__(self, n_input, n_output, n_nodes=128, n_layers=3):
+        super().__init__()
+        self.network = nn.ModuleList([nn.Linear(n_input, n_nodes)] + [nn.Linear(n_nodes, n_nodes) for _ in range(n_layers)])
+        self.output = nn.Linear(n_nodes, n_output)
+        with torch.no_grad():
+            self.output.weight *= 0.33
+            for layer in self.network:
+                nn.init.kaiming_normal_(layer.weight, a=0.1, mode="fan_in", nonlinearity="leaky_relu")
+
+    def forward(self, row_feats, broadcast):
+        """z = [broadcast.expand(P, -1) | row_feats] (the reference's column order) -> (P, n_output)."""
+        first = self.network[0]
+        nb = broadcast.numel()
+        bias0 = F.linear(broadcast.reshape(1, nb), first.weight[:, :nb], first.bias)[0]      # folded pose columns
+        h = linear_act(row_feats, first.weight[:, nb:], bias0, 0.1)
+        for layer in list(self.network)[1:]:
+            h = linear_act(h, layer.weight, layer.bias, 0.1)
+        return linear_act(h, self.output.weight, self.output.bias, 1.0)
+
+
+class CanonicalField(FieldMLP):
+    """models/mlp.py:74-110.  forward(barys, rots, scales, pose) -> (tanh(.)*scale_bary (P,4), (P,4), (P,3)) with
+    z = [pose | rots | scales | barys]."""
+
+    def __init__(self, n_cond=98, n_nodes=128, n_layers=3, scale_bary=0.25, bary_size=4):
+        super().__init__(n_cond + 4 + 3 + bary_size, 4 + 3 + bary_size, n_nodes, n_layers)
+        self.scale_bary, self.bary_size = scale_bary, bary_size
+
+    def forward(self, barys, rots, scales, pose):
+        pred = super().forward(torch.cat([rots, scales, barys], dim=1), pose)
+        s = self.bary_size
+        return torch.tanh(pred[:, :s]) * self.scale_bary, pred[:, s:s + 4], pred[:, s + 4:]
+
+
+def embed(x, multires=7):
+    """utils/pos_encoder.py get_embedder(7): [x, sin(2^i x), cos(2^i x)] -> 45 columns."""
+    out = [x]
+    for i in range(multires):
+        out += [torch.sin(x * float(2 ** i)), torch.cos(x * float(2 ** i))]
+    return torch.cat(out, -1)
+
+
+class DeformationField(FieldMLP):
+    """models/mlp.py:39-71.  forward(canonical (V,3), pose) -> tanh(.) * scaling with z = [pose | embed_7(canonical)]."""
+
+    def __init__(self, n_cond=98, n_nodes=128, n_layers=3, scaling=0.2):
+        super().__init__(n_cond + 45, 3, n_nodes, n_layers)
+        self.scaling = scaling
+
+    def forward(self, canonical, pose):
+        return torch.tanh(super().forward(embed(canonical), pose)) * self.scaling

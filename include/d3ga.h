@@ -248,6 +248,19 @@ int d3ga_compute_bary(int P, int T, const float *points, const float *tetra_corn
  * point i to its 3 nearest other points.  points (P,3) -> out (P).  Exhaustive O(P^2). */
 int d3ga_knn3_mean_dist2(int P, const float *points, float *out, d3ga_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Field networks: the dense layer of models/mlp.py:39-110 -- every field is
+ * z -> [Linear(128) + leaky_relu(0.1)] x (1 + n_layers) -> Linear -- on the matrix cores in exact f32.
+ *   Y (P, n_out) = act_out( A (P,K) . Wt + bias ),  act_out(y) = y > 0 ? y : out_slope * y   (out_slope = 1: identity)
+ *   A = X, or, with mask != NULL, A = X (.) (mask > 0 ? 1 : mask_slope)  -- the leaky_relu backward applied to an
+ *   incoming gradient X = dY with mask = the layer's output; A is then also written to a_out (P,K) when non-NULL
+ *   (it is the operand of the weight-gradient GEMM dW = A^T . input).
+ *   Wt: (2*ceil(K/2), 32*ceil(n_out/32)) row-major, zero padded, Wt[k][n] = weight of input k for output n.
+ *   K <= 128, n_out <= 128; X, mask, a_out, Wt 16-byte aligned.  bias may be NULL.
+ * ------------------------------------------------------------------------------------------------------- */
+int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const float *mask, float mask_slope,
+                    float *a_out, const float *Wt, const float *bias, float out_slope, float *Y, d3ga_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

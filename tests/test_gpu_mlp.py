@@ -1,0 +1,62 @@
+"""Field networks (d3ga_amd/mlp.py, d3ga_mlp_linear) against goldens captured from the reference's own CanonicalField /
+DeformationField (models/mlp.py) and against the oracle at production row counts."""
+import numpy as np
+import pytest
+import torch
+
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _load(module, g, prefix):
+    sd = {k[len(prefix) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix + "_w_")}
+    module.load_state_dict(sd)            # the reference's own parameter names
+    return module.to(DEV)
+
+
+def test_fields_match_reference_goldens(golden):
+    from d3ga_amd.mlp import CanonicalField, DeformationField
+    g = golden("field_cases.npz")
+    leaf = lambda k: torch.from_numpy(g[k]).to(DEV).requires_grad_(True)
+    cf = _load(CanonicalField(), g, "cf")
+    barys, rots, scales, pose = leaf("cf_barys"), leaf("cf_rots"), leaf("cf_scales"), leaf("cf_pose")
+    outs = cf(rots, scales, barys, pose)           # the reference's argument-order quirk (cage_net.py:199-204)
+    for o, k in zip(outs, ("cf_d_bary", "cf_d_rot", "cf_d_scale")):
+        np.testing.assert_allclose(o.detach().cpu().numpy(), g[k], rtol=1e-4, atol=2e-6)
+    torch.autograd.backward(list(outs), [torch.from_numpy(g[f"cf_up{i}"]).to(DEV) for i in range(3)])
+    for t, k in ((barys, "cf_g_barys"), (rots, "cf_g_rots"), (scales, "cf_g_scales"), (pose, "cf_g_pose")):
+        assert rel_err(t.grad.cpu().numpy(), g[k]) < 1e-4, k
+    for name, prm in cf.named_parameters():
+        assert rel_err(prm.grad.cpu().numpy(), g[f"cf_gw_{name}"]) < 1e-4, name
+    df = _load(DeformationField(scaling=0.07), g, "df")
+    canon, pose = leaf("df_canon"), leaf("df_pose")
+    delta = df(canon, pose)
+    np.testing.assert_allclose(delta.detach().cpu().numpy(), g["df_delta"], rtol=1e-4, atol=1e-6)
+    delta.backward(torch.from_numpy(g["df_up"]).to(DEV))
+    assert rel_err(canon.grad.cpu().numpy(), g["df_g_canon"]) < 1e-3
+    assert rel_err(pose.grad.cpu().numpy(), g["df_g_pose"]) < 1e-4
+    for name, prm in df.named_parameters():
+        assert rel_err(prm.grad.cpu().numpy(), g[f"df_gw_{name}"]) < 1e-4, name
+
+
+@pytest.mark.parametrize("P,K,N,slope", [(1, 128, 128, 0.1), (127, 11, 128, 0.1), (1000, 128, 11, 1.0), (4099, 45, 128, 0.1),
+                                         (300, 128, 3, 1.0), (513, 64, 96, 0.1)])
+def test_linear_act_against_torch(P, K, N, slope):
+    """One layer, ragged row counts and every width class of the kernel, values and all three gradients."""
+    from d3ga_amd.mlp import linear_act
+    g = torch.Generator().manual_seed(P + K + N)
+    x = torch.randn(P, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    up = torch.randn(P, N, generator=g)
+    ref_in = [t.clone().double().requires_grad_(True) for t in (x, w, b)]
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.linear(*ref_in), slope)
+    ref.backward(up.double())
+    mine_in = [t.to(DEV).requires_grad_(True) for t in (x, w, b)]
+    y = linear_act(mine_in[0], mine_in[1], mine_in[2], slope)
+    y.backward(up.to(DEV))
+    assert rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) < 2e-6
+    for a, r in zip(mine_in, ref_in):
+        assert rel_err(a.grad.cpu().numpy(), r.grad.numpy()) < 5e-6
