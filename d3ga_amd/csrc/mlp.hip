@@ -7,101 +7,128 @@
 // with exact f32 arithmetic on the matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bitwise an fmaf chain;
 // 157 TFLOP/s peak on MI355X = the f32 vector peak, but no operand shuffling and no VALU slots spent on the products).
 //
-// Work decomposition: a workgroup (4 wavefronts) owns 128 rows, a wavefront 32 rows x all output columns
-// (NB blocks of 32).  The 32x32x2 instruction contracts two k per issue: lanes 0-31 supply k_a, lanes 32-63 k_b.  K is
-// split in two halves -- lanes 0-31 walk k = 0..KH-1, lanes 32-63 k = KH..2KH-1 -- so every lane reads ONE contiguous
-// run of its row (16-byte loads for K = 128) and keeps it in registers: the A operand never touches LDS.  The weight
-// panel Wt (2*KH x 32*NB, zero padded, prepared by the host layer) sits in LDS for the whole persistent workgroup;
-// lane l reads Wt[k(l)][ (l & 31) + 32 nb ]: 32 consecutive floats per half-wavefront, conflict free.
+// Work decomposition: a workgroup (8 wavefronts) owns 256 rows, a wavefront 32 rows x all output columns (NB blocks of
+// 32).  K is walked in chunks of 32: the wavefront moves its 32 x 32 chunk with full-segment loads into a private LDS
+// buffer (next chunk prefetched into registers), then lane l takes row l & 31 and, of the chunk, k = 16 (l >> 5) + s
+// (the 32x32x2 instruction contracts lanes 0-31's k with lanes 32-63's k, any pairing is a valid order of the sum).  The
+// weight panel Wt (32*ceil(K/32) x 32*NB, zero padded, prepared by the host layer) sits in LDS for the whole
+// persistent workgroup; lane l reads Wt[k(l)][(l & 31) + 32 nb]: 32 consecutive floats per half-wavefront.
 // Weight gradients (dW = dPre^T X, a reduction over all rows) are plain library GEMMs in the host layer (hipBLASLt).
 #include "d3ga_internal.h"
 
 namespace d3ga {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int kMlpRows = 128;        // rows per workgroup
-constexpr int kMlpMaxKH = 64;        // K <= 128
+constexpr int kMlpThreads = 1024;    // 16 wavefronts share one weight panel in LDS (138 KB: 4 wavefronts per SIMD)
+constexpr int kMlpRows = 512;        // rows per workgroup (32 per wavefront)
+constexpr int kMlpMaxK = 128;        // K <= 128
+constexpr int kMlpXPitch = 36;       // floats per row of a wavefront's 32 x 32 activation chunk in LDS (16-byte aligned rows)
 
-template <int NB>
-__global__ __launch_bounds__(256) void linear_kernel(int P, int K, int KH, int n_store, const float *__restrict__ X,
-                                                     const float *__restrict__ mask, float mask_slope,
-                                                     float *__restrict__ a_out, const float *__restrict__ Wt,
-                                                     const float *__restrict__ bias, float out_slope,
-                                                     float *__restrict__ Y) {
-    extern __shared__ __attribute__((aligned(16))) float s_w[];        // [2*KH][32*NB]
-    constexpr int N32 = 32 * NB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5, l32 = lane & 31;
-    {   // weight panel: contiguous copy, 16 bytes per thread and step
-        const int nvec = 2 * KH * N32 / 4;
-        for (int v = tid; v < nvec; v += 256) reinterpret_cast<float4 *>(s_w)[v] = reinterpret_cast<const float4 *>(Wt)[v];
-    }
-    __syncthreads();
-    const bool fast = (K == 2 * KH) && (KH % 4 == 0);                  // 16-byte loads of the lane's run (K = 128: KH = 64)
-    const int ntiles = (P + kMlpRows - 1) / kMlpRows;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int row0 = tile * kMlpRows + wave * 32;
-        const int row = row0 + l32;
-        const bool in = row < P;
-        float a[kMlpMaxKH];
-        const int k0 = half * KH;
-        if (fast) {
+// One K-chunk (32 columns) of a wavefront's 32 rows, global -> registers in the COOPERATIVE order: lane l covers the
+// 16 bytes (l & 7) of the 128-byte segment of row 8*j + (l >> 3), j = 0..3 -- every load instruction touches eight full
+// 128-byte segments.  (A lane reading its own row straight from global memory touches 64 different cache lines per
+// instruction and re-fetches every line 8 times from L2: measured 1.4 TB/s, the first version of this kernel.)
+template <bool VEC, bool MASK>
+__device__ __forceinline__ void chunk_load(float4 (&v)[4], int P, int K, int row0, int kc, int lane,
+                                           const float *__restrict__ X, const float *__restrict__ mask, float mask_slope,
+                                           float *__restrict__ a_out) {
 #pragma unroll
-            for (int j = 0; j < kMlpMaxKH / 4; ++j) {
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (in && 4 * j < KH) {
-                    const size_t o = (size_t)row * K + k0 + 4 * j;
+    for (int j = 0; j < 4; ++j) {
+        const int r = row0 + 8 * j + (lane >> 3), k = kc + 4 * (lane & 7);
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < P) {
+            const uint32_t o = (uint32_t)r * (uint32_t)K + (uint32_t)k;
+            if constexpr (VEC) {                                       // K % 4 == 0: rows are 16-byte aligned
+                if (k < K) {
                     x = *reinterpret_cast<const float4 *>(X + o);
-                    if (mask) {
+                    if constexpr (MASK) {
                         const float4 m = *reinterpret_cast<const float4 *>(mask + o);
                         x.x *= m.x > 0.f ? 1.f : mask_slope; x.y *= m.y > 0.f ? 1.f : mask_slope;
                         x.z *= m.z > 0.f ? 1.f : mask_slope; x.w *= m.w > 0.f ? 1.f : mask_slope;
                         if (a_out) *reinterpret_cast<float4 *>(a_out + o) = x;
                     }
                 }
-                a[4 * j] = x.x; a[4 * j + 1] = x.y; a[4 * j + 2] = x.z; a[4 * j + 3] = x.w;
-            }
-        } else {
+            } else {
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < kMlpMaxKH; ++s) {
-                float x = 0.f;
-                const int k = k0 + s;
-                if (in && s < KH && k < K) {
-                    const size_t o = (size_t)row * K + k;
-                    x = X[o];
-                    if (mask) {
-                        x *= mask[o] > 0.f ? 1.f : mask_slope;
-                        if (a_out) a_out[o] = x;
+                for (int c = 0; c < 4; ++c)
+                    if (k + c < K) {
+                        e[c] = X[o + c];
+                        if constexpr (MASK) {
+                            e[c] *= mask[o + c] > 0.f ? 1.f : mask_slope;
+                            if (a_out) a_out[o + c] = e[c];
+                        }
                     }
-                }
-                a[s] = x;
+                x = make_float4(e[0], e[1], e[2], e[3]);
             }
         }
+        v[j] = x;
+    }
+}
+
+template <int NB, bool VEC, bool MASK>
+__global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n_store, const float *__restrict__ X,
+                                                             const float *__restrict__ mask, float mask_slope,
+                                                             float *__restrict__ a_out, const float *__restrict__ Wt,
+                                                             const float *__restrict__ bias, float out_slope,
+                                                             float *__restrict__ Y) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];       // weight panel [KP][32*NB] | 8 x activation chunk
+    constexpr int N32 = 32 * NB;
+    const int KP = 32 * ((K + 31) / 32);                               // panel rows (K padded to the chunk size)
+    float *s_w = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *s_x = smem + KP * N32 + wave * (32 * kMlpXPitch);           // this wavefront's [32 rows][32 k] chunk, padded
+    const int half = lane >> 5, l32 = lane & 31;
+    {   // weight panel: contiguous copy, 16 bytes per thread and step
+        const int nvec = KP * N32 / 4;
+        for (int v = tid; v < nvec; v += kMlpThreads) reinterpret_cast<float4 *>(s_w)[v] = reinterpret_cast<const float4 *>(Wt)[v];
+    }
+    __syncthreads();
+    const int ntiles = (P + kMlpRows - 1) / kMlpRows;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * kMlpRows + wave * 32;
         f32x16 acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-        const float *wrow = s_w + (size_t)k0 * N32 + l32;
+        float4 nxt[4];
+        chunk_load<VEC, MASK>(nxt, P, K, row0, 0, lane, X, mask, mask_slope, a_out);
+        for (int kc = 0; kc < KP; kc += 32) {
+            __builtin_amdgcn_wave_barrier();                           // previous chunk's LDS reads are done
 #pragma unroll
-        for (int s = 0; s < kMlpMaxKH; ++s) {
-            if (s < KH) {                                              // wave-uniform
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4 *>(s_x + (8 * j + (lane >> 3)) * kMlpXPitch + 4 * (lane & 7)) = nxt[j];
+            if (kc + 32 < KP) chunk_load<VEC, MASK>(nxt, P, K, row0, kc + 32, lane, X, mask, mask_slope, a_out);   // prefetch
+            __builtin_amdgcn_wave_barrier();
+            // A operand: row l32, k = kc + 16*half + s  (the instruction contracts lanes 0-31's k with lanes 32-63's k)
+            float a[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 t = *reinterpret_cast<const float4 *>(s_x + l32 * kMlpXPitch + 16 * half + 4 * j);
+                a[4 * j] = t.x; a[4 * j + 1] = t.y; a[4 * j + 2] = t.z; a[4 * j + 3] = t.w;
+            }
+            const float *wrow = s_w + (kc + 16 * half) * N32 + l32;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wrow[s * N32 + 32 * nb], acc[nb], 0, 0, 0);
             }
         }
-        // epilogue: C/D layout of the 32x32 shapes: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        // epilogue: C/D layout of the 32x32 shapes: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5);
+        // every store instruction writes two full 128-byte row segments
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int n = l32 + 32 * nb;
             const float b = (bias && n < n_store) ? bias[n] : 0.f;
+            const uint32_t ybase = (uint32_t)(row0 + 4 * half) * (uint32_t)n_store + (uint32_t)n;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int dr = (r & 3) + 8 * (r >> 2);
                 float y = acc[nb][r] + b;
                 y = y > 0.f ? y : out_slope * y;
-                if (rr < P && n < n_store) Y[(size_t)rr * n_store + n] = y;
+                if (row0 + 4 * half + dr < P && n < n_store) Y[ybase + (uint32_t)dr * (uint32_t)n_store] = y;
             }
         }
     }
@@ -116,28 +143,38 @@ using namespace d3ga;
 extern "C" int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const float *mask, float mask_slope,
                                float *a_out, const float *Wt, const float *bias, float out_slope, float *Y,
                                d3ga_stream_t stream) {
-    if (P < 0 || K < 1 || K > 2 * kMlpMaxKH || n_out < 1 || n_out > 128) return D3GA_E_SIZE;
+    if (P < 0 || K < 1 || K > kMlpMaxK || n_out < 1 || n_out > 128) return D3GA_E_SIZE;
     if (P == 0) return D3GA_OK;
     if (!X || !Wt || !Y) return D3GA_E_NULL;
     if (a_out && !mask) return D3GA_E_CONFIG;
     if ((((uintptr_t)X | (uintptr_t)Wt | (uintptr_t)mask | (uintptr_t)a_out) & 15) != 0) return D3GA_E_CONFIG;
+    if ((int64_t)P * K >= (1ll << 31) || (int64_t)P * n_out >= (1ll << 31)) return D3GA_E_SIZE;      // 32-bit element offsets
     hipStream_t s = (hipStream_t)stream;
-    const int KH = (K + 1) / 2, NB = (n_out + 31) / 32;
-    const size_t lds = (size_t)2 * KH * 32 * NB * sizeof(float);
+    const int KP = 32 * ((K + 31) / 32), NB = (n_out + 31) / 32;
+    const size_t lds = ((size_t)KP * 32 * NB + (size_t)(kMlpThreads / 64) * 32 * kMlpXPitch) * sizeof(float);
     const int ntiles = (P + kMlpRows - 1) / kMlpRows;
-    const int grid = ntiles < 512 ? ntiles : 512;                     // persistent: the weight panel is staged once
-#define D3GA_MLP_LAUNCH(NBV)                                                                                          \
+    const int grid = ntiles < 256 ? ntiles : 256;                     // persistent: the weight panel is staged once
+    const bool vec = (K % 4) == 0;
+#define D3GA_MLP_LAUNCH2(NBV, VECV, MASKV)                                                                            \
     do {                                                                                                              \
         static bool attr[64] = {};                                                                                    \
         int dev = 0;                                                                                                  \
         D3GA_HIP(hipGetDevice(&dev));                                                                                 \
         if (dev >= 0 && dev < 64 && !attr[dev]) {                                                                     \
-            D3GA_HIP(hipFuncSetAttribute((const void *)linear_kernel<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         2 * kMlpMaxKH * 32 * NBV * (int)sizeof(float)));                             \
+            D3GA_HIP(hipFuncSetAttribute((const void *)linear_kernel<NBV, VECV, MASKV>,                               \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,                                  \
+                                         (kMlpMaxK * 32 * NBV + (kMlpThreads / 64) * 32 * kMlpXPitch) * (int)sizeof(float))); \
             attr[dev] = true;                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL(linear_kernel<NBV>, dim3(grid), dim3(256), lds, s, P, K, KH, n_out, X, mask, mask_slope,    \
-                           a_out, Wt, bias, out_slope, Y);                                                            \
+        hipLaunchKernelGGL((linear_kernel<NBV, VECV, MASKV>), dim3(grid), dim3(kMlpThreads), lds, s, P, K, n_out, X,    \
+                           mask, mask_slope, a_out, Wt, bias, out_slope, Y);                                          \
+    } while (0)
+#define D3GA_MLP_LAUNCH(NBV)                                                                                          \
+    do {                                                                                                              \
+        if (vec && mask) D3GA_MLP_LAUNCH2(NBV, true, true);                                                           \
+        else if (vec) D3GA_MLP_LAUNCH2(NBV, true, false);                                                             \
+        else if (mask) D3GA_MLP_LAUNCH2(NBV, false, true);                                                            \
+        else D3GA_MLP_LAUNCH2(NBV, false, false);                                                                     \
     } while (0)
     switch (NB) {
         case 1: D3GA_MLP_LAUNCH(1); break;
@@ -146,5 +183,6 @@ extern "C" int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float 
         default: D3GA_MLP_LAUNCH(4); break;
     }
 #undef D3GA_MLP_LAUNCH
+#undef D3GA_MLP_LAUNCH2
     return check_launch(s, 0);
 }

@@ -21,7 +21,7 @@ _panels = {}
 
 
 def _panel(weight, transpose):
-    """Zero-padded weight panel the kernel stages in LDS: (2*ceil(K/2), 32*ceil(N/32)) with panel[k][n] = weight of input k
+    """Zero-padded weight panel the kernel stages in LDS: (32*ceil(K/32), 32*ceil(N/32)) with panel[k][n] = weight of input k
     for output n.  transpose=True: forward (weight is (N,K) as in nn.Linear); False: input-gradient GEMM (contracts over
     the layer's outputs: panel[k=n_layer][n=k_layer] = weight[n_layer][k_layer]).  Cached per (storage, version)."""
     key = (weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()), transpose)
@@ -32,7 +32,7 @@ def _panel(weight, transpose):
         w = weight.detach()
         src = w.t() if transpose else w                      # (K, N) in the kernel's sense
         K, N = src.shape
-        p = torch.zeros((2 * ((K + 1) // 2), 32 * ((N + 31) // 32)), dtype=torch.float32, device=w.device)
+        p = torch.zeros((32 * ((K + 31) // 32), 32 * ((N + 31) // 32)), dtype=torch.float32, device=w.device)
         p[:K, :N] = src
         hit = (p, weight)                                     # holds the weight alive: its address cannot be recycled
         _panels[key] = hit
