@@ -45,6 +45,9 @@ def parse():
                     help="N>1 gradient exchange: 'cut' = summed at the rasterizer's inputs with the SH gradient in factored "
                          "form (dist.ViewShardedGrads); 'params' = one all-reduce per parameter tensor (dist.GradReducer)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the 2-render training-step variant")
+    ap.add_argument("--field-mlp", action="store_true",
+                    help="instead of the frame: the per-Gaussian CanonicalField network (SURVEY sec. 8f rank 1) forward + "
+                         "backward at the workload's Gaussian count, roofline against the f32 MFMA peak")
     ap.add_argument("--no-graph", action="store_true",
                     help="time eager launches instead of replaying the captured hipGraph of one step")
     return ap.parse_args()
@@ -229,8 +232,79 @@ def cpu_baseline(wl_name, budget_s=20.0):
             "deform_only_frames_per_s": round(1.0 / min(deform_times), 3)}
 
 
+def field_mlp_bench(args):
+    """CanonicalField (models/mlp.py:74-110, widths of configs/actorshq_actor02.yml) forward + backward to inputs and weights
+    over the workload's Gaussians: rows/s, achieved f32 MFMA rate, the same module under ATen on this GPU and the oracle on
+    the host cores."""
+    from d3ga_amd import synthetic as syn
+    from d3ga_amd.mlp import CanonicalField
+    from oracle import mlp as om
+    dev = torch.device("cuda", 0)
+    P = syn.WORKLOADS[args.workload].n_gaussians
+    torch.manual_seed(17)
+    cf = CanonicalField().to(dev)
+    g = torch.Generator().manual_seed(17)
+    barys = torch.rand(P, 4, generator=g).to(dev).requires_grad_(True)
+    rots = torch.randn(P, 4, generator=g).to(dev).requires_grad_(True)
+    scales = (0.1 * torch.randn(P, 3, generator=g)).to(dev).requires_grad_(True)
+    pose = (0.3 * torch.randn(98, generator=g)).to(dev)
+    leaves = list(cf.parameters()) + [barys, rots, scales]
+    hidden = [(l.weight, l.bias) for l in cf.network]
+
+    def step(fn):
+        for t in leaves:
+            t.grad = None
+        o = fn()
+        (o[0].sum() + o[1].sum() + o[2].sum()).backward()
+
+    fused = lambda: step(lambda: cf(rots, scales, barys, pose))
+    aten = lambda: step(lambda: om.canonical_field(rots, scales, barys, pose, hidden, cf.output.weight, cf.output.bias))
+
+    def timed(fn, n):
+        for _ in range(max(args.warmup, 3)):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    ms = timed(fused, args.steps)
+    ms_aten = timed(aten, max(5, args.steps // 4))
+    flops = 3 * 2.0 * P * (11 * 128 + 3 * 128 * 128 + 128 * 11)         # forward + input-gradient + weight-gradient GEMMs
+    out = {"metric": f"CanonicalField fwd+bwd rows/sec ({P} Gaussians, 109->128x4->11, f32)", "value": round(P / (ms * 1e-3), 1),
+           "unit": "rows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"CanonicalField over the Gaussians of {args.workload}", "rows": P},
+           "roofline": {"kernel": "linear_kernel + wgrad_kernel", "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2),
+                        "peak": 157.3, "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / 157.3, 4), "traffic": None},
+           "same_gpu_aten_ms": round(ms_aten, 4)}
+    if not args.no_cpu_baseline:
+        n = min(P, 50_000)
+        cpu = lambda t: t.detach()[:n].cpu().requires_grad_(True)
+        cb, cr, cs, cp = cpu(barys), cpu(rots), cpu(scales), pose.cpu()
+        ch = [(w.detach().cpu().requires_grad_(True), b.detach().cpu().requires_grad_(True)) for w, b in hidden]
+        cow, cob = cf.output.weight.detach().cpu().requires_grad_(True), cf.output.bias.detach().cpu().requires_grad_(True)
+        cores = min(os.cpu_count() or 1, 32)
+        torch.set_num_threads(cores)
+        best = 1e9
+        for _ in range(5):
+            t0 = time.time()
+            o = om.canonical_field(cr, cs, cb, cp, ch, cow, cob)
+            (o[0].sum() + o[1].sum() + o[2].sum()).backward()
+            best = min(best, time.time() - t0)
+        out["cpu_baseline"] = {"value": round(n / best, 1), "unit": "rows/s", "cores": cores, "kind": "port",
+                               "sample": f"{n} rows, oracle/mlp.py (torch CPU), best of 5"}
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.field_mlp:
+        return field_mlp_bench(args)
     from d3ga_amd import dist as ddist
     if args.single_device:
         os.environ["LOCAL_RANK"] = "0"

@@ -134,6 +134,56 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
     }
 }
 
+// Weight gradient dW (N,K) += dPre^T (N x rows) . X (rows x K): the contraction runs over the ROWS, so both MFMA operands
+// are read straight from global memory in their natural row-major layout -- lane l supplies dPre[row][32 nb + (l & 31)] and
+// X[row][32 kb + (l & 31)] for row = r + (l >> 5): two full 128-byte segments per load instruction.  A workgroup owns a
+// contiguous row range, one wavefront per 32x32 block of dW (NBn x NBk wavefronts); partial results meet in global memory
+// through float atomics (dW zeroed by the launcher).  The kb == 0 wavefronts also accumulate the bias gradient.
+__global__ __launch_bounds__(1024) void wgrad_kernel(int P, int N, int K, int NBk, int rows_per_block,
+                                                     const float *__restrict__ dpre, const float *__restrict__ X,
+                                                     float *__restrict__ dW, float *__restrict__ db) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb = wave / NBk, kb = wave - nb * NBk;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int n = 32 * nb + l32, k = 32 * kb + l32;
+    const bool n_ok = n < N, k_ok = k < K;
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int r_end = min(P, r_begin + rows_per_block);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    const float *pa = dpre + (uint32_t)n, *pb = X + (uint32_t)k;
+    const int trips = (r_end - r_begin + 1) / 2;                       // both lane halves run the same trip count
+    for (int t0 = 0; t0 < trips; t0 += 8) {                            // eight row pairs per round: loads first, then MFMAs
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r_begin + 2 * (t0 + u) + half;
+            const bool ok = (t0 + u < trips) && r < r_end;
+            a[u] = (ok && n_ok) ? pa[(uint32_t)r * (uint32_t)N] : 0.f;
+            b[u] = (ok && k_ok) ? pb[(uint32_t)r * (uint32_t)K] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            bsum += a[u];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+        }
+    }
+    // C/D layout: col = lane & 31 -> k, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> n
+    if (k_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nn = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (nn < N) atomicAdd(dW + (uint32_t)nn * (uint32_t)K + (uint32_t)k, acc[r]);
+        }
+    }
+    if (db && kb == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (half == 0 && n_ok) atomicAdd(db + n, bsum);
+    }
+}
+
 }  // namespace d3ga
 
 using namespace d3ga;
@@ -184,5 +234,26 @@ extern "C" int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float 
     }
 #undef D3GA_MLP_LAUNCH
 #undef D3GA_MLP_LAUNCH2
+    return check_launch(s, 0);
+}
+
+// dW (N,K) = dPre^T . X and (optionally) db (N) = column sums of dPre; both outputs are zeroed by the call.
+extern "C" int d3ga_mlp_wgrad(int32_t P, int32_t N, int32_t K, const float *dpre, const float *X, float *dW, float *db,
+                              d3ga_stream_t stream) {
+    if (P < 0 || N < 1 || N > 128 || K < 1 || K > 128) return D3GA_E_SIZE;
+    if (!dW) return D3GA_E_NULL;
+    if ((int64_t)P * N >= (1ll << 31) || (int64_t)P * K >= (1ll << 31)) return D3GA_E_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    D3GA_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, s));
+    if (db) D3GA_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, s));
+    if (P == 0) return D3GA_OK;
+    if (!dpre || !X) return D3GA_E_NULL;
+    const int NBn = (N + 31) / 32, NBk = (K + 31) / 32;
+    int grid = 512;                                                   // row ranges; every workgroup ends with N*K atomics
+    int rows = (P + grid - 1) / grid;
+    rows = (rows + 1) & ~1;                                            // even: the two lane halves take alternate rows
+    if (rows < 64) rows = 64;
+    grid = (P + rows - 1) / rows;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(64 * NBn * NBk), 0, s, P, N, K, NBk, rows, dpre, X, dW, db);
     return check_launch(s, 0);
 }

@@ -6,7 +6,8 @@ with ``z = [pose.expand(P, -1) | per-row features]`` (models/mlp.py:58-69, 94-10
     128-vector instead of 98 of the 109 input columns for every one of the P rows),
   * every dense layer is one launch of ``d3ga_mlp_linear`` (exact-f32 MFMA, bias + leaky_relu fused; the backward's
     ``dY (.) lrelu'(Y)`` is fused into the operand load of the input-gradient GEMM),
-  * weight gradients are plain library GEMMs (``dPre^T @ X`` through hipBLASLt).
+  * weight and bias gradients (``dPre^T @ X``, a reduction over all rows) come from ``d3ga_mlp_wgrad``, which feeds both
+    MFMA operands straight from their row-major global layout.
 Modules keep the reference's parameter names (``network.{i}.weight/bias``, ``output.weight/bias``): state dicts
 interchange.  GPU tensors only.
 """
@@ -74,9 +75,13 @@ class _LinearAct(torch.autograd.Function):
             check(_lib.lib().d3ga_mlp_linear(P, N, K, dptr(dy), dptr(y) if masked else None, ctx.slope,
                                              dptr(dpre) if masked else None, dptr(_panel(weight, False)), None, 1.0,
                                              dptr(dx), stream_handle()), "d3ga_mlp_linear")
-        dw = dpre.t().mm(x) if need_w else None                # plain library GEMM (hipBLASLt): a reduction over all rows
-        db = dpre.sum(0) if need_b else None
-        return (dx if need_x else None), dw, db, None
+        dw = db = None
+        if need_w or need_b:                                   # dW = dPre^T X (a reduction over all rows), db = column sums
+            dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+            db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_b else None
+            check(_lib.lib().d3ga_mlp_wgrad(P, N, K, dptr(dpre), dptr(x), dptr(dw), dptr(db), stream_handle()),
+                  "d3ga_mlp_wgrad")
+        return (dx if need_x else None), (dw if need_w else None), db, None
 
 
 def linear_act(x, weight, bias=None, negative_slope=1.0):

@@ -260,6 +260,11 @@ int d3ga_knn3_mean_dist2(int P, const float *points, float *out, d3ga_stream_t s
  * ------------------------------------------------------------------------------------------------------- */
 int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const float *mask, float mask_slope,
                     float *a_out, const float *Wt, const float *bias, float out_slope, float *Y, d3ga_stream_t stream);
+/* Weight and bias gradient of that layer: dW (N,K) = dPre^T . X, db (N) = column sums of dPre (db may be NULL);
+ * dPre (P,N) = the a_out of the input-gradient call (or dY itself for a layer without activation), X (P,K) the layer's
+ * input.  Both outputs are zeroed by the call; partial sums meet through float atomics. */
+int d3ga_mlp_wgrad(int32_t P, int32_t N, int32_t K, const float *dpre, const float *X, float *dW, float *db,
+                   d3ga_stream_t stream);
 
 #ifdef __cplusplus
 }
