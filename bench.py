@@ -103,10 +103,11 @@ class Frame:
         return loss
 
 
-    def train_step(self):
+    def train_step(self, with_fields=False):
         """The reference's training step renders twice (models/trainer.py:102-110): RGB, then a silhouette pass with a
         constant per-Gaussian colour on a black background; losses as in train.py:190-193 (L1 + SSIM on RGB, L1 on the
-        silhouette)."""
+        silhouette).  with_fields: the cage-vertex offsets and the per-Gaussian (delta_bary, delta_rot, delta_scale) come
+        from the DeformationField / CanonicalField networks as in models/cage_net.py:197-215 instead of free parameters."""
         from d3ga_amd.cage_deform import cage_deform, lbs_cage
         from d3ga_amd.losses import l1_loss, l1_ssim
         from d3ga_amd.renderer import render
@@ -116,9 +117,26 @@ class Frame:
             self.sil_rgb = torch.ones(P, 3, device=self.bg.device)
             self.sil_target = (self.target.mean(0, keepdim=True) > 0.5).float().expand(3, -1, -1).contiguous()
             self.bg0 = torch.zeros_like(self.bg)
-        tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
-        means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad, p["scaling"],
-                                  p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp")
+        if with_fields:
+            if not hasattr(self, "canon_field"):
+                from d3ga_amd.mlp import CanonicalField, DeformationField
+                torch.manual_seed(17)
+                dev = self.bg.device
+                self.canon_field, self.deform_field = CanonicalField().to(dev), DeformationField(scaling=0.07).to(dev)
+                self.pose = 0.3 * torch.randn(98, device=dev)
+                self.field_params = list(self.canon_field.parameters()) + list(self.deform_field.parameters())
+            for q in self.field_params:
+                q.grad = None
+            delta_node = self.deform_field(self.canon, self.pose)                                  # cage_net.py:197
+            d_bary, d_rot, d_scale = self.canon_field(p["rotation"], p["scaling"], self.barys0, self.pose)   # :199-204
+            tetpoints = lbs_cage(self.canon, delta_node, self.joint_mats, self.skin_idx, self.skin_w)
+            means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad,
+                                      p["scaling"] + d_scale, p["rotation"] + d_rot, delta_barys=d_bary,
+                                      scale_activation="exp")                                      # :213-230
+        else:
+            tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
+            means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad, p["scaling"],
+                                      p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp")
         pkg = {"means3D": means, "cov3D_precomp": cov6, "opacities": torch.sigmoid(p["opacity"]),
                "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
         img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
@@ -421,6 +439,17 @@ def main():
                  "launch_mode": "eager",
                  "ms_per_step": round(1e3 * (time.perf_counter() - t1) / n_ts, 4)}
         train["steps_per_s"] = round(1e3 / train["ms_per_step"], 2)
+        # the same step with the field networks in front of the deform (models/cage_net.py:197-215)
+        for _ in range(3):
+            flat.zero()
+            frame.train_step(with_fields=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_ts):
+            flat.zero()
+            frame.train_step(with_fields=True)
+        torch.cuda.synchronize()
+        train["with_field_networks_ms_per_step"] = round(1e3 * (time.perf_counter() - t1) / n_ts, 4)
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
