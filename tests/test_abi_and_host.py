@@ -149,3 +149,29 @@ def test_tetra_container_and_medit_reader(tmp_path):
     x = cage.points[cage.tetras]
     J = cage.gradient(x @ R.T) @ torch.linalg.inv(cage.gradient(x))
     np.testing.assert_allclose(J.numpy(), R[None].expand_as(J).numpy(), atol=1e-5)
+
+
+def test_checkpoint_layout_round_trip(tmp_path):
+    """chkpntNNNNNN.pth holds ((model_sd, optim_sd, sched_sd), iteration) (models/trainer.py:194-209); restore picks the last
+    file or the requested iteration (trainer.py:145-178); parameter names are the reference's (network.{i}, output)."""
+    import torch
+    from d3ga_amd import checkpoint as ck
+    from d3ga_amd.mlp import CanonicalField
+    m = CanonicalField()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sch = torch.optim.lr_scheduler.ExponentialLR(opt, 0.9)
+    run = str(tmp_path)
+    assert ck.load_checkpoint(run, m) == 0
+    p1 = ck.save_checkpoint(run, 20000, m, opt, sch)
+    assert p1.endswith("checkpoints/chkpnt020000.pth")
+    with torch.no_grad():
+        m.output.bias.add_(1.0)
+    ck.save_checkpoint(run, 40000, m, opt, sch)
+    raw = torch.load(p1, weights_only=False)
+    assert isinstance(raw, tuple) and raw[1] == 20000 and len(raw[0]) == 3
+    assert set(raw[0][0]) == {f"network.{i}.{k}" for i in range(4) for k in ("weight", "bias")} | {"output.weight", "output.bias"}
+    m2 = CanonicalField()
+    assert ck.load_checkpoint(run, m2) == 40000
+    assert torch.equal(m2.output.bias, m.output.bias)
+    assert ck.load_checkpoint(run, m2, iteration=20000) == 20000
+    assert torch.allclose(m2.output.bias + 1.0, m.output.bias)
