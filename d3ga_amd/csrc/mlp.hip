@@ -85,6 +85,9 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
     }
     __syncthreads();
     const int ntiles = (P + kMlpRows - 1) / kMlpRows;
+    float4 nxt[4];
+    if ((int)blockIdx.x < ntiles)
+        chunk_load<VEC, MASK>(nxt, P, K, blockIdx.x * kMlpRows + wave * 32, 0, lane, X, mask, mask_slope, a_out);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * kMlpRows + wave * 32;
         f32x16 acc[NB];
@@ -92,14 +95,17 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-        float4 nxt[4];
-        chunk_load<VEC, MASK>(nxt, P, K, row0, 0, lane, X, mask, mask_slope, a_out);
         for (int kc = 0; kc < KP; kc += 32) {
             __builtin_amdgcn_wave_barrier();                           // previous chunk's LDS reads are done
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<float4 *>(s_x + (8 * j + (lane >> 3)) * kMlpXPitch + 4 * (lane & 7)) = nxt[j];
-            if (kc + 32 < KP) chunk_load<VEC, MASK>(nxt, P, K, row0, kc + 32, lane, X, mask, mask_slope, a_out);   // prefetch
+            // prefetch: the next chunk of this tile, or -- BEFORE this tile's epilogue stores are issued (loads and stores
+            // share the in-order vmcnt counter: a load issued after 64 stores cannot be waited for without draining them)
+            // -- the first chunk of the workgroup's next tile
+            if (kc + 32 < KP) chunk_load<VEC, MASK>(nxt, P, K, row0, kc + 32, lane, X, mask, mask_slope, a_out);
+            else if (tile + (int)gridDim.x < ntiles)
+                chunk_load<VEC, MASK>(nxt, P, K, row0 + (int)gridDim.x * kMlpRows, 0, lane, X, mask, mask_slope, a_out);
             __builtin_amdgcn_wave_barrier();
             // A operand: row l32, k = kc + 16*half + s  (the instruction contracts lanes 0-31's k with lanes 32-63's k)
             float a[16];
