@@ -12,7 +12,8 @@
 // buffer (next chunk prefetched into registers), then lane l takes row l & 31 and, of the chunk, k = 16 (l >> 5) + s
 // (the 32x32x2 instruction contracts lanes 0-31's k with lanes 32-63's k, any pairing is a valid order of the sum).  The
 // weight panel Wt (32*ceil(K/32) x 32*NB, zero padded, prepared by the host layer) sits in LDS for the whole
-// persistent workgroup; lane l reads Wt[k(l)][(l & 31) + 32 nb]: 32 consecutive floats per half-wavefront.
+// persistent workgroup in the interleaved order [k][n & 31][n >> 5]: the NB operands a lane needs for one k-step are
+// one 16-byte LDS read.
 // Weight gradients (dW = dPre^T X, a reduction over all rows) are plain library GEMMs in the host layer (hipBLASLt).
 #include "d3ga_internal.h"
 
@@ -34,7 +35,11 @@ __device__ __forceinline__ void chunk_load(float4 (&v)[4], int P, int K, int row
                                            float *__restrict__ a_out) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int r = row0 + 8 * j + (lane >> 3), k = kc + 4 * (lane & 7);
+        int r = row0 + 8 * j + (lane >> 3);
+        const int k = kc + 4 * (lane & 7);
+#ifdef D3GA_DIAG
+        if (mask_slope == -12345.f) r &= 511;            // diagnostic: every tile re-reads the first 512 rows (L2 resident)
+#endif
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < P) {
             const uint32_t o = (uint32_t)r * (uint32_t)K + (uint32_t)k;
@@ -114,12 +119,24 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
                 const float4 t = *reinterpret_cast<const float4 *>(s_x + l32 * kMlpXPitch + 16 * half + 4 * j);
                 a[4 * j] = t.x; a[4 * j + 1] = t.y; a[4 * j + 2] = t.z; a[4 * j + 3] = t.w;
             }
-            const float *wrow = s_w + (kc + 16 * half) * N32 + l32;
+            // panel layout [k][l32][nb]: the NB operands of one k-step are contiguous for a lane (one 16-byte LDS read)
+            const float *wrow = s_w + ((kc + 16 * half) * 32 + l32) * NB;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
+                float bv[NB];
+                if constexpr (NB == 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(wrow + s * N32);
+                    bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+                } else if constexpr (NB == 2) {
+                    const float2 t = *reinterpret_cast<const float2 *>(wrow + s * N32);
+                    bv[0] = t.x; bv[1] = t.y;
+                } else {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) bv[nb] = wrow[s * N32 + nb];
+                }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wrow[s * N32 + 32 * nb], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bv[nb], acc[nb], 0, 0, 0);
             }
         }
         // epilogue: C/D layout of the 32x32 shapes: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5);

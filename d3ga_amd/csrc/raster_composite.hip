@@ -1019,7 +1019,7 @@ extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const fl
     if (composite_variant() & 512) {
         hipLaunchKernelGGL(composite_bwd_rows3_kernel, dim3(2 * quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
                            gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
-                           im.final_T, im.n_contrib, dL_dpix, acc);
+                           im.final_T, im.n_contrib, dL_dpix, acc, (const uint32_t *)nullptr);
         return check_launch(s, prm->debug);
     }
 #endif

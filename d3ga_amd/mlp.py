@@ -33,8 +33,10 @@ def _panel(weight, transpose):
         w = weight.detach()
         src = w.t() if transpose else w                      # (K, N) in the kernel's sense
         K, N = src.shape
-        p = torch.zeros((32 * ((K + 31) // 32), 32 * ((N + 31) // 32)), dtype=torch.float32, device=w.device)
+        KP, NB = 32 * ((K + 31) // 32), (N + 31) // 32
+        p = torch.zeros((KP, 32 * NB), dtype=torch.float32, device=w.device)
         p[:K, :N] = src
+        p = p.view(KP, NB, 32).transpose(1, 2).contiguous()          # [k][n & 31][n >> 5]: a lane's NB operands contiguous
         hit = (p, weight)                                     # holds the weight alive: its address cannot be recycled
         _panels[key] = hit
     return hit[0]

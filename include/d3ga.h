@@ -255,7 +255,8 @@ int d3ga_knn3_mean_dist2(int P, const float *points, float *out, d3ga_stream_t s
  *   A = X, or, with mask != NULL, A = X (.) (mask > 0 ? 1 : mask_slope)  -- the leaky_relu backward applied to an
  *   incoming gradient X = dY with mask = the layer's output; A is then also written to a_out (P,K) when non-NULL
  *   (it is the operand of the weight-gradient GEMM dW = A^T . input).
- *   Wt: (32*ceil(K/32), 32*ceil(n_out/32)) row-major, zero padded, Wt[k][n] = weight of input k for output n.
+ *   Wt: zero-padded panel of KP = 32*ceil(K/32) rows and NB = ceil(n_out/32) column blocks in the interleaved order
+ *   Wt[(k*32 + (n & 31))*NB + (n >> 5)] = weight of input k for output n.
  *   K <= 128, n_out <= 128; X, mask, a_out, Wt 16-byte aligned.  bias may be NULL.
  * ------------------------------------------------------------------------------------------------------- */
 int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const float *mask, float mask_slope,

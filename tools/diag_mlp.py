@@ -7,10 +7,10 @@ P = 500_000
 x = torch.randn(P, 128, device="cuda"); w = torch.randn(128, 128, device="cuda") / 11; b = torch.randn(128, device="cuda")
 y = torch.empty(P, 128, device="cuda")
 L = _lib.lib()
-panel = _panel(w, True)
-def run(n_out, rows=P):
+panel = _panel(w, True)   # interleaved layout prepared by the host layer
+def run(n_out, rows=P, slope=0.0):
     # n_out = 97..128 keeps NB = 4 but stores only columns < n_out
-    return L.d3ga_mlp_linear(rows, 128, n_out, dptr(x), None, 0.0, None, dptr(panel), dptr(b), 0.1, dptr(y), stream_handle())
+    return L.d3ga_mlp_linear(rows, 128, n_out, dptr(x), None, slope, None, dptr(panel), dptr(b), 0.1, dptr(y), stream_handle())
 def t(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -23,3 +23,4 @@ print("full 128 cols stored      ms", t(lambda: run(128)))
 print("97 cols stored (NB=4)     ms", t(lambda: run(97)))
 for rows in (131072, 262144, 500000):
     print(rows, "rows ms", t(lambda: run(128, rows)))
+print("reads folded onto 512 rows (needs D3GA_DIAG build) ms", t(lambda: run(128, P, -12345.0)))
