@@ -344,7 +344,7 @@ def main():
         frame.grad_sync = ddist.ViewShardedGrads()        # gradients leave the rasterizer already averaged over the ranks
 
     def reduce_params():
-        if not cut:
+        if not cut and world > 1:
             flat.all_reduce_mean()
 
     def one_step():
@@ -358,6 +358,16 @@ def main():
         torch.cuda.synchronize()
 
     # warm-up (auto capacity: learns the duplicate count), then freeze the capacity: no host sync inside a frame
+    exchange_note = None
+    if cut:
+        try:                                   # first exchange: if the backend rejects a collective of the cut exchange,
+            one_step()                         # fall back to the per-parameter all-reduce instead of losing the run
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            exchange_note = f"cut exchange failed ({type(e).__name__}: {e}); fell back to per-parameter all-reduce"
+            print(f"[bench] rank {rank}: {exchange_note}", file=sys.stderr)
+            cut = False
+            frame.grad_sync = None
     for _ in range(max(args.warmup, 2)):
         one_step()
     torch.cuda.synchronize()
@@ -512,6 +522,7 @@ def main():
             "roofline": roof, "kernels": kernels,
             "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 4),
             "launch_mode": "hipGraph replay of one captured step" if graph is not None else "eager",
+            **({"grad_exchange_note": exchange_note} if exchange_note else {}),
             "stage_events": "separate eager pass, same K steps" if graph is not None else "none" if args.no_stage_events else "separate eager pass",
         }
         if train is not None:
