@@ -29,8 +29,8 @@
 namespace d3ga {
 
 // D3GA_COMPOSITE_VARIANT (A/B knob, tools/gpu_ab.sh): bit 0 fwd LDS slab, bit 1 bwd LDS slab (64-lane kernels); bit 2 fwd
-// row-segmented, bit 3 bwd row-segmented, bit 4 (with 3) bwd third generation (composite_bwd_rows3_kernel), bit 5 work-
-// ordered dispatch of the row-segmented kernels (tile_order).
+// row-segmented, bit 3 bwd row-segmented (composite_bwd_rows3_kernel; bit 4 is unused since the second generation was
+// removed), bit 5 work-ordered dispatch of the row-segmented kernels (tile_order).
 constexpr int kDefaultCompositeVariant = 63;  // measured at C3: fwd 248 -> 133 us, bwd 508 -> 376 (rows) -> 337 us (rows3)
 
 // ---- wavefront (64 lanes) reductions through DPP ----
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Backward, third generation of the row-segmented kernel.  Same work decomposition as composite_bwd_rows_kernel; what
+// Backward, third generation of the row-segmented kernel.  Same work decomposition as the forward above; what
 // changed is the instruction stream of the inner loop (the kernel is VALU-issue bound):
 //  * RAW MOMENTS: with w = o*G*dL/dalpha the five geometric gradients are linear in  S = sum w*{dx, dy, dx^2, dx*dy,
 //    dy^2}; the per-entry constants (conic, -1/2, the NDC scale) are applied ONCE per entry when the batch accumulator
@@ -795,139 +795,6 @@ __global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
 #endif
 }
 
-__global__ __launch_bounds__(64) void composite_bwd_rows_kernel(
-    int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
-    uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
-    const float4 *__restrict__ rgb_invd, const float *__restrict__ bg, const float *__restrict__ final_T,
-    const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix, float *__restrict__ acc) {
-    const Quad q = quad_of_block(gx, gy);
-    if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
-    const int lane = threadIdx.x & 63;
-    const RowGeom rg = row_geom(q, lane);
-    const bool inside = rg.px < W && rg.py < H;
-    const float fx = (float)rg.px, fy = (float)rg.py;
-    const float bx0 = (float)q.qx0, by0 = (float)q.qy0;
-    const uint32_t begin = (uint32_t)min((uint64_t)tile_start[q.tile], dcap);
-    const uint32_t end = (uint32_t)min((uint64_t)tile_start[q.tile + 1], dcap);
-    if (begin >= end) return;                              // uniform: empty tile
-
-    const size_t pid = (size_t)rg.py * W + rg.px;
-    const size_t hw = (size_t)H * W;
-    const float T_final = inside ? final_T[pid] : 0.f;
-    const uint32_t last = inside ? n_contrib[pid] : 0u;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (inside) { g0 = dL_dpix[pid]; g1 = dL_dpix[hw + pid]; g2 = dL_dpix[2 * hw + pid]; }
-    const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
-    const uint32_t rowlast = row_max_u32(last);            // deepest position used inside this lane's 4x4 block
-    const uint32_t maxlast = wave_max_u32(rowlast);
-    if (maxlast == 0) return;
-    // every lane needs all four row limits for the per-block tests of ITS staged entry
-    const uint32_t rl0 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 0), rl1 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 16);
-    const uint32_t rl2 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 32), rl3 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 48);
-
-    __shared__ float2 s_xy[64];
-    __shared__ float4 s_co[64];
-    __shared__ float4 s_rgb[64];
-    __shared__ uint32_t s_id[64];
-    __shared__ uint8_t s_list[4][64];
-
-    float T = T_final;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-    const int l16 = lane & 15;
-    const int slot_off = l16 < 2 ? l16 : l16 + 1;          // lanes 0..8 of each row publish value l16; acc layout 0,1|3,4,5|6|7,8,9
-
-    float2 nxy = make_float2(0.f, 0.f);
-    float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t nid = 0;
-    if ((uint32_t)lane < maxlast) {
-        nid = point_list[begin + (maxlast - 1 - lane)];
-        nxy = xy[nid]; nco = conic_o[nid]; nrgb = rgb_invd[nid];
-    }
-    for (uint32_t hi = maxlast; hi > 0; hi = hi > 64 ? hi - 64 : 0) {
-        const float2 cxy = nxy;
-        const float4 cco = nco, crgb = nrgb;
-        const uint32_t cid = nid;
-        const bool have = (uint32_t)lane < hi;
-        if (hi > 64 && (uint32_t)lane < hi - 64) {
-            nid = point_list[begin + (hi - 64 - 1 - lane)];
-            nxy = xy[nid]; nco = conic_o[nid]; nrgb = rgb_invd[nid];
-        }
-        float hx, hy;
-        splat_extent(cco.x, cco.y, cco.z, cco.w, hx, hy);
-        if (!have) hx = -1.0f;
-        const uint32_t mypos = hi - (uint32_t)lane;        // list position of the entry this lane staged
-        __builtin_amdgcn_wave_barrier();
-        s_xy[lane] = cxy; s_co[lane] = cco; s_rgb[lane] = crgb; s_id[lane] = cid;
-        int trip;
-        const int my_cnt = build_row_lists(
-            s_list, mypos <= rl0 && block_hit(cxy.x, cxy.y, hx, hy, bx0, by0, 3.0f),
-            mypos <= rl1 && block_hit(cxy.x, cxy.y, hx, hy, bx0 + 4.0f, by0, 3.0f),
-            mypos <= rl2 && block_hit(cxy.x, cxy.y, hx, hy, bx0, by0 + 4.0f, 3.0f),
-            mypos <= rl3 && block_hit(cxy.x, cxy.y, hx, hy, bx0 + 4.0f, by0 + 4.0f, 3.0f), lane, rg.row, trip);
-        __builtin_amdgcn_wave_barrier();
-        for (int i = 0; i < trip; ++i) {
-            const bool valid = i < my_cnt;
-            const int j = s_list[rg.row][i] & 63;          // ascending staged lane = back-to-front (& 63: stale slots)
-            const uint32_t pos = hi - (uint32_t)j;
-            const float2 exy = s_xy[j];
-            const float4 eco = s_co[j];
-            const float dx = exy.x - fx, dy = exy.y - fy;
-            float al, G;
-            bool ok;
-            splat_eval(dx, dy, eco.x, eco.y, eco.z, eco.w, al, G, ok);
-            const bool hit = ok && valid && inside && pos <= last;
-            const unsigned long long hm = __ballot(hit);
-            if (hm == 0) continue;                         // wave-uniform skip
-            const float4 ergb = s_rgb[j];
-            const uint32_t gid = s_id[j];
-            // NOTE: keep this body in the kernel (no helper functions / lambdas over v[]): hipcc then turns the
-            // lane-indexed select below into a scratch-memory table lookup.  A divergent `if (hit)` block beats
-            // computing masked partials for every lane (measured 376 vs 410 us at C3).
-            float v[kNG];
-#pragma unroll
-            for (int k = 0; k < kNG; ++k) v[k] = 0.f;
-            if (hit) {
-                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - al);
-                T = T * inv1ma;
-                const float dch = al * T;
-                a0 = last_alpha * lc0 + (1.f - last_alpha) * a0;
-                a1 = last_alpha * lc1 + (1.f - last_alpha) * a1;
-                a2 = last_alpha * lc2 + (1.f - last_alpha) * a2;
-                lc0 = ergb.x; lc1 = ergb.y; lc2 = ergb.z;
-                float dL_dalpha = ((ergb.x - a0) * g0 + (ergb.y - a1) * g1 + (ergb.z - a2) * g2) * T;
-                last_alpha = al;
-                dL_dalpha += (-T_final * inv1ma) * bg_dot;
-                const float dL_dG = eco.w * dL_dalpha;     // the 0.99 clamp passes the gradient through
-                const float gdx = G * dx, gdy = G * dy;
-                v[0] = dL_dG * (-gdx * eco.x - gdy * eco.y) * ddelx_dx;
-                v[1] = dL_dG * (-gdy * eco.z - gdx * eco.y) * ddely_dy;
-                v[2] = -0.5f * gdx * dx * dL_dG;
-                v[3] = -0.5f * gdx * dy * dL_dG;            // half of dL/dB, doubled in the per-Gaussian backward
-                v[4] = -0.5f * gdy * dy * dL_dG;
-                v[5] = G * dL_dalpha;
-                v[6] = dch * g0; v[7] = dch * g1; v[8] = dch * g2;
-            }
-            // row-local reduction: every lane of a row ends up with the row's nine totals
-#pragma unroll
-            for (int k = 0; k < kNG; ++k) v[k] = dpp_add<0xB1, 0xf>(v[k]);
-#pragma unroll
-            for (int k = 0; k < kNG; ++k) v[k] = dpp_add<0x4E, 0xf>(v[k]);
-#pragma unroll
-            for (int k = 0; k < kNG; ++k) v[k] = dpp_add<0x141, 0xf>(v[k]);
-#pragma unroll
-            for (int k = 0; k < kNG; ++k) v[k] = dpp_add<0x140, 0xf>(v[k]);
-            float mine = v[0];
-#pragma unroll
-            for (int k = 1; k < kNG; ++k) mine = (l16 == k) ? v[k] : mine;
-            const bool row_any = ((hm >> (rg.row << 4)) & 0xffffull) != 0;
-            // lanes 0..8 of every row that was hit: one atomic instruction, up to 36 active lanes
-            if (l16 < kNG && row_any) atomicAdd(acc + 12 * (size_t)gid + slot_off, mine);
-        }
-    }
-}
-
 // self-test kernel for the cross-lane reductions (tests/).  Per wave w with inputs x[0..63]:
 //   out[10 w + k] = sum_l (k+1) x[l] + k   for k = 0..8, through wave_reduce9 and the lane mapping the backward uses;
 //   out[10 w + 9] = sum_l x[l]              through wave_sum / wave_sum_multi (or -1e30 if those two disagree).
@@ -1023,17 +890,13 @@ extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const fl
         return check_launch(s, prm->debug);
     }
 #endif
-    if ((composite_variant() & 24) == 24) {
+    if (composite_variant() & 8) {
         const bool ordered = (composite_variant() & 32) != 0;
         hipLaunchKernelGGL(composite_bwd_rows3_kernel, dim3(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy)),
                            dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity,
                            g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc,
                            ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr);
     }
-    else if (composite_variant() & 8)
-        hipLaunchKernelGGL(composite_bwd_rows_kernel, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
-                           gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
-                           im.final_T, im.n_contrib, dL_dpix, acc);
     else if (composite_variant() & 2)
         hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
                            bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
