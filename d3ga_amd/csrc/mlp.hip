@@ -29,49 +29,69 @@ constexpr int kMlpXPitch = 36;       // floats per row of a wavefront's 32 x 32 
 // 16 bytes (l & 7) of the 128-byte segment of row 8*j + (l >> 3), j = 0..3 -- every load instruction touches eight full
 // 128-byte segments.  (A lane reading its own row straight from global memory touches 64 different cache lines per
 // instruction and re-fetches every line 8 times from L2: measured 1.4 TB/s, the first version of this kernel.)
+// chunk_issue only ISSUES the loads (raw values into registers, addresses clamped to stay in range): nothing may consume
+// them here -- a select or the mask multiply right after the load makes the compiler wait for HBM on the spot and the
+// "prefetch" degenerates into a blocking load (measured: launch time = MFMA time + HBM time).  chunk_commit, called one
+// chunk later, applies the leaky_relu mask, zeroes what lies past the matrix, writes the masked operand back (a_out) and
+// stores the chunk into the wavefront's LDS buffer.
 template <bool VEC, bool MASK>
-__device__ __forceinline__ void chunk_load(float4 (&v)[4], int P, int K, int row0, int kc, int lane,
-                                           const float *__restrict__ X, const float *__restrict__ mask, float mask_slope,
-                                           float *__restrict__ a_out) {
+__device__ __forceinline__ void chunk_issue(float4 (&v)[4], float4 (&m)[4], int P, int K, int row0, int kc, int lane,
+                                            const float *__restrict__ X, const float *__restrict__ mask) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        int r = row0 + 8 * j + (lane >> 3);
-        const int k = kc + 4 * (lane & 7);
-#ifdef D3GA_DIAG
-        if (mask_slope == -12345.f) r &= 511;            // diagnostic: every tile re-reads the first 512 rows (L2 resident)
-#endif
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < P) {
-            const uint32_t o = (uint32_t)r * (uint32_t)K + (uint32_t)k;
-            if constexpr (VEC) {                                       // K % 4 == 0: rows are 16-byte aligned
-                if (k < K) {
-                    x = *reinterpret_cast<const float4 *>(X + o);
-                    if constexpr (MASK) {
-                        const float4 m = *reinterpret_cast<const float4 *>(mask + o);
-                        x.x *= m.x > 0.f ? 1.f : mask_slope; x.y *= m.y > 0.f ? 1.f : mask_slope;
-                        x.z *= m.z > 0.f ? 1.f : mask_slope; x.w *= m.w > 0.f ? 1.f : mask_slope;
-                        if (a_out) *reinterpret_cast<float4 *>(a_out + o) = x;
-                    }
-                }
-            } else {
-                float e[4] = {0.f, 0.f, 0.f, 0.f};
+        const int r = row0 + 8 * j + (lane >> 3), k = kc + 4 * (lane & 7);
+        const int rc = r < P ? r : P - 1;
+        if constexpr (VEC) {                                           // K % 4 == 0: rows are 16-byte aligned
+            const uint32_t o = (uint32_t)rc * (uint32_t)K + (uint32_t)(k < K ? k : 0);
+            v[j] = *reinterpret_cast<const float4 *>(X + o);
+            if constexpr (MASK) m[j] = *reinterpret_cast<const float4 *>(mask + o);
+        } else {
+            float e[4], f[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (k + c < K) {
-                        e[c] = X[o + c];
-                        if constexpr (MASK) {
-                            e[c] *= mask[o + c] > 0.f ? 1.f : mask_slope;
-                            if (a_out) a_out[o + c] = e[c];
-                        }
-                    }
-                x = make_float4(e[0], e[1], e[2], e[3]);
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t o = (uint32_t)rc * (uint32_t)K + (uint32_t)(k + c < K ? k + c : 0);
+                e[c] = X[o];
+                if constexpr (MASK) f[c] = mask[o];
             }
+            v[j] = make_float4(e[0], e[1], e[2], e[3]);
+            if constexpr (MASK) m[j] = make_float4(f[0], f[1], f[2], f[3]);
         }
-        v[j] = x;
     }
 }
 
-template <int NB, bool VEC, bool MASK>
+template <bool VEC, bool MASK, bool RAGGED>
+__device__ __forceinline__ void chunk_commit(float *s_x, float4 (&v)[4], float4 (&m)[4], int P, int K, int row0, int kc,
+                                             int lane, float mask_slope, float *__restrict__ a_out) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = row0 + 8 * j + (lane >> 3), k = kc + 4 * (lane & 7);
+        float4 x = v[j];
+        if constexpr (MASK) {
+            x.x *= m[j].x > 0.f ? 1.f : mask_slope; x.y *= m[j].y > 0.f ? 1.f : mask_slope;
+            x.z *= m[j].z > 0.f ? 1.f : mask_slope; x.w *= m[j].w > 0.f ? 1.f : mask_slope;
+        }
+        const bool ok_r = RAGGED ? r < P : true;                       // !RAGGED: the launcher guarantees P % 32 == 0
+        if (!(ok_r && k < K)) x.x = 0.f;
+        if (!(ok_r && k + 1 < K)) x.y = 0.f;
+        if (!(ok_r && k + 2 < K)) x.z = 0.f;
+        if (!(ok_r && k + 3 < K)) x.w = 0.f;
+        if constexpr (MASK) {
+            if (a_out && ok_r) {
+                const uint32_t o = (uint32_t)r * (uint32_t)K + (uint32_t)k;
+                if (VEC) { if (k < K) *reinterpret_cast<float4 *>(a_out + o) = x; }
+                else {
+                    if (k < K) a_out[o] = x.x;
+                    if (k + 1 < K) a_out[o + 1] = x.y;
+                    if (k + 2 < K) a_out[o + 2] = x.z;
+                    if (k + 3 < K) a_out[o + 3] = x.w;
+                }
+            }
+        }
+        *reinterpret_cast<float4 *>(s_x + (8 * j + (lane >> 3)) * kMlpXPitch + 4 * (lane & 7)) = x;
+    }
+}
+
+template <int NB, bool VEC, bool MASK, bool RAGGED>
 __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n_store, const float *__restrict__ X,
                                                              const float *__restrict__ mask, float mask_slope,
                                                              float *__restrict__ a_out, const float *__restrict__ Wt,
@@ -90,11 +110,18 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
     }
     __syncthreads();
     const int ntiles = (P + kMlpRows - 1) / kMlpRows;
-    float4 nxt[4];
-    if ((int)blockIdx.x < ntiles)
-        chunk_load<VEC, MASK>(nxt, P, K, blockIdx.x * kMlpRows + wave * 32, 0, lane, X, mask, mask_slope, a_out);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // this lane's bias values, once (a global load inside the epilogue would force a vmcnt(0) in front of the stores)
+    float bias_r[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bias_r[nb] = (bias && l32 + 32 * nb < n_store) ? bias[l32 + 32 * nb] : 0.f;
+    float4 nxt[4], nxm[4];
+    chunk_issue<VEC, MASK>(nxt, nxm, P, K, blockIdx.x * kMlpRows + wave * 32, 0, lane, X, mask);
+    // The tile body is instantiated twice -- once for the workgroup's first tile, once inside the steady-state loop -- so
+    // that every path into the loop header has the same shape "prefetch load, then this tile's epilogue stores": the
+    // compiler can then wait for the prefetched chunk with an exact vmcnt(N) instead of draining the stores (vmcnt(0)).
+    auto do_tile = [&](int tile) __attribute__((always_inline)) {
         const int row0 = tile * kMlpRows + wave * 32;
+        if (!RAGGED && row0 >= P) return;                              // wave-uniform: the last tile may be partly empty
         f32x16 acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -102,15 +129,14 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
         for (int kc = 0; kc < KP; kc += 32) {
             __builtin_amdgcn_wave_barrier();                           // previous chunk's LDS reads are done
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<float4 *>(s_x + (8 * j + (lane >> 3)) * kMlpXPitch + 4 * (lane & 7)) = nxt[j];
-            // prefetch: the next chunk of this tile, or -- BEFORE this tile's epilogue stores are issued (loads and stores
-            // share the in-order vmcnt counter: a load issued after 64 stores cannot be waited for without draining them)
-            // -- the first chunk of the workgroup's next tile
-            if (kc + 32 < KP) chunk_load<VEC, MASK>(nxt, P, K, row0, kc + 32, lane, X, mask, mask_slope, a_out);
-            else if (tile + (int)gridDim.x < ntiles)
-                chunk_load<VEC, MASK>(nxt, P, K, row0 + (int)gridDim.x * kMlpRows, 0, lane, X, mask, mask_slope, a_out);
+            chunk_commit<VEC, MASK, RAGGED>(s_x, nxt, nxm, P, K, row0, kc, lane, mask_slope, a_out);
+            // prefetch (always exactly one chunk_issue, no branch): the next chunk of this tile, or -- BEFORE this tile's
+            // epilogue stores are issued -- the first chunk of the workgroup's next tile (past the last tile: clamped rows)
+            {
+                const bool same = kc + 32 < KP;
+                chunk_issue<VEC, MASK>(nxt, nxm, P, K, same ? row0 : row0 + (int)gridDim.x * kMlpRows, same ? kc + 32 : 0,
+                                       lane, X, mask);
+            }
             __builtin_amdgcn_wave_barrier();
             // A operand: row l32, k = kc + 16*half + s  (the instruction contracts lanes 0-31's k with lanes 32-63's k)
             float a[16];
@@ -141,20 +167,33 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
         }
         // epilogue: C/D layout of the 32x32 shapes: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5);
         // every store instruction writes two full 128-byte row segments
+        constexpr bool full = !RAGGED;                                 // launcher: P % 32 == 0 and n_store == 32*NB
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int n = l32 + 32 * nb;
-            const float b = (bias && n < n_store) ? bias[n] : 0.f;
+            const float b = bias_r[nb];
             const uint32_t ybase = (uint32_t)(row0 + 4 * half) * (uint32_t)n_store + (uint32_t)n;
+            if constexpr (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dr = (r & 3) + 8 * (r >> 2);
-                float y = acc[nb][r] + b;
-                y = y > 0.f ? y : out_slope * y;
-                if (row0 + 4 * half + dr < P && n < n_store) Y[ybase + (uint32_t)dr * (uint32_t)n_store] = y;
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    float y = acc[nb][r] + b;
+                    y = y > 0.f ? y : out_slope * y;
+                    Y[ybase + (uint32_t)dr * (uint32_t)n_store] = y;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    float y = acc[nb][r] + b;
+                    y = y > 0.f ? y : out_slope * y;
+                    if (row0 + 4 * half + dr < P && n < n_store) Y[ybase + (uint32_t)dr * (uint32_t)n_store] = y;
+                }
             }
         }
-    }
+    };
+    if ((int)blockIdx.x < ntiles) do_tile((int)blockIdx.x);
+    for (int tile = (int)blockIdx.x + (int)gridDim.x; tile < ntiles; tile += gridDim.x) do_tile(tile);
 }
 
 // Weight gradient dW (N,K) += dPre^T (N x rows) . X (rows x K): the contraction runs over the ROWS, so both MFMA operands
@@ -225,22 +264,33 @@ extern "C" int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float 
     hipStream_t s = (hipStream_t)stream;
     const int KP = 32 * ((K + 31) / 32), NB = (n_out + 31) / 32;
     const size_t lds = ((size_t)KP * 32 * NB + (size_t)(kMlpThreads / 64) * 32 * kMlpXPitch) * sizeof(float);
-    const int ntiles = (P + kMlpRows - 1) / kMlpRows;
-    const int grid = ntiles < 256 ? ntiles : 256;                     // persistent: the weight panel is staged once
     const bool vec = (K % 4) == 0;
-#define D3GA_MLP_LAUNCH2(NBV, VECV, MASKV)                                                                            \
+#define D3GA_MLP_LAUNCH3(NBV, VECV, MASKV, RAGV, PV, XV, MV, AV, YV)                                                  \
     do {                                                                                                              \
         static bool attr[64] = {};                                                                                    \
         int dev = 0;                                                                                                  \
         D3GA_HIP(hipGetDevice(&dev));                                                                                 \
         if (dev >= 0 && dev < 64 && !attr[dev]) {                                                                     \
-            D3GA_HIP(hipFuncSetAttribute((const void *)linear_kernel<NBV, VECV, MASKV>,                               \
+            D3GA_HIP(hipFuncSetAttribute((const void *)linear_kernel<NBV, VECV, MASKV, RAGV>,                         \
                                          hipFuncAttributeMaxDynamicSharedMemorySize,                                  \
                                          (kMlpMaxK * 32 * NBV + (kMlpThreads / 64) * 32 * kMlpXPitch) * (int)sizeof(float))); \
             attr[dev] = true;                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((linear_kernel<NBV, VECV, MASKV>), dim3(grid), dim3(kMlpThreads), lds, s, P, K, n_out, X,    \
-                           mask, mask_slope, a_out, Wt, bias, out_slope, Y);                                          \
+        const int nt = ((PV) + kMlpRows - 1) / kMlpRows;                                                              \
+        hipLaunchKernelGGL((linear_kernel<NBV, VECV, MASKV, RAGV>), dim3(nt < 256 ? nt : 256), dim3(kMlpThreads), lds, \
+                           s, (PV), K, n_out, (XV), (MV), mask_slope, (AV), Wt, bias, out_slope, (YV));               \
+    } while (0)
+    // rows [0, P_full): no bounds checks at all (straight-line loads and stores); the ragged remainder (< 32 rows), or
+    // everything when n_out is not a multiple of 32, goes through the bounds-checked instantiation
+    const int P_full = (n_out % 32 == 0) ? P - P % 32 : 0;
+    const int P_rest = P - P_full;
+    const size_t xo = (size_t)P_full * K, yo = (size_t)P_full * n_out;
+#define D3GA_MLP_LAUNCH2(NBV, VECV, MASKV)                                                                            \
+    do {                                                                                                              \
+        if (P_full > 0) D3GA_MLP_LAUNCH3(NBV, VECV, MASKV, false, P_full, X, mask, a_out, Y);                         \
+        if (P_rest > 0)                                                                                               \
+            D3GA_MLP_LAUNCH3(NBV, VECV, MASKV, true, P_rest, X + xo, mask ? mask + xo : nullptr,                      \
+                             a_out ? a_out + xo : nullptr, Y + yo);                                                   \
     } while (0)
 #define D3GA_MLP_LAUNCH(NBV)                                                                                          \
     do {                                                                                                              \
@@ -257,6 +307,7 @@ extern "C" int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float 
     }
 #undef D3GA_MLP_LAUNCH
 #undef D3GA_MLP_LAUNCH2
+#undef D3GA_MLP_LAUNCH3
     return check_launch(s, 0);
 }
 
