@@ -116,9 +116,6 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
     for (int nb = 0; nb < NB; ++nb) bias_r[nb] = (bias && l32 + 32 * nb < n_store) ? bias[l32 + 32 * nb] : 0.f;
     float4 nxt[4], nxm[4];
     chunk_issue<VEC, MASK>(nxt, nxm, P, K, blockIdx.x * kMlpRows + wave * 32, 0, lane, X, mask);
-    // The tile body is instantiated twice -- once for the workgroup's first tile, once inside the steady-state loop -- so
-    // that every path into the loop header has the same shape "prefetch load, then this tile's epilogue stores": the
-    // compiler can then wait for the prefetched chunk with an exact vmcnt(N) instead of draining the stores (vmcnt(0)).
     auto do_tile = [&](int tile) __attribute__((always_inline)) {
         const int row0 = tile * kMlpRows + wave * 32;
         if (!RAGGED && row0 >= P) return;                              // wave-uniform: the last tile may be partly empty
@@ -192,8 +189,7 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
             }
         }
     };
-    if ((int)blockIdx.x < ntiles) do_tile((int)blockIdx.x);
-    for (int tile = (int)blockIdx.x + (int)gridDim.x; tile < ntiles; tile += gridDim.x) do_tile(tile);
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += gridDim.x) do_tile(tile);
 }
 
 // Weight gradient dW (N,K) += dPre^T (N x rows) . X (rows x K): the contraction runs over the ROWS, so both MFMA operands
