@@ -62,28 +62,73 @@ __global__ __launch_bounds__(kBlock) void l1_mean_bwd_kernel(int64_t n4, int64_t
 // ---------------------------------------------------------------------------------------------------------
 // SSIM.  ssim_map = (2 mu1 mu2 + C1)(2 s12 + C2) / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2)) with mu = w*x, s1 = w*x^2 - mu1^2,
 // s12 = w*xy - mu1 mu2 and w the 11x11 window gaussian(11, 1.5) (x) gaussian(11, 1.5) (utils/loss_utils.py:46-57),
-// zero padding of 5 (F.conv2d(..., padding=window_size // 2)).  The window is separable: a workgroup owns a 16x16
-// output tile of one channel, stages the (16+10)^2 halo of both images in LDS, convolves the five maps
+// zero padding of 5 (F.conv2d(..., padding=window_size // 2)).  The window is separable: a workgroup owns a 16x32
+// output tile of one channel, stages the (16+10)x(32+10) halo of both images in LDS, convolves the five maps
 // (x, y, x^2, y^2, xy) horizontally into LDS and vertically into registers.  The forward also stores the three
 // partial derivatives the backward needs (d ssim / d(w*x), d(w*x^2), d(w*xy)); the backward convolves those three maps
 // with the same (symmetric) window:  dL/dx = w*Dm + 2 x (w*Dq1) + y (w*Dq12).
 // HBM traffic per pixel and channel: forward 8 B read + 12 B written, backward 20 B read + 4 B written.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kSsimTile = 16, kSsimHalo = 5, kSsimIn = kSsimTile + 2 * kSsimHalo;     // 26
+constexpr int kSsimTW = 16, kSsimTH = 32, kSsimHalo = 5;               // output tile 16 wide x 32 high per workgroup
+constexpr int kSsimInW = kSsimTW + 2 * kSsimHalo, kSsimInH = kSsimTH + 2 * kSsimHalo;   // 26 x 42 input halo
+constexpr int kSsimXP = 28;                                            // floats per input row in LDS (16-byte aligned rows)
+constexpr int kSsimHP = 44;                                            // floats per COLUMN of the transposed horizontal result
+using f2 = __attribute__((ext_vector_type(2))) float;                  // two pixels per lane: v_pk_fma_f32 / v_pk_mul_f32
 __device__ __constant__ float c_ssim_w[11] = {1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f,
                                               2.130055279e-01f, 2.660117149e-01f, 2.130055279e-01f, 1.093606874e-01f,
                                               3.600077331e-02f, 7.598758209e-03f, 1.028380124e-03f};
 constexpr float kSsimC1 = 0.01f * 0.01f, kSsimC2 = 0.03f * 0.03f;
+
+// Register tiling.  The first version gave every thread one output pixel and read every tap from LDS (90 ds_read_b32 per
+// pixel): the LDS pipe, not the VALU, was the limit.  Now
+//   horizontal pass: one thread = FOUR adjacent outputs of a row: 16 input floats per image come in with four 16-byte LDS
+//                    reads, the products x^2, y^2, xy are formed once per input, the taps run on registers; the
+//                    results are written TRANSPOSED (s_h[map][column][row]);
+//   vertical pass:   one thread = TWO vertically adjacent outputs of a column: 12 consecutive rows per map = six 8-byte
+//                    LDS reads, both outputs accumulated as one 2-vector (packed f32 instructions).
+// LDS instructions per output pixel: 0.45 instead of 3.
+
+// 11-tap window over 14 consecutive samples -> 4 outputs (o = 0..3 uses samples o..o+10)
+__device__ __forceinline__ void taps4(const float (&v)[16], const float (&w)[11], float (&o)[4]) {
+    f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const f2 wk = {w[k], w[k]};
+        a01 += wk * (f2){v[k], v[k + 1]};
+        a23 += wk * (f2){v[k + 2], v[k + 3]};
+    }
+    o[0] = a01.x; o[1] = a01.y; o[2] = a23.x; o[3] = a23.y;
+}
+__device__ __forceinline__ void load16(const float *row, float (&v)[16]) {      // row: 16-byte aligned
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 t = reinterpret_cast<const float4 *>(row)[j];
+        v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+    }
+}
+// two vertically adjacent outputs (rows r, r+1; r even) of one column: samples r..r+11 of the transposed map
+__device__ __forceinline__ f2 vtaps2(const float *col, int r, const float (&w)[11]) {
+    float v[12];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float2 t = reinterpret_cast<const float2 *>(col + r)[j];
+        v[2 * j] = t.x; v[2 * j + 1] = t.y;
+    }
+    f2 a = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 11; ++k) a += (f2){w[k], w[k]} * (f2){v[k], v[k + 1]};
+    return a;
+}
 
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(int C, int H, int W, int tiles_x, int tiles_y,
                                                        const float *__restrict__ img1, const float *__restrict__ img2,
                                                        float inv_n, float *__restrict__ out, float *__restrict__ Dm,
                                                        float *__restrict__ Dq1, float *__restrict__ Dq12,
                                                        float *__restrict__ out_l1) {
-    __shared__ float s_x[kSsimIn][kSsimIn + 1], s_y[kSsimIn][kSsimIn + 1];
-    __shared__ float s_h[5][kSsimIn][kSsimTile + 1];
+    __shared__ __attribute__((aligned(16))) float s_x[kSsimInH][kSsimXP], s_y[kSsimInH][kSsimXP];
+    __shared__ __attribute__((aligned(16))) float s_h[5][kSsimTW][kSsimHP];
     __shared__ float s_part[8];
-    const int tid = threadIdx.x, px = tid & 15, py = tid >> 4;
+    const int tid = threadIdx.x;
     const int ntiles = C * tiles_x * tiles_y;
     float w[11];
 #pragma unroll
@@ -94,50 +139,69 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int C, int H, int W, int 
         const int ty = r / tiles_x, tx = r - ty * tiles_x;
         const float *p1 = img1 + (size_t)c * H * W, *p2 = img2 + (size_t)c * H * W;
         __syncthreads();                                   // previous tile's LDS reads are done
-        for (int idx = tid; idx < kSsimIn * kSsimIn; idx += 256) {
-            const int rr = idx / kSsimIn, cc = idx - rr * kSsimIn;
-            const int gy = ty * kSsimTile + rr - kSsimHalo, gx = tx * kSsimTile + cc - kSsimHalo;
-            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        for (int idx = tid; idx < kSsimInH * kSsimXP; idx += 256) {         // (the two pad columns are zero-filled too)
+            const int rr = idx / kSsimXP, cc = idx - rr * kSsimXP;
+            const int gy = ty * kSsimTH + rr - kSsimHalo, gx = tx * kSsimTW + cc - kSsimHalo;
+            const bool in = cc < kSsimInW && gy >= 0 && gy < H && gx >= 0 && gx < W;
             s_x[rr][cc] = in ? p1[(size_t)gy * W + gx] : 0.f;
             s_y[rr][cc] = in ? p2[(size_t)gy * W + gx] : 0.f;
         }
         __syncthreads();
-        for (int idx = tid; idx < kSsimIn * kSsimTile; idx += 256) {        // horizontal pass
-            const int rr = idx >> 4, cx = idx & 15;
-            float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+        if (tid < kSsimInH * (kSsimTW / 4)) {              // horizontal pass: 42 rows x 4 column quads
+            const int rr = tid >> 2, c0 = 4 * (tid & 3);
+            float x[16], y[16], p[16], o[4];
+            load16(&s_x[rr][c0], x);
+            load16(&s_y[rr][c0], y);
+            taps4(x, w, o);
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float x = s_x[rr][cx + k], y = s_y[rr][cx + k], wk = w[k];
-                a += wk * x; b += wk * y; aa += wk * x * x; bb += wk * y * y; ab += wk * x * y;
-            }
-            s_h[0][rr][cx] = a; s_h[1][rr][cx] = b; s_h[2][rr][cx] = aa; s_h[3][rr][cx] = bb; s_h[4][rr][cx] = ab;
+            for (int q = 0; q < 4; ++q) s_h[0][c0 + q][rr] = o[q];
+            taps4(y, w, o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_h[1][c0 + q][rr] = o[q];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = x[i] * x[i];
+            taps4(p, w, o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_h[2][c0 + q][rr] = o[q];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = y[i] * y[i];
+            taps4(p, w, o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_h[3][c0 + q][rr] = o[q];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = x[i] * y[i];
+            taps4(p, w, o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_h[4][c0 + q][rr] = o[q];
         }
         __syncthreads();
-        float mu1 = 0.f, mu2 = 0.f, q1 = 0.f, q2 = 0.f, q12 = 0.f;           // vertical pass
+        // vertical pass: thread = column px, output rows py2 and py2 + 1
+        const int px = tid & 15, py2 = 2 * (tid >> 4);
+        const f2 mu1 = vtaps2(s_h[0][px], py2, w), mu2 = vtaps2(s_h[1][px], py2, w);
+        const f2 q1 = vtaps2(s_h[2][px], py2, w), q2 = vtaps2(s_h[3][px], py2, w), q12 = vtaps2(s_h[4][px], py2, w);
+        const f2 s1 = q1 - mu1 * mu1, s2 = q2 - mu2 * mu2, s12 = q12 - mu1 * mu2;
+        const f2 A = 2.f * mu1 * mu2 + kSsimC1, B = 2.f * s12 + kSsimC2;
+        const f2 Dd = mu1 * mu1 + mu2 * mu2 + kSsimC1, E = s1 + s2 + kSsimC2;
+        const f2 iD = {1.0f / Dd.x, 1.0f / Dd.y}, iE = {1.0f / E.x, 1.0f / E.y};
+        const f2 val = A * B * iD * iE;
+        // partials w.r.t. the five convolved maps (s1, s12 depend on mu1 through -mu1^2, -mu1 mu2)
+        const f2 d_s1 = -val * iE;                                          // d/d s1   (= d/d q1)
+        const f2 d_s12 = 2.f * A * iD * iE;                                 // d/d s12  (= d/d q12)
+        const f2 d_mu1 = 2.f * mu2 * B * iD * iE - 2.f * mu1 * val * iD;
+        const f2 dm = d_mu1 - 2.f * mu1 * d_s1 - mu2 * d_s12;
+        const int gx = tx * kSsimTW + px;
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float wk = w[k];
-            mu1 += wk * s_h[0][py + k][px]; mu2 += wk * s_h[1][py + k][px]; q1 += wk * s_h[2][py + k][px];
-            q2 += wk * s_h[3][py + k][px]; q12 += wk * s_h[4][py + k][px];
-        }
-        const int gy = ty * kSsimTile + py, gx = tx * kSsimTile + px;
-        if (gy < H && gx < W) {
-            const float s1 = q1 - mu1 * mu1, s2 = q2 - mu2 * mu2, s12 = q12 - mu1 * mu2;
-            const float A = 2.f * mu1 * mu2 + kSsimC1, B = 2.f * s12 + kSsimC2;
-            const float Dd = mu1 * mu1 + mu2 * mu2 + kSsimC1, E = s1 + s2 + kSsimC2;
-            const float iD = 1.0f / Dd, iE = 1.0f / E;
-            const float val = A * B * iD * iE;
-            local += val;
-            local_l1 += fabsf(s_x[py + kSsimHalo][px + kSsimHalo] - s_y[py + kSsimHalo][px + kSsimHalo]);   // fused L1
-            if (Dm) {
-                // partials w.r.t. the five convolved maps (s1, s12 depend on mu1 through -mu1^2, -mu1 mu2)
-                const float d_s1 = -val * iE;                              // d/d s1   (= d/d q1)
-                const float d_s12 = 2.f * A * iD * iE;                     // d/d s12  (= d/d q12)
-                const float d_mu1 = 2.f * mu2 * B * iD * iE - 2.f * mu1 * val * iD;
-                const size_t o = (size_t)c * H * W + (size_t)gy * W + gx;
-                Dm[o] = d_mu1 - 2.f * mu1 * d_s1 - mu2 * d_s12;
-                Dq1[o] = d_s1;
-                Dq12[o] = d_s12;
+        for (int h = 0; h < 2; ++h) {
+            const int gy = ty * kSsimTH + py2 + h;
+            if (gy < H && gx < W) {
+                local += h ? val.y : val.x;
+                local_l1 += fabsf(s_x[py2 + h + kSsimHalo][px + kSsimHalo] - s_y[py2 + h + kSsimHalo][px + kSsimHalo]);   // fused L1
+                if (Dm) {
+                    const size_t o = (size_t)c * H * W + (size_t)gy * W + gx;
+                    Dm[o] = h ? dm.y : dm.x;
+                    Dq1[o] = h ? d_s1.y : d_s1.x;
+                    Dq12[o] = h ? d_s12.y : d_s12.x;
+                }
             }
         }
     }
@@ -157,9 +221,9 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int C, int H, int W, int 
                                                        const float *__restrict__ Dq12, const float *__restrict__ g,
                                                        const float *__restrict__ g_l1, float inv_n,
                                                        float *__restrict__ grad1) {
-    __shared__ float s_in[3][kSsimIn][kSsimIn + 1];
-    __shared__ float s_h[3][kSsimIn][kSsimTile + 1];
-    const int tid = threadIdx.x, px = tid & 15, py = tid >> 4;
+    __shared__ __attribute__((aligned(16))) float s_in[3][kSsimInH][kSsimXP];
+    __shared__ __attribute__((aligned(16))) float s_h[3][kSsimTW][kSsimHP];
+    const int tid = threadIdx.x;
     const int ntiles = C * tiles_x * tiles_y;
     const float scale = g[0] * inv_n;
     const float scale_l1 = g_l1 ? g_l1[0] * inv_n : 0.f;
@@ -171,38 +235,40 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int C, int H, int W, int 
         const int ty = r / tiles_x, tx = r - ty * tiles_x;
         const size_t plane = (size_t)c * H * W;
         __syncthreads();
-        for (int idx = tid; idx < kSsimIn * kSsimIn; idx += 256) {
-            const int rr = idx / kSsimIn, cc = idx - rr * kSsimIn;
-            const int gy = ty * kSsimTile + rr - kSsimHalo, gx = tx * kSsimTile + cc - kSsimHalo;
-            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        for (int idx = tid; idx < kSsimInH * kSsimXP; idx += 256) {
+            const int rr = idx / kSsimXP, cc = idx - rr * kSsimXP;
+            const int gy = ty * kSsimTH + rr - kSsimHalo, gx = tx * kSsimTW + cc - kSsimHalo;
+            const bool in = cc < kSsimInW && gy >= 0 && gy < H && gx >= 0 && gx < W;
             const size_t o = plane + (size_t)gy * W + gx;
             s_in[0][rr][cc] = in ? Dm[o] : 0.f;
             s_in[1][rr][cc] = in ? Dq1[o] : 0.f;
             s_in[2][rr][cc] = in ? Dq12[o] : 0.f;
         }
         __syncthreads();
-        for (int idx = tid; idx < kSsimIn * kSsimTile; idx += 256) {
-            const int rr = idx >> 4, cx = idx & 15;
-            float a = 0.f, b = 0.f, d = 0.f;
+        if (tid < kSsimInH * (kSsimTW / 4)) {
+            const int rr = tid >> 2, c0 = 4 * (tid & 3);
+            float v[16], o[4];
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float wk = w[k];
-                a += wk * s_in[0][rr][cx + k]; b += wk * s_in[1][rr][cx + k]; d += wk * s_in[2][rr][cx + k];
+            for (int m = 0; m < 3; ++m) {
+                load16(&s_in[m][rr][c0], v);
+                taps4(v, w, o);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s_h[m][c0 + q][rr] = o[q];
             }
-            s_h[0][rr][cx] = a; s_h[1][rr][cx] = b; s_h[2][rr][cx] = d;
         }
         __syncthreads();
-        float a = 0.f, b = 0.f, d = 0.f;
+        const int px = tid & 15, py2 = 2 * (tid >> 4);
+        const f2 a = vtaps2(s_h[0][px], py2, w), b = vtaps2(s_h[1][px], py2, w), d = vtaps2(s_h[2][px], py2, w);
+        const int gx = tx * kSsimTW + px;
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float wk = w[k];
-            a += wk * s_h[0][py + k][px]; b += wk * s_h[1][py + k][px]; d += wk * s_h[2][py + k][px];
-        }
-        const int gy = ty * kSsimTile + py, gx = tx * kSsimTile + px;
-        if (gy < H && gx < W) {
-            const size_t o = plane + (size_t)gy * W + gx;
-            const float x = img1[o], y = img2[o], df = x - y;
-            grad1[o] = scale * (a + 2.f * x * b + y * d) + scale_l1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+        for (int h = 0; h < 2; ++h) {
+            const int gy = ty * kSsimTH + py2 + h;
+            if (gy < H && gx < W) {
+                const size_t o = plane + (size_t)gy * W + gx;
+                const float x = img1[o], y = img2[o], df = x - y;
+                const float aa = h ? a.y : a.x, bb = h ? b.y : b.x, dd = h ? d.y : d.x;
+                grad1[o] = scale * (aa + 2.f * x * bb + y * dd) + scale_l1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+            }
         }
     }
 }
@@ -251,7 +317,7 @@ extern "C" int d3ga_ssim_l1_fwd(int32_t C, int32_t H, int32_t W, const float *im
     hipStream_t s = (hipStream_t)stream;
     D3GA_HIP(hipMemsetAsync(out, 0, sizeof(float), s));
     if (out_l1) D3GA_HIP(hipMemsetAsync(out_l1, 0, sizeof(float), s));
-    const int tx = (W + kSsimTile - 1) / kSsimTile, ty = (H + kSsimTile - 1) / kSsimTile;
+    const int tx = (W + kSsimTW - 1) / kSsimTW, ty = (H + kSsimTH - 1) / kSsimTH;
     // persistent grid: every workgroup ends with ONE atomic on the result word (same-address atomics serialise)
     hipLaunchKernelGGL(ssim_fwd_kernel, dim3(ssim_grid(C * tx * ty, 2048)), dim3(256), 0, s, C, H, W, tx, ty, img1, img2,
                        1.0f / ((float)C * (float)H * (float)W), out, Dm, Dq1, Dq12, out_l1);
@@ -269,7 +335,7 @@ extern "C" int d3ga_ssim_l1_bwd(int32_t C, int32_t H, int32_t W, const float *im
     if (C <= 0 || H <= 0 || W <= 0) return D3GA_E_SIZE;
     if (!img1 || !img2 || !Dm || !Dq1 || !Dq12 || !g || !grad_img1) return D3GA_E_NULL;
     hipStream_t s = (hipStream_t)stream;
-    const int tx = (W + kSsimTile - 1) / kSsimTile, ty = (H + kSsimTile - 1) / kSsimTile;
+    const int tx = (W + kSsimTW - 1) / kSsimTW, ty = (H + kSsimTH - 1) / kSsimTH;
     hipLaunchKernelGGL(ssim_bwd_kernel, dim3(ssim_grid(C * tx * ty, 8192)), dim3(256), 0, s, C, H, W, tx, ty, img1, img2,
                        Dm, Dq1, Dq12, g, g_l1, 1.0f / ((float)C * (float)H * (float)W), grad_img1);
     return check_launch(s, 0);
