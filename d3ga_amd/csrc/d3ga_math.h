@@ -299,7 +299,7 @@ D3GA_HD Splat project_gaussian(V3 mean, const float c6[6], const float *view, co
     s.conic[0] = s.conic[1] = s.conic[2] = 0.f;
     s.rect[0] = s.rect[1] = s.rect[2] = s.rect[3] = 0;
     const V3 pv = xform_point(view, mean);
-    if (pv.z <= kNear) return s;
+    if (!(pv.z > kNear)) return s;        // z <= 0.2 is culled; so is a NaN position (it would poison the depth keys)
     const V3 ph = xform_point(proj, mean);
     const float pw = 1.0f / (xform_w(proj, mean) + 0.0000001f);
     const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
@@ -313,6 +313,7 @@ D3GA_HD Splat project_gaussian(V3 mean, const float c6[6], const float *view, co
     const float mid = 0.5f * (a + c);
     const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
     const float radius = ceilf(3.0f * sqrtf(fmaxf(mid + root, mid - root)));
+    if (!(radius == radius) || !(ph.x * pw == ph.x * pw) || !(ph.y * pw == ph.y * pw)) return s;   // NaN covariance / projection: culled
     const float px = ((ph.x * pw + 1.0f) * W - 1.0f) * 0.5f;
     const float py = ((ph.y * pw + 1.0f) * H - 1.0f) * 0.5f;
     tile_rect(px, py, radius, (W + kTile - 1) / kTile, (H + kTile - 1) / kTile, s.rect);

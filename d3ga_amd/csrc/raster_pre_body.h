@@ -56,6 +56,12 @@ D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float 
     o.opacity = 0.f;
     if (!o.sp.visible) return o;
     o.opacity = opacities[i];
+    if (!(o.opacity == o.opacity)) {         // NaN opacity: min(0.99, NaN * G) would evaluate to 0.99 -- cull instead
+        o.sp.visible = false; o.sp.radius = 0;
+        o.sp.rect[0] = o.sp.rect[1] = o.sp.rect[2] = o.sp.rect[3] = 0;
+        o.opacity = 0.f;
+        return o;
+    }
     if (colors_precomp) {
         o.rgb[0] = colors_precomp[3 * (size_t)i]; o.rgb[1] = colors_precomp[3 * (size_t)i + 1];
         o.rgb[2] = colors_precomp[3 * (size_t)i + 2];

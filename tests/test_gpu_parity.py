@@ -764,3 +764,32 @@ def test_fuzz_ragged_sizes_and_argument_paths(seed):
             assert float(t.grad.abs().max()) == 0
         else:
             assert rel_err(_np(t.grad), ref) < 2e-3, (k, rel_err(_np(t.grad), ref))
+
+
+def test_nan_and_inf_inputs_are_contained():
+    """A few Gaussians with NaN / Inf positions, covariances or opacities must not hang, crash or poison the rest of the
+    frame: they are culled (or contribute nothing) and every other Gaussian renders as if they were absent."""
+    from d3ga_amd import rasterizer as R
+    inp = scene_inputs("T1", scale_mult=3.0)
+    bg = torch.tensor([0.2, 0.3, 0.4])
+    rast = R.GaussianRasterizer(_settings(inp, bg, 3))
+    means, cov, op, sh = (inp[k].to(DEV).clone() for k in ("means3D", "cov6", "opacities", "shs"))
+    bad = torch.tensor([3, 50, 117, 400, 801], device=DEV)
+    keep = torch.ones(means.shape[0], dtype=torch.bool, device=DEV)
+    keep[bad] = False
+    ref, _, _ = rast(means3D=means[keep], means2D=None, opacities=op[keep], shs=sh[keep], cov3D_precomp=cov[keep])
+    means[bad[0]] = float("nan")
+    means[bad[1], 2] = float("inf")
+    cov[bad[2]] = float("nan")
+    cov[bad[3], 0] = float("inf")
+    op[bad[4]] = float("nan")
+    m = means.requires_grad_(True)
+    img, radii, _ = rast(means3D=m, means2D=None, opacities=op, shs=sh, cov3D_precomp=cov)
+    assert not R.last_counters()["overflow"]
+    assert bool(torch.isfinite(img).all())
+    assert rel_err(_np(img), _np(ref)) < 1e-5
+    assert int(radii[bad[0]]) == 0 and int(radii[bad[2]]) == 0
+    img.sum().backward()
+    good = torch.ones_like(keep)
+    good[bad] = False
+    assert bool(torch.isfinite(m.grad[good]).all())
