@@ -108,7 +108,10 @@ class FieldMLP(nn.Module):
         """z = [broadcast.expand(P, -1) | row_feats] (the reference's column order) -> (P, n_output)."""
         first = self.network[0]
         nb = broadcast.numel()
-        bias0 = F.linear(broadcast.reshape(1, nb), first.weight[:, :nb], first.bias)[0]      # folded pose columns
+        if nb:
+            bias0 = F.linear(broadcast.reshape(1, nb), first.weight[:, :nb], first.bias)[0]  # folded pose columns
+        else:
+            bias0 = first.bias
         h = linear_act(row_feats, first.weight[:, nb:], bias0, 0.1)
         for layer in list(self.network)[1:]:
             h = linear_act(h, layer.weight, layer.bias, 0.1)
@@ -146,3 +149,26 @@ class DeformationField(FieldMLP):
 
     def forward(self, canonical, pose):
         return torch.tanh(super().forward(embed(canonical), pose)) * self.scaling
+
+
+class ShadowDecoder(FieldMLP):
+    """models/mlp.py:262-297.  forward(pose) -> sigmoid(.) (V,1) with z = [pose[6:] | embed_7(template)]; the embedded
+    template is a constant of the module, as in the reference."""
+
+    def __init__(self, template, n_cond=98, n_nodes=128, n_layers=3):
+        super().__init__(n_cond + 45, 1, n_nodes, n_layers)
+        self.register_buffer("embedded_template", embed(template), persistent=False)
+
+    def forward(self, pose):
+        return torch.sigmoid(super().forward(self.embedded_template, pose[6:]))
+
+
+class FaceDecoder(FieldMLP):
+    """models/mlp.py:235-259.  forward(kpt (n,3)) -> (n_output,): the flattened keypoints through the trunk (one row)."""
+
+    def __init__(self, n_valid_kpts, n_output=128, n_nodes=128, n_layers=3):
+        super().__init__(n_valid_kpts * 3, n_output, n_nodes, n_layers)
+
+    def forward(self, kpt):
+        z = kpt.reshape(1, -1)
+        return super().forward(z, z.new_zeros(0))[0]

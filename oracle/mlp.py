@@ -37,3 +37,15 @@ def deformation_field(canonical, pose, hidden, out_w, out_b, scaling):
     P = canonical.shape[0]
     z = torch.cat([pose.expand(P, -1), embed(canonical)], dim=1)
     return torch.tanh(field_mlp(z, hidden, out_w, out_b)) * scaling
+
+
+def shadow_decoder(template, pose, hidden, out_w, out_b):
+    """models/mlp.py:262-297: z = [pose[6:] | embed_7(template)] -> sigmoid(pred)  (per template vertex)."""
+    P = template.shape[0]
+    z = torch.cat([pose[6:].expand(P, -1), embed(template)], dim=1)
+    return torch.sigmoid(field_mlp(z, hidden, out_w, out_b))
+
+
+def face_decoder(kpt, hidden, out_w, out_b):
+    """models/mlp.py:235-259: the flattened keypoints through the trunk (a single row)."""
+    return field_mlp(kpt.reshape(-1), hidden, out_w, out_b)

@@ -41,6 +41,28 @@ def test_fields_match_reference_goldens(golden):
         assert rel_err(prm.grad.cpu().numpy(), g[f"df_gw_{name}"]) < 1e-4, name
 
 
+def test_shadow_and_face_decoders_match_reference_goldens(golden):
+    from d3ga_amd.mlp import FaceDecoder, ShadowDecoder
+    g = golden("field_cases.npz")
+    leaf = lambda k: torch.from_numpy(g[k]).to(DEV).requires_grad_(True)
+    sd = _load(ShadowDecoder(torch.from_numpy(g["sd_template"])), g, "sd")
+    pose = leaf("sd_pose")
+    ao = sd(pose)
+    np.testing.assert_allclose(ao.detach().cpu().numpy(), g["sd_ao"], rtol=1e-4, atol=2e-6)
+    ao.backward(torch.from_numpy(g["sd_up"]).to(DEV))
+    assert rel_err(pose.grad.cpu().numpy(), g["sd_g_pose"]) < 1e-4
+    for name, prm in sd.named_parameters():
+        assert rel_err(prm.grad.cpu().numpy(), g[f"sd_gw_{name}"]) < 1e-4, name
+    fd = _load(FaceDecoder(33), g, "fd")
+    kpt = leaf("fd_kpt")
+    code = fd(kpt)
+    np.testing.assert_allclose(code.detach().cpu().numpy(), g["fd_code"], rtol=1e-4, atol=2e-6)
+    code.backward(torch.from_numpy(g["fd_up"]).to(DEV))
+    assert rel_err(kpt.grad.cpu().numpy(), g["fd_g_kpt"]) < 1e-4
+    for name, prm in fd.named_parameters():
+        assert rel_err(prm.grad.cpu().numpy(), g[f"fd_gw_{name}"]) < 1e-4, name
+
+
 @pytest.mark.parametrize("P,K,N,slope", [(1, 128, 128, 0.1), (127, 11, 128, 0.1), (1000, 128, 11, 1.0), (4099, 45, 128, 0.1),
                                          (300, 128, 3, 1.0), (513, 64, 96, 0.1)])
 def test_linear_act_against_torch(P, K, N, slope):

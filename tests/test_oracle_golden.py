@@ -153,3 +153,16 @@ def test_field_oracle_matches_reference_fields(golden):
     gc, gp = torch.autograd.grad(delta, [canon, pose], torch.from_numpy(g["df_up"]))
     np.testing.assert_allclose(gc.numpy(), g["df_g_canon"], rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(gp.numpy(), g["df_g_pose"], rtol=1e-4, atol=1e-6)
+    # ShadowDecoder / FaceDecoder (models/mlp.py:235-297)
+    hidden, ow, ob = _field_weights(g, "sd")
+    pose = leaf("sd_pose")
+    ao = om.shadow_decoder(torch.from_numpy(g["sd_template"]), pose, hidden, ow, ob)
+    np.testing.assert_allclose(ao.detach().numpy(), g["sd_ao"], rtol=1e-5, atol=1e-7)
+    (gp,) = torch.autograd.grad(ao, [pose], torch.from_numpy(g["sd_up"]))
+    np.testing.assert_allclose(gp.numpy(), g["sd_g_pose"], rtol=1e-4, atol=1e-7)
+    hidden, ow, ob = _field_weights(g, "fd")
+    kpt = leaf("fd_kpt")
+    code = om.face_decoder(kpt, hidden, ow, ob)
+    np.testing.assert_allclose(code.detach().numpy(), g["fd_code"], rtol=1e-5, atol=1e-6)
+    (gk,) = torch.autograd.grad(code, [kpt], torch.from_numpy(g["fd_up"]))
+    np.testing.assert_allclose(gk.numpy(), g["fd_g_kpt"], rtol=1e-4, atol=1e-7)

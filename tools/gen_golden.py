@@ -407,6 +407,32 @@ def gen_fields(mlp_mod):
     for (name, prm), gr in zip(df.named_parameters(), grads[2:]):
         out[f"df_w_{name}"] = prm.detach().numpy()
         out[f"df_gw_{name}"] = gr.numpy()
+    # --- ShadowDecoder: z = [pose[6:](92) | embed_7(template)(45)] -> 128 x (1+3) -> 1, sigmoid   (models/mlp.py:262-297)
+    config["shadow_mlp"] = Cfg(n_layers=3, n_nodes=128)
+    tmpl = torch.randn(97, 3, generator=g)
+    sd = mlp_mod.ShadowDecoder(config, tmpl)
+    pose3 = (0.3 * torch.randn(104, generator=g)).requires_grad_(True)      # pose[6:] must have 98 entries (mlp.py:271,288)
+    ao = sd(pose3)
+    up3 = torch.randn(97, 1, generator=g)
+    params = list(sd.parameters())
+    grads = torch.autograd.grad(ao, [pose3] + params, up3)
+    out.update(sd_template=tmpl.numpy(), sd_pose=pose3.detach().numpy(), sd_ao=ao.detach().numpy(), sd_up=up3.numpy(),
+               sd_g_pose=grads[0].numpy())
+    for (name, prm), gr in zip(sd.named_parameters(), grads[1:]):
+        out[f"sd_w_{name}"] = prm.detach().numpy()
+        out[f"sd_gw_{name}"] = gr.numpy()
+    # --- FaceDecoder: keypoints (n,3) flattened -> 128 x (1+3) -> n_output   (models/mlp.py:235-259)
+    config["face_mlp"] = Cfg(n_layers=3, n_nodes=128, n_output=128)
+    fd = mlp_mod.FaceDecoder(config, 33)
+    kpt = torch.randn(33, 3, generator=g).requires_grad_(True)
+    code = fd(kpt)
+    up4 = torch.randn(128, generator=g)
+    params = list(fd.parameters())
+    grads = torch.autograd.grad(code, [kpt] + params, up4)
+    out.update(fd_kpt=kpt.detach().numpy(), fd_code=code.detach().numpy(), fd_up=up4.numpy(), fd_g_kpt=grads[0].numpy())
+    for (name, prm), gr in zip(fd.named_parameters(), grads[1:]):
+        out[f"fd_w_{name}"] = prm.detach().numpy()
+        out[f"fd_gw_{name}"] = gr.numpy()
     np.savez(os.path.join(OUT, "field_cases.npz"), **out)
 
 
