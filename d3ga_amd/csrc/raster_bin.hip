@@ -74,11 +74,23 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(int tiles, const 
         for (int k = 0; k < kPer; ++k) {
             e[k] = run;
             run += c[k];
-            // work lists for the long-list sort kernels (usually empty: those launches then cost one tiny grid)
+            // work lists for the long-list sort kernels (usually empty: those launches then cost one tiny grid).  Slots are
+            // reserved per WAVEFRONT (ballot + one atomic): at 4K with 2M Gaussians thousands of tiles are in the mid class
+            // and one same-address global atomic per tile made this kernel 79 us.
             const int t = c0 + kPer * tid + k;
-            if (c[k] > n_large) huge_tiles[atomicAdd(&counters[D3GA_CNT_HUGE], 1u)] = (uint32_t)t;
-            else if (c[k] > n_mid) big_tiles[atomicAdd(&counters[D3GA_CNT_BIG], 1u)] = (uint32_t)t;
-            else if (c[k] > n_small) mid_tiles[atomicAdd(&counters[D3GA_CNT_MID], 1u)] = (uint32_t)t;
+            const int cls = c[k] > n_large ? 2 : (c[k] > n_mid ? 1 : (c[k] > n_small ? 0 : -1));
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const unsigned long long m = __ballot(cls == q);
+                if (m == 0) continue;                                   // wave-uniform
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&counters[q == 0 ? D3GA_CNT_MID : (q == 1 ? D3GA_CNT_BIG : D3GA_CNT_HUGE)], (uint32_t)__popcll(m));
+                base = (uint32_t)__shfl((int)base, 0);
+                if (cls == q) {
+                    uint32_t *list = q == 0 ? mid_tiles : (q == 1 ? big_tiles : huge_tiles);
+                    list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)t;
+                }
+            }
         }
         reinterpret_cast<uint4 *>(s_c)[2 * tid] = make_uint4(e[0], e[1], e[2], e[3]);
         reinterpret_cast<uint4 *>(s_c)[2 * tid + 1] = make_uint4(e[4], e[5], e[6], e[7]);
