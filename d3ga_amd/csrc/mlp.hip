@@ -71,10 +71,12 @@ __device__ __forceinline__ void chunk_commit(float *s_x, float4 (&v)[4], float4 
             x.z *= m[j].z > 0.f ? 1.f : mask_slope; x.w *= m[j].w > 0.f ? 1.f : mask_slope;
         }
         const bool ok_r = RAGGED ? r < P : true;                       // !RAGGED: the launcher guarantees P % 32 == 0
-        if (!(ok_r && k < K)) x.x = 0.f;
-        if (!(ok_r && k + 1 < K)) x.y = 0.f;
-        if (!(ok_r && k + 2 < K)) x.z = 0.f;
-        if (!(ok_r && k + 3 < K)) x.w = 0.f;
+        if (RAGGED || (K & 31)) {                                      // (uniform) nothing to zero when K fills its chunks
+            if (!(ok_r && k < K)) x.x = 0.f;
+            if (!(ok_r && k + 1 < K)) x.y = 0.f;
+            if (!(ok_r && k + 2 < K)) x.z = 0.f;
+            if (!(ok_r && k + 3 < K)) x.w = 0.f;
+        }
         if constexpr (MASK) {
             if (a_out && ok_r) {
                 const uint32_t o = (uint32_t)r * (uint32_t)K + (uint32_t)k;
