@@ -104,6 +104,32 @@ class FieldMLP(nn.Module):
             for layer in self.network:
                 nn.init.kaiming_normal_(layer.weight, a=0.1, mode="fan_in", nonlinearity="leaky_relu")
 
+    def forward_parts(self, parts):
+        """General column layout: `parts` lists z's column groups in the reference's order, each a (P, w) per-row tensor or a
+        1-D broadcast vector (ColorField mixes both kinds: models/mlp.py:208-226).  Broadcast groups are folded into the
+        first layer's bias, per-row groups are concatenated and meet the matching columns of the first weight."""
+        first = self.network[0]
+        row_cols, bc_cols, rows, bcs, c = [], [], [], [], 0
+        for t in parts:
+            w = t.shape[-1]
+            if t.dim() == 1:
+                bc_cols += list(range(c, c + w)); bcs.append(t)
+            else:
+                row_cols += list(range(c, c + w)); rows.append(t)
+            c += w
+        if c != first.weight.shape[1]:
+            raise ValueError(f"field input has {c} columns, the first layer expects {first.weight.shape[1]}")
+        dev = first.weight.device
+        w_row = first.weight.index_select(1, torch.tensor(row_cols, device=dev))
+        bias0 = first.bias
+        if bcs:
+            bias0 = F.linear(torch.cat(bcs).reshape(1, -1), first.weight.index_select(1, torch.tensor(bc_cols, device=dev)),
+                             first.bias)[0]
+        h = linear_act(torch.cat(rows, dim=1) if len(rows) > 1 else rows[0], w_row, bias0, 0.1)
+        for layer in list(self.network)[1:]:
+            h = linear_act(h, layer.weight, layer.bias, 0.1)
+        return linear_act(h, self.output.weight, self.output.bias, 1.0)
+
     def forward(self, row_feats, broadcast):
         """z = [broadcast.expand(P, -1) | row_feats] (the reference's column order) -> (P, n_output)."""
         first = self.network[0]
@@ -172,3 +198,44 @@ class FaceDecoder(FieldMLP):
     def forward(self, kpt):
         z = kpt.reshape(1, -1)
         return super().forward(z, z.new_zeros(0))[0]
+
+
+def sh4_direction_encoding(d):
+    """Stand-in for tiny-cuda-nn's degree-4 `SphericalHarmonics` direction encoding (16 outputs, models/mlp.py:166-179):
+    x = 2 d - 1, then the real SH polynomials of degree < 4 (constants of utils/sh_utils.py:7-24).  tiny-cuda-nn is
+    un-vendored: parity of THIS function is unpinned; everything around it is pinned."""
+    x, y, z = (2.0 * d - 1.0).unbind(-1)
+    xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+    return torch.stack([
+        torch.full_like(x, 0.28209479177387814),
+        -0.48860251190291987 * y, 0.48860251190291987 * z, -0.48860251190291987 * x,
+        1.0925484305920792 * xy, -1.0925484305920792 * yz, 0.94617469575755997 * zz - 0.31539156525251999,
+        -1.0925484305920792 * xz, 0.54627421529603959 * xx - 0.54627421529603959 * yy,
+        0.59004358992664352 * y * (-3.0 * xx + yy), 2.8906114426405538 * xy * z,
+        0.45704579946446572 * y * (1.0 - 5.0 * zz), 0.3731763325901154 * z * (5.0 * zz - 3.0),
+        0.45704579946446572 * x * (1.0 - 5.0 * zz), 1.4453057213202769 * z * (xx - yy),
+        0.59004358992664352 * x * (-xx + 3.0 * yy)], dim=-1)
+
+
+class ColorField(FieldMLP):
+    """models/mlp.py:152-232 with use_pose and use_view_enc (configs/actorshq_actor02.yml:100-105): the per-Gaussian colour
+    network of the reference's main configuration (`use_shs: false`).
+    forward(shs (P,n_features), pose, view_dir (P,3), frame_encoding=None, camera_encoding=None, shadow=None)
+      -> (sigmoid(pred[:, :3]), sigmoid(0.1 + pred[:, 3:4])),  z = [enc(view_dir) | pose | shadow | camera | frame | shs]."""
+
+    def __init__(self, n_features=64, n_cond=98, frame_dims=32, camera_dims=0, n_nodes=128, n_layers=4,
+                 direction_encoding=sh4_direction_encoding, n_view_enc=16):
+        super().__init__(n_cond + n_features + n_view_enc + frame_dims + camera_dims, 3 + 1, n_nodes, n_layers)
+        self.direction_encoding = direction_encoding
+
+    def forward(self, shs, pose, view_dir, frame_encoding=None, camera_encoding=None, shadow=None):
+        parts = [self.direction_encoding(view_dir), pose.reshape(-1)]
+        if shadow is not None:
+            parts.append(shadow)
+        if camera_encoding is not None:
+            parts.append(camera_encoding.reshape(-1))
+        if frame_encoding is not None:
+            parts.append(frame_encoding.reshape(-1))
+        parts.append(shs)
+        pkg = self.forward_parts(parts)
+        return torch.sigmoid(pkg[:, 0:3]), torch.sigmoid(0.1 + pkg[:, 3:4])

@@ -63,6 +63,24 @@ def test_shadow_and_face_decoders_match_reference_goldens(golden):
         assert rel_err(prm.grad.cpu().numpy(), g[f"fd_gw_{name}"]) < 1e-4, name
 
 
+def test_color_field_matches_reference_golden(golden):
+    """The colour network of configs/actorshq_actor02.yml (use_shs false): the reference's own ColorField run with the
+    stand-in direction encoding; inputs in the mixed per-row / broadcast column order of models/mlp.py:208-226."""
+    from d3ga_amd.mlp import ColorField
+    g = golden("field_cases.npz")
+    leaf = lambda k: torch.from_numpy(g[k]).to(DEV).requires_grad_(True)
+    col = _load(ColorField(), g, "col")
+    feat, pose, vd, frame = leaf("col_feat"), leaf("col_pose"), leaf("col_viewdir"), leaf("col_frame")
+    rgb, opa = col(feat, pose, vd, frame_encoding=frame)
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), g["col_rgb"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(opa.detach().cpu().numpy(), g["col_opacity"], rtol=1e-4, atol=2e-6)
+    torch.autograd.backward([rgb, opa], [torch.from_numpy(g["col_up0"]).to(DEV), torch.from_numpy(g["col_up1"]).to(DEV)])
+    for t, k in ((feat, "col_g_feat"), (pose, "col_g_pose"), (vd, "col_g_viewdir"), (frame, "col_g_frame")):
+        assert rel_err(t.grad.cpu().numpy(), g[k]) < 2e-4, k
+    for name, prm in col.named_parameters():
+        assert rel_err(prm.grad.cpu().numpy(), g[f"col_gw_{name}"]) < 2e-4, name
+
+
 @pytest.mark.parametrize("P,K,N,slope", [(1, 128, 128, 0.1), (127, 11, 128, 0.1), (1000, 128, 11, 1.0), (4099, 45, 128, 0.1),
                                          (300, 128, 3, 1.0), (513, 64, 96, 0.1)])
 def test_linear_act_against_torch(P, K, N, slope):

@@ -166,3 +166,12 @@ def test_field_oracle_matches_reference_fields(golden):
     np.testing.assert_allclose(code.detach().numpy(), g["fd_code"], rtol=1e-5, atol=1e-6)
     (gk,) = torch.autograd.grad(code, [kpt], torch.from_numpy(g["fd_up"]))
     np.testing.assert_allclose(gk.numpy(), g["fd_g_kpt"], rtol=1e-4, atol=1e-7)
+    # ColorField (models/mlp.py:152-232) -- the reference module with tiny-cuda-nn's encoding replaced by the oracle's stand-in
+    hidden, ow, ob = _field_weights(g, "col", n_hidden=5)
+    feat, pose, vd, frame = leaf("col_feat"), leaf("col_pose"), leaf("col_viewdir"), leaf("col_frame")
+    rgb, opa = om.color_field(feat, pose, vd, frame, None, None, hidden, ow, ob)
+    np.testing.assert_allclose(rgb.detach().numpy(), g["col_rgb"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(opa.detach().numpy(), g["col_opacity"], rtol=1e-5, atol=1e-6)
+    grads = torch.autograd.grad([rgb, opa], [feat, pose, vd, frame], [torch.from_numpy(g["col_up0"]), torch.from_numpy(g["col_up1"])])
+    for gr, k in zip(grads, ("col_g_feat", "col_g_pose", "col_g_viewdir", "col_g_frame")):
+        np.testing.assert_allclose(gr.numpy(), g[k], rtol=1e-4, atol=1e-6)

@@ -433,6 +433,43 @@ def gen_fields(mlp_mod):
     for (name, prm), gr in zip(fd.named_parameters(), grads[1:]):
         out[f"fd_w_{name}"] = prm.detach().numpy()
         out[f"fd_gw_{name}"] = gr.numpy()
+    # --- ColorField (the colour path of configs/actorshq_actor02.yml: use_shs false, use_pose, use_view_enc, frame
+    # embedder 32): the reference's own module, with tiny-cuda-nn's un-vendored direction encoding replaced by the
+    # oracle's stand-in (so everything BUT that encoding is pinned)   (models/mlp.py:152-232)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import mlp as om
+
+    class _Enc:
+        n_output_dims = 16
+
+        def __init__(self, n_input_dims, encoding_config):
+            assert n_input_dims == 3 and encoding_config["nested"][0]["degree"] == 4
+
+        def __call__(self, x):
+            return om.sh4_direction_encoding(x)
+
+    mlp_mod.tcnn = NS(Encoding=_Enc)
+    config["color_mlp"] = Cfg(n_layers=4, n_nodes=128, n_features=64, use_pose=True, use_view_enc=True)
+    config["frame_embedder"] = Cfg(n_dims=32)
+    config["train"] = Cfg()
+    col = mlp_mod.ColorField(config, cage_config)
+    Pc = 260
+    feat = (0.33 * torch.rand(Pc, 64, generator=g)).requires_grad_(True)
+    pose4 = (0.3 * torch.randn(98, generator=g)).requires_grad_(True)
+    vd = torch.nn.functional.normalize(torch.randn(Pc, 3, generator=g), dim=1).requires_grad_(True)
+    frame = (0.5 * torch.randn(32, generator=g)).requires_grad_(True)
+    rgb, opa = col(feat, pose4, vd, frame, None, None)     # (shadow would make z one column wider than n_input: mlp.py:188)
+    upc = [torch.randn(Pc, 3, generator=g), torch.randn(Pc, 1, generator=g)]
+    params = list(col.parameters())
+    grads = torch.autograd.grad([rgb, opa], [feat, pose4, vd, frame] + params, upc)
+    out.update(col_feat=feat.detach().numpy(), col_pose=pose4.detach().numpy(), col_viewdir=vd.detach().numpy(),
+               col_frame=frame.detach().numpy(), col_rgb=rgb.detach().numpy(),
+               col_opacity=opa.detach().numpy(), col_up0=upc[0].numpy(), col_up1=upc[1].numpy(),
+               col_g_feat=grads[0].numpy(), col_g_pose=grads[1].numpy(), col_g_viewdir=grads[2].numpy(),
+               col_g_frame=grads[3].numpy())
+    for (name, prm), gr in zip(col.named_parameters(), grads[4:]):
+        out[f"col_w_{name}"] = prm.detach().numpy()
+        out[f"col_gw_{name}"] = gr.numpy()
     np.savez(os.path.join(OUT, "field_cases.npz"), **out)
 
 
