@@ -117,7 +117,7 @@ class Frame:
             self.sil_rgb = torch.ones(P, 3, device=self.bg.device)
             self.sil_target = (self.target.mean(0, keepdim=True) > 0.5).float().expand(3, -1, -1).contiguous()
             self.bg0 = torch.zeros_like(self.bg)
-        if with_fields:
+        if with_fields:         # True: geometry networks; "color": geometry + colour networks
             if not hasattr(self, "canon_field"):
                 from d3ga_amd.mlp import CanonicalField, DeformationField
                 torch.manual_seed(17)
@@ -139,6 +139,25 @@ class Frame:
                                       p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp")
         pkg = {"means3D": means, "cov3D_precomp": cov6, "opacities": torch.sigmoid(p["opacity"]),
                "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
+        if with_fields == "color":
+            from d3ga_amd.mlp import view_directions
+            # configs/actorshq_actor02.yml (use_shs false): colour AND opacity from ColorField on per-Gaussian features,
+            # the pose, the view direction and the frame embedding (cage_net.py:232-258)
+            if not hasattr(self, "color_field"):
+                from d3ga_amd.mlp import ColorField
+                dev = self.bg.device
+                self.color_field = ColorField().to(dev)
+                self.field_params += list(self.color_field.parameters())
+                self.color_feat = (0.33 * torch.rand(self.barys0.shape[0], 64, device=dev)).requires_grad_(True)   # :59
+                self.frame_enc = (0.1 * torch.randn(32, device=dev)).requires_grad_(True)
+                from d3ga_amd.cameras import batch_to_camera
+                self.cam_center = batch_to_camera(self.batch, device=dev).camera_center.reshape(1, 3)
+            self.color_feat.grad = None
+            self.frame_enc.grad = None
+            viewdirs = view_directions(means, self.cam_center)                                     # :233-235
+            rgb, opac = self.color_field(self.color_feat, self.pose, viewdirs, frame_encoding=self.frame_enc)
+            pkg = {"means3D": means, "cov3D_precomp": cov6, "opacities": opac, "shs": None, "rgb": rgb,
+                   "sh_degree": self.sh_degree}
         img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
         sil = render(self.batch, pkg, self.bg0, colors_precomp=self.sil_rgb, grad_sync=self.grad_sync)["render"]
         # train.py:190-193: (1 - lambda) L1 + lambda (1 - SSIM) on the RGB image, L1 on the silhouette
@@ -460,6 +479,18 @@ def main():
             frame.train_step(with_fields=True)
         torch.cuda.synchronize()
         train["with_field_networks_ms_per_step"] = round(1e3 * (time.perf_counter() - t1) / n_ts, 4)
+        # the reference's main configuration (configs/actorshq_actor02.yml: use_shs false): ColorField supplies colour
+        # and opacity as well
+        for _ in range(3):
+            flat.zero()
+            frame.train_step(with_fields="color")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_ts):
+            flat.zero()
+            frame.train_step(with_fields="color")
+        torch.cuda.synchronize()
+        train["with_field_and_color_networks_ms_per_step"] = round(1e3 * (time.perf_counter() - t1) / n_ts, 4)
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:

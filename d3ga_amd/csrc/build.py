@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["deform.hip", "raster_pre.hip", "raster_bin.hip", "raster_composite.hip", "raster_api.hip", "bary.hip", "loss.hip", "mlp.hip"]
+SOURCES = ["deform.hip", "raster_pre.hip", "raster_bin.hip", "raster_composite.hip", "raster_api.hip", "bary.hip", "loss.hip", "mlp.hip", "encoding.hip"]
 HEADERS = ["d3ga_math.h", "d3ga_internal.h", "raster_pre_body.h", os.path.join("..", "..", "include", "d3ga.h")]
 OUT = os.path.join(HERE, "..", "libd3ga_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc",

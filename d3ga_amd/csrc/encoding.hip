@@ -1,0 +1,115 @@
+// encoding.hip -- the two element-wise ops in front of ColorField:
+//   view_dirs_*     v = (means3D - campos) / |means3D - campos|        (models/cage_net.py:233-235)
+//   sh4_encoding_*  the 16 real spherical-harmonics polynomials of degree < 4 on x = 2 v - 1: the degree-4
+//                   "SphericalHarmonics" direction encoding models/mlp.py:166-179 takes from tiny-cuda-nn.
+// ATen ran these as ~45 element-wise kernels forward and ~110 backward (1.16 ms at 500k Gaussians); here one kernel
+// each way, bound by the 64-byte encoding row: (12 + 64) B and (12 + 64 + 12) B per Gaussian.
+#include "d3ga_internal.h"
+
+namespace d3ga {
+
+namespace sh4 {
+constexpr float c0 = 0.28209479177387814f, c1 = 0.48860251190291987f;
+constexpr float c2a = 1.0925484305920792f, c2b = 0.94617469575755997f, c2c = 0.31539156525251999f,
+                c2d = 0.54627421529603959f;
+constexpr float c3a = 0.59004358992664352f, c3b = 2.8906114426405538f, c3c = 0.45704579946446572f,
+                c3d = 0.3731763325901154f, c3e = 1.4453057213202769f;
+}  // namespace sh4
+
+__global__ __launch_bounds__(kBlock) void view_dirs_fwd_kernel(int P, const float *__restrict__ means,
+                                                               const float *__restrict__ campos, float *__restrict__ dirs) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    const float dx = means[3 * i] - campos[0], dy = means[3 * i + 1] - campos[1], dz = means[3 * i + 2] - campos[2];
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    dirs[3 * i] = dx * inv, dirs[3 * i + 1] = dy * inv, dirs[3 * i + 2] = dz * inv;
+}
+
+__global__ __launch_bounds__(kBlock) void view_dirs_bwd_kernel(int P, const float *__restrict__ means,
+                                                               const float *__restrict__ campos, const float *__restrict__ g,
+                                                               float *__restrict__ d_means) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    const float dx = means[3 * i] - campos[0], dy = means[3 * i + 1] - campos[1], dz = means[3 * i + 2] - campos[2];
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    const float vx = dx * inv, vy = dy * inv, vz = dz * inv;
+    const float gx = g[3 * i], gy = g[3 * i + 1], gz = g[3 * i + 2];
+    const float vg = vx * gx + vy * gy + vz * gz;          // d v / d m = (I - v v^T) / |m - c|
+    d_means[3 * i] = (gx - vx * vg) * inv, d_means[3 * i + 1] = (gy - vy * vg) * inv, d_means[3 * i + 2] = (gz - vz * vg) * inv;
+}
+
+__global__ __launch_bounds__(kBlock) void sh4_encoding_fwd_kernel(int P, const float *__restrict__ dirs,
+                                                                  float *__restrict__ enc) {
+    using namespace sh4;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    const float x = 2.0f * dirs[3 * i] - 1.0f, y = 2.0f * dirs[3 * i + 1] - 1.0f, z = 2.0f * dirs[3 * i + 2] - 1.0f;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    float4 *o = reinterpret_cast<float4 *>(enc + 16 * (size_t)i);
+    o[0] = make_float4(c0, -c1 * y, c1 * z, -c1 * x);
+    o[1] = make_float4(c2a * xy, -c2a * yz, c2b * zz - c2c, -c2a * xz);
+    o[2] = make_float4(c2d * xx - c2d * yy, c3a * y * (-3.0f * xx + yy), c3b * xy * z, c3c * y * (1.0f - 5.0f * zz));
+    o[3] = make_float4(c3d * z * (5.0f * zz - 3.0f), c3c * x * (1.0f - 5.0f * zz), c3e * z * (xx - yy),
+                       c3a * x * (-xx + 3.0f * yy));
+}
+
+__global__ __launch_bounds__(kBlock) void sh4_encoding_bwd_kernel(int P, const float *__restrict__ dirs,
+                                                                  const float *__restrict__ d_enc, float *__restrict__ d_dirs) {
+    using namespace sh4;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    const float x = 2.0f * dirs[3 * i] - 1.0f, y = 2.0f * dirs[3 * i + 1] - 1.0f, z = 2.0f * dirs[3 * i + 2] - 1.0f;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    const float4 *gp = reinterpret_cast<const float4 *>(d_enc + 16 * (size_t)i);
+    const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2], g3 = gp[3];
+    // g0 = (e0..e3), g1 = (e4..e7), g2 = (e8..e11), g3 = (e12..e15)
+    const float q = 1.0f - 5.0f * zz, r = 3.0f * (yy - xx);
+    float gx = -c1 * g0.w + c2a * (y * g1.x - z * g1.w) + 2.0f * c2d * x * g2.x - 6.0f * c3a * xy * g2.y + c3b * yz * g2.z +
+               c3c * q * g3.y + 2.0f * c3e * xz * g3.z + c3a * r * g3.w;
+    float gy = -c1 * g0.y + c2a * (x * g1.x - z * g1.y) - 2.0f * c2d * y * g2.x + c3a * r * g2.y + c3b * xz * g2.z +
+               c3c * q * g2.w - 2.0f * c3e * yz * g3.z + 6.0f * c3a * xy * g3.w;
+    float gz = c1 * g0.z - c2a * (y * g1.y + x * g1.w) + 2.0f * c2b * z * g1.z + c3b * xy * g2.z - 10.0f * c3c * yz * g2.w +
+               c3d * (15.0f * zz - 3.0f) * g3.x - 10.0f * c3c * xz * g3.y + c3e * (xx - yy) * g3.z;
+    d_dirs[3 * i] = 2.0f * gx, d_dirs[3 * i + 1] = 2.0f * gy, d_dirs[3 * i + 2] = 2.0f * gz;     // x = 2 d - 1
+}
+
+static inline int ew_grid(int P) { return (P + kBlock - 1) / kBlock; }
+
+}  // namespace d3ga
+
+using namespace d3ga;
+
+extern "C" int d3ga_view_dirs_fwd(int32_t P, const float *means3D, const float *campos, float *dirs, d3ga_stream_t stream) {
+    if (P <= 0) return D3GA_E_SIZE;
+    if (!means3D || !campos || !dirs) return D3GA_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(view_dirs_fwd_kernel, dim3(ew_grid(P)), dim3(kBlock), 0, s, P, means3D, campos, dirs);
+    return check_launch(s, 0);
+}
+
+extern "C" int d3ga_view_dirs_bwd(int32_t P, const float *means3D, const float *campos, const float *d_dirs, float *d_means3D,
+                                  d3ga_stream_t stream) {
+    if (P <= 0) return D3GA_E_SIZE;
+    if (!means3D || !campos || !d_dirs || !d_means3D) return D3GA_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(view_dirs_bwd_kernel, dim3(ew_grid(P)), dim3(kBlock), 0, s, P, means3D, campos, d_dirs, d_means3D);
+    return check_launch(s, 0);
+}
+
+extern "C" int d3ga_sh4_encoding_fwd(int32_t P, const float *dirs, float *enc, d3ga_stream_t stream) {
+    if (P <= 0) return D3GA_E_SIZE;
+    if (!dirs || !enc) return D3GA_E_NULL;
+    if ((uintptr_t)enc & 15) return D3GA_E_CONFIG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sh4_encoding_fwd_kernel, dim3(ew_grid(P)), dim3(kBlock), 0, s, P, dirs, enc);
+    return check_launch(s, 0);
+}
+
+extern "C" int d3ga_sh4_encoding_bwd(int32_t P, const float *dirs, const float *d_enc, float *d_dirs, d3ga_stream_t stream) {
+    if (P <= 0) return D3GA_E_SIZE;
+    if (!dirs || !d_enc || !d_dirs) return D3GA_E_NULL;
+    if ((uintptr_t)d_enc & 15) return D3GA_E_CONFIG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sh4_encoding_bwd_kernel, dim3(ew_grid(P)), dim3(kBlock), 0, s, P, dirs, d_enc, d_dirs);
+    return check_launch(s, 0);
+}

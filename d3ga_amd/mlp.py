@@ -200,21 +200,59 @@ class FaceDecoder(FieldMLP):
         return super().forward(z, z.new_zeros(0))[0]
 
 
+class _Sh4Encoding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d):
+        require_cuda(d)
+        d = d.float().contiguous()
+        P = d.shape[0]
+        enc = torch.empty((P, 16), dtype=torch.float32, device=d.device)
+        check(_lib.lib().d3ga_sh4_encoding_fwd(P, dptr(d), dptr(enc), stream_handle()), "d3ga_sh4_encoding_fwd")
+        ctx.save_for_backward(d)
+        return enc
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        gd = torch.empty_like(d)
+        check(_lib.lib().d3ga_sh4_encoding_bwd(d.shape[0], dptr(d), dptr(g.float().contiguous()), dptr(gd), stream_handle()),
+              "d3ga_sh4_encoding_bwd")
+        return gd
+
+
 def sh4_direction_encoding(d):
     """Stand-in for tiny-cuda-nn's degree-4 `SphericalHarmonics` direction encoding (16 outputs, models/mlp.py:166-179):
-    x = 2 d - 1, then the real SH polynomials of degree < 4 (constants of utils/sh_utils.py:7-24).  tiny-cuda-nn is
-    un-vendored: parity of THIS function is unpinned; everything around it is pinned."""
-    x, y, z = (2.0 * d - 1.0).unbind(-1)
-    xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
-    return torch.stack([
-        torch.full_like(x, 0.28209479177387814),
-        -0.48860251190291987 * y, 0.48860251190291987 * z, -0.48860251190291987 * x,
-        1.0925484305920792 * xy, -1.0925484305920792 * yz, 0.94617469575755997 * zz - 0.31539156525251999,
-        -1.0925484305920792 * xz, 0.54627421529603959 * xx - 0.54627421529603959 * yy,
-        0.59004358992664352 * y * (-3.0 * xx + yy), 2.8906114426405538 * xy * z,
-        0.45704579946446572 * y * (1.0 - 5.0 * zz), 0.3731763325901154 * z * (5.0 * zz - 3.0),
-        0.45704579946446572 * x * (1.0 - 5.0 * zz), 1.4453057213202769 * z * (xx - yy),
-        0.59004358992664352 * x * (-xx + 3.0 * yy)], dim=-1)
+    x = 2 d - 1, then the real SH polynomials of degree < 4 (constants of utils/sh_utils.py:7-24); one HIP kernel each way
+    (csrc/encoding.hip).  tiny-cuda-nn is un-vendored: parity of THIS function is unpinned; everything
+    around it is pinned."""
+    if d.dim() != 2 or d.shape[1] != 3:
+        raise ValueError("sh4_direction_encoding: (P,3) directions")
+    return _Sh4Encoding.apply(d)
+
+
+class _ViewDirs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, campos):
+        require_cuda(means3D, campos)
+        means3D, campos = means3D.float().contiguous(), campos.float().contiguous()
+        v = torch.empty_like(means3D)
+        check(_lib.lib().d3ga_view_dirs_fwd(means3D.shape[0], dptr(means3D), dptr(campos), dptr(v), stream_handle()),
+              "d3ga_view_dirs_fwd")
+        ctx.save_for_backward(means3D, campos)
+        return v
+
+    @staticmethod
+    def backward(ctx, g):
+        means3D, campos = ctx.saved_tensors
+        gm = torch.empty_like(means3D)
+        check(_lib.lib().d3ga_view_dirs_bwd(means3D.shape[0], dptr(means3D), dptr(campos), dptr(g.float().contiguous()),
+                                            dptr(gm), stream_handle()), "d3ga_view_dirs_bwd")
+        return gm, None
+
+
+def view_directions(means3D, camera_center):
+    """models/cage_net.py:233-235: unit vectors from the (detached) camera centre to every Gaussian, one kernel each way."""
+    return _ViewDirs.apply(means3D, camera_center.detach().reshape(3))
 
 
 class ColorField(FieldMLP):

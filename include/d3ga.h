@@ -267,6 +267,20 @@ int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const f
 int d3ga_mlp_wgrad(int32_t P, int32_t N, int32_t K, const float *dpre, const float *X, float *dW, float *db,
                    d3ga_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * The element-wise ops in front of ColorField.
+ *   view_dirs:     dirs (P,3) = (means3D - campos) / |means3D - campos|          models/cage_net.py:233-235
+ *   sh4_encoding:  enc (P,16) = real spherical harmonics of degree < 4 on x = 2 dirs - 1: the degree-4
+ *                  "SphericalHarmonics" direction encoding of models/mlp.py:166-179 (tiny-cuda-nn, un-vendored:
+ *                  restated from its published definition, constants of utils/sh_utils.py:7-24).
+ * The backward calls overwrite d_means3D / d_dirs (no accumulation).  enc, d_enc 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------------- */
+int d3ga_view_dirs_fwd(int32_t P, const float *means3D, const float *campos, float *dirs, d3ga_stream_t stream);
+int d3ga_view_dirs_bwd(int32_t P, const float *means3D, const float *campos, const float *d_dirs, float *d_means3D,
+                       d3ga_stream_t stream);
+int d3ga_sh4_encoding_fwd(int32_t P, const float *dirs, float *enc, d3ga_stream_t stream);
+int d3ga_sh4_encoding_bwd(int32_t P, const float *dirs, const float *d_enc, float *d_dirs, d3ga_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

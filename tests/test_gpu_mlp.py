@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import mlp as om
 from util import rel_err
 
 pytestmark = pytest.mark.gpu
@@ -79,6 +80,29 @@ def test_color_field_matches_reference_golden(golden):
         assert rel_err(t.grad.cpu().numpy(), g[k]) < 2e-4, k
     for name, prm in col.named_parameters():
         assert rel_err(prm.grad.cpu().numpy(), g[f"col_gw_{name}"]) < 2e-4, name
+
+
+@pytest.mark.parametrize("P", [1, 63, 5000])
+def test_view_dirs_and_sh4_encoding_match_oracle(P):
+    """csrc/encoding.hip against the oracle's tensor program (f64 on the CPU): values and the input gradient through
+    both ops chained as in models/cage_net.py:233-235 -> models/mlp.py:208."""
+    from d3ga_amd.mlp import sh4_direction_encoding, view_directions
+    g = torch.Generator().manual_seed(P)
+    means = torch.randn(P, 3, generator=g) * 2.0
+    cam = torch.tensor([0.3, -0.2, 4.0])
+    up = torch.randn(P, 16, generator=g)
+    m64 = means.double().requires_grad_(True)
+    d64 = m64 - cam.double()
+    v64 = d64 / torch.linalg.norm(d64, dim=-1, keepdim=True)
+    e64 = om.sh4_direction_encoding(v64)
+    e64.backward(up.double())
+    md = means.to(DEV).requires_grad_(True)
+    v = view_directions(md, cam.to(DEV)[None])
+    e = sh4_direction_encoding(v)
+    e.backward(up.to(DEV))
+    np.testing.assert_allclose(v.detach().cpu().numpy(), v64.detach().numpy(), rtol=0, atol=2e-7)
+    np.testing.assert_allclose(e.detach().cpu().numpy(), e64.detach().numpy(), rtol=1e-5, atol=2e-6)
+    assert rel_err(md.grad.cpu().numpy(), m64.grad.numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("P,K,N,slope", [(1, 128, 128, 0.1), (127, 11, 128, 0.1), (1000, 128, 11, 1.0), (4099, 45, 128, 0.1),
