@@ -1,45 +1,89 @@
-// mlp.hip -- the dense layer of the reference's field networks (models/mlp.py:39-110:
+// mlp.hip -- the dense layer of the reference's field networks (models/mlp.py:39-232:
 // DeformationField / CanonicalField / ColorField are all  z -> [Linear(128) + leaky_relu(0.1)] x (1 + n_layers) -> Linear).
 //
 // One kernel template does every GEMM of the forward and of the input-gradient chain of the backward:
-//     Y[r][n] = act_out( sum_k A[r][k] * Wt[k][n] + bias[n] ),        A = X            (forward)
+//     Y[r][n] = act_out( sum_k A[r][k] * W[k][n] + bias[n] ),         A = X            (forward)
 //                                                                     A = dY (.) lrelu'(H)   (backward; A is also stored)
-// with exact f32 arithmetic on the matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bitwise an fmaf chain;
-// 157 TFLOP/s peak on MI355X = the f32 vector peak, but no operand shuffling and no VALU slots spent on the products).
+// with f32-EQUIVALENT arithmetic on the bf16 matrix cores: every f32 operand is split exactly into three bf16 pieces
+// (x = x0 + x1 + x2: round to nearest, subtract, repeat -- the remainders are exact, 3 x 8 significand bits cover f32's
+// 24), and the six products x_i w_j with i + j <= 2 are accumulated in f32 by v_mfma_f32_32x32x16_bf16.  The dropped
+// products are below 2^-24 |x||w|, i.e. below the rounding of an f32 fmaf chain: measured max error against f64 on a
+// 128 -> 128 layer 1.48e-6 (fmaf chain: 1.54e-6).  Six 32-cycle instructions per 16 k instead of eight 64-cycle
+// v_mfma_f32_32x32x2_f32: 2.7x less matrix time, which turns the layer from matrix-bound (196 us at 500k rows) into
+// HBM-bound.
 //
-// Work decomposition: a workgroup (8 wavefronts) owns 256 rows, a wavefront 32 rows x all output columns (NB blocks of
-// 32).  K is walked in chunks of 32: the wavefront moves its 32 x 32 chunk with full-segment loads into a private LDS
-// buffer (next chunk prefetched into registers), then lane l takes row l & 31 and, of the chunk, k = 16 (l >> 5) + s
-// (the 32x32x2 instruction contracts lanes 0-31's k with lanes 32-63's k, any pairing is a valid order of the sum).  The
-// weight panel Wt (32*ceil(K/32) x 32*NB, zero padded, prepared by the host layer) sits in LDS for the whole
-// persistent workgroup in the interleaved order [k][n & 31][n >> 5]: the NB operands a lane needs for one k-step are
-// one 16-byte LDS read.
-// Weight gradients (dW = dPre^T X, a reduction over all rows) are plain library GEMMs in the host layer (hipBLASLt).
+// Work decomposition: a persistent workgroup (16 wavefronts) owns 512 rows per step, a wavefront 32 rows x all output
+// columns (NB blocks of 32).  K is walked in half-chunks of 16 (one MFMA k-step): the wavefront moves 32 rows x 16 k with
+// loads that cover 16 rows x 64 bytes each, splits them, and stores the three bf16 planes into a private LDS buffer in
+// operand order (lane l of the MFMA reads the 8 k of row l & 31, k-half l >> 5, with one 16-byte read per plane).  Two
+// register slots (even / odd half-chunks) are re-issued as soon as they are committed, so two half-chunks are always in
+// flight.  The weight planes (prepared once per weight version by d3ga_mlp_pack_weights) sit in LDS for the whole
+// persistent workgroup in operand order [plane][k-step][k-half][column block][column & 31][8 k].
+// Weight gradients (dW = dPre^T X, a reduction over all rows) are wgrad_kernel below.
 #include "d3ga_internal.h"
 
 namespace d3ga {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int kMlpThreads = 1024;    // 16 wavefronts share one weight panel in LDS (138 KB: 4 wavefronts per SIMD)
-constexpr int kMlpRows = 512;        // rows per workgroup (32 per wavefront)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int kMlpThreads = 1024;    // 16 wavefronts share one set of weight planes in LDS (4 wavefronts per SIMD)
+constexpr int kMlpRows = 512;        // rows per workgroup step (32 per wavefront)
 constexpr int kMlpMaxK = 128;        // K <= 128
-constexpr int kMlpXPitch = 36;       // floats per row of a wavefront's 32 x 32 activation chunk in LDS (16-byte aligned rows)
+constexpr int kMlpAHalf = 640;       // bytes: 32 rows x 16 B of one k-half (+128: the two halves start 32 banks apart)
+constexpr int kMlpAPlane = 2 * kMlpAHalf;
+constexpr int kMlpABytes = 3 * kMlpAPlane;          // a wavefront's operand buffer: 3 planes x 2 k-halves x 32 rows x 8 bf16
+__host__ __device__ constexpr int mlp_panel_units(int K, int n_out) { return 3 * ((K + 15) / 16) * 2 * ((n_out + 31) / 32) * 32; }
 
-// One K-chunk (32 columns) of a wavefront's 32 rows, global -> registers in the COOPERATIVE order: lane l covers the
-// 16 bytes (l & 7) of the 128-byte segment of row 8*j + (l >> 3), j = 0..3 -- every load instruction touches eight full
-// 128-byte segments.  (A lane reading its own row straight from global memory touches 64 different cache lines per
-// instruction and re-fetches every line 8 times from L2: measured 1.4 TB/s, the first version of this kernel.)
-// chunk_issue only ISSUES the loads (raw values into registers, addresses clamped to stay in range): nothing may consume
-// them here -- a select or the mask multiply right after the load makes the compiler wait for HBM on the spot and the
-// "prefetch" degenerates into a blocking load (measured: launch time = MFMA time + HBM time).  chunk_commit, called one
-// chunk later, applies the leaky_relu mask, zeroes what lies past the matrix, writes the masked operand back (a_out) and
-// stores the chunk into the wavefront's LDS buffer.
-template <bool VEC, bool MASK>
-__device__ __forceinline__ void chunk_issue(float4 (&v)[4], float4 (&m)[4], int P, int K, int row0, int kc, int lane,
-                                            const float *__restrict__ X, const float *__restrict__ mask) {
+// two f32 -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32); element 0 in the low half
+__device__ __forceinline__ uint32_t bf16_pack(float a, float b) {
+    f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+// x = p0 + p1 + p2 exactly (each piece a bf16; the subtractions are exact)
+__device__ __forceinline__ void bf16_split2(float x, float y, uint32_t &p0, uint32_t &p1, uint32_t &p2) {
+    p0 = bf16_pack(x, y);
+    const float r0 = x - bf16_lo(p0), r1 = y - bf16_hi(p0);
+    p1 = bf16_pack(r0, r1);
+    p2 = bf16_pack(r0 - bf16_lo(p1), r1 - bf16_hi(p1));
+}
+
+// Weight planes for linear_kernel: unit (plane, kk, half, nb, n32) = the 8 bf16 pieces w[k = 16 kk + 8 half + j][n = 32 nb + n32],
+// j = 0..7, of weight(k, n) = W[k * ld_k + n * ld_n]; zero past K / n_out.  One thread per (kk, half, nb, n32).
+__global__ __launch_bounds__(kBlock) void pack_weights_kernel(int K, int n_out, const float *__restrict__ W, int64_t ld_k,
+                                                              int64_t ld_n, uint4 *__restrict__ panel) {
+    const int KK = (K + 15) / 16, NB = (n_out + 31) / 32;
+    const int u = blockIdx.x * kBlock + threadIdx.x;
+    if (u >= KK * 2 * NB * 32) return;
+    const int n32 = u & 31, nb = (u >> 5) % NB, kh = (u >> 5) / NB;          // kh = 2 kk + half
+    const int n = 32 * nb + n32, k0 = 8 * kh;
+    uint32_t q[3][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int r = row0 + 8 * j + (lane >> 3), k = kc + 4 * (lane & 7);
+        const int ka = k0 + 2 * j, kb = ka + 1;
+        const float wa = (ka < K && n < n_out) ? W[ka * ld_k + n * ld_n] : 0.f;
+        const float wb = (kb < K && n < n_out) ? W[kb * ld_k + n * ld_n] : 0.f;
+        bf16_split2(wa, wb, q[0][j], q[1][j], q[2][j]);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) panel[pl * (KK * 2 * NB * 32) + u] = make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
+}
+
+// One half-chunk (16 columns) of a wavefront's 32 rows, global -> registers: lane l covers the 16 bytes (l & 3) of the
+// 64-byte piece of row 16*j + (l >> 2), j = 0..1.  slot_issue only ISSUES the loads (raw values, addresses clamped to stay
+// in range): nothing may consume them here -- a select or the mask multiply right after the load makes the compiler wait
+// for HBM on the spot and the prefetch degenerates into a blocking load.  slot_commit, called two half-chunks later,
+// applies the leaky_relu mask, zeroes what lies past the matrix, writes the masked operand back (a_out), splits it into
+// the three bf16 planes and stores them into the wavefront's LDS buffer.
+template <bool VEC, bool MASK>
+__device__ __forceinline__ void slot_issue(float4 (&v)[2], float4 (&m)[2], int P, int K, int row0, int k0, int lane,
+                                           const float *__restrict__ X, const float *__restrict__ mask) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = row0 + 16 * j + (lane >> 2), k = k0 + 4 * (lane & 3);
         const int rc = r < P ? r : P - 1;
         if constexpr (VEC) {                                           // K % 4 == 0: rows are 16-byte aligned
             const uint32_t o = (uint32_t)rc * (uint32_t)K + (uint32_t)(k < K ? k : 0);
@@ -60,18 +104,18 @@ __device__ __forceinline__ void chunk_issue(float4 (&v)[4], float4 (&m)[4], int 
 }
 
 template <bool VEC, bool MASK, bool RAGGED>
-__device__ __forceinline__ void chunk_commit(float *s_x, float4 (&v)[4], float4 (&m)[4], int P, int K, int row0, int kc,
-                                             int lane, float mask_slope, float *__restrict__ a_out) {
+__device__ __forceinline__ void slot_commit(char *s_a, const float4 (&v)[2], const float4 (&m)[2], int P, int K, int row0,
+                                            int k0, int lane, float mask_slope, float *__restrict__ a_out) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = row0 + 8 * j + (lane >> 3), k = kc + 4 * (lane & 7);
+    for (int j = 0; j < 2; ++j) {
+        const int r = row0 + 16 * j + (lane >> 2), k = k0 + 4 * (lane & 3);
         float4 x = v[j];
         if constexpr (MASK) {
             x.x *= m[j].x > 0.f ? 1.f : mask_slope; x.y *= m[j].y > 0.f ? 1.f : mask_slope;
             x.z *= m[j].z > 0.f ? 1.f : mask_slope; x.w *= m[j].w > 0.f ? 1.f : mask_slope;
         }
         const bool ok_r = RAGGED ? r < P : true;                       // !RAGGED: the launcher guarantees P % 32 == 0
-        if (RAGGED || (K & 31)) {                                      // (uniform) nothing to zero when K fills its chunks
+        if (RAGGED || (K & 15)) {                                      // (uniform) nothing to zero when K fills its half-chunks
             if (!(ok_r && k < K)) x.x = 0.f;
             if (!(ok_r && k + 1 < K)) x.y = 0.f;
             if (!(ok_r && k + 2 < K)) x.z = 0.f;
@@ -89,79 +133,100 @@ __device__ __forceinline__ void chunk_commit(float *s_x, float4 (&v)[4], float4 
                 }
             }
         }
-        *reinterpret_cast<float4 *>(s_x + (8 * j + (lane >> 3)) * kMlpXPitch + 4 * (lane & 7)) = x;
+        uint32_t a0, a1, a2, b0, b1, b2;
+        bf16_split2(x.x, x.y, a0, a1, a2);
+        bf16_split2(x.z, x.w, b0, b1, b2);
+        // operand order: [plane][k-half = (l & 3) >> 1][row][8 bf16]; this lane's 4 k are the (l & 1)-th 8 bytes of the unit
+        char *d = s_a + ((lane & 3) >> 1) * kMlpAHalf + (16 * j + (lane >> 2)) * 16 + (lane & 1) * 8;
+        *reinterpret_cast<uint2 *>(d) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2 *>(d + kMlpAPlane) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2 *>(d + 2 * kMlpAPlane) = make_uint2(a2, b2);
     }
 }
 
 template <int NB, bool VEC, bool MASK, bool RAGGED>
 __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n_store, const float *__restrict__ X,
                                                              const float *__restrict__ mask, float mask_slope,
-                                                             float *__restrict__ a_out, const float *__restrict__ Wt,
+                                                             float *__restrict__ a_out, const uint4 *__restrict__ Wp,
                                                              const float *__restrict__ bias, float out_slope,
                                                              float *__restrict__ Y) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];       // weight panel [KP][32*NB] | 8 x activation chunk
-    constexpr int N32 = 32 * NB;
-    const int KP = 32 * ((K + 31) / 32);                               // panel rows (K padded to the chunk size)
-    float *s_w = smem;
+    extern __shared__ __attribute__((aligned(16))) char smem_mlp[];    // weight planes | 16 x operand buffer
+    const int KK = (K + 15) / 16;                                      // MFMA k-steps (K padded to 16)
+    const int plane_units = KK * 2 * NB * 32;
+    uint4 *s_w = reinterpret_cast<uint4 *>(smem_mlp);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float *s_x = smem + KP * N32 + wave * (32 * kMlpXPitch);           // this wavefront's [32 rows][32 k] chunk, padded
+    char *s_a = smem_mlp + 3 * plane_units * 16 + wave * kMlpABytes;
     const int half = lane >> 5, l32 = lane & 31;
-    {   // weight panel: contiguous copy, 16 bytes per thread and step
-        const int nvec = KP * N32 / 4;
-        for (int v = tid; v < nvec; v += kMlpThreads) reinterpret_cast<float4 *>(s_w)[v] = reinterpret_cast<const float4 *>(Wt)[v];
-    }
+    for (int u = tid; u < 3 * plane_units; u += kMlpThreads) s_w[u] = Wp[u];       // contiguous copy
     __syncthreads();
     const int ntiles = (P + kMlpRows - 1) / kMlpRows;
     // this lane's bias values, once (a global load inside the epilogue would force a vmcnt(0) in front of the stores)
     float bias_r[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) bias_r[nb] = (bias && l32 + 32 * nb < n_store) ? bias[l32 + 32 * nb] : 0.f;
-    float4 nxt[4], nxm[4];
-    chunk_issue<VEC, MASK>(nxt, nxm, P, K, blockIdx.x * kMlpRows + wave * 32, 0, lane, X, mask);
-    auto do_tile = [&](int tile) __attribute__((always_inline)) {
+    float4 va[2], vb[2], ma[2], mb[2];
+    {   // the two slots in issue order (the waits below count on it)
+        const int row0 = blockIdx.x * kMlpRows + wave * 32;
+        slot_issue<VEC, MASK>(va, ma, P, K, row0, 0, lane, X, mask);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_issue<VEC, MASK>(vb, mb, P, K, row0, 16, lane, X, mask);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const char *a_rd = s_a + half * kMlpAHalf + l32 * 16;
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * kMlpRows + wave * 32;
-        if (!RAGGED && row0 >= P) return;                              // wave-uniform: the last tile may be partly empty
+        const int nrow0 = row0 + (int)gridDim.x * kMlpRows;            // past the last tile: slot_issue clamps the rows
+        if (!RAGGED && row0 >= P) continue;                            // wave-uniform: the last tile may be partly empty
         f32x16 acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-        for (int kc = 0; kc < KP; kc += 32) {
-            __builtin_amdgcn_wave_barrier();                           // previous chunk's LDS reads are done
-            chunk_commit<VEC, MASK, RAGGED>(s_x, nxt, nxm, P, K, row0, kc, lane, mask_slope, a_out);
-            // prefetch (always exactly one chunk_issue, no branch): the next chunk of this tile, or -- BEFORE this tile's
-            // epilogue stores are issued -- the first chunk of the workgroup's next tile (past the last tile: clamped rows)
+        auto mma = [&](int kk) __attribute__((always_inline)) {
+            bf16x8_t a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                a[pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(a_rd + pl * kMlpAPlane));
+            const uint4 *wrd = s_w + ((kk * 2 + half) * NB) * 32 + l32;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                bf16x8_t w[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) w[pl] = __builtin_bit_cast(bf16x8_t, wrd[pl * plane_units + nb * 32]);
+                // smallest products first
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], w[0], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], w[1], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[2], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], w[0], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[1], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[0], acc[nb], 0, 0, 0);
+            }
+        };
+        for (int kk = 0; kk < KK; kk += 2) {
+            // even half-chunk: commit slot a, re-issue it (two half-chunks ahead, or the next tile's first), multiply
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_wave_barrier();                           // the previous half-chunk's LDS reads are done
+            slot_commit<VEC, MASK, RAGGED>(s_a, va, ma, P, K, row0, 16 * kk, lane, mask_slope, a_out);
             {
-                const bool same = kc + 32 < KP;
-                chunk_issue<VEC, MASK>(nxt, nxm, P, K, same ? row0 : row0 + (int)gridDim.x * kMlpRows, same ? kc + 32 : 0,
-                                       lane, X, mask);
+                const bool same = kk + 2 < KK;
+                slot_issue<VEC, MASK>(va, ma, P, K, same ? row0 : nrow0, same ? 16 * (kk + 2) : 0, lane, X, mask);
             }
             __builtin_amdgcn_wave_barrier();
-            // A operand: row l32, k = kc + 16*half + s  (the instruction contracts lanes 0-31's k with lanes 32-63's k)
-            float a[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 t = *reinterpret_cast<const float4 *>(s_x + l32 * kMlpXPitch + 16 * half + 4 * j);
-                a[4 * j] = t.x; a[4 * j + 1] = t.y; a[4 * j + 2] = t.z; a[4 * j + 3] = t.w;
+            mma(kk);
+            // odd half-chunk (absent in the last pair when KK is odd: its slot is still re-issued, never committed)
+            __builtin_amdgcn_sched_barrier(0);
+            const bool has_b = kk + 1 < KK;
+            if (has_b) {
+                __builtin_amdgcn_wave_barrier();
+                slot_commit<VEC, MASK, RAGGED>(s_a, vb, mb, P, K, row0, 16 * (kk + 1), lane, mask_slope, a_out);
             }
-            // panel layout [k][l32][nb]: the NB operands of one k-step are contiguous for a lane (one 16-byte LDS read)
-            const float *wrow = s_w + ((kc + 16 * half) * 32 + l32) * NB;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                float bv[NB];
-                if constexpr (NB == 4) {
-                    const float4 t = *reinterpret_cast<const float4 *>(wrow + s * N32);
-                    bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
-                } else if constexpr (NB == 2) {
-                    const float2 t = *reinterpret_cast<const float2 *>(wrow + s * N32);
-                    bv[0] = t.x; bv[1] = t.y;
-                } else {
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) bv[nb] = wrow[s * N32 + nb];
-                }
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bv[nb], acc[nb], 0, 0, 0);
+            {
+                const bool same = kk + 3 < KK;
+                slot_issue<VEC, MASK>(vb, mb, P, K, same ? row0 : nrow0, same ? 16 * (kk + 3) : 16, lane, X, mask);
+            }
+            if (has_b) {
+                __builtin_amdgcn_wave_barrier();
+                mma(kk + 1);
             }
         }
         // epilogue: C/D layout of the 32x32 shapes: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5);
@@ -190,8 +255,7 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
                 }
             }
         }
-    };
-    for (int tile = (int)blockIdx.x; tile < ntiles; tile += gridDim.x) do_tile(tile);
+    }
 }
 
 // Weight gradient dW (N,K) += dPre^T (N x rows) . X (rows x K): the contraction runs over the ROWS.  A workgroup owns a
@@ -311,20 +375,38 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(int P, int N, int K, 
 
 using namespace d3ga;
 
-// Y (P, n_out) = act( A (P,K) * Wt + bias ),  A = X, or X (.) lrelu'(mask) when mask != NULL (A then also written to a_out).
-// Wt: (2*ceil(K/2), 32*ceil(n_out/32)) row-major, zero padded: Wt[k][n] = weight of input k for output n.
+extern "C" int64_t d3ga_mlp_panel_bytes(int32_t K, int32_t n_out) {
+    if (K < 1 || K > kMlpMaxK || n_out < 1 || n_out > 128) return D3GA_E_SIZE;
+    return (int64_t)mlp_panel_units(K, n_out) * 16;
+}
+
+extern "C" int d3ga_mlp_pack_weights(int32_t K, int32_t n_out, const float *W, int64_t ld_k, int64_t ld_n, void *panel,
+                                     d3ga_stream_t stream) {
+    if (K < 1 || K > kMlpMaxK || n_out < 1 || n_out > 128) return D3GA_E_SIZE;
+    if (!W || !panel) return D3GA_E_NULL;
+    if ((uintptr_t)panel & 15) return D3GA_E_CONFIG;
+    hipStream_t s = (hipStream_t)stream;
+    const int units = mlp_panel_units(K, n_out) / 3;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((units + kBlock - 1) / kBlock), dim3(kBlock), 0, s, K, n_out, W, ld_k, ld_n,
+                       reinterpret_cast<uint4 *>(panel));
+    return check_launch(s, 0);
+}
+
+// Y (P, n_out) = act( A (P,K) * W + bias ),  A = X, or X (.) lrelu'(mask) when mask != NULL (A then also written to a_out).
+// panel: the bf16 weight planes written by d3ga_mlp_pack_weights for the same (K, n_out).
 extern "C" int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const float *mask, float mask_slope,
-                               float *a_out, const float *Wt, const float *bias, float out_slope, float *Y,
+                               float *a_out, const void *panel, const float *bias, float out_slope, float *Y,
                                d3ga_stream_t stream) {
     if (P < 0 || K < 1 || K > kMlpMaxK || n_out < 1 || n_out > 128) return D3GA_E_SIZE;
     if (P == 0) return D3GA_OK;
-    if (!X || !Wt || !Y) return D3GA_E_NULL;
+    if (!X || !panel || !Y) return D3GA_E_NULL;
     if (a_out && !mask) return D3GA_E_CONFIG;
-    if ((((uintptr_t)X | (uintptr_t)Wt | (uintptr_t)mask | (uintptr_t)a_out) & 15) != 0) return D3GA_E_CONFIG;
+    if ((((uintptr_t)X | (uintptr_t)panel | (uintptr_t)mask | (uintptr_t)a_out) & 15) != 0) return D3GA_E_CONFIG;
     if ((int64_t)P * K >= (1ll << 31) || (int64_t)P * n_out >= (1ll << 31)) return D3GA_E_SIZE;      // 32-bit element offsets
     hipStream_t s = (hipStream_t)stream;
-    const int KP = 32 * ((K + 31) / 32), NB = (n_out + 31) / 32;
-    const size_t lds = ((size_t)KP * 32 * NB + (size_t)(kMlpThreads / 64) * 32 * kMlpXPitch) * sizeof(float);
+    const int NB = (n_out + 31) / 32;
+    const uint4 *Wp = reinterpret_cast<const uint4 *>(panel);
+    const size_t lds = (size_t)mlp_panel_units(K, n_out) * 16 + (size_t)(kMlpThreads / 64) * kMlpABytes;
     const bool vec = (K % 4) == 0;
 #define D3GA_MLP_LAUNCH3(NBV, VECV, MASKV, RAGV, PV, XV, MV, AV, YV)                                                  \
     do {                                                                                                              \
@@ -334,12 +416,12 @@ extern "C" int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float 
         if (dev >= 0 && dev < 64 && !attr[dev]) {                                                                     \
             D3GA_HIP(hipFuncSetAttribute((const void *)linear_kernel<NBV, VECV, MASKV, RAGV>,                         \
                                          hipFuncAttributeMaxDynamicSharedMemorySize,                                  \
-                                         (kMlpMaxK * 32 * NBV + (kMlpThreads / 64) * 32 * kMlpXPitch) * (int)sizeof(float))); \
+                                         mlp_panel_units(kMlpMaxK, 32 * NBV) * 16 + (kMlpThreads / 64) * kMlpABytes));  \
             attr[dev] = true;                                                                                         \
         }                                                                                                             \
         const int nt = ((PV) + kMlpRows - 1) / kMlpRows;                                                              \
         hipLaunchKernelGGL((linear_kernel<NBV, VECV, MASKV, RAGV>), dim3(nt < 256 ? nt : 256), dim3(kMlpThreads), lds, \
-                           s, (PV), K, n_out, (XV), (MV), mask_slope, (AV), Wt, bias, out_slope, (YV));               \
+                           s, (PV), K, n_out, (XV), (MV), mask_slope, (AV), Wp, bias, out_slope, (YV));               \
     } while (0)
     // rows [0, P_full): no bounds checks at all (straight-line loads and stores); the ragged remainder (< 32 rows), or
     // everything when n_out is not a multiple of 32, goes through the bounds-checked instantiation

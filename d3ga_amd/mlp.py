@@ -22,22 +22,27 @@ _panels = {}
 
 
 def _panel(weight, transpose):
-    """Zero-padded weight panel the kernel stages in LDS: (32*ceil(K/32), 32*ceil(N/32)) with panel[k][n] = weight of input k
-    for output n.  transpose=True: forward (weight is (N,K) as in nn.Linear); False: input-gradient GEMM (contracts over
-    the layer's outputs: panel[k=n_layer][n=k_layer] = weight[n_layer][k_layer]).  Cached per (storage, version)."""
+    """The layer's weights split into bf16 planes in the kernel's operand order (d3ga_mlp_pack_weights).  transpose=True:
+    forward (weight is (N,K) as in nn.Linear: weight of input k for output n = weight[n][k]); False: the input-gradient
+    GEMM, which contracts over the layer's outputs (input n_layer, output k_layer: weight[n_layer][k_layer]).  Cached per
+    (storage, version): an optimizer step bumps the version and the next call re-packs (one tiny launch)."""
     key = (weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()), transpose)
     hit = _panels.get(key)
     if hit is None:
         if len(_panels) > 64:
             _panels.clear()
         w = weight.detach()
-        src = w.t() if transpose else w                      # (K, N) in the kernel's sense
-        K, N = src.shape
-        KP, NB = 32 * ((K + 31) // 32), (N + 31) // 32
-        p = torch.zeros((KP, 32 * NB), dtype=torch.float32, device=w.device)
-        p[:K, :N] = src
-        p = p.view(KP, NB, 32).transpose(1, 2).contiguous()          # [k][n & 31][n >> 5]: a lane's NB operands contiguous
-        hit = (p, weight)                                     # holds the weight alive: its address cannot be recycled
+        if w.dtype != torch.float32:
+            w = w.float()
+        n_layer, k_layer = w.shape
+        s_n, s_k = w.stride()
+        K, N, ld_k, ld_n = (k_layer, n_layer, s_k, s_n) if transpose else (n_layer, k_layer, s_n, s_k)
+        nbytes = _lib.lib().d3ga_mlp_panel_bytes(K, N)
+        if nbytes < 0:
+            raise ValueError(f"linear_act: layer {n_layer}x{k_layer} is outside the kernel's range (K, N <= 128)")
+        p = torch.empty(nbytes // 4, dtype=torch.int32, device=w.device)
+        check(_lib.lib().d3ga_mlp_pack_weights(K, N, dptr(w), ld_k, ld_n, dptr(p), stream_handle()), "d3ga_mlp_pack_weights")
+        hit = (p, weight, w)                                  # holds the weight alive: its address cannot be recycled
         _panels[key] = hit
     return hit[0]
 
