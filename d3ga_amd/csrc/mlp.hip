@@ -2,8 +2,11 @@
 // DeformationField / CanonicalField / ColorField are all  z -> [Linear(128) + leaky_relu(0.1)] x (1 + n_layers) -> Linear).
 //
 // One kernel template does every GEMM of the forward and of the input-gradient chain of the backward:
-//     Y[r][n] = act_out( sum_k A[r][k] * W[k][n] + bias[n] ),         A = X            (forward)
-//                                                                     A = dY (.) lrelu'(H)   (backward; A is also stored)
+//     Y[r][n] = act_out( sum_k X[r][k] * W[k][n] + bias[n] ) [ (.) lrelu'(M[r][n]) ]
+// (forward: X = activations, bias + leaky_relu epilogue, and one SIGN BIT per output element on the side; backward:
+// X = dPre of the layer, W its transposed weights, and the epilogue multiplies by the leaky_relu derivative of the
+// layer below, read from those bits -- 4 bytes per row and column block instead of 128 -- so that what is stored is that
+// layer's dPre: the operand of its weight gradient and of the next input-gradient GEMM; no masked copy is ever made)
 // with f32-EQUIVALENT arithmetic on the bf16 matrix cores: every f32 operand is split exactly into three bf16 pieces
 // (x = x0 + x1 + x2: round to nearest, subtract, repeat -- the remainders are exact, 3 x 8 significand bits cover f32's
 // 24), and the six products x_i w_j with i + j <= 2 are accumulated in f32 by v_mfma_f32_32x32x16_bf16.  The dropped
@@ -21,6 +24,7 @@
 // persistent workgroup in operand order [plane][k-step][k-half][column block][column & 31][8 k].
 // Weight gradients (dW = dPre^T X, a reduction over all rows) are wgrad_kernel below.
 #include "d3ga_internal.h"
+#include <utility>
 
 namespace d3ga {
 
@@ -35,6 +39,11 @@ constexpr int kMlpAHalf = 640;       // bytes: 32 rows x 16 B of one k-half (+12
 constexpr int kMlpAPlane = 2 * kMlpAHalf;
 constexpr int kMlpABytes = 3 * kMlpAPlane;          // a wavefront's operand buffer: 3 planes x 2 k-halves x 32 rows x 8 bf16
 __host__ __device__ constexpr int mlp_panel_units(int K, int n_out) { return 3 * ((K + 15) / 16) * 2 * ((n_out + 31) / 32) * 32; }
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <class F>
+__device__ __forceinline__ void static_for_16(F &&f) { static_for_impl(f, std::make_integer_sequence<int, 16>{}); }
 
 // two f32 -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32); element 0 in the low half
 __device__ __forceinline__ uint32_t bf16_pack(float a, float b) {
@@ -76,11 +85,11 @@ __global__ __launch_bounds__(kBlock) void pack_weights_kernel(int K, int n_out, 
 // 64-byte piece of row 16*j + (l >> 2), j = 0..1.  slot_issue only ISSUES the loads (raw values, addresses clamped to stay
 // in range): nothing may consume them here -- a select or the mask multiply right after the load makes the compiler wait
 // for HBM on the spot and the prefetch degenerates into a blocking load.  slot_commit, called two half-chunks later,
-// applies the leaky_relu mask, zeroes what lies past the matrix, writes the masked operand back (a_out), splits it into
-// the three bf16 planes and stores them into the wavefront's LDS buffer.
-template <bool VEC, bool MASK>
-__device__ __forceinline__ void slot_issue(float4 (&v)[2], float4 (&m)[2], int P, int K, int row0, int k0, int lane,
-                                           const float *__restrict__ X, const float *__restrict__ mask) {
+// zeroes what lies past the matrix, splits the values into the three bf16 planes and stores them into the wavefront's
+// LDS buffer.
+template <bool VEC>
+__device__ __forceinline__ void slot_issue(float4 (&v)[2], int P, int K, int row0, int k0, int lane,
+                                           const float *__restrict__ X) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = row0 + 16 * j + (lane >> 2), k = k0 + 4 * (lane & 3);
@@ -88,50 +97,27 @@ __device__ __forceinline__ void slot_issue(float4 (&v)[2], float4 (&m)[2], int P
         if constexpr (VEC) {                                           // K % 4 == 0: rows are 16-byte aligned
             const uint32_t o = (uint32_t)rc * (uint32_t)K + (uint32_t)(k < K ? k : 0);
             v[j] = *reinterpret_cast<const float4 *>(X + o);
-            if constexpr (MASK) m[j] = *reinterpret_cast<const float4 *>(mask + o);
         } else {
-            float e[4], f[4] = {0.f, 0.f, 0.f, 0.f};
+            float e[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t o = (uint32_t)rc * (uint32_t)K + (uint32_t)(k + c < K ? k + c : 0);
-                e[c] = X[o];
-                if constexpr (MASK) f[c] = mask[o];
-            }
+            for (int c = 0; c < 4; ++c) e[c] = X[(uint32_t)rc * (uint32_t)K + (uint32_t)(k + c < K ? k + c : 0)];
             v[j] = make_float4(e[0], e[1], e[2], e[3]);
-            if constexpr (MASK) m[j] = make_float4(f[0], f[1], f[2], f[3]);
         }
     }
 }
 
-template <bool VEC, bool MASK, bool RAGGED>
-__device__ __forceinline__ void slot_commit(char *s_a, const float4 (&v)[2], const float4 (&m)[2], int P, int K, int row0,
-                                            int k0, int lane, float mask_slope, float *__restrict__ a_out) {
+template <bool RAGGED>
+__device__ __forceinline__ void slot_commit(char *s_a, const float4 (&v)[2], int P, int K, int row0, int k0, int lane) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = row0 + 16 * j + (lane >> 2), k = k0 + 4 * (lane & 3);
         float4 x = v[j];
-        if constexpr (MASK) {
-            x.x *= m[j].x > 0.f ? 1.f : mask_slope; x.y *= m[j].y > 0.f ? 1.f : mask_slope;
-            x.z *= m[j].z > 0.f ? 1.f : mask_slope; x.w *= m[j].w > 0.f ? 1.f : mask_slope;
-        }
         const bool ok_r = RAGGED ? r < P : true;                       // !RAGGED: the launcher guarantees P % 32 == 0
         if (RAGGED || (K & 15)) {                                      // (uniform) nothing to zero when K fills its half-chunks
             if (!(ok_r && k < K)) x.x = 0.f;
             if (!(ok_r && k + 1 < K)) x.y = 0.f;
             if (!(ok_r && k + 2 < K)) x.z = 0.f;
             if (!(ok_r && k + 3 < K)) x.w = 0.f;
-        }
-        if constexpr (MASK) {
-            if (a_out && ok_r) {
-                const uint32_t o = (uint32_t)r * (uint32_t)K + (uint32_t)k;
-                if (VEC) { if (k < K) *reinterpret_cast<float4 *>(a_out + o) = x; }
-                else {
-                    if (k < K) a_out[o] = x.x;
-                    if (k + 1 < K) a_out[o + 1] = x.y;
-                    if (k + 2 < K) a_out[o + 2] = x.z;
-                    if (k + 3 < K) a_out[o + 3] = x.w;
-                }
-            }
         }
         uint32_t a0, a1, a2, b0, b1, b2;
         bf16_split2(x.x, x.y, a0, a1, a2);
@@ -144,11 +130,11 @@ __device__ __forceinline__ void slot_commit(char *s_a, const float4 (&v)[2], con
     }
 }
 
-template <int NB, bool VEC, bool MASK, bool RAGGED>
+template <int NB, bool VEC, bool EMASK, bool RAGGED>
 __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n_store, const float *__restrict__ X,
-                                                             const float *__restrict__ mask, float mask_slope,
-                                                             float *__restrict__ a_out, const uint4 *__restrict__ Wp,
-                                                             const float *__restrict__ bias, float out_slope,
+                                                             const uint4 *__restrict__ Wp, const float *__restrict__ bias,
+                                                             float out_slope, uint32_t *__restrict__ sign_out,
+                                                             const uint32_t *__restrict__ mask_bits, float emask_slope,
                                                              float *__restrict__ Y) {
     extern __shared__ __attribute__((aligned(16))) char smem_mlp[];    // weight planes | 16 x operand buffer
     const int KK = (K + 15) / 16;                                      // MFMA k-steps (K padded to 16)
@@ -164,12 +150,12 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
     float bias_r[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) bias_r[nb] = (bias && l32 + 32 * nb < n_store) ? bias[l32 + 32 * nb] : 0.f;
-    float4 va[2], vb[2], ma[2], mb[2];
+    float4 va[2], vb[2];
     {   // the two slots in issue order (the waits below count on it)
         const int row0 = blockIdx.x * kMlpRows + wave * 32;
-        slot_issue<VEC, MASK>(va, ma, P, K, row0, 0, lane, X, mask);
+        slot_issue<VEC>(va, P, K, row0, 0, lane, X);
         __builtin_amdgcn_sched_barrier(0);
-        slot_issue<VEC, MASK>(vb, mb, P, K, row0, 16, lane, X, mask);
+        slot_issue<VEC>(vb, P, K, row0, 16, lane, X);
         __builtin_amdgcn_sched_barrier(0);
     }
     const char *a_rd = s_a + half * kMlpAHalf + l32 * 16;
@@ -206,10 +192,10 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
             // even half-chunk: commit slot a, re-issue it (two half-chunks ahead, or the next tile's first), multiply
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_wave_barrier();                           // the previous half-chunk's LDS reads are done
-            slot_commit<VEC, MASK, RAGGED>(s_a, va, ma, P, K, row0, 16 * kk, lane, mask_slope, a_out);
+            slot_commit<RAGGED>(s_a, va, P, K, row0, 16 * kk, lane);
             {
                 const bool same = kk + 2 < KK;
-                slot_issue<VEC, MASK>(va, ma, P, K, same ? row0 : nrow0, same ? 16 * (kk + 2) : 0, lane, X, mask);
+                slot_issue<VEC>(va, P, K, same ? row0 : nrow0, same ? 16 * (kk + 2) : 0, lane, X);
             }
             __builtin_amdgcn_wave_barrier();
             mma(kk);
@@ -218,11 +204,11 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
             const bool has_b = kk + 1 < KK;
             if (has_b) {
                 __builtin_amdgcn_wave_barrier();
-                slot_commit<VEC, MASK, RAGGED>(s_a, vb, mb, P, K, row0, 16 * (kk + 1), lane, mask_slope, a_out);
+                slot_commit<RAGGED>(s_a, vb, P, K, row0, 16 * (kk + 1), lane);
             }
             {
                 const bool same = kk + 3 < KK;
-                slot_issue<VEC, MASK>(vb, mb, P, K, same ? row0 : nrow0, same ? 16 * (kk + 3) : 16, lane, X, mask);
+                slot_issue<VEC>(vb, P, K, same ? row0 : nrow0, same ? 16 * (kk + 3) : 16, lane, X);
             }
             if (has_b) {
                 __builtin_amdgcn_wave_barrier();
@@ -230,30 +216,52 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
             }
         }
         // epilogue: C/D layout of the 32x32 shapes: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5);
-        // every store instruction writes two full 128-byte row segments
+        // every store instruction covers two full 128-byte row segments.
+        // Sign bits: the ballot of (y > 0) for register r IS the pair of 32-bit words (columns of block nb) of rows
+        // dr(r) and dr(r) + 4; lane r (and 32 + r) collects them (v_writelane) and the sixteen lanes r < 16 of each half
+        // store NB words each.  EMASK reads the same words back (one load per lane), broadcasts them with v_readlane and
+        // uses the 64-bit pair directly as the lane mask of the select.
         constexpr bool full = !RAGGED;                                 // launcher: P % 32 == 0 and n_store == 32*NB
+        const uint32_t ybase0 = (uint32_t)(row0 + 4 * half) * (uint32_t)n_store + (uint32_t)l32;
+        const int my_row = row0 + 4 * half + (l32 & 3) + 8 * ((l32 >> 2) & 3);        // the row lane l32 < 16 keeps words of
+        const bool word_lane = l32 < 16 && (full || my_row < P);
+        uint32_t mw[NB];
+        if constexpr (EMASK) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) mw[nb] = word_lane ? mask_bits[(uint32_t)my_row * (uint32_t)NB + nb] : 0u;
+        }
+        uint32_t sw[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int n = l32 + 32 * nb;
             const float b = bias_r[nb];
-            const uint32_t ybase = (uint32_t)(row0 + 4 * half) * (uint32_t)n_store + (uint32_t)n;
-            if constexpr (full) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    float y = acc[nb][r] + b;
-                    y = y > 0.f ? y : out_slope * y;
-                    Y[ybase + (uint32_t)dr * (uint32_t)n_store] = y;
+            sw[nb] = 0u;
+            static_for_16([&](auto rc) __attribute__((always_inline)) {
+                constexpr int r = decltype(rc)::value;                 // a constant expression: v_writelane's lane select
+                const int dr = (r & 3) + 8 * (r >> 2);
+                float y = acc[nb][r] + b;
+                y = y > 0.f ? y : out_slope * y;
+                if constexpr (EMASK) {
+                    const uint64_t keep = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mw[nb], 32 + r) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)mw[nb], r);
+                    const float ys = y * emask_slope;
+                    // (s_nop: gfx950 wants two wait states between a VALU write of an SGPR -- the v_readlanes -- and a VALU
+                    // read of it as a lane mask; inside inline asm nobody inserts them)
+                    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(y) : "v"(ys), "v"(y), "s"(keep));
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    float y = acc[nb][r] + b;
-                    y = y > 0.f ? y : out_slope * y;
-                    if (row0 + 4 * half + dr < P && n < n_store) Y[ybase + (uint32_t)dr * (uint32_t)n_store] = y;
+                if (sign_out) {                                        // (uniform)
+                    const uint64_t pos = __ballot(y > 0.f);
+                    // (the s_nop: v_writelane reading an SGPR the VALU has just written -- the ballot -- needs wait
+                    // states the assembler does not insert inside inline asm; without them lanes got stale words)
+                    asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2\n\tv_writelane_b32 %0, %3, %4"
+                        : "+v"(sw[nb]) : "s"((uint32_t)pos), "n"(r), "s"((uint32_t)(pos >> 32)), "n"(32 + r));
                 }
-            }
+                if (full || (row0 + 4 * half + dr < P && n < n_store)) Y[ybase0 + 32 * nb + (uint32_t)dr * (uint32_t)n_store] = y;
+            });
+        }
+        if (sign_out && word_lane) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) sign_out[(uint32_t)my_row * (uint32_t)NB + nb] = sw[nb];
         }
     }
 }
@@ -392,23 +400,22 @@ extern "C" int d3ga_mlp_pack_weights(int32_t K, int32_t n_out, const float *W, i
     return check_launch(s, 0);
 }
 
-// Y (P, n_out) = act( A (P,K) * W + bias ),  A = X, or X (.) lrelu'(mask) when mask != NULL (A then also written to a_out).
+// Y (P, n_out) = act( X (P,K) * W + bias ) [ (.) (mask bit ? 1 : mask_slope) ];  sign_out: bit (Y > 0) per element
 // panel: the bf16 weight planes written by d3ga_mlp_pack_weights for the same (K, n_out).
-extern "C" int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const float *mask, float mask_slope,
-                               float *a_out, const void *panel, const float *bias, float out_slope, float *Y,
+extern "C" int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const void *panel, const float *bias,
+                               float out_slope, uint32_t *sign_out, const uint32_t *mask_bits, float mask_slope, float *Y,
                                d3ga_stream_t stream) {
     if (P < 0 || K < 1 || K > kMlpMaxK || n_out < 1 || n_out > 128) return D3GA_E_SIZE;
     if (P == 0) return D3GA_OK;
     if (!X || !panel || !Y) return D3GA_E_NULL;
-    if (a_out && !mask) return D3GA_E_CONFIG;
-    if ((((uintptr_t)X | (uintptr_t)panel | (uintptr_t)mask | (uintptr_t)a_out) & 15) != 0) return D3GA_E_CONFIG;
+    if ((((uintptr_t)X | (uintptr_t)panel) & 15) != 0) return D3GA_E_CONFIG;
     if ((int64_t)P * K >= (1ll << 31) || (int64_t)P * n_out >= (1ll << 31)) return D3GA_E_SIZE;      // 32-bit element offsets
     hipStream_t s = (hipStream_t)stream;
     const int NB = (n_out + 31) / 32;
     const uint4 *Wp = reinterpret_cast<const uint4 *>(panel);
     const size_t lds = (size_t)mlp_panel_units(K, n_out) * 16 + (size_t)(kMlpThreads / 64) * kMlpABytes;
     const bool vec = (K % 4) == 0;
-#define D3GA_MLP_LAUNCH3(NBV, VECV, MASKV, RAGV, PV, XV, MV, AV, YV)                                                  \
+#define D3GA_MLP_LAUNCH3(NBV, VECV, MASKV, RAGV, PV, XV, SV, MV, YV)                                                  \
     do {                                                                                                              \
         static bool attr[64] = {};                                                                                    \
         int dev = 0;                                                                                                  \
@@ -421,25 +428,25 @@ extern "C" int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float 
         }                                                                                                             \
         const int nt = ((PV) + kMlpRows - 1) / kMlpRows;                                                              \
         hipLaunchKernelGGL((linear_kernel<NBV, VECV, MASKV, RAGV>), dim3(nt < 256 ? nt : 256), dim3(kMlpThreads), lds, \
-                           s, (PV), K, n_out, (XV), (MV), mask_slope, (AV), Wp, bias, out_slope, (YV));               \
+                           s, (PV), K, n_out, (XV), Wp, bias, out_slope, (SV), (MV), mask_slope, (YV));               \
     } while (0)
     // rows [0, P_full): no bounds checks at all (straight-line loads and stores); the ragged remainder (< 32 rows), or
     // everything when n_out is not a multiple of 32, goes through the bounds-checked instantiation
     const int P_full = (n_out % 32 == 0) ? P - P % 32 : 0;
     const int P_rest = P - P_full;
-    const size_t xo = (size_t)P_full * K, yo = (size_t)P_full * n_out;
+    const size_t xo = (size_t)P_full * K, yo = (size_t)P_full * n_out, wo = (size_t)P_full * NB;
 #define D3GA_MLP_LAUNCH2(NBV, VECV, MASKV)                                                                            \
     do {                                                                                                              \
-        if (P_full > 0) D3GA_MLP_LAUNCH3(NBV, VECV, MASKV, false, P_full, X, mask, a_out, Y);                         \
+        if (P_full > 0) D3GA_MLP_LAUNCH3(NBV, VECV, MASKV, false, P_full, X, sign_out, mask_bits, Y);                 \
         if (P_rest > 0)                                                                                               \
-            D3GA_MLP_LAUNCH3(NBV, VECV, MASKV, true, P_rest, X + xo, mask ? mask + xo : nullptr,                      \
-                             a_out ? a_out + xo : nullptr, Y + yo);                                                   \
+            D3GA_MLP_LAUNCH3(NBV, VECV, MASKV, true, P_rest, X + xo, sign_out ? sign_out + wo : nullptr,              \
+                             mask_bits ? mask_bits + wo : nullptr, Y + yo);                                           \
     } while (0)
 #define D3GA_MLP_LAUNCH(NBV)                                                                                          \
     do {                                                                                                              \
-        if (vec && mask) D3GA_MLP_LAUNCH2(NBV, true, true);                                                           \
+        if (vec && mask_bits) D3GA_MLP_LAUNCH2(NBV, true, true);                                                       \
         else if (vec) D3GA_MLP_LAUNCH2(NBV, true, false);                                                             \
-        else if (mask) D3GA_MLP_LAUNCH2(NBV, false, true);                                                            \
+        else if (mask_bits) D3GA_MLP_LAUNCH2(NBV, false, true);                                                           \
         else D3GA_MLP_LAUNCH2(NBV, false, false);                                                                     \
     } while (0)
     switch (NB) {

@@ -47,53 +47,80 @@ def _panel(weight, transpose):
     return hit[0]
 
 
-class _LinearAct(torch.autograd.Function):
-    """y = act(x @ weight.T + bias), act(y) = y if y > 0 else slope * y  (slope = 1: plain linear layer)."""
+def _linear(x, panel, bias, slope, n_out, want_sign=False, mask_bits=None, mask_slope=1.0):
+    P, K = x.shape
+    y = torch.empty((P, n_out), dtype=torch.float32, device=x.device)
+    sign = torch.empty((P, (n_out + 31) // 32), dtype=torch.int32, device=x.device) if want_sign else None
+    check(_lib.lib().d3ga_mlp_linear(P, K, n_out, dptr(x), dptr(panel), dptr(bias), float(slope), dptr(sign), dptr(mask_bits),
+                                     float(mask_slope), dptr(y), stream_handle()), "d3ga_mlp_linear")
+    return y, sign
+
+
+class _Chain(torch.autograd.Function):
+    """h_{i+1} = act_i(h_i @ W_i.T + b_i), act(y) = y if y > 0 else slope_i * y (slope 1: none), i = 0..L-1, h_0 = x.
+    apply(x, slopes, W_0, b_0, W_1, b_1, ...) -> h_L.  The backward walks the chain once: the input-gradient GEMM of layer
+    i multiplies by the leaky_relu derivative of layer i-1 in its epilogue, so each layer's pre-activation gradient is
+    written exactly once and feeds both its weight gradient and the next GEMM."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, slope):
-        require_cuda(x, weight)
-        x = x.float().contiguous()
-        P, K = x.shape
-        N = weight.shape[0]
-        if weight.shape[1] != K or K > 128 or N > 128:
-            raise ValueError(f"linear_act: x (P,{K}) weight {tuple(weight.shape)}: need matching K <= 128 and N <= 128")
-        y = torch.empty((P, N), dtype=torch.float32, device=x.device)
-        b = None if bias is None else bias.float().contiguous()
-        check(_lib.lib().d3ga_mlp_linear(P, K, N, dptr(x), None, 0.0, None, dptr(_panel(weight, True)), dptr(b),
-                                         float(slope), dptr(y), stream_handle()), "d3ga_mlp_linear")
-        ctx.slope = float(slope)
-        ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, weight, y)
-        return y
+    def forward(ctx, x, slopes, *wb):
+        weights, biases = wb[0::2], wb[1::2]
+        require_cuda(x, *weights)
+        h = x.float().contiguous()
+        acts, signs = [h], []
+        track = any(ctx.needs_input_grad)                      # (grad mode is off inside forward: ask the node instead)
+        for w, b, slope in zip(weights, biases, slopes):
+            N, K = w.shape
+            if h.shape[1] != K or K > 128 or N > 128:
+                raise ValueError(f"linear_act: x (P,{h.shape[1]}) weight {tuple(w.shape)}: need matching K <= 128 and N <= 128")
+            h, sign = _linear(h, _panel(w, True), None if b is None else b.float().contiguous(), slope, N,
+                              want_sign=track and slope != 1.0)
+            acts.append(h)
+            signs.append(sign)
+        ctx.slopes = tuple(float(v) for v in slopes)
+        ctx.n_layers = len(weights)
+        ctx.has_bias = tuple(b is not None for b in biases)
+        ctx.signs = signs                                      # int32 bit words: not differentiable, kept on the ctx
+        ctx.save_for_backward(*acts, *weights)
+        return h
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, y = ctx.saved_tensors
-        dy = dy.float().contiguous()
-        P, K = x.shape
-        N = weight.shape[0]
-        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        masked = ctx.slope != 1.0
-        dpre = torch.empty_like(dy) if masked else dy          # dY (.) act'(y): operand of the weight-gradient GEMM
+        L = ctx.n_layers
+        acts, weights = ctx.saved_tensors[:L + 1], ctx.saved_tensors[L + 1:]
+        dpre = dy.float().contiguous()
+        if ctx.slopes[-1] != 1.0:                             # a chain that ENDS in an activation (not the fields' case)
+            dpre = dpre * torch.where(acts[L] > 0, 1.0, ctx.slopes[-1])
+        grads = [None] * (2 * L)
         dx = None
-        if need_x or masked:
-            dx = torch.empty((P, K), dtype=torch.float32, device=x.device)
-            check(_lib.lib().d3ga_mlp_linear(P, N, K, dptr(dy), dptr(y) if masked else None, ctx.slope,
-                                             dptr(dpre) if masked else None, dptr(_panel(weight, False)), None, 1.0,
-                                             dptr(dx), stream_handle()), "d3ga_mlp_linear")
-        dw = db = None
-        if need_w or need_b:                                   # dW = dPre^T X (a reduction over all rows), db = column sums
-            dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
-            db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_b else None
-            check(_lib.lib().d3ga_mlp_wgrad(P, N, K, dptr(dpre), dptr(x), dptr(dw), dptr(db), stream_handle()),
-                  "d3ga_mlp_wgrad")
-        return (dx if need_x else None), (dw if need_w else None), db, None
+        for i in range(L - 1, -1, -1):
+            w, x_in = weights[i], acts[i]
+            N, K = w.shape
+            need_w, need_b = ctx.needs_input_grad[2 + 2 * i], ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]
+            if need_w or need_b:                              # dW = dPre^T X (a reduction over all rows), db = column sums
+                dw = torch.empty((N, K), dtype=torch.float32, device=dpre.device)
+                db = torch.empty((N,), dtype=torch.float32, device=dpre.device) if need_b else None
+                check(_lib.lib().d3ga_mlp_wgrad(dpre.shape[0], N, K, dptr(dpre), dptr(x_in), dptr(dw), dptr(db),
+                                                stream_handle()), "d3ga_mlp_wgrad")
+                grads[2 * i], grads[2 * i + 1] = (dw if need_w else None), db
+            if i > 0:                                         # dPre of the layer below: (dPre W) (.) act'_{i-1}(h_i)
+                below = ctx.slopes[i - 1]
+                dpre = _linear(dpre, _panel(w, False), None, 1.0, K, mask_bits=ctx.signs[i - 1] if below != 1.0 else None,
+                               mask_slope=below)[0]
+            elif ctx.needs_input_grad[0]:
+                dx = _linear(dpre, _panel(w, False), None, 1.0, K)[0]
+        return (dx, None, *grads)
 
 
 def linear_act(x, weight, bias=None, negative_slope=1.0):
     """``leaky_relu(F.linear(x, weight, bias), negative_slope)`` in one launch (negative_slope=1: no activation)."""
-    return _LinearAct.apply(x, weight, bias, negative_slope)
+    return _Chain.apply(x, (negative_slope,), weight, bias)
+
+
+def mlp_chain(x, layers, slopes):
+    """The whole trunk as ONE autograd node: layers = [(weight, bias), ...], slopes[i] the leaky_relu slope after layer i."""
+    flat = [t for wb in layers for t in wb]
+    return _Chain.apply(x, tuple(slopes), *flat)
 
 
 class FieldMLP(nn.Module):
@@ -130,10 +157,12 @@ class FieldMLP(nn.Module):
         if bcs:
             bias0 = F.linear(torch.cat(bcs).reshape(1, -1), first.weight.index_select(1, torch.tensor(bc_cols, device=dev)),
                              first.bias)[0]
-        h = linear_act(torch.cat(rows, dim=1) if len(rows) > 1 else rows[0], w_row, bias0, 0.1)
-        for layer in list(self.network)[1:]:
-            h = linear_act(h, layer.weight, layer.bias, 0.1)
-        return linear_act(h, self.output.weight, self.output.bias, 1.0)
+        return self._trunk(torch.cat(rows, dim=1) if len(rows) > 1 else rows[0], w_row, bias0)
+
+    def _trunk(self, x, w_first, b_first):
+        hidden = list(self.network)[1:]
+        layers = [(w_first, b_first)] + [(l.weight, l.bias) for l in hidden] + [(self.output.weight, self.output.bias)]
+        return mlp_chain(x, layers, [0.1] * (1 + len(hidden)) + [1.0])
 
     def forward(self, row_feats, broadcast):
         """z = [broadcast.expand(P, -1) | row_feats] (the reference's column order) -> (P, n_output)."""
@@ -143,10 +172,7 @@ class FieldMLP(nn.Module):
             bias0 = F.linear(broadcast.reshape(1, nb), first.weight[:, :nb], first.bias)[0]  # folded pose columns
         else:
             bias0 = first.bias
-        h = linear_act(row_feats, first.weight[:, nb:], bias0, 0.1)
-        for layer in list(self.network)[1:]:
-            h = linear_act(h, layer.weight, layer.bias, 0.1)
-        return linear_act(h, self.output.weight, self.output.bias, 1.0)
+        return self._trunk(row_feats, first.weight[:, nb:], bias0)
 
 
 class CanonicalField(FieldMLP):

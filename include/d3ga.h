@@ -253,24 +253,26 @@ int d3ga_knn3_mean_dist2(int P, const float *points, float *out, d3ga_stream_t s
  * z -> [Linear(128) + leaky_relu(0.1)] x (1 + n_layers) -> Linear -- on the matrix cores with f32-equivalent accuracy:
  * every f32 operand is split exactly into three bf16 pieces and the six leading cross products are accumulated in f32
  * (v_mfma_f32_32x32x16_bf16); the dropped products are below 2^-24 |x||w|, the rounding of an f32 fmaf chain.
- *   Y (P, n_out) = act_out( A (P,K) . W + bias ),  act_out(y) = y > 0 ? y : out_slope * y   (out_slope = 1: identity)
- *   A = X, or, with mask != NULL, A = X (.) (mask > 0 ? 1 : mask_slope)  -- the leaky_relu backward applied to an
- *   incoming gradient X = dY with mask = the layer's output; A is then also written to a_out (P,K) when non-NULL
- *   (it is the operand of the weight-gradient GEMM dW = A^T . input).
+ *   Y (P, n_out) = act_out( X (P,K) . W + bias ),  act_out(y) = y > 0 ? y : out_slope * y   (out_slope = 1: identity)
+ *   sign_out (P, ceil(n_out/32)) uint32, optional: bit (n & 31) of word [r][n >> 5] = (Y[r][n] > 0) -- all the backward
+ *   needs of a leaky_relu output.
+ *   mask_bits (same layout), optional:  Y (.)= (bit ? 1 : mask_slope)  -- the backward chain: X = dPre of a layer, W its
+ *   transposed weights, mask_bits = the sign bits of the layer below, so that Y is THAT layer's dPre (the operand of
+ *   its weight gradient dW = dPre^T . input and of the next call); no masked copy is ever written.
  *   panel: the split weights in the kernel's operand order, d3ga_mlp_panel_bytes(K, n_out) bytes, written by
  *   d3ga_mlp_pack_weights from plain f32 weights: weight of input k for output n = W[k*ld_k + n*ld_n]
  *   (an nn.Linear weight (n_out,K): ld_k = 1, ld_n = K; the input-gradient GEMM of the same layer contracts over the
  *   layer's outputs: K := n_out, n_out := K, ld_k = K_layer, ld_n = 1).  Re-pack whenever the weights change.
- *   K <= 128, n_out <= 128; X, mask, a_out, panel 16-byte aligned.  bias may be NULL.
+ *   K <= 128, n_out <= 128; X, panel 16-byte aligned.  bias may be NULL.
  * ------------------------------------------------------------------------------------------------------- */
 int64_t d3ga_mlp_panel_bytes(int32_t K, int32_t n_out);          /* < 0: D3GA_E_SIZE */
 int d3ga_mlp_pack_weights(int32_t K, int32_t n_out, const float *W, int64_t ld_k, int64_t ld_n, void *panel,
                           d3ga_stream_t stream);
-int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const float *mask, float mask_slope,
-                    float *a_out, const void *panel, const float *bias, float out_slope, float *Y, d3ga_stream_t stream);
+int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const void *panel, const float *bias,
+                    float out_slope, uint32_t *sign_out, const uint32_t *mask_bits, float mask_slope, float *Y,
+                    d3ga_stream_t stream);
 /* Weight and bias gradient of that layer: dW (N,K) = dPre^T . X, db (N) = column sums of dPre (db may be NULL);
- * dPre (P,N) = the a_out of the input-gradient call (or dY itself for a layer without activation), X (P,K) the layer's
- * input.  Both outputs are zeroed by the call; partial sums meet through float atomics. */
+ * dPre (P,N) = the gradient at the layer's pre-activation (see above), X (P,K) the layer's input.  Both outputs are zeroed by the call; partial sums meet through float atomics. */
 int d3ga_mlp_wgrad(int32_t P, int32_t N, int32_t K, const float *dpre, const float *X, float *dW, float *db,
                    d3ga_stream_t stream);
 

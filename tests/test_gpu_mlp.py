@@ -105,6 +105,29 @@ def test_view_dirs_and_sh4_encoding_match_oracle(P):
     assert rel_err(md.grad.cpu().numpy(), m64.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("P,K,N", [(64, 128, 128), (300, 128, 128), (300, 48, 96), (1000, 128, 11), (33, 20, 40)])
+def test_sign_bits_and_mask_epilogue(P, K, N):
+    """d3ga_mlp_linear's side outputs: one sign bit per element of the activated output, and the same bits applied as the
+    leaky_relu derivative in the epilogue of the backward GEMM."""
+    from d3ga_amd.mlp import _linear, _panel
+    g = torch.Generator().manual_seed(P + K + N)
+    x = torch.randn(P, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    y, sign = _linear(x, _panel(w, True), b, 0.1, N, want_sign=True)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.linear(x.double(), w.double(), b.double()), 0.1)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    bits = ((sign.cpu().numpy().view(np.uint32)[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(P, -1)[:, :N]
+    assert np.array_equal(bits.astype(bool), (y > 0).cpu().numpy())
+    # backward GEMM of a layer ABOVE (M outputs) whose input is y: dPre_below = (dPre_above @ W_above) (.) lrelu'(y)
+    M = 64
+    w2 = (torch.randn(M, N, generator=g) / N ** 0.5).to(DEV)
+    d_above = torch.randn(P, M, generator=g).to(DEV)
+    d_below = _linear(d_above, _panel(w2, False), None, 1.0, N, mask_bits=sign, mask_slope=0.1)[0]
+    ref2 = (d_above.double() @ w2.double()) * torch.where(y > 0, 1.0, 0.1).double()
+    np.testing.assert_allclose(d_below.cpu().numpy(), ref2.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("P,K,N,slope", [(1, 128, 128, 0.1), (127, 11, 128, 0.1), (1000, 128, 11, 1.0), (4099, 45, 128, 0.1),
                                          (300, 128, 3, 1.0), (513, 64, 96, 0.1)])
 def test_linear_act_against_torch(P, K, N, slope):
