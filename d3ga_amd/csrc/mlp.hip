@@ -266,116 +266,151 @@ __global__ __launch_bounds__(kMlpThreads) void linear_kernel(int P, int K, int n
     }
 }
 
-// Weight gradient dW (N,K) += dPre^T (N x rows) . X (rows x K): the contraction runs over the ROWS.  A workgroup owns a
-// contiguous row range and walks it in chunks of 64 rows: both operands of the chunk are fetched ONCE with full-width
-// loads into registers (next chunk) / LDS (current chunk), then one wavefront per 32x32 block of dW (NBn x NBk wavefronts)
-// reads dPre[row][32 nb + (l & 31)] and X[row][32 kb + (l & 31)] for row = 2 s + (l >> 5) from LDS.  (First version: every
-// wavefront fetched its operands from global memory itself -- each 128-byte segment was requested by four wavefronts at
-// different times, 2 GB of L2 traffic per 128x128 layer: 311 us at 500k rows.)  Partial results meet in global memory
-// through float atomics (dW zeroed by the launcher); the kb == 0 wavefronts also accumulate the bias gradient.
+// Weight gradient dW (N,K) += dPre^T (N x rows) . X (rows x K): the contraction runs over the ROWS, so the MFMA operands
+// are COLUMNS of the row-major arrays -- lane l needs 8 consecutive rows of one column as one bf16x8.  A workgroup owns
+// a contiguous row range and walks it in chunks of 64 rows.  Wavefronts 0-7 fetch dPre, 8-15 fetch X: wavefront w owns
+// the 8 rows of row group w & 7, lane l the columns 2l, 2l+1 (every load instruction is one full 512-byte row), so after
+// the loads a lane HOLDS its two columns' 8 rows: it splits them (same exact 3-way bf16 split as above) and writes
+// operand-ready 16-byte units [plane][row group][column] -- the transpose costs nothing.  Then one wavefront per 32x32
+// block of dW (NBn x NBk of the 16) multiplies: 4 k-steps x 6 products per chunk.  The next chunk's loads are in flight
+// meanwhile.  Partial results meet in global memory through float atomics (dW zeroed by the launcher); the dPre loaders
+// also accumulate the bias gradient from their f32 values.  (History: per-wavefront global fetches 311 us per 128x128
+// layer at 500k rows; LDS-staged f32 MFMA 202 us.)
 constexpr int kWgRows = 64;
-constexpr int kWgThreads = 1024;     // 16 wavefronts: NBn x NBk of them own a block of dW, all of them move data
+constexpr int kWgThreads = 1024;     // 16 wavefronts: all of them move data, NBn x NBk of them own a block of dW
+constexpr int kWgPlaneUnits = 8 * 128;              // 16-byte units per plane of one operand: [row group][column]
+constexpr int kWgOperandBytes = 3 * kWgPlaneUnits * 16;
 
-// one operand array of a chunk: global -> registers (issue) -> LDS (commit).  VEC: 16-byte pieces (width % 4 == 0),
-// two per thread; else scalars, eight per thread (64 x 128 floats / 1024 threads).
-template <bool VEC>
-struct WgPiece { float4 v[VEC ? 2 : 1]; float s[VEC ? 1 : 8]; };
-template <bool VEC>
-__device__ __forceinline__ void wg_issue(WgPiece<VEC> &p, const float *__restrict__ src, int width, int r0, int r_end, int tid) {
-    if constexpr (VEC) {
-        const int w4 = width / 4;
+// A loader job: this lane fetches 8 consecutive rows (row group g of the chunk) of the columns c, c+1 (nc = 2) or c
+// (nc = 1) of one operand: global -> registers (issue; raw values, clamped addresses) -> LDS units (commit).
+struct WgJob {
+    const float *src;    // operand (row-major, `width` columns); nullptr: no job
+    uint4 *s_op;         // its planes in LDS
+    int width, g, c, nc;
+    bool is_a;           // dPre: its f32 values also feed the bias gradient
+};
+template <bool VEC2>
+__device__ __forceinline__ void wg_issue(float2 (&v)[8], const WgJob &job, int r0, int r_end) {
+    const int c = job.c, w = job.width;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = tid + u * kWgThreads, r = i / w4, c = i - r * w4;
-            const int rr = min(r0 + min(r, kWgRows - 1), r_end - 1);
-            p.v[u] = *reinterpret_cast<const float4 *>(src + (uint32_t)rr * (uint32_t)width + 4 * c);
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = tid + u * kWgThreads, r = i / width, c = i - r * width;
-            const int rr = min(r0 + min(r, kWgRows - 1), r_end - 1);
-            p.s[u] = src[(uint32_t)rr * (uint32_t)width + c];
-        }
+    for (int i = 0; i < 8; ++i) {
+        const int rr = min(r0 + 8 * job.g + i, r_end - 1);
+        const uint32_t o = (uint32_t)rr * (uint32_t)w;
+        if (VEC2 && job.nc == 2) v[i] = *reinterpret_cast<const float2 *>(job.src + o + (c < w ? c : 0));
+        else v[i] = make_float2(job.src[o + (c < w ? c : 0)], job.src[o + (c + 1 < w ? c + 1 : 0)]);
     }
 }
-template <bool VEC>
-__device__ __forceinline__ void wg_commit(const WgPiece<VEC> &p, float *dst, int pitch, int width, int r0, int r_end, int tid) {
-    if constexpr (VEC) {                                               // rows past the range are stored as zeros
-        const int w4 = width / 4;
+__device__ __forceinline__ void wg_commit(const float2 (&v)[8], const WgJob &job, int r0, int r_end, float (&colsum)[2]) {
+    const int c = job.c;
+    float x[8], y[8];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = tid + u * kWgThreads, r = i / w4, c = i - r * w4;
-            if (r < kWgRows) *reinterpret_cast<float4 *>(dst + r * pitch + 4 * c) = (r0 + r < r_end) ? p.v[u] : make_float4(0, 0, 0, 0);
-        }
-    } else {
+    for (int i = 0; i < 8; ++i) {
+        const bool ok = r0 + 8 * job.g + i < r_end;
+        x[i] = (ok && c < job.width) ? v[i].x : 0.f;
+        y[i] = (ok && job.nc == 2 && c + 1 < job.width) ? v[i].y : 0.f;
+        colsum[0] += x[i];
+        colsum[1] += y[i];
+    }
+    uint32_t px[3][4], py[3][4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = tid + u * kWgThreads, r = i / width, c = i - r * width;
-            if (r < kWgRows) dst[r * pitch + c] = (r0 + r < r_end) ? p.s[u] : 0.f;
-        }
+    for (int q = 0; q < 4; ++q) {
+        bf16_split2(x[2 * q], x[2 * q + 1], px[0][q], px[1][q], px[2][q]);
+        bf16_split2(y[2 * q], y[2 * q + 1], py[0][q], py[1][q], py[2][q]);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        uint4 *d = job.s_op + pl * kWgPlaneUnits + job.g * 128 + c;
+        d[0] = make_uint4(px[pl][0], px[pl][1], px[pl][2], px[pl][3]);
+        if (job.nc == 2) d[1] = make_uint4(py[pl][0], py[pl][1], py[pl][2], py[pl][3]);
     }
 }
 
-template <bool VECA, bool VECB>
+// Loader assignment (all wave-uniform).  Both operands wide: wavefronts 0-7 take dPre, 8-15 take X, row group w & 7, lane l
+// the columns 2l, 2l+1.  One operand narrow (<= 16 columns: the first and last layers of the fields): the WIDE one is
+// spread over all 16 wavefronts (row group w & 7, column 64 (w >> 3) + l) so that as many bytes stay in flight as in
+// the square case, and wavefront 0 fetches the whole narrow chunk as a second job (row group l >> 3, columns 2 (l & 7)).
+template <bool VECA, bool VECB, bool MIXED>
 __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(int P, int N, int K, int NBk, int n_blocks, int rows_per_block,
                                                            const float *__restrict__ dpre, const float *__restrict__ X,
                                                            float *__restrict__ dW, float *__restrict__ db) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];       // s_a [64][NP] | s_b [64][KP]
+    extern __shared__ __attribute__((aligned(16))) char smem_wg[];     // dPre planes | X planes
+    uint4 *s_a = reinterpret_cast<uint4 *>(smem_wg), *s_b = reinterpret_cast<uint4 *>(smem_wg + kWgOperandBytes);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int nthreads = kWgThreads;
     const bool worker = wave < n_blocks;                               // wave-uniform: owns a 32x32 block of dW
     const int nb = wave / NBk, kb = wave - nb * NBk;
     const int half = lane >> 5, l32 = lane & 31;
-    const int NP = 32 * ((N + 31) / 32), KP = 32 * ((K + 31) / 32);
-    float *s_a = smem, *s_b = smem + kWgRows * NP;
-    const int n = 32 * nb + l32, k = 32 * kb + l32;
     const int r_begin = blockIdx.x * rows_per_block;
     const int r_end = min(P, r_begin + rows_per_block);
-    WgPiece<VECA> pa_r;
-    WgPiece<VECB> pb_r;
+    if (r_begin >= r_end) return;
+    const bool narrow_a = MIXED && N <= 16, narrow_b = MIXED && K <= 16;      // !MIXED: the launcher saw two wide operands
+    WgJob j1 = {nullptr, nullptr, 0, 0, 0, 0, false}, j2 = j1;
+    const WgJob wide2_a = {dpre, s_a, N, wave & 7, 2 * lane, 2, true}, wide2_b = {X, s_b, K, wave & 7, 2 * lane, 2, false};
+    const WgJob wide1_a = {dpre, s_a, N, wave & 7, 64 * (wave >> 3) + lane, 1, true};
+    const WgJob wide1_b = {X, s_b, K, wave & 7, 64 * (wave >> 3) + lane, 1, false};
+    const WgJob small_a = {dpre, s_a, N, lane >> 3, 2 * (lane & 7), 2, true}, small_b = {X, s_b, K, lane >> 3, 2 * (lane & 7), 2, false};
+    if (!narrow_a && !narrow_b) j1 = wave < 8 ? wide2_a : wide2_b;
+    else if (narrow_a && !narrow_b) { j1 = wide1_b; if (wave == 0) j2 = small_a; }
+    else if (!narrow_a && narrow_b) { j1 = wide1_a; if (wave == 0) j2 = small_b; }
+    else { if (wave == 0) j1 = small_a; if (wave == 8) j1 = small_b; }
+    float2 v1[8], v2[8];
+    float cs1[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
     auto issue = [&](int r0) __attribute__((always_inline)) {
-        wg_issue<VECA>(pa_r, dpre, N, r0, r_end, tid);
-        wg_issue<VECB>(pb_r, X, K, r0, r_end, tid);
+        if (j1.src) { if (j1.is_a) wg_issue<VECA>(v1, j1, r0, r_end); else wg_issue<VECB>(v1, j1, r0, r_end); }
+        if constexpr (MIXED) { if (j2.src) wg_issue<false>(v2, j2, r0, r_end); }
     };
-    auto commit = [&](int r0) __attribute__((always_inline)) {
-        wg_commit<VECA>(pa_r, s_a, NP, N, r0, r_end, tid);
-        wg_commit<VECB>(pb_r, s_b, KP, K, r0, r_end, tid);
-    };
-    // zero the pad columns once (they are never written by commit)
-    for (int i = tid; i < kWgRows * (NP + KP); i += nthreads) smem[i] = 0.f;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float bsum = 0.f;
-    if (r_begin < r_end) issue(r_begin);
+    if (narrow_a || narrow_b) {    // columns no job writes must read as zero (a narrow job covers 16 columns, MFMA blocks are 32)
+        for (int u = tid; u < 2 * 3 * kWgPlaneUnits; u += kWgThreads) reinterpret_cast<uint4 *>(smem_wg)[u] = make_uint4(0, 0, 0, 0);
+    }
+    issue(r_begin);
     for (int r0 = r_begin; r0 < r_end; r0 += kWgRows) {
         __syncthreads();                                               // previous chunk's LDS reads are done
-        commit(r0);
+        if (j1.src) wg_commit(v1, j1, r0, r_end, cs1);
+        if constexpr (MIXED) { if (j2.src) wg_commit(v2, j2, r0, r_end, cs2); }
         __syncthreads();
-        if (r0 + kWgRows < r_end) issue(r0 + kWgRows);                 // prefetch while the MFMAs below run
+        issue(min(r0 + kWgRows, r_end - 1));                           // prefetch while the MFMAs below run (clamped rows)
         if (worker) {
-            const float *pa = s_a + half * NP + n, *pb = s_b + half * KP + k;
-#pragma unroll 8
-            for (int s2 = 0; s2 < kWgRows / 2; ++s2) {
-                const float a = pa[2 * s2 * NP], b = pb[2 * s2 * KP];
-                bsum += a;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            const uint4 *pa = s_a + half * 128 + 32 * nb + l32, *pb = s_b + half * 128 + 32 * kb + l32;
+#pragma unroll
+            for (int ks = 0; ks < kWgRows / 16; ++ks) {
+                bf16x8_t a[3], b[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[pl] = __builtin_bit_cast(bf16x8_t, pa[pl * kWgPlaneUnits + 2 * ks * 128]);
+                    b[pl] = __builtin_bit_cast(bf16x8_t, pb[pl * kWgPlaneUnits + 2 * ks * 128]);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
             }
         }
     }
+    // bias gradient: every dPre loader lane holds the sums of its columns over its row groups; meet in LDS (float
+    // atomics on 128 words), then one global atomic per column
+    if (db) {
+        __syncthreads();
+        float *s_sum = reinterpret_cast<float *>(smem_wg);
+        if (tid < 128) s_sum[tid] = 0.f;
+        __syncthreads();
+        if (j1.src && j1.is_a) { if (j1.c < N) atomicAdd(s_sum + j1.c, cs1[0]); if (j1.nc == 2 && j1.c + 1 < N) atomicAdd(s_sum + j1.c + 1, cs1[1]); }
+        if (MIXED && j2.src && j2.is_a) { if (j2.c < N) atomicAdd(s_sum + j2.c, cs2[0]); if (j2.c + 1 < N) atomicAdd(s_sum + j2.c + 1, cs2[1]); }
+        __syncthreads();
+        if (tid < N) atomicAdd(db + tid, s_sum[tid]);
+    }
     if (!worker) return;
     // C/D layout: col = lane & 31 -> k, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> n
+    const int k = 32 * kb + l32;
     if (k < K) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int nn = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (nn < N) atomicAdd(dW + (uint32_t)nn * (uint32_t)K + (uint32_t)k, acc[r]);
         }
-    }
-    if (db && kb == 0) {
-        bsum += __shfl_xor(bsum, 32);
-        if (half == 0 && n < N) atomicAdd(db + n, bsum);
     }
 }
 
@@ -477,15 +512,32 @@ extern "C" int d3ga_mlp_wgrad(int32_t P, int32_t N, int32_t K, const float *dpre
     int rows = (P + grid - 1) / grid;
     rows = ((rows + kWgRows - 1) / kWgRows) * kWgRows;                 // whole chunks
     grid = (P + rows - 1) / rows;
-    const size_t lds = (size_t)kWgRows * (32 * NBn + 32 * NBk) * sizeof(float);
-    const bool va = N % 4 == 0, vb = K % 4 == 0;                       // 16-byte pieces need 16-byte aligned rows
-#define D3GA_WG(VA, VB)                                                                                               \
-    hipLaunchKernelGGL((wgrad_kernel<VA, VB>), dim3(grid), dim3(kWgThreads), lds, s, P, N, K, NBk, NBn * NBk, rows, dpre, \
-                       X, dW, db)
-    if (va && vb) D3GA_WG(true, true);
-    else if (va) D3GA_WG(true, false);
-    else if (vb) D3GA_WG(false, true);
-    else D3GA_WG(false, false);
+    const size_t lds = 2 * (size_t)kWgOperandBytes;
+    const bool va = N % 2 == 0 && ((uintptr_t)dpre & 7) == 0, vb = K % 2 == 0 && ((uintptr_t)X & 7) == 0;   // float2 loads
+    const bool mixed = N <= 16 || K <= 16;
+#define D3GA_WG(VA, VB, MX)                                                                                           \
+    do {                                                                                                              \
+        static bool attr[64] = {};                                                                                    \
+        int dev = 0;                                                                                                  \
+        D3GA_HIP(hipGetDevice(&dev));                                                                                 \
+        if (dev >= 0 && dev < 64 && !attr[dev]) {                                                                     \
+            D3GA_HIP(hipFuncSetAttribute((const void *)wgrad_kernel<VA, VB, MX>,                                      \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+            attr[dev] = true;                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((wgrad_kernel<VA, VB, MX>), dim3(grid), dim3(kWgThreads), lds, s, P, N, K, NBk, NBn * NBk, \
+                           rows, dpre, X, dW, db);                                                                    \
+    } while (0)
+#define D3GA_WG2(VA, VB)                                                                                              \
+    do {                                                                                                              \
+        if (mixed) D3GA_WG(VA, VB, true);                                                                             \
+        else D3GA_WG(VA, VB, false);                                                                                  \
+    } while (0)
+    if (va && vb) D3GA_WG2(true, true);
+    else if (va) D3GA_WG2(true, false);
+    else if (vb) D3GA_WG2(false, true);
+    else D3GA_WG2(false, false);
+#undef D3GA_WG2
 #undef D3GA_WG
     return check_launch(s, 0);
 }

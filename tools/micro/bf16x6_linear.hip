@@ -8,6 +8,12 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#ifndef VARIANT
+#define VARIANT 0
+#endif
+#ifndef MODE
+#define MODE 0
+#endif
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -31,6 +37,9 @@ __device__ __forceinline__ void split4(float4 x, uint2 &p0, uint2 &p1, uint2 &p2
 }
 // slot h (k-half of a 32-k chunk): v[0] = rows 0-15, v[1] = rows 16-31; lane l: row 16 j + (l >> 2), 16 bytes (l & 3) of 64
 __device__ __forceinline__ void issue(float4 (&v)[2], const float *__restrict__ X, int row0, int k0, int lane) {
+#if MODE == 3
+    if (k0 >= 0) return;                      // compute only: keep the first values
+#endif
 #pragma unroll
     for (int j = 0; j < 2; ++j)
         v[j] = *reinterpret_cast<const float4 *>(X + ((unsigned)(row0 + 16 * j + (lane >> 2)) * (unsigned)K + (unsigned)(k0 + 4 * (lane & 3))));
@@ -81,6 +90,11 @@ __global__ __launch_bounds__(kThreads) void linear_bf16x6(int P, const float *__
             const bool same = kp + 2 < KK;
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_wave_barrier();
+#if MODE == 2
+            if (kh) { acc[0][0] += vb[0].x + vb[1].y; issue(vb, X, same ? row0 : nrow0, same ? 16 * (kk + 2) : 16, lane); }
+            else    { acc[0][1] += va[0].x + va[1].y; issue(va, X, same ? row0 : nrow0, same ? 16 * (kk + 2) : 0, lane); }
+            continue;
+#endif
             if (kh) { commit(s_a, vb, lane); issue(vb, X, same ? row0 : nrow0, same ? 16 * (kk + 2) : 16, lane); }
             else    { commit(s_a, va, lane); issue(va, X, same ? row0 : nrow0, same ? 16 * (kk + 2) : 0, lane); }
             __builtin_amdgcn_wave_barrier();
@@ -88,6 +102,36 @@ __global__ __launch_bounds__(kThreads) void linear_bf16x6(int P, const float *__
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 a[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(s_a + p * kAPlane + half * kAHalf + l32 * 16));
+#if MODE == 1
+            acc[0][2] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, a[0]).x ^ __builtin_bit_cast(uint4, a[1]).y ^ __builtin_bit_cast(uint4, a[2]).z);
+            continue;
+#endif
+#if VARIANT & 2
+            __builtin_amdgcn_s_setprio(3);
+#endif
+#if VARIANT & 1
+#pragma unroll
+            for (int nb = 0; nb < NB; nb += 2) {
+                bf16x8 w[3], u[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    w[p] = __builtin_bit_cast(bf16x8, s_w[(((p * KK + kk) * 2 + half) * NB + nb) * 32 + l32]);
+                    u[p] = __builtin_bit_cast(bf16x8, s_w[(((p * KK + kk) * 2 + half) * NB + nb + 1) * 32 + l32]);
+                }
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], w[0], acc[nb], 0, 0, 0);
+                acc[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], u[0], acc[nb + 1], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], w[1], acc[nb], 0, 0, 0);
+                acc[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], u[1], acc[nb + 1], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[2], acc[nb], 0, 0, 0);
+                acc[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], u[2], acc[nb + 1], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], w[0], acc[nb], 0, 0, 0);
+                acc[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], u[0], acc[nb + 1], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[1], acc[nb], 0, 0, 0);
+                acc[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], u[1], acc[nb + 1], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[0], acc[nb], 0, 0, 0);
+                acc[nb + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], u[0], acc[nb + 1], 0, 0, 0);
+            }
+#else
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 bf16x8 w[3];
@@ -101,6 +145,10 @@ __global__ __launch_bounds__(kThreads) void linear_bf16x6(int P, const float *__
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[1], acc[nb], 0, 0, 0);
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[0], acc[nb], 0, 0, 0);
             }
+#endif
+#if VARIANT & 2
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
