@@ -271,7 +271,7 @@ def cpu_baseline(wl_name, budget_s=20.0):
 
 def field_mlp_bench(args):
     """CanonicalField (models/mlp.py:74-110, widths of configs/actorshq_actor02.yml) forward + backward to inputs and weights
-    over the workload's Gaussians: rows/s, achieved f32 MFMA rate, the same module under ATen on this GPU and the oracle on
+    over the workload's Gaussians: rows/s, achieved HBM rate (and the f32-equivalent FLOP rate), the same module under ATen on this GPU and the oracle on
     the host cores."""
     from d3ga_amd import synthetic as syn
     from d3ga_amd.mlp import CanonicalField
@@ -312,12 +312,22 @@ def field_mlp_bench(args):
     ms = timed(fused, args.steps)
     ms_aten = timed(aten, max(5, args.steps // 4))
     flops = 3 * 2.0 * P * (11 * 128 + 3 * 128 * 128 + 128 * 11)         # forward + input-gradient + weight-gradient GEMMs
+    # algorithmic bytes per row (f32 = 4 B): every GEMM reads its row operand(s) and writes its result once; sign bits 16 B
+    widths = [11, 128, 128, 128, 128, 11]                                # 109 -> 128 x4 -> 11 with the 98 pose columns folded
+    fwd_b = sum(4 * (a + b) for a, b in zip(widths[:-1], widths[1:])) + 16 * 4
+    dx_b = sum(4 * (a + b) for a, b in zip(widths[:-1], widths[1:])) + 16 * 4
+    wg_b = sum(4 * (a + b) for a, b in zip(widths[:-1], widths[1:]))
+    hbm_bytes = float(P) * (fwd_b + dx_b + wg_b)
     out = {"metric": f"CanonicalField fwd+bwd rows/sec ({P} Gaussians, 109->128x4->11, f32)", "value": round(P / (ms * 1e-3), 1),
            "unit": "rows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"CanonicalField over the Gaussians of {args.workload}", "rows": P},
-           "roofline": {"kernel": "linear_kernel + wgrad_kernel", "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2),
-                        "peak": 157.3, "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / 157.3, 4), "traffic": None},
+           # the split-bf16 products (6 per f32 product, 16x the f32 MFMA rate) leave the layers HBM-bound
+           "roofline": {"kernel": "linear_kernel + wgrad_kernel", "bound": "hbm", "achieved": round(hbm_bytes / (ms * 1e-3) / 1e9, 1),
+                        "peak": 8000.0, "unit": "GB/s", "frac": round(hbm_bytes / (ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                        "f32_equivalent_tflops": round(flops / (ms * 1e-3) / 1e12, 2), "f32_mfma_peak_tflops": 157.3,
+                        "arithmetic": "exact 3-way bf16 split of every f32 operand, 6 products on v_mfma_f32_32x32x16_bf16, "
+                                      "f32 accumulate (error of an f32 fmaf chain)"},
            "same_gpu_aten_ms": round(ms_aten, 4)}
     if not args.no_cpu_baseline:
         n = min(P, 50_000)
