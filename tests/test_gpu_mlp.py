@@ -105,6 +105,30 @@ def test_view_dirs_and_sh4_encoding_match_oracle(P):
     assert rel_err(md.grad.cpu().numpy(), m64.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("spread", [0.0, 4.0])
+def test_split_bf16_products_have_f32_accuracy(spread):
+    """The dense layer splits every f32 operand exactly into three bf16 pieces and keeps six of the nine cross products
+    (DESIGN.md sec. 4b).  Claim under test: the result is as accurate as f32 arithmetic -- the error against f64, in units
+    of 2^-24 sum_k |x_k||w_k| per output, is no larger than that of ATen's f32 GEMM on the same data (measured: 10-35 %
+    smaller) -- also when the magnitudes of the operands spread over many binades (spread = decades)."""
+    from d3ga_amd.mlp import linear_act
+    P, K, N = 4096, 128, 128
+    g = torch.Generator().manual_seed(int(spread) + 5)
+    mag = lambda *shape: 10.0 ** (spread * (torch.rand(*shape, generator=g) - 0.5))
+    x = (torch.randn(P, K, generator=g) * mag(P, K)).to(DEV)
+    w = (torch.randn(N, K, generator=g) * mag(N, K) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    with torch.no_grad():
+        y = linear_act(x, w, b, 1.0).double()
+        ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+        y32 = torch.nn.functional.linear(x, w, b).double()
+        bound = (x.double().abs() @ w.double().abs().t() + b.double().abs()) * 2.0 ** -24
+    err, err32 = (y - ref).abs() / bound, (y32 - ref).abs() / bound
+    assert float(err.max()) < 32.0, float(err.max())                  # sqrt(K)-ish multiples of one f32 rounding
+    assert float(err.max()) <= 1.25 * float(err32.max()), (float(err.max()), float(err32.max()))
+    assert float(err.mean()) <= 1.1 * float(err32.mean()), (float(err.mean()), float(err32.mean()))
+
+
 @pytest.mark.parametrize("P,K,N", [(64, 128, 128), (300, 128, 128), (300, 48, 96), (1000, 128, 11), (33, 20, 40)])
 def test_sign_bits_and_mask_epilogue(P, K, N):
     """d3ga_mlp_linear's side outputs: one sign bit per element of the activated output, and the same bits applied as the
