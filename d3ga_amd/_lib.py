@@ -60,6 +60,7 @@ _SIGNATURES = {
     "d3ga_mlp_pack_weights": ([ctypes.c_int32, ctypes.c_int32, _vp, _i64, _i64, _vp, _vp], _i),
     "d3ga_mlp_linear": ([ctypes.c_int32] * 3 + [_vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp, _vp], _i),
     "d3ga_mlp_wgrad": ([ctypes.c_int32] * 3 + [_vp] * 4 + [_vp], _i),
+    "d3ga_mlp_wgrad_acc": ([ctypes.c_int32] * 3 + [_vp] * 4 + [_vp], _i),
     "d3ga_view_dirs_fwd": ([ctypes.c_int32, _vp, _vp, _vp, _vp], _i),
     "d3ga_view_dirs_bwd": ([ctypes.c_int32, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_sh4_encoding_fwd": ([ctypes.c_int32, _vp, _vp, _vp], _i),

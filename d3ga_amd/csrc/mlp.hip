@@ -496,15 +496,17 @@ extern "C" int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float 
     return check_launch(s, 0);
 }
 
-// dW (N,K) = dPre^T . X and (optionally) db (N) = column sums of dPre; both outputs are zeroed by the call.
-extern "C" int d3ga_mlp_wgrad(int32_t P, int32_t N, int32_t K, const float *dpre, const float *X, float *dW, float *db,
-                              d3ga_stream_t stream) {
+// dW (N,K) (+)= dPre^T . X and (optionally) db (N) (+)= column sums of dPre
+static int mlp_wgrad_launch(int32_t P, int32_t N, int32_t K, const float *dpre, const float *X, float *dW, float *db,
+                            bool zero_first, d3ga_stream_t stream) {
     if (P < 0 || N < 1 || N > 128 || K < 1 || K > 128) return D3GA_E_SIZE;
     if (!dW) return D3GA_E_NULL;
     if ((int64_t)P * N >= (1ll << 31) || (int64_t)P * K >= (1ll << 31)) return D3GA_E_SIZE;
     hipStream_t s = (hipStream_t)stream;
-    D3GA_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, s));
-    if (db) D3GA_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, s));
+    if (zero_first) {
+        D3GA_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, s));
+        if (db) D3GA_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, s));
+    }
     if (P == 0) return D3GA_OK;
     if (!dpre || !X) return D3GA_E_NULL;
     const int NBn = (N + 31) / 32, NBk = (K + 31) / 32;
@@ -540,4 +542,14 @@ extern "C" int d3ga_mlp_wgrad(int32_t P, int32_t N, int32_t K, const float *dpre
 #undef D3GA_WG2
 #undef D3GA_WG
     return check_launch(s, 0);
+}
+
+extern "C" int d3ga_mlp_wgrad(int32_t P, int32_t N, int32_t K, const float *dpre, const float *X, float *dW, float *db,
+                              d3ga_stream_t stream) {
+    return mlp_wgrad_launch(P, N, K, dpre, X, dW, db, true, stream);
+}
+
+extern "C" int d3ga_mlp_wgrad_acc(int32_t P, int32_t N, int32_t K, const float *dpre, const float *X, float *dW, float *db,
+                                  d3ga_stream_t stream) {
+    return mlp_wgrad_launch(P, N, K, dpre, X, dW, db, false, stream);
 }

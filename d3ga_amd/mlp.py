@@ -93,15 +93,23 @@ class _Chain(torch.autograd.Function):
             dpre = dpre * torch.where(acts[L] > 0, 1.0, ctx.slopes[-1])
         grads = [None] * (2 * L)
         dx = None
+        # all weight / bias gradients of the chain live in ONE zero-filled buffer (one fill instead of two memsets a layer)
+        need = [(ctx.needs_input_grad[2 + 2 * i], ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]) for i in range(L)]
+        sizes = [(w.numel() if nw or nbias else 0, w.shape[0] if nbias else 0) for w, (nw, nbias) in zip(weights, need)]
+        flat = torch.zeros(sum(a + b for a, b in sizes), dtype=torch.float32, device=dpre.device)
+        offs, o = [], 0
+        for a, b in sizes:
+            offs.append((o, o + a))
+            o += a + b
         for i in range(L - 1, -1, -1):
             w, x_in = weights[i], acts[i]
             N, K = w.shape
-            need_w, need_b = ctx.needs_input_grad[2 + 2 * i], ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]
-            if need_w or need_b:                              # dW = dPre^T X (a reduction over all rows), db = column sums
-                dw = torch.empty((N, K), dtype=torch.float32, device=dpre.device)
-                db = torch.empty((N,), dtype=torch.float32, device=dpre.device) if need_b else None
-                check(_lib.lib().d3ga_mlp_wgrad(dpre.shape[0], N, K, dptr(dpre), dptr(x_in), dptr(dw), dptr(db),
-                                                stream_handle()), "d3ga_mlp_wgrad")
+            need_w, need_b = need[i]
+            if need_w or need_b:                              # dW += dPre^T X (a reduction over all rows), db += column sums
+                dw = flat[offs[i][0]:offs[i][1]].view(N, K)
+                db = flat[offs[i][1]:offs[i][1] + N] if need_b else None
+                check(_lib.lib().d3ga_mlp_wgrad_acc(dpre.shape[0], N, K, dptr(dpre), dptr(x_in), dptr(dw), dptr(db),
+                                                    stream_handle()), "d3ga_mlp_wgrad_acc")
                 grads[2 * i], grads[2 * i + 1] = (dw if need_w else None), db
             if i > 0:                                         # dPre of the layer below: (dPre W) (.) act'_{i-1}(h_i)
                 below = ctx.slopes[i - 1]

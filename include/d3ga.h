@@ -275,6 +275,10 @@ int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const v
  * dPre (P,N) = the gradient at the layer's pre-activation (see above), X (P,K) the layer's input.  Both outputs are zeroed by the call; partial sums meet through float atomics. */
 int d3ga_mlp_wgrad(int32_t P, int32_t N, int32_t K, const float *dpre, const float *X, float *dW, float *db,
                    d3ga_stream_t stream);
+/* Same, accumulating: dW += dPre^T . X, db += column sums; nothing is zeroed (a chain of layers zeroes ONE flat buffer
+ * for all its weight gradients instead of two memsets per layer). */
+int d3ga_mlp_wgrad_acc(int32_t P, int32_t N, int32_t K, const float *dpre, const float *X, float *dW, float *db,
+                       d3ga_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * The element-wise ops in front of ColorField.
