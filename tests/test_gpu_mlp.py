@@ -105,6 +105,39 @@ def test_view_dirs_and_sh4_encoding_match_oracle(P):
     assert rel_err(md.grad.cpu().numpy(), m64.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("P,widths", [(1, [5, 32, 7]), (31, [16, 128, 128, 4]), (33, [3, 40, 96, 11]), (700, [80, 128, 64, 128, 4]),
+                                      (0, [8, 32, 3])])
+def test_chain_matches_torch_autograd(P, widths):
+    """mlp_chain (one autograd node per trunk: sign-bit masks in the GEMM epilogues, one zeroed buffer for all weight
+    gradients) against the same layers under torch autograd in f64, over ragged row counts and widths that exercise the
+    bounds-checked kernels, the narrow-operand weight-gradient layout and the empty case."""
+    from d3ga_amd.mlp import mlp_chain
+    g = torch.Generator().manual_seed(P + sum(widths))
+    x = torch.randn(P, widths[0], generator=g)
+    layers = [(torch.randn(b, a, generator=g) / a ** 0.5, torch.randn(b, generator=g)) for a, b in zip(widths[:-1], widths[1:])]
+    slopes = [0.1] * (len(layers) - 1) + [1.0]
+    up = torch.randn(P, widths[-1], generator=g)
+    xr = x.double().requires_grad_(True)
+    lr = [(w.double().requires_grad_(True), b.double().requires_grad_(True)) for w, b in layers]
+    h = xr
+    for (w, b), sl in zip(lr, slopes):
+        h = torch.nn.functional.leaky_relu(torch.nn.functional.linear(h, w, b), sl)
+    h.backward(up.double())
+    xd = x.to(DEV).requires_grad_(True)
+    ld = [(w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)) for w, b in layers]
+    y = mlp_chain(xd, ld, slopes)
+    y.backward(up.to(DEV))
+    assert y.shape == (P, widths[-1])
+    if P == 0:
+        assert all(float(w.grad.abs().sum()) == 0.0 and float(b.grad.abs().sum()) == 0.0 for w, b in ld)
+        return
+    np.testing.assert_allclose(y.detach().cpu().numpy(), h.detach().numpy(), rtol=1e-5, atol=1e-5)
+    assert rel_err(xd.grad.cpu().numpy(), xr.grad.numpy()) < 1e-5
+    for (w, b), (wr, br) in zip(ld, lr):
+        assert rel_err(w.grad.cpu().numpy(), wr.grad.numpy()) < 1e-5
+        assert rel_err(b.grad.cpu().numpy(), br.grad.numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("spread", [0.0, 4.0])
 def test_split_bf16_products_have_f32_accuracy(spread):
     """The dense layer splits every f32 operand exactly into three bf16 pieces and keeps six of the nine cross products
