@@ -28,4 +28,14 @@ for other in ("C1", "C2", "C4", "C5"):
     b = os.path.join(ROOT, "gpurun_out", f"bench_{other}.log")
     if os.path.exists(b) and os.path.getsize(b) > 10:
         shutil.copy(b, os.path.join(ROOT, "profiles", f"{tag}_bench_{other}.json"))
+for other in ("C3", "C4"):
+    b = os.path.join(ROOT, "gpurun_out", f"bench_field_mlp_{other}.log")
+    if os.path.exists(b) and os.path.getsize(b) > 10:
+        shutil.copy(b, os.path.join(ROOT, "profiles", f"{tag}_bench_field_mlp_{other}.json"))
+for src, dst in (("prof_mlp/mlp_kernel_stats.csv", f"{tag}_field_mlp_kernel_stats.csv"),
+                 ("prof_step/step_kernel_stats.csv", f"{tag}_training_step_color_kernel_stats.csv"),
+                 ("prof_step_color_summary.txt", f"{tag}_training_step_color_summary.txt")):
+    f = os.path.join(ROOT, "gpurun_out", src)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(ROOT, "profiles", dst))
 print(sorted(os.listdir(os.path.join(ROOT, "profiles"))))

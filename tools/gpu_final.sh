@@ -24,3 +24,10 @@ for wl in C1 C2 C4 C5; do
   timeout 600 python bench.py --workload $wl --steps 30 --warmup 5 --no-cpu-baseline --no-train-step > gpurun_out/bench_$wl.log 2> gpurun_out/bench_$wl.err
 done
 tail -c 300 gpurun_out/bench_C5.log
+for wl in C3 C4; do
+  timeout 600 python bench.py --field-mlp --workload $wl --steps 50 --warmup 10 > gpurun_out/bench_field_mlp_$wl.log 2> gpurun_out/bench_field_mlp_$wl.err
+done
+# per-kernel summaries of the field networks (CanonicalField fwd+bwd) and of the reference's training step with colour MLP
+bash tools/prof_mlp.sh > gpurun_out/prof_mlp_summary.txt 2>&1
+bash tools/prof_step.sh color > gpurun_out/prof_step_color_summary.txt 2>&1
+cut -c1-400 gpurun_out/bench_field_mlp_C3.log
