@@ -4,10 +4,13 @@ Every field of the reference is the same trunk -- ``z -> [Linear(128) + leaky_re
 with ``z = [pose.expand(P, -1) | per-row features]`` (models/mlp.py:58-69, 94-105).  Here
   * the broadcast part of the first layer is folded into its bias once per call (``W0[:, :n_pose] @ pose + b0``: a
     128-vector instead of 98 of the 109 input columns for every one of the P rows),
-  * every dense layer is one launch of ``d3ga_mlp_linear`` (exact-f32 MFMA, bias + leaky_relu fused; the backward's
-    ``dY (.) lrelu'(Y)`` is fused into the operand load of the input-gradient GEMM),
-  * weight and bias gradients (``dPre^T @ X``, a reduction over all rows) come from ``d3ga_mlp_wgrad``, which feeds both
-    MFMA operands straight from their row-major global layout.
+  * every dense layer is one launch of ``d3ga_mlp_linear`` (f32-equivalent arithmetic on the bf16 matrix cores -- an exact
+    3-way split of every operand, six products, f32 accumulate: DESIGN.md sec. 4b -- with bias + leaky_relu fused),
+  * the whole trunk is ONE autograd node (``_Chain``): the forward keeps one sign bit per activation, the input-gradient
+    GEMM of a layer applies the leaky_relu derivative of the layer below from those bits in its epilogue, so every
+    pre-activation gradient is written once and no activation is re-read for masking,
+  * weight and bias gradients (``dPre^T @ X``, a reduction over all rows) come from ``d3ga_mlp_wgrad_acc`` into one
+    zero-filled buffer per chain.
 Modules keep the reference's parameter names (``network.{i}.weight/bias``, ``output.weight/bias``): state dicts
 interchange.  GPU tensors only.
 """

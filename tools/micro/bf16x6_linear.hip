@@ -175,7 +175,8 @@ int main() {
     std::vector<float> X((size_t)P * K), W((size_t)N * K), B(N);
     srand(1);
     auto rnd = [] { float s = 0; for (int i = 0; i < 6; ++i) s += rand() / (float)RAND_MAX; return (s - 3.f) * 1.41f; };
-    for (auto &v : X) v = rnd();
+    const bool zero_x = getenv("ZERO_X") != nullptr;
+    for (auto &v : X) v = zero_x ? 0.f : rnd();
     for (auto &v : W) v = rnd() / 11.f;
     for (auto &v : B) v = rnd();
     std::vector<unsigned short> Wp((size_t)kWUnits * 8);
