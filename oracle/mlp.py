@@ -1,7 +1,11 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's field networks (models/mlp.py, utils/pos_encoder.py).
 
 Pinned: tests/golden/field_cases.npz holds weights, inputs, outputs and autograd gradients of the reference's own
-`CanonicalField` and `DeformationField` (tools/gen_golden.py imports /root/reference/models/mlp.py in the build container).
+`CanonicalField`, `DeformationField`, `ShadowDecoder`, `FaceDecoder` and `ColorField` (tools/gen_golden.py imports
+/root/reference/models/mlp.py in the build container).  PARITY UNPINNED for one function: `sh4_direction_encoding`, the
+stand-in for tiny-cuda-nn's degree-4 SphericalHarmonics encoding inside ColorField (tiny-cuda-nn is un-vendored,
+install.sh:14; restated from its published definition) -- the ColorField golden was generated with this stand-in plugged
+into the reference module, so everything around the encoding is pinned.
 """
 import torch
 import torch.nn.functional as F
