@@ -37,3 +37,20 @@ def test_bench_line_contract_small_workload():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_bench_two_ranks_as_the_driver_launches_it():
+    """The N > 1 launch line of the driver (`python -m torch.distributed.run ... bench.py --gpus N ...`), with both ranks on
+    the test box's one GPU over gloo (`--backend gloo --single-device`; the scaling runs use RCCL, one GPU per rank):
+    rank 0 prints one line, the value is the whole-job rate over the max-over-ranks time, the gradient exchange ran."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--single-device", "--workload", "C1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["views_per_step"] == 2
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) / d["value"] < 0.02          # whole-job frames / max-over-ranks time
+    assert d["config"]["grad_exchange"].startswith("cut") and d["config"]["grad_exchange_bytes_per_rank"] > 0
