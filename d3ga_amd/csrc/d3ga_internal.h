@@ -156,4 +156,32 @@ static inline int check_launch(hipStream_t s, int debug) {
         if (_e != hipSuccess) return (int)_e;   \
     } while (0)
 
+// Zero-fill as a KERNEL node.  hipMemsetAsync becomes a memset node under stream capture, and on this stack (ROCm 7.2,
+// gfx950) a replayed graph did not reliably order such a node against the kernels around it: with the tile histogram
+// zeroed by a memset node, replays of preprocess -> bin_sort faulted as soon as anything disturbed the caches between two
+// replays (tools/diag_graph3.py), i.e. the histogram was being zeroed while the next kernel already counted into it.
+// Kernel -> kernel edges are honoured, so every clear in this library is a (tiny) kernel.
+#ifdef __HIPCC__
+static __global__ void zero_words_kernel(uint32_t *__restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static __global__ void zero_bytes_kernel(unsigned char *__restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0;
+}
+static inline hipError_t zero_async(void *ptr, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    if ((((uintptr_t)ptr | bytes) & 3) == 0) {
+        const size_t n = bytes / 4;
+        const size_t blocks = (n + 4 * kBlock - 1) / (4 * kBlock);
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks))), dim3(kBlock), 0, s,
+                           reinterpret_cast<uint32_t *>(ptr), n);
+    } else {
+        const size_t blocks = (bytes + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(kBlock), 0, s,
+                           reinterpret_cast<unsigned char *>(ptr), bytes);
+    }
+    return hipGetLastError();
+}
+#endif
+
 }  // namespace d3ga

@@ -281,7 +281,7 @@ extern "C" int d3ga_cage_deform_bwd_ex(int P, int V, const float *tetpoints, con
     if (flags & ~D3GA_DEFORM_LOG_SCALES) return D3GA_E_CONFIG;
     hipStream_t s = (hipStream_t)stream;
     const bool csr = g_tetpoints && vert_start && vert_items && corner_grads;
-    if (g_tetpoints && V > 0 && (!csr || P == 0)) D3GA_HIP(hipMemsetAsync(g_tetpoints, 0, sizeof(float) * 3 * (size_t)V, s));
+    if (g_tetpoints && V > 0 && (!csr || P == 0)) D3GA_HIP(zero_async(g_tetpoints, sizeof(float) * 3 * (size_t)V, s));
     if (P == 0) return D3GA_OK;
     if (!tetpoints || !tetras || !tetra_id || !barys || !canon_grad || !scales || !rots || !g_means || !g_cov6)
         return D3GA_E_NULL;
@@ -322,7 +322,7 @@ extern "C" int d3ga_fem_energy_bwd(int T, int V, const float *tetpoints, const i
                                    const float *g_energy, float *g_tetpoints, d3ga_stream_t stream) {
     if (T < 0 || V < 0) return D3GA_E_SIZE;
     if (!g_tetpoints) return D3GA_E_NULL;
-    if (V > 0) D3GA_HIP(hipMemsetAsync(g_tetpoints, 0, sizeof(float) * 3 * (size_t)V, (hipStream_t)stream));
+    if (V > 0) D3GA_HIP(zero_async(g_tetpoints, sizeof(float) * 3 * (size_t)V, (hipStream_t)stream));
     if (T == 0) return D3GA_OK;
     if (!tetpoints || !tetras || !Dn_inv || !g_energy) return D3GA_E_NULL;
     hipLaunchKernelGGL(fem_bwd_kernel, dim3(nblocks(T)), dim3(kBlock), 0, (hipStream_t)stream, T, tetpoints, tetras,

@@ -287,7 +287,7 @@ extern "C" int d3ga_l1_mean_fwd(int64_t n, const float *a, const float *b, float
     if (!a || !b || !out) return D3GA_E_NULL;
     if (((uintptr_t)a | (uintptr_t)b) & 15) return D3GA_E_CONFIG;       // 16-byte aligned inputs
     hipStream_t s = (hipStream_t)stream;
-    D3GA_HIP(hipMemsetAsync(out, 0, sizeof(float), s));
+    D3GA_HIP(zero_async(out, sizeof(float), s));
     const int64_t n4 = n / 4;
     // few, fat workgroups: every workgroup ends with ONE float atomic on the same word, and same-address device-scope
     // atomics serialise at ~12 ns each (2048 of them cost more than streaming the two images)
@@ -315,8 +315,8 @@ extern "C" int d3ga_ssim_l1_fwd(int32_t C, int32_t H, int32_t W, const float *im
     if (!img1 || !img2 || !out) return D3GA_E_NULL;
     if ((Dm != nullptr) != (Dq1 != nullptr) || (Dm != nullptr) != (Dq12 != nullptr)) return D3GA_E_CONFIG;
     hipStream_t s = (hipStream_t)stream;
-    D3GA_HIP(hipMemsetAsync(out, 0, sizeof(float), s));
-    if (out_l1) D3GA_HIP(hipMemsetAsync(out_l1, 0, sizeof(float), s));
+    D3GA_HIP(zero_async(out, sizeof(float), s));
+    if (out_l1) D3GA_HIP(zero_async(out_l1, sizeof(float), s));
     const int tx = (W + kSsimTW - 1) / kSsimTW, ty = (H + kSsimTH - 1) / kSsimTH;
     // persistent grid: every workgroup ends with ONE atomic on the result word (same-address atomics serialise)
     hipLaunchKernelGGL(ssim_fwd_kernel, dim3(ssim_grid(C * tx * ty, 2048)), dim3(256), 0, s, C, H, W, tx, ty, img1, img2,

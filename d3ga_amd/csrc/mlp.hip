@@ -504,8 +504,8 @@ static int mlp_wgrad_launch(int32_t P, int32_t N, int32_t K, const float *dpre, 
     if ((int64_t)P * N >= (1ll << 31) || (int64_t)P * K >= (1ll << 31)) return D3GA_E_SIZE;
     hipStream_t s = (hipStream_t)stream;
     if (zero_first) {
-        D3GA_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, s));
-        if (db) D3GA_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)N, s));
+        D3GA_HIP(zero_async(dW, sizeof(float) * (size_t)N * K, s));
+        if (db) D3GA_HIP(zero_async(db, sizeof(float) * (size_t)N, s));
     }
     if (P == 0) return D3GA_OK;
     if (!dpre || !X) return D3GA_E_NULL;

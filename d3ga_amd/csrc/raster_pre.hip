@@ -340,7 +340,7 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     const int64_t tiles = (int64_t)tiles_x(prm->W) * tiles_y(prm->H);
     BinBuf bin = carve_bin(binning, tiles, d_capacity);
     // counters + tile_count are adjacent: one memset
-    D3GA_HIP(hipMemsetAsync(bin.counters, 0, 256 + align256(4 * tiles), s));
+    D3GA_HIP(zero_async(bin.counters, 256 + align256(4 * tiles), s));
     if (prm->P == 0) return D3GA_OK;          // empty scene: every per-Gaussian tensor is empty (NULL)
     if ((shs != nullptr) == (colors_precomp != nullptr)) return D3GA_E_CONFIG;
     const bool sr = scales != nullptr && rotations != nullptr;

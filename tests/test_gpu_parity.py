@@ -433,6 +433,30 @@ def test_hipgraph_replay_equals_eager():
         assert torch.allclose(img_g, ref_img, atol=1e-6)
         assert rel_err(_np(tp.grad), _np(ref_tp)) < 1e-4          # float atomics: order-dependent rounding only
         assert rel_err(_np(sh.grad), _np(ref_sh)) < 1e-4
+        # The graph must survive anything that happens between two replays.  (Regression: with the tile histogram cleared
+        # by a hipMemsetAsync *memset node*, replays faulted after an unrelated allocation + fill, a D2H copy or an eager
+        # step had disturbed the caches -- the node was not ordered against the kernels around it.  Every clear in the
+        # library is a kernel now.)
+        junk = torch.empty(64 << 20, device=DEV)
+        junk.fill_(1.0)
+        R.last_counters()                                          # D2H copy of a tensor that lives in the graph's pool
+        del junk
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.allclose(img_g, ref_img, atol=1e-6)
+        assert rel_err(_np(tp.grad), _np(ref_tp)) < 1e-4
+        # and it must follow its inputs: new cage vertices in the SAME storage -> the replay equals a fresh eager step
+        with torch.no_grad():
+            tp += 0.01 * torch.randn(tp.shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+        g.replay()
+        torch.cuda.synchronize()
+        got_img, got_tp = img_g.detach().clone(), tp.grad.clone()
+        tp.grad = None; sh.grad = None
+        img_e2, _ = step()
+        torch.cuda.synchronize()
+        assert torch.allclose(got_img, img_e2.detach(), atol=1e-6)
+        assert rel_err(_np(got_tp), _np(tp.grad)) < 1e-4
     finally:
         R.set_capacity_policy("auto")
 

@@ -439,21 +439,6 @@ def main():
 
     for _ in range(3):
         timed_step()
-    # Per-step distribution (HIP events around the op sequence, median / p10 / p90), outside (just before) the
-    # timed region: one event pair per step on the launch stream, K more steps of the same kind (graph replays at N = 1).
-    step_dist = None
-    if world == 1:
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        for e0, e1 in evs:
-            e0.record()
-            timed_step()
-            e1.record()
-        torch.cuda.synchronize()
-        ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
-        pick = lambda q: round(ts[min(len(ts) - 1, int(q * len(ts)))], 4)
-        step_dist = {"median": pick(0.5), "p10": pick(0.1), "p90": pick(0.9), "n": len(ts),
-                     "frames_per_s_at_median": round(1e3 / pick(0.5), 1), "method": "HIP events per step, before the timed region"}
-
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -577,7 +562,6 @@ def main():
                                                         else flat.nbytes())},
             "roofline": roof, "kernels": kernels,
             "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 4),
-            "step_ms": step_dist,
             "launch_mode": "hipGraph replay of one captured step" if graph is not None else "eager",
             **({"grad_exchange_note": exchange_note} if exchange_note else {}),
             "stage_events": "separate eager pass, same K steps" if graph is not None else "none" if args.no_stage_events else "separate eager pass",
