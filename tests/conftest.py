@@ -48,3 +48,28 @@ def hostcheck():
 
 def ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _poison_uninitialised_memory():
+    """D3GA_POISON=1: every torch.empty / empty_like on the GPU comes back filled with 0xFF bytes (NaN as float,
+    -1 / 4e9 as integers), so that any kernel that reads a buffer before writing it -- and only works because fresh
+    allocations happen to hold zeros or last step's values -- fails loudly.  Run: D3GA_POISON=1 pytest -m gpu."""
+    if os.environ.get("D3GA_POISON") != "1":
+        yield
+        return
+    import torch
+    real_empty, real_empty_like = torch.empty, torch.empty_like
+
+    def poison(t):
+        if t.is_cuda and t.numel() > 0 and t.is_contiguous():
+            if t.dtype == torch.bool:
+                t.fill_(True)
+            else:
+                t.reshape(-1).view(torch.uint8).fill_(0xFF)
+        return t
+
+    torch.empty = lambda *a, **k: poison(real_empty(*a, **k))
+    torch.empty_like = lambda *a, **k: poison(real_empty_like(*a, **k))
+    yield
+    torch.empty, torch.empty_like = real_empty, real_empty_like
