@@ -304,8 +304,10 @@ class ColorField(FieldMLP):
       -> (sigmoid(pred[:, :3]), sigmoid(0.1 + pred[:, 3:4])),  z = [enc(view_dir) | pose | shadow | camera | frame | shs]."""
 
     def __init__(self, n_features=64, n_cond=98, frame_dims=32, camera_dims=0, n_nodes=128, n_layers=4,
-                 direction_encoding=sh4_direction_encoding, n_view_enc=16):
-        super().__init__(n_cond + n_features + n_view_enc + frame_dims + camera_dims, 3 + 1, n_nodes, n_layers)
+                 direction_encoding=sh4_direction_encoding, n_view_enc=16, shadow_dims=0):
+        # (the reference sizes its first layer without the shadow column, models/mlp.py:181-193, so a forward WITH shadow
+        # fails there; shadow_dims = 1 makes room for it)
+        super().__init__(n_cond + n_features + n_view_enc + frame_dims + camera_dims + shadow_dims, 3 + 1, n_nodes, n_layers)
         self.direction_encoding = direction_encoding
 
     def forward(self, shs, pose, view_dir, frame_encoding=None, camera_encoding=None, shadow=None):

@@ -82,6 +82,32 @@ def test_color_field_matches_reference_golden(golden):
         assert rel_err(prm.grad.cpu().numpy(), g[f"col_gw_{name}"]) < 2e-4, name
 
 
+def test_color_field_all_column_groups_match_oracle():
+    """ColorField with every optional column group present -- z = [enc(view_dir) | pose | shadow | camera | frame | shs],
+    models/mlp.py:208-226 -- against the oracle's restatement in f64 (values and all input gradients)."""
+    from d3ga_amd.mlp import ColorField
+    P = 777
+    torch.manual_seed(5)
+    col = ColorField(n_features=24, n_cond=30, frame_dims=8, camera_dims=6, n_nodes=64, n_layers=2, shadow_dims=1).to(DEV)
+    g = torch.Generator().manual_seed(6)
+    mk = lambda *shape: torch.randn(*shape, generator=g)
+    feat, pose, frame, cam, shadow = mk(P, 24), mk(30), mk(8), mk(6), torch.rand(P, 1, generator=g)
+    vd = torch.nn.functional.normalize(mk(P, 3), dim=-1)
+    up0, up1 = mk(P, 3), mk(P, 1)
+    leaves64 = [t.double().requires_grad_(True) for t in (feat, pose, vd, frame, cam, shadow)]
+    hidden = [(l.weight.detach().double().cpu(), l.bias.detach().double().cpu()) for l in col.network]
+    rgb64, op64 = om.color_field(leaves64[0], leaves64[1], leaves64[2], leaves64[3], leaves64[4], leaves64[5], hidden,
+                                 col.output.weight.detach().double().cpu(), col.output.bias.detach().double().cpu())
+    torch.autograd.backward([rgb64, op64], [up0.double(), up1.double()])
+    leaves = [t.to(DEV).requires_grad_(True) for t in (feat, pose, vd, frame, cam, shadow)]
+    rgb, op = col(leaves[0], leaves[1], leaves[2], frame_encoding=leaves[3], camera_encoding=leaves[4], shadow=leaves[5])
+    torch.autograd.backward([rgb, op], [up0.to(DEV), up1.to(DEV)])
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), rgb64.detach().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(op.detach().cpu().numpy(), op64.detach().numpy(), rtol=1e-5, atol=2e-6)
+    for a, b, name in zip(leaves, leaves64, ("feat", "pose", "view_dir", "frame", "camera", "shadow")):
+        assert rel_err(a.grad.cpu().numpy(), b.grad.numpy()) < 2e-5, name
+
+
 @pytest.mark.parametrize("P", [1, 63, 5000])
 def test_view_dirs_and_sh4_encoding_match_oracle(P):
     """csrc/encoding.hip against the oracle's tensor program (f64 on the CPU): values and the input gradient through
