@@ -61,6 +61,8 @@ _SIGNATURES = {
     "d3ga_mlp_linear": ([ctypes.c_int32] * 3 + [_vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp, _vp], _i),
     "d3ga_mlp_wgrad": ([ctypes.c_int32] * 3 + [_vp] * 4 + [_vp], _i),
     "d3ga_mlp_wgrad_acc": ([ctypes.c_int32] * 3 + [_vp] * 4 + [_vp], _i),
+    "d3ga_field_heads_fwd": ([ctypes.c_int32] * 3 + [_vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "d3ga_field_heads_bwd": ([ctypes.c_int32] * 3 + [_vp, _vp, _vp] + [_vp] * 6 + [_vp], _i),
     "d3ga_view_dirs_fwd": ([ctypes.c_int32, _vp, _vp, _vp, _vp], _i),
     "d3ga_view_dirs_bwd": ([ctypes.c_int32, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_sh4_encoding_fwd": ([ctypes.c_int32, _vp, _vp, _vp], _i),

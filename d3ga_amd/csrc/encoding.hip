@@ -73,11 +73,97 @@ __global__ __launch_bounds__(kBlock) void sh4_encoding_bwd_kernel(int P, const f
     d_dirs[3 * i] = 2.0f * gx, d_dirs[3 * i + 1] = 2.0f * gy, d_dirs[3 * i + 2] = 2.0f * gz;     // x = 2 d - 1
 }
 
+// Output heads of a field network: pred (P,N) -> up to four column groups, each written as its own contiguous (P, w_h)
+// block of one planar buffer (block h starts at P * start_h floats) through its activation:
+//   0: y = x        1: y = a * tanh(x)        2: y = sigmoid(x + a)
+// (CanonicalField: tanh(pred[:, :4]) * scale_bary | pred[:, 4:8] | pred[:, 8:], models/mlp.py:107-110; ColorField:
+// sigmoid(pred[:, :3]) | sigmoid(0.1 + pred[:, 3:4]), models/mlp.py:232.)  ATen ran each head as slice + activation (+ a
+// copy when the consumer needs contiguous rows) and, backward, a zero-filled (P,N) buffer + strided copy + add per head.
+struct HeadSpec { int n_heads; int start[4]; int width[4]; int act[4]; float a[4]; };
+
+__global__ __launch_bounds__(kBlock) void field_heads_fwd_kernel(int P, int N, HeadSpec hs, const float *__restrict__ pred,
+                                                                 float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (size_t)P * N) return;
+    const int r = (int)(i / N), n = (int)(i - (size_t)r * N);
+    int h = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) h = (q < hs.n_heads && n >= hs.start[q]) ? q : h;
+    const float x = pred[i], a = hs.a[h];
+    float y = x;
+    if (hs.act[h] == 1) y = a * tanhf(x);
+    else if (hs.act[h] == 2) y = 1.0f / (1.0f + expf(-(x + a)));
+    out[(size_t)P * hs.start[h] + (size_t)r * hs.width[h] + (n - hs.start[h])] = y;
+}
+
+__global__ __launch_bounds__(kBlock) void field_heads_bwd_kernel(int P, int N, HeadSpec hs, const float *__restrict__ out,
+                                                                 const float *__restrict__ g0, const float *__restrict__ g1,
+                                                                 const float *__restrict__ g2, const float *__restrict__ g3,
+                                                                 float *__restrict__ d_pred) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (size_t)P * N) return;
+    const int r = (int)(i / N), n = (int)(i - (size_t)r * N);
+    int h = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) h = (q < hs.n_heads && n >= hs.start[q]) ? q : h;
+    const float *g = h == 0 ? g0 : (h == 1 ? g1 : (h == 2 ? g2 : g3));
+    const size_t o = (size_t)r * hs.width[h] + (n - hs.start[h]);
+    float d = 0.f;
+    if (g) {                                               // a head nobody used has no gradient
+        d = g[o];
+        const float y = out[(size_t)P * hs.start[h] + o], a = hs.a[h];
+        if (hs.act[h] == 1) d *= a - y * y / a;            // d/dx a tanh(x) = a (1 - tanh^2)
+        else if (hs.act[h] == 2) d *= y * (1.0f - y);
+    }
+    d_pred[i] = d;
+}
+
 static inline int ew_grid(int P) { return (P + kBlock - 1) / kBlock; }
 
 }  // namespace d3ga
 
 using namespace d3ga;
+
+static int make_heads(int N, int n_heads, const int32_t *width, const int32_t *act, const float *param, HeadSpec &hs) {
+    if (n_heads < 1 || n_heads > 4 || !width || !act || !param) return D3GA_E_CONFIG;
+    hs.n_heads = n_heads;
+    int c = 0;
+    for (int h = 0; h < 4; ++h) {
+        hs.start[h] = c; hs.width[h] = h < n_heads ? width[h] : 0; hs.act[h] = h < n_heads ? act[h] : 0;
+        hs.a[h] = h < n_heads ? param[h] : 0.f;
+        if (h < n_heads && (width[h] < 1 || act[h] < 0 || act[h] > 2 || (act[h] == 1 && param[h] == 0.f))) return D3GA_E_CONFIG;
+        c += hs.width[h];
+    }
+    return c == N ? D3GA_OK : D3GA_E_SIZE;
+}
+
+extern "C" int d3ga_field_heads_fwd(int32_t P, int32_t N, int32_t n_heads, const int32_t *width, const int32_t *act,
+                                    const float *param, const float *pred, float *out, d3ga_stream_t stream) {
+    if (P < 0 || N < 1) return D3GA_E_SIZE;
+    HeadSpec hs;
+    D3GA_TRY(make_heads(N, n_heads, width, act, param, hs));
+    if (P == 0) return D3GA_OK;
+    if (!pred || !out) return D3GA_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)P * N;
+    hipLaunchKernelGGL(field_heads_fwd_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, P, N, hs, pred, out);
+    return check_launch(s, 0);
+}
+
+extern "C" int d3ga_field_heads_bwd(int32_t P, int32_t N, int32_t n_heads, const int32_t *width, const int32_t *act,
+                                    const float *param, const float *out, const float *g0, const float *g1, const float *g2,
+                                    const float *g3, float *d_pred, d3ga_stream_t stream) {
+    if (P < 0 || N < 1) return D3GA_E_SIZE;
+    HeadSpec hs;
+    D3GA_TRY(make_heads(N, n_heads, width, act, param, hs));
+    if (P == 0) return D3GA_OK;
+    if (!out || !d_pred) return D3GA_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)P * N;
+    hipLaunchKernelGGL(field_heads_bwd_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, P, N, hs, out, g0,
+                       g1, g2, g3, d_pred);
+    return check_launch(s, 0);
+}
 
 extern "C" int d3ga_view_dirs_fwd(int32_t P, const float *means3D, const float *campos, float *dirs, d3ga_stream_t stream) {
     if (P <= 0) return D3GA_E_SIZE;

@@ -134,6 +134,48 @@ def mlp_chain(x, layers, slopes):
     return _Chain.apply(x, tuple(slopes), *flat)
 
 
+_ACT = {"none": 0, "tanh": 1, "sigmoid": 2}
+
+
+class _Heads(torch.autograd.Function):
+    """pred (P,N) -> its column groups, each contiguous and through its activation, in one launch each way
+    (d3ga_field_heads_*).  spec = ((width, act, param), ...): act "none", "tanh" (param * tanh(x)) or "sigmoid"
+    (sigmoid(x + param))."""
+
+    @staticmethod
+    def forward(ctx, pred, spec):
+        require_cuda(pred)
+        pred = pred.float().contiguous()
+        P, N = pred.shape
+        n = len(spec)
+        import ctypes
+        ctx.c_spec = ((ctypes.c_int32 * n)(*[w for w, _, _ in spec]), (ctypes.c_int32 * n)(*[_ACT[a] for _, a, _ in spec]),
+                      (ctypes.c_float * n)(*[float(v) for _, _, v in spec]))
+        out = torch.empty(P * N, dtype=torch.float32, device=pred.device)
+        check(_lib.lib().d3ga_field_heads_fwd(P, N, n, *ctx.c_spec, dptr(pred), dptr(out), stream_handle()), "d3ga_field_heads_fwd")
+        heads, off = [], 0
+        for w, _, _ in spec:
+            heads.append(out[P * off:P * (off + w)].view(P, w))
+            off += w
+        ctx.shape, ctx.n = (P, N), n
+        ctx.save_for_backward(out)
+        return tuple(heads)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (out,) = ctx.saved_tensors
+        P, N = ctx.shape
+        gs = [None if g is None else g.float().contiguous() for g in grads] + [None] * (4 - ctx.n)
+        d_pred = torch.empty((P, N), dtype=torch.float32, device=out.device)
+        check(_lib.lib().d3ga_field_heads_bwd(P, N, ctx.n, *ctx.c_spec, dptr(out), dptr(gs[0]), dptr(gs[1]), dptr(gs[2]),
+                                              dptr(gs[3]), dptr(d_pred), stream_handle()), "d3ga_field_heads_bwd")
+        return d_pred, None
+
+
+def field_heads(pred, spec):
+    return _Heads.apply(pred, tuple(spec))
+
+
 class FieldMLP(nn.Module):
     """The trunk shared by the reference's fields (models/mlp.py:50-69): ``n_layers + 1`` hidden layers of ``n_nodes`` with
     leaky_relu(0.1) and a linear head; kaiming-leaky init, head weights scaled by 0.33 (models/mlp.py:17-20,55-57)."""
@@ -197,7 +239,7 @@ class CanonicalField(FieldMLP):
     def forward(self, barys, rots, scales, pose):
         pred = super().forward(torch.cat([rots, scales, barys], dim=1), pose)
         s = self.bary_size
-        return torch.tanh(pred[:, :s]) * self.scale_bary, pred[:, s:s + 4], pred[:, s + 4:]
+        return field_heads(pred, ((s, "tanh", self.scale_bary), (4, "none", 0.0), (pred.shape[1] - s - 4, "none", 0.0)))
 
 
 def embed(x, multires=7):
@@ -216,7 +258,7 @@ class DeformationField(FieldMLP):
         self.scaling = scaling
 
     def forward(self, canonical, pose):
-        return torch.tanh(super().forward(embed(canonical), pose)) * self.scaling
+        return field_heads(super().forward(embed(canonical), pose), ((3, "tanh", self.scaling),))[0]
 
 
 class ShadowDecoder(FieldMLP):
@@ -319,5 +361,4 @@ class ColorField(FieldMLP):
         if frame_encoding is not None:
             parts.append(frame_encoding.reshape(-1))
         parts.append(shs)
-        pkg = self.forward_parts(parts)
-        return torch.sigmoid(pkg[:, 0:3]), torch.sigmoid(0.1 + pkg[:, 3:4])
+        return field_heads(self.forward_parts(parts), ((3, "sigmoid", 0.0), (1, "sigmoid", 0.1)))

@@ -288,6 +288,16 @@ int d3ga_mlp_wgrad_acc(int32_t P, int32_t N, int32_t K, const float *dpre, const
  *                  restated from its published definition, constants of utils/sh_utils.py:7-24).
  * The backward calls overwrite d_means3D / d_dirs (no accumulation).  enc, d_enc 16-byte aligned.
  * ------------------------------------------------------------------------------------------------------- */
+/* Output heads of a field network (models/mlp.py:107-110, 232): pred (P,N) -> n_heads <= 4 consecutive column groups of
+ * widths width[h] (sum = N), head h written as a contiguous (P, width[h]) block at out + P * (width[0] + .. + width[h-1])
+ * through act[h]: 0 identity, 1 param[h] * tanh(x), 2 sigmoid(x + param[h]).  width, act, param are HOST arrays.
+ * bwd: d_pred (P,N) from the heads' gradients g0..g3 (each (P, width[h]) contiguous, NULL = unused head -> zero) and the
+ * forward's `out`. */
+int d3ga_field_heads_fwd(int32_t P, int32_t N, int32_t n_heads, const int32_t *width, const int32_t *act, const float *param,
+                         const float *pred, float *out, d3ga_stream_t stream);
+int d3ga_field_heads_bwd(int32_t P, int32_t N, int32_t n_heads, const int32_t *width, const int32_t *act, const float *param,
+                         const float *out, const float *g0, const float *g1, const float *g2, const float *g3, float *d_pred,
+                         d3ga_stream_t stream);
 int d3ga_view_dirs_fwd(int32_t P, const float *means3D, const float *campos, float *dirs, d3ga_stream_t stream);
 int d3ga_view_dirs_bwd(int32_t P, const float *means3D, const float *campos, const float *d_dirs, float *d_means3D,
                        d3ga_stream_t stream);
