@@ -103,14 +103,14 @@ class Frame:
         return loss
 
 
-    def train_step(self, with_fields=False):
+    def train_step(self, with_fields=False, pair=False):
         """The reference's training step renders twice (models/trainer.py:102-110): RGB, then a silhouette pass with a
         constant per-Gaussian colour on a black background; losses as in train.py:190-193 (L1 + SSIM on RGB, L1 on the
         silhouette).  with_fields: the cage-vertex offsets and the per-Gaussian (delta_bary, delta_rot, delta_scale) come
         from the DeformationField / CanonicalField networks as in models/cage_net.py:197-215 instead of free parameters."""
         from d3ga_amd.cage_deform import cage_deform, lbs_cage
         from d3ga_amd.losses import l1_loss, l1_ssim
-        from d3ga_amd.renderer import render
+        from d3ga_amd.renderer import render, render_pair
         p = self.params
         if not hasattr(self, "sil_rgb"):
             P = self.barys0.shape[0]
@@ -158,8 +158,12 @@ class Frame:
             rgb, opac = self.color_field(self.color_feat, self.pose, viewdirs, frame_encoding=self.frame_enc)
             pkg = {"means3D": means, "cov3D_precomp": cov6, "opacities": opac, "shs": None, "rgb": rgb,
                    "sh_degree": self.sh_degree}
-        img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
-        sil = render(self.batch, pkg, self.bg0, colors_precomp=self.sil_rgb, grad_sync=self.grad_sync)["render"]
+        if pair:       # both images from ONE compositing pass (d3ga_amd.renderer.render_pair; same images, same gradients)
+            both = render_pair(self.batch, pkg, self.bg, self.sil_rgb, self.bg0, grad_sync=self.grad_sync)
+            img, sil = both["render"], both["render2"]
+        else:
+            img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
+            sil = render(self.batch, pkg, self.bg0, colors_precomp=self.sil_rgb, grad_sync=self.grad_sync)["render"]
         # train.py:190-193: (1 - lambda) L1 + lambda (1 - SSIM) on the RGB image, L1 on the silhouette
         lam = 0.2
         rgb_l1, rgb_ssim = l1_ssim(img, self.target)          # one fused kernel each way
@@ -493,6 +497,22 @@ def main():
                  "launch_mode": "eager",
                  "ms_per_step": round(1e3 * (time.perf_counter() - t1) / n_ts, 4)}
         train["steps_per_s"] = round(1e3 / train["ms_per_step"], 2)
+
+        def timed_train(**kw):
+            for _ in range(3):
+                flat.zero()
+                frame.train_step(**kw)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_ts):
+                flat.zero()
+                frame.train_step(**kw)
+            torch.cuda.synchronize()
+            return round(1e3 * (time.perf_counter() - t1) / n_ts, 4)
+
+        # the same step with both images from one compositing pass (render_pair: an extension, same results)
+        train["render_pair_ms_per_step"] = timed_train(pair=True)
+        train["render_pair_with_field_and_color_networks_ms_per_step"] = timed_train(pair=True, with_fields="color")
         # the same step with the field networks in front of the deform (models/cage_net.py:197-215)
         for _ in range(3):
             flat.zero()

@@ -490,12 +490,18 @@ __device__ __forceinline__ int build_row_lists(uint8_t (*s_list)[64], bool r0, b
     return row == 0 ? c0 : (row == 1 ? c1 : (row == 2 ? c2 : c3));
 }
 
+// DUAL: a second set of per-Gaussian colours (colors2, (P,3), read by Gaussian id) is blended with the same alphas into
+// out_color2 over bg2 -- the reference's training step renders every package twice with identical geometry and opacities
+// (RGB, then the silhouette colours on black: models/trainer.py:102-110); alpha, T, the culled lists and the early exit
+// are shared, the second image costs three more FMAs per (pixel, entry).
+template <bool DUAL>
 __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
     uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
     const float4 *__restrict__ rgb_invd, const float *__restrict__ bg, float *__restrict__ final_T,
     uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_invdepth,
-    const uint32_t *__restrict__ tile_order) {
+    const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2, const float *__restrict__ bg2,
+    float *__restrict__ out_color2) {
     const Quad q = tile_order ? quad_of_block_ordered(gx, gx * gy, tile_order) : quad_of_block(gx, gy);
     if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
     const int lane = threadIdx.x & 63;
@@ -509,32 +515,37 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
     __shared__ float2 s_xy[64];
     __shared__ float4 s_co[64];
     __shared__ float4 s_rgb[64];
+    __shared__ float4 s_rgb2[DUAL ? 64 : 1];
     __shared__ uint8_t s_list[4][64];
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    float E0 = 0.f, E1 = 0.f, E2 = 0.f;                    // DUAL: the second image
     uint32_t last = 0;
     bool done = !inside;
 
     float2 nxy = make_float2(0.f, 0.f);
-    float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f), nrgb2 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (begin + lane < end) {
         const uint32_t g = point_list[begin + lane];
         nxy = xy[g]; nco = conic_o[g]; nrgb = rgb_invd[g];
+        if constexpr (DUAL) nrgb2 = make_float4(colors2[3 * (size_t)g], colors2[3 * (size_t)g + 1], colors2[3 * (size_t)g + 2], 0.f);
     }
     for (uint32_t base = begin; base < end; base += 64) {
         const float2 cxy = nxy;
-        const float4 cco = nco, crgb = nrgb;
+        const float4 cco = nco, crgb = nrgb, crgb2 = nrgb2;
         const bool have = base + lane < end;
         const uint32_t nb = base + 64;
         if (nb + lane < end) {
             const uint32_t g = point_list[nb + lane];
             nxy = xy[g]; nco = conic_o[g]; nrgb = rgb_invd[g];
+            if constexpr (DUAL) nrgb2 = make_float4(colors2[3 * (size_t)g], colors2[3 * (size_t)g + 1], colors2[3 * (size_t)g + 2], 0.f);
         }
         float hx, hy;
         splat_extent(cco.x, cco.y, cco.z, cco.w, hx, hy);
         if (!have) hx = -1.0f;
         __builtin_amdgcn_wave_barrier();                  // previous batch's LDS reads are done (program order)
         s_xy[lane] = cxy; s_co[lane] = cco; s_rgb[lane] = crgb;
+        if constexpr (DUAL) s_rgb2[lane] = crgb2;
         int trip;
         const BlockHits bh = block_hits4(cxy.x, cxy.y, hx, hy, bx0, by0);
         const int my_cnt = build_row_lists(s_list, bh.r0, bh.r1, bh.r2, bh.r3, lane, rg.row, trip);
@@ -558,6 +569,7 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
                 const bool bl = act && !sat;
                 const float w = bl ? al0 * T : 0.f;
                 C0 += e0rgb.x * w; C1 += e0rgb.y * w; C2 += e0rgb.z * w; Dp += e0rgb.w * w;
+                if constexpr (DUAL) { const float4 u = s_rgb2[j0]; E0 += u.x * w; E1 += u.y * w; E2 += u.z * w; }
                 T = bl ? test_T : T;
                 last = bl ? (base - begin + (uint32_t)j0 + 1u) : last;   // 1-based position in the FULL tile list
                 done = done || sat;
@@ -569,6 +581,7 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
                 const bool bl = act && !sat;
                 const float w = bl ? al1 * T : 0.f;
                 C0 += e1rgb.x * w; C1 += e1rgb.y * w; C2 += e1rgb.z * w; Dp += e1rgb.w * w;
+                if constexpr (DUAL) { const float4 u = s_rgb2[j1]; E0 += u.x * w; E1 += u.y * w; E2 += u.z * w; }
                 T = bl ? test_T : T;
                 last = bl ? (base - begin + (uint32_t)j1 + 1u) : last;
                 done = done || sat;
@@ -585,6 +598,11 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
         out_color[hw + pid] = C1 + T * bg[1];
         out_color[2 * hw + pid] = C2 + T * bg[2];
         if (out_invdepth) out_invdepth[pid] = Dp;
+        if constexpr (DUAL) {
+            out_color2[pid] = E0 + T * bg2[0];
+            out_color2[hw + pid] = E1 + T * bg2[1];
+            out_color2[2 * hw + pid] = E2 + T * bg2[2];
+        }
     }
 }
 
@@ -606,12 +624,16 @@ constexpr int kRecBytes = 48;
 #ifdef D3GA_DIAG
 __device__ unsigned long long g_diag[8];     // diagnostic build only (tools/diag_bwd.py): loop statistics of the kernel below
 #endif
+// DUAL: the gradient of a second image blended with the same alphas from constant colours (colors2 over bg2, see the
+// forward) joins dL/dalpha; the nine moments, their reduction and the flush are unchanged (no gradient flows to colors2).
+template <bool DUAL>
 __global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
     uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
     const float4 *__restrict__ rgb_invd, const float *__restrict__ bg, const float *__restrict__ final_T,
     const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix, float *__restrict__ acc,
-    const uint32_t *__restrict__ tile_order) {
+    const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2, const float *__restrict__ bg2,
+    const float *__restrict__ dL_dpix2) {
     const Quad q = tile_order ? quad_of_block_ordered(gx, gx * gy, tile_order) : quad_of_block(gx, gy);
     if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
     const int lane = threadIdx.x & 63;
@@ -629,7 +651,12 @@ __global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
     const uint32_t last = inside ? n_contrib[pid] : 0u;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (inside) { g0 = dL_dpix[pid]; g1 = dL_dpix[hw + pid]; g2 = dL_dpix[2 * hw + pid]; }
-    const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    float h0 = 0.f, h1 = 0.f, h2 = 0.f;                    // DUAL: dL/dpixel of the second image
+    if constexpr (DUAL) {
+        if (inside) { h0 = dL_dpix2[pid]; h1 = dL_dpix2[hw + pid]; h2 = dL_dpix2[2 * hw + pid]; }
+        bg_dot += bg2[0] * h0 + bg2[1] * h1 + bg2[2] * h2;                   // both backgrounds sit behind the same T
+    }
     const uint32_t rowlast = row_max_u32(last);            // deepest position used inside this lane's 4x4 block
     const uint32_t maxlast = wave_max_u32(rowlast);
     if (maxlast == 0) return;
@@ -638,6 +665,7 @@ __global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
 
     __shared__ __attribute__((aligned(16))) char s_rec[64 * kRecBytes];      // [0,16) conic+o  [16,32) rgb,id  [32,40) xy
     __shared__ __attribute__((aligned(16))) char s_accb[64 * kRecBytes];     // nine float sums per staged entry (+3 pad)
+    __shared__ float4 s_rgb2[DUAL ? 64 : 1];                                 // DUAL: the entry's second colour
     __shared__ uint16_t s_list[5][64];                                       // byte offsets j*48; [4] = union of the four rows
     s_list[0][lane] = 0; s_list[1][lane] = 0; s_list[2][lane] = 0; s_list[3][lane] = 0;   // stale slots stay in range
 
@@ -647,6 +675,7 @@ __global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
     float T = T_final;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, ld0 = 0.f, ld1 = 0.f, ld2 = 0.f;   // DUAL: suffix colour / last colour of image 2
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     const int l16 = lane & 15, t4 = lane & 3;
     const bool t_is0 = t4 == 0, t_is1 = t4 == 1, t_is2 = t4 == 2;
@@ -658,20 +687,24 @@ __global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
 
     float2 nxy = make_float2(0.f, 0.f);
     float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 nrgb2 = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t nid = 0;
     if ((uint32_t)lane < maxlast) {
         nid = point_list[begin + (maxlast - 1 - lane)];
         nxy = xy[nid]; nco = conic_o[nid]; nrgb = rgb_invd[nid];
+        if constexpr (DUAL) nrgb2 = make_float4(colors2[3 * (size_t)nid], colors2[3 * (size_t)nid + 1], colors2[3 * (size_t)nid + 2], 0.f);
     }
     for (uint32_t hi = maxlast; hi > 0; hi = hi > 64 ? hi - 64 : 0) {
         const float2 cxy = nxy;
         const float4 cco = nco;
         float4 crgb = nrgb;
         crgb.w = __uint_as_float(nid);
+        const float4 crgb2 = nrgb2;
         const bool have = (uint32_t)lane < hi;
         if (hi > 64 && (uint32_t)lane < hi - 64) {
             nid = point_list[begin + (hi - 64 - 1 - lane)];
             nxy = xy[nid]; nco = conic_o[nid]; nrgb = rgb_invd[nid];
+            if constexpr (DUAL) nrgb2 = make_float4(colors2[3 * (size_t)nid], colors2[3 * (size_t)nid + 1], colors2[3 * (size_t)nid + 2], 0.f);
         }
         float hx, hy;
         splat_extent(cco.x, cco.y, cco.z, cco.w, hx, hy);
@@ -683,6 +716,7 @@ __global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
         *reinterpret_cast<float4 *>(s_rec + my_off) = cco;
         *reinterpret_cast<float4 *>(s_rec + my_off + 16) = crgb;
         *reinterpret_cast<float2 *>(s_rec + my_off + 32) = cxy;
+        if constexpr (DUAL) s_rgb2[lane] = crgb2;
         {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4 *>(s_accb + my_off) = z;
@@ -737,6 +771,14 @@ __global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
                 a2 = last_alpha * lc2 + (1.f - last_alpha) * a2;
                 lc0 = ergb.x; lc1 = ergb.y; lc2 = ergb.z;
                 float dL_dalpha = ((ergb.x - a0) * g0 + (ergb.y - a1) * g1 + (ergb.z - a2) * g2) * T;
+                if constexpr (DUAL) {
+                    const float4 u = s_rgb2[off / kRecBytes];
+                    b0 = last_alpha * ld0 + (1.f - last_alpha) * b0;
+                    b1 = last_alpha * ld1 + (1.f - last_alpha) * b1;
+                    b2 = last_alpha * ld2 + (1.f - last_alpha) * b2;
+                    ld0 = u.x; ld1 = u.y; ld2 = u.z;
+                    dL_dalpha += ((u.x - b0) * h0 + (u.y - b1) * h1 + (u.z - b2) * h2) * T;
+                }
                 last_alpha = al;
                 dL_dalpha += (-T_final * inv1ma) * bg_dot;
                 const float gop = G * dL_dalpha;           // dL/dopacity term
@@ -831,11 +873,13 @@ static int composite_variant() {
     return v;
 }
 
-extern "C" int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const float *bg, const void *geom,
-                                         const void *binning, int64_t d_capacity, void *img, float *out_color,
-                                         float *out_invdepth, d3ga_stream_t stream) {
+static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
+                              int64_t d_capacity, void *img, float *out_color, float *out_invdepth, const float *colors2,
+                              const float *bg2, float *out_color2, d3ga_stream_t stream) {
     if (!prm || !bg || !geom || !binning || !img || !out_color) return D3GA_E_NULL;
     if (prm->P < 0 || prm->W <= 0 || prm->H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
+    if (colors2 && (!bg2 || !out_color2)) return D3GA_E_NULL;
+    if (colors2 && !(composite_variant() & 4)) return D3GA_E_CONFIG;          // only the row-segmented kernels blend two images
     hipStream_t s = (hipStream_t)stream;
     const int gx = tiles_x(prm->W), gy = tiles_y(prm->H);
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
@@ -843,10 +887,17 @@ extern "C" int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const fl
     const ImgBuf im = carve_img(img, prm->W, prm->H);
     if (composite_variant() & 4) {
         const bool ordered = (composite_variant() & 32) != 0;
-        hipLaunchKernelGGL(composite_fwd_rows_kernel, dim3(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy)),
-                           dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity,
-                           g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, out_color, out_invdepth,
-                           ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr);
+        if (colors2)
+            hipLaunchKernelGGL(composite_fwd_rows_kernel<true>, dim3(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy)),
+                               dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity,
+                               g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, out_color, out_invdepth,
+                               ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr, colors2, bg2, out_color2);
+        else
+            hipLaunchKernelGGL(composite_fwd_rows_kernel<false>, dim3(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy)),
+                               dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity,
+                               g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, out_color, out_invdepth,
+                               ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr,
+                               (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
     }
     else if (composite_variant() & 1)
         hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
@@ -857,6 +908,19 @@ extern "C" int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const fl
                            bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
                            im.final_T, im.n_contrib, out_color, out_invdepth);
     return check_launch(s, prm->debug);
+}
+
+extern "C" int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const float *bg, const void *geom,
+                                         const void *binning, int64_t d_capacity, void *img, float *out_color,
+                                         float *out_invdepth, d3ga_stream_t stream) {
+    return composite_fwd_impl(prm, bg, geom, binning, d_capacity, img, out_color, out_invdepth, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int d3ga_raster_composite_fwd2(const d3ga_raster_params *prm, const float *bg, const float *bg2, const void *geom,
+                                          const float *colors2, const void *binning, int64_t d_capacity, void *img,
+                                          float *out_color, float *out_color2, float *out_invdepth, d3ga_stream_t stream) {
+    if (!colors2) return D3GA_E_NULL;
+    return composite_fwd_impl(prm, bg, geom, binning, d_capacity, img, out_color, out_invdepth, colors2, bg2, out_color2, stream);
 }
 
 #ifdef D3GA_DIAG
@@ -870,13 +934,15 @@ extern "C" int d3ga_diag_read(unsigned long long *out8, int reset) {
 }
 #endif
 
-extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const float *bg, const void *geom,
-                                         const void *binning, int64_t d_capacity, const void *img,
-                                         const float *dL_dpix, float *acc, d3ga_stream_t stream) {
+static int composite_bwd_impl(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
+                              int64_t d_capacity, const void *img, const float *dL_dpix, float *acc, const float *colors2,
+                              const float *bg2, const float *dL_dpix2, d3ga_stream_t stream) {
     if (!prm) return D3GA_E_NULL;
     if (prm->P < 0 || prm->W <= 0 || prm->H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
     if (prm->P == 0) return D3GA_OK;
     if (!bg || !geom || !binning || !img || !dL_dpix || !acc) return D3GA_E_NULL;
+    if (colors2 && (!bg2 || !dL_dpix2)) return D3GA_E_NULL;
+    if (colors2 && !(composite_variant() & 8)) return D3GA_E_CONFIG;
     hipStream_t s = (hipStream_t)stream;
     const int gx = tiles_x(prm->W), gy = tiles_y(prm->H);
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
@@ -884,18 +950,26 @@ extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const fl
     const ImgBuf im = carve_img(const_cast<void *>(img), prm->W, prm->H);
 #ifdef D3GA_DIAG
     if (composite_variant() & 512) {
-        hipLaunchKernelGGL(composite_bwd_rows3_kernel, dim3(2 * quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
+        hipLaunchKernelGGL(composite_bwd_rows3_kernel<false>, dim3(2 * quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
                            gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
-                           im.final_T, im.n_contrib, dL_dpix, acc, (const uint32_t *)nullptr);
+                           im.final_T, im.n_contrib, dL_dpix, acc, (const uint32_t *)nullptr, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr);
         return check_launch(s, prm->debug);
     }
 #endif
     if (composite_variant() & 8) {
         const bool ordered = (composite_variant() & 32) != 0;
-        hipLaunchKernelGGL(composite_bwd_rows3_kernel, dim3(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy)),
-                           dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity,
-                           g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc,
-                           ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr);
+        if (colors2)
+            hipLaunchKernelGGL(composite_bwd_rows3_kernel<true>, dim3(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy)),
+                               dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity,
+                               g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc,
+                               ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr, colors2, bg2, dL_dpix2);
+        else
+            hipLaunchKernelGGL(composite_bwd_rows3_kernel<false>, dim3(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy)),
+                               dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity,
+                               g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc,
+                               ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr, (const float *)nullptr,
+                               (const float *)nullptr, (const float *)nullptr);
     }
     else if (composite_variant() & 2)
         hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
@@ -906,6 +980,19 @@ extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const fl
                            bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
                            im.final_T, im.n_contrib, dL_dpix, acc);
     return check_launch(s, prm->debug);
+}
+
+extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const float *bg, const void *geom,
+                                         const void *binning, int64_t d_capacity, const void *img,
+                                         const float *dL_dpix, float *acc, d3ga_stream_t stream) {
+    return composite_bwd_impl(prm, bg, geom, binning, d_capacity, img, dL_dpix, acc, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int d3ga_raster_composite_bwd2(const d3ga_raster_params *prm, const float *bg, const float *bg2, const void *geom,
+                                          const float *colors2, const void *binning, int64_t d_capacity, const void *img,
+                                          const float *dL_dpix, const float *dL_dpix2, float *acc, d3ga_stream_t stream) {
+    if (!colors2) return D3GA_E_NULL;
+    return composite_bwd_impl(prm, bg, geom, binning, d_capacity, img, dL_dpix, acc, colors2, bg2, dL_dpix2, stream);
 }
 
 // test hook (not part of the drop-in surface): n multiple of 256, in (n) -> out (10 * n/64)

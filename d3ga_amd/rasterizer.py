@@ -155,7 +155,7 @@ def _empty_to_none(t):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, grad_sync=None):
+                raster_settings, grad_sync=None, colors2=None, bg2=None):
         s = raster_settings
         require_cuda(means3D)
         dev = means3D.device
@@ -166,6 +166,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             _f32(t, dev) for t in (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
         view, proj, campos, bg = (_f32(t, dev) for t in (s.viewmatrix, s.projmatrix, s.campos, s.bg))
         P = means3D.shape[0]
+        dual = colors2 is not None and P > 0             # second image from the same pass (rasterize_gaussians_pair)
+        empty_pair = colors2 is not None and P == 0      # nothing to blend: the second image is its background
+        if colors2 is not None:
+            colors2, bg2 = _f32(colors2.detach(), dev), _f32(bg2, dev)
         H, W = int(s.image_height), int(s.image_width)
         M = sh.shape[1] if sh is not None else 0
         prm = RasterParams(P=P, M=M, sh_degree=int(s.sh_degree), W=W, H=H, tanfovx=float(s.tanfovx),
@@ -179,7 +183,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         static = _policy["mode"] == "static"
         cap = _policy["static"] if static else max(_hwm.get(dev.index, 0), 4 * P + 1024)
         geo_inputs = (means3D, opacities, scales, rotations, cov3Ds_precomp, view, proj)
-        use_cache = _reuse["enabled"] and P > 0 and not torch.cuda.is_current_stream_capturing()
+        color2 = torch.empty((3, H, W), dtype=torch.float32, device=dev) if dual else None
+        use_cache = _reuse["enabled"] and P > 0 and not dual and not torch.cuda.is_current_stream_capturing()
         key = _geometry_key(prm, ("static", cap) if static else "auto", geo_inputs) if use_cache else None
         hit = _geom_cache.get(dev.index) if use_cache else None
         if hit is not None and hit["key"] == key:
@@ -195,7 +200,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _last[dev.index] = (binning, cap)
         while hit is None or hit["key"] != key:
             geom, binning, img = _scratch(P, W, H, cap, dev)
-            if stage_timer.enabled:
+            if stage_timer.enabled or dual:
                 st, pp = stream_handle(), ctypes.byref(prm)
                 stage_timer.stage("preprocess", lambda: check(L.d3ga_raster_preprocess(
                     pp, dptr(means3D), dptr(sh), dptr(colors_precomp), dptr(opacities), dptr(scales), dptr(rotations),
@@ -203,9 +208,14 @@ class _RasterizeGaussians(torch.autograd.Function):
                     dptr(radii), st), "d3ga_raster_preprocess"))
                 stage_timer.stage("bin_sort", lambda: check(L.d3ga_raster_bin_sort(
                     pp, dptr(geom), dptr(binning), cap, st), "d3ga_raster_bin_sort"))
-                stage_timer.stage("composite_fwd", lambda: check(L.d3ga_raster_composite_fwd(
-                    pp, dptr(bg), dptr(geom), dptr(binning), cap, dptr(img), dptr(color), dptr(invdepth), st),
-                    "d3ga_raster_composite_fwd"))
+                if dual:
+                    stage_timer.stage("composite_fwd", lambda: check(L.d3ga_raster_composite_fwd2(
+                        pp, dptr(bg), dptr(bg2), dptr(geom), dptr(colors2), dptr(binning), cap, dptr(img), dptr(color),
+                        dptr(color2), dptr(invdepth), st), "d3ga_raster_composite_fwd2"))
+                else:
+                    stage_timer.stage("composite_fwd", lambda: check(L.d3ga_raster_composite_fwd(
+                        pp, dptr(bg), dptr(geom), dptr(binning), cap, dptr(img), dptr(color), dptr(invdepth), st),
+                        "d3ga_raster_composite_fwd"))
             else:
                 check(L.d3ga_raster_forward(ctypes.byref(prm), dptr(means3D), dptr(sh), dptr(colors_precomp),
                                             dptr(opacities), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp),
@@ -229,15 +239,27 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.cap = cap
         ctx.has_means2D = means2D is not None
         ctx.grad_sync = grad_sync if (grad_sync is not None and grad_sync.world > 1 and P > 0) else None
-        ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img)
+        ctx.dual = dual
+        ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img,
+                              colors2, bg2)
         ctx.mark_non_differentiable(radii, invdepth)
+        if dual:
+            return color, radii, invdepth, color2
+        if empty_pair:
+            return color, radii, invdepth, bg2.reshape(3, 1, 1).expand(3, H, W).contiguous()
         return color, radii, invdepth
 
     @staticmethod
-    def backward(ctx, grad_color, _grad_radii, _grad_invdepth):
-        means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img = ctx.saved_tensors
+    def backward(ctx, grad_color, _grad_radii, _grad_invdepth, grad_color2=None):
+        (means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img, colors2,
+         bg2) = ctx.saved_tensors
         prm, dev, P = ctx.prm, means3D.device, means3D.shape[0]
+        dual = ctx.dual
+        if grad_color is None:                           # only the second image was used
+            grad_color = torch.zeros((3, prm.H, prm.W), dtype=torch.float32, device=dev)
         grad_color = _f32(grad_color, dev)
+        if dual:
+            grad_color2 = (torch.zeros_like(grad_color) if grad_color2 is None else _f32(grad_color2, dev))
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         acc = new(P, 12)
         from_sr = cov3Ds_precomp is None
@@ -270,12 +292,17 @@ class _RasterizeGaussians(torch.autograd.Function):
                 factor = new(P + 1, 3)
                 g_col = factor[:P]
         L = _lib.lib()
-        if stage_timer.enabled:
+        if stage_timer.enabled or dual:
             st, pp = stream_handle(), ctypes.byref(prm)
             acc.zero_()
-            stage_timer.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd(
-                pp, dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img), dptr(grad_color), dptr(acc), st),
-                "d3ga_raster_composite_bwd"))
+            if dual:
+                stage_timer.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd2(
+                    pp, dptr(bg), dptr(bg2), dptr(geom), dptr(colors2), dptr(binning), ctx.cap, dptr(img), dptr(grad_color),
+                    dptr(grad_color2), dptr(acc), st), "d3ga_raster_composite_bwd2"))
+            else:
+                stage_timer.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd(
+                    pp, dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img), dptr(grad_color), dptr(acc), st),
+                    "d3ga_raster_composite_bwd"))
             stage_timer.stage("preprocess_bwd", lambda: check(L.d3ga_raster_preprocess_bwd(
                 pp, dptr(means3D), dptr(sh), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp), dptr(view), dptr(proj),
                 dptr(campos), dptr(geom), dptr(acc), dptr(g_means3D), dptr(g_means2D), dptr(g_opac), dptr(g_sh),
@@ -297,13 +324,21 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                 stream_handle()), "d3ga_sh_grad_from_views")
                 g_col = None
         return (g_means3D, g_means2D if ctx.has_means2D else None, g_sh, g_col, g_opac, g_scales, g_rots, g_cov, None,
-                None)
+                None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, grad_sync=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, grad_sync)
+
+
+def rasterize_gaussians_pair(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                             raster_settings, colors2, bg2, grad_sync=None):
+    """Two images from ONE pass: the usual one and `colors2` (P,3; constants, no gradient) blended with the same alphas over
+    `bg2`.  Returns (color, radii, invdepth, color2).  Gradients of both images reach the geometry and the opacities."""
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings, grad_sync, colors2, bg2)
 
 
 class GaussianRasterizer(nn.Module):

@@ -4,7 +4,7 @@ solid_bg=True, fast=False, detach=[]) -> {"render": (3,H',W')}` (renderer.py:69-
 import torch
 
 from .cameras import batch_to_camera
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_pair
 
 bg_colors = {"white": (1.0, 1.0, 1.0), "black": (0.0, 0.0, 0.0)}
 
@@ -34,8 +34,17 @@ def paste(img, crop):
     return img
 
 
+def render_pair(batch, pkg, bg_color, colors2, bg_color2, grad_sync=None):
+    """The two renders of the reference's training step (models/trainer.py:102-110: `render(frame, pkg, bg)` and
+    `render(frame, pkg, colors_precomp=pkg["silhouette_rgb"], bg_color=zeros)`) from ONE pass over the same geometry:
+    -> {"render": (3,H',W'), "render2": (3,H',W')}.  Same images and the same summed gradients as the two calls (colors2
+    is treated as constant, as the reference's silhouette colours are); use the two calls when `detach` differs."""
+    out = render(batch, pkg, bg_color, grad_sync=grad_sync, _pair=(colors2, bg_color2))
+    return out
+
+
 def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_bg=True, fast=False, detach=[],
-           grad_sync=None):
+           grad_sync=None, _pair=None):
     means3D = pkg["means3D"]
     cam = batch_to_camera(batch, device=means3D.device)
     crop = batch["crop"]
@@ -85,6 +94,10 @@ def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_
     except Exception:
         pass
 
+    if _pair is not None:
+        img, _radii, _invd, img2 = rasterize_gaussians_pair(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                                            cov3D_precomp, settings, _pair[0], _pair[1], grad_sync)
+        return {"render": paste(img, crop), "render2": paste(img2, crop)}
     rasterizer = GaussianRasterizer(raster_settings=settings)
     if grad_sync is not None:                       # extension over upstream's constructor: set only when asked for
         rasterizer.grad_sync = grad_sync

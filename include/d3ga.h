@@ -154,6 +154,18 @@ int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const float *bg, co
 int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, const void *img, const float *dL_dpix, float *acc,
                               d3ga_stream_t stream);
+
+/* Two images from one pass (an extension over upstream's rasterizer; the reference's training step renders every package
+ * twice with the same geometry and opacities -- RGB, then constant silhouette colours on black, models/trainer.py:102-110):
+ * colors2 (P,3) is blended with the same alphas into out_color2 over bg2; alpha, T, the tile lists and the early exit are
+ * shared.  The backward adds the second image's dL/dpixel to dL/dalpha; NO gradient is produced for colors2 (constants).
+ * geom / binning / img exactly as for the single-image calls. */
+int d3ga_raster_composite_fwd2(const d3ga_raster_params *prm, const float *bg, const float *bg2, const void *geom,
+                               const float *colors2, const void *binning, int64_t d_capacity, void *img, float *out_color,
+                               float *out_color2, float *out_invdepth, d3ga_stream_t stream);
+int d3ga_raster_composite_bwd2(const d3ga_raster_params *prm, const float *bg, const float *bg2, const void *geom,
+                               const float *colors2, const void *binning, int64_t d_capacity, const void *img,
+                               const float *dL_dpix, const float *dL_dpix2, float *acc, d3ga_stream_t stream);
 /* Re-render of the SAME geometry (same means3D / covariance / opacities / camera / image size) with other colours: the
  * reference's training step renders an RGB and a silhouette pass from one package (models/trainer.py:102-110).
  * Copies the geometry records of geom_src (a d3ga_raster_preprocess result) to geom_dst and evaluates only the colour

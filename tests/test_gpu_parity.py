@@ -461,6 +461,48 @@ def test_hipgraph_replay_equals_eager():
         R.set_capacity_policy("auto")
 
 
+@pytest.mark.parametrize("sh_path", [True, False])
+def test_render_pair_equals_the_two_renders_of_the_training_step(sh_path):
+    """render_pair (one compositing pass, two images) against the reference's two calls (models/trainer.py:102-110):
+    render(pkg, bg) and render(pkg, colors_precomp=silhouette_rgb, bg=0) -- images bit-identical, the gradients of a loss
+    on both images equal to the sum over the two separate renders."""
+    from d3ga_amd.renderer import render, render_pair
+    inp = scene_inputs("T1", scale_mult=3.0)
+    g = torch.Generator().manual_seed(21)
+    P = inp["means3D"].shape[0]
+    sil = torch.rand(P, 3, generator=g).to(DEV)                       # per-Gaussian constants (one colour per cage upstream)
+    bg, bg0 = torch.tensor([0.3, 0.6, 0.9], device=DEV), torch.zeros(3, device=DEV)
+    t1 = torch.rand(3, inp["H"], inp["W"], generator=g).to(DEV)
+    t2 = torch.rand(3, inp["H"], inp["W"], generator=g).to(DEV)
+
+    def leaves():
+        return [_cu(inp["means3D"], True), _cu(inp["cov6"], True), _cu(inp["opacities"], True),
+                _cu(inp["shs"], True) if sh_path else _cu(torch.rand(P, 3, generator=torch.Generator().manual_seed(4)), True)]
+
+    def pkg_of(l):
+        return {"means3D": l[0], "cov3D_precomp": l[1], "opacities": l[2], "shs": l[3] if sh_path else None,
+                "rgb": None if sh_path else l[3], "sh_degree": 3}
+
+    a = leaves()
+    i1 = render(inp["batch"], pkg_of(a), bg)["render"]
+    i2 = render(inp["batch"], pkg_of(a), bg0, colors_precomp=sil)["render"]
+    ((i1 - t1).abs().mean() + 0.7 * (i2 - t2).abs().mean()).backward()
+    b = leaves()
+    out = render_pair(inp["batch"], pkg_of(b), bg, sil, bg0)
+    ((out["render"] - t1).abs().mean() + 0.7 * (out["render2"] - t2).abs().mean()).backward()
+    assert torch.equal(out["render"], i1) and torch.equal(out["render2"], i2)
+    for x, y, name in zip(a, b, ("means3D", "cov3D", "opacity", "colour")):
+        assert rel_err(_np(y.grad), _np(x.grad)) < 1e-4, name
+    # only the second image in the loss
+    c = leaves()
+    out = render_pair(inp["batch"], pkg_of(c), bg, sil, bg0)
+    (out["render2"] - t2).abs().mean().backward()
+    d = leaves()
+    (render(inp["batch"], pkg_of(d), bg0, colors_precomp=sil)["render"] - t2).abs().mean().backward()
+    for x, y, name in zip(d[:3], c[:3], ("means3D", "cov3D", "opacity")):
+        assert rel_err(_np(y.grad), _np(x.grad)) < 1e-4, name
+
+
 def test_multi_view_gradient_sum_matches_sequential():
     """Camera sharding invariant: the mean over V views of the per-view parameter gradients equals
     the gradient of the mean loss -- checked here by rendering V views sequentially on one GPU."""
