@@ -92,6 +92,49 @@ def test_exchange_at_the_cut_equals_mean_of_per_view_gradients(path):
         assert float(got["shs"].abs().max()) > 0
 
 
+def test_pair_render_exchanges_like_two_renders():
+    """render_pair under view sharding: the summed gradient of both images crosses the cut in ONE exchange and equals the
+    mean over the views of the two-call gradients."""
+    from d3ga_amd.rasterizer import GaussianRasterizer, rasterize_gaussians_pair
+    inp = scene_inputs("T1", scale_mult=3.0)
+    g = torch.Generator().manual_seed(9)
+    t1 = torch.rand(3, inp["H"], inp["W"], generator=g).to(DEV)
+    t2 = torch.rand(3, inp["H"], inp["W"], generator=g).to(DEV)
+    sil = torch.rand(inp["means3D"].shape[0], 3, generator=g).to(DEV)
+    bg0 = torch.zeros(3, device=DEV)
+    leaf = lambda t: t.to(DEV).clone().requires_grad_(True)
+    args = {"means3D": leaf(inp["means3D"]), "opacities": leaf(inp["opacities"]), "shs": leaf(inp["shs"]),
+            "cov3D_precomp": leaf(inp["cov6"])}
+
+    def two_calls(azimuth):
+        for t in args.values():
+            t.grad = None
+        st = _settings(inp, azimuth)
+        i1 = GaussianRasterizer(st)(means2D=torch.zeros_like(args["means3D"], requires_grad=True), **args)[0]
+        a2 = {k: v for k, v in args.items() if k != "shs"}
+        i2 = GaussianRasterizer(st._replace(bg=bg0))(means2D=torch.zeros_like(args["means3D"], requires_grad=True),
+                                                     colors_precomp=sil, **a2)[0]
+        ((i1 - t1).abs().mean() + (i2 - t2).abs().mean()).backward()
+        return {k: t.grad.clone() for k, t in args.items()}
+
+    def pair(azimuth, sync):
+        for t in args.values():
+            t.grad = None
+        i1, _r, _d, i2 = rasterize_gaussians_pair(args["means3D"], torch.zeros_like(args["means3D"], requires_grad=True),
+                                                  args["shs"], None, args["opacities"], None, None, args["cov3D_precomp"],
+                                                  _settings(inp, azimuth), sil, bg0, sync)
+        ((i1 - t1).abs().mean() + (i2 - t2).abs().mean()).backward()
+        return {k: t.grad.clone() for k, t in args.items()}
+
+    gA, gB = two_calls(0.3), two_calls(2.1)
+    rec = _Record()
+    pair(2.1, rec)
+    got = pair(0.3, _Replay(rec))
+    for k in args:
+        want = 0.5 * (gA[k] + gB[k])
+        assert rel_err(got[k].cpu().numpy(), want.cpu().numpy()) < 1e-4, k
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
