@@ -325,6 +325,32 @@ __device__ __forceinline__ void wg_commit(const float2 (&v)[8], const WgJob &job
     }
 }
 
+// the same commit for the wavefront-specialised kernel below (4 row groups per plane instead of 8)
+__device__ __forceinline__ void wg_commit_ws(const float2 (&v)[8], const WgJob &job, int r0, int r_end, float (&colsum)[2]) {
+    const int c = job.c;
+    float x[8], y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool ok = r0 + 8 * job.g + i < r_end;
+        x[i] = (ok && c < job.width) ? v[i].x : 0.f;
+        y[i] = (ok && c + 1 < job.width) ? v[i].y : 0.f;
+        colsum[0] += x[i];
+        colsum[1] += y[i];
+    }
+    uint32_t px[3][4], py[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bf16_split2(x[2 * q], x[2 * q + 1], px[0][q], px[1][q], px[2][q]);
+        bf16_split2(y[2 * q], y[2 * q + 1], py[0][q], py[1][q], py[2][q]);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        uint4 *d = job.s_op + pl * (4 * 128) + job.g * 128 + c;
+        d[0] = make_uint4(px[pl][0], px[pl][1], px[pl][2], px[pl][3]);
+        d[1] = make_uint4(py[pl][0], py[pl][1], py[pl][2], py[pl][3]);
+    }
+}
+
 // Loader assignment (all wave-uniform).  Both operands wide: wavefronts 0-7 take dPre, 8-15 take X, row group w & 7, lane l
 // the columns 2l, 2l+1.  One operand narrow (<= 16 columns: the first and last layers of the fields): the WIDE one is
 // spread over all 16 wavefronts (row group w & 7, column 64 (w >> 3) + l) so that as many bytes stay in flight as in
@@ -413,6 +439,128 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_kernel(int P, int N, int K, 
         }
     }
 }
+
+// Wavefront-specialised variant for two wide operands (the square layers): wavefronts 0-7 only MOVE data (global ->
+// registers -> split -> LDS), wavefronts 8-15 only MULTIPLY.  Chunks of 32 rows, two LDS buffers: while the loaders
+// commit chunk c into buffer c & 1 the multipliers work on chunk c - 1 in the other buffer, one barrier per chunk.  (In
+// wgrad_kernel every wavefront does both and the two phases are separated by barriers: measured, the 3100-cycle multiply
+// phase of each chunk simply ADDS to the load / commit skeleton -- 161 vs 118 us per 128x128 layer at 500k rows.)
+// Loader w: operand w >> 2 (dPre | X), row group w & 3, lane l the columns 2l, 2l+1, two chunks of loads in flight.
+// Multiplier m: column block nb = m / NBk2 of dPre against the k blocks 2 (m % NBk2), +1 of X (the A operand is read once
+// for both).
+constexpr int kWsRows = 32;
+constexpr int kWsPlaneUnits = 4 * 128;                              // [row group][column]
+constexpr int kWsOperandUnits = 3 * kWsPlaneUnits;
+constexpr int kWsBufferUnits = 2 * kWsOperandUnits;                 // dPre planes | X planes
+template <bool VECA, bool VECB>
+__global__ __launch_bounds__(kWgThreads) void wgrad_ws_kernel(int P, int N, int K, int NBk, int NBn, int rows_per_block,
+                                                              const float *__restrict__ dpre, const float *__restrict__ X,
+                                                              float *__restrict__ dW, float *__restrict__ db) {
+    extern __shared__ __attribute__((aligned(16))) char smem_ws[];     // two buffers x (dPre planes | X planes)
+    uint4 *s_buf = reinterpret_cast<uint4 *>(smem_ws);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int r_end = min(P, r_begin + rows_per_block);
+    if (r_begin >= r_end) return;
+    const int n_chunks = (r_end - r_begin + kWsRows - 1) / kWsRows;
+    const bool loader = wave < 8;
+    // loader state
+    const bool is_a = wave < 4;
+    WgJob job = {is_a ? dpre : X, nullptr, is_a ? N : K, wave & 3, 2 * lane, 2, is_a};
+    float2 v0[8], v1[8];
+    float cs[2] = {0.f, 0.f};
+    // multiplier state
+    const int m = wave - 8, NBk2 = (NBk + 1) / 2;
+    const bool worker = !loader && m < NBn * NBk2;
+    const int nb = worker ? m / NBk2 : 0, kb0 = worker ? 2 * (m - nb * NBk2) : 0;
+    const bool two = kb0 + 1 < NBk;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    auto fetch = [&](float2 (&v)[8], int c) __attribute__((always_inline)) {
+        const int r0 = min(r_begin + c * kWsRows, r_end - 1);          // past the range: clamped rows, never committed
+        if (is_a) wg_issue<VECA>(v, job, r0, r_end); else wg_issue<VECB>(v, job, r0, r_end);
+    };
+    auto commit = [&](const float2 (&v)[8], int c) __attribute__((always_inline)) {
+        WgJob j = job;
+        j.s_op = s_buf + (c & 1) * kWsBufferUnits + (is_a ? 0 : kWsOperandUnits);
+        wg_commit_ws(v, j, r_begin + c * kWsRows, r_end, cs);
+    };
+    auto multiply = [&](int c) __attribute__((always_inline)) {
+        const uint4 *pa = s_buf + (c & 1) * kWsBufferUnits + half * 128 + 32 * nb + l32;
+        const uint4 *pb = s_buf + (c & 1) * kWsBufferUnits + kWsOperandUnits + half * 128 + 32 * kb0 + l32;
+#pragma unroll
+        for (int ks = 0; ks < kWsRows / 16; ++ks) {
+            bf16x8_t a[3], b[3], d[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                a[pl] = __builtin_bit_cast(bf16x8_t, pa[pl * kWsPlaneUnits + 2 * ks * 128]);
+                b[pl] = __builtin_bit_cast(bf16x8_t, pb[pl * kWsPlaneUnits + 2 * ks * 128]);
+                d[pl] = __builtin_bit_cast(bf16x8_t, pb[pl * kWsPlaneUnits + 2 * ks * 128 + (two ? 32 : 0)]);
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], d[0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], d[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], d[2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], d[0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], d[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], d[0], acc1, 0, 0, 0);
+        }
+    };
+    if (loader) {
+        fetch(v0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(v1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // iteration c: loaders commit chunk c (even chunks live in v0, odd in v1) and re-issue that register set for chunk
+    // c + 2; multipliers work on chunk c - 1.  One barrier per iteration; one more round drains the pipeline.
+    for (int c = 0; c <= n_chunks; c += 2) {
+        if (loader) {
+            if (c < n_chunks) { commit(v0, c); fetch(v0, c + 2); }
+        } else if (worker && c >= 1) multiply(c - 1);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 <= n_chunks) {                                       // (uniform)
+            if (loader) {
+                if (c + 1 < n_chunks) { commit(v1, c + 1); fetch(v1, c + 3); }
+            } else if (worker) multiply(c);
+            __syncthreads();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // bias gradient: the dPre loaders hold the sums of their columns over their row groups
+    if (db) {
+        __syncthreads();
+        float *s_sum = reinterpret_cast<float *>(smem_ws);
+        if (tid < 128) s_sum[tid] = 0.f;
+        __syncthreads();
+        if (loader && is_a) { if (job.c < N) atomicAdd(s_sum + job.c, cs[0]); if (job.c + 1 < N) atomicAdd(s_sum + job.c + 1, cs[1]); }
+        __syncthreads();
+        if (tid < N) atomicAdd(db + tid, s_sum[tid]);
+    }
+    if (!worker) return;
+    // C/D layout: col = lane & 31 -> k, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> n
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        if (blk == 1 && !two) break;
+        const int k = 32 * (kb0 + blk) + l32;
+        if (k < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (nn < N) atomicAdd(dW + (uint32_t)nn * (uint32_t)K + (uint32_t)k, blk ? acc1[r] : acc0[r]);
+            }
+        }
+    }
+}
+
 
 }  // namespace d3ga
 
@@ -517,6 +665,7 @@ static int mlp_wgrad_launch(int32_t P, int32_t N, int32_t K, const float *dpre, 
     const size_t lds = 2 * (size_t)kWgOperandBytes;
     const bool va = N % 2 == 0 && ((uintptr_t)dpre & 7) == 0, vb = K % 2 == 0 && ((uintptr_t)X & 7) == 0;   // float2 loads
     const bool mixed = N <= 16 || K <= 16;
+    static const bool use_ws = [] { const char *e = getenv("D3GA_WGRAD_WS"); return !e || atoi(e) != 0; }();   // A/B knob
 #define D3GA_WG(VA, VB, MX)                                                                                           \
     do {                                                                                                              \
         static bool attr[64] = {};                                                                                    \
@@ -530,9 +679,24 @@ static int mlp_wgrad_launch(int32_t P, int32_t N, int32_t K, const float *dpre, 
         hipLaunchKernelGGL((wgrad_kernel<VA, VB, MX>), dim3(grid), dim3(kWgThreads), lds, s, P, N, K, NBk, NBn * NBk, \
                            rows, dpre, X, dW, db);                                                                    \
     } while (0)
+#define D3GA_WS(VA, VB)                                                                                               \
+    do {                                                                                                              \
+        static bool attr[64] = {};                                                                                    \
+        int dev = 0;                                                                                                  \
+        D3GA_HIP(hipGetDevice(&dev));                                                                                 \
+        const size_t lds_ws = 2 * (size_t)kWsBufferUnits * 16;                                                        \
+        if (dev >= 0 && dev < 64 && !attr[dev]) {                                                                     \
+            D3GA_HIP(hipFuncSetAttribute((const void *)wgrad_ws_kernel<VA, VB>,                                       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));                   \
+            attr[dev] = true;                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((wgrad_ws_kernel<VA, VB>), dim3(grid), dim3(kWgThreads), lds_ws, s, P, N, K, NBk, NBn, rows, \
+                           dpre, X, dW, db);                                                                          \
+    } while (0)
 #define D3GA_WG2(VA, VB)                                                                                              \
     do {                                                                                                              \
         if (mixed) D3GA_WG(VA, VB, true);                                                                             \
+        else if (use_ws) D3GA_WS(VA, VB);                                                                             \
         else D3GA_WG(VA, VB, false);                                                                                  \
     } while (0)
     if (va && vb) D3GA_WG2(true, true);
@@ -540,6 +704,7 @@ static int mlp_wgrad_launch(int32_t P, int32_t N, int32_t K, const float *dpre, 
     else if (vb) D3GA_WG2(false, true);
     else D3GA_WG2(false, false);
 #undef D3GA_WG2
+#undef D3GA_WS
 #undef D3GA_WG
     return check_launch(s, 0);
 }
