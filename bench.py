@@ -413,10 +413,11 @@ def main():
     # The step is launch-bound on the host (~50 small launches): capture ONE whole step -- LBS, deform, rasterizer
     # forward, loss, the full backward -- into a hipGraph and replay it.  Same kernels, same order, same stream
     # semantics; only the per-launch host work disappears.  The gradient all-reduce (N > 1) stays outside the graph.
-    # (N > 1 runs eagerly: replaying a captured backward and then reducing its graph-pool gradient tensors with a
-    # collective corrupted the graph's private pool in a 2-rank gloo test on this PyTorch-ROCm build, and the RCCL
-    # path cannot be exercised on the 1-GPU development box.  At C3 eager and replay are equally fast -- the host
-    # enqueues a step in ~0.75 ms against ~1.1 ms of GPU time.)
+    # (N > 1 runs eagerly: the cut exchange sits INSIDE the backward, so capturing the step would capture the collectives;
+    # RCCL supports that in principle, but it cannot be exercised on the 1-GPU development box and gloo cannot be captured
+    # at all.  An earlier 2-rank gloo experiment that replayed a captured backward and then reduced its gradients
+    # "corrupted the graph's pool" -- in hindsight most likely the memset-node ordering bug described in DESIGN.md sec. 5,
+    # fixed since.  At C3 the eager host cost is ~0.75 ms per step against ~0.70 ms of GPU work plus the exchange.)
     graph = None
     if not args.no_graph and world == 1:
         flat.zero()
