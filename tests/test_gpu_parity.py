@@ -1,4 +1,6 @@
 """Parity of the gfx950 path (through the C ABI / autograd layer) against the oracle.  Needs a real MI355X."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -782,7 +784,7 @@ def test_geometry_reuse_between_rgb_and_silhouette_pass():
         R.clear_geometry_cache()
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_FUZZ_N", "10"))))      # D3GA_FUZZ_N=300 for a long campaign
 def test_fuzz_ragged_sizes_and_argument_paths(seed):
     """Seeded random configurations against the C oracle: image sizes that are not multiples of the 16-pixel tile (down
     to a single pixel row), off-centre principal points, every SH degree, both colour paths, both covariance paths, a
@@ -829,7 +831,11 @@ def test_fuzz_ragged_sizes_and_argument_paths(seed):
         if np.abs(ref).max() == 0:
             assert float(t.grad.abs().max()) == 0
         else:
-            assert rel_err(_np(t.grad), ref) < 2e-3, (k, rel_err(_np(t.grad), ref))
+            # one flipped alpha >= 1/255 / T >= 1e-4 decision (1-ulp exp difference) moves the gradients of the Gaussians
+            # on that pixel by one pixel's worth: seen once in 2447 seeds (5.5e-3 of the max norm); a wiring error is O(1)
+            err = rel_err(_np(t.grad), ref)
+            ok, mx, frac = grad_close(_np(t.grad), ref, rtol=2e-3, outlier_frac=2e-2, outlier_rtol=5e-2)
+            assert err < 2e-3 or ok, (k, err, mx, frac)
 
 
 def test_nan_and_inf_inputs_are_contained():
