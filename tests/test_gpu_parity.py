@@ -62,6 +62,48 @@ def test_cage_deform_matches_reference_golden(golden):
         assert rel_err(_np(r.grad), _np(r64.grad)) < 1e-3
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_DEFORM_FUZZ_N", "5"))))
+def test_cage_deform_fuzz(seed):
+    """cage_deform / lbs_cage / fem_energy over random cages (V vertices, T tets with random corners, P Gaussians with
+    random tet ids incl. repeats and unused tets, fused and plain activations) against the oracle in f64: values and every
+    gradient.  D3GA_DEFORM_FUZZ_N=1000 for a campaign."""
+    from d3ga_amd.cage_deform import cage_deform, fem_energy, lbs_cage
+    rng = np.random.default_rng(9000 + seed)
+    V, T = int(rng.integers(4, 400)), int(rng.integers(1, 900))
+    P = int(rng.choice([1, 2, 63, 64, 65, 255, 257, int(rng.integers(1, 5000))]))
+    g = torch.Generator().manual_seed(seed)
+    canon = torch.randn(V, 3, generator=g)
+    tetras = torch.stack([torch.randperm(V, generator=g)[:4] for _ in range(T)]).int()
+    tet_id = torch.randint(0, T, (P,), generator=g).int()
+    barys = torch.rand(P, 4, generator=g); barys = barys / barys.sum(1, keepdim=True)
+    cg = od.canonical_gradient(canon.double(), tetras.long(), tet_id.long())
+    if not torch.isfinite(cg).all() or float(cg.abs().max()) > 1e4:        # a (nearly) flat random tet: no inverse
+        pytest.skip("degenerate random tet")
+    tp0 = canon + 0.1 * torch.randn(V, 3, generator=g)
+    raw_s, rot = 0.3 * torch.randn(P, 3, generator=g) - 2.0, torch.randn(P, 4, generator=g)
+    dbary = 0.05 * torch.randn(P, 4, generator=g)
+    fused = bool(seed % 2)
+    up_m, up_c = torch.randn(P, 3, generator=g), torch.randn(P, 6, generator=g)
+    # oracle, f64
+    L64 = lambda t: t.double().requires_grad_(True)
+    tp64, b64, s64, r64, d64 = L64(tp0), L64(barys), L64(raw_s), L64(rot), L64(dbary)
+    m64, c64 = od.cage_deform(tp64, tetras.long(), tet_id.long(), (b64 + d64) if fused else b64, cg, torch.exp(s64), r64)
+    ((m64 * up_m.double()).sum() + (c64 * up_c.double()).sum()).backward()
+    # product
+    tp, b, sr, r, db = (_cu(t, True) for t in (tp0, barys, raw_s, rot, dbary))
+    if fused:
+        m, c = cage_deform(tp, tetras.to(DEV), tet_id.to(DEV), b, cg.float().to(DEV), sr, r, delta_barys=db, scale_activation="exp")
+    else:
+        m, c = cage_deform(tp, tetras.to(DEV), tet_id.to(DEV), b, cg.float().to(DEV), torch.exp(sr), r)
+    ((m * up_m.to(DEV)).sum() + (c * up_c.to(DEV)).sum()).backward()
+    tag = (seed, V, T, P, fused)
+    np.testing.assert_allclose(_np(m), m64.detach().numpy(), rtol=1e-4, atol=1e-5, err_msg=str(tag))
+    assert rel_err(_np(c), c64.detach().numpy()) < 1e-4, tag
+    for mine, ref, name in ((tp.grad, tp64.grad, "tetpoints"), (b.grad, b64.grad, "barys"), (sr.grad, s64.grad, "scales"),
+                            (r.grad, r64.grad, "rot")) + (((db.grad, d64.grad, "dbary"),) if fused else ()):
+        assert rel_err(_np(mine), ref.numpy()) < 1e-3, (tag, name)
+
+
 def test_lbs_and_fem_match_oracle(golden):
     from d3ga_amd.cage_deform import fem_energy, lbs_cage
     inp = scene_inputs("T1")
