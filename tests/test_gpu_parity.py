@@ -769,6 +769,31 @@ def test_full_size_c5_properties_without_an_oracle():
     assert rel_err(_np(m.grad), -3.0 * _np(g1)) < 1e-4
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_LOSS_FUZZ_N", "5"))))
+def test_losses_fuzz(seed):
+    """l1_loss, ssim and the fused l1_ssim pair at random image sizes (1..300 px per side: every ragged border of the
+    16x32 SSIM tiles) against the oracle: values and the gradient w.r.t. the first image."""
+    from d3ga_amd.losses import l1_loss, l1_ssim, ssim
+    from oracle import losses as ol
+    rng = np.random.default_rng(11000 + seed)
+    C, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 300)), int(rng.integers(1, 300))
+    g = torch.Generator().manual_seed(seed)
+    b = torch.rand(C, H, W, generator=g)
+    a = (b + 0.3 * torch.randn(C, H, W, generator=g)).clamp(0, 1)
+    a64 = a.double().requires_grad_(True)
+    vo_s, vo_l = ol.ssim(a64, b.double()), ol.l1_loss(a64, b.double())
+    (0.7 * vo_l + 0.3 * (1 - vo_s)).backward()
+    ad = a.to(DEV).requires_grad_(True)
+    l1v, sv = l1_ssim(ad, b.to(DEV))
+    (0.7 * l1v + 0.3 * (1 - sv)).backward()
+    tag = (seed, C, H, W)
+    assert abs(float(sv.detach()) - float(vo_s.detach())) < 5e-6 and abs(float(l1v.detach()) - float(vo_l.detach())) < 1e-6, tag
+    assert rel_err(_np(ad.grad), a64.grad.numpy()) < 5e-5, tag
+    a2 = a.to(DEV).requires_grad_(True)
+    (0.7 * l1_loss(a2, b.to(DEV)) + 0.3 * (1 - ssim(a2, b.to(DEV)))).backward()
+    assert rel_err(_np(a2.grad), a64.grad.numpy()) < 5e-5, tag
+
+
 def test_fused_ssim_matches_reference_goldens_and_oracle(golden):
     """d3ga_ssim_{fwd,bwd} against (i) values and gradients of the reference's own ssim() (loss_cases.npz) and (ii) the
     oracle at image sizes with ragged tile borders and at 1080p; gradient w.r.t. both images."""
