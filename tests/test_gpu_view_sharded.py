@@ -54,11 +54,15 @@ class _Replay:
         return None if factor is None else torch.stack([factor, self.rec.factor])
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_SHARD_FUZZ_N", "1"))))
 @pytest.mark.parametrize("path", ["sh_cov", "sh_scale_rot", "rgb_cov"])
-def test_exchange_at_the_cut_equals_mean_of_per_view_gradients(path):
+def test_exchange_at_the_cut_equals_mean_of_per_view_gradients(path, seed):
     from d3ga_amd.rasterizer import GaussianRasterizer
-    inp = scene_inputs("T1", scale_mult=3.0)
-    g = torch.Generator().manual_seed(5)
+    rng = np.random.default_rng(13000 + seed)
+    az_a, az_b = (0.3, 2.1) if seed == 0 else (float(rng.uniform(0, 6.28)), float(rng.uniform(0, 6.28)))
+    inp = scene_inputs("T1", scale_mult=3.0) if seed == 0 else scene_inputs(
+        ["T0", "T1"][seed % 2], seed=int(rng.integers(1, 10_000)), scale_mult=float(rng.uniform(0.5, 8.0)))
+    g = torch.Generator().manual_seed(5 + seed)
     target = torch.rand(3, inp["H"], inp["W"], generator=g).to(DEV)
     leaf = lambda t: t.to(DEV).clone().requires_grad_(True)
     args = {"means3D": leaf(inp["means3D"]), "opacities": leaf(inp["opacities"])}
@@ -80,15 +84,15 @@ def test_exchange_at_the_cut_equals_mean_of_per_view_gradients(path):
         (img - target).abs().mean().backward()
         return {k: t.grad.clone() for k, t in args.items()}
 
-    gA, gB = grads(0.3, None), grads(2.1, None)
+    gA, gB = grads(az_a, None), grads(az_b, None)
     rec = _Record()
-    grads(2.1, rec)                                   # view B, recorded
-    got = grads(0.3, _Replay(rec))                    # view A + replayed peer
+    grads(az_b, rec)                                  # view B, recorded
+    got = grads(az_a, _Replay(rec))                   # view A + replayed peer
     for k in args:
         want = 0.5 * (gA[k] + gB[k])
         err = rel_err(got[k].cpu().numpy(), want.cpu().numpy())
-        assert err < 1e-5, (path, k, err)        # run-to-run float-atomic ordering is ~1e-7; a wiring error is O(1)
-    if path.startswith("sh"):
+        assert err < 1e-4, (path, seed, k, err)  # float-atomic ordering: ~1e-7 typical, 1.1e-5 seen once in 900; a wiring error is O(1)
+    if path.startswith("sh") and seed == 0:
         assert float(got["shs"].abs().max()) > 0
 
 
