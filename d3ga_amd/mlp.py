@@ -184,6 +184,7 @@ class FieldMLP(nn.Module):
         super().__init__()
         self.network = nn.ModuleList([nn.Linear(n_input, n_nodes)] + [nn.Linear(n_nodes, n_nodes) for _ in range(n_layers)])
         self.output = nn.Linear(n_nodes, n_output)
+        self._col_index = {}             # forward_parts: column layout -> (per-row columns, broadcast columns) index tensors
         with torch.no_grad():
             self.output.weight *= 0.33
             for layer in self.network:
@@ -194,22 +195,24 @@ class FieldMLP(nn.Module):
         1-D broadcast vector (ColorField mixes both kinds: models/mlp.py:208-226).  Broadcast groups are folded into the
         first layer's bias, per-row groups are concatenated and meet the matching columns of the first weight."""
         first = self.network[0]
-        row_cols, bc_cols, rows, bcs, c = [], [], [], [], 0
-        for t in parts:
-            w = t.shape[-1]
-            if t.dim() == 1:
-                bc_cols += list(range(c, c + w)); bcs.append(t)
-            else:
-                row_cols += list(range(c, c + w)); rows.append(t)
-            c += w
-        if c != first.weight.shape[1]:
-            raise ValueError(f"field input has {c} columns, the first layer expects {first.weight.shape[1]}")
-        dev = first.weight.device
-        w_row = first.weight.index_select(1, torch.tensor(row_cols, device=dev))
+        rows = [t for t in parts if t.dim() != 1]
+        bcs = [t for t in parts if t.dim() == 1]
+        sig = tuple((t.dim() == 1, t.shape[-1]) for t in parts)
+        idx = self._col_index.get((sig, first.weight.device))
+        if idx is None:                  # column indices of the two kinds, built once per layout (no H2D copy per call)
+            row_cols, bc_cols, c = [], [], 0
+            for is_bc, w in sig:
+                (bc_cols if is_bc else row_cols).extend(range(c, c + w))
+                c += w
+            if c != first.weight.shape[1]:
+                raise ValueError(f"field input has {c} columns, the first layer expects {first.weight.shape[1]}")
+            dev = first.weight.device
+            idx = (torch.tensor(row_cols, device=dev), torch.tensor(bc_cols, device=dev) if bc_cols else None)
+            self._col_index[(sig, dev)] = idx
+        w_row = first.weight.index_select(1, idx[0])
         bias0 = first.bias
         if bcs:
-            bias0 = F.linear(torch.cat(bcs).reshape(1, -1), first.weight.index_select(1, torch.tensor(bc_cols, device=dev)),
-                             first.bias)[0]
+            bias0 = F.linear(torch.cat(bcs).reshape(1, -1), first.weight.index_select(1, idx[1]), first.bias)[0]
         return self._trunk(torch.cat(rows, dim=1) if len(rows) > 1 else rows[0], w_row, bias0)
 
     def _trunk(self, x, w_first, b_first):

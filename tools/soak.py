@@ -37,6 +37,12 @@ for it in range(steps):
         bad = [n for n, q in zip(names, params) if q.grad is not None and not torch.isfinite(q.grad).all()]
         if bad or not torch.isfinite(loss):
             print("first non-finite at step", it, "loss", float(loss), "grads", bad[:12], flush=True)
+            with torch.no_grad():
+                d_bary, d_rot, d_scale = frame.canon_field(frame.params["rotation"], frame.params["scaling"], frame.barys0, frame.pose)
+                raw = frame.params["scaling"] + d_scale
+                q = frame.params["rotation"] + d_rot
+                print("    raw log-scale max", float(raw.max()), "min", float(raw.min()), "| quaternion norm min", float(q.norm(dim=1).min()),
+                      "| d_scale absmax", float(d_scale.abs().max()), "d_rot absmax", float(d_rot.abs().max()), flush=True)
             for n, q in zip(names, params):
                 print("   ", n, "param finite", bool(torch.isfinite(q).all()), "absmax", float(q.detach().abs().max()), flush=True)
             sys.exit(1)
