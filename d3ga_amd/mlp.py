@@ -45,7 +45,9 @@ def _panel(weight, transpose):
             raise ValueError(f"linear_act: layer {n_layer}x{k_layer} is outside the kernel's range (K, N <= 128)")
         p = torch.empty(nbytes // 4, dtype=torch.int32, device=w.device)
         check(_lib.lib().d3ga_mlp_pack_weights(K, N, dptr(w), ld_k, ld_n, dptr(p), stream_handle()), "d3ga_mlp_pack_weights")
-        hit = (p, weight, w)                                  # holds the weight alive: its address cannot be recycled
+        # holds the weight's STORAGE alive (its address cannot be recycled) through detached aliases: a cached view that
+        # still carried the grad_fn of an earlier forward made PyTorch-ROCm 2.10 crash in capture_end() of a later capture
+        hit = (p, weight.detach(), w)
         _panels[key] = hit
     return hit[0]
 

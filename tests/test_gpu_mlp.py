@@ -212,6 +212,49 @@ def test_chain_fuzz(seed):
             assert rel_err(b.grad.cpu().numpy(), br.grad.numpy()) < wtol, tag
 
 
+def test_field_networks_survive_stream_capture():
+    """CanonicalField + ColorField forward + backward captured in a hipGraph replay to the eager gradients.  (Regression:
+    the split-weight cache used to pin the `first.weight[:, n_pose:]` VIEW itself, a tensor that carries the grad_fn of an
+    earlier forward; PyTorch-ROCm 2.10 crashes in capture_end() when such a tensor is alive during a captured backward.)"""
+    from d3ga_amd.mlp import CanonicalField, ColorField
+    torch.manual_seed(3)
+    P = 700
+    cf, col = CanonicalField().to(DEV), ColorField().to(DEV)
+    g = torch.Generator().manual_seed(4)
+    mk = lambda *shape: torch.randn(*shape, generator=g).to(DEV)
+    barys, rots, scales, pose = mk(P, 4).requires_grad_(True), mk(P, 4).requires_grad_(True), mk(P, 3).requires_grad_(True), mk(98)
+    feat, frame = mk(P, 64).requires_grad_(True), mk(32).requires_grad_(True)
+    vd = torch.nn.functional.normalize(mk(P, 3), dim=-1)
+    leaves = [barys, rots, scales, feat, frame] + list(cf.parameters()) + list(col.parameters())
+
+    def step():
+        for t in leaves:
+            t.grad = None
+        a, b, c = cf(rots, scales, barys, pose)
+        rgb, op = col(feat, pose, vd, frame_encoding=frame)
+        (a.sum() + (b * b).sum() + c.sum() + (rgb * rgb).sum() + op.sum()).backward()
+
+    step(); step()
+    torch.cuda.synchronize()
+    ref = [t.grad.clone() for t in leaves]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for t in leaves:
+        t.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    for t, r in zip(leaves, ref):
+        assert rel_err(t.grad.cpu().numpy(), r.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("spread", [0.0, 4.0])
 def test_split_bf16_products_have_f32_accuracy(spread):
     """The dense layer splits every f32 operand exactly into three bf16 pieces and keeps six of the nine cross products
