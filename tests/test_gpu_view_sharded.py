@@ -200,3 +200,28 @@ def test_two_ranks_one_gpu_gloo_full_chain():
         assert err < 1e-5, res
         assert same, res
         assert nbytes > 0
+
+
+def test_exchange_over_rccl_one_rank_group():
+    """The collectives of ViewShardedGrads.exchange on the REAL backend of the scaling runs (nccl = RCCL) -- a one-rank
+    group is all a single-GPU box offers, but it proves that the library loads, that both collectives accept these
+    tensors (flat all-reduce, all_gather_into_tensor of the (P+1,3) factor) and that values pass through unchanged."""
+    import subprocess
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        f"os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='{_free_port()}', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "from d3ga_amd.dist import ViewShardedGrads\n"
+        "s = ViewShardedGrads()\n"
+        "flat = torch.arange(1_000_000, dtype=torch.float32, device='cuda')\n"
+        "factor = torch.randn(50_001, 3, device='cuda')\n"
+        "ref = flat.clone()\n"
+        "g = s.exchange(flat, factor)\n"
+        "torch.cuda.synchronize()\n"
+        "assert s.world == 1 and tuple(g.shape) == (1, 50_001, 3) and torch.equal(g[0], factor) and torch.equal(flat, ref)\n"
+        "dist.destroy_process_group()\n"
+        "print('RCCL-OK')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL-OK" in out.stdout, out.stderr[-2000:]
