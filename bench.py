@@ -563,7 +563,7 @@ def main():
         # HBM traffic of the compositing kernels from the committed rocprofv3 --pmc passes of this same command
         # (tools/gpu_pmc.sh -> profiles/*.json): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH doubled per the gfx950
         # correction of MI355X_MICROARCH.md.  None when no PMC summary for this workload is present.
-        pmc_traffic, pmc_lds, pmc_valu = {}, {}, {}
+        pmc_traffic, pmc_lds, pmc_valu, pmc_busy = {}, {}, {}, {}
         try:
             pj = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
             if os.path.exists(pj):
@@ -575,6 +575,11 @@ def main():
                             pmc_lds[short] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
                         if c.get("SQ_INSTS_VALU"):
                             pmc_valu[short] = int(c["SQ_INSTS_VALU"])
+                        if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_BUSY_CYCLES"):
+                            # share of ALL SIMD cycles of the launch in which a VALU instruction was executing:
+                            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip, SQ_BUSY_CYCLES the launch's
+                            # cycles summed over the 32 shader engines; 256 CUs x 4 SIMDs
+                            pmc_busy[short] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * c["SQ_BUSY_CYCLES"] / 32.0), 4)
         except Exception:
             pmc_traffic = {}
         roof = None
@@ -584,6 +589,7 @@ def main():
             roof = {"kernel": k, "bound": "hbm", "achieved": kernels[k]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": kernels[k]["frac_hbm_peak"], "traffic": pmc_traffic.get(k),
                     "lds_bank_conflict_per_lds_active": pmc_lds.get(k), "valu_wave_instructions": pmc_valu.get(k),
+                    "valu_busy_frac_of_all_simd_cycles": pmc_busy.get(k),
                     "alg_bytes_per_launch": alg[k], "avg_ms": kernels[k]["ms"]}
         out = {
             "metric": "fwd+bwd frames/sec @500k Gaussians 1920x1080" if args.workload == "C3" else f"fwd+bwd frames/sec ({wl.name})",
