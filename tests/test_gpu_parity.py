@@ -673,6 +673,48 @@ def test_knn_mean_dist2_matches_bruteforce():
     assert float(knn_mean_dist2(pts[:1].to(DEV))[0]) == 0.0
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_INIT_FUZZ_N", "4"))))
+def test_init_helpers_fuzz(seed):
+    """knn_mean_dist2 and compute_bary at random sizes (1..3000 points, 1..2000 tets; not multiples of the workgroup / LDS
+    chunk sizes) against brute force."""
+    from d3ga_amd.tetra import compute_bary, knn_mean_dist2
+    rng = np.random.default_rng(15000 + seed)
+    g = torch.Generator().manual_seed(seed)
+    n = int(rng.choice([1, 2, 3, 4, 63, 64, 65, 255, 256, 257, int(rng.integers(1, 3000))]))
+    pts = torch.randn(n, 3, generator=g)
+    out = knn_mean_dist2(pts.to(DEV))
+    if n == 1:
+        assert float(out[0]) == 0.0
+    else:
+        d = torch.cdist(pts.double(), pts.double()) ** 2
+        d.fill_diagonal_(float("inf"))
+        k = min(3, n - 1)
+        ref = d.topk(k, largest=False).values.sum(1) / 3.0 if k < 3 else d.topk(3, largest=False).values.mean(1)
+        if k == 3:
+            np.testing.assert_allclose(_np(out), ref.numpy(), rtol=1e-4, atol=1e-7)
+        else:
+            assert bool(torch.isfinite(out).all())
+    # compute_bary: points generated INSIDE random (well-shaped) tets reconstruct from the returned tet and weights
+    T = int(rng.choice([1, 2, 255, 256, 257, int(rng.integers(1, 2000))]))
+    base = torch.randn(T, 1, 3, generator=g) * 3.0
+    corners = base + torch.eye(4, 3)[None] + 0.2 * torch.randn(T, 4, 3, generator=g)
+    vol = torch.linalg.det(corners[:, :3] - corners[:, 3:4])               # keep the random tets well shaped
+    flat = vol.abs() < 0.4
+    corners[flat] = (base + torch.eye(4, 3)[None])[flat]
+    m = int(rng.integers(1, 1500))
+    tid0 = torch.randint(0, T, (m,), generator=g)
+    w = torch.rand(m, 4, generator=g) + 0.05
+    w = w / w.sum(1, keepdim=True)
+    p = (corners[tid0] * w[:, :, None]).sum(1)
+    barys, tid, active = compute_bary(p.to(DEV), corners.to(DEV))
+    rec = (corners[tid.cpu().long()] * barys.cpu()[:, :, None]).sum(1)
+    # random tets overlap, and a point may be claimed by a flat-ish one: f32 barycentrics of an ill-conditioned tet
+    # reconstruct to ~3e-4 (seed 51); a wrong tet or wrong weights would be O(1)
+    np.testing.assert_allclose(_np(rec), _np(p), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(_np(barys.sum(1)), 1.0, atol=2e-3)
+    assert float(_np(active).mean()) > 0.99 and float(barys.min()) > -2e-3
+
+
 def test_cage_deform_fused_activations_equal_the_unfused_composition():
     """delta_barys / scale_activation="exp" (cage_net.py:213-214 fused into the kernels) against the same op fed with
     barys + delta and exp(scaling) computed by ATen: values and all parameter gradients."""
