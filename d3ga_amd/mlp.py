@@ -14,6 +14,8 @@ with ``z = [pose.expand(P, -1) | per-row features]`` (models/mlp.py:58-69, 94-10
 Modules keep the reference's parameter names (``network.{i}.weight/bias``, ``output.weight/bias``): state dicts
 interchange.  GPU tensors only.
 """
+import ctypes
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -150,7 +152,6 @@ class _Heads(torch.autograd.Function):
         pred = pred.float().contiguous()
         P, N = pred.shape
         n = len(spec)
-        import ctypes
         ctx.c_spec = ((ctypes.c_int32 * n)(*[w for w, _, _ in spec]), (ctypes.c_int32 * n)(*[_ACT[a] for _, a, _ in spec]),
                       (ctypes.c_float * n)(*[float(v) for _, _, v in spec]))
         out = torch.empty(P * N, dtype=torch.float32, device=pred.device)
