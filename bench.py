@@ -443,6 +443,11 @@ def main():
             frame.step()
         reduce_params()
 
+    # Python's cyclic GC: the first full collection of the (large) post-import heap costs ~40 ms and lands wherever it likes --
+    # seen as one 3 ms/step outlier in an eager loop of 1.4 ms steps.  Collect now and freeze the survivors.
+    import gc
+    gc.collect()
+    gc.freeze()
     for _ in range(3):
         timed_step()
     # Per-step distribution (HIP events around the op sequence, median / p10 / p90), outside (just before) the

@@ -15,8 +15,14 @@ for rep in range(8):
     for _ in range(25):
         zero(); frame.train_step(pair=True)
     torch.cuda.synchronize(); print("pair ms/step", round((time.perf_counter() - t0) / 25 * 1e3, 3), flush=True)
-for rep in range(3):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(25):
-        zero(); frame.train_step()
-    torch.cuda.synchronize(); print("two-call ms/step", round((time.perf_counter() - t0) / 25 * 1e3, 3), flush=True)
+import gc
+for label in ("gc on", "gc off"):
+    if label == "gc off":
+        gc.collect(); gc.disable()
+    ts = []
+    for rep in range(12):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(25):
+            zero(); frame.train_step()
+        torch.cuda.synchronize(); ts.append(round((time.perf_counter() - t0) / 25 * 1e3, 3))
+    print("two-call ms/step,", label, ts, flush=True)
