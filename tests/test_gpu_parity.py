@@ -933,12 +933,13 @@ def test_fuzz_ragged_sizes_and_argument_paths(seed):
     scale modifier, random background, few or many Gaussians per tile.  Integer results (radii, tile lists) bit-exact."""
     from d3ga_amd import rasterizer as R
     rng = np.random.default_rng(1000 + seed)
-    W, H = int(rng.integers(1, 150)), int(rng.integers(1, 150))
+    big = os.environ.get("D3GA_FUZZ_SCENE") == "C1"                  # campaign variant: 10k Gaussians, images up to 500 px
+    W, H = int(rng.integers(1, 500 if big else 150)), int(rng.integers(1, 500 if big else 150))
     if seed == 0:
         W, H = 1, 1
     if seed == 1:
         W, H = 257, 3
-    inp = scene_inputs(["T0", "T1"][seed % 2], seed=int(rng.integers(1, 10_000)), azimuth=float(rng.uniform(0, 6.28)),
+    inp = scene_inputs("C1" if big else ["T0", "T1"][seed % 2], seed=int(rng.integers(1, 10_000)), azimuth=float(rng.uniform(0, 6.28)),
                        scale_mult=float(rng.uniform(0.5, 8.0)), width=W, height=H,
                        cx=float(rng.uniform(0.3, 0.7)) * W if seed % 3 == 0 else None,
                        cy=float(rng.uniform(0.3, 0.7)) * H if seed % 3 == 0 else None)
