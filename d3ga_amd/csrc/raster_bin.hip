@@ -7,7 +7,8 @@
 // (8 B read + 4 B written per duplicate).  The 64-bit key (depth bits << 32 | index) makes the order total, so
 // the result does not depend on the order in which the atomics of the scatter pass landed.
 //
-//   tile_scan_kernel      one workgroup: exclusive prefix of the tile histogram, D, overflow flag
+//   tile_scan_order_kernel  two workgroups: [0] exclusive prefix of the tile histogram, D, overflow flag;
+//                         [1] tile indices by descending list length (work-ordered dispatch)
 //   tile_scatter_kernel   one thread per Gaussian: emit its key into every tile of its rectangle; slots are reserved
 //                         per (block, tile) through an LDS window (d3ga_internal.h: TileWindow)
 //   tile_sort_lds_kernel       one workgroup per tile: LDS bitonic sort, 8 keys per thread (lists up to 2048 entries)
@@ -19,14 +20,12 @@ namespace d3ga {
 
 constexpr int kScanBlock = 1024;
 
-__global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(int tiles, const uint32_t *__restrict__ count,
-                                                               uint32_t *__restrict__ start,
-                                                               uint32_t *__restrict__ cursor,
-                                                               uint32_t *__restrict__ counters, uint64_t dcap,
-                                                               uint32_t *__restrict__ big_tiles,
-                                                               uint32_t *__restrict__ huge_tiles,
-                                                               uint32_t *__restrict__ mid_tiles, uint32_t n_small,
-                                                               uint32_t n_mid, uint32_t n_large) {
+__device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__restrict__ count,
+                                               uint32_t *__restrict__ start, uint32_t *__restrict__ cursor,
+                                               uint32_t *__restrict__ counters, uint64_t dcap,
+                                               uint32_t *__restrict__ big_tiles, uint32_t *__restrict__ huge_tiles,
+                                               uint32_t *__restrict__ mid_tiles, uint32_t n_small, uint32_t n_mid,
+                                               uint32_t n_large) {
     // The histogram is staged through LDS in chunks of 8 tiles per thread: lane-contiguous global loads/stores with all of
     // a thread's requests in flight at once (a thread-strided read of 8 values is 8 dependent L2 round trips), then each
     // thread scans its 8 consecutive values from LDS (two 16-byte reads) and a wavefront scan + 16 LDS totals finish it.
@@ -122,18 +121,28 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_kernel(int tiles, const 
 // scaled to the longest list; order inside a bucket is arbitrary).  All active compositing wavefronts are resident at once
 // and the dispatcher deals workgroups round-robin, so dealing them in descending order of work gives every SIMD one
 // wavefront from each work quantile instead of a random handful.
-__global__ __launch_bounds__(kScanBlock) void tile_order_kernel(int tiles, const uint32_t *__restrict__ count,
-                                                                const uint32_t *__restrict__ counters,
-                                                                uint32_t *__restrict__ order) {
+__device__ __forceinline__ void tile_order_body(int tiles, const uint32_t *__restrict__ count,
+                                                uint32_t *__restrict__ order) {
     __shared__ uint32_t s_hist[256];                      // buckets 0..254: non-empty tiles, longest lists first
     __shared__ uint32_t s_zero;                           // empty tiles (most of the image for an avatar): wavefront-
-    const int tid = threadIdx.x, lane = tid & 63;         // aggregated, thousands of same-address LDS atomics serialise
+    __shared__ uint32_t s_omax;                           // aggregated, thousands of same-address LDS atomics serialise
+    const int tid = threadIdx.x, lane = tid & 63;
     if (tid < 256) s_hist[tid] = 0;
-    if (tid == 0) s_zero = 0;
-    const uint32_t mx = counters[D3GA_CNT_MAXTILE];
-    const int shift = mx >= 255u ? (32 - __clz((int)mx) - 8 + 1) : 0;      // (count >> shift) < 255
+    if (tid == 0) { s_zero = 0; s_omax = 0; }
     __syncthreads();
     const int rounds = (tiles + kScanBlock - 1) / kScanBlock;
+    // the longest list: this workgroup runs BESIDE the scan workgroup (same launch), so it takes its own maximum
+    uint32_t mx = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const int t = r * kScanBlock + tid;
+        mx = max(mx, t < tiles ? count[t] : 0u);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+    if (lane == 0) atomicMax(&s_omax, mx);
+    __syncthreads();
+    mx = s_omax;
+    const int shift = mx >= 255u ? (32 - __clz((int)mx) - 8 + 1) : 0;      // (count >> shift) < 255
     for (int r = 0; r < rounds; ++r) {
         const int t = r * kScanBlock + tid;
         const uint32_t c = t < tiles ? count[t] : 0u;
@@ -171,6 +180,20 @@ __global__ __launch_bounds__(kScanBlock) void tile_order_kernel(int tiles, const
         if (zero) order[zbase + (uint32_t)__popcll(zm & ((1ull << lane) - 1ull))] = (uint32_t)t;
         if (t < tiles && c) order[atomicAdd(&s_hist[254u - min(c >> shift, 254u)], 1u)] = (uint32_t)t;
     }
+}
+
+// one launch, two workgroups: block 0 scans the histogram, block 1 orders the tiles (they only share the read-only counts)
+__global__ __launch_bounds__(kScanBlock) void tile_scan_order_kernel(int tiles, const uint32_t *__restrict__ count,
+                                                                     uint32_t *__restrict__ start,
+                                                                     uint32_t *__restrict__ cursor,
+                                                                     uint32_t *__restrict__ counters, uint64_t dcap,
+                                                                     uint32_t *__restrict__ big_tiles,
+                                                                     uint32_t *__restrict__ huge_tiles,
+                                                                     uint32_t *__restrict__ mid_tiles, uint32_t n_small,
+                                                                     uint32_t n_mid, uint32_t n_large,
+                                                                     uint32_t *__restrict__ order) {
+    if (blockIdx.x == 0) tile_scan_body(tiles, count, start, cursor, counters, dcap, big_tiles, huge_tiles, mid_tiles, n_small, n_mid, n_large);
+    else tile_order_body(tiles, count, order);
 }
 
 __global__ __launch_bounds__(kBlock) void tile_scatter_kernel(int P, int gx, const uint2 *__restrict__ rect,
@@ -357,7 +380,7 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_lds_kernel(const uint32_t *__
     sort_one_tile_lds<BLOCK, CAP, true>(s_key, tile, start, keys, point_list, dcap);
 }
 
-// persistent grid over a work list written by tile_scan_kernel (tiles whose list does not fit the kernel above);
+// persistent grid over a work list written by the scan workgroup of tile_scan_order_kernel (tiles whose list does not fit the kernel above);
 // dynamic LDS: CAP + CAP/8 keys in the padded register-phase layout (36 KB for 4096, 72 KB for 8192)
 template <int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_t *__restrict__ start,
@@ -409,12 +432,9 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
     const int tiles = gx * tiles_y(prm->H);
     BinBuf bin = carve_bin(binning, tiles, d_capacity);
     GeomBuf g = carve_geom(geom, prm->P);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(kScanBlock), 0, s, tiles, bin.tile_count, bin.tile_start,
+    hipLaunchKernelGGL(tile_scan_order_kernel, dim3(2), dim3(kScanBlock), 0, s, tiles, bin.tile_count, bin.tile_start,
                        bin.tile_cursor, bin.counters, (uint64_t)d_capacity, bin.big_tiles, bin.huge_tiles, bin.mid_tiles,
-                       (uint32_t)kSortSmall, (uint32_t)kSortMid, (uint32_t)kSortLarge);
-    D3GA_TRY(check_launch(s, prm->debug));
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kScanBlock), 0, s, tiles, bin.tile_count, bin.counters,
-                       bin.tile_order);
+                       (uint32_t)kSortSmall, (uint32_t)kSortMid, (uint32_t)kSortLarge, bin.tile_order);
     D3GA_TRY(check_launch(s, prm->debug));
     if (prm->P == 0 || d_capacity == 0) return D3GA_OK;
     hipLaunchKernelGGL(tile_scatter_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, prm->P, gx, g.rect,
