@@ -3,8 +3,10 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "libd3ga_hip.so")
+# D3GA_LIB_PATH: a diagnostic build (D3GA_DIAG=... python d3ga_amd/csrc/build.py -> libd3ga_hip_diag.so); never set in production
+_PATH = os.environ.get("D3GA_LIB_PATH") or os.path.join(_HERE, "libd3ga_hip.so")
 _lib = None
+ACC_STRIDE = 16          # D3GA_ACC_STRIDE (include/d3ga.h): floats per Gaussian in the screen-space gradient accumulator
 
 
 class D3GAError(RuntimeError):
@@ -121,6 +123,17 @@ def dptr(t):
 
 
 def require_cuda(*tensors):
+    """Every launch of this library goes to the CURRENT device's current stream (stream_handle): a tensor that lives on
+    another GPU would be touched from the wrong device / an unordered stream, so that is refused here."""
+    import torch
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise D3GAError("d3ga_amd ops run on the GPU only (tensor on %s); there is no CPU fallback" % t.device)
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise D3GAError(f"tensor on {t.device} but the current device is cuda:{cur}: wrap the call in "
+                            f"`with torch.cuda.device({t.device.index}):` (launches go to the current device's stream)")

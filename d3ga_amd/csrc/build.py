@@ -4,11 +4,18 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["deform.hip", "raster_pre.hip", "raster_bin.hip", "raster_composite.hip", "raster_api.hip", "bary.hip", "loss.hip", "mlp.hip", "encoding.hip"]
-HEADERS = ["d3ga_math.h", "d3ga_internal.h", "raster_pre_body.h", os.path.join("..", "..", "include", "d3ga.h")]
-OUT = os.path.join(HERE, "..", "libd3ga_hip.so")
+SOURCES = ["deform.hip", "raster_pre.hip", "raster_bin.hip", "raster_composite.hip", "raster_composite_scan.hip", "raster_api.hip", "bary.hip", "loss.hip", "mlp.hip", "encoding.hip"]
+HEADERS = ["d3ga_math.h", "d3ga_internal.h", "raster_pre_body.h", "composite_common.h", os.path.join("..", "..", "include", "d3ga.h")]
+ABL = os.environ.get("D3GA_SCAN_ABL")       # timing ablation of the compositing backward (wrong results): own objects + .so
+DIAG = os.environ.get("D3GA_DIAG") or (("abl" + ABL) if ABL else None)          # diagnostic build: its own objects and its own .so (D3GA_LIB_PATH selects it)
+OUT = os.path.join(HERE, "..", (f"libd3ga_hip_abl{ABL}.so" if ABL else "libd3ga_hip_diag.so") if DIAG else "libd3ga_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
+# per-source extras.  The entry-per-lane compositing backward is VALU-issue bound; SLP-packing its scalar f32 chains into
+# v_pk_* costs ~35 register shuffles per 4 pixels (ISA inspected), so the vectoriser is off for that file.
+EXTRA = {"raster_composite_scan.hip": ["-fno-slp-vectorize"]}
+if ABL:
+    FLAGS.append("-DD3GA_SCAN_ABL=" + ABL)
 if os.environ.get("D3GA_DIAG"):            # diagnostic build (loop statistics, tools/diag_bwd.py); never the shipped one
     FLAGS.append("-DD3GA_DIAG")
     if os.environ.get("D3GA_DIAG") == "counters":
@@ -24,7 +31,7 @@ def _newer(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, (f"build_abl{ABL}" if ABL else "build_diag") if DIAG else "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     objs = []
@@ -32,7 +39,7 @@ def build(force=False, verbose=False):
         s = os.path.join(HERE, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _newer(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -75,12 +75,23 @@ static inline BinBuf carve_bin(void *base, int64_t tiles, int64_t dcap) {
 struct ImgBuf {
     float *final_T;        // H*W
     uint32_t *n_contrib;   // H*W   1-based tile-list position of the last contributing Gaussian
+    // Per-4x4-block culled lists, written by the compositing forward for its backward (raster_composite_scan.hip):
+    // a 16x16 tile has 16 blocks (quadrant q = 0..3, row r = 0..3 of that quadrant's wavefront -> block 4q + r); the
+    // list of block b of a tile whose depth-sorted list is [begin, end) occupies blk_list[16*begin + b*(end-begin) ...],
+    // blk_count[16*tile + b] entries {1-based position in the tile list, Gaussian index}, front to back.
+    uint32_t *blk_count;   // 16 * tiles
+    uint2 *blk_list;       // 16 * d_capacity
 };
-static inline int64_t img_bytes(int64_t W, int64_t H) { return 2 * align256(4 * W * H); }
-static inline ImgBuf carve_img(void *base, int64_t W, int64_t H) {
+static inline int64_t img_bytes(int64_t W, int64_t H, int64_t tiles, int64_t dcap) {
+    return 2 * align256(4 * W * H) + align256(64 * tiles) + align256(128 * dcap);
+}
+static inline ImgBuf carve_img(void *base, int64_t W, int64_t H, int64_t tiles) {
     ImgBuf i;
-    i.final_T = (float *)base;
-    i.n_contrib = (uint32_t *)((char *)base + align256(4 * W * H));
+    char *p = (char *)base;
+    i.final_T = (float *)p;        p += align256(4 * W * H);
+    i.n_contrib = (uint32_t *)p;   p += align256(4 * W * H);
+    i.blk_count = (uint32_t *)p;   p += align256(64 * tiles);
+    i.blk_list = (uint2 *)p;
     return i;
 }
 

@@ -23,7 +23,7 @@ extern "C" int d3ga_raster_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_
     if (P < 0 || W <= 0 || H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
     sizes[0] = geom_bytes(P > 0 ? P : 1);
     sizes[1] = bin_bytes((int64_t)tiles_x(W) * tiles_y(H), d_capacity > 0 ? d_capacity : 1);
-    sizes[2] = img_bytes(W, H);
+    sizes[2] = img_bytes(W, H, (int64_t)tiles_x(W) * tiles_y(H), d_capacity > 0 ? d_capacity : 1);
     return D3GA_OK;
 }
 
@@ -69,7 +69,7 @@ extern "C" int d3ga_raster_backward(const d3ga_raster_params *prm, const float *
                                     float *dL_dmeans2D, float *dL_dopacity, float *dL_dsh, float *dL_dcolors,
                                     float *dL_dcov3D, float *dL_dscales, float *dL_drots, d3ga_stream_t stream) {
     if (prm && prm->P > 0 && acc)
-        D3GA_HIP(zero_async(acc, sizeof(float) * 12 * (size_t)prm->P, (hipStream_t)stream));
+        D3GA_HIP(zero_async(acc, sizeof(float) * D3GA_ACC_STRIDE * (size_t)prm->P, (hipStream_t)stream));
     D3GA_TRY(d3ga_raster_composite_bwd(prm, bg, geom, binning, d_capacity, img, dL_dpix, acc, stream));
     return d3ga_raster_preprocess_bwd(prm, means3D, shs, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                                       campos, geom, acc, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors,

@@ -24,173 +24,9 @@
 // across XCDs for balance.
 #include <stdlib.h>
 
-#include "d3ga_internal.h"
+#include "composite_common.h"
 
 namespace d3ga {
-
-// D3GA_COMPOSITE_VARIANT (A/B knob, tools/gpu_ab.sh): bit 0 fwd LDS slab, bit 1 bwd LDS slab (64-lane kernels); bit 2 fwd
-// row-segmented, bit 3 bwd row-segmented (composite_bwd_rows3_kernel; bit 4 is unused since the second generation was
-// removed), bit 5 work-ordered dispatch of the row-segmented kernels (tile_order).
-constexpr int kDefaultCompositeVariant = 63;  // measured at C3: fwd 248 -> 133 us, bwd 508 -> 376 (rows) -> 337 us (rows3)
-
-// ---- wavefront (64 lanes) reductions through DPP ----
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
-    return v + __int_as_float(t);
-}
-// single value; total broadcast to all lanes
-__device__ __forceinline__ float wave_sum(float v) {
-    v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
-    v = dpp_add<0x140, 0xf>(v);   // row_mirror        -> every lane holds its 16-lane row sum
-    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
-    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> row 3 holds the total
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-// NV values at once: the chains are independent, so the scheduler interleaves them and the DPP wait states of one
-// chain are filled by the others.  Totals end up in every lane of row 3 (lanes 48..63).
-template <int NV>
-__device__ __forceinline__ void wave_sum_multi(float (&v)[NV]) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = dpp_add<0xB1, 0xf>(v[k]);
-#pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = dpp_add<0x4E, 0xf>(v[k]);
-#pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = dpp_add<0x141, 0xf>(v[k]);
-#pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = dpp_add<0x140, 0xf>(v[k]);
-#pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = dpp_add<0x142, 0xa>(v[k]);
-#pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = dpp_add<0x143, 0xc>(v[k]);
-}
-// ---- nine values at once: reduce-scatter with the gfx950 lane-swap instructions ----
-// v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of the second; adding the two results
-// leaves the half-wave sums of the first value in lanes 0..31 and of the second in lanes 32..63 (2 instructions retire
-// one of two values).  v_permlane16_swap does the same for odd/even 16-lane rows.  Two levels take 8 values down to 2
-// registers whose four rows each hold a different value; four row-local DPP adds finish them.
-//   q0 rows 0..3 = totals of v[0], v[2], v[1], v[3]     q1 rows 0..3 = totals of v[4], v[6], v[5], v[7]
-//   r8 row 3     = total of v[8] (plain six-step chain)
-// 30 VALU instructions instead of 72 for nine independent six-step chains.
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float swap32_add(float a, float b) {
-    const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-__device__ __forceinline__ float swap16_add(float a, float b) {
-    const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-__device__ __forceinline__ float row_sum16(float v) {       // every lane <- sum over its 16-lane row
-    v = dpp_add<0xB1, 0xf>(v); v = dpp_add<0x4E, 0xf>(v); v = dpp_add<0x141, 0xf>(v); v = dpp_add<0x140, 0xf>(v);
-    return v;
-}
-struct Reduced9 { float q0, q1, r8; };
-__device__ __forceinline__ Reduced9 wave_reduce9(const float (&v)[9]) {
-    Reduced9 r;
-    const float p0 = swap32_add(v[0], v[1]), p1 = swap32_add(v[2], v[3]);
-    const float p2 = swap32_add(v[4], v[5]), p3 = swap32_add(v[6], v[7]);
-    r.q0 = row_sum16(swap16_add(p0, p1));
-    r.q1 = row_sum16(swap16_add(p2, p3));
-    float t = row_sum16(v[8]);
-    t = dpp_add<0x142, 0xa>(t);
-    r.r8 = dpp_add<0x143, 0xc>(t);
-    return r;
-}
-// which of the nine totals does this lane publish?  (-1: none).  Lanes 0,16,32,48 -> q0; 1,17,33,49 -> q1; 50 -> r8.
-__device__ __forceinline__ int reduce9_value_of_lane(int lane) {
-    const int row = lane >> 4, c = lane & 15;
-    const int perm = (row == 1) ? 2 : (row == 2) ? 1 : row;           // rows hold values 0,2,1,3
-    if (c == 0) return perm;
-    if (c == 1) return 4 + perm;
-    if (lane == 50) return 8;
-    return -1;
-}
-__device__ __forceinline__ float reduce9_pick(const Reduced9 &r, int lane) {
-    const int c = lane & 15;
-    return c == 0 ? r.q0 : (c == 1 ? r.q1 : r.r8);
-}
-
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
-    return v;
-}
-__device__ __forceinline__ float bcast(float v, int lane) {   // lane is wave-uniform
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-// ---- work item -> (tile, quadrant) with tile rows interleaved over the 8 XCDs ----
-struct Quad {
-    bool valid;
-    int tile, px, py;            // tile index, this lane's pixel
-    int qx0, qy0;                // quadrant origin in pixels
-};
-__device__ __forceinline__ Quad quad_of_block(int gx, int gy) {
-    Quad q;
-    int b = blockIdx.x;
-#ifdef D3GA_DIAG
-    {   // diagnostic build: a grid launched k times too large runs every quadrant k times (throughput vs balance test)
-        const int n = 8 * ((gy + 7) / 8) * gx * 4;
-        b = b % n;
-    }
-#endif
-    const int xcd = b & 7, slot = b >> 3;
-    const int per_row = gx * 4;
-    const int k = slot / per_row, rem = slot - k * per_row;
-    const int ty = xcd + 8 * k, tx = rem >> 2, quad = rem & 3;
-    q.valid = ty < gy;
-    q.tile = ty * gx + tx;
-    q.qx0 = tx * kTile + ((quad & 1) << 3);
-    q.qy0 = ty * kTile + ((quad >> 1) << 3);
-    const int lane = threadIdx.x & 63;
-    q.px = q.qx0 + (lane & 7);
-    q.py = q.qy0 + (lane >> 3);
-    return q;
-}
-static inline int quad_grid(int gx, int gy) { return 8 * ((gy + 7) / 8) * gx * 4; }
-// Work-ordered mapping: tile rank k (tile_order: descending list length) -> blocks b, b+8, b+16, b+24 of one XCD (the four
-// quadrants of a tile keep sharing an L2), ranks dealt round-robin over the XCDs.
-__device__ __forceinline__ Quad quad_of_block_ordered(int gx, int tiles, const uint32_t *__restrict__ order) {
-    Quad q;
-    const int b = blockIdx.x;
-    const int k = (b & 7) + 8 * (b >> 5), quad = (b >> 3) & 3;
-    q.valid = k < tiles;
-    q.tile = q.valid ? (int)order[k] : 0;
-    const int ty = q.tile / gx, tx = q.tile - ty * gx;
-    q.qx0 = tx * kTile + ((quad & 1) << 3);
-    q.qy0 = ty * kTile + ((quad >> 1) << 3);
-    const int lane = threadIdx.x & 63;
-    q.px = q.qx0 + (lane & 7);
-    q.py = q.qy0 + (lane >> 3);
-    return q;
-}
-static inline int quad_grid_ordered(int tiles) { return 32 * ((tiles + 7) / 8); }
-
-// Conservative test: can the Gaussian reach alpha >= 1/255 on any pixel of the quadrant [x0,x0+7]x[y0,y0+7]?
-// alpha = o*exp(-q/2) >= 1/255  <=>  q = A dx^2 + 2B dx dy + C dy^2 <= 2 ln(255 o) =: tau.  The ellipse q <= tau has the
-// axis-aligned half extents sqrt(tau*C/det), sqrt(tau*A/det); they are inflated by 0.1 % + 0.02 px against rounding.
-// Comparisons are written so that NaNs answer "relevant".
-__device__ __forceinline__ bool quad_relevant(float cx, float cy, float A, float B, float C, float o, float x0, float y0) {
-    if (o * 255.0f < 1.0f) return false;                  // o*G <= o < 1/255 for every G <= 1
-    // hardware rcp / sqrt / log (1 ulp-ish) are fine here: the extents are inflated below
-    const float tau = 2.0f * __logf(255.0f * o) * 1.001f + 1e-4f;
-    const float idet = __builtin_amdgcn_rcpf(A * C - B * B);
-    const float hx = __builtin_amdgcn_sqrtf(tau * C * idet) * 1.001f + 0.02f;
-    const float hy = __builtin_amdgcn_sqrtf(tau * A * idet) * 1.001f + 0.02f;
-    return !(cx + hx < x0) && !(cx - hx > x0 + 7.0f) && !(cy + hy < y0) && !(cy - hy > y0 + 7.0f);
-}
-
-// alpha of one splat on one pixel, branch-free: ok <=> the splat touches the pixel (power <= 0 and alpha >= 1/255)
-__device__ __forceinline__ void splat_eval(float dx, float dy, float ca, float cb, float cc, float o, float &alpha,
-                                           float &G, bool &ok) {
-    const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
-    G = __expf(power);
-    alpha = fminf(kAlphaMax, o * G);
-    ok = (power <= 0.0f) && (alpha >= kAlphaMin);
-}
 
 template <bool LDS>
 __global__ __launch_bounds__(64) void composite_fwd_kernel(
@@ -417,7 +253,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(
                 v[6] = dch * g0; v[7] = dch * g1; v[8] = dch * g2;
             }
             const Reduced9 red = wave_reduce9(v);
-            if (slot >= 0) atomicAdd(acc + 12 * (size_t)gid + slot_off, reduce9_pick(red, lane));   // one instruction, 9 lanes
+            if (slot >= 0) atomicAdd(acc + D3GA_ACC_STRIDE * (size_t)gid + slot_off, reduce9_pick(red, lane));   // one instruction, 9 lanes
         }
     }
 }
@@ -429,66 +265,6 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(
 // entry of list r.  A 4x4 block is touched by ~1.6x fewer list entries than an 8x8 quadrant (measured at C3: 160 vs
 // 251 iterations per quadrant), and the backward's cross-lane reduction shrinks to the four row-local DPP steps.
 // =========================================================================================================
-struct RowGeom {
-    int row, px, py;
-    float x0, y0;     // sub-block origin
-};
-__device__ __forceinline__ RowGeom row_geom(const Quad &q, int lane) {
-    RowGeom g;
-    g.row = lane >> 4;
-    const int l = lane & 15;
-    const int sx = q.qx0 + ((g.row & 1) << 2), sy = q.qy0 + ((g.row >> 1) << 2);
-    g.px = sx + (l & 3);
-    g.py = sy + (l >> 2);
-    g.x0 = (float)sx; g.y0 = (float)sy;
-    return g;
-}
-// half extents of the alpha >= 1/255 ellipse (inflated); negative hx marks "never visible"
-__device__ __forceinline__ void splat_extent(float A, float B, float C, float o, float &hx, float &hy) {
-    if (o * 255.0f < 1.0f) { hx = -1.0f; hy = -1.0f; return; }
-    const float tau = 2.0f * __logf(255.0f * o) * 1.001f + 1e-4f;
-    const float idet = __builtin_amdgcn_rcpf(A * C - B * B);
-    hx = __builtin_amdgcn_sqrtf(tau * C * idet) * 1.001f + 0.02f;
-    hy = __builtin_amdgcn_sqrtf(tau * A * idet) * 1.001f + 0.02f;
-}
-// the four 4x4 sub-blocks of the quadrant at (bx0, by0) share their x / y range tests: 8 compares instead of 16
-struct BlockHits { bool r0, r1, r2, r3; };
-__device__ __forceinline__ BlockHits block_hits4(float cx, float cy, float hx, float hy, float bx0, float by0) {
-    const bool vis = !(hx < 0.0f);
-    const float xl = cx - hx, xr = cx + hx, yt = cy - hy, yb = cy + hy;
-    const bool x0 = vis && !(xr < bx0) && !(xl > bx0 + 3.0f), x1 = vis && !(xr < bx0 + 4.0f) && !(xl > bx0 + 7.0f);
-    const bool y0 = !(yb < by0) && !(yt > by0 + 3.0f), y1 = !(yb < by0 + 4.0f) && !(yt > by0 + 7.0f);
-    BlockHits h;
-    h.r0 = x0 && y0; h.r1 = x1 && y0; h.r2 = x0 && y1; h.r3 = x1 && y1;
-    return h;
-}
-__device__ __forceinline__ bool block_hit(float cx, float cy, float hx, float hy, float x0, float y0, float ext) {
-    return !(hx < 0.0f) && !(cx + hx < x0) && !(cx - hx > x0 + ext) && !(cy + hy < y0) && !(cy - hy > y0 + ext);
-}
-__device__ __forceinline__ int lanes_below(unsigned long long m) {   // popcount of m restricted to lower lanes
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-}
-__device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {       // every lane <- max over its 16-lane row
-    uint32_t t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); v = max(v, t);
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true); v = max(v, t);
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true); v = max(v, t);
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true); v = max(v, t);
-    return v;
-}
-
-// builds the four per-row lists of one staged batch; returns the per-lane count of THIS lane's row and the trip count
-__device__ __forceinline__ int build_row_lists(uint8_t (*s_list)[64], bool r0, bool r1, bool r2, bool r3, int lane, int row,
-                                               int &trip) {
-    const unsigned long long m0 = __ballot(r0), m1 = __ballot(r1), m2 = __ballot(r2), m3 = __ballot(r3);
-    if (r0) s_list[0][lanes_below(m0)] = (uint8_t)lane;
-    if (r1) s_list[1][lanes_below(m1)] = (uint8_t)lane;
-    if (r2) s_list[2][lanes_below(m2)] = (uint8_t)lane;
-    if (r3) s_list[3][lanes_below(m3)] = (uint8_t)lane;
-    const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
-    trip = max(max(c0, c1), max(c2, c3));
-    return row == 0 ? c0 : (row == 1 ? c1 : (row == 2 ? c2 : c3));
-}
 
 // DUAL: a second set of per-Gaussian colours (colors2, (P,3), read by Gaussian id) is blended with the same alphas into
 // out_color2 over bg2 -- the reference's training step renders every package twice with identical geometry and opacities
@@ -501,7 +277,7 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
     const float4 *__restrict__ rgb_invd, const float *__restrict__ bg, float *__restrict__ final_T,
     uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_invdepth,
     const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2, const float *__restrict__ bg2,
-    float *__restrict__ out_color2) {
+    float *__restrict__ out_color2, uint2 *__restrict__ blk_list, uint32_t *__restrict__ blk_count, bool exact_cull) {
     const Quad q = tile_order ? quad_of_block_ordered(gx, gx * gy, tile_order) : quad_of_block(gx, gy);
     if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
     const int lane = threadIdx.x & 63;
@@ -511,6 +287,10 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
     const float bx0 = (float)q.qx0, by0 = (float)q.qy0;
     const uint32_t begin = (uint32_t)min((uint64_t)tile_start[q.tile], dcap);
     const uint32_t end = (uint32_t)min((uint64_t)tile_start[q.tile + 1], dcap);
+    // culled per-block lists for the backward (ImgBuf): block 4*quad + r of this tile, capacity end - begin each
+    const uint32_t blk_cap = end - begin;
+    uint2 *const blk_base = blk_list ? blk_list + 16 * (size_t)begin + (size_t)(4 * q.quad) * blk_cap : nullptr;
+    uint32_t bc0 = 0, bc1 = 0, bc2 = 0, bc3 = 0;           // entries emitted per row so far (wave-uniform)
 
     __shared__ float2 s_xy[64];
     __shared__ float4 s_co[64];
@@ -525,30 +305,56 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
 
     float2 nxy = make_float2(0.f, 0.f);
     float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f), nrgb2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t ng = 0;
     if (begin + lane < end) {
         const uint32_t g = point_list[begin + lane];
+        ng = g;
         nxy = xy[g]; nco = conic_o[g]; nrgb = rgb_invd[g];
         if constexpr (DUAL) nrgb2 = make_float4(colors2[3 * (size_t)g], colors2[3 * (size_t)g + 1], colors2[3 * (size_t)g + 2], 0.f);
     }
     for (uint32_t base = begin; base < end; base += 64) {
         const float2 cxy = nxy;
         const float4 cco = nco, crgb = nrgb, crgb2 = nrgb2;
+        const uint32_t cg = ng;
         const bool have = base + lane < end;
         const uint32_t nb = base + 64;
         if (nb + lane < end) {
             const uint32_t g = point_list[nb + lane];
+            ng = g;
             nxy = xy[g]; nco = conic_o[g]; nrgb = rgb_invd[g];
             if constexpr (DUAL) nrgb2 = make_float4(colors2[3 * (size_t)g], colors2[3 * (size_t)g + 1], colors2[3 * (size_t)g + 2], 0.f);
         }
-        float hx, hy;
-        splat_extent(cco.x, cco.y, cco.z, cco.w, hx, hy);
-        if (!have) hx = -1.0f;
+        const SplatCull sc = splat_cull(cco.x, cco.y, cco.z, cco.w);
+        const float hx = have ? sc.hx : -1.0f, hy = sc.hy;
         __builtin_amdgcn_wave_barrier();                  // previous batch's LDS reads are done (program order)
         s_xy[lane] = cxy; s_co[lane] = cco; s_rgb[lane] = crgb;
         if constexpr (DUAL) s_rgb2[lane] = crgb2;
         int trip;
-        const BlockHits bh = block_hits4(cxy.x, cxy.y, hx, hy, bx0, by0);
+        BlockHits bh = block_hits4(cxy.x, cxy.y, hx, hy, bx0, by0);
+        if (exact_cull) bh = block_hits4_exact(cxy.x, cxy.y, cco.x, cco.y, cco.z, sc, bx0, by0, bh);
         const int my_cnt = build_row_lists(s_list, bh.r0, bh.r1, bh.r2, bh.r3, lane, rg.row, trip);
+        if (blk_base) {
+            // rows whose 16 pixels are all saturated (or outside the image) will not use this batch in the backward
+            const unsigned long long dm = __ballot(done);
+            const uint2 rec = make_uint2(base - begin + (uint32_t)lane + 1u, cg);          // 1-based list position, id
+            const unsigned long long m0 = __ballot(bh.r0), m1 = __ballot(bh.r1), m2 = __ballot(bh.r2), m3 = __ballot(bh.r3);
+            if ((dm & 0xffffull) != 0xffffull) {
+                if (bh.r0) blk_base[bc0 + (uint32_t)lanes_below(m0)] = rec;
+                bc0 += (uint32_t)__popcll(m0);
+            }
+            if (((dm >> 16) & 0xffffull) != 0xffffull) {
+                if (bh.r1) blk_base[blk_cap + bc1 + (uint32_t)lanes_below(m1)] = rec;
+                bc1 += (uint32_t)__popcll(m1);
+            }
+            if (((dm >> 32) & 0xffffull) != 0xffffull) {
+                if (bh.r2) blk_base[2 * (size_t)blk_cap + bc2 + (uint32_t)lanes_below(m2)] = rec;
+                bc2 += (uint32_t)__popcll(m2);
+            }
+            if ((dm >> 48) != 0xffffull) {
+                if (bh.r3) blk_base[3 * (size_t)blk_cap + bc3 + (uint32_t)lanes_below(m3)] = rec;
+                bc3 += (uint32_t)__popcll(m3);
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         for (int i = 0; i < trip; i += 2) {
             // two list positions per iteration, straight-line; rows whose list is exhausted idle (valid = false)
@@ -603,6 +409,10 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
             out_color2[hw + pid] = E1 + T * bg2[1];
             out_color2[2 * hw + pid] = E2 + T * bg2[2];
         }
+    }
+    if (blk_count && (lane & 15) == 0) {
+        const int r = lane >> 4;
+        blk_count[16 * (size_t)q.tile + 4 * q.quad + r] = r == 0 ? bc0 : (r == 1 ? bc1 : (r == 2 ? bc2 : bc3));
     }
 }
 
@@ -820,7 +630,7 @@ __global__ __launch_bounds__(64) void composite_bwd_rows3_kernel(
                     else if (fk < 5) val = -0.5f * S;
                     if (val != 0.f) {
                         const uint32_t gid = __float_as_uint(*reinterpret_cast<const float *>(s_rec + eoff + 28));
-                        atomicAdd(acc + 12 * (size_t)gid + fk_off, val);
+                        atomicAdd(acc + D3GA_ACC_STRIDE * (size_t)gid + fk_off, val);
                     }
                 }
             }
@@ -861,18 +671,6 @@ __global__ void wave_sum_selftest_kernel(const float *__restrict__ in, float *__
 
 using namespace d3ga;
 
-// Tuning knob (read once): D3GA_COMPOSITE_VARIANT bit 0 = forward, bit 1 = backward fetch entry records through a
-// wave-private LDS slab (1) instead of v_readlane broadcasts (0); bit 2 = forward, bit 3 = backward use the
-// row-segmented kernels (four 4x4 blocks per wavefront); bit 4 (with bit 3) = backward accumulates a batch in LDS
-// before the global atomics.
-static int composite_variant() {
-    static const int v = [] {
-        const char *e = getenv("D3GA_COMPOSITE_VARIANT");
-        return e ? atoi(e) : kDefaultCompositeVariant;
-    }();
-    return v;
-}
-
 static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, void *img, float *out_color, float *out_invdepth, const float *colors2,
                               const float *bg2, float *out_color2, d3ga_stream_t stream) {
@@ -884,22 +682,26 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
     const int gx = tiles_x(prm->W), gy = tiles_y(prm->H);
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
-    const ImgBuf im = carve_img(img, prm->W, prm->H);
+    const ImgBuf im = carve_img(img, prm->W, prm->H, (int64_t)gx * gy);
+    const bool emit = (composite_variant() & 64) != 0;      // the entry-per-lane backward consumes the per-block lists
     if (composite_variant() & 4) {
         const bool ordered = (composite_variant() & 32) != 0;
         if (colors2)
             hipLaunchKernelGGL(composite_fwd_rows_kernel<true>, dim3(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy)),
                                dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity,
                                g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, out_color, out_invdepth,
-                               ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr, colors2, bg2, out_color2);
+                               ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr, colors2, bg2, out_color2,
+                               emit ? im.blk_list : (uint2 *)nullptr, emit ? im.blk_count : (uint32_t *)nullptr, (composite_variant() & 128) != 0);
         else
             hipLaunchKernelGGL(composite_fwd_rows_kernel<false>, dim3(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy)),
                                dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start, bin.point_list, (uint64_t)d_capacity,
                                g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, out_color, out_invdepth,
                                ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr,
-                               (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
+                               (const float *)nullptr, (const float *)nullptr, (float *)nullptr,
+                               emit ? im.blk_list : (uint2 *)nullptr, emit ? im.blk_count : (uint32_t *)nullptr, (composite_variant() & 128) != 0);
     }
-    else if (composite_variant() & 1)
+    if (composite_variant() & 4) return check_launch(s, prm->debug);
+    if (composite_variant() & 1)
         hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx, gy,
                            bin.tile_start, bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg,
                            im.final_T, im.n_contrib, out_color, out_invdepth);
@@ -947,7 +749,7 @@ static int composite_bwd_impl(const d3ga_raster_params *prm, const float *bg, co
     const int gx = tiles_x(prm->W), gy = tiles_y(prm->H);
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
-    const ImgBuf im = carve_img(const_cast<void *>(img), prm->W, prm->H);
+    const ImgBuf im = carve_img(const_cast<void *>(img), prm->W, prm->H, (int64_t)gx * gy);
 #ifdef D3GA_DIAG
     if (composite_variant() & 512) {
         hipLaunchKernelGGL(composite_bwd_rows3_kernel<false>, dim3(2 * quad_grid(gx, gy)), dim3(64), 0, s, prm->W, prm->H, gx,
@@ -957,6 +759,9 @@ static int composite_bwd_impl(const d3ga_raster_params *prm, const float *bg, co
         return check_launch(s, prm->debug);
     }
 #endif
+    if ((composite_variant() & 64) && (composite_variant() & 4))       // entry-per-lane backward over the forward's block lists
+        return launch_composite_bwd_scan(prm, gx, gy, bin, g, im, d_capacity, bg, dL_dpix, acc, (composite_variant() & 32) != 0,
+                                         colors2, bg2, dL_dpix2, s);
     if (composite_variant() & 8) {
         const bool ordered = (composite_variant() & 32) != 0;
         if (colors2)

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
         const bool visible = ((rc.y & 0xffffu) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.x >> 16));
         float a[12], c6[6];
         if (visible) {
-            const float4 *ap = reinterpret_cast<const float4 *>(acc + 12 * (size_t)i);
+            const float4 *ap = reinterpret_cast<const float4 *>(acc + D3GA_ACC_STRIDE * (size_t)i);
             const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
             a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
             a[8] = a2.x; a[9] = a2.y; a[10] = a2.z; a[11] = a2.w;

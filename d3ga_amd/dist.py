@@ -109,6 +109,10 @@ class FlatGrads:
         return None
 
 
+class ViewDependentInputError(RuntimeError):
+    """Raised by ViewShardedGrads.verify_inputs: a tensor entering the rasterizer differs between the ranks."""
+
+
 class ViewShardedGrads:
     """Gradient exchange of camera-sharded training at the narrowest cut of the graph.
 
@@ -119,6 +123,18 @@ class ViewShardedGrads:
     NO parameter all-reduce is needed (terms of the loss that do not pass through the rasterizer, e.g. the FEM energy,
     are view-independent and therefore identical on every rank by construction).
 
+    PRECONDITION -- everything upstream of the rasterizer's inputs must be VIEW-INDEPENDENT.  Summing dL/d(input) over
+    the ranks and back-propagating the sum through rank r's own graph computes J_r^T sum_v g_v; that equals the wanted
+    sum_v J_v^T g_v only when the Jacobian J of (parameters -> rasterizer inputs) is the same on every rank.  True for the
+    SH path (means / covariance / opacity / SH coefficients are functions of the pose only; the view dependence of the
+    colour lives INSIDE the rasterizer and is handled by the factored SH exchange).  NOT true when colours or opacities come
+    from a network that sees the camera -- the reference's main configuration (configs/actorshq_actor02.yml, use_shs false:
+    ColorField(view_dir, camera / frame encodings), models/cage_net.py:232-258) -- nor for per-camera parameters AFTER the
+    rasterizer (learnable blur, pixel calibration): those configurations must use `GradReducer` / `FlatGrads` over ALL
+    parameters instead.  Because the silent failure mode is replicas that drift apart,
+    `verify_inputs` compares checksums of the rasterizer's inputs across the ranks on the first `verify_steps` calls
+    (one small all-reduce + a host read-back each) and raises ViewDependentInputError when they differ.
+
     Per step and rank, for P Gaussians:
       * one all-reduce of a planar buffer [dL/dmeans3D | dL/dopacity | dL/dcov3D  (or dL/dscales | dL/drots)
         | dL/dcolors_precomp]: 40 B per Gaussian on the cov3D_precomp path;
@@ -127,17 +143,55 @@ class ViewShardedGrads:
         sum_v Y(dir_v) (x) g_v locally (d3ga_sh_grad_from_views) instead of moving 12*M B per Gaussian.
     At C3 (P = 500k, M = 16) on 8 ranks: 20 MB all-reduced + 42 MB gathered per rank, against 124 MB all-reduced by
     the parameter-level reducers below.
+
+    `timing=True` brackets every exchange with an event pair on the launch stream (`exchange_ms()`; bench.py's
+    exchange_ms / compute_ms split).
     """
 
-    def __init__(self, group=None, average=True):
+    def __init__(self, group=None, average=True, verify_steps=1, timing=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.scale = 1.0 / self.world if average else 1.0
         self.bytes_last = 0           # payload bytes this rank contributed in the most recent exchange
+        self.verify_left = int(verify_steps)
+        self.timing = bool(timing)
+        self._events = []             # (start, end) event pairs of the exchanges since the last exchange_ms()
+
+    def verify_inputs(self, named):
+        """Collective.  `named`: dict name -> tensor (or None) entering the rasterizer on this rank.  Raises
+        ViewDependentInputError if any of them differs between the ranks (see the class docstring).  No-op after
+        `verify_steps` calls, for a single rank, and during stream capture."""
+        if self.verify_left <= 0 or self.world == 1:
+            return
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return
+        self.verify_left -= 1
+        names = [k for k, t in named.items() if t is not None and t.numel() > 0]
+        if not names:
+            return
+        t0 = named[names[0]]
+        sums = torch.stack([torch.stack((named[k].detach().double().sum(), named[k].detach().double().abs().sum()))
+                            for k in names]).reshape(-1)
+        both = torch.cat([sums, -sums]).to(t0.device)
+        dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.group)       # max(x) and max(-x) = -min(x) in one collective
+        n = sums.numel()
+        hi, lo = both[:n].cpu(), (-both[n:]).cpu()
+        scale = torch.maximum(hi.abs(), lo.abs()).clamp_min(1e-30)
+        bad = ((hi - lo) / scale > 1e-9).reshape(-1, 2).any(dim=1)
+        if bool(bad.any()):
+            which = [k for k, b in zip(names, bad.tolist()) if b]
+            raise ViewDependentInputError(
+                f"ViewShardedGrads: rasterizer input(s) {which} differ between the ranks, i.e. they depend on the view "
+                "(e.g. ColorField colours / opacities).  Summing gradients at the rasterizer's inputs is only valid for "
+                "view-independent inputs; use d3ga_amd.dist.GradReducer or FlatGrads over all parameters instead.")
 
     def exchange(self, flat, factor=None):
         """Sums `flat` over the ranks in place (times `scale`); gathers `factor` (P+1,3) of every rank into a
         (world, P+1, 3) tensor (returned; None without `factor`).  Both collectives are in flight together."""
+        ev = None
+        if self.timing and flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         works = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
         gathered = None
         self.bytes_last = flat.numel() * 4
@@ -152,4 +206,16 @@ class ViewShardedGrads:
             w.wait()
         if self.scale != 1.0:
             flat.mul_(self.scale)
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
         return gathered
+
+    def exchange_ms(self):
+        """Mean milliseconds per exchange since the last call (synchronises); None if nothing was timed."""
+        if not self._events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._events]
+        self._events = []
+        return sum(ms) / len(ms)

@@ -189,7 +189,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         hit = _geom_cache.get(dev.index) if use_cache else None
         if hit is not None and hit["key"] == key:
             cap, binning, radii = hit["cap"], hit["binning"], hit["radii"]
-            geom, _unused, img = _scratch(P, W, H, 0, dev)
+            geom, _unused, img = _scratch(P, W, H, cap, dev)     # img carries the per-block lists: sized by cap
             st, pp = stream_handle(), ctypes.byref(prm)
             stage_timer.stage("recolor", lambda: check(L.d3ga_raster_recolor(
                 pp, dptr(means3D), dptr(sh), dptr(colors_precomp), dptr(campos), dptr(hit["geom"]), dptr(geom), st),
@@ -239,6 +239,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.cap = cap
         ctx.has_means2D = means2D is not None
         ctx.grad_sync = grad_sync if (grad_sync is not None and grad_sync.world > 1 and P > 0) else None
+        if ctx.grad_sync is not None and hasattr(grad_sync, "verify_inputs"):
+            # the cut exchange is only valid for view-independent inputs (dist.ViewShardedGrads): checked on the first call(s)
+            grad_sync.verify_inputs({"means3D": means3D, "opacities": opacities, "colors_precomp": colors_precomp,
+                                     "shs": sh, "cov3D_precomp": cov3Ds_precomp, "scales": scales, "rotations": rotations})
         ctx.dual = dual
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img,
                               colors2, bg2)
@@ -261,7 +265,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if dual:
             grad_color2 = (torch.zeros_like(grad_color) if grad_color2 is None else _f32(grad_color2, dev))
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        acc = new(P, 12)
+        acc = new(P, _lib.ACC_STRIDE)
         from_sr = cov3Ds_precomp is None
         sync = ctx.grad_sync
         if sync is None:

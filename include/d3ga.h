@@ -148,9 +148,12 @@ int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, void *binnin
 int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, void *img, float *out_color, float *out_invdepth,
                               d3ga_stream_t stream);
-/* R5 back-to-front compositing backward.  dL_dpix (3,H,W).  Accumulates (atomically) into acc (P,12) float, which
- * the CALLER must have zeroed (d3ga_raster_backward does it itself): [0..2] dL/dmean2D (x,y in NDC-scaled units, z unused), [3..5] dL/dconic (a, b/2, c),
- * [6] dL/dopacity, [7..9] dL/dcolor, [10..11] pad. */
+/* R5 back-to-front compositing backward.  dL_dpix (3,H,W).  Accumulates (atomically) into acc (P, D3GA_ACC_STRIDE) float,
+ * which the CALLER must have zeroed (d3ga_raster_backward does it itself): [0..2] dL/dmean2D (x,y in NDC-scaled units, z
+ * unused), [3..5] dL/dconic (a, b/2, c), [6] dL/dopacity, [7..9] dL/dcolor, [10..15] pad.  One record = one 64-byte line:
+ * the nine float atomics of a (tile, Gaussian) contribution then meet the memory side as ONE request (with the former
+ * 48-byte stride half of the records straddled two lines: compositing backward 246 -> 185 us at C3). */
+#define D3GA_ACC_STRIDE 16
 int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, const void *img, const float *dL_dpix, float *acc,
                               d3ga_stream_t stream);

@@ -104,7 +104,7 @@ void hc_preprocess_bwd(const d3ga_raster_params *prm, const float *means3D, cons
     for (int i = 0; i < prm->P; ++i) {
         const bool vis = radii[i] > 0;
         preprocess_bwd_one(*prm, i, vis, means3D, shs ? shs + (size_t)3 * prm->M * i : nullptr, scales, rots, view, proj,
-                           campos, cov3D + 6 * (size_t)i, clamped[i], vis ? acc + 12 * (size_t)i : zeros, dL_dmeans3D,
+                           campos, cov3D + 6 * (size_t)i, clamped[i], vis ? acc + D3GA_ACC_STRIDE * (size_t)i : zeros, dL_dmeans3D,
                            dL_dmeans2D, dL_dopacity, dL_dsh ? dL_dsh + (size_t)3 * prm->M * i : nullptr, dL_dcolors,
                            dL_dcov3D, dL_dscales, dL_drots);
     }

@@ -123,7 +123,7 @@ def _bwd_case(hostcheck, inp, prm, use_sh, from_sr, seed):
     cov = None if from_sr else _np(inp["cov6"])
     o = _run_pre(hostcheck, inp, prm, shs=shs, colors=colors, cov=cov, scales=scales, rots=rots)
     vis = o["radii"] > 0
-    acc = np.zeros((P, 12), np.float32)
+    acc = np.zeros((P, 16), np.float32)       # D3GA_ACC_STRIDE
     acc[:, [0, 1, 3, 4, 5, 6, 7, 8, 9]] = rng.normal(size=(P, 9)).astype(np.float32)
     acc[~vis] = 0
     outs = dict(m3=np.zeros((P, 3), np.float32), m2=np.zeros((P, 3), np.float32), op=np.zeros((P, 1), np.float32),

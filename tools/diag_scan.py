@@ -1,0 +1,67 @@
+"""Loop statistics of composite_bwd_scan_kernel on a workload (needs a library built with D3GA_DIAG=counters)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from d3ga_amd import _lib  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
+L = ctypes.CDLL(_lib._PATH)
+f = bench.Frame(wl, torch.device("cuda", 0), 0)
+for _ in range(30):                      # clocks up, allocator warm
+    for p in f.params.values():
+        p.grad = None
+    f.step()
+torch.cuda.synchronize()
+out = (ctypes.c_ulonglong * 8)()
+assert L.d3ga_diag_scan_read(out, 1) == 0
+for p in f.params.values():
+    p.grad = None
+from d3ga_amd import rasterizer as R
+R.stage_timer.enabled = True
+R.stage_timer.reset()
+f.step()
+torch.cuda.synchronize()
+print("stage times of the measured step (ms):", {k: round(v[1], 4) for k, v in R.stage_timer.summary().items()})
+R.stage_timer.enabled = False
+assert L.d3ga_diag_scan_read(out, 1) == 0
+w = int(out[0])
+print("active waves", w)
+# per-wave timeline (s_memtime ticks): when do waves start / end, how long does a group take, how busy is each SIMD
+import numpy as np
+n = min(w, 32768)
+buf = (ctypes.c_ulonglong * (4 * n))()
+assert L.d3ga_diag_scan_waves(buf, n) == 0
+a = np.array(buf, dtype=np.uint64).reshape(n, 4)
+memtime_dur = (a[:, 0] >> np.uint64(40)).astype(np.int64)
+t0, t1, hw = (a[:, 0] & np.uint64((1 << 40) - 1)).astype(np.int64), (a[:, 1] & np.uint64((1 << 40) - 1)).astype(np.int64), a[:, 3]
+g = (a[:, 2] & np.uint64(0xffff)).astype(np.int64); rowg = ((a[:, 2] >> np.uint64(16)) & np.uint64(0xffff)).astype(np.int64); ents = (a[:, 2] >> np.uint64(32)).astype(np.int64)
+print({'wave_groups': int(g.sum()), 'row_groups': int(rowg.sum()), 'list_entries': int(ents.sum()), 'max_groups_of_a_wave': int(g.max()),
+       'row_balance': round(4 * g.sum() / max(rowg.sum(), 1), 3)})
+print("s_memtime ticks per 100 MHz tick (median over waves):", float(np.median(memtime_dur / np.maximum(t1 - t0, 1))))
+b = t0.min()                             # s_memrealtime: one 100 MHz counter for the whole device
+t0 -= b; t1 -= b
+dur = t1 - t0
+print("kernel span (10 ns ticks)", int(t1.max()), "| waves", n)
+print("start time percentiles", [int(np.percentile(t0, q)) for q in (0, 25, 50, 75, 90, 100)])
+print("end   time percentiles", [int(np.percentile(t1, q)) for q in (0, 25, 50, 75, 90, 100)])
+print("ticks per group: median", float(np.median(dur / np.maximum(g, 1))), "p10", float(np.percentile(dur / np.maximum(g, 1), 10)),
+      "p90", float(np.percentile(dur / np.maximum(g, 1), 90)))
+order = np.argsort(-dur)[:5]
+print("longest waves (dur, groups, start):", [(int(dur[i]), int(g[i]), int(t0[i])) for i in order])
+hwid = (hw & np.uint64(0xffffffff)).astype(np.int64); xcc = (hw >> np.uint64(32)).astype(np.int64)
+simd = (hwid >> 4) & 3; cu = (hwid >> 8) & 15; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 7
+key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+key = key * 4 + simd
+uniq = np.unique(key)
+busy = np.array([dur[key == k].sum() for k in uniq]); last = np.array([t1[key == k].max() for k in uniq]); grp = np.array([g[key == k].sum() for k in uniq])
+print("SIMDs seen", len(uniq), "| groups per SIMD min/med/max", int(grp.min()), float(np.median(grp)), int(grp.max()),
+      "| last end per SIMD min/med/max", int(last.min()), float(np.median(last)), int(last.max()))
+# concurrency over time: number of resident waves at 10 sample points
+for q in (0.1, 0.3, 0.5, 0.7, 0.9):
+    t = q * t1.max()
+    print(f"resident waves at {q:.1f} of the span:", int(((t0 <= t) & (t1 > t)).sum()))
