@@ -111,6 +111,21 @@ def geom(ctx):
     return dict(depth=depth, xy=xy, conic_o=co, rgb=rgb, n_contrib=nc, final_T=fT)
 
 
+def margins(ctx, eps_alpha=1e-5, eps_T=1e-3):
+    """(pixel mask (H,W) bool, Gaussian mask (P,) bool): where a discontinuous decision of the algorithm (alpha < 1/255,
+    T(1-alpha) < 1e-4) sits within float32 implementation noise of its threshold (ro_marginal in raster_oracle.c).
+    eps_alpha: two f32 evaluations of alpha differ by the rounding of the quadratic form (its terms cancel, |term| up to
+    ~20 => ~1e-6 absolute in the exponent) plus the exp itself; eps_T: test_T is a product of up to a few hundred
+    (1 - alpha) factors."""
+    k = ctx.keep
+    pix = np.zeros((k["H"], k["W"]), np.uint8)
+    gs = np.zeros(max(k["P"], 1), np.uint8)
+    L = lib()
+    L.ro_marginal.restype = ctypes.c_int64
+    L.ro_marginal(ctypes.c_void_p(ctx.handle), ctypes.c_float(eps_alpha), ctypes.c_float(eps_T), _p(pix), _p(gs))
+    return pix.astype(bool), gs[:k["P"]].astype(bool)
+
+
 def backward(ctx, dL_dpix):
     """Returns dict of numpy grads: means3D, means2D(P,3), shs|colors, opacities(P,1), scales, rotations, cov3D."""
     k = ctx.keep

@@ -47,6 +47,9 @@ typedef struct {
     /* per pixel */
     float *final_T;
     int *n_contrib;
+    /* decision margins (see ro_marginal): per pixel the smallest relative distance of any evaluated alpha to the
+     * 1/255 cut-off and of any test_T to the 1e-4 cut-off */
+    float *margin_alpha, *margin_T;
 } ro_ctx;
 
 static void xform4x3(const float *m, const float *p, float *o) {
@@ -150,6 +153,7 @@ void ro_free(ro_ctx *c) {
     if (!c) return;
     free(c->depth); free(c->xy); free(c->conic_o); free(c->rgb); free(c->cov3D); free(c->radii);
     free(c->clamped); free(c->rect); free(c->tile_start); free(c->point_list); free(c->final_T); free(c->n_contrib);
+    free(c->margin_alpha); free(c->margin_T);
     free(c);
 }
 
@@ -273,6 +277,8 @@ ro_ctx *ro_forward(int P, int M, int deg, int W, int H, const float *means3D, co
 
     c->final_T = (float *)malloc(4 * (size_t)W * H);
     c->n_contrib = (int *)malloc(4 * (size_t)W * H);
+    c->margin_alpha = (float *)malloc(4 * (size_t)W * H);
+    c->margin_T = (float *)malloc(4 * (size_t)W * H);
 #pragma omp parallel for schedule(dynamic, 4)
     for (int t = 0; t < tiles; t++) {
         int tx = t % c->gx, ty = t / c->gx;
@@ -280,6 +286,7 @@ ro_ctx *ro_forward(int P, int M, int deg, int W, int H, const float *means3D, co
         for (int py = ty * TILE; py < ty * TILE + TILE && py < H; py++)
             for (int px = tx * TILE; px < tx * TILE + TILE && px < W; px++) {
                 float T = 1.0f, C[3] = {0, 0, 0}, invd = 0.f;
+                float m_alpha = INFINITY, m_T = INFINITY;
                 int contributor = 0, last = 0;
                 for (int64_t k = s; k < e; k++) {
                     contributor++;
@@ -289,8 +296,10 @@ ro_ctx *ro_forward(int P, int M, int deg, int W, int H, const float *means3D, co
                     float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                     if (power > 0.0f) continue;
                     float alpha = fminf(0.99f, co[3] * expf(power));
+                    m_alpha = fminf(m_alpha, fabsf(alpha * 255.0f - 1.0f));
                     if (alpha < 1.0f / 255.0f) continue;
                     float test_T = T * (1 - alpha);
+                    m_T = fminf(m_T, fabsf(test_T * 10000.0f - 1.0f));
                     if (test_T < 0.0001f) break;
                     for (int ch = 0; ch < 3; ch++) C[ch] += c->rgb[3 * g + ch] * alpha * T;
                     invd += (1.f / c->depth[g]) * alpha * T;
@@ -300,11 +309,47 @@ ro_ctx *ro_forward(int P, int M, int deg, int W, int H, const float *means3D, co
                 size_t pid = (size_t)py * W + px;
                 c->final_T[pid] = T;
                 c->n_contrib[pid] = last;
+                c->margin_alpha[pid] = m_alpha;
+                c->margin_T[pid] = m_T;
                 for (int ch = 0; ch < 3; ch++) out_color[(size_t)ch * H * W + pid] = C[ch] + T * bg[ch];
                 if (out_invdepth) out_invdepth[pid] = invd;
             }
     }
     return c;
+}
+
+/* Decision margins.  The algorithm is discontinuous in two places per (pixel, Gaussian): alpha < 1/255 drops the splat, and
+ * T (1 - alpha) < 1e-4 ends the pixel.  Two correct float32 implementations (different exp, different FMA contraction
+ * in the quadratic form) disagree on such a decision whenever the compared value sits within their rounding difference
+ * of the threshold; the pixel then moves by up to alpha T <= 1/255 and so do the gradients of the Gaussians on it.  A
+ * pixel is MARGINAL when some alpha it evaluated lies within eps_alpha (relative) of 1/255 or some test_T within eps_T
+ * (relative) of 1e-4; a Gaussian is marginal when it can contribute (alpha >= (1 - eps_alpha)/255) to a marginal pixel
+ * -- a flipped decision changes T for everything behind it and the colour accumulated behind everything before it.
+ * pix_flag (H*W) and gauss_flag (P) receive 0/1.  Parity tests hold every NON-marginal pixel / Gaussian to the strict
+ * bars with no allowance; returns the number of marginal pixels. */
+int64_t ro_marginal(const ro_ctx *c, float eps_alpha, float eps_T, uint8_t *pix_flag, uint8_t *gauss_flag) {
+    const int W = c->W, H = c->H;
+    int64_t n = 0;
+    memset(gauss_flag, 0, (size_t)(c->P > 0 ? c->P : 1));
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            size_t pid = (size_t)py * W + px;
+            int marg = (c->margin_alpha[pid] < eps_alpha) || (c->margin_T[pid] < eps_T);
+            pix_flag[pid] = (uint8_t)marg;
+            if (!marg) continue;
+            n++;
+            int t = (py / TILE) * c->gx + px / TILE;
+            for (int64_t k = c->tile_start[t]; k < c->tile_start[t + 1]; k++) {
+                int g = c->point_list[k];
+                float dx = c->xy[2 * g] - (float)px, dy = c->xy[2 * g + 1] - (float)py;
+                const float *co = c->conic_o + 4 * g;
+                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > 1e-5f) continue;
+                float alpha = fminf(0.99f, co[3] * expf(power));
+                if (alpha * 255.0f >= 1.0f - eps_alpha) gauss_flag[g] = 1;
+            }
+        }
+    return n;
 }
 
 /* Per-Gaussian sums over pixels are accumulated in DOUBLE: the terms are the float32 values a tile splatter

@@ -8,7 +8,7 @@ import torch
 from oracle import bary as ob
 from oracle import deform as od
 from oracle import raster_c as rc
-from util import grad_close, image_close, rel_err, scene_inputs
+from util import Parity, rel_err, scene_inputs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -163,6 +163,19 @@ def _oracle(inp, bg, gpix, sh_degree, use_sh=True, from_sr=False, mod=1.0, rots=
     return color, radii, invd, ctx, grads
 
 
+def _assert_image(par, img, ref, what="rgb", **kw):
+    ok, strict, loose, n = par.image(img, ref, **kw)
+    assert ok, f"{what}: non-marginal pixels max {strict:.3e} (bar 1e-4, no outliers), {n} marginal pixels max {loose:.3e}"
+
+
+def _assert_grads(par, pairs, **kw):
+    """pairs: (mine, oracle, name) of per-Gaussian tensors."""
+    for mine, ref, what in pairs:
+        ok, strict, loose, n = par.grads(_np(mine) if torch.is_tensor(mine) else mine, _np(ref) if torch.is_tensor(ref) else ref, **kw)
+        assert ok, (f"dL/d{what}: non-marginal Gaussians exceed |a-b| <= 1e-3|b| + 1e-6 max|b| by x{strict:.2f}; "
+                    f"{n} marginal Gaussians max-norm error {loose:.3e}")
+
+
 @pytest.mark.parametrize("name,scale_mult,deg", [("T0", 3.0, 3), ("T1", 2.0, 3), ("T1", 6.0, 1), ("C1", 1.0, 3)])
 def test_rasterizer_sh_precomp_cov_forward_backward(name, scale_mult, deg):
     from d3ga_amd.rasterizer import GaussianRasterizer, last_counters, tile_lists
@@ -178,15 +191,13 @@ def test_rasterizer_sh_precomp_cov_forward_backward(name, scale_mult, deg):
     cnt = last_counters()
     assert cnt["D"] == rc.num_rendered(ctx) and not cnt["overflow"]
     assert cnt["visible"] == int((oradii > 0).sum())
-    ok, mx, frac = image_close(_np(color), ocolor)
-    assert ok, (mx, frac)
-    ok, mx, frac = image_close(_np(invd)[0], oinvd, atol=1e-4, outlier_atol=2e-2)
-    assert ok, (mx, frac)
+    par = Parity(ctx)
+    _assert_image(par, _np(color), ocolor)
+    _assert_image(par, _np(invd)[0], oinvd, what="invdepth", marginal_atol=2e-2)
     (color * gpix.to(DEV)).sum().backward()
-    for mine, ref, what in ((means.grad, og["means3D"], "means3D"), (cov.grad, og["cov3D"], "cov3D"),
-                            (op.grad, og["opacities"], "opacity"), (sh.grad, og["shs"], "sh"),
-                            (m2d.grad, og["means2D"], "means2D")):
-        assert rel_err(_np(mine), ref) < 1e-3, what
+    _assert_grads(par, ((means.grad, og["means3D"], "means3D"), (cov.grad, og["cov3D"], "cov3D"),
+                        (op.grad, og["opacities"], "opacity"), (sh.grad, og["shs"], "sh"),
+                        (m2d.grad, og["means2D"], "means2D")))
 
 
 def test_tile_lists_identical_to_oracle():
@@ -216,15 +227,14 @@ def test_rasterizer_colors_scale_rotation_path():
     rast = GaussianRasterizer(_settings(inp, bg, 0, mod=1.2))
     color, radii, _ = rast(means3D=means, means2D=torch.zeros_like(means), opacities=op, colors_precomp=col,
                            scales=sc, rotations=ro)
-    ocolor, oradii, _, _, og = _oracle(inp, bg, gpix, 0, use_sh=False, from_sr=True, mod=1.2, rots=rots)
+    ocolor, oradii, _, ctx, og = _oracle(inp, bg, gpix, 0, use_sh=False, from_sr=True, mod=1.2, rots=rots)
     np.testing.assert_array_equal(_np(radii), oradii)
-    ok, mx, frac = image_close(_np(color), ocolor)
-    assert ok, (mx, frac)
+    par = Parity(ctx)
+    _assert_image(par, _np(color), ocolor)
     (color * gpix.to(DEV)).sum().backward()
-    for mine, ref, what in ((means.grad, og["means3D"], "means3D"), (sc.grad, og["scales"], "scales"),
-                            (ro.grad, og["rotations"], "rotations"), (op.grad, og["opacities"], "opacity"),
-                            (col.grad, og["colors"], "colors")):
-        assert rel_err(_np(mine), ref) < 1e-3, what
+    _assert_grads(par, ((means.grad, og["means3D"], "means3D"), (sc.grad, og["scales"], "scales"),
+                        (ro.grad, og["rotations"], "rotations"), (op.grad, og["opacities"], "opacity"),
+                        (col.grad, og["colors"], "colors")))
 
 
 def test_render_boundary_end_to_end_with_crop_and_detach():
@@ -242,10 +252,13 @@ def test_render_boundary_end_to_end_with_crop_and_detach():
     out = render(inp["batch"], pkg, bg.to(DEV))["render"]
     crop = inp["batch"]["crop"]
     assert out.shape == (3, int(crop[5]), int(crop[4]))
-    ocolor, _, _, ctx, _ = _oracle(inp, bg, None, 0, use_sh=False)
+    inp_r = dict(inp, means3D=means.detach().cpu(), cov6=cov6.detach().cpu())     # the rasterizers see identical Gaussians
+    ocolor, _, _, ctx, _ = _oracle(inp_r, bg, None, 0, use_sh=False)
     from oracle.camera import paste
-    ok, mx, frac = image_close(_np(out), paste(ocolor, crop))
-    assert ok, (mx, frac)
+    par = Parity(ctx)
+    par_crop = Parity.__new__(Parity)                    # the same masks seen through the crop window
+    par_crop.pix, par_crop.gauss = paste(par.pix[None], crop)[0], par.gauss
+    _assert_image(par_crop, _np(out), paste(ocolor, crop))
     target = torch.rand(out.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
     (out - target).abs().mean().backward()
     gfull = torch.zeros(3, inp["H"], inp["W"])
@@ -256,10 +269,8 @@ def test_render_boundary_end_to_end_with_crop_and_detach():
     tp64, b64, s64, r64 = t64(tp), t64(b), t64(s), t64(r)
     m, c = od.cage_deform(tp64, sc["tetras"], sc["tetra_id"], b64, inp["canon_grad"].double(), s64, r64)
     ((m * torch.from_numpy(og["means3D"]).double()).sum() + (c * torch.from_numpy(og["cov3D"]).double()).sum()).backward()
-    assert rel_err(_np(tp.grad), _np(tp64.grad)) < 1e-3
-    assert rel_err(_np(b.grad), _np(b64.grad)) < 1e-3
-    assert rel_err(_np(s.grad), _np(s64.grad)) < 1e-3
-    assert rel_err(_np(r.grad), _np(r64.grad)) < 1e-3
+    assert rel_err(_np(tp.grad), _np(tp64.grad)) < 1e-3      # per vertex (a sum over Gaussians): max-norm
+    _assert_grads(par, ((b.grad, b64.grad, "barys"), (s.grad, s64.grad, "scales"), (r.grad, r64.grad, "rotations")))
     # silhouette pass: detach position + covariance => no gradient reaches the cage
     tp.grad = None
     means, cov6 = cage_deform(tp, sc["tetras"].to(DEV), sc["tetra_id"].to(DEV), b, inp["canon_grad"].to(DEV), s, r)
@@ -282,9 +293,8 @@ def test_capacity_overflow_is_detected_and_retried():
     cnt = R.last_counters()
     assert cnt["D"] > 4 * inp["means3D"].shape[0] + 1024, "scene too small to exercise the retry"
     assert not cnt["overflow"]
-    ocolor, *_ = _oracle(inp, bg, None, 0, use_sh=False)
-    ok, mx, frac = image_close(_np(color), ocolor)
-    assert ok, (mx, frac)
+    ocolor, _, _, ctx, _ = _oracle(inp, bg, None, 0, use_sh=False)
+    _assert_image(Parity(ctx), _np(color), ocolor)
     # static policy with a too-small capacity: flagged, no crash
     R.set_capacity_policy("static", 1000)
     try:
@@ -361,7 +371,8 @@ def test_full_size_c3_against_oracle_and_properties():
     np.testing.assert_allclose(_np(cov_d), cref, rtol=5e-4, atol=2e-6 * np.abs(cref).max())
     means, cov, op, sh = (_cu(inp[k], True) for k in ("means3D", "cov6", "opacities", "shs"))
     rast = R.GaussianRasterizer(_settings(inp, bg, 3))
-    color, radii, _ = rast(means3D=means, means2D=torch.zeros_like(means), opacities=op, shs=sh, cov3D_precomp=cov)
+    m2d = torch.zeros_like(means, requires_grad=True)
+    color, radii, _ = rast(means3D=means, means2D=m2d, opacities=op, shs=sh, cov3D_precomp=cov)
     cnt = R.last_counters()
     gpix = torch.randn(3, inp["H"], inp["W"], generator=torch.Generator().manual_seed(11))
     t0 = time.time()
@@ -369,13 +380,13 @@ def test_full_size_c3_against_oracle_and_properties():
     print("oracle C3 fwd+bwd seconds", time.time() - t0, "D", cnt["D"], "max tile", cnt["max_tile"])
     np.testing.assert_array_equal(_np(radii), oradii)
     assert cnt["D"] == rc.num_rendered(ctx)
-    ok, mx, frac = image_close(_np(color), ocolor)
-    assert ok, (mx, frac)
+    par = Parity(ctx)
+    print("marginal pixels", int(par.pix.sum()), "of", par.pix.size, "| marginal Gaussians", int(par.gauss.sum()), "of", par.gauss.size)
+    _assert_image(par, _np(color), ocolor)
     (color * gpix.to(DEV)).sum().backward()
-    for mine, ref, what in ((means.grad, og["means3D"], "means3D"), (cov.grad, og["cov3D"], "cov3D"),
-                            (op.grad, og["opacities"], "opacity"), (sh.grad, og["shs"], "sh")):
-        ok, mx, frac = grad_close(_np(mine), ref)
-        assert ok, (what, mx, frac)
+    _assert_grads(par, ((means.grad, og["means3D"], "means3D"), (cov.grad, og["cov3D"], "cov3D"),
+                        (op.grad, og["opacities"], "opacity"), (sh.grad, og["shs"], "sh"),
+                        (m2d.grad, og["means2D"], "means2D")))
     # properties
     ostart, olist = rc.tile_lists(ctx)
     start, plist, _ = R.last_tile_lists(inp["W"], inp["H"])
@@ -411,21 +422,26 @@ def test_baseline_configs_c2_c4_against_oracle(name, cx, cy):
     (out * gsub.to(DEV)).sum().backward()
     gfull = torch.zeros(3, inp["H"], inp["W"])
     paste(gfull, crop)[:] = gsub
-    ocolor, _, _, ctx, og = _oracle(inp, bg, gfull, 3)
-    ok, mx, frac = image_close(_np(out), paste(ocolor, crop))
-    assert ok, (mx, frac)
-    for mine, ref, what in ((sh.grad, og["shs"], "sh"), (op.grad, og["opacities"], "opacity")):
-        ok, mx, frac = grad_close(_np(mine), ref)
-        assert ok, (what, mx, frac)
+    # the oracle rasterizer gets the SAME Gaussians the HIP rasterizer got (the HIP deform's outputs; the deform itself is
+    # checked against its own goldens): otherwise its ~1e-4 relative covariance differences move alpha at the thresholds
+    inp_r = dict(inp, means3D=means.detach().cpu(), cov6=cov6.detach().cpu())
+    ocolor, _, _, ctx, og = _oracle(inp_r, bg, gfull, 3)
+    par = Parity(ctx)
+    par_crop = Parity.__new__(Parity)                    # the same masks seen through the crop window
+    par_crop.pix, par_crop.gauss = paste(par.pix[None], crop)[0], par.gauss
+    _assert_image(par_crop, _np(out), paste(ocolor, crop))
+    _assert_grads(par, ((sh.grad, og["shs"], "sh"), (op.grad, og["opacities"], "opacity")))
     t64 = lambda t: t.detach().cpu().double().requires_grad_(True)
     tp64, b64, s64, r64 = t64(tp), t64(b), t64(s), t64(r)
     m, c = od.cage_deform(tp64, sc["tetras"], sc["tetra_id"], b64, inp["canon_grad"].double(), s64, r64)
     ((m * torch.from_numpy(og["means3D"]).double()).sum() + (c * torch.from_numpy(og["cov3D"]).double()).sum()).backward()
-    for mine, ref, what in ((tp.grad, tp64.grad, "tetpoints"), (b.grad, b64.grad, "barys"), (s.grad, s64.grad, "scales"),
-                            (r.grad, r64.grad, "rotations")):
-        # a Gaussian on a flipped pixel feeds its 4 cage vertices: allow a few of the 24k vertices to move
-        ok, mx, frac = grad_close(_np(mine), _np(ref), outlier_frac=1e-3 if what == "tetpoints" else 1e-4)
-        assert ok, (what, mx, frac)
+    _assert_grads(par, ((b.grad, b64.grad, "barys"), (s.grad, s64.grad, "scales"), (r.grad, r64.grad, "rotations")))
+    # cage vertices: a vertex sums the Gaussians of its tets, so it inherits their marginal flag
+    vmask = np.zeros(tp.shape[0], bool)
+    vmask[_np(sc["tetras"].long()[sc["tetra_id"].long()[torch.from_numpy(par.gauss)]]).reshape(-1)] = True
+    par_v = Parity.__new__(Parity)
+    par_v.pix, par_v.gauss = par.pix, vmask
+    _assert_grads(par_v, ((tp.grad, tp64.grad, "tetpoints"),))
 
 
 def test_hipgraph_replay_equals_eager():
@@ -620,8 +636,7 @@ def test_long_tile_lists_use_the_large_sort_paths(name, scale_mult, min_longest)
     ostart, olist = rc.tile_lists(ctx)
     np.testing.assert_array_equal(_np(start), ostart)
     np.testing.assert_array_equal(_np(plist), olist)
-    ok, mx, frac = image_close(_np(color), ocolor)
-    assert ok, (mx, frac)
+    _assert_image(Parity(ctx), _np(color), ocolor)
 
 
 def test_fused_l1_loss_matches_torch():
@@ -657,8 +672,7 @@ def test_screen_filling_splats_exceed_the_lds_tile_window():
     ostart, olist = rc.tile_lists(ctx)
     np.testing.assert_array_equal(_np(start), ostart)
     np.testing.assert_array_equal(_np(plist), olist)
-    ok, mx, frac = image_close(_np(color), ocolor)
-    assert ok, (mx, frac)
+    _assert_image(Parity(ctx), _np(color), ocolor)
 
 
 def test_knn_mean_dist2_matches_bruteforce():
@@ -964,8 +978,8 @@ def test_fuzz_ragged_sizes_and_argument_paths(seed):
     ostart, olist = rc.tile_lists(ctx)
     np.testing.assert_array_equal(_np(start), ostart)
     np.testing.assert_array_equal(_np(plist), olist)
-    ok, mx, frac = image_close(_np(color), ocolor, outlier_frac=2e-3)
-    assert ok, (mx, frac)
+    par = Parity(ctx)
+    _assert_image(par, _np(color), ocolor)
     (color * gpix.to(DEV)).sum().backward()
     names = {"means3D": "means3D", "opacities": "opacities", "shs": "shs", "colors_precomp": "colors",
              "cov3D_precomp": "cov3D", "scales": "scales", "rotations": "rotations"}
@@ -974,11 +988,7 @@ def test_fuzz_ragged_sizes_and_argument_paths(seed):
         if np.abs(ref).max() == 0:
             assert float(t.grad.abs().max()) == 0
         else:
-            # one flipped alpha >= 1/255 / T >= 1e-4 decision (1-ulp exp difference) moves the gradients of the Gaussians
-            # on that pixel by one pixel's worth: seen once in 2447 seeds (5.5e-3 of the max norm); a wiring error is O(1)
-            err = rel_err(_np(t.grad), ref)
-            ok, mx, frac = grad_close(_np(t.grad), ref, rtol=2e-3, outlier_frac=2e-2, outlier_rtol=5e-2)
-            assert err < 2e-3 or ok, (k, err, mx, frac)
+            _assert_grads(par, ((t.grad, ref, k),))
 
 
 def test_nan_and_inf_inputs_are_contained():

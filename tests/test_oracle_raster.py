@@ -124,3 +124,36 @@ def test_front_to_back_order_and_termination():
                               math.tan(fov / 2), math.tan(fov / 2), W, H, cov3D_precomp=cov.numpy(), colors_precomp=col.numpy())
     np.testing.assert_allclose(c[:, 8, 8], [0.0, 0.99, a_blue * 0.01], atol=1e-6)
     assert rc.geom(ctx)["n_contrib"][8, 8] == 2
+
+
+def test_decision_margins_flag_threshold_pixels_and_their_gaussians():
+    """oracle.raster_c.margins: a pixel is marginal when an evaluated alpha sits within eps of 1/255 (or a test_T within eps of
+    1e-4); a Gaussian is marginal when it can contribute to such a pixel.  Checked against a direct evaluation."""
+    W = H = 33
+    fov = 0.6
+    f = W / (2 * math.tan(fov / 2))
+    z, sigma, o = 4.0, 0.08, 0.7
+    from oracle.camera import projection
+    view = np.eye(4, dtype=np.float32)
+    proj = projection(0.01, 100.0, fov, fov).T.copy().astype(np.float32)
+    means = np.array([[0.0, 0.0, z], [5.0, 5.0, z]], np.float32)             # the second one is far outside the image
+    cov = np.array([[sigma ** 2, 0, 0, sigma ** 2, 0, sigma ** 2]] * 2, np.float32)
+    _, radii, _, ctx = rc.forward(means, np.array([[o], [o]], np.float32), np.zeros(3, np.float32), view, proj, np.zeros(3, np.float32),
+                                  math.tan(fov / 2), math.tan(fov / 2), W, H, cov3D_precomp=cov, colors_precomp=np.ones((2, 3), np.float32))
+    s2 = (f * sigma / z) ** 2 + 0.3
+    ys, xs = np.mgrid[0:H, 0:W]
+    alpha = np.minimum(0.99, o * np.exp(-0.5 * ((xs - 16.0) ** 2 + (ys - 16.0) ** 2) / s2))
+    rel = np.abs(alpha * 255.0 - 1.0)
+    inside = np.hypot(xs - 16.0, ys - 16.0) <= radii[0] + 16          # pixels whose tile holds the splat at all
+    for eps in (0.5, 0.05):
+        pix, gs = rc.margins(ctx, eps_alpha=eps, eps_T=0.0)
+        want = (rel < eps)
+        # tiles the splat does not touch evaluate nothing there: compare where the oracle evaluated it
+        t_touched = np.zeros((H, W), bool)
+        r = int(radii[0])
+        t_touched[max(0, (16 - r) // 16 * 16):min(H, ((16 + r) // 16 + 1) * 16), max(0, (16 - r) // 16 * 16):min(W, ((16 + r) // 16 + 1) * 16)] = True
+        assert np.array_equal(pix & t_touched, want & t_touched), eps
+        assert bool(gs[0]) == bool(want[t_touched].any()) and not gs[1]
+    pix, gs = rc.margins(ctx, eps_alpha=1e-9, eps_T=0.0)
+    assert not pix.any() and not gs.any()
+    assert inside.any()

@@ -33,23 +33,41 @@ def scene_inputs(name="T0", seed=17, azimuth=0.4, scale_mult=1.0, cx=None, cy=No
     )
 
 
-def image_close(img, ref, atol=1e-4, outlier_frac=1e-4, outlier_atol=8e-3):
-    """RGB parity: max-abs <= atol, except for a vanishing fraction of pixels where a 1-ulp difference in exp()
-    flips an `alpha < 1/255` or `T < 1e-4` decision (each flip moves a pixel by at most alpha*T <= 1/255 * T)."""
-    d = np.abs(np.asarray(img, np.float64) - np.asarray(ref, np.float64))
-    bad = d > atol
-    frac = bad.mean()
-    return bool(frac <= outlier_frac and d.max() <= outlier_atol), float(d.max()), float(frac)
+class Parity:
+    """Strict comparison of the HIP rasterizer with the C oracle.
 
+    The algorithm is discontinuous where alpha crosses 1/255 and where T (1 - alpha) crosses 1e-4; two correct float32
+    implementations can take different branches when the compared value sits within their rounding difference of the
+    threshold.  The oracle reports exactly those places (`oracle.raster_c.margins`: per-pixel decision margins, and the
+    Gaussians that can contribute to a marginal pixel).  Everything else is held to the bars of BASELINE.md with NO
+    allowance:
+        image     non-marginal pixels     max |a - b| <= 1e-4            (zero outliers)
+        gradients non-marginal Gaussians  |a - b| <= 1e-3 |b| + 1e-6 max|b|   element-wise
+    Marginal pixels may move by one dropped / extra splat (<= alpha T <= 1/255 per decision, 8e-3 allowed), marginal
+    Gaussians by one pixel's worth of gradient (5 % of the largest gradient allowed)."""
 
-def grad_close(a, b, rtol=1e-3, outlier_frac=2e-5, outlier_rtol=5e-2):
-    """Gradient parity at FULL size: per-Gaussian max |a-b| <= rtol * max|b| for all but a vanishing fraction of
-    Gaussians.  A pixel whose `alpha < 1/255` / `T < 1e-4` decision flips (1-ulp exp difference, see image_close)
-    moves the gradient of the few Gaussians on that pixel by one pixel's worth; with ~2e8 (pixel, Gaussian) pairs per
-    frame a handful of such flips is unavoidable between any two exp implementations."""
-    a = np.asarray(a, np.float64).reshape(len(b), -1)
-    b = np.asarray(b, np.float64).reshape(len(b), -1)
-    scale = np.abs(b).max() + 1e-30
-    d = np.abs(a - b).max(1) / scale
-    frac = float((d > rtol).mean())
-    return bool(frac <= outlier_frac and d.max() <= outlier_rtol), float(d.max()), frac
+    def __init__(self, ctx, eps_alpha=1e-5, eps_T=1e-3):
+        from oracle import raster_c as rc
+        self.pix, self.gauss = rc.margins(ctx, eps_alpha, eps_T)
+
+    def image(self, img, ref, atol=1e-4, marginal_atol=8e-3):
+        """-> (ok, max error on non-marginal pixels, max error on marginal pixels, number of marginal pixels)"""
+        d = np.abs(np.asarray(img, np.float64) - np.asarray(ref, np.float64))
+        d = d.reshape((-1,) + self.pix.shape).max(0)
+        strict = float(d[~self.pix].max()) if (~self.pix).any() else 0.0
+        loose = float(d[self.pix].max()) if self.pix.any() else 0.0
+        return bool(strict <= atol and loose <= marginal_atol), strict, loose, int(self.pix.sum())
+
+    def grads(self, a, b, rtol=1e-3, atol_rel=1e-6, marginal_rtol=5e-2):
+        """per-Gaussian tensors (P, ...) -> (ok, worst excess ratio on non-marginal Gaussians (<= 1 passes), worst
+        max-norm error on marginal Gaussians, number of marginal Gaussians)"""
+        b = np.asarray(b, np.float64)
+        a = np.asarray(a, np.float64).reshape(b.shape)
+        a, b = a.reshape(len(b), -1), b.reshape(len(b), -1)
+        scale = np.abs(b).max() + 1e-300
+        d = np.abs(a - b)
+        excess = d / (rtol * np.abs(b) + atol_rel * scale)
+        m = self.gauss[:len(b)]
+        strict = float(excess[~m].max()) if (~m).any() else 0.0
+        loose = float(d[m].max() / scale) if m.any() else 0.0
+        return bool(strict <= 1.0 and loose <= marginal_rtol), strict, loose, int(m.sum())
