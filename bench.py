@@ -95,7 +95,8 @@ class Frame:
         # canon_barys = barys + delta_bary, scales = exp(scaling) (cage_net.py:213-214): fused into the deform kernels
         means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad, p["scaling"],
                                   p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp")
-        pkg = {"means3D": means, "cov3D_precomp": cov6, "opacities": torch.sigmoid(p["opacity"]),
+        # opacity = sigmoid(opacities) (cage_net.py:247): fused into the per-Gaussian kernels (pkg["opacity_logits"])
+        pkg = {"means3D": means, "cov3D_precomp": cov6, "opacity_logits": p["opacity"],
                "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
         img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
         loss = l1_loss(img, self.target)              # fused mean |img - target| (utils/loss_utils.py:29)
@@ -137,7 +138,7 @@ class Frame:
             tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
             means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad, p["scaling"],
                                       p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp")
-        pkg = {"means3D": means, "cov3D_precomp": cov6, "opacities": torch.sigmoid(p["opacity"]),
+        pkg = {"means3D": means, "cov3D_precomp": cov6, "opacity_logits": p["opacity"],
                "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
         if with_fields == "color":
             from d3ga_amd.mlp import view_directions
@@ -162,8 +163,10 @@ class Frame:
             both = render_pair(self.batch, pkg, self.bg, self.sil_rgb, self.bg0, grad_sync=self.grad_sync)
             img, sil = both["render"], both["render2"]
         else:
-            img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
-            sil = render(self.batch, pkg, self.bg0, colors_precomp=self.sil_rgb, grad_sync=self.grad_sync)["render"]
+            from d3ga_amd.rasterizer import geometry_reuse
+            with geometry_reuse():       # the silhouette pass reuses the RGB pass's projection / binning / sort (opt-in)
+                img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
+                sil = render(self.batch, pkg, self.bg0, colors_precomp=self.sil_rgb, grad_sync=self.grad_sync)["render"]
         # train.py:190-193: (1 - lambda) L1 + lambda (1 - SSIM) on the RGB image, L1 on the silhouette
         lam = 0.2
         rgb_l1, rgb_ssim = l1_ssim(img, self.target)          # one fused kernel each way

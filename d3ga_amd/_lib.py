@@ -22,7 +22,8 @@ class RasterParams(ctypes.Structure):
     _fields_ = [("P", ctypes.c_int32), ("M", ctypes.c_int32), ("sh_degree", ctypes.c_int32),
                 ("W", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
-                ("antialiasing", ctypes.c_int32), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32)]
+                ("antialiasing", ctypes.c_int32), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
+                ("opacity_activation", ctypes.c_int32)]
 
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -120,6 +121,18 @@ def stream_handle():
 def dptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def f32c16(t):
+    """float32, contiguous AND 16-byte aligned (the vectorised kernels load 16 bytes per lane).  `.contiguous()` keeps a
+    contiguous VIEW with a storage offset as it is -- e.g. `imgs[1]` of an (N,3,H,W) batch with odd H*W, or `x[1:]` -- so such
+    a tensor is copied here instead of being rejected by the C ABI (D3GA_E_CONFIG)."""
+    if t is None:
+        return None
+    t = t.float().contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone(memory_format=__import__("torch").contiguous_format)
+    return t
 
 
 def require_cuda(*tensors):

@@ -42,18 +42,13 @@ class Camera:
     full_proj_transform, camera_center are float32 tensors in the transposed, row-vector layout)."""
 
     def __init__(self, colmap_id, R, T, FoVx, FoVy, image_name=None, uid=None, width=None, height=None,
-                 data_device="cuda"):
+                 data_device="cuda", _matrices=None):
         self.uid, self.colmap_id, self.image_name = uid, colmap_id, image_name
         self.R, self.T, self.FoVx, self.FoVy = R, T, float(FoVx), float(FoVy)
         self.image_width, self.image_height = width, height
         self.znear, self.zfar = ZNEAR, ZFAR
-        wv = _view_matrix(R, T).T.copy()
-        pr = _projection_matrix(self.FoVx, self.FoVy).T.copy()
-        full = wv @ pr
-        center = np.linalg.inv(wv)[3, :3].astype(np.float32)
-        packed = np.concatenate([wv.ravel(), pr.ravel(), full.ravel(), center]).astype(np.float32)
-        dev = torch.device(data_device)
-        buf = torch.from_numpy(packed).to(dev)                 # one H2D copy
+        buf = _matrices if _matrices is not None else self.pack_matrices(R, T, self.FoVx, self.FoVy, data_device)
+        self.matrices = buf                                    # (51,) float32 on the device: view | proj | full | centre
         self.world_view_transform = buf[0:16].view(4, 4)
         self.projection_matrix = buf[16:32].view(4, 4)
         self.full_proj_transform = buf[32:48].view(4, 4)
@@ -61,24 +56,39 @@ class Camera:
         self.tanfovx = math.tan(self.FoVx * 0.5)
         self.tanfovy = math.tan(self.FoVy * 0.5)
 
+    @staticmethod
+    def pack_host(R, T, FoVx, FoVy):
+        """The 51 float32 numbers of a camera on the HOST: view (16) | projection (16) | full projection (16) | centre (3)."""
+        wv = _view_matrix(R, T).T.copy()
+        pr = _projection_matrix(float(FoVx), float(FoVy)).T.copy()
+        full = wv @ pr
+        center = np.linalg.inv(wv)[3, :3].astype(np.float32)
+        return np.concatenate([wv.ravel(), pr.ravel(), full.ravel(), center]).astype(np.float32)
+
+    @staticmethod
+    def pack_matrices(R, T, FoVx, FoVy, device):
+        return torch.from_numpy(Camera.pack_host(R, T, FoVx, FoVy)).to(torch.device(device))     # one H2D copy
+
 
 _cache = OrderedDict()
 _CACHE_MAX = 512
 
 
 def batch_to_camera(batch, device="cuda"):
-    """lib/cameras.py:14-26, cached on the camera's defining numbers."""
+    """lib/cameras.py:14-26.  Only the DEVICE MATRICES are cached (keyed on the numbers that define them: R, T, FoV, device);
+    the Camera object itself is built fresh from the current batch, so uid / colmap_id / image_name / image size always
+    belong to this frame."""
     R = np.ascontiguousarray(np.asarray(batch["R"], dtype=np.float64))
     T = np.ascontiguousarray(np.asarray(batch["T"], dtype=np.float64))
     key = (R.tobytes(), T.tobytes(), float(batch["FoVx"]), float(batch["FoVy"]), str(device))
-    cam = _cache.get(key)
-    if cam is None:
-        cam = Camera(colmap_id=batch.get("camera_id"), R=R, T=T, FoVx=batch["FoVx"], FoVy=batch["FoVy"],
-                     image_name=f'{batch.get("frame_id")}_{batch.get("camera_id")}', uid=batch.get("frame_id"),
-                     width=batch.get("width"), height=batch.get("height"), data_device=device)
-        _cache[key] = cam
+    mats = _cache.get(key)
+    if mats is None:
+        mats = Camera.pack_matrices(R, T, batch["FoVx"], batch["FoVy"], device)
+        _cache[key] = mats
         if len(_cache) > _CACHE_MAX:
             _cache.popitem(last=False)
     else:
         _cache.move_to_end(key)
-    return cam
+    return Camera(colmap_id=batch.get("camera_id"), R=R, T=T, FoVx=batch["FoVx"], FoVy=batch["FoVy"],
+                  image_name=f'{batch.get("frame_id")}_{batch.get("camera_id")}', uid=batch.get("frame_id"),
+                  width=batch.get("width"), height=batch.get("height"), data_device=device, _matrices=mats)

@@ -241,12 +241,14 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
         if (staged)
             preprocess_bwd_one(prm, i, visible, means3D, slab + lane * kShRow, scales, rotations, viewmatrix, projmatrix,
                                campos, c6, geom.clamped[i], a, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
-                               dL_dsh ? slab + lane * kShRow : nullptr, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots);
+                               dL_dsh ? slab + lane * kShRow : nullptr, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots,
+                               visible ? geom.conic_o[i].w : 0.f);
         else
             preprocess_bwd_one(prm, i, visible, means3D, shs ? shs + (size_t)M3 * i : nullptr, scales, rotations,
                                viewmatrix, projmatrix, campos, c6, geom.clamped[i], a, dL_dmeans3D, dL_dmeans2D,
                                dL_dopacity, dL_dsh ? dL_dsh + (size_t)M3 * i : nullptr, dL_dcolors, dL_dcov3D,
-                               dL_dscales, dL_drots);
+                               dL_dscales, dL_drots,
+                               visible ? geom.conic_o[i].w : 0.f);
     }
     if (staged && dL_dsh) {
         __syncthreads();

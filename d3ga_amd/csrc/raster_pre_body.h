@@ -56,6 +56,7 @@ D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float 
     o.opacity = 0.f;
     if (!o.sp.visible) return o;
     o.opacity = opacities[i];
+    if (prm.opacity_activation == D3GA_OPACITY_SIGMOID) o.opacity = 1.0f / (1.0f + expf(-o.opacity));   // cage_net.py:247
     if (!(o.opacity == o.opacity)) {         // NaN opacity: min(0.99, NaN * G) would evaluate to 0.99 -- cull instead
         o.sp.visible = false; o.sp.radius = 0;
         o.sp.rect[0] = o.sp.rect[1] = o.sp.rect[2] = o.sp.rect[3] = 0;
@@ -91,7 +92,7 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
                                 const float *viewmatrix, const float *projmatrix, const float *campos,
                                 const float *c6, uint8_t clampmask, const float *a, float *dL_dmeans3D,
                                 float *dL_dmeans2D, float *dL_dopacity, float *dsh_row, float *dL_dcolors,
-                                float *dL_dcov3D, float *dL_dscales, float *dL_drots) {
+                                float *dL_dcov3D, float *dL_dscales, float *dL_drots, float act_opacity = 0.f) {
     float gmean[3] = {0.f, 0.f, 0.f};
     float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const V3 mean = ld3(means3D, i);
@@ -147,7 +148,8 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
     if (dL_dmeans2D) {
         dL_dmeans2D[3 * (size_t)i] = a[0]; dL_dmeans2D[3 * (size_t)i + 1] = a[1]; dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
     }
-    if (dL_dopacity) dL_dopacity[i] = a[6];
+    // act_opacity: the activated opacity the forward stored (conic_o.w); sigmoid' = s (1 - s)
+    if (dL_dopacity) dL_dopacity[i] = prm.opacity_activation == D3GA_OPACITY_SIGMOID ? a[6] * act_opacity * (1.0f - act_opacity) : a[6];
     if (dL_dcov3D) {
         for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = g6[k];
     }

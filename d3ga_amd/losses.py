@@ -9,15 +9,15 @@ direction).  GPU tensors only.
 import torch
 
 from . import _lib
-from ._lib import check, dptr, require_cuda, stream_handle
+from ._lib import check, dptr, f32c16, require_cuda, stream_handle
 
 
 class _L1Mean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         require_cuda(a, b)
-        a = a.float().contiguous()
-        b = b.float().contiguous()
+        a = f32c16(a)
+        b = f32c16(b)
         if a.shape != b.shape:
             raise ValueError(f"l1_loss: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
         out = torch.empty((), dtype=torch.float32, device=a.device)
@@ -29,7 +29,7 @@ class _L1Mean(torch.autograd.Function):
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         ga = torch.empty_like(a)
-        check(_lib.lib().d3ga_l1_mean_bwd(a.numel(), dptr(a), dptr(b), dptr(g.float().contiguous()), dptr(ga),
+        check(_lib.lib().d3ga_l1_mean_bwd(a.numel(), dptr(a), dptr(b), dptr(f32c16(g)), dptr(ga),
                                           stream_handle()), "d3ga_l1_mean_bwd")
         return ga, (-ga if ctx.needs_input_grad[1] else None)
 
@@ -43,8 +43,8 @@ class _SSIM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img1, img2):
         require_cuda(img1, img2)
-        a = img1.float().contiguous()
-        b = img2.float().contiguous()
+        a = f32c16(img1)
+        b = f32c16(img2)
         if a.shape != b.shape or a.dim() != 3:
             raise ValueError(f"ssim: expected two (C,H,W) images of equal shape, got {tuple(a.shape)} / {tuple(b.shape)}")
         C, H, W = a.shape
@@ -62,7 +62,7 @@ class _SSIM(torch.autograd.Function):
         saved = ctx.saved_tensors
         a, b = saved[0], saved[1]
         C, H, W = a.shape
-        g = g.float().contiguous()
+        g = f32c16(g)
         L = _lib.lib()
         ga = gb = None
         if ctx.needs_input_grad[0]:
@@ -98,8 +98,8 @@ class _L1SSIM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img1, img2):
         require_cuda(img1, img2)
-        a = img1.float().contiguous()
-        b = img2.float().contiguous()
+        a = f32c16(img1)
+        b = f32c16(img2)
         if a.shape != b.shape or a.dim() != 3:
             raise ValueError(f"l1_ssim: expected two (C,H,W) images of equal shape, got {tuple(a.shape)} / {tuple(b.shape)}")
         C, H, W = a.shape

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from ._lib import check, dptr, require_cuda, stream_handle
+from ._lib import f32c16, check, dptr, require_cuda, stream_handle
 
 _panels = {}
 
@@ -73,7 +73,7 @@ class _Chain(torch.autograd.Function):
     def forward(ctx, x, slopes, *wb):
         weights, biases = wb[0::2], wb[1::2]
         require_cuda(x, *weights)
-        h = x.float().contiguous()
+        h = f32c16(x)
         acts, signs = [h], []
         track = any(ctx.needs_input_grad)                      # (grad mode is off inside forward: ask the node instead)
         for w, b, slope in zip(weights, biases, slopes):
@@ -95,7 +95,7 @@ class _Chain(torch.autograd.Function):
     def backward(ctx, dy):
         L = ctx.n_layers
         acts, weights = ctx.saved_tensors[:L + 1], ctx.saved_tensors[L + 1:]
-        dpre = dy.float().contiguous()
+        dpre = f32c16(dy)
         if ctx.slopes[-1] != 1.0:                             # a chain that ENDS in an activation (not the fields' case)
             dpre = dpre * torch.where(acts[L] > 0, 1.0, ctx.slopes[-1])
         grads = [None] * (2 * L)
@@ -294,7 +294,7 @@ class _Sh4Encoding(torch.autograd.Function):
     @staticmethod
     def forward(ctx, d):
         require_cuda(d)
-        d = d.float().contiguous()
+        d = f32c16(d)
         P = d.shape[0]
         enc = torch.empty((P, 16), dtype=torch.float32, device=d.device)
         check(_lib.lib().d3ga_sh4_encoding_fwd(P, dptr(d), dptr(enc), stream_handle()), "d3ga_sh4_encoding_fwd")
@@ -305,7 +305,7 @@ class _Sh4Encoding(torch.autograd.Function):
     def backward(ctx, g):
         (d,) = ctx.saved_tensors
         gd = torch.empty_like(d)
-        check(_lib.lib().d3ga_sh4_encoding_bwd(d.shape[0], dptr(d), dptr(g.float().contiguous()), dptr(gd), stream_handle()),
+        check(_lib.lib().d3ga_sh4_encoding_bwd(d.shape[0], dptr(d), dptr(f32c16(g)), dptr(gd), stream_handle()),
               "d3ga_sh4_encoding_bwd")
         return gd
 

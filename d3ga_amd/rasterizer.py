@@ -125,7 +125,13 @@ def _f32(t, device):
 # re-evaluates only the colour (d3ga_raster_recolor) and shares its binning buffer.  A call hits the cache when its
 # inputs ARE the previous call's tensors (same storage address and version counter; the cache keeps them alive, so an
 # address cannot be recycled for different data).  Never used while a stream capture is in progress.
-_reuse = {"enabled": True}
+#
+# OPT-IN (off by default).  A hit is decided from (data_ptr, _version, shape) only, so a write that does not bump the
+# version counter is invisible to it: `p.data.add_()` / `.data.copy_()` style updates, or a kernel (this library's own C
+# ABI included) writing into a preallocated buffer.  With such inputs every later render would silently reuse stale
+# projection and binning.  Enable it only around the two renders of one step (`with geometry_reuse():`) -- the cache is
+# dropped on exit -- or use `renderer.render_pair`, which needs no cache at all.
+_reuse = {"enabled": False}
 _geom_cache = {}     # device index -> dict(key, geom, binning, cap, radii, pins)
 
 
@@ -139,12 +145,27 @@ def clear_geometry_cache():
     _geom_cache.clear()
 
 
+class geometry_reuse:
+    """`with geometry_reuse(): rgb = render(...); sil = render(...)` -- the second render of the same package reuses the
+    first one's projection / binning / sort; nothing is pinned or trusted beyond the block."""
+
+    def __enter__(self):
+        self._was = _reuse["enabled"]
+        _reuse["enabled"] = True
+        return self
+
+    def __exit__(self, *exc):
+        _reuse["enabled"] = self._was
+        _geom_cache.clear()
+        return False
+
+
 def _tkey(t):
     return None if t is None else (t.data_ptr(), t._version, tuple(t.shape))
 
 
 def _geometry_key(prm, cap_mode, tensors):
-    return (prm.P, prm.W, prm.H, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, cap_mode) + tuple(
+    return (prm.P, prm.W, prm.H, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.opacity_activation, cap_mode) + tuple(
         _tkey(t) for t in tensors)
 
 
@@ -155,7 +176,7 @@ def _empty_to_none(t):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, grad_sync=None, colors2=None, bg2=None):
+                raster_settings, grad_sync=None, colors2=None, bg2=None, opacity_activation=None):
         s = raster_settings
         require_cuda(means3D)
         dev = means3D.device
@@ -175,7 +196,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         prm = RasterParams(P=P, M=M, sh_degree=int(s.sh_degree), W=W, H=H, tanfovx=float(s.tanfovx),
                            tanfovy=float(s.tanfovy), scale_modifier=float(s.scale_modifier),
                            antialiasing=int(bool(s.antialiasing)), prefiltered=int(bool(s.prefiltered)),
-                           debug=int(bool(s.debug)))
+                           debug=int(bool(s.debug)), opacity_activation=_ACTIVATIONS[opacity_activation])
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         invdepth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
@@ -328,31 +349,37 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                 stream_handle()), "d3ga_sh_grad_from_views")
                 g_col = None
         return (g_means3D, g_means2D if ctx.has_means2D else None, g_sh, g_col, g_opac, g_scales, g_rots, g_cov, None,
-                None, None, None)
+                None, None, None, None)
+
+
+_ACTIVATIONS = {None: 0, "none": 0, "sigmoid": 1}       # D3GA_OPACITY_SIGMOID
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, grad_sync=None):
+                        raster_settings, grad_sync=None, opacity_activation=None):
+    """opacity_activation="sigmoid" (extension over upstream): `opacities` holds the raw logits and the sigmoid of
+    models/cage_net.py:247 runs inside the per-Gaussian kernels, forward and backward."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, grad_sync)
+                                     cov3Ds_precomp, raster_settings, grad_sync, None, None, opacity_activation)
 
 
 def rasterize_gaussians_pair(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                             raster_settings, colors2, bg2, grad_sync=None):
+                             raster_settings, colors2, bg2, grad_sync=None, opacity_activation=None):
     """Two images from ONE pass: the usual one and `colors2` (P,3; constants, no gradient) blended with the same alphas over
     `bg2`.  Returns (color, radii, invdepth, color2).  Gradients of both images reach the geometry and the opacities."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, grad_sync, colors2, bg2)
+                                     cov3Ds_precomp, raster_settings, grad_sync, colors2, bg2, opacity_activation)
 
 
 class GaussianRasterizer(nn.Module):
     """`grad_sync` (optional, not in upstream): a d3ga_amd.dist.ViewShardedGrads -- the gradients returned by the
     backward are then already summed/averaged over the ranks of the group (each rank renders its own camera)."""
 
-    def __init__(self, raster_settings, grad_sync=None):
+    def __init__(self, raster_settings, grad_sync=None, opacity_activation=None):
         super().__init__()
         self.raster_settings = raster_settings
         self.grad_sync = grad_sync
+        self.opacity_activation = opacity_activation      # "sigmoid": `opacities` are logits (fused D8 activation)
 
     def markVisible(self, positions):
         """Boolean (P,) mask: view-space z > 0.2 (upstream _C.mark_visible)."""
@@ -376,7 +403,7 @@ class GaussianRasterizer(nn.Module):
         if self.raster_settings.antialiasing:
             raise NotImplementedError("antialiasing=True is not implemented (the D3GA renderer passes False, renderer.py:92)")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   self.raster_settings, self.grad_sync)
+                                   self.raster_settings, self.grad_sync, self.opacity_activation)
 
 
 def last_tile_lists(W, H, device=None):

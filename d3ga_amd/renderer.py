@@ -68,7 +68,12 @@ def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_
     cov3D_precomp = pkg.get("cov3D_precomp")
     scales = pkg.get("scales")
     rotations = pkg.get("rotations")
-    opacities = pkg["opacities"]
+    opacities = pkg.get("opacities")
+    # extension: a package may carry the raw `opacity_logits` instead of activated `opacities` (models/cage_net.py:247
+    # applies sigmoid in Python): the activation then runs inside the per-Gaussian kernels, forward and backward
+    act = None
+    if opacities is None and pkg.get("opacity_logits") is not None:
+        opacities, act = pkg["opacity_logits"], "sigmoid"
     shs = pkg["shs"]
 
     if len(detach) > 0:
@@ -96,9 +101,10 @@ def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_
 
     if _pair is not None:
         img, _radii, _invd, img2 = rasterize_gaussians_pair(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                                            cov3D_precomp, settings, _pair[0], _pair[1], grad_sync)
+                                                            cov3D_precomp, settings, _pair[0], _pair[1], grad_sync, act)
         return {"render": paste(img, crop), "render2": paste(img2, crop)}
     rasterizer = GaussianRasterizer(raster_settings=settings)
+    rasterizer.opacity_activation = act
     if grad_sync is not None:                       # extension over upstream's constructor: set only when asked for
         rasterizer.grad_sync = grad_sync
     if measure_time:

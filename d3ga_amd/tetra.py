@@ -123,3 +123,59 @@ def gaussian_ply_arrays(features_dc, features_rest, opacities, scaling, rotation
     f_rest = features_rest.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy()
     return (f_dc, f_rest, opacities.detach().cpu().numpy(), scaling.detach().cpu().numpy(),
             rotation.detach().cpu().numpy())
+
+
+def save_gaussian_ply(path, xyz, features_dc, features_rest, opacities, scaling, rotation, normals=None):
+    """Writes the 3DGS-style point cloud the reference describes with `describe_ply` / `get_ply` (models/cage_net.py:111-132,
+    models/mesh_net.py:98-119): one `vertex` element, binary little-endian float32 properties in the order
+    x y z nx ny nz | f_dc_* | f_rest_* | opacity | scale_* | rot_*, the feature blocks channel-major (`transpose(1, 2)`) as in
+    `get_ply`.  The reference builds the column list and the blocks but leaves the file writing to plyfile-based viewers'
+    converters; this is that writer without the plyfile dependency (same bytes plyfile's PlyElement.describe produces)."""
+    import numpy as np
+    cols = gaussian_ply_columns(features_dc, features_rest, scaling, rotation)
+    f_dc, f_rest, op, sc, rot = gaussian_ply_arrays(features_dc, features_rest, opacities, scaling, rotation)
+    xyz = xyz.detach().cpu().numpy() if hasattr(xyz, "detach") else np.asarray(xyz)
+    nrm = np.zeros_like(xyz) if normals is None else (normals.detach().cpu().numpy() if hasattr(normals, "detach") else np.asarray(normals))
+    table = np.concatenate([xyz, nrm, f_dc, f_rest, op.reshape(len(xyz), -1), sc, rot], axis=1).astype("<f4")
+    assert table.shape[1] == len(cols), (table.shape, len(cols))
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % len(xyz)
+    header += "".join(f"property float {c}\n" for c in cols) + "end_header\n"
+    with open(path, "wb") as f:
+        f.write(header.encode("ascii"))
+        f.write(np.ascontiguousarray(table).tobytes())
+    return cols
+
+
+def load_gaussian_ply(path):
+    """-> dict(columns, xyz (P,3), normals (P,3), features_dc (P,1,3), features_rest (P,R,3), opacities (P,1), scaling (P,S),
+    rotation (P,4)) as float32 torch tensors: the inverse of save_gaussian_ply (binary little-endian or ascii, float
+    properties)."""
+    import numpy as np
+    with open(path, "rb") as f:
+        raw = f.read()
+    end = raw.index(b"end_header\n") + len(b"end_header\n")
+    lines = raw[:end].decode("ascii").split("\n")
+    if lines[0].strip() != "ply":
+        raise ValueError(f"{path}: not a PLY file")
+    fmt = [l.split()[1] for l in lines if l.startswith("format")][0]
+    n = int([l.split()[2] for l in lines if l.startswith("element vertex")][0])
+    props = [l.split() for l in lines if l.startswith("property")]
+    if any(p[1] not in ("float", "float32") for p in props):
+        raise ValueError(f"{path}: only float32 properties are supported")
+    cols = [p[2] for p in props]
+    if fmt == "binary_little_endian":
+        table = np.frombuffer(raw, dtype="<f4", count=n * len(cols), offset=end).reshape(n, len(cols))
+    elif fmt == "ascii":
+        table = np.array(raw[end:].split(), dtype=np.float32)[:n * len(cols)].reshape(n, len(cols))
+    else:
+        raise ValueError(f"{path}: unsupported PLY format {fmt}")
+    col = {c: i for i, c in enumerate(cols)}
+    pick = lambda prefix: [col[c] for c in sorted((c for c in cols if c.startswith(prefix)), key=lambda c: int(c.rsplit("_", 1)[1]))]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    dc, rest = table[:, pick("f_dc_")], table[:, pick("f_rest_")]
+    return {"columns": cols, "xyz": t(table[:, [col["x"], col["y"], col["z"]]]),
+            "normals": t(table[:, [col["nx"], col["ny"], col["nz"]]]),
+            "features_dc": t(dc.reshape(n, 3, -1)).transpose(1, 2).contiguous(),          # file is channel-major
+            "features_rest": t(rest.reshape(n, 3, -1)).transpose(1, 2).contiguous(),
+            "opacities": t(table[:, [col["opacity"]]]), "scaling": t(table[:, pick("scale_")]),
+            "rotation": t(table[:, pick("rot_")])}

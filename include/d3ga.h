@@ -106,7 +106,12 @@ typedef struct d3ga_raster_params {
     int32_t antialiasing; /* must be 0 (renderer.py:92) */
     int32_t prefiltered;  /* accepted, ignored (renderer.py:90) */
     int32_t debug;        /* !=0: synchronise + check after every kernel (renderer.py:91 passes 0) */
+    /* D8 (models/cage_net.py:139-159, 247-249: opacity = sigmoid(opacities)): 0 = `opacities` holds activated values
+     * (upstream's contract); D3GA_OPACITY_SIGMOID = `opacities` holds LOGITS, the sigmoid is applied on load in
+     * d3ga_raster_preprocess and dL_dopacity of d3ga_raster_preprocess_bwd is the gradient w.r.t. the logit. */
+    int32_t opacity_activation;
 } d3ga_raster_params;
+#define D3GA_OPACITY_SIGMOID 1
 
 /* Byte sizes of the three caller-owned scratch buffers (the analogue of upstream's geomBuffer /
  * binningBuffer / imgBuffer).  d_capacity = capacity in (tile,Gaussian) duplicates of the binning lists.

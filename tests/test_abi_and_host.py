@@ -175,3 +175,45 @@ def test_checkpoint_layout_round_trip(tmp_path):
     assert torch.equal(m2.output.bias, m.output.bias)
     assert ck.load_checkpoint(run, m2, iteration=20000) == 20000
     assert torch.allclose(m2.output.bias + 1.0, m.output.bias)
+
+
+def test_camera_cache_keeps_matrices_not_metadata():
+    """batch_to_camera caches the device matrices of (R, T, FoV) only: ids, names and the image size come from the
+    CURRENT batch (lib/cameras.py:14-26 builds a fresh Camera per call)."""
+    from d3ga_amd import synthetic as syn
+    from d3ga_amd.cameras import batch_to_camera
+    b1 = syn.make_batch(64, 48, azimuth=0.3, frame_id=7, camera_id=2)
+    b2 = dict(b1, frame_id=9, camera_id=5, width=128, height=96)
+    c1 = batch_to_camera(b1, device="cpu")
+    c2 = batch_to_camera(b2, device="cpu")
+    assert c1.matrices.data_ptr() == c2.matrices.data_ptr()                  # one upload for the same (R, T, FoV)
+    assert (c1.uid, c1.colmap_id, c1.image_width, c1.image_height) == (7, 2, 64, 48)
+    assert (c2.uid, c2.colmap_id, c2.image_width, c2.image_height) == (9, 5, 128, 96)
+    assert c2.image_name == "9_5"
+
+
+def test_ply_export_matches_the_reference_and_round_trips(tmp_path):
+    """SURVEY sec. 8f-4.  Column list and the five blocks against the reference's own CageNet.describe_ply / get_ply
+    (tests/golden/ply_case.npz, tools/gen_golden.py G7); the file written from them reads back bit-identically."""
+    import numpy as np
+    import torch
+    from d3ga_amd.tetra import gaussian_ply_arrays, gaussian_ply_columns, load_gaussian_ply, save_gaussian_ply
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ply_case.npz"))
+    T = lambda k: torch.from_numpy(g[k])
+    cols = gaussian_ply_columns(T("features_dc"), T("features_rest"), T("scaling"), T("rotation"))
+    assert cols == [str(c) for c in g["columns"]]
+    blocks = gaussian_ply_arrays(T("features_dc"), T("features_rest"), T("opacities"), T("scaling"), T("rotation"))
+    for mine, key in zip(blocks, ("f_dc", "f_rest", "opacity", "scale", "rot")):
+        np.testing.assert_array_equal(mine, g[key])
+    xyz = torch.randn(g["opacities"].shape[0], 3, generator=torch.Generator().manual_seed(3))
+    path = str(tmp_path / "avatar.ply")
+    written = save_gaussian_ply(path, xyz, T("features_dc"), T("features_rest"), T("opacities"), T("scaling"), T("rotation"))
+    assert written == cols
+    head = open(path, "rb").read(400).decode("ascii", "ignore")
+    assert head.startswith("ply\nformat binary_little_endian 1.0\nelement vertex 37\nproperty float x\n")
+    back = load_gaussian_ply(path)
+    assert back["columns"] == cols
+    for key, ref in (("xyz", xyz), ("features_dc", T("features_dc")), ("features_rest", T("features_rest")),
+                     ("opacities", T("opacities")), ("scaling", T("scaling")), ("rotation", T("rotation"))):
+        assert torch.equal(back[key], ref), key
+    assert float(back["normals"].abs().max()) == 0.0

@@ -654,6 +654,72 @@ def test_fused_l1_loss_matches_torch():
         assert torch.allclose(a.grad, gref, atol=1e-12)
 
 
+def test_fused_sigmoid_opacity_matches_the_separate_activation():
+    """SURVEY sec. 8a D8 (models/cage_net.py:247 opacity = sigmoid(opacities)): with opacity_activation="sigmoid" the logits
+    go straight into the rasterizer; image identical to sigmoid-then-rasterize up to the 1-ulp difference between
+    torch.sigmoid and 1/(1+expf(-x)), gradient w.r.t. the logits = the chain rule through torch.sigmoid, and the oracle
+    (fed the activated values) agrees under the strict bars."""
+    from d3ga_amd.rasterizer import GaussianRasterizer
+    from d3ga_amd.renderer import render
+    inp = scene_inputs("T1", scale_mult=3.0)
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    logits = torch.logit(inp["opacities"].clamp(1e-4, 1 - 1e-4))
+    gpix = torch.randn(3, inp["H"], inp["W"], generator=torch.Generator().manual_seed(6))
+    means, cov, sh = (_cu(inp[k], True) for k in ("means3D", "cov6", "shs"))
+    lg_a, lg_b = _cu(logits, True), _cu(logits, True)
+    st = _settings(inp, bg, 3)
+    fused, _, _ = GaussianRasterizer(st, opacity_activation="sigmoid")(means3D=means, means2D=None, opacities=lg_a, shs=sh,
+                                                                       cov3D_precomp=cov)
+    (fused * gpix.to(DEV)).sum().backward()
+    g_means_fused = means.grad.clone(); means.grad = None; sh.grad = None; cov.grad = None
+    act = torch.sigmoid(lg_b)
+    plain, _, _ = GaussianRasterizer(st)(means3D=means, means2D=None, opacities=act, shs=sh, cov3D_precomp=cov)
+    (plain * gpix.to(DEV)).sum().backward()
+    inp_o = dict(inp, opacities=torch.sigmoid(logits))
+    ocolor, _, _, ctx, og = _oracle(inp_o, bg, gpix, 3)
+    par = Parity(ctx)
+    _assert_image(par, _np(fused), ocolor)
+    _assert_image(par, _np(plain), ocolor)
+    s = torch.sigmoid(logits).double().numpy()
+    _assert_grads(par, ((lg_a.grad, og["opacities"].astype(np.float64) * s * (1 - s), "opacity_logits"),
+                        (g_means_fused, og["means3D"], "means3D")))
+    assert rel_err(_np(lg_a.grad), _np(lg_b.grad)) < 1e-5
+    # and through render(): a package carrying `opacity_logits` instead of `opacities`
+    out = render(inp["batch"], {"means3D": means.detach(), "cov3D_precomp": cov.detach(), "opacity_logits": lg_a.detach(),
+                                "shs": sh.detach(), "rgb": None, "sh_degree": 3}, bg.to(DEV))["render"]
+    from oracle.camera import paste
+    assert torch.equal(out, paste(fused.detach(), inp["batch"]["crop"]))
+
+
+def test_losses_accept_misaligned_views():
+    """A contiguous VIEW with a storage offset that is not a multiple of 16 bytes (imgs[1] of a batch with odd H*W, x[1:])
+    is a valid input of the reference's l1_loss / ssim; the vectorised kernels want 16-byte alignment, so the wrapper
+    copies such a view instead of failing with D3GA_E_CONFIG."""
+    from d3ga_amd.losses import l1_loss, ssim
+    g = torch.Generator().manual_seed(31)
+    batch = torch.rand(2, 3, 37, 53, generator=g).to(DEV)                 # 3*37*53 floats per image: odd
+    a, b = batch[1].clone().requires_grad_(True), batch[0]
+    view = batch[1]
+    assert view.data_ptr() % 16 != 0 and view.is_contiguous()
+    a2 = view.detach().requires_grad_(True)
+    ref = l1_loss(a, b); ref.backward()
+    got = l1_loss(a2, b); got.backward()
+    assert float(ref) == float(got) and torch.equal(a.grad, a2.grad)
+    flat = torch.rand(1001, generator=g).to(DEV)
+    assert abs(float(l1_loss(flat[1:], flat[:-1])) - float((flat[1:] - flat[:-1]).abs().mean())) < 1e-6
+    assert abs(float(ssim(view, b)) - float(ssim(batch[1].clone(), b))) < 1e-7
+
+
+def test_wrong_device_is_refused():
+    """Launches go to the CURRENT device's stream: a tensor on another device must raise, not race (single-GPU box: the
+    check is exercised through its message for a fake index)."""
+    from d3ga_amd import _lib
+    t = torch.zeros(4, device=DEV)
+    _lib.require_cuda(t)
+    with pytest.raises(_lib.D3GAError):
+        _lib.require_cuda(torch.zeros(4))
+
+
 def test_screen_filling_splats_exceed_the_lds_tile_window():
     """600 Gaussians, each covering most of a 1600x900 image (5700 tiles > the 4096-tile LDS window): the histogram
     and scatter kernels take their global-atomic fallback; lists and image must still match the oracle."""
@@ -935,7 +1001,7 @@ def test_geometry_reuse_between_rgb_and_silhouette_pass():
         fresh, _, _ = rast(means3D=means.clone(), means2D=z(), opacities=op, colors_precomp=sil, cov3D_precomp=cov)
         assert torch.equal(moved, fresh)
     finally:
-        R.set_geometry_reuse(True)
+        R.set_geometry_reuse(False)                      # the library's default: reuse is opt-in
         R.clear_geometry_cache()
 
 

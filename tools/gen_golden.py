@@ -14,6 +14,7 @@ called as they are:
   G4 boundary renderer.render up to the rasterizer call (recording stub)   -> boundary_cases.npz
   G5 SH       utils.sh_utils constants                                     -> sh_consts.npz
   G6 lbs      lib.smplman.Smplman.deform (unbound)                         -> lbs_case.npz
+  G7 ply      models.cage_net.CageNet.describe_ply / get_ply (unbound)     -> ply_case.npz
 The only stand-in with numerical content is ``Tetra.gradient`` (un-vendored tetra_sampler): it is
 written here as the column-edge matrix of lib/tet_mesh.py:88-94 (the reference's in-tree analogue).
 """
@@ -473,6 +474,21 @@ def gen_fields(mlp_mod):
     np.savez(os.path.join(OUT, "field_cases.npz"), **out)
 
 
+def gen_ply(cn):
+    """G7: CageNet.describe_ply / get_ply (models/cage_net.py:111-132), called unbound on a stand-in carrying the five
+    parameter tensors -> the column names and the five blocks of the 3DGS-style export."""
+    g = torch.Generator().manual_seed(23)
+    P = 37
+    self = SimpleNamespace(features_dc=torch.randn(P, 1, 3, generator=g), features_rest=torch.randn(P, 15, 3, generator=g),
+                           opacities=torch.randn(P, 1, generator=g), scaling=torch.randn(P, 3, generator=g),
+                           rotation=torch.randn(P, 4, generator=g))
+    cols = cn.CageNet.describe_ply(self)
+    f_dc, f_rest, op, sc, rot = cn.CageNet.get_ply(self)
+    np.savez(os.path.join(OUT, "ply_case.npz"), columns=np.array(cols), features_dc=self.features_dc.numpy(),
+             features_rest=self.features_rest.numpy(), opacities=self.opacities.numpy(), scaling=self.scaling.numpy(),
+             rotation=self.rotation.numpy(), f_dc=f_dc, f_rest=f_rest, opacity=op, scale=sc, rot=rot)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_harness()
@@ -484,6 +500,10 @@ def main():
     import renderer
     import lib.smplman as smplman_mod
 
+    if sys.argv[1:] == ["ply"]:                 # one section only (the other fixtures are left untouched)
+        gen_ply(cn)
+        return
+    gen_ply(cn)
     gen_camera(cameras_mod)
     gen_cov(gu)
     gen_deform(cn, CageBase, "deform_case0", n_cell=3, P=257, seed=17, dtype=torch.float32, use_shs=True)
