@@ -70,6 +70,41 @@ class Camera:
         return torch.from_numpy(Camera.pack_host(R, T, FoVx, FoVy)).to(torch.device(device))     # one H2D copy
 
 
+class CameraSlot:
+    """A camera whose numbers live in ONE static device buffer, so that a step captured in a hipGraph can be replayed with a
+    different camera every time (the reference trains on one random camera per step, datasets/actorshq_dataset.py:229,
+    models/trainer.py:91-110).  Layout (53 float32): view (16) | projection (16) | full projection (16) | centre (3) |
+    tan(FoVx/2) | tan(FoVy/2).  The two tangents are read by the kernels FROM THE BUFFER (the settings carry tanfovx = 0 as
+    the marker, include/d3ga.h), so only the raster size is fixed per slot -- use one slot / one captured step per
+    resolution.  `set(batch)` stages the numbers in pinned memory and enqueues one asynchronous H2D copy on the current
+    stream; put `batch["camera_slot"] = slot` into the batch handed to `render()`."""
+
+    def __init__(self, width, height, device="cuda"):
+        self.image_width, self.image_height = int(width), int(height)
+        dev = torch.device(device)
+        self.matrices = torch.zeros(53, dtype=torch.float32, device=dev)
+        self._stage = torch.zeros(53, dtype=torch.float32)
+        if dev.type == "cuda":
+            self._stage = self._stage.pin_memory()
+        self.world_view_transform = self.matrices[0:16].view(4, 4)
+        self.projection_matrix = self.matrices[16:32].view(4, 4)
+        self.full_proj_transform = self.matrices[32:48].view(4, 4)
+        self.camera_center = self.matrices[48:53]              # 3 used as the centre; [3], [4] = the tangents
+        self.tanfovx = self.tanfovy = 0.0                      # marker: read them from the buffer
+        self.znear, self.zfar = ZNEAR, ZFAR
+
+    def set(self, batch):
+        if int(batch["width"]) != self.image_width or int(batch["height"]) != self.image_height:
+            raise ValueError(f"CameraSlot is {self.image_width}x{self.image_height}; the batch is "
+                             f"{batch['width']}x{batch['height']} (one slot / captured step per raster size)")
+        host = Camera.pack_host(batch["R"], batch["T"], batch["FoVx"], batch["FoVy"])
+        self._stage[:51] = torch.from_numpy(host)
+        self._stage[51] = math.tan(float(batch["FoVx"]) * 0.5)
+        self._stage[52] = math.tan(float(batch["FoVy"]) * 0.5)
+        self.matrices.copy_(self._stage, non_blocking=True)
+        return self
+
+
 _cache = OrderedDict()
 _CACHE_MAX = 512
 

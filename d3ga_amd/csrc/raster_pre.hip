@@ -80,6 +80,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, const float *__restrict__ viewmatrix,
     const float *__restrict__ projmatrix, const float *__restrict__ campos, GeomBuf geom,
     uint32_t *__restrict__ tile_count, uint32_t *__restrict__ counters, int32_t *__restrict__ radii) {
+    if (!(prm.tanfovx > 0.f)) { prm.tanfovx = campos[3]; prm.tanfovy = campos[4]; }     // camera slot: see d3ga.h
     // one dynamic LDS region, used first as the SH staging slabs and then (after a barrier) as the tile window
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_box[4];
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const float *__restrict__ acc, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
     float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors,
     float *__restrict__ dL_dcov3D, float *__restrict__ dL_dscales, float *__restrict__ dL_drots) {
+    if (!(prm.tanfovx > 0.f)) { prm.tanfovx = campos[3]; prm.tanfovy = campos[4]; }     // camera slot: see d3ga.h
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_sh = reinterpret_cast<float *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -1,0 +1,59 @@
+"""A training step captured once in a hipGraph and replayed with new inputs every step.
+
+The step of this path is ~45 small launches; issued eagerly from Python it is host-bound (~0.75 ms of enqueue work against
+0.6 ms of GPU work at 500k Gaussians, and 2x host-bound at the reference's own 135k-Gaussian size).  A captured graph removes
+the per-launch host cost -- but the reference draws a NEW camera (and target image, and pose) every step
+(datasets/actorshq_dataset.py:229, models/trainer.py:91-110), so whatever changes from step to step has to live in STATIC
+device buffers ("slots") that the captured kernels read:
+
+    slot = CameraSlot(W, H)                       # cameras.py: matrices + tan(FoV/2) in one device buffer
+    target = torch.empty(3, H, W, device="cuda")  # any tensor the step reads can be a slot
+    batch["camera_slot"] = slot
+    step = CapturedStep(lambda: train_step(batch, target), params=model.parameters(), slots={"target": target}, camera=slot)
+    for frame in loader:
+        step.replay(camera=frame, target=frame["image"])      # two async copies + one graph launch
+
+Constraints (hipGraph): fixed shapes, fixed raster size (grid dimensions are baked), the binning capacity must be static
+(`rasterizer.set_capacity_policy("static", n)`, check `last_counters()["overflow"]` now and then), no host synchronisation
+inside `step_fn`.  Gradients land in the same static `.grad` tensors on every replay.
+"""
+import torch
+
+
+class CapturedStep:
+    def __init__(self, step_fn, params=(), slots=None, camera=None, warmup=2):
+        """step_fn(): the whole step (forward, loss, backward[, optimizer]) reading its per-step inputs from `slots`
+        (name -> static device tensor) and, for the camera, from `camera` (a cameras.CameraSlot placed in the batch).
+        params: the leaves whose `.grad` the step produces -- their gradients are dropped between the warm-up steps and the
+        capture, so that the captured backward WRITES fresh static gradient tensors instead of accumulating into the
+        warm-up's (every replay then leaves exactly this step's gradients in `p.grad`)."""
+        self.slots = dict(slots or {})
+        self.camera = camera
+        self.step_fn = step_fn
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # allocator warm-up on a capture-capable stream
+            for _ in range(max(int(warmup), 1)):
+                step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for p in params:
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.result = step_fn()
+        torch.cuda.synchronize()
+
+    def replay(self, camera=None, **values):
+        """camera: a batch dict (R, T, FoVx, FoVy, width, height) written into the CameraSlot; values: name -> tensor / array
+        copied into the slot of that name.  Everything is enqueued on the current stream; returns what step_fn returned at
+        capture time (static tensors holding this replay's results once the stream reaches them)."""
+        if camera is not None:
+            if self.camera is None:
+                raise ValueError("this step was captured without a CameraSlot")
+            self.camera.set(camera)
+        for name, v in values.items():
+            slot = self.slots[name]
+            slot.copy_(v if torch.is_tensor(v) else torch.as_tensor(v), non_blocking=True)
+        self.graph.replay()
+        return self.result

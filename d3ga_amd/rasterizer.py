@@ -340,7 +340,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 dptr(g_cov), dptr(g_scales), dptr(g_rots), stream_handle()), "d3ga_raster_backward")
         if sync is not None:
             if factor is not None:
-                factor[P].copy_(campos.reshape(3))
+                factor[P].copy_(campos.reshape(-1)[:3])
             gathered = sync.exchange(flat, factor)         # flat: summed (averaged) in place; gathered: (world, P+1, 3)
             if factor is not None:
                 g_sh = new(P, prm.M, 3)

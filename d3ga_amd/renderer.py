@@ -46,7 +46,9 @@ def render_pair(batch, pkg, bg_color, colors2, bg_color2, grad_sync=None):
 def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_bg=True, fast=False, detach=[],
            grad_sync=None, _pair=None):
     means3D = pkg["means3D"]
-    cam = batch_to_camera(batch, device=means3D.device)
+    # a cameras.CameraSlot in the batch: the camera is read from its static device buffer (graph-capturable step that
+    # follows the trainer's camera-per-step, d3ga_amd/graph.py)
+    cam = batch.get("camera_slot") or batch_to_camera(batch, device=means3D.device)
     crop = batch["crop"]
 
     settings = GaussianRasterizationSettings(

@@ -101,7 +101,9 @@ typedef struct d3ga_raster_params {
     int32_t M;           /* SH coefficients per Gaussian in `shs` (stride), 0 if colors_precomp */
     int32_t sh_degree;   /* active degree 0..3 */
     int32_t W, H;        /* raster size (renderer.py:80-81) */
-    float tanfovx, tanfovy;
+    float tanfovx, tanfovy; /* tan(FoV/2) (renderer.py:76-77).  tanfovx <= 0: CAMERA SLOT -- the kernels read both from device
+                             * memory, campos[3] and campos[4] (campos is then 5 floats), so that a captured hipGraph can be
+                             * replayed with another camera by rewriting one device buffer (d3ga_amd/cameras.py:CameraSlot) */
     float scale_modifier;
     int32_t antialiasing; /* must be 0 (renderer.py:92) */
     int32_t prefiltered;  /* accepted, ignored (renderer.py:90) */

@@ -654,6 +654,70 @@ def test_fused_l1_loss_matches_torch():
         assert torch.allclose(a.grad, gref, atol=1e-12)
 
 
+def test_captured_step_follows_the_camera_of_every_replay():
+    """d3ga_amd.graph.CapturedStep + cameras.CameraSlot: ONE captured hipGraph of the whole step (deform -> render -> L1 ->
+    backward), replayed with camera k and target k written into static slots, equals the eager step with camera k -- for 8
+    cameras of different azimuth AND different field of view, at the actor02-shaped size (C4: 135k Gaussians).  The
+    reference draws a new camera every step (datasets/actorshq_dataset.py:229, models/trainer.py:91-110)."""
+    import math
+    from d3ga_amd import rasterizer as R
+    from d3ga_amd import synthetic as syn
+    from d3ga_amd.cage_deform import cage_deform
+    from d3ga_amd.cameras import CameraSlot
+    from d3ga_amd.graph import CapturedStep
+    from d3ga_amd.losses import l1_loss
+    from d3ga_amd.renderer import render
+    inp = scene_inputs("C4")
+    sc = inp["scene"]
+    W, H = inp["W"], inp["H"]
+    tp, sh, lg = _cu(inp["tetpoints"], True), _cu(inp["shs"], True), _cu(torch.logit(inp["opacities"].clamp(1e-4, 1 - 1e-4)), True)
+    consts = [sc["tetras"].to(DEV), sc["tetra_id"].to(DEV), sc["barys"].to(DEV), inp["canon_grad"].to(DEV),
+              inp["scales"].to(DEV), sc["rotation"].to(DEV)]
+    bg = torch.ones(3, device=DEV)
+    views = []
+    for k in range(8):
+        b = syn.make_batch(W, H, azimuth=2 * math.pi * k / 8, dist=3.0 + 0.1 * k, fill=0.85 - 0.03 * k)    # FoV differs per view
+        assert (b["width"], b["height"]) == (W, H)
+        views.append((b, torch.rand(3, H, W, generator=torch.Generator().manual_seed(40 + k)).to(DEV)))
+    assert len({round(v[0]["FoVx"], 6) for v in views}) == 8
+    params = (tp, sh, lg)
+
+    def step(batch, target):
+        means, cov6 = cage_deform(tp, consts[0], consts[1], consts[2], consts[3], consts[4], consts[5])
+        img = render(batch, {"means3D": means, "cov3D_precomp": cov6, "opacity_logits": lg, "shs": sh, "rgb": None,
+                             "sh_degree": 3}, bg)["render"]
+        loss = l1_loss(img, target)
+        loss.backward()
+        return img.detach(), loss.detach()
+
+    eager, dmax = [], 0
+    for b, t in views:
+        for p in params:
+            p.grad = None
+        img, loss = step(b, t)
+        eager.append((img.clone(), float(loss), [p.grad.clone() for p in params]))
+        dmax = max(dmax, R.last_counters()["D"])
+    R.set_capacity_policy("static", int(1.25 * dmax) + 4096)
+    try:
+        slot = CameraSlot(W, H, device=DEV).set(views[0][0])
+        target = views[0][1].clone()
+        slot_batch = dict(views[0][0], camera_slot=slot)
+        for p in params:
+            p.grad = None
+        cap = CapturedStep(lambda: step(slot_batch, target), params=params, slots={"target": target}, camera=slot)
+        for k in (3, 0, 7, 5, 1, 2, 6, 4, 3):                       # any order, a repeat included
+            img_g, loss_g = cap.replay(camera=views[k][0], target=views[k][1])
+            torch.cuda.synchronize()
+            assert not R.last_counters()["overflow"]
+            img_e, loss_e, grads_e = eager[k]
+            assert torch.equal(img_g, img_e), k                        # same kernels, same inputs: bit-identical image
+            assert abs(float(loss_g) - loss_e) <= 1e-6 * abs(loss_e) + 1e-9
+            for p, ge in zip(params, grads_e):
+                assert rel_err(_np(p.grad), _np(ge)) < 1e-5, k         # float atomics: order-dependent rounding only
+    finally:
+        R.set_capacity_policy("auto")
+
+
 def test_fused_sigmoid_opacity_matches_the_separate_activation():
     """SURVEY sec. 8a D8 (models/cage_net.py:247 opacity = sigmoid(opacities)): with opacity_activation="sigmoid" the logits
     go straight into the rasterizer; image identical to sigmoid-then-rasterize up to the 1-ulp difference between
