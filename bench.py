@@ -50,13 +50,25 @@ def parse():
                          "backward at the workload's Gaussian count, roofline against the f32 MFMA peak")
     ap.add_argument("--no-graph", action="store_true",
                     help="time eager launches instead of replaying the captured hipGraph of one step")
+    ap.add_argument("--graph-collectives", action="store_true",
+                    help="N>1: capture the step INCLUDING the gradient exchange (RCCL collectives) in the hipGraph")
+    ap.add_argument("--fixed-camera", action="store_true",
+                    help="N=1: replay the captured step with ONE camera / target (round-1 behaviour) instead of writing a new "
+                         "camera and target into the step's slots before every replay")
+    ap.add_argument("--scale-mult", type=float, default=1.0,
+                    help="sensitivity: multiply the Gaussians' world-space scales (D/P grows ~quadratically)")
+    ap.add_argument("--fill", type=float, default=0.85,
+                    help="sensitivity: fraction of the image height the 1.8 m body fills (0.85 = SURVEY sec. 8d recipe)")
+    ap.add_argument("--pmc", action="store_true",
+                    help="collect the HBM / SQ counters of the compositing kernels with rocprofv3 (separate --pmc passes of this "
+                         "same command, MI355X_MICROARCH.md) into profiles/pmc_<workload>.json, then run normally")
     return ap.parse_args()
 
 
 class Frame:
     """Avatar parameters + one camera, resident on the device."""
 
-    def __init__(self, wl_name, dev, view_index, n_views=8):
+    def __init__(self, wl_name, dev, view_index, n_views=8, scale_mult=1.0, fill=0.85):
         from d3ga_amd import synthetic as syn
         from d3ga_amd.cage_deform import canonical_gradient
         self.syn = syn
@@ -72,19 +84,37 @@ class Frame:
         self.params = {
             "delta_node": par(sc["delta_node"]),
             "delta_bary": torch.zeros(P, 4, device=dev, requires_grad=True),
-            "scaling": par(sc["scaling"]),
+            "scaling": par(sc["scaling"] + math.log(scale_mult)),
             "rotation": par(sc["rotation"]),
             "opacity": par(sc["opacity_logit"]),
             # one contiguous SH buffer (features_dc | features_rest), instead of torch.cat per frame (cage_net.py:155-159)
             "features": par(torch.cat([sc["features_dc"], sc["features_rest"]], 1)),
         }
+        self.n_views, self.fill, self.dev = n_views, fill, dev
         self.batch = syn.make_batch(self.wl.width, self.wl.height, azimuth=2 * math.pi * view_index / n_views,
-                                    camera_id=view_index)
+                                    camera_id=view_index, fill=fill)
         self.bg = torch.ones(3, device=dev)
         g = torch.Generator().manual_seed(100 + view_index)
         self.target = torch.rand(3, self.wl.height, self.wl.width, generator=g).to(dev)
+        self.views = None              # camera_cycle(): the n_views cameras + targets a trainer would draw from
         self.sh_degree = self.wl.sh_degree
         self.grad_sync = None          # d3ga_amd.dist.ViewShardedGrads when the views are sharded over ranks
+
+    def camera_cycle(self):
+        """The reference draws a new camera (and its ground-truth image) every step (datasets/actorshq_dataset.py:229): keep
+        the n_views cameras of this pose and their targets resident, put a CameraSlot into the batch and make `target` a
+        static buffer -- a captured step is then replayed with `graph.replay(camera=..., target=...)`."""
+        from d3ga_amd.cameras import CameraSlot
+        W, H = self.batch["width"], self.batch["height"]
+        self.views = []
+        for v in range(self.n_views):
+            b = self.syn.make_batch(self.wl.width, self.wl.height, azimuth=2 * math.pi * v / self.n_views, camera_id=v, fill=self.fill)
+            g = torch.Generator().manual_seed(100 + v)
+            self.views.append((b, torch.rand(3, self.wl.height, self.wl.width, generator=g).to(self.dev)))
+        self.slot = CameraSlot(W, H, device=self.dev).set(self.batch)
+        self.batch = dict(self.batch, camera_slot=self.slot)
+        self.target = self.target.clone()
+        return self.views
 
     def step(self):
         from d3ga_amd.cage_deform import cage_deform, lbs_cage
@@ -175,6 +205,66 @@ class Frame:
         return loss
 
 
+def collect_pmc(args):
+    """bench.py --pmc: the HBM / SQ counters of every d3ga kernel of THIS workload, collected with rocprofv3 in separate
+    --pmc passes of this same command (FETCH_SIZE and WRITE_SIZE cannot share a pass; counters perturb timing, so the
+    passes only count) and written to profiles/pmc_<workload>.json, where the normal run below picks them up."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    passes = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"], "grbm": ["GRBM_GUI_ACTIVE"],
+              "sq": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY",
+                     "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"],
+              "lds": ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY",
+                      "SQ_ACTIVE_INST_ANY"]}
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for name, counters in passes.items():
+        d = tempfile.mkdtemp(prefix=f"d3ga_pmc_{name}_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--kernel-include-regex", "d3ga", "--output-format", "csv",
+               "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "5",
+               "--warmup", "3", "--no-cpu-baseline", "--no-train-step", "--no-stage-events", "--no-graph", "--fixed-camera",
+               "--scale-mult", str(args.scale_mult), "--fill", str(args.fill)]
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+        files = glob.glob(os.path.join(d, "**", "pmc_counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            print(f"[bench --pmc] pass {name} failed: rc {r.returncode} {r.stderr[-300:]}", file=sys.stderr)
+            shutil.rmtree(d, ignore_errors=True)
+            continue
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for row in csv.DictReader(open(files[0])):
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for k, v in acc.items():
+            out.setdefault(k, {}).update({c: round(sum(x) / len(x), 1) for c, x in v.items()})
+        shutil.rmtree(d, ignore_errors=True)
+    if out:
+        os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+        suffix = "" if (args.scale_mult == 1.0 and args.fill == 0.85) else f"_s{args.scale_mult:g}_f{args.fill:g}"
+        json.dump(out, open(os.path.join(ROOT, "profiles", f"pmc_{args.workload}{suffix}.json"), "w"), indent=1)
+    return out
+
+
+def valu_issue_model():
+    """Calibrated VALU issue costs (tools/micro/valu_issue.hip -> profiles/r02_valu_issue_pmc.json, cycles per wave-instruction
+    per SIMD at 8 waves/SIMD) and the static instruction mix of the compositing backward's loop (tools/isa_mix.py ->
+    profiles/r02_composite_bwd_mix.json).  Returns (average cycles per VALU instruction of that kernel, dict) or (None, None)."""
+    try:
+        cal = {(r["kind"], r["waves_per_simd"]): r for r in json.load(open(os.path.join(ROOT, "profiles", "r02_valu_issue_pmc.json")))}
+        cyc = lambda kind: cal[(kind, 8)]["cycles_per_wave_inst_per_simd"]
+        cost = {"plain": cyc("v_fma_f32"), "dpp": cyc("v_add_f32_dpp"), "trans": cyc("v_exp_f32"), "packed": cyc("v_pk_fma_f32")}
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r02_composite_bwd_mix.json")))
+        cost["vop3_other"] = mix.get("vop3_other_cycles", 1.6 * cost["plain"])
+        n = sum(mix["counts"].values())
+        avg = sum(mix["counts"][k] * cost[k] for k in mix["counts"]) / n
+        return avg, {"cycles_per_class": {k: round(v, 2) for k, v in cost.items()}, "mix": mix["counts"]}
+    except Exception:
+        return None, None
+
+
 def measured_copy_gbs(dev, nbytes=1 << 30, reps=10):
     """Device-to-device copy rate (read + write bytes / time): the practical HBM ceiling quoted beside the 8 TB/s peak."""
     a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
@@ -228,14 +318,17 @@ def deform_gpu_comparison(frame, reps=50):
     return res
 
 
-def cpu_baseline(wl_name, budget_s=20.0):
+def cpu_baseline(wl_name, budget_s=20.0, threads=None):
     """The oracle (CPU port of the path) on this box's host cores: torch deform fwd+bwd + C rasterizer fwd+bwd."""
     from d3ga_amd import synthetic as syn
     from oracle import camera as oc
     from oracle import deform as od
     from oracle import raster_c as rc
-    # threads actually used: capped -- on a 256-thread host torch's intra-op pool and libgomp oversubscribe badly
-    cores = min(os.cpu_count() or 1, 32)
+    # threads actually used.  All hardware threads of the box are tried as well (budget split): on a 256-thread host torch's
+    # intra-op pool and libgomp oversubscribe badly, so `value` / `cores` report the FASTER of the two settings and
+    # `host_threads` / `all_threads_frames_per_s` state the other
+    host_threads = os.cpu_count() or 1
+    cores = min(host_threads, 32) if threads is None else threads
     torch.set_num_threads(cores)
     rc.set_threads(cores)
     sc = syn.make_scene(wl_name)
@@ -272,6 +365,20 @@ def cpu_baseline(wl_name, budget_s=20.0):
         if el > budget_s or (el > 10.0 and len(times) >= 5) or len(times) >= 60:
             break
     best = min(times)
+    if threads is None and host_threads > cores:
+        try:
+            alt = cpu_baseline(wl_name, budget_s=budget_s / 2, threads=host_threads)
+        except Exception:  # noqa: BLE001
+            alt = None
+        mine = {"value": round(1.0 / best, 4), "cores": cores, "frames": len(times), "deform": round(1.0 / min(deform_times), 3)}
+        other = None if alt is None else {"value": alt["value"], "cores": host_threads, "frames": None,
+                                          "deform": alt["deform_only_frames_per_s"]}
+        win = mine if other is None or mine["value"] >= other["value"] else other
+        return {"value": win["value"], "unit": "frames/s", "cores": win["cores"], "kind": "port", "host_threads": host_threads,
+                "frames_per_s_by_threads": {str(cores): mine["value"], **({str(host_threads): other["value"]} if other else {})},
+                "sample": f"{len(times)} full frames of {wl.name} at {cores} threads (+ a second sample at all {host_threads} hardware "
+                          "threads) -- oracle: torch CPU deform fwd+bwd + OpenMP C rasterizer fwd+bwd, best frame; the faster setting is `value`",
+                "deform_only_frames_per_s": win["deform"]}
     return {"value": round(1.0 / best, 4), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} full frames of {wl.name} (oracle: torch CPU deform fwd+bwd + OpenMP C rasterizer fwd+bwd), best of {len(times)}",
             "deform_only_frames_per_s": round(1.0 / min(deform_times), 3)}
@@ -374,17 +481,33 @@ def main():
     d3ga_amd.lib()
     from d3ga_amd import rasterizer as R
 
-    frame = Frame(args.workload, dev, view_index=rank % 8)
+    if args.pmc and world == 1:
+        collect_pmc(args)
+    frame = Frame(args.workload, dev, view_index=rank % 8, scale_mult=args.scale_mult, fill=args.fill)
     flat = ddist.GradReducer(list(frame.params.values()))
     cut = world > 1 and args.reduce == "cut"
     if cut:
-        frame.grad_sync = ddist.ViewShardedGrads()        # gradients leave the rasterizer already averaged over the ranks
+        frame.grad_sync = ddist.ViewShardedGrads(timing=True)   # gradients leave the rasterizer already averaged over the ranks
+    # N = 1: the step follows the trainer -- a NEW camera and target every step (datasets/actorshq_dataset.py:229), written
+    # into the static slots of ONE captured hipGraph (d3ga_amd/graph.py).  N > 1: every rank keeps its own view (camera
+    # sharding: the views of one pose are spread over the ranks).
+    cycle = world == 1 and not args.fixed_camera
+    views = frame.camera_cycle() if cycle else None
+
+    def set_view(i):
+        if cycle:
+            b, t = views[i % len(views)]
+            frame.slot.set(b)
+            frame.target.copy_(t, non_blocking=True)
 
     def reduce_params():
         if not cut and world > 1:
             flat.all_reduce_mean()
 
+    step_no = [0]
+
     def one_step():
+        set_view(step_no[0]); step_no[0] += 1
         flat.zero()
         frame.step()
         reduce_params()
@@ -394,7 +517,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # warm-up (auto capacity: learns the duplicate count), then freeze the capacity: no host sync inside a frame
+    # warm-up (auto capacity: learns the duplicate count of every view), then freeze the capacity: no host sync inside a frame
     exchange_note = None
     if cut:
         try:                                   # first exchange: if the backend rejects a collective of the cut exchange,
@@ -405,43 +528,42 @@ def main():
             print(f"[bench] rank {rank}: {exchange_note}", file=sys.stderr)
             cut = False
             frame.grad_sync = None
-    for _ in range(max(args.warmup, 2)):
+    d_max = 0
+    for _ in range(max(args.warmup, 2, len(views) if cycle else 0)):
         one_step()
-    torch.cuda.synchronize()
+        d_max = max(d_max, R.last_counters()["D"])
     cnt = R.last_counters()
-    R.set_capacity_policy("static", int(cnt["D"] * 1.25) + 4096)
+    R.set_capacity_policy("static", int(d_max * 1.25) + 4096)
     one_step()
     torch.cuda.synchronize()
 
-    # The step is launch-bound on the host (~50 small launches): capture ONE whole step -- LBS, deform, rasterizer
-    # forward, loss, the full backward -- into a hipGraph and replay it.  Same kernels, same order, same stream
-    # semantics; only the per-launch host work disappears.  The gradient all-reduce (N > 1) stays outside the graph.
-    # (N > 1 runs eagerly: the cut exchange sits INSIDE the backward, so capturing the step would capture the collectives;
-    # RCCL supports that in principle, but it cannot be exercised on the 1-GPU development box and gloo cannot be captured
-    # at all.  An earlier 2-rank gloo experiment that replayed a captured backward and then reduced its gradients
-    # "corrupted the graph's pool" -- in hindsight most likely the memset-node ordering bug described in DESIGN.md sec. 5,
-    # fixed since.  At C3 the eager host cost is ~0.75 ms per step against ~0.70 ms of GPU work plus the exchange.)
+    # The step is launch-bound on the host (~45 small launches): capture ONE whole step -- LBS, deform, rasterizer forward,
+    # loss, the full backward -- into a hipGraph and replay it with this step's camera / target in its slots.  N > 1 runs
+    # eagerly by default: the cut exchange sits INSIDE the backward, so a captured step contains the collectives;
+    # --graph-collectives captures them too (RCCL supports capture; verified here only on a one-rank group,
+    # tests/test_gpu_view_sharded.py -- the 8-GPU run keeps the conservative default).
     graph = None
-    if not args.no_graph and world == 1:
-        flat.zero()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):                    # allocator warm-up on the capture stream
-                flat.zero()
-                frame.step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        flat.zero()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            frame.step()
-        torch.cuda.synchronize()
+    if not args.no_graph and (world == 1 or args.graph_collectives):
+        from d3ga_amd.graph import CapturedStep
+        try:
+            graph = CapturedStep(frame.step, params=list(frame.params.values()),
+                                 slots={"target": frame.target} if cycle else None, camera=frame.slot if cycle else None)
+        except Exception as e:  # noqa: BLE001
+            if world == 1:
+                raise
+            exchange_note = (exchange_note or "") + f" graph capture of the N>1 step failed ({type(e).__name__}); eager"
+            graph = None
 
     def timed_step():
+        i = step_no[0]; step_no[0] += 1
         if graph is not None:
-            graph.replay()                        # gradients land in the graph's static .grad tensors
+            if cycle:
+                b, t = views[i % len(views)]
+                graph.replay(camera=b, target=t)      # gradients land in the graph's static .grad tensors
+            else:
+                graph.replay()
         else:
+            set_view(i)
             flat.zero()
             frame.step()
         reduce_params()
@@ -499,26 +621,54 @@ def main():
         torch.cuda.synchronize()
         n_ts = max(5, args.steps // 2)
 
-        def timed_train(**kw):
-            """ms per eager training step: median of three runs of n_ts steps (an occasional host stall of tens of ms --
-            Python GC / allocator -- otherwise lands in one run's mean: 3.07 instead of 1.37 ms seen for a single run)."""
-            for _ in range(3):
-                flat.zero()
-                frame.train_step(**kw)
+        def timed_train(captured=False, **kw):
+            """ms per training step (a new camera + target every step): median of three runs of n_ts steps (an occasional host
+            stall of tens of ms -- Python GC / allocator -- otherwise lands in one run's mean).  captured: ONE hipGraph of
+            the step, replayed with the step's camera / target in its slots (d3ga_amd/graph.py)."""
+            cap = None
+            if captured:
+                from d3ga_amd.graph import CapturedStep
+                leaves = list(frame.params.values()) + list(getattr(frame, "field_params", []))
+                leaves += [t for t in (getattr(frame, "color_feat", None), getattr(frame, "frame_enc", None)) if t is not None]
+                for _ in range(2):
+                    flat.zero(); frame.train_step(**kw)
+                leaves = list(frame.params.values()) + list(getattr(frame, "field_params", []))
+                leaves += [t for t in (getattr(frame, "color_feat", None), getattr(frame, "frame_enc", None)) if t is not None]
+                cap = CapturedStep(lambda: frame.train_step(**kw), params=leaves, slots={"target": frame.target} if cycle else None,
+                                   camera=frame.slot if cycle else None)
+
+            def one(i):
+                if cap is not None:
+                    if cycle:
+                        cap.replay(camera=views[i % len(views)][0], target=views[i % len(views)][1])
+                    else:
+                        cap.replay()
+                else:
+                    set_view(i)
+                    flat.zero()
+                    frame.train_step(**kw)
+            for i in range(3):
+                one(i)
             runs = []
             for _ in range(3):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for _ in range(n_ts):
-                    flat.zero()
-                    frame.train_step(**kw)
+                for i in range(n_ts):
+                    one(i)
                 torch.cuda.synchronize()
                 runs.append(1e3 * (time.perf_counter() - t1) / n_ts)
             return round(sorted(runs)[1], 4)
 
         train = {"renders_per_step": 2, "losses": "0.8 L1 + 0.2 (1 - SSIM) on RGB, L1 on the silhouette", "steps": n_ts,
+                 "cameras": "a new camera and target image every step (8 views)" if cycle else "one fixed camera",
                  "launch_mode": "eager", "timing": "median of 3 runs of `steps` steps", "ms_per_step": timed_train()}
         train["steps_per_s"] = round(1e3 / train["ms_per_step"], 2)
+        # the same steps as ONE captured hipGraph each, replayed with the step's camera / target (VERDICT r1 item 4)
+        try:
+            train["captured_ms_per_step"] = timed_train(captured=True)
+            train["captured_render_pair_ms_per_step"] = timed_train(captured=True, pair=True)
+        except Exception as e:  # noqa: BLE001
+            train["captured_error"] = repr(e)
 
         # the same step with both images from one compositing pass (render_pair: an extension, same results)
         train["render_pair_ms_per_step"] = timed_train(pair=True)
@@ -530,8 +680,33 @@ def main():
         train["with_field_and_color_networks_ms_per_step"] = timed_train(with_fields="color")
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist_info = None
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        # compute / exchange split of the N > 1 step: HIP events around every exchange (dist.ViewShardedGrads timing) resp.
+        # around the parameter all-reduce, over a few more steps; nranks_seen = what an all-reduce of ones returns
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        ex_ms = None
+        if cut:
+            frame.grad_sync.exchange_ms()                      # drop what the timed region recorded
+            for _ in range(5):
+                one_step()
+            ex_ms = frame.grad_sync.exchange_ms()
+        else:
+            evs = []
+            for _ in range(5):
+                flat.zero(); frame.step()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); flat.all_reduce_mean(); e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            ex_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        step_ms_all = 1e3 * float(tmax.item()) / args.steps
+        dist_info = {"nranks_seen": int(ones.item()), "exchange_ms": None if ex_ms is None else round(ex_ms, 4),
+                     "compute_ms": None if ex_ms is None else round(step_ms_all - ex_ms, 4),
+                     "note": "exchange_ms: HIP events around the collectives of one step (all-reduce + all-gather in flight "
+                             "together); compute_ms = ms_per_step - exchange_ms (the exchange is not overlapped with compute)"}
     dt = float(tmax.item())
 
     if rank == 0:
@@ -551,7 +726,7 @@ def main():
                        "frac_hbm_peak": round(alg[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                    for k, (n, ms) in stages.items() if k in alg}
         # HBM traffic of the compositing kernels from the committed rocprofv3 --pmc passes of this same command
-        # (tools/gpu_pmc.sh -> profiles/*.json): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH doubled per the gfx950
+        # (bench.py --pmc -> profiles/pmc_<workload>.json): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH doubled per the gfx950
         # correction of MI355X_MICROARCH.md.  None when no PMC summary for this workload is present.
         pmc_traffic, pmc_lds, pmc_valu, pmc_busy = {}, {}, {}, {}
         try:
@@ -559,34 +734,51 @@ def main():
             if os.path.exists(pj):
                 for kname, c in json.load(open(pj)).items():
                     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                        short = re.sub(r"_rows\d*", "", kname.split("::")[-1].split("_kernel")[0])
+                        short = re.sub(r"_(rows\d*|scan)", "", kname.split("::")[-1].split("_kernel")[0])
                         pmc_traffic[short] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
                         if c.get("SQ_LDS_IDX_ACTIVE"):     # LDS bank-conflict cycles / LDS-active cycles
                             pmc_lds[short] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
                         if c.get("SQ_INSTS_VALU"):
                             pmc_valu[short] = int(c["SQ_INSTS_VALU"])
-                        if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_BUSY_CYCLES"):
-                            # share of ALL SIMD cycles of the launch in which a VALU instruction was executing:
-                            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip, SQ_BUSY_CYCLES the launch's
-                            # cycles summed over the 32 shader engines; 256 CUs x 4 SIMDs
-                            pmc_busy[short] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * c["SQ_BUSY_CYCLES"] / 32.0), 4)
         except Exception:
             pmc_traffic = {}
         roof = None
+        pmc_all = {}
+        try:
+            suffix = "" if (args.scale_mult == 1.0 and args.fill == 0.85) else f"_s{args.scale_mult:g}_f{args.fill:g}"
+            pj = os.path.join(ROOT, "profiles", f"pmc_{args.workload}{suffix}.json")
+            if os.path.exists(pj):
+                for kname, c in json.load(open(pj)).items():
+                    short = re.sub(r"_(rows\d*|scan)", "", kname.split("::")[-1].split("_kernel")[0])
+                    pmc_all[short] = c
+        except Exception:
+            pmc_all = {}
         comp = [k for k in ("composite_bwd", "composite_fwd") if k in kernels]
         if comp:
             k = max(comp, key=lambda n: kernels[n]["ms"])
             roof = {"kernel": k, "bound": "hbm", "achieved": kernels[k]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": kernels[k]["frac_hbm_peak"], "traffic": pmc_traffic.get(k),
                     "lds_bank_conflict_per_lds_active": pmc_lds.get(k), "valu_wave_instructions": pmc_valu.get(k),
-                    "valu_busy_frac_of_all_simd_cycles": pmc_busy.get(k),
-                    "alg_bytes_per_launch": alg[k], "avg_ms": kernels[k]["ms"]}
+                    "alg_bytes_per_launch": alg[k], "avg_ms": kernels[k]["ms"],
+                    "traffic_source": ("profiles/pmc_%s.json (bench.py --pmc: separate rocprofv3 --pmc passes of this command; "
+                                       "(2 x FETCH_SIZE + WRITE_SIZE) KiB)" % args.workload) if pmc_traffic.get(k) else None}
+            # VALU issue share, calibrated: wave-instructions x the kernel's average issue cost (static mix
+            # of its loop x the measured cycles of each instruction class) / (1024 SIMDs x launch cycles at the measured clock)
+            c = pmc_all.get(k, {})
+            avg_cyc, model = valu_issue_model()
+            if k == "composite_bwd" and avg_cyc and c.get("SQ_INSTS_VALU") and c.get("GRBM_GUI_ACTIVE"):
+                launch_cycles = c["GRBM_GUI_ACTIVE"] / 8.0               # summed over the 8 XCDs
+                roof["valu_frac"] = round(c["SQ_INSTS_VALU"] * avg_cyc / (1024.0 * launch_cycles), 4)
+                roof["valu_model"] = {"avg_cycles_per_valu_instruction": round(avg_cyc, 3), **model,
+                                      "source": "tools/micro/valu_issue.hip (profiles/r02_valu_issue_pmc.json) x tools/isa_mix.py"}
         out = {
             "metric": "fwd+bwd frames/sec @500k Gaussians 1920x1080" if args.workload == "C3" else f"fwd+bwd frames/sec ({wl.name})",
             "value": round(world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl.name, "gaussians": P, "width": W, "height": H, "sh_degree": wl.sh_degree,
+            "config": {"workload": wl.name + ("" if (args.scale_mult == 1.0 and args.fill == 0.85) else
+                                              f" [sensitivity: scales x{args.scale_mult:g}, body fills {args.fill:g} of the image height]"),
+                       "gaussians": P, "width": W, "height": H, "sh_degree": wl.sh_degree,
                        "duplicates_D": D, "max_tile_list": cnt_end["max_tile"], "visible": cnt_end["visible"],
                        "views_per_step": world, "parallelism": f"camera-sharded dp{world}",
                        "grad_exchange": ("none" if world == 1 else "cut: all-reduce of the rasterizer-input gradients + "
@@ -596,7 +788,10 @@ def main():
             "roofline": roof, "kernels": kernels,
             "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 4),
             "step_ms": step_dist,
-            "launch_mode": "hipGraph replay of one captured step" if graph is not None else "eager",
+            "launch_mode": ("hipGraph replay of ONE captured step; a new camera (matrices + FoV) and target image are written into "
+                            "its static slots before every replay" if graph is not None and cycle else
+                            "hipGraph replay of one captured step" if graph is not None else "eager"),
+            **({"distributed": dist_info} if dist_info else {}),
             **({"grad_exchange_note": exchange_note} if exchange_note else {}),
             "stage_events": "separate eager pass, same K steps" if graph is not None else "none" if args.no_stage_events else "separate eager pass",
         }

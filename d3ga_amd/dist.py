@@ -155,6 +155,7 @@ class ViewShardedGrads:
         self.bytes_last = 0           # payload bytes this rank contributed in the most recent exchange
         self.verify_left = int(verify_steps)
         self.timing = bool(timing)
+        self.always = False           # tests: run the exchange even in a one-rank group (the collectives are then identities)
         self._events = []             # (start, end) event pairs of the exchanges since the last exchange_ms()
 
     def verify_inputs(self, named):

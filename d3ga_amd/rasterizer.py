@@ -259,7 +259,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.prm = prm
         ctx.cap = cap
         ctx.has_means2D = means2D is not None
-        ctx.grad_sync = grad_sync if (grad_sync is not None and grad_sync.world > 1 and P > 0) else None
+        ctx.grad_sync = grad_sync if (grad_sync is not None and (grad_sync.world > 1 or getattr(grad_sync, "always", False)) and P > 0) else None
         if ctx.grad_sync is not None and hasattr(grad_sync, "verify_inputs"):
             # the cut exchange is only valid for view-independent inputs (dist.ViewShardedGrads): checked on the first call(s)
             grad_sync.verify_inputs({"means3D": means3D, "opacities": opacities, "colors_precomp": colors_precomp,

@@ -225,3 +225,40 @@ def test_exchange_over_rccl_one_rank_group():
         "print('RCCL-OK')\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "RCCL-OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_whole_step_with_the_exchange_captured_over_rccl_one_rank_group():
+    """the N > 1 step -- deform, render, loss, backward WITH the cut exchange (an RCCL all-reduce and
+    all-gather inside the rasterizer's backward) -- captured in ONE hipGraph over a real nccl (= RCCL) process group and
+    replayed; a one-rank group is what a single-GPU box offers, so the collectives are identities, but capture, replay and
+    stream ordering of RCCL work inside the graph are the real thing.  Replay must equal the eager step."""
+    import subprocess
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        f"os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='{_free_port()}', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "import bench\n"
+        "from d3ga_amd import rasterizer as R\n"
+        "from d3ga_amd.dist import ViewShardedGrads\n"
+        "from d3ga_amd.graph import CapturedStep\n"
+        "f = bench.Frame('T1', torch.device('cuda', 0), 0)\n"
+        "f.grad_sync = ViewShardedGrads(); f.grad_sync.always = True\n"
+        "params = list(f.params.values())\n"
+        "for _ in range(2):\n"
+        "    for p in params: p.grad = None\n"
+        "    f.step()\n"
+        "torch.cuda.synchronize()\n"
+        "assert f.grad_sync.bytes_last > 0, 'the exchange did not run'\n"
+        "ref = [p.grad.clone() for p in params]\n"
+        "R.set_capacity_policy('static', int(R.last_counters()['D'] * 1.5) + 1024)\n"
+        "cap = CapturedStep(f.step, params=params)\n"
+        "for _ in range(3): cap.replay()\n"
+        "torch.cuda.synchronize()\n"
+        "err = max(float((p.grad - r).abs().max() / (r.abs().max() + 1e-30)) for p, r in zip(params, ref))\n"
+        "assert err < 1e-5, err\n"
+        "dist.destroy_process_group()\n"
+        "print('RCCL-GRAPH-OK', err)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL-GRAPH-OK" in out.stdout, (out.stdout[-500:], out.stderr[-2500:])
