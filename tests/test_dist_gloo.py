@@ -50,6 +50,17 @@ def _worker(rank, world, port, out):
         sum(((v + 1.0) * p).sum() for p in params).backward()
     red.all_reduce_mean()
     ok = ok and all(torch.allclose(p.grad, torch.full_like(p, expect)) for p in params)
+    # ViewShardedGrads.verify_inputs: identical inputs pass, rank-dependent ("view-dependent") inputs raise on every rank
+    sync = dd.ViewShardedGrads(verify_steps=2)
+    same = torch.arange(12.0).reshape(4, 3)
+    sync.verify_inputs({"means3D": same, "opacities": None})
+    raised = False
+    try:
+        sync.verify_inputs({"means3D": same, "colors_precomp": same + 1e-3 * rank})
+    except dd.ViewDependentInputError as e:
+        raised = "colors_precomp" in str(e) and "means3D" not in str(e).split("differ")[0]
+    ok = ok and raised
+    sync.verify_inputs({"colors_precomp": same + rank})          # verify_steps exhausted: no collective, no error
     out[rank] = bool(ok)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

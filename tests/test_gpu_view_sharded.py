@@ -262,3 +262,71 @@ def test_whole_step_with_the_exchange_captured_over_rccl_one_rank_group():
         "print('RCCL-GRAPH-OK', err)\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "RCCL-GRAPH-OK" in out.stdout, (out.stdout[-500:], out.stderr[-2500:])
+
+
+def _worker_color(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench
+    from d3ga_amd import dist as dd
+    dd.init_process_group(backend="gloo")
+    dev = torch.device("cuda", 0)
+
+    def leaves(f):
+        return dict(f.params, **{f"field{i}": q for i, q in enumerate(f.field_params)}, color_feat=f.color_feat, frame_enc=f.frame_enc)
+
+    # expected: mean over the views of the per-view gradients of EVERY leaf (avatar parameters, all three field networks,
+    # per-Gaussian colour features, frame encoding), computed locally
+    want = {}
+    for v in range(world):
+        f = bench.Frame("T1", dev, view_index=v)
+        f.train_step(with_fields="color")
+        for k, p in leaves(f).items():
+            if p.grad is not None:            # delta_node / delta_bary are produced by the field networks in this configuration
+                want[k] = want.get(k, 0) + p.grad / world
+    mine = bench.Frame("T1", dev, view_index=rank)
+    # 1. the cut exchange must REFUSE this configuration: ColorField sees the view direction, so the rasterizer's colour and
+    #    opacity inputs differ between the ranks (dist.ViewShardedGrads precondition)
+    mine.grad_sync = dd.ViewShardedGrads()
+    refused = False
+    try:
+        mine.train_step(with_fields="color")
+    except dd.ViewDependentInputError:
+        refused = True
+    torch.distributed.barrier()
+    # 2. the recommended path for this configuration: one all-reduce per parameter tensor over ALL leaves
+    mine = bench.Frame("T1", dev, view_index=rank)
+    mine.grad_sync = None
+    mine.train_step(with_fields="color")
+    red = dd.GradReducer(list(leaves(mine).values()))
+    red.all_reduce_mean()
+    torch.cuda.synchronize()
+    err = {k: rel_err(p.grad.cpu().numpy(), want[k].cpu().numpy()) for k, p in leaves(mine).items() if k in want}
+    assert len(err) >= 20 and all(p.grad is not None for k, p in leaves(mine).items() if k in want)
+    out[rank] = (refused, max(err.values()), max(err, key=err.get))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_view_dependent_colour_needs_the_parameter_reducer():
+    """with colours / opacities from ColorField(view_dir, ...) -- the reference's main configuration,
+    configs/actorshq_actor02.yml use_shs false -- summing gradients at the rasterizer's inputs is WRONG (J_r^T sum_v g_v
+    instead of sum_v J_v^T g_v).  ViewShardedGrads detects it (the inputs differ between the ranks) and refuses;
+    GradReducer over all leaves gives the mean of the per-view gradients."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        out = m.dict()
+        procs = [ctx.Process(target=_worker_color, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0
+        res = dict(out)
+    assert set(res) == {0, 1}
+    for r in range(world):
+        refused, err, worst = res[r]
+        assert refused, "ViewShardedGrads must refuse view-dependent rasterizer inputs"
+        assert err < 1e-4, (r, err, worst)
