@@ -59,6 +59,9 @@ def parse():
                     help="sensitivity: multiply the Gaussians' world-space scales (D/P grows ~quadratically)")
     ap.add_argument("--fill", type=float, default=0.85,
                     help="sensitivity: fraction of the image height the 1.8 m body fills (0.85 = SURVEY sec. 8d recipe)")
+    ap.add_argument("--init-timing", action="store_true",
+                    help="also time the init-time helpers at the workload's size: compute_bary (point -> tet + barycentrics, "
+                         "lib/cage.py:325-327) and the 3-NN scale seed (models/cage_net.py:66), uniform grid vs exhaustive")
     ap.add_argument("--pmc", action="store_true",
                     help="collect the HBM / SQ counters of the compositing kernels with rocprofv3 (separate --pmc passes of this "
                          "same command, MI355X_MICROARCH.md) into profiles/pmc_<workload>.json, then run normally")
@@ -263,6 +266,41 @@ def valu_issue_model():
         return avg, {"cycles_per_class": {k: round(v, 2) for k, v in cost.items()}, "mix": mix["counts"]}
     except Exception:
         return None, None
+
+
+def init_timing(frame):
+    """SURVEY sec. 8f-3 at the workload's size: every Gaussian located in the canonical cage (compute_bary) and the 3-nearest-
+    neighbour scale seed over the Gaussian centres, uniform-grid search against the exhaustive kernels (same outputs)."""
+    from d3ga_amd.tetra import compute_bary, knn_mean_dist2
+    corners = frame.canon[frame.tetras.long()].contiguous()                                 # (T,4,3)
+    pts = (corners[frame.tetra_id.long()] * frame.barys0[:, :, None]).sum(1).contiguous()   # the Gaussians' canonical centres
+    P, T = pts.shape[0], corners.shape[0]
+
+    def timed(fn):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+        return time.perf_counter() - t0, r
+    out = {"points": P, "tets": T}
+    tg, rg = timed(lambda: compute_bary(pts, corners, method="grid"))
+    out["compute_bary_grid_s"] = round(tg, 4)
+    n_ex = P if P * T <= 2e11 else max(1, int(2e11 // T))              # bound the exhaustive leg to ~2e11 point-in-tet tests
+    te, re_ = timed(lambda: compute_bary(pts[:n_ex].contiguous(), corners, method="exhaustive"))
+    out["compute_bary_exhaustive_s"] = round(te * P / n_ex, 4)
+    out["compute_bary_exhaustive_sample"] = n_ex
+    out["compute_bary_same_result"] = bool(torch.equal(rg[1][:n_ex], re_[1]) and torch.equal(rg[0][:n_ex], re_[0]))
+    out["recovered_tet_fraction"] = round(float((rg[1] == frame.tetra_id.long()).float().mean()), 4)
+    tk, rk = timed(lambda: knn_mean_dist2(pts, method="grid"))
+    out["knn3_grid_s"] = round(tk, 4)
+    n_ex = P if P <= 300_000 else 300_000
+    if n_ex == P:
+        tke, rke = timed(lambda: knn_mean_dist2(pts, method="exhaustive"))
+        out["knn3_exhaustive_s"] = round(tke, 4)
+        out["knn3_same_result"] = bool(torch.equal(rk, rke))
+    else:
+        tke, _ = timed(lambda: knn_mean_dist2(pts[:n_ex].contiguous(), method="exhaustive"))
+        out["knn3_exhaustive_s"] = round(tke * (P / n_ex) ** 2, 4)
+        out["knn3_exhaustive_note"] = f"extrapolated quadratically from {n_ex} points"
+    return out
 
 
 def measured_copy_gbs(dev, nbytes=1 << 30, reps=10):
@@ -797,6 +835,11 @@ def main():
         }
         if train is not None:
             out["training_step"] = train
+        if args.init_timing:
+            try:
+                out["init"] = init_timing(frame)
+            except Exception as e:  # noqa: BLE001
+                out["init"] = {"error": repr(e)}
         if roof is not None:
             try:
                 roof["measured_copy_GBs"] = round(measured_copy_gbs(dev), 1)

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "d3ga_compute_bary": ([_i, _i] + [_vp] * 5 + [_vp], _i),
     "d3ga_selftest_wave_sum": ([_i, _vp, _vp, _vp], _i),
     "d3ga_knn3_mean_dist2": ([_i, _vp, _vp, _vp], _i),
+    "d3ga_compute_bary_grid": ([_i] + [_vp] * 9 + [_vp], _i),
+    "d3ga_knn3_mean_dist2_grid": ([_i] + [_vp] * 6 + [_vp], _i),
     "d3ga_l1_mean_fwd": ([_i64, _vp, _vp, _vp, _vp], _i),
     "d3ga_l1_mean_bwd": ([_i64, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_mlp_panel_bytes": ([ctypes.c_int32, ctypes.c_int32], _i64),

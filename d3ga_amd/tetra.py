@@ -9,6 +9,8 @@ reference pins are decided here and documented in DESIGN.md:
   * a point outside every tet is assigned the tet with the largest minimum barycentric weight.
 """
 import numpy as np
+import math
+
 import torch
 
 from . import _lib
@@ -77,10 +79,34 @@ class Tetra:
         return vertices[self.triangles]
 
 
-def compute_bary(points, tetras, triangles=None, tri_to_tetra=None, cage=None):
+def _grid_csr(lo_cells, hi_cells, dims):
+    """CSR (cell_start (ncell+1,) int32, items (N,) int32) of the items whose inclusive integer cell boxes [lo, hi] (n,3)
+    overlap each cell of a dims = (nx, ny, nz) grid.  Device-side: expand every item into its cells, sort by cell."""
+    dev = lo_cells.device
+    nx, ny, nz = dims
+    ext = (hi_cells - lo_cells + 1).clamp_min(0)
+    cnt = ext[:, 0] * ext[:, 1] * ext[:, 2]
+    item = torch.repeat_interleave(torch.arange(lo_cells.shape[0], device=dev), cnt)
+    first = torch.cumsum(cnt, 0) - cnt
+    k = torch.arange(item.shape[0], device=dev) - first[item]              # running index inside the item's box
+    ex, ey = ext[item, 0], ext[item, 1]
+    cx = lo_cells[item, 0] + k % ex
+    cy = lo_cells[item, 1] + (k // ex) % ey
+    cz = lo_cells[item, 2] + k // (ex * ey)
+    cell = (cz * ny + cy) * nx + cx
+    order = torch.argsort(cell, stable=True)                               # stable: items stay ascending inside a cell
+    counts = torch.bincount(cell, minlength=nx * ny * nz)
+    start = torch.zeros(nx * ny * nz + 1, dtype=torch.int64, device=dev)
+    start[1:] = torch.cumsum(counts, 0)
+    return start.int().contiguous(), item[order].int().contiguous()
+
+
+def compute_bary(points, tetras, triangles=None, tri_to_tetra=None, cage=None, method="grid"):
     """(points (P,3), tetras (T,4,3) corner coordinates, ...) -> (barys (P,4) f32, tetra_id (P,) int64, active (P,) bool).
-    `triangles`, `tri_to_tetra` and `cage` are accepted for signature compatibility (lib/cage.py:325-327); the
-    exhaustive GPU search needs none of them."""
+    `triangles`, `tri_to_tetra` and `cage` are accepted for signature compatibility (lib/cage.py:325-327).
+    method="grid" (default): a uniform grid over the cage prunes the candidates of every point to the tets whose bounding
+    boxes overlap its cell; the few points no candidate contains (outside the cage) go through the exhaustive search, so
+    the result equals method="exhaustive" (O(P T)) bit for bit."""
     require_cuda(points, tetras)
     pts = points.detach().float().contiguous()
     cor = tetras.detach().float().contiguous()
@@ -88,18 +114,72 @@ def compute_bary(points, tetras, triangles=None, tri_to_tetra=None, cage=None):
     barys = torch.empty((P, 4), dtype=torch.float32, device=pts.device)
     tid = torch.empty((P,), dtype=torch.int32, device=pts.device)
     act = torch.empty((P,), dtype=torch.uint8, device=pts.device)
-    check(_lib.lib().d3ga_compute_bary(P, T, dptr(pts), dptr(cor), dptr(barys), dptr(tid), dptr(act), stream_handle()),
-          "d3ga_compute_bary")
-    return barys, tid.long(), act.bool()
+    L = _lib.lib()
+    if method == "exhaustive" or P == 0 or T < 64:
+        check(L.d3ga_compute_bary(P, T, dptr(pts), dptr(cor), dptr(barys), dptr(tid), dptr(act), stream_handle()),
+              "d3ga_compute_bary")
+        return barys, tid.long(), act.bool()
+    # grid over the cage: cell edge ~ twice the mean tet box edge, at most 128 cells per axis
+    lo, hi = cor.amin(1), cor.amax(1)                                       # (T,3) tet boxes
+    glo, ghi = lo.amin(0), hi.amax(0)
+    mean_edge = float((hi - lo).mean())
+    span = (ghi - glo).cpu()
+    h = max(2.0 * mean_edge, float(span.max()) / 128.0, 1e-12)
+    dims = [max(1, int(math.ceil(float(span[a]) / h)) + 1) for a in range(3)]
+    pad = 1e-5 * float(span.max()) + 1e-9                                   # a point ON a face is inside the inflated box
+    origin = (glo - pad).cpu()
+    o = origin.to(pts.device)
+    lo_c = ((lo - pad - o) / h).floor().long().clamp_min(0)
+    hi_c = ((hi + pad - o) / h).floor().long()
+    hi_c = torch.minimum(hi_c, torch.tensor([d - 1 for d in dims], device=pts.device))
+    cell_start, cell_tets = _grid_csr(lo_c, hi_c, dims)
+    import ctypes
+    origin_h = (ctypes.c_float * 4)(float(origin[0]), float(origin[1]), float(origin[2]), h)
+    cdims = (ctypes.c_int32 * 3)(*dims)
+    minw = torch.empty((P,), dtype=torch.float32, device=pts.device)
+    check(L.d3ga_compute_bary_grid(P, dptr(pts), dptr(cor), dptr(cell_start), dptr(cell_tets), origin_h, cdims, dptr(barys),
+                                   dptr(tid), dptr(minw), stream_handle()), "d3ga_compute_bary_grid")
+    outside = torch.nonzero(~(minw >= 0.0)).reshape(-1)                     # no containing candidate (or NaN): exhaustive
+    act = (minw >= 0.0)
+    if outside.numel():
+        sub = pts[outside].contiguous()
+        n = sub.shape[0]
+        b2 = torch.empty((n, 4), dtype=torch.float32, device=pts.device)
+        t2 = torch.empty((n,), dtype=torch.int32, device=pts.device)
+        a2 = torch.empty((n,), dtype=torch.uint8, device=pts.device)
+        check(L.d3ga_compute_bary(n, T, dptr(sub), dptr(cor), dptr(b2), dptr(t2), dptr(a2), stream_handle()), "d3ga_compute_bary")
+        barys[outside] = b2
+        tid[outside] = t2
+        act[outside] = a2.bool()
+    return barys, tid.long(), act
 
 
-def knn_mean_dist2(points):
+def knn_mean_dist2(points, method="grid"):
     """(P,3) -> (P,) mean squared distance to the 3 nearest neighbours: `simple_knn._C.distCUDA2(points)`
-    (models/mesh_net.py:66) == `knn_points(p[None], p[None], K=4)[0][0, :, 1:].mean(-1)` (models/cage_net.py:66)."""
+    (models/mesh_net.py:66) == `knn_points(p[None], p[None], K=4)[0][0, :, 1:].mean(-1)` (models/cage_net.py:66).
+    method="grid" (default): points bucketed into a uniform grid (~4 per cell), exact ring search; "exhaustive": O(P^2)."""
     require_cuda(points)
     pts = points.detach().float().contiguous()
-    out = torch.empty((pts.shape[0],), dtype=torch.float32, device=pts.device)
-    check(_lib.lib().d3ga_knn3_mean_dist2(pts.shape[0], dptr(pts), dptr(out), stream_handle()), "d3ga_knn3_mean_dist2")
+    P = pts.shape[0]
+    out = torch.empty((P,), dtype=torch.float32, device=pts.device)
+    L = _lib.lib()
+    if method == "exhaustive" or P < 2048:
+        check(L.d3ga_knn3_mean_dist2(P, dptr(pts), dptr(out), stream_handle()), "d3ga_knn3_mean_dist2")
+        return out
+    glo, ghi = pts.amin(0), pts.amax(0)
+    span = (ghi - glo).cpu()
+    vol = float(torch.clamp(span, min=1e-9).prod())
+    h = max((vol / (P / 4.0)) ** (1.0 / 3.0), float(span.max()) / 256.0, 1e-12)
+    dims = [max(1, int(math.ceil(float(span[a]) / h)) + 1) for a in range(3)]
+    origin = glo.cpu()
+    c = ((pts - glo) / h).floor().long()
+    c = torch.minimum(c.clamp_min(0), torch.tensor([d - 1 for d in dims], device=pts.device))
+    cell_start, cell_points = _grid_csr(c, c, dims)
+    import ctypes
+    origin_h = (ctypes.c_float * 4)(float(origin[0]), float(origin[1]), float(origin[2]), h)
+    cdims = (ctypes.c_int32 * 3)(*dims)
+    check(L.d3ga_knn3_mean_dist2_grid(P, dptr(pts), dptr(cell_start), dptr(cell_points), origin_h, cdims, dptr(out),
+                                      stream_handle()), "d3ga_knn3_mean_dist2_grid")
     return out
 
 

@@ -265,10 +265,23 @@ int d3ga_selftest_wave_sum(int n, const float *in, float *out, d3ga_stream_t str
 int d3ga_compute_bary(int P, int T, const float *points, const float *tetra_corners, float *barys,
                       int32_t *tetra_id, uint8_t *active, d3ga_stream_t stream);
 
+/* The same search with uniform-grid candidate pruning (bit-identical results for points inside the
+ * cage).  cell_start (nx*ny*nz + 1) / cell_tets: per grid cell the tets whose bounding box overlaps it (CSR, int32);
+ * origin_h = {ox, oy, oz, cell edge} (HOST array), dims = {nx, ny, nz} (HOST array).  min_weight (P) receives the
+ * winner's smallest weight: < 0 means no candidate contains the point -- re-run those through d3ga_compute_bary. */
+int d3ga_compute_bary_grid(int P, const float *points, const float *tetra_corners, const int32_t *cell_start,
+                           const int32_t *cell_tets, const float *origin_h, const int32_t *dims, float *barys,
+                           int32_t *tetra_id, float *min_weight, d3ga_stream_t stream);
+
 /* Init-time scale seed.  Replaces simple_knn._C.distCUDA2 (models/mesh_net.py:22,66) and
  * pytorch3d knn_points(p, p, K=4)[0][0,:,1:].mean(-1) (models/cage_net.py:66): out[i] = mean squared distance of
- * point i to its 3 nearest other points.  points (P,3) -> out (P).  Exhaustive O(P^2). */
+ * point i to its 3 nearest other points (sum / 3; missing neighbours count as 0, like pytorch3d's padding).  points (P,3) -> out (P).
+ * Exhaustive O(P^2). */
 int d3ga_knn3_mean_dist2(int P, const float *points, float *out, d3ga_stream_t stream);
+/* The same with a uniform grid over the points (cell_start / cell_points: CSR of point indices per cell; origin_h, dims as
+ * above, HOST arrays): ring search outwards from the point's cell, exact. */
+int d3ga_knn3_mean_dist2_grid(int P, const float *points, const int32_t *cell_start, const int32_t *cell_points,
+                              const float *origin_h, const int32_t *dims, float *out, d3ga_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Field networks: the dense layer of models/mlp.py:39-232 -- every field is

@@ -815,6 +815,40 @@ def test_knn_mean_dist2_matches_bruteforce():
     out = knn_mean_dist2(pts.to(DEV))
     np.testing.assert_allclose(_np(out), ref.numpy(), rtol=1e-4, atol=1e-7)
     assert float(knn_mean_dist2(pts[:1].to(DEV))[0]) == 0.0
+    # fewer than three other points: the mean is still over THREE slots (pytorch3d pads the missing distances with 0)
+    two = torch.tensor([[0.0, 0.0, 0.0], [2.0, 0.0, 0.0]])
+    np.testing.assert_allclose(_np(knn_mean_dist2(two.to(DEV))), [4.0 / 3.0, 4.0 / 3.0], rtol=1e-6)
+
+
+def test_grid_search_equals_exhaustive_search():
+    """the uniform-grid versions of compute_bary and knn_mean_dist2 return what the exhaustive O(P T) /
+    O(P^2) kernels return -- bit for bit (same per-candidate arithmetic, same tie rules) -- for points inside the cage, on
+    its faces and vertices, and outside it; clustered and uniform point sets for the neighbour search."""
+    import time
+    from d3ga_amd import synthetic as syn
+    from d3ga_amd.tetra import compute_bary, knn_mean_dist2
+    sc = syn.make_scene("C2")
+    corners = sc["canon_points"][sc["tetras"].long()].to(DEV)                 # (T,4,3), three cages
+    rng = np.random.default_rng(21)
+    P = 60_000
+    inside = (corners[sc["tetra_id"].long()[:P].to(DEV)] * sc["barys"][:P, :, None].to(DEV)).sum(1)
+    on_faces = corners[torch.from_numpy(rng.integers(0, corners.shape[0], 2000)).to(DEV), :3].mean(1)      # face centroids
+    on_verts = corners[torch.from_numpy(rng.integers(0, corners.shape[0], 500)).to(DEV), 0]
+    outside = torch.from_numpy(rng.uniform(-1.5, 1.5, size=(1500, 3)).astype(np.float32)).to(DEV)
+    pts = torch.cat([inside, on_faces, on_verts, outside], 0).contiguous()
+    torch.cuda.synchronize(); t0 = time.time()
+    b_g, t_g, a_g = compute_bary(pts, corners, method="grid")
+    torch.cuda.synchronize(); t1 = time.time()
+    b_e, t_e, a_e = compute_bary(pts, corners, method="exhaustive")
+    torch.cuda.synchronize(); t2 = time.time()
+    print(f"compute_bary {pts.shape[0]} points x {corners.shape[0]} tets: grid {t1 - t0:.3f} s (incl. grid build), exhaustive {t2 - t1:.3f} s")
+    assert torch.equal(t_g, t_e) and torch.equal(b_g, b_e) and torch.equal(a_g, a_e)
+    assert float(a_g[:P].float().mean()) > 0.97 and not bool(a_g[-1500:].all())
+    for pts_k in (sc["canon_points"].to(DEV)[:20_000], (0.05 * torch.randn(30_000, 3, generator=torch.Generator().manual_seed(3))
+                                                        + torch.tensor([0.3, 0.0, -0.2])).to(DEV), outside):
+        k_g = knn_mean_dist2(pts_k.contiguous(), method="grid")
+        k_e = knn_mean_dist2(pts_k.contiguous(), method="exhaustive")
+        assert torch.equal(k_g, k_e), float((k_g - k_e).abs().max())
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_INIT_FUZZ_N", "4"))))
