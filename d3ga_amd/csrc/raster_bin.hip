@@ -279,91 +279,96 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr k, int n, int tid, int nthre
     }
 }
 
-// Same network with 8 keys per thread: every stage whose partner distance is < 8 (sizes 2..8 entirely, and the last
-// three disperse stages of every larger size) runs on registers -- 36 LDS stages + barriers instead of 66 for 2048
-// keys.  Requires n <= 8 * nthreads.
-__device__ __forceinline__ void cmpex(uint64_t &a, uint64_t &b) {
-    const uint64_t lo = min(a, b), hi = max(a, b);
-    a = lo; b = hi;
-}
-// LDS index with one pad slot per 8 keys: a thread's 8 consecutive keys start 72 B apart, so the 16-byte row reads /
-// writes of the register phases hit distinct banks.
-#define PH(i) ((i) + ((i) >> 3))
-__device__ __forceinline__ void bitonic_sort_regs8(uint64_t *k, int n, int tid, int nthreads) {
-    int n2 = 8;
-    while (n2 < n) n2 <<= 1;
-    const int half = n2 >> 1;
-    const int base = tid * 8;
-    const bool act = base < n2;
-    uint64_t r[8];
-    if (act) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = (base + i < n) ? k[PH(base + i)] : ~0ull;
-        cmpex(r[0], r[1]); cmpex(r[2], r[3]); cmpex(r[4], r[5]); cmpex(r[6], r[7]);      // size 2
-        cmpex(r[0], r[3]); cmpex(r[1], r[2]); cmpex(r[4], r[7]); cmpex(r[5], r[6]);      // size 4: flip
-        cmpex(r[0], r[1]); cmpex(r[2], r[3]); cmpex(r[4], r[5]); cmpex(r[6], r[7]);      //         disperse 1
-        cmpex(r[0], r[7]); cmpex(r[1], r[6]); cmpex(r[2], r[5]); cmpex(r[3], r[4]);      // size 8: flip
-        cmpex(r[0], r[2]); cmpex(r[1], r[3]); cmpex(r[4], r[6]); cmpex(r[5], r[7]);      //         disperse 2
-        cmpex(r[0], r[1]); cmpex(r[2], r[3]); cmpex(r[4], r[5]); cmpex(r[6], r[7]);      //         disperse 1
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (base + i < n) k[PH(base + i)] = r[i];
-    }
-    __syncthreads();
-    for (int size = 16, lsz = 4; size <= n2; size <<= 1, ++lsz) {
-        const int hs = size >> 1;
-        for (int i = tid; i < half; i += nthreads) {          // flip (LDS)
-            const int blk = i >> (lsz - 1), off = i & (hs - 1);
-            const int lo = (blk << lsz) + off, hi = (blk << lsz) + size - 1 - off;
-            if (hi < n) {
-                const uint64_t a = k[PH(lo)], b = k[PH(hi)];
-                if (b < a) { k[PH(lo)] = b; k[PH(hi)] = a; }
-            }
-        }
-        __syncthreads();
-        for (int j = hs >> 1, lj = lsz - 2; j >= 8; j >>= 1, --lj) {   // disperse, distance >= 8 (LDS)
-            for (int i = tid; i < half; i += nthreads) {
-                const int blk = i >> lj, off = i & (j - 1);
-                const int lo = (blk << (lj + 1)) + off, hi = lo + j;
-                if (hi < n) {
-                    const uint64_t a = k[PH(lo)], b = k[PH(hi)];
-                    if (b < a) { k[PH(lo)] = b; k[PH(hi)] = a; }
-                }
-            }
-            __syncthreads();
-        }
-        if (act) {                                            // disperse 4, 2, 1 (registers)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = (base + i < n) ? k[PH(base + i)] : ~0ull;
-            cmpex(r[0], r[4]); cmpex(r[1], r[5]); cmpex(r[2], r[6]); cmpex(r[3], r[7]);
-            cmpex(r[0], r[2]); cmpex(r[1], r[3]); cmpex(r[4], r[6]); cmpex(r[5], r[7]);
-            cmpex(r[0], r[1]); cmpex(r[2], r[3]); cmpex(r[4], r[5]); cmpex(r[6], r[7]);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (base + i < n) k[PH(base + i)] = r[i];
-        }
-        __syncthreads();
-    }
-}
-#undef PH
-
-template <int BLOCK, int CAP, bool kRegs>
-__device__ __forceinline__ void sort_one_tile_lds(uint64_t *s_key, int tile, const uint32_t *__restrict__ start,
-                                                  const uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
-                                                  uint64_t dcap) {
+// Depth sort of ONE tile list in LDS by BUCKETING (counting sort on a power-of-two quantisation of the depth bits, then an exact
+// fix-up inside every bucket).  The bitonic network above moves every 8-byte key through LDS 36 times (2048 keys: 1.5 MB of
+// LDS traffic per tile -- the sort was LDS-bandwidth bound, 52 us of the 82 us bin+sort at C3); here a key is written to LDS
+// once and read about twice:
+//   1. keys -> registers (CAP / BLOCK = 8 per thread); block-wide min / max of the depth bits (view-space z > 0.2, so the
+//      float bits order like unsigned integers);
+//   2. bucket b = (bits - min) >> sh with sh = the smallest shift that maps the range into CAP buckets: monotone in the depth,
+//      so buckets are depth-ordered; one RETURNING LDS atomic per key counts the bucket and hands out a slot in it;
+//   3. exclusive scan of the CAP counters (8 per thread + wave scan + wave totals);
+//   4. the key goes to s_key[base[b] + slot]: bucket-ordered, arbitrary order inside a bucket (atomic arrival order);
+//   5. exact position = base[b] + #{keys of the bucket smaller than mine} (full 64-bit compare: depth bits, then index -- the
+//      total order of DESIGN.md sec. 2).  A bucket holds ~0.6 keys on average (n = 1200, CAP = 2048); the loop is O(bucket^2)
+//      only for coplanar splats of IDENTICAL quantised depth, bounded by CAP.
+// The result is the sorted list, independent of the atomic arrival order.
+template <int BLOCK, int CAP>
+__device__ __forceinline__ void sort_one_tile_bucket(uint64_t *s_key, uint32_t *s_bin, uint32_t *s_red, int tile,
+                                                     const uint32_t *__restrict__ start, const uint64_t *__restrict__ keys,
+                                                     uint32_t *__restrict__ point_list, uint64_t dcap) {
+    static_assert(CAP == 8 * BLOCK, "eight keys / eight counters per thread");
+    constexpr int NW = BLOCK / 64;
     const uint64_t b64 = min((uint64_t)start[tile], dcap), e64 = min((uint64_t)start[tile + 1], dcap);
     const int n = min((int)(e64 - b64), CAP);             // (lists are clamped only if the capacity overflowed)
-    const int tid = threadIdx.x;
-    if constexpr (kRegs) {
-        for (int i = tid; i < n; i += BLOCK) s_key[i + (i >> 3)] = keys[b64 + i];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t r[8];
+    uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = tid + k * BLOCK;
+        r[k] = i < n ? keys[b64 + i] : ~0ull;
+        if (i < n) { const uint32_t d = (uint32_t)(r[k] >> 32); lo = min(lo, d); hi = max(hi, d); }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+    }
+    if (lane == 0) { s_red[wave] = lo; s_red[NW + wave] = hi; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_bin[tid + k * BLOCK] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { lo = min(lo, s_red[w]); hi = max(hi, s_red[NW + w]); }
+    const uint32_t range = hi - lo;                                         // < 2^32
+    int sh = 32 - __clz((int)(range | 1u)) - (31 - __clz(CAP));             // range >> sh < CAP
+    if (range & 0x80000000u) sh = 32 - (31 - __clz(CAP));                   // (__clz of a "negative" int)
+    sh = max(sh, 0);
+    uint32_t bucket[8], slot[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = tid + k * BLOCK;
+        bucket[k] = ((uint32_t)(r[k] >> 32) - lo) >> sh;
+        slot[k] = 0u;
+        if (i < n) slot[k] = atomicAdd(&s_bin[bucket[k]], 1u);
+    }
+    __syncthreads();
+    {   // exclusive scan of the CAP counters, in place; s_bin[CAP] = n
+        uint32_t c[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { c[k] = s_bin[8 * tid + k]; sum += c[k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = (uint32_t)__shfl_up((int)incl, off);
+            if (lane >= off) incl += u;
+        }
+        if (lane == 63) s_red[wave] = incl;
         __syncthreads();
-        bitonic_sort_regs8(s_key, n, tid, BLOCK);
-        for (int i = tid; i < n; i += BLOCK) point_list[b64 + i] = (uint32_t)s_key[i + (i >> 3)];
-    } else {
-        for (int i = tid; i < n; i += BLOCK) s_key[i] = keys[b64 + i];
-        __syncthreads();
-        bitonic_sort(s_key, n, tid, BLOCK);
-        for (int i = tid; i < n; i += BLOCK) point_list[b64 + i] = (uint32_t)s_key[i];
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) if (w < wave) run += s_red[w];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s_bin[8 * tid + k] = run; run += c[k]; }
+        if (tid == BLOCK - 1) s_bin[CAP] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = tid + k * BLOCK;
+        if (i < n) s_key[s_bin[bucket[k]] + slot[k]] = r[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = tid + k * BLOCK;
+        if (i < n) {
+            const uint32_t b0 = s_bin[bucket[k]], b1 = s_bin[bucket[k] + 1];
+            uint32_t less = 0;
+            for (uint32_t p = b0; p < b1; ++p) less += s_key[p] < r[k] ? 1u : 0u;
+            point_list[b64 + b0 + less] = (uint32_t)r[k];
+        }
     }
 }
 
@@ -372,16 +377,17 @@ template <int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void tile_sort_lds_kernel(const uint32_t *__restrict__ start,
                                                               const uint64_t *__restrict__ keys,
                                                               uint32_t *__restrict__ point_list, uint64_t dcap) {
-    static_assert(CAP <= 8 * BLOCK, "8 keys per thread");
-    __shared__ uint64_t s_key[CAP + CAP / 8];             // padded layout of bitonic_sort_regs8
+    __shared__ uint64_t s_key[CAP];
+    __shared__ uint32_t s_bin[CAP + 1];
+    __shared__ uint32_t s_red[2 * (BLOCK / 64)];
     const int tile = blockIdx.x;
     const uint32_t n = start[tile + 1] - start[tile];
     if (n == 0 || n > (uint32_t)CAP) return;
-    sort_one_tile_lds<BLOCK, CAP, true>(s_key, tile, start, keys, point_list, dcap);
+    sort_one_tile_bucket<BLOCK, CAP>(s_key, s_bin, s_red, tile, start, keys, point_list, dcap);
 }
 
 // persistent grid over a work list written by the scan workgroup of tile_scan_order_kernel (tiles whose list does not fit the kernel above);
-// dynamic LDS: CAP + CAP/8 keys in the padded register-phase layout (36 KB for 4096, 72 KB for 8192)
+// dynamic LDS: CAP keys + CAP + 1 bucket counters (+ reduction scratch): 48 KB for 4096, 96 KB for 8192
 template <int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_t *__restrict__ start,
                                                                    const uint64_t *__restrict__ keys,
@@ -391,12 +397,13 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_
                                                                    uint64_t *__restrict__ keys_rw,
                                                                    const uint32_t *__restrict__ huge_list,
                                                                    const uint32_t *__restrict__ huge_count) {
-    static_assert(CAP <= 8 * BLOCK, "8 keys per thread");
     extern __shared__ __attribute__((aligned(16))) uint64_t s_key_dyn[];
+    uint32_t *s_bin = reinterpret_cast<uint32_t *>(s_key_dyn + CAP);
+    uint32_t *s_red = s_bin + CAP + 1;
     const uint32_t count = *list_count;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
         __syncthreads();
-        sort_one_tile_lds<BLOCK, CAP, true>(s_key_dyn, (int)list[k], start, keys, point_list, dcap);
+        sort_one_tile_bucket<BLOCK, CAP>(s_key_dyn, s_bin, s_red, (int)list[k], start, keys, point_list, dcap);
     }
     // lists that do not fit any LDS class (huge_list != null: same launch, saves a near-empty grid per frame):
     // the same network on global memory
@@ -418,9 +425,10 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_
 
 using namespace d3ga;
 
-constexpr int kSortSmall = 2048;   // 18 KiB LDS, 256 threads, one workgroup per tile
-constexpr int kSortMid = 4096;     // 36 KiB LDS, 512 threads, list-driven
-constexpr int kSortLarge = 8192;   // 72 KiB LDS, 1024 threads, list-driven
+constexpr int kSortSmall = 2048;   // 24 KiB LDS, 256 threads, one workgroup per tile
+constexpr int kSortMid = 4096;     // 48 KiB LDS, 512 threads, list-driven
+constexpr int kSortLarge = 8192;   // 96 KiB LDS, 1024 threads, list-driven
+static inline size_t sort_lds_bytes(int cap, int block) { return (size_t)cap * 8 + ((size_t)cap + 1 + 2 * (block / 64)) * 4 + 16; }
 
 
 extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, void *binning, int64_t d_capacity,
@@ -450,18 +458,18 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
         D3GA_HIP(hipGetDevice(&dev));
         if (dev >= 0 && dev < 64 && !attr_set[dev]) {
             D3GA_HIP(hipFuncSetAttribute((const void *)tile_sort_lds_list_kernel<1024, kSortLarge>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (kSortLarge + kSortLarge / 8) * 8));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(kSortLarge, 1024)));
             attr_set[dev] = true;
         }
     }
     const int lgrid = tiles < 1024 ? tiles : 1024;
-    hipLaunchKernelGGL((tile_sort_lds_list_kernel<512, kSortMid>), dim3(lgrid), dim3(512), (kSortMid + kSortMid / 8) * 8, s,
+    hipLaunchKernelGGL((tile_sort_lds_list_kernel<512, kSortMid>), dim3(lgrid), dim3(512), sort_lds_bytes(kSortMid, 512), s,
                        bin.tile_start, bin.keys, bin.point_list, (uint64_t)d_capacity, bin.mid_tiles,
                        bin.counters + D3GA_CNT_MID, (uint64_t *)nullptr, (const uint32_t *)nullptr,
                        (const uint32_t *)nullptr);
     D3GA_TRY(check_launch(s, prm->debug));
     hipLaunchKernelGGL((tile_sort_lds_list_kernel<1024, kSortLarge>), dim3(lgrid < 512 ? lgrid : 512), dim3(1024),
-                       (kSortLarge + kSortLarge / 8) * 8, s, bin.tile_start, bin.keys, bin.point_list,
+                       sort_lds_bytes(kSortLarge, 1024), s, bin.tile_start, bin.keys, bin.point_list,
                        (uint64_t)d_capacity, bin.big_tiles, bin.counters + D3GA_CNT_BIG, bin.keys,
                        (const uint32_t *)bin.huge_tiles, (const uint32_t *)(bin.counters + D3GA_CNT_HUGE));
     return check_launch(s, prm->debug);
