@@ -79,13 +79,19 @@ class CameraSlot:
     resolution.  `set(batch)` stages the numbers in pinned memory and enqueues one asynchronous H2D copy on the current
     stream; put `batch["camera_slot"] = slot` into the batch handed to `render()`."""
 
+    _RING = 16
+
     def __init__(self, width, height, device="cuda"):
         self.image_width, self.image_height = int(width), int(height)
         dev = torch.device(device)
         self.matrices = torch.zeros(53, dtype=torch.float32, device=dev)
-        self._stage = torch.zeros(53, dtype=torch.float32)
+        # pinned staging ring: the host runs many steps ahead of the GPU, so a staging buffer may only be rewritten once the
+        # asynchronous copy that reads it has executed (an event per slot of the ring)
+        self._ring = [torch.zeros(53, dtype=torch.float32) for _ in range(self._RING)]
+        self._events = [None] * self._RING
+        self._next = 0
         if dev.type == "cuda":
-            self._stage = self._stage.pin_memory()
+            self._ring = [t.pin_memory() for t in self._ring]
         self.world_view_transform = self.matrices[0:16].view(4, 4)
         self.projection_matrix = self.matrices[16:32].view(4, 4)
         self.full_proj_transform = self.matrices[32:48].view(4, 4)
@@ -98,10 +104,19 @@ class CameraSlot:
             raise ValueError(f"CameraSlot is {self.image_width}x{self.image_height}; the batch is "
                              f"{batch['width']}x{batch['height']} (one slot / captured step per raster size)")
         host = Camera.pack_host(batch["R"], batch["T"], batch["FoVx"], batch["FoVy"])
-        self._stage[:51] = torch.from_numpy(host)
-        self._stage[51] = math.tan(float(batch["FoVx"]) * 0.5)
-        self._stage[52] = math.tan(float(batch["FoVy"]) * 0.5)
-        self.matrices.copy_(self._stage, non_blocking=True)
+        i = self._next
+        self._next = (i + 1) % self._RING
+        if self._events[i] is not None:
+            self._events[i].synchronize()                      # the copy that last read this staging buffer has run
+        stage = self._ring[i]
+        stage[:51] = torch.from_numpy(host)
+        stage[51] = math.tan(float(batch["FoVx"]) * 0.5)
+        stage[52] = math.tan(float(batch["FoVy"]) * 0.5)
+        self.matrices.copy_(stage, non_blocking=True)
+        if self.matrices.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[i] = ev
         return self
 
 

@@ -24,6 +24,14 @@ for f in glob.glob(os.path.join(ROOT, "gpurun_out", "prof", "*kernel_stats.csv")
 b = os.path.join(ROOT, "gpurun_out", "bench.log")
 if os.path.exists(b) and os.path.getsize(b) > 10:
     shutil.copy(b, os.path.join(ROOT, "profiles", f"{tag}_bench_{wl}.json"))
+pj = os.path.join(ROOT, "gpurun_out", f"pmc_{wl}.json")          # written by `bench.py --pmc` on the GPU box (tools/gpu_evidence.sh)
+if os.path.exists(pj):
+    shutil.copy(pj, os.path.join(ROOT, "profiles", f"pmc_{wl}.json"))
+    shutil.copy(pj, os.path.join(ROOT, "profiles", f"{tag}_pmc_{wl}.json"))
+for name in ("C3_s2", "C3_s4", "C3_fill"):                       # sensitivity lines
+    b = os.path.join(ROOT, "gpurun_out", f"bench_{name}.log")
+    if os.path.exists(b) and os.path.getsize(b) > 10:
+        shutil.copy(b, os.path.join(ROOT, "profiles", f"{tag}_bench_{name}.json"))
 for other in ("C1", "C2", "C4", "C5"):
     b = os.path.join(ROOT, "gpurun_out", f"bench_{other}.log")
     if os.path.exists(b) and os.path.getsize(b) > 10:
