@@ -639,6 +639,32 @@ def test_long_tile_lists_use_the_large_sort_paths(name, scale_mult, min_longest)
     _assert_image(Parity(ctx), _np(color), ocolor)
 
 
+def test_more_than_8192_splats_of_identical_depth_in_one_tile():
+    """The degenerate input of the segmented bucket sort: > 8192 entries of ONE tile share their depth bits (a single bucket
+    that exceeds the largest LDS class), so the list falls back to the bitonic network on global memory and the order is
+    decided by the Gaussian index alone."""
+    from d3ga_amd import rasterizer as R
+    inp = scene_inputs("T0", scale_mult=1.0)
+    n = 9000
+    p = inp["means3D"][:1].repeat(n, 1).contiguous()                 # identical centres: identical depth bits
+    cov = torch.tensor([[4e-4, 0, 0, 4e-4, 0, 4e-4]]).repeat(n, 1)
+    op = torch.full((n, 1), 0.002)                                   # alpha < 1/255 everywhere: the list is walked, nothing blends
+    col = torch.rand(n, 3, generator=torch.Generator().manual_seed(2))
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    rast = R.GaussianRasterizer(_settings(inp, bg, 0))
+    with torch.no_grad():
+        color, radii, _ = rast(means3D=p.to(DEV), means2D=None, opacities=op.to(DEV), colors_precomp=col.to(DEV), cov3D_precomp=cov.to(DEV))
+    cnt = R.last_counters()
+    assert cnt["max_tile"] >= 8193, cnt
+    start, plist, keys = R.last_tile_lists(inp["W"], inp["H"])
+    st = _np(start)
+    pl = _np(plist)
+    for t in np.nonzero(np.diff(st) > 8192)[0][:4]:
+        seg = pl[st[t]:st[t + 1]]
+        assert np.array_equal(seg, np.sort(seg))                     # equal depth: ascending index
+    assert torch.allclose(color, bg.to(DEV).reshape(3, 1, 1).expand_as(color))
+
+
 def test_fused_l1_loss_matches_torch():
     from d3ga_amd.losses import l1_loss
     g = torch.Generator().manual_seed(21)
