@@ -3,14 +3,15 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-export D3GA_ACC_MULT=8
 : > gpurun_out/ablate.log
 run() {
-  echo -n "$1 variant=${2:-default} " >> gpurun_out/ablate.log
-  D3GA_COMPOSITE_VARIANT=${2:-127} D3GA_LIB_PATH=$GRAFT_REPO_ROOT/d3ga_amd/$1 timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-train-step 2>/dev/null | python -c "
+  echo -n "$1 " >> gpurun_out/ablate.log
+  D3GA_LIB_PATH=$GRAFT_REPO_ROOT/d3ga_amd/$1 timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-train-step --fixed-camera 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); print(d['ms_per_step'], {k:v['ms'] for k,v in d['kernels'].items()})" >> gpurun_out/ablate.log
 }
-run libd3ga_hip.so 127
-for lib in $(cd d3ga_amd && ls libd3ga_hip_abl*.so 2>/dev/null); do run $lib 127; done
+for round in 1 2; do
+run libd3ga_hip.so
+for lib in $(cd d3ga_amd && ls libd3ga_hip_abl*.so 2>/dev/null); do run $lib; done
+done
 cat gpurun_out/ablate.log
