@@ -12,8 +12,12 @@ OUT = os.path.join(HERE, "..", (f"libd3ga_hip_abl{ABL}.so" if ABL else "libd3ga_
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
 # per-source extras.  The entry-per-lane compositing backward is VALU-issue bound; SLP-packing its scalar f32 chains into
-# v_pk_* costs ~35 register shuffles per 4 pixels (ISA inspected), so the vectoriser is off for that file.
-EXTRA = {"raster_composite_scan.hip": ["-fno-slp-vectorize"]}
+# v_pk_* costs ~35 register shuffles per 4 pixels (ISA inspected) and a v_pk_fma_f32 issues in 4.2 cycles against 2.4 for a
+# v_fma_f32 (tools/micro/valu_issue.hip), so the vectoriser is off for the two compositing files.
+EXTRA = {"raster_composite_scan.hip": ["-fno-slp-vectorize"],
+         "raster_composite.hip": ["-fno-slp-vectorize"]}      # forward 117 -> 103 us at C3: packed f32 ops cost 2x, plus their shuffles
+if os.environ.get("D3GA_ALL_NOSLP"):                          # A/B: every translation unit
+    FLAGS.append("-fno-slp-vectorize")
 if ABL:
     FLAGS.append("-DD3GA_SCAN_ABL=" + ABL)
 if os.environ.get("D3GA_DIAG"):            # diagnostic build (loop statistics, tools/diag_bwd.py); never the shipped one
