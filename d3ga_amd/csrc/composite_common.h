@@ -178,13 +178,31 @@ __device__ __forceinline__ bool quad_relevant(float cx, float cy, float A, float
     return !(cx + hx < x0) && !(cx - hx > x0 + 7.0f) && !(cy + hy < y0) && !(cy - hy > y0 + 7.0f);
 }
 
-// alpha of one splat on one pixel, branch-free: ok <=> the splat touches the pixel (power <= 0 and alpha >= 1/255)
+// alpha of one splat on one pixel, branch-free: ok <=> the splat touches the pixel (power <= 0 and alpha >= 1/255).
+// The constants of  G = exp(-1/2 (a dx^2 + c dy^2) - b dx dy)  are folded into the conic once per entry:
+//   q = (-1/2 log2(e) a, -log2(e) b, -1/2 log2(e) c),   G = exp2(dx (q.a dx + q.b dy) + q.c dy^2)
+// -> two multiplies and two FMAs in front of v_exp_f32 instead of seven multiplies/FMAs and the log2(e) scaling; callers
+// whose lanes share dy (the entry-per-lane backward) hoist tb = q.b dy and tc = q.c dy^2 out of the pixel loop.  Forward and
+// backward use THIS expression tree (explicit fmaf), so both see bit-identical alphas.
+constexpr float kLog2e = 1.4426950408889634f;
+struct ConicQ { float a, b, c; };
+__device__ __forceinline__ ConicQ conic_q(float a, float b, float c) {
+    return ConicQ{(-0.5f * kLog2e) * a, (-kLog2e) * b, (-0.5f * kLog2e) * c};
+}
+__device__ __forceinline__ void splat_eval_q(float dx, float tb, float tc, float qa, float o, float &alpha, float &G, bool &ok) {
+    const float p = fmaf(dx, fmaf(qa, dx, tb), tc);       // log2 of G
+    G = __builtin_amdgcn_exp2f(p);
+    alpha = fminf(kAlphaMax, o * G);
+    ok = (p <= 0.0f) && (alpha >= kAlphaMin);
+}
+__device__ __forceinline__ void splat_eval_q(float dx, float dy, const ConicQ &q, float o, float &alpha, float &G, bool &ok) {
+    splat_eval_q(dx, q.b * dy, (q.c * dy) * dy, q.a, o, alpha, G, ok);
+}
+
 __device__ __forceinline__ void splat_eval(float dx, float dy, float ca, float cb, float cc, float o, float &alpha,
                                            float &G, bool &ok) {
-    const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
-    G = __expf(power);
-    alpha = fminf(kAlphaMax, o * G);
-    ok = (power <= 0.0f) && (alpha >= kAlphaMin);
+    const ConicQ q = conic_q(ca, cb, cc);
+    splat_eval_q(dx, dy, q, o, alpha, G, ok);
 }
 
 struct RowGeom {

@@ -327,7 +327,11 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
         const SplatCull sc = splat_cull(cco.x, cco.y, cco.z, cco.w);
         const float hx = have ? sc.hx : -1.0f, hy = sc.hy;
         __builtin_amdgcn_wave_barrier();                  // previous batch's LDS reads are done (program order)
-        s_xy[lane] = cxy; s_co[lane] = cco; s_rgb[lane] = crgb;
+        s_xy[lane] = cxy; s_rgb[lane] = crgb;
+        {   // the blend reads the conic with its constants folded in (splat_eval_q)
+            const ConicQ cq = conic_q(cco.x, cco.y, cco.z);
+            s_co[lane] = make_float4(cq.a, cq.b, cq.c, cco.w);
+        }
         if constexpr (DUAL) s_rgb2[lane] = crgb2;
         int trip;
         BlockHits bh = block_hits4(cxy.x, cxy.y, hx, hy, bx0, by0);
@@ -366,8 +370,8 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
             const float4 e0rgb = s_rgb[j0], e1rgb = s_rgb[j1];
             float al0, G0, al1, G1;
             bool ok0, ok1;
-            splat_eval(e0xy.x - fx, e0xy.y - fy, e0co.x, e0co.y, e0co.z, e0co.w, al0, G0, ok0);
-            splat_eval(e1xy.x - fx, e1xy.y - fy, e1co.x, e1co.y, e1co.z, e1co.w, al1, G1, ok1);
+            splat_eval_q(e0xy.x - fx, e0xy.y - fy, ConicQ{e0co.x, e0co.y, e0co.z}, e0co.w, al0, G0, ok0);
+            splat_eval_q(e1xy.x - fx, e1xy.y - fy, ConicQ{e1co.x, e1co.y, e1co.z}, e1co.w, al1, G1, ok1);
             {
                 const bool act = ok0 && v0 && !done;
                 const float test_T = T * (1.0f - al0);

@@ -18,7 +18,7 @@
 //     atomic requests), seven entries per instruction.
 // Instructions per (entry, 4x4 block) pair: ~16 x 58 / 16 + ~7 = 65, against ~100 per (entry, block) visit before -- and a
 // visit used to occupy a whole wavefront iteration in which on average 2.6 of the 4 rows had an entry at all.
-// alpha is evaluated by the same splat_eval() as the forward and the validity test is the forward's (power <= 0,
+// alpha is evaluated by the same splat_eval_q() as the forward and the validity test is the forward's (power <= 0,
 // alpha >= 1/255, list position <= the pixel's n_contrib), so the set of (pixel, entry) pairs is exactly the forward's.
 #include "composite_common.h"
 
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
         uint2 pg2 = list_entry(g + 2);
         const bool act = e.pos != 0u;
         const float exr = e.xy.x - bxr, eyr = e.xy.y - byr;                   // centre relative to the block origin
+        const ConicQ cq = conic_q(e.co.x, e.co.y, e.co.z);
         float M0 = 0.f, M1 = 0.f, M2 = 0.f, M3 = 0.f, M4 = 0.f, M5 = 0.f, M6 = 0.f, M7 = 0.f, M8 = 0.f;
 #pragma unroll 1
         for (int ky = 0; ky < (D3GA_SCAN_ABL == 6 ? 1 : 4); ++ky) {
@@ -196,13 +197,14 @@ __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
                 if constexpr (DUAL) pc[k] = *reinterpret_cast<const float4 *>(pixq + k * PIXF + 8);
             }
             const float dy = eyr - (float)ky;
+            const float tb = cq.b * dy, tc = (cq.c * dy) * dy;              // shared by the four pixels of the line
             float al[4], G[4], r[4], u[4], cgv[4], dx[4];
             bool valid[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 dx[k] = exr - (float)k;
                 bool ok;
-                splat_eval(dx[k], dy, e.co.x, e.co.y, e.co.z, e.co.w, al[k], G[k], ok);
+                splat_eval_q(dx[k], tb, tc, cq.a, e.co.w, al[k], G[k], ok);
                 valid[k] = ok & act & (e.pos <= __float_as_uint(pb[k].z));
                 al[k] = valid[k] ? al[k] : 0.f;
                 r[k] = __builtin_amdgcn_rcpf(1.0f - al[k]);
