@@ -20,7 +20,7 @@ if os.environ.get("D3GA_ALL_NOSLP"):                          # A/B: every trans
     FLAGS.append("-fno-slp-vectorize")
 if ABL:
     FLAGS.append("-DD3GA_SCAN_ABL=" + ABL)
-if os.environ.get("D3GA_DIAG"):            # diagnostic build (loop statistics, tools/diag_bwd.py); never the shipped one
+if os.environ.get("D3GA_DIAG"):            # diagnostic build (loop statistics and per-wave timeline, tools/diag_scan.py); never the shipped one
     FLAGS.append("-DD3GA_DIAG")
     if os.environ.get("D3GA_DIAG") == "counters":
         FLAGS.append("-DD3GA_DIAG_COUNTERS")

@@ -1,8 +1,8 @@
 // raster_composite_scan.hip -- compositing backward, entry-per-lane ("scan") formulation.
 //
-// The row-segmented backward of raster_composite.hip gives every LANE a pixel and every ITERATION a list entry: the nine
-// partial derivatives of that entry then have to be summed across the 16 lanes of the row (32 DPP instructions per
-// iteration) and meet in an LDS accumulator, and only ~8 of the 16 lanes of a row are inside the entry's footprint.
+// The round-1 backward gave every LANE a pixel and every ITERATION a list entry, like the forward: the nine partial
+// derivatives of that entry then had to be summed across the 16 lanes of the row (32 DPP instructions per iteration) and
+// meet in an LDS accumulator, and only ~8 of the 16 lanes of a row are inside the entry's footprint.
 // Here the roles are swapped.  A 16-lane DPP row still owns one 4x4 pixel block and walks that block's culled list (which
 // the FORWARD wrote: ImgBuf::blk_list), but 16 consecutive list entries sit in the 16 lanes and the row steps through the
 // block's 16 pixels:
@@ -306,4 +306,24 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
     return check_launch(s, prm->debug);
 }
 
+// test hook for the two row scans (d3ga_selftest_row_scan): lane l of every 16-lane row ends up with the inclusive sum /
+// product of lanes 0..l of its row; the four chains of one call carry x, 2x, 3x, 4x (sums) and 1+x/8, 1+x/4, ... (products)
+__global__ void row_scan_selftest_kernel(const float *__restrict__ in, float *__restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float x = in[i];
+    float a0 = x, a1 = 2.f * x, a2 = 3.f * x, a3 = 4.f * x;
+    row_scan_add4(a0, a1, a2, a3);
+    float m0 = 1.f + 0.125f * x, m1 = 1.f + 0.25f * x, m2 = 1.f + 0.375f * x, m3 = 1.f + 0.5f * x;
+    row_scan_mul4(m0, m1, m2, m3);
+    float *o = out + 8 * (size_t)i;
+    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = m0; o[5] = m1; o[6] = m2; o[7] = m3;
+}
+
 }  // namespace d3ga
+
+extern "C" int d3ga_selftest_row_scan(int n, const float *in, float *out, d3ga_stream_t stream) {
+    if (n <= 0 || (n % 256) != 0) return D3GA_E_SIZE;
+    if (!in || !out) return D3GA_E_NULL;
+    hipLaunchKernelGGL(d3ga::row_scan_selftest_kernel, dim3(n / 256), dim3(256), 0, (hipStream_t)stream, in, out, n);
+    return d3ga::check_launch((hipStream_t)stream, 0);
+}

@@ -258,9 +258,10 @@ int d3ga_ssim_l1_bwd(int32_t C, int32_t H, int32_t W, const float *img1, const f
                      const float *Dq1, const float *Dq12, const float *g, const float *g_l1, float *grad_img1,
                      d3ga_stream_t stream);
 
-/* Test hook, not part of the drop-in surface: the 64-lane reductions of the compositing backward.  n multiple of 256;
- * in (n) -> out (10*n/64): per wavefront w, out[10w+k] = sum_l ((k+1) in[l] + k/64) for k<9, out[10w+9] = sum_l in[l]. */
-int d3ga_selftest_wave_sum(int n, const float *in, float *out, d3ga_stream_t stream);
+/* Test hook, not part of the drop-in surface: the 16-lane DPP row scans of the compositing backward.  n multiple of
+ * 256; in (n) -> out (8n): for element i (lane l of its row), out[8i+k] = sum over lanes <= l of (k+1) in, k < 4, and
+ * out[8i+4+k] = product over lanes <= l of (1 + (k+1)/8 in). */
+int d3ga_selftest_row_scan(int n, const float *in, float *out, d3ga_stream_t stream);
 
 int d3ga_compute_bary(int P, int T, const float *points, const float *tetra_corners, float *barys,
                       int32_t *tetra_id, uint8_t *active, d3ga_stream_t stream);

@@ -22,20 +22,21 @@ def _cu(t, grad=False):
     return t.detach().to(DEV).clone().requires_grad_(grad)
 
 
-def test_library_loaded_and_wave_sum():
+def test_library_loaded_and_row_scans():
     import d3ga_amd
     from d3ga_amd._lib import check, dptr, stream_handle
     L = d3ga_amd.lib()
     assert L.d3ga_version() == 100
     x = torch.randn(256 * 8, device=DEV)
-    out = torch.full((256 * 8 // 64, 10), float("nan"), device=DEV)
-    check(L.d3ga_selftest_wave_sum(x.numel(), dptr(x), dptr(out), stream_handle()), "selftest")
+    out = torch.full((256 * 8, 8), float("nan"), device=DEV)
+    check(L.d3ga_selftest_row_scan(x.numel(), dptr(x), dptr(out), stream_handle()), "selftest")
     torch.cuda.synchronize()
-    xs = x.double().view(-1, 64)
-    k = torch.arange(9, device=DEV, dtype=torch.float64)
-    ref9 = (k + 1)[None] * xs.sum(1, keepdim=True) + k[None]          # sum_l ((k+1) x_l + k/64)
-    assert torch.allclose(out[:, :9].double(), ref9, atol=1e-3), (out[0], ref9[0])
-    assert torch.allclose(out[:, 9].double(), xs.sum(1), atol=1e-4)
+    xs = x.double().view(-1, 16)                                       # one DPP row per line
+    k = torch.arange(1, 5, device=DEV, dtype=torch.float64)
+    sums = (xs.cumsum(1)[..., None] * k).reshape(-1, 4)
+    prods = (1.0 + xs[..., None] * k / 8.0).cumprod(1).reshape(-1, 4)
+    assert torch.allclose(out[:, :4].double(), sums, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(out[:, 4:].double(), prods, rtol=1e-5, atol=1e-6)
 
 
 def test_cage_deform_matches_reference_golden(golden):

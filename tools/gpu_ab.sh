@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of composite variants inside one box: interleaved rounds.  usage: gpu_ab.sh "3 7 11 15" [test_variant]
+# A/B of composite variants inside one box: interleaved rounds.  usage: gpu_ab.sh "160 128 32" [test_variant]  (32 = work-ordered dispatch, 128 = exact cull)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-VARS=${1:-"3 15"}
+VARS=${1:-"160"}
 : > gpurun_out/ab.log
 for round in 1 2; do
  for v in $VARS; do
