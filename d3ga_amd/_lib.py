@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PATH = os.environ.get("D3GA_LIB_PATH") or os.path.join(_HERE, "libd3ga_hip.so")
 _lib = None
 ACC_STRIDE = 16          # D3GA_ACC_STRIDE (include/d3ga.h): floats per Gaussian in the screen-space gradient accumulator
+LOSS_PARTIALS = 2048     # D3GA_LOSS_PARTIALS (include/d3ga.h): floats of scratch behind a two-stage loss reduction
 
 
 class D3GAError(RuntimeError):
@@ -62,6 +63,7 @@ _SIGNATURES = {
     "d3ga_compute_bary_grid": ([_i] + [_vp] * 9 + [_vp], _i),
     "d3ga_knn3_mean_dist2_grid": ([_i] + [_vp] * 6 + [_vp], _i),
     "d3ga_l1_mean_fwd": ([_i64, _vp, _vp, _vp, _vp], _i),
+    "d3ga_l1_mean_fwd_ws": ([_i64, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_l1_mean_bwd": ([_i64, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_mlp_panel_bytes": ([ctypes.c_int32, ctypes.c_int32], _i64),
     "d3ga_mlp_pack_weights": ([ctypes.c_int32, ctypes.c_int32, _vp, _i64, _i64, _vp, _vp], _i),

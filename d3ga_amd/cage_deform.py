@@ -77,6 +77,7 @@ class _CageDeform(torch.autograd.Function):
               "d3ga_cage_deform_fwd_ex")
         ctx.flags = flags
         ctx.has_delta = delta_barys is not None
+        ctx.set_materialize_grads(False)                 # backward() fills in the gradient of an unused output itself
         ctx.save_for_backward(tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations,
                               delta_barys if delta_barys is not None else torch.empty(0, device=barys.device))
         return means, cov6

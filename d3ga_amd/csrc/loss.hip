@@ -14,10 +14,9 @@ __device__ __forceinline__ float wave_sum_loss(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(kBlock) void l1_mean_fwd_kernel(int64_t n4, int64_t n, const float *__restrict__ a,
-                                                             const float *__restrict__ b, float inv_n,
-                                                             float *__restrict__ out) {
-    __shared__ float s_part[kBlock / 64];
+// sum |a - b| of this workgroup's grid-stride share, times inv_n (every thread returns; thread 0 holds the value)
+__device__ __forceinline__ float l1_block_sum(int64_t n4, int64_t n, const float *__restrict__ a, const float *__restrict__ b,
+                                              float inv_n, float *s_part) {
     float acc = 0.f;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -35,11 +34,43 @@ __global__ __launch_bounds__(kBlock) void l1_mean_fwd_kernel(int64_t n4, int64_t
     acc = wave_sum_loss(acc);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
     __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) t += s_part[w];
+    }
+    return t * inv_n;
+}
+
+__global__ __launch_bounds__(kBlock) void l1_mean_fwd_kernel(int64_t n4, int64_t n, const float *__restrict__ a,
+                                                             const float *__restrict__ b, float inv_n,
+                                                             float *__restrict__ out) {
+    __shared__ float s_part[kBlock / 64];
+    const float t = l1_block_sum(n4, n, a, b, inv_n, s_part);
+    if (threadIdx.x == 0) atomicAdd(out, t);
+}
+
+// Two-stage form: one partial per workgroup (plain store), then ONE workgroup adds the partials in index order -- no zero
+// fill, no same-address atomics (2048 of them serialise for ~25 us), and the result does not depend on arrival order.
+__global__ __launch_bounds__(kBlock) void l1_mean_partial_kernel(int64_t n4, int64_t n, const float *__restrict__ a,
+                                                                 const float *__restrict__ b, float inv_n,
+                                                                 float *__restrict__ partials) {
+    __shared__ float s_part[kBlock / 64];
+    const float t = l1_block_sum(n4, n, a, b, inv_n, s_part);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(kBlock) void sum_partials_kernel(int np, const float *__restrict__ partials, float *__restrict__ out) {
+    __shared__ float s_part[kBlock / 64];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < np; i += kBlock) acc += partials[i];
+    acc = wave_sum_loss(acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
     if (threadIdx.x == 0) {
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; ++w) t += s_part[w];
-        atomicAdd(out, t * inv_n);
+        out[0] = t;
     }
 }
 
@@ -49,10 +80,19 @@ __global__ __launch_bounds__(kBlock) void l1_mean_bwd_kernel(int64_t n4, int64_t
     const float s = g[0] * inv_n;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     auto sgn = [](float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); };
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+    auto sgn4 = [&](const float4 &x, const float4 &y) {
+        return make_float4(s * sgn(x.x - y.x), s * sgn(x.y - y.y), s * sgn(x.z - y.z), s * sgn(x.w - y.w));
+    };
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {             // two independent 16-byte loads per array in flight
+        const float4 x0 = reinterpret_cast<const float4 *>(a)[i], y0 = reinterpret_cast<const float4 *>(b)[i];
+        const float4 x1 = reinterpret_cast<const float4 *>(a)[i + stride], y1 = reinterpret_cast<const float4 *>(b)[i + stride];
+        reinterpret_cast<float4 *>(grad_a)[i] = sgn4(x0, y0);
+        reinterpret_cast<float4 *>(grad_a)[i + stride] = sgn4(x1, y1);
+    }
+    for (; i < n4; i += stride) {
         const float4 x = reinterpret_cast<const float4 *>(a)[i], y = reinterpret_cast<const float4 *>(b)[i];
-        reinterpret_cast<float4 *>(grad_a)[i] =
-            make_float4(s * sgn(x.x - y.x), s * sgn(x.y - y.y), s * sgn(x.z - y.z), s * sgn(x.w - y.w));
+        reinterpret_cast<float4 *>(grad_a)[i] = sgn4(x, y);
     }
     for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
         grad_a[i] = s * sgn(a[i] - b[i]);
@@ -292,6 +332,19 @@ extern "C" int d3ga_l1_mean_fwd(int64_t n, const float *a, const float *b, float
     // few, fat workgroups: every workgroup ends with ONE float atomic on the same word, and same-address device-scope
     // atomics serialise at ~12 ns each (2048 of them cost more than streaming the two images)
     hipLaunchKernelGGL(l1_mean_fwd_kernel, dim3(loss_grid(n4, 512)), dim3(kBlock), 0, s, n4, n, a, b, 1.0f / (float)n, out);
+    return check_launch(s, 0);
+}
+
+extern "C" int d3ga_l1_mean_fwd_ws(int64_t n, const float *a, const float *b, float *out, float *partials,
+                                   d3ga_stream_t stream) {
+    if (n <= 0) return D3GA_E_SIZE;
+    if (!a || !b || !out || !partials) return D3GA_E_NULL;
+    if (((uintptr_t)a | (uintptr_t)b) & 15) return D3GA_E_CONFIG;       // 16-byte aligned inputs
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n4 = n / 4;
+    const int np = loss_grid(n4, D3GA_LOSS_PARTIALS);
+    hipLaunchKernelGGL(l1_mean_partial_kernel, dim3(np), dim3(kBlock), 0, s, n4, n, a, b, 1.0f / (float)n, partials);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, np, (const float *)partials, out);
     return check_launch(s, 0);
 }
 

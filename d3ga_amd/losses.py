@@ -20,8 +20,11 @@ class _L1Mean(torch.autograd.Function):
         b = f32c16(b)
         if a.shape != b.shape:
             raise ValueError(f"l1_loss: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
-        out = torch.empty((), dtype=torch.float32, device=a.device)
-        check(_lib.lib().d3ga_l1_mean_fwd(a.numel(), dptr(a), dptr(b), dptr(out), stream_handle()), "d3ga_l1_mean_fwd")
+        # [0]: the loss; [4:]: one partial sum per workgroup (two-stage reduction: no zero fill, no atomics, reproducible)
+        buf = torch.empty(4 + _lib.LOSS_PARTIALS, dtype=torch.float32, device=a.device)
+        out = buf[0]
+        check(_lib.lib().d3ga_l1_mean_fwd_ws(a.numel(), dptr(a), dptr(b), dptr(out), dptr(buf[4:]), stream_handle()),
+              "d3ga_l1_mean_fwd_ws")
         ctx.save_for_backward(a, b)
         return out
 

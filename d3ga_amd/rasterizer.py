@@ -268,6 +268,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img,
                               colors2, bg2)
         ctx.mark_non_differentiable(radii, invdepth)
+        ctx.set_materialize_grads(False)                 # no zero-filled (P,) / (H,W) gradients for radii / invdepth per step
         if dual:
             return color, radii, invdepth, color2
         if empty_pair:
