@@ -356,6 +356,19 @@ def deform_gpu_comparison(frame, reps=50):
     return res
 
 
+def usable_cpus():
+    """Hardware threads this process may actually use: the affinity mask, capped by a cgroup CPU quota if there is one
+    (os.cpu_count() reports the whole host inside a container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(wl_name, budget_s=20.0, threads=None):
     """The oracle (CPU port of the path) on this box's host cores: torch deform fwd+bwd + C rasterizer fwd+bwd."""
     from d3ga_amd import synthetic as syn
@@ -365,7 +378,7 @@ def cpu_baseline(wl_name, budget_s=20.0, threads=None):
     # threads actually used.  All hardware threads of the box are tried as well (budget split): on a 256-thread host torch's
     # intra-op pool and libgomp oversubscribe badly, so `value` / `cores` report the FASTER of the two settings and
     # `host_threads` / `all_threads_frames_per_s` state the other
-    host_threads = os.cpu_count() or 1
+    host_threads = usable_cpus()
     cores = min(host_threads, 32) if threads is None else threads
     torch.set_num_threads(cores)
     rc.set_threads(cores)
