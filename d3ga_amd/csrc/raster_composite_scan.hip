@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
 #ifdef D3GA_DIAG_COUNTERS
     // per-wave record only (one returning atomic for the slot): shared counters would serialise the start of 5401 waves
     const unsigned long long diag_t0 = __builtin_readcyclecounter(), diag_w0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long diag_slot = 0, diag_rowgroups = 0, diag_entries = 0;
+    unsigned long long diag_slot = 0, diag_rowgroups = 0, diag_entries = 0, diag_live = 0, diag_dups = 0;
     {
         const uint32_t c0 = __builtin_amdgcn_readlane(cnt, 0), c1 = __builtin_amdgcn_readlane(cnt, 16);
         const uint32_t c2 = __builtin_amdgcn_readlane(cnt, 32), c3 = __builtin_amdgcn_readlane(cnt, 48);
@@ -245,6 +245,16 @@ __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
         }
         scan_consume<DUAL>(nxt, pg2);                      // the loads issued at the top have landed (see above)
         __builtin_amdgcn_wave_barrier();
+#ifdef D3GA_DIAG_COUNTERS
+        {   // how many of this flush's entries are the same Gaussian as an entry of a LOWER row (a merge would save their line)
+            const uint32_t mygid = e.gid;
+            bool dup = false;
+            for (int o = 0; o < 16 * rg.row; ++o) dup = dup || (__float_as_uint(s_stage[o * kStageStride + 9]) == mygid && s_stage[o * kStageStride + 5] != 0.f);
+            const bool live = act && M5 != 0.f;
+            diag_live += __popcll(__ballot(live));
+            diag_dups += __popcll(__ballot(live && dup));
+        }
+#endif
         float fval[10];
         uint32_t fgid[10];
 #pragma unroll
@@ -266,6 +276,7 @@ __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
         pg1 = pg2;
     }
 #ifdef D3GA_DIAG_COUNTERS
+    if (lane == 0) { atomicAdd(&g_diag_scan[1], diag_live); atomicAdd(&g_diag_scan[2], diag_dups); }
     if (lane == 0 && diag_slot < 32768) {
         g_diag_waves[4 * diag_slot] = diag_w0 | ((__builtin_readcyclecounter() - diag_t0) << 40);   // 100 MHz wall | s_memtime duration
         g_diag_waves[4 * diag_slot + 1] = __builtin_amdgcn_s_memrealtime();

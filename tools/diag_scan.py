@@ -30,6 +30,7 @@ print("stage times of the measured step (ms):", {k: round(v[1], 4) for k, v in R
 R.stage_timer.enabled = False
 assert L.d3ga_diag_scan_read(out, 1) == 0
 w = int(out[0])
+print('flushed entries with a gradient:', int(out[1]), '| of them also present in a lower row of the same flush:', int(out[2]))
 print("active waves", w)
 # per-wave timeline (s_memtime ticks): when do waves start / end, how long does a group take, how busy is each SIMD
 import numpy as np
