@@ -44,6 +44,36 @@ __device__ __forceinline__ void sh_slab_store(const float *slab, float *__restri
     }
 }
 
+// The common case -- full rows of 48 floats (M = 16) and a full set of ROWS rows -- with every load of the set in flight at
+// once: the loop above is one load -> wait -> LDS store per iteration (an integer division by the run-time row length
+// sits between them), i.e. ROWS*12/64 memory round trips in series per wavefront, and that chain, not bandwidth, set the
+// pace of both per-Gaussian kernels (preprocess 53 -> .. us, preprocess_bwd 58 -> .. us at C3).
+template <int ROWS>
+struct ShRegs { float4 v[ROWS * 12 / 64]; };
+template <int ROWS>
+__device__ __forceinline__ ShRegs<ROWS> sh_rows48_load(const float *__restrict__ src, int lane) {
+    ShRegs<ROWS> r;
+#pragma unroll
+    for (int k = 0; k < ROWS * 12 / 64; ++k) r.v[k] = reinterpret_cast<const float4 *>(src)[lane + 64 * k];
+    return r;
+}
+template <int ROWS>
+__device__ __forceinline__ void sh_rows48_to_slab(float *slab, const ShRegs<ROWS> &r, int lane) {
+#pragma unroll
+    for (int k = 0; k < ROWS * 12 / 64; ++k) {
+        const int e = 4 * (lane + 64 * k), row = e / 48, c = e - row * 48;
+        *reinterpret_cast<float4 *>(slab + row * kShRow + c) = r.v[k];
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void sh_rows48_store(const float *slab, float *__restrict__ dst, int lane) {
+#pragma unroll
+    for (int k = 0; k < ROWS * 12 / 64; ++k) {
+        const int e = 4 * (lane + 64 * k), row = e / 48, c = e - row * 48;
+        reinterpret_cast<float4 *>(dst)[lane + 64 * k] = *reinterpret_cast<const float4 *>(slab + row * kShRow + c);
+    }
+}
+
 // forward staging (see preprocess_kernel): half of a wavefront's rows at a time
 constexpr int kShHalfSlab = 32 * kShRow;
 constexpr size_t kShHalfLdsBytes = (size_t)(kBlock / 64) * kShHalfSlab * sizeof(float);      // 26,624 B per block
@@ -64,6 +94,21 @@ __device__ __forceinline__ void staged_sh_colour(const d3ga_raster_params &prm, 
     const int rows = min(64, prm.P - row0);
     const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
     float B[16];
+    if (M3 == 48 && rows == 64) {                              // wave-uniform: a full wavefront of full rows
+        // both halves' loads are issued up front (the second half waits in registers while the first is evaluated)
+        const ShRegs<32> h0 = sh_rows48_load<32>(shs + (size_t)48 * row0, lane);
+        const ShRegs<32> h1 = sh_rows48_load<32>(shs + (size_t)48 * (row0 + 32), lane);
+        sh_view_basis(prm, means3D, i, campos, B);
+        __builtin_amdgcn_wave_barrier();
+        sh_rows48_to_slab<32>(slab, h0, lane);
+        __builtin_amdgcn_wave_barrier();
+        if ((lane >> 5) == 0) sh_accumulate(B, slab + (lane & 31) * kShRow, 0, 16, nb, acc);
+        __builtin_amdgcn_wave_barrier();
+        sh_rows48_to_slab<32>(slab, h1, lane);
+        __builtin_amdgcn_wave_barrier();
+        if ((lane >> 5) == 1) sh_accumulate(B, slab + (lane & 31) * kShRow, 0, 16, nb, acc);
+        return;
+    }
     if (i < prm.P) sh_view_basis(prm, means3D, i, campos, B);
     for (int h = 0; h < 2; ++h) {
         const int r = min(32, rows - 32 * h);
@@ -217,8 +262,10 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const int row0 = blockIdx.x * kBlock + wave * 64;
     const int rows = min(64, prm.P - row0);
     float *slab = s_sh + wave * kShSlab;
+    const bool full48 = M3 == 48 && rows == 64;                 // wave-uniform
     if (staged) {
-        if (rows > 0) sh_slab_load(slab, shs + (size_t)M3 * row0, rows, M3, lane);
+        if (full48) sh_rows48_to_slab<64>(slab, sh_rows48_load<64>(shs + (size_t)48 * row0, lane), lane);
+        else if (rows > 0) sh_slab_load(slab, shs + (size_t)M3 * row0, rows, M3, lane);
         __syncthreads();
     }
     if (i < prm.P) {
@@ -254,7 +301,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     }
     if (staged && dL_dsh) {
         __syncthreads();
-        if (rows > 0) sh_slab_store(slab, dL_dsh + (size_t)M3 * row0, rows, M3, lane);
+        if (full48) sh_rows48_store<64>(slab, dL_dsh + (size_t)48 * row0, lane);
+        else if (rows > 0) sh_slab_store(slab, dL_dsh + (size_t)M3 * row0, rows, M3, lane);
     }
 }
 
