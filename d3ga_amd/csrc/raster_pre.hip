@@ -136,6 +136,14 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     const int M3 = 3 * prm.M;
     const bool staged = shs != nullptr && sh_staged(prm.M);
     float acc[3] = {0.f, 0.f, 0.f};
+    // covariance row and opacity: in flight while the SH rows are staged
+    float pc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pop = 0.f;
+    const bool pre = staged && cov3D_precomp != nullptr;
+    if (pre && i < prm.P) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pc6[k] = cov3D_precomp[6 * (size_t)i + k];
+        pop = opacities[i];
+    }
     if (staged) {
         staged_sh_colour(prm, means3D, shs, campos, s_sh, acc);
         __syncthreads();                                            // the region becomes the tile window below
@@ -148,7 +156,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     if (i < prm.P) {
         // two call sites so that each inlined copy sees ONE address space (registers vs global_load, never flat)
         const PreOut o = staged ? preprocess_one(prm, i, means3D, nullptr, colors_precomp, opacities, scales, rotations,
-                                                 cov3D_precomp, viewmatrix, projmatrix, campos, acc)
+                                                 cov3D_precomp, viewmatrix, projmatrix, campos, acc, pre ? pc6 : nullptr,
+                                                 pre ? &pop : nullptr)
                                 : preprocess_one(prm, i, means3D, shs ? shs + (size_t)M3 * i : nullptr, colors_precomp,
                                                  opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                                                  campos);
@@ -263,41 +272,51 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const int rows = min(64, prm.P - row0);
     float *slab = s_sh + wave * kShSlab;
     const bool full48 = M3 == 48 && rows == 64;                 // wave-uniform
+    // This Gaussian's records first, unconditionally (an invisible one has an all-zero accumulator row and a valid
+    // covariance row): they are in flight together with the SH rows instead of two dependent round trips behind them.
+    uint2 rc = make_uint2(0u, 0u);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+    float a[12], c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint8_t clampmask = 0;
+    float act_opacity = 0.f;
+    if (i < prm.P) {
+        rc = geom.rect[i];
+        const float4 *ap = reinterpret_cast<const float4 *>(acc + D3GA_ACC_STRIDE * (size_t)i);
+        a0 = ap[0]; a1 = ap[1]; a2 = ap[2];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = geom.cov3D[6 * (size_t)i + k];
+        clampmask = geom.clamped[i];
+        act_opacity = geom.conic_o[i].w;
+    }
     if (staged) {
         if (full48) sh_rows48_to_slab<64>(slab, sh_rows48_load<64>(shs + (size_t)48 * row0, lane), lane);
         else if (rows > 0) sh_slab_load(slab, shs + (size_t)M3 * row0, rows, M3, lane);
         __syncthreads();
     }
     if (i < prm.P) {
-        const uint2 rc = geom.rect[i];
         const bool visible = ((rc.y & 0xffffu) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.x >> 16));
-        float a[12], c6[6];
-        if (visible) {
-            const float4 *ap = reinterpret_cast<const float4 *>(acc + D3GA_ACC_STRIDE * (size_t)i);
-            const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
-            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
-            a[8] = a2.x; a[9] = a2.y; a[10] = a2.z; a[11] = a2.w;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) c6[k] = geom.cov3D[6 * (size_t)i + k];
-        } else {
+        a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+        a[8] = a2.x; a[9] = a2.y; a[10] = a2.z; a[11] = a2.w;
+        if (!visible) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) a[k] = 0.f;
 #pragma unroll
             for (int k = 0; k < 6; ++k) c6[k] = 0.f;
+            act_opacity = 0.f;
         }
         // two call sites so that each inlined copy sees ONE address space (LDS row vs global row, never flat);
         // staged: the gradient row overwrites the coefficient row in place
         if (staged)
             preprocess_bwd_one(prm, i, visible, means3D, slab + lane * kShRow, scales, rotations, viewmatrix, projmatrix,
-                               campos, c6, geom.clamped[i], a, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
+                               campos, c6, clampmask, a, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
                                dL_dsh ? slab + lane * kShRow : nullptr, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots,
-                               visible ? geom.conic_o[i].w : 0.f);
+                               act_opacity);
         else
             preprocess_bwd_one(prm, i, visible, means3D, shs ? shs + (size_t)M3 * i : nullptr, scales, rotations,
-                               viewmatrix, projmatrix, campos, c6, geom.clamped[i], a, dL_dmeans3D, dL_dmeans2D,
+                               viewmatrix, projmatrix, campos, c6, clampmask, a, dL_dmeans3D, dL_dmeans2D,
                                dL_dopacity, dL_dsh ? dL_dsh + (size_t)M3 * i : nullptr, dL_dcolors, dL_dcov3D,
                                dL_dscales, dL_drots,
-                               visible ? geom.conic_o[i].w : 0.f);
+                               act_opacity);
     }
     if (staged && dL_dsh) {
         __syncthreads();

@@ -36,13 +36,20 @@ D3GA_HD void sh_accumulate(const float B[16], const float *part, int k0, int k1,
 // R1 for Gaussian i.  Exactly one of (sh_row|sh_acc|colors_precomp), ((scales,rotations)|cov3D_precomp) is non-null.
 // sh_row points at THIS Gaussian's 3*M SH floats (in global memory or in an LDS staging row); alternatively sh_acc
 // holds the already evaluated sum_k Y_k(dir) * coeff_k (3 floats, see sh_view_basis / sh_accumulate).
+// pre_c6 / pre_op: this Gaussian's covariance row and raw opacity if the caller has loaded them already (the kernel issues
+// those loads before it stages the SH rows).  The opacity is read unconditionally: behind the visibility test it would be
+// one more dependent memory round trip per wavefront.
 D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float *means3D, const float *sh_row,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
-                              const float *projmatrix, const float *campos, const float *sh_acc = nullptr) {
+                              const float *projmatrix, const float *campos, const float *sh_acc = nullptr,
+                              const float *pre_c6 = nullptr, const float *pre_op = nullptr) {
     PreOut o;
     const V3 mean = ld3(means3D, i);
-    if (cov3D_precomp) {
+    const float raw_opacity = pre_op ? *pre_op : opacities[i];
+    if (pre_c6) {
+        for (int k = 0; k < 6; ++k) o.c6[k] = pre_c6[k];
+    } else if (cov3D_precomp) {
         for (int k = 0; k < 6; ++k) o.c6[k] = cov3D_precomp[6 * (size_t)i + k];
     } else {
         const float s[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
@@ -55,7 +62,7 @@ D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float 
     o.clampmask = 0;
     o.opacity = 0.f;
     if (!o.sp.visible) return o;
-    o.opacity = opacities[i];
+    o.opacity = raw_opacity;
     if (prm.opacity_activation == D3GA_OPACITY_SIGMOID) o.opacity = 1.0f / (1.0f + expf(-o.opacity));   // cage_net.py:247
     if (!(o.opacity == o.opacity)) {         // NaN opacity: min(0.99, NaN * G) would evaluate to 0.99 -- cull instead
         o.sp.visible = false; o.sp.radius = 0;
