@@ -23,7 +23,7 @@
 #include "composite_common.h"
 
 // D3GA_SCAN_ABL: timing ablations of the kernel below (diagnostic builds only, results are WRONG; tools/gpu_ablate.sh):
-//   1 no atomics | 6 one of the four pixel lines and no atomics | 7 plain stores instead of atomics
+//   1 no atomics | 6 one of the four pixel lines and no atomics | 7 plain stores instead of atomics | 11 no merge of the rows' duplicates
 #ifndef D3GA_SCAN_ABL
 #define D3GA_SCAN_ABL 0
 #endif
@@ -89,7 +89,8 @@ __device__ __forceinline__ void scan_consume(ScanEntry &e, uint2 &pg) {
     if constexpr (DUAL) asm volatile("" : "+v"(e.c2r), "+v"(e.c2g), "+v"(e.c2b));
 }
 
-constexpr int kStageStride = 12;     // floats per entry in the flush staging area: nine values, the id, two pads
+constexpr int kStageStride = 12;     // floats per entry in the flush staging area: nine values, the id, the list position, a pad
+constexpr uint32_t kNoGaussian = 0xffffffffu;   // id of a staged entry that was merged into a lower row's
 
 template <bool DUAL>
 __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
@@ -235,13 +236,14 @@ __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
             }
         }
         // publish: per-entry constants, then nine consecutive lanes per entry
+        const float v0 = -(e.co.x * M0 + e.co.y * M1) * ddelx_dx;
+        const float v1 = -(e.co.z * M1 + e.co.y * M0) * ddely_dy;
+        const float4 va = make_float4(v0, v1, -0.5f * M2, -0.5f * M3), vb = make_float4(-0.5f * M4, M5, M6, M7);
         {
             float *st = s_stage + lane * kStageStride;
-            const float v0 = -(e.co.x * M0 + e.co.y * M1) * ddelx_dx;
-            const float v1 = -(e.co.z * M1 + e.co.y * M0) * ddely_dy;
-            *reinterpret_cast<float4 *>(st) = make_float4(v0, v1, -0.5f * M2, -0.5f * M3);
-            *reinterpret_cast<float4 *>(st + 4) = make_float4(-0.5f * M4, M5, M6, M7);
-            *reinterpret_cast<float4 *>(st + 8) = make_float4(M8, __uint_as_float(e.gid), 0.f, 0.f);
+            *reinterpret_cast<float4 *>(st) = va;
+            *reinterpret_cast<float4 *>(st + 4) = vb;
+            *reinterpret_cast<float4 *>(st + 8) = make_float4(M8, __uint_as_float(e.gid), __uint_as_float(e.pos), 0.f);
         }
         scan_consume<DUAL>(nxt, pg2);                      // the loads issued at the top have landed (see above)
         __builtin_amdgcn_wave_barrier();
@@ -255,6 +257,45 @@ __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
             diag_dups += __popcll(__ballot(live && dup));
         }
 #endif
+        if (D3GA_SCAN_ABL != 11) {
+            // Merge the rows' copies of one Gaussian before they leave the CU.  What bounds this kernel is the number of 64-byte
+            // accumulator lines it sends to the memory-side atomic units; the four rows walk subsets of ONE
+            // depth-ordered tile list roughly in step, so 18 % of a flush's entries (C3) are a Gaussian that a lower row
+            // publishes in the same flush.  Rows 1..3 look their position up in each lower row (binary search over the row's 16
+            // staged positions: descending, 0 = no entry), add their nine values to the first match and retire their own entry.
+            // One SOURCE row per phase (its lanes hold distinct Gaussians, so they hit distinct targets and a plain LDS
+            // read-add-write is safe); the lower rows are searched in order, so a Gaussian ends up in the lowest row that has it.
+#pragma unroll
+            for (int sr = 1; sr < 4; ++sr) {
+                if (rg.row == sr && act) {
+                    int found = -1;
+#pragma unroll
+                    for (int tr = 0; tr < sr; ++tr) {
+                        const float *const trow = s_stage + (16 * tr) * kStageStride;
+                        int j = 0;
+                        uint32_t aj = __float_as_uint(trow[10]);
+#pragma unroll
+                        for (int sft = 8; sft >= 1; sft >>= 1) {
+                            const uint32_t t = __float_as_uint(trow[(j + sft) * kStageStride + 10]);
+                            if (t >= e.pos) { j += sft; aj = t; }
+                        }
+                        if (found < 0 && aj == e.pos) found = 16 * tr + j;
+                    }
+                    if (found >= 0) {
+                        float *tg = s_stage + found * kStageStride;
+                        float4 ta = *reinterpret_cast<float4 *>(tg), tb = *reinterpret_cast<float4 *>(tg + 4);
+                        const float t8 = tg[8];
+                        ta.x += va.x; ta.y += va.y; ta.z += va.z; ta.w += va.w;
+                        tb.x += vb.x; tb.y += vb.y; tb.z += vb.z; tb.w += vb.w;
+                        *reinterpret_cast<float4 *>(tg) = ta;
+                        *reinterpret_cast<float4 *>(tg + 4) = tb;
+                        tg[8] = t8 + M8;
+                        s_stage[lane * kStageStride + 9] = __uint_as_float(kNoGaussian);       // the flush skips this entry
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
         float fval[10];
         uint32_t fgid[10];
 #pragma unroll
@@ -266,7 +307,7 @@ __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
 #pragma unroll
         for (int it = 0; it < 10; ++it) {
             const bool mine = it == 9 ? fq == 0 : fq < 7;
-            if (D3GA_SCAN_ABL != 1 && D3GA_SCAN_ABL != 6 && mine && fval[it] != 0.f) {
+            if (D3GA_SCAN_ABL != 1 && D3GA_SCAN_ABL != 6 && mine && fval[it] != 0.f && fgid[it] != kNoGaussian) {
                 if (D3GA_SCAN_ABL == 7) acc[kAccStride * (size_t)fgid[it] + fk_off] = fval[it];          // plain store instead of the atomic
                 else atomicAdd(acc + kAccStride * (size_t)fgid[it] + fk_off, fval[it]);
             }
