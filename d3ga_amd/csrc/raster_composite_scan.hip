@@ -23,7 +23,8 @@
 #include "composite_common.h"
 
 // D3GA_SCAN_ABL: timing ablations of the kernel below (diagnostic builds only, results are WRONG; tools/gpu_ablate.sh):
-//   1 no atomics | 6 one of the four pixel lines and no atomics | 7 plain stores instead of atomics | 11 no merge of the rows' duplicates
+//   1 no atomics | 6 one of the four pixel lines and no atomics | 7 plain stores instead of atomics |
+//   8 every atomic but no pixel steps | 11 no merge of the rows' duplicates
 #ifndef D3GA_SCAN_ABL
 #define D3GA_SCAN_ABL 0
 #endif
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
         const ConicQ cq = conic_q(e.co.x, e.co.y, e.co.z);
         float M0 = 0.f, M1 = 0.f, M2 = 0.f, M3 = 0.f, M4 = 0.f, M5 = 0.f, M6 = 0.f, M7 = 0.f, M8 = 0.f;
 #pragma unroll 1
-        for (int ky = 0; ky < (D3GA_SCAN_ABL == 6 ? 1 : 4); ++ky) {
+        for (int ky = 0; ky < (D3GA_SCAN_ABL == 6 ? 1 : (D3GA_SCAN_ABL == 8 ? 0 : 4)); ++ky) {
             // the four pixels of block line ky, side by side (independent until the carries are written back)
             const float *const pixq = pixrow + ky * 4 * PIXF;
             float4 pa[4], pb[4], pc[4];
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
                 *reinterpret_cast<float2 *>(wq + k * PIXF) = make_float2(Ti[k], Sin[k]);
             }
         }
+        if (D3GA_SCAN_ABL == 8 && act) { M0 = M1 = M2 = M3 = M4 = M5 = M6 = M7 = M8 = 1.0f; }   // ablation: every atomic, no arithmetic
         // publish: per-entry constants, then nine consecutive lanes per entry
         const float v0 = -(e.co.x * M0 + e.co.y * M1) * ddelx_dx;
         const float v1 = -(e.co.z * M1 + e.co.y * M0) * ddely_dy;
