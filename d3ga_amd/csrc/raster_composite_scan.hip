@@ -24,7 +24,7 @@
 
 // D3GA_SCAN_ABL: timing ablations of the kernel below (diagnostic builds only, results are WRONG; tools/gpu_ablate.sh):
 //   1 no atomics | 6 one of the four pixel lines and no atomics | 7 plain stores instead of atomics |
-//   8 every atomic but no pixel steps | 11 no merge of the rows' duplicates
+//   8 every atomic but no pixel steps | 11 no merge of the rows' duplicates | 12 rows not paced
 #ifndef D3GA_SCAN_ABL
 #define D3GA_SCAN_ABL 0
 #endif
@@ -149,13 +149,18 @@ __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
     const int fk_off = fk < 2 ? fk : fk + 1;               // acc layout 0,1 | 3,4,5 | 6 | 7,8,9
     constexpr int kAccStride = D3GA_ACC_STRIDE;
 
-    // back to front: group g holds list entries cnt-1-16g ... cnt-16-16g, lane l the entry cnt-1-16g-l
+    // Back to front, all four rows PACED TO FINISH TOGETHER: the wavefront runs as many groups as its longest list needs
+    // anyway, so a shorter list hands out per = ceil(cnt / ngroups) <= 16 entries per group instead of 16 until it runs dry.
+    // The four lists are subsets of one depth-ordered tile list; at equal fractions of their length they are at (nearly) the
+    // same depth, so the copies of a Gaussian in different rows meet in the same flush, where they are merged (below).
+    // Group g holds list entries cnt-1-per*g ... (per of them), lane l < per the entry cnt-1-per*g-l.
     // (unconditional load from a clamped index + select: a load under a branch makes the compiler copy the result into the
     // merge register right behind the load, i.e. wait for it on the spot)
+    const int per = D3GA_SCAN_ABL == 12 ? 16 : (ngroups > 0 ? ((int)cnt + ngroups - 1) / ngroups : 0);
     auto list_entry = [&](int g) -> uint2 {
-        const int idx = (int)cnt - 1 - 16 * g - l16;
+        const int idx = (int)cnt - 1 - per * g - l16;
         uint2 v = list[max(idx, 0)];
-        v.x = idx >= 0 ? v.x : 0u;
+        v.x = (idx >= 0 && l16 < per) ? v.x : 0u;
         return v;
     };
 #ifdef D3GA_DIAG_COUNTERS
