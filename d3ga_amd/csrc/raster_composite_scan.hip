@@ -16,6 +16,9 @@
 //     LDS atomics.  After the 16 steps the per-entry constants are applied once (conic, -1/2, NDC scale) and the group is
 //     published through an LDS transpose: nine consecutive lanes write one entry (36 contiguous bytes, two memory-side
 //     atomic requests), seven entries per instruction.
+//   * what bounds the kernel is the number of 64-byte accumulator lines it sends to the memory-side atomic units (DESIGN.md
+//     sec. 4: with the arithmetic removed it takes as long), so the four rows are paced to reach the same depth together and
+//     the copies of a Gaussian that meet in one flush are merged in LDS first (28 % of the entries at C3).
 // Instructions per (entry, 4x4 block) pair: ~16 x 58 / 16 + ~7 = 65, against ~100 per (entry, block) visit before -- and a
 // visit used to occupy a whole wavefront iteration in which on average 2.6 of the 4 rows had an entry at all.
 // alpha is evaluated by the same splat_eval_q() as the forward and the validity test is the forward's (power <= 0,
