@@ -273,35 +273,36 @@ __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
             // depth-ordered tile list roughly in step, so 18 % of a flush's entries (C3) are a Gaussian that a lower row
             // publishes in the same flush.  Rows 1..3 look their position up in each lower row (binary search over the row's 16
             // staged positions: descending, 0 = no entry), add their nine values to the first match and retire their own entry.
-            // One SOURCE row per phase (its lanes hold distinct Gaussians, so they hit distinct targets and a plain LDS
-            // read-add-write is safe); the lower rows are searched in order, so a Gaussian ends up in the lowest row that has it.
+            // All rows search at once (a search only reads positions); then one SOURCE row per phase adds its entries to their
+            // targets (its lanes hold distinct Gaussians, so they hit distinct entries and a plain LDS read-add-write is safe).
+            // The lower rows are searched in order, so a Gaussian ends up in the lowest row that has it.
+            int found = -1;
+#pragma unroll
+            for (int tr = 0; tr < 3; ++tr) {
+                if (rg.row > tr && act) {
+                    const float *const trow = s_stage + (16 * tr) * kStageStride;
+                    int j = 0;
+                    uint32_t aj = __float_as_uint(trow[10]);
+#pragma unroll
+                    for (int sft = 8; sft >= 1; sft >>= 1) {
+                        const uint32_t t = __float_as_uint(trow[(j + sft) * kStageStride + 10]);
+                        if (t >= e.pos) { j += sft; aj = t; }
+                    }
+                    if (found < 0 && aj == e.pos) found = 16 * tr + j;
+                }
+            }
 #pragma unroll
             for (int sr = 1; sr < 4; ++sr) {
-                if (rg.row == sr && act) {
-                    int found = -1;
-#pragma unroll
-                    for (int tr = 0; tr < sr; ++tr) {
-                        const float *const trow = s_stage + (16 * tr) * kStageStride;
-                        int j = 0;
-                        uint32_t aj = __float_as_uint(trow[10]);
-#pragma unroll
-                        for (int sft = 8; sft >= 1; sft >>= 1) {
-                            const uint32_t t = __float_as_uint(trow[(j + sft) * kStageStride + 10]);
-                            if (t >= e.pos) { j += sft; aj = t; }
-                        }
-                        if (found < 0 && aj == e.pos) found = 16 * tr + j;
-                    }
-                    if (found >= 0) {
-                        float *tg = s_stage + found * kStageStride;
-                        float4 ta = *reinterpret_cast<float4 *>(tg), tb = *reinterpret_cast<float4 *>(tg + 4);
-                        const float t8 = tg[8];
-                        ta.x += va.x; ta.y += va.y; ta.z += va.z; ta.w += va.w;
-                        tb.x += vb.x; tb.y += vb.y; tb.z += vb.z; tb.w += vb.w;
-                        *reinterpret_cast<float4 *>(tg) = ta;
-                        *reinterpret_cast<float4 *>(tg + 4) = tb;
-                        tg[8] = t8 + M8;
-                        s_stage[lane * kStageStride + 9] = __uint_as_float(kNoGaussian);       // the flush skips this entry
-                    }
+                if (rg.row == sr && found >= 0) {
+                    float *tg = s_stage + found * kStageStride;
+                    float4 ta = *reinterpret_cast<float4 *>(tg), tb = *reinterpret_cast<float4 *>(tg + 4);
+                    const float t8 = tg[8];
+                    ta.x += va.x; ta.y += va.y; ta.z += va.z; ta.w += va.w;
+                    tb.x += vb.x; tb.y += vb.y; tb.z += vb.z; tb.w += vb.w;
+                    *reinterpret_cast<float4 *>(tg) = ta;
+                    *reinterpret_cast<float4 *>(tg + 4) = tb;
+                    tg[8] = t8 + M8;
+                    s_stage[lane * kStageStride + 9] = __uint_as_float(kNoGaussian);       // the flush skips this entry
                 }
                 __builtin_amdgcn_wave_barrier();
             }
