@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     if (staged) {
         if (full48) sh_rows48_to_slab<64>(slab, sh_rows48_load<64>(shs + (size_t)48 * row0, lane), lane);
         else if (rows > 0) sh_slab_load(slab, shs + (size_t)M3 * row0, rows, M3, lane);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();          // the slab is private to the wavefront: program order suffices
     }
     if (i < prm.P) {
         const bool visible = ((rc.y & 0xffffu) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.x >> 16));
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
                                act_opacity);
     }
     if (staged && dL_dsh) {
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();          // the slab is private to the wavefront: program order suffices
         if (full48) sh_rows48_store<64>(slab, dL_dsh + (size_t)48 * row0, lane);
         else if (rows > 0) sh_slab_store(slab, dL_dsh + (size_t)M3 * row0, rows, M3, lane);
     }
