@@ -50,6 +50,9 @@ def parse():
                          "backward at the workload's Gaussian count, roofline against the f32 MFMA peak")
     ap.add_argument("--no-graph", action="store_true",
                     help="time eager launches instead of replaying the captured hipGraph of one step")
+    ap.add_argument("--force-cut", action="store_true",
+                    help="diagnostic, one GPU: run the N>1 step (cut exchange over a one-rank nccl group, two hipGraphs) to "
+                         "measure what the camera-sharded step costs per rank apart from the wire time")
     ap.add_argument("--graph-collectives", action="store_true",
                     help="N>1: capture the step INCLUDING the gradient exchange (RCCL collectives) in the hipGraph")
     ap.add_argument("--fixed-camera", action="store_true",
@@ -119,20 +122,26 @@ class Frame:
         self.target = self.target.clone()
         return self.views
 
-    def step(self):
+    def upstream(self):
+        """Parameters -> what enters the rasterizer (view-independent: the same on every rank of a camera-sharded run)."""
         from d3ga_amd.cage_deform import cage_deform, lbs_cage
-        from d3ga_amd.losses import l1_loss
-        from d3ga_amd.renderer import render
         p = self.params
         tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
         # canon_barys = barys + delta_bary, scales = exp(scaling) (cage_net.py:213-214): fused into the deform kernels
         means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad, p["scaling"],
                                   p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp")
         # opacity = sigmoid(opacities) (cage_net.py:247): fused into the per-Gaussian kernels (pkg["opacity_logits"])
-        pkg = {"means3D": means, "cov3D_precomp": cov6, "opacity_logits": p["opacity"],
-               "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
+        return {"means3D": means, "cov3D_precomp": cov6, "opacity_logits": p["opacity"],
+                "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
+
+    def loss_from(self, pkg):
+        from d3ga_amd.losses import l1_loss
+        from d3ga_amd.renderer import render
         img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
-        loss = l1_loss(img, self.target)              # fused mean |img - target| (utils/loss_utils.py:29)
+        return l1_loss(img, self.target)              # fused mean |img - target| (utils/loss_utils.py:29)
+
+    def step(self):
+        loss = self.loss_from(self.upstream())
         loss.backward()
         return loss
 
@@ -537,8 +546,14 @@ def main():
     frame = Frame(args.workload, dev, view_index=rank % 8, scale_mult=args.scale_mult, fill=args.fill)
     flat = ddist.GradReducer(list(frame.params.values()))
     cut = world > 1 and args.reduce == "cut"
+    if args.force_cut and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+        cut, args.fixed_camera = True, True
     if cut:
         frame.grad_sync = ddist.ViewShardedGrads(timing=True)   # gradients leave the rasterizer already averaged over the ranks
+        frame.grad_sync.always = args.force_cut
     # N = 1: the step follows the trainer -- a NEW camera and target every step (datasets/actorshq_dataset.py:229), written
     # into the static slots of ONE captured hipGraph (d3ga_amd/graph.py).  N > 1: every rank keeps its own view (camera
     # sharding: the views of one pose are spread over the ranks).
@@ -594,7 +609,20 @@ def main():
     # --graph-collectives captures them too (RCCL supports capture; verified here only on a one-rank group,
     # tests/test_gpu_view_sharded.py -- the 8-GPU run keeps the conservative default).
     graph = None
-    if not args.no_graph and (world == 1 or args.graph_collectives):
+    if not args.no_graph and cut and not args.graph_collectives and not args.single_device:
+        # (--single-device puts several ranks on ONE GPU for functional checks: their graph launches are time-sliced by the
+        # driver in ~100 ms quanta and every later launch of the process suffers -- eager there)
+        # N > 1 with the cut exchange: TWO graphs, the collectives issued eagerly between them (d3ga_amd/graph.py:
+        # CapturedCutStep) -- no collective is captured, and the step is no longer bound by the host
+        from d3ga_amd.graph import CapturedCutStep
+        try:
+            graph = CapturedCutStep(frame.upstream, frame.loss_from, frame.grad_sync, params=list(frame.params.values()))
+            exchange_note = (exchange_note or "") + " step captured as two hipGraphs around the eager exchange"
+        except Exception as e:  # noqa: BLE001
+            exchange_note = (exchange_note or "") + f" two-graph capture of the N>1 step failed ({type(e).__name__}: {e}); eager"
+            print(f"[bench] rank {rank}: {exchange_note}", file=sys.stderr)
+            graph = None
+    elif not args.no_graph and (world == 1 or args.graph_collectives):
         from d3ga_amd.graph import CapturedStep
         try:
             graph = CapturedStep(frame.step, params=list(frame.params.values()),
@@ -618,6 +646,31 @@ def main():
             flat.zero()
             frame.step()
         reduce_params()
+
+    if graph is not None and hasattr(graph, "graph_b"):
+        # Two graphs + eager collectives, or everything eager?  The two-graph step saves the host ~0.45 ms of launches per step
+        # but pays two graph launches; which one wins depends on the size (measured on one GPU over a one-rank nccl group: C3
+        # 0.61 vs 0.57 ms, the smaller configurations the other way round).  Time both (all ranks in step, slowest rank counts)
+        # and keep the faster.
+        def probe(g, n=12):
+            nonlocal graph
+            keep, graph = graph, g
+            for _ in range(3):
+                timed_step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                timed_step()
+            barrier()
+            dt = torch.tensor([time.perf_counter() - t0], device=dev)
+            if world > 1:
+                torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+            graph = keep
+            return float(dt) / n
+        t_two, t_eager = probe(graph), probe(None)
+        exchange_note = (exchange_note or "") + f" (probe: two-graph {1e3 * t_two:.3f} ms/step, eager {1e3 * t_eager:.3f} ms/step: kept the faster)"
+        if t_eager < t_two:
+            graph = None
 
     # Python's cyclic GC: the first full collection of the (large) post-import heap costs ~40 ms and lands wherever it likes --
     # seen as one 3 ms/step outlier in an eager loop of 1.4 ms steps.  Collect now and freeze the survivors.
@@ -841,6 +894,8 @@ def main():
             "step_ms": step_dist,
             "launch_mode": ("hipGraph replay of ONE captured step; a new camera (matrices + FoV) and target image are written into "
                             "its static slots before every replay" if graph is not None and cycle else
+                            "two hipGraphs per step (up to the rasterizer's backward | the rest of the backward) with the gradient "
+                            "exchange issued eagerly between them" if graph is not None and hasattr(graph, "graph_b") else
                             "hipGraph replay of one captured step" if graph is not None else "eager"),
             **({"distributed": dist_info} if dist_info else {}),
             **({"grad_exchange_note": exchange_note} if exchange_note else {}),

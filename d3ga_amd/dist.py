@@ -157,6 +157,11 @@ class ViewShardedGrads:
         self.timing = bool(timing)
         self.always = False           # tests: run the exchange even in a one-rank group (the collectives are then identities)
         self._events = []             # (start, end) event pairs of the exchanges since the last exchange_ms()
+        # Deferred mode (d3ga_amd.graph.CapturedCutStep): the rasterizer's backward parks its outputs here instead of
+        # exchanging them, so that the step can be captured as two hipGraphs with the collectives issued between them.
+        self.deferred = False
+        self.pending = None           # dict: flat, factor, parts {input name -> gradient view of flat}, sh (rebuild arguments)
+        self.gathered = None
 
     def verify_inputs(self, named):
         """Collective.  `named`: dict name -> tensor (or None) entering the rasterizer on this rank.  Raises
@@ -186,9 +191,9 @@ class ViewShardedGrads:
                 "(e.g. ColorField colours / opacities).  Summing gradients at the rasterizer's inputs is only valid for "
                 "view-independent inputs; use d3ga_amd.dist.GradReducer or FlatGrads over all parameters instead.")
 
-    def exchange(self, flat, factor=None):
+    def exchange(self, flat, factor=None, out=None):
         """Sums `flat` over the ranks in place (times `scale`); gathers `factor` (P+1,3) of every rank into a
-        (world, P+1, 3) tensor (returned; None without `factor`).  Both collectives are in flight together."""
+        (world, P+1, 3) tensor (returned; `out` if given; None without `factor`).  Both collectives are in flight together."""
         ev = None
         if self.timing and flat.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -197,7 +202,8 @@ class ViewShardedGrads:
         gathered = None
         self.bytes_last = flat.numel() * 4
         if factor is not None:
-            gathered = torch.empty((self.world,) + tuple(factor.shape), dtype=factor.dtype, device=factor.device)
+            shape = (self.world,) + tuple(factor.shape)
+            gathered = out if (out is not None and tuple(out.shape) == shape) else torch.empty(shape, dtype=factor.dtype, device=factor.device)
             try:
                 works.append(dist.all_gather_into_tensor(gathered, factor, group=self.group, async_op=True))
             except (RuntimeError, NotImplementedError):      # backends without the flat variant
@@ -211,6 +217,35 @@ class ViewShardedGrads:
             ev[1].record()
             self._events.append(ev)
         return gathered
+
+    def park(self, flat, factor, parts, sh=None):
+        """Deferred mode, called by the rasterizer's backward: remember this step's buffers (static tensors when the
+        backward is being captured).  `parts`: rasterizer input name -> its gradient, a view of `flat`."""
+        self.pending = {"flat": flat, "factor": factor, "parts": parts, "sh": sh}
+
+    def exchange_parked(self):
+        """Deferred mode, eager, between the two graphs: the collectives of `exchange` on the parked buffers."""
+        if self.pending is None:
+            raise RuntimeError("ViewShardedGrads.exchange_parked: no rasterizer backward has parked its gradients")
+        # the gather buffer is kept: a captured second half of the step reads it at a fixed address
+        self.gathered = self.exchange(self.pending["flat"], self.pending["factor"], out=self.gathered)
+
+    def parked_gradients(self):
+        """Deferred mode, after `exchange_parked` (capturable): rasterizer input name -> reduced gradient, with the SH block
+        rebuilt from the gathered factors (d3ga_sh_grad_from_views)."""
+        from . import _lib
+        from ._lib import check, dptr, stream_handle
+        out = dict(self.pending["parts"])
+        sh = self.pending["sh"]
+        if sh is not None:
+            P, M, deg, means3D = sh["P"], sh["M"], sh["sh_degree"], sh["means3D"]
+            g_sh = torch.empty((P, M, 3), dtype=torch.float32, device=means3D.device)
+            g = self.gathered
+            check(_lib.lib().d3ga_sh_grad_from_views(P, M, deg, self.world, dptr(means3D), dptr(g), 3 * (P + 1),
+                                                     dptr(g[0, P]), 3 * (P + 1), self.scale, dptr(g_sh), stream_handle()),
+                  "d3ga_sh_grad_from_views")
+            out["shs"] = g_sh
+        return out
 
     def exchange_ms(self):
         """Mean milliseconds per exchange since the last call (synchronises); None if nothing was timed."""

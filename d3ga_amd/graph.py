@@ -57,3 +57,90 @@ class CapturedStep:
             slot.copy_(v if torch.is_tensor(v) else torch.as_tensor(v), non_blocking=True)
         self.graph.replay()
         return self.result
+
+
+class CapturedCutStep:
+    """A camera-sharded training step as TWO hipGraphs with the gradient exchange between them.
+
+    With `ViewShardedGrads` the collectives sit inside the rasterizer's backward, i.e. in the middle of the step: a captured
+    step would contain them (possible with RCCL, but a mis-captured collective hangs a multi-GPU job instead of slowing
+    it), an eager step is bound by the host (~0.75 ms of Python per step against ~0.5 ms of GPU work at C3).  Here the step
+    is cut where the exchange is:
+
+        graph A   upstream()            parameters -> the tensors that enter the rasterizer (with their autograd graph)
+                  loss_fn(leaves)       render + loss on detached copies; backward down to the rasterizer's inputs, whose
+                                        gradients the rasterizer parks in `sync` (ViewShardedGrads.deferred)
+        eager     sync.exchange_parked()    one all-reduce + one all-gather on static buffers, any backend
+        graph B   sync.parked_gradients()   reduced gradients (+ the SH block rebuilt from the gathered factors), pushed
+                                        through upstream's autograd graph into the parameters' .grad
+
+    upstream() -> dict name -> tensor; the names the rasterizer differentiates are "means3D", "opacities" (also
+    "opacity_logits"), "cov3D_precomp" | "scales" + "rotations", "shs" | "colors_precomp" (`rgb`); other entries are
+    passed through.  loss_fn(pkg) -> scalar loss; it must render with `grad_sync=sync`.
+    """
+
+    _ALIASES = {"opacity_logits": "opacities", "rgb": "colors_precomp"}
+
+    def __init__(self, upstream, loss_fn, sync, params=(), slots=None, camera=None, warmup=2):
+        self.slots = dict(slots or {})
+        self.camera = camera
+        self.sync = sync
+        was = sync.deferred
+        sync.deferred = True
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                  # allocator warm-up on a capture-capable stream
+                for _ in range(max(int(warmup), 1)):
+                    self._eager(upstream, loss_fn)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for p in params:
+                p.grad = None
+            self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_a):
+                up, self.result = self._to_the_cut(upstream, loss_fn)
+            sync.exchange_parked()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+                self._from_the_cut(up)
+            torch.cuda.synchronize()
+        finally:
+            sync.deferred = was
+
+    @classmethod
+    def _to_the_cut(cls, upstream, loss_fn):
+        up = upstream()
+        pkg = {k: (v.detach().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() and v.requires_grad else v)
+               for k, v in up.items()}
+        loss = loss_fn(pkg)
+        loss.backward()
+        return up, loss
+
+    def _from_the_cut(self, up):
+        grads = self.sync.parked_gradients()
+        outs, gs = [], []
+        for k, v in up.items():
+            g = grads.get(self._ALIASES.get(k, k))
+            if g is not None and torch.is_tensor(v) and v.requires_grad:
+                outs.append(v)
+                gs.append(g.reshape(v.shape))
+        torch.autograd.backward(outs, gs)
+
+    def _eager(self, upstream, loss_fn):
+        up, loss = self._to_the_cut(upstream, loss_fn)
+        self.sync.exchange_parked()
+        self._from_the_cut(up)
+        return loss
+
+    def replay(self, camera=None, **values):
+        """As CapturedStep.replay; the two collectives are issued on the current stream between the two graph launches."""
+        if camera is not None:
+            if self.camera is None:
+                raise ValueError("this step was captured without a CameraSlot")
+            self.camera.set(camera)
+        for name, v in values.items():
+            self.slots[name].copy_(v if torch.is_tensor(v) else torch.as_tensor(v), non_blocking=True)
+        self.graph_a.replay()
+        self.sync.exchange_parked()
+        self.graph_b.replay()
+        return self.result

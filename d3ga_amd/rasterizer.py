@@ -342,6 +342,19 @@ class _RasterizeGaussians(torch.autograd.Function):
         if sync is not None:
             if factor is not None:
                 factor[P].copy_(campos.reshape(-1)[:3])
+            if getattr(sync, "deferred", False):
+                # two-graph step (d3ga_amd.graph.CapturedCutStep): the collectives run between the graphs, on these buffers
+                parts_by_name = {"means3D": g_means3D, "opacities": g_opac}
+                if from_sr:
+                    parts_by_name.update(scales=g_scales, rotations=g_rots)
+                else:
+                    parts_by_name["cov3D_precomp"] = g_cov
+                if sh is None:
+                    parts_by_name["colors_precomp"] = g_col
+                sync.park(flat, factor, parts_by_name,
+                          None if factor is None else {"P": P, "M": prm.M, "sh_degree": prm.sh_degree, "means3D": means3D})
+                return (g_means3D, g_means2D if ctx.has_means2D else None, None, g_col if sh is None else None, g_opac,
+                        g_scales, g_rots, g_cov, None, None, None, None, None)
             gathered = sync.exchange(flat, factor)         # flat: summed (averaged) in place; gathered: (world, P+1, 3)
             if factor is not None:
                 g_sh = new(P, prm.M, 3)

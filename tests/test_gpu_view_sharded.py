@@ -176,7 +176,19 @@ def _worker(rank, world, port, out):
     both = [torch.zeros_like(digest) for _ in range(world)]
     torch.distributed.all_gather(both, digest)
     same = bool(torch.allclose(both[0], both[1], rtol=1e-6, atol=0))
-    out[rank] = (max(err.values()), same, mine.grad_sync.bytes_last)
+    # the same step as two hipGraphs with the exchange issued eagerly between them (d3ga_amd.graph.CapturedCutStep)
+    from d3ga_amd import rasterizer as R
+    from d3ga_amd.graph import CapturedCutStep
+    R.set_capacity_policy("static", int(R.last_counters()["D"] * 1.5) + 4096)
+    cut = CapturedCutStep(mine.upstream, mine.loss_from, mine.grad_sync, params=list(mine.params.values()))
+    for _ in range(2):
+        for p in mine.params.values():
+            if p.grad is not None:
+                p.grad.zero_()                        # a replay must WRITE this step's gradients, not add to what is there
+        cut.replay()
+    torch.cuda.synchronize()
+    err_cut = max(rel_err(p.grad.cpu().numpy(), want[k].cpu().numpy()) for k, p in mine.params.items())
+    out[rank] = (max(max(err.values()), err_cut), same, mine.grad_sync.bytes_last)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
