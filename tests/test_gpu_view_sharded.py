@@ -270,6 +270,16 @@ def test_whole_step_with_the_exchange_captured_over_rccl_one_rank_group():
         "torch.cuda.synchronize()\n"
         "err = max(float((p.grad - r).abs().max() / (r.abs().max() + 1e-30)) for p, r in zip(params, ref))\n"
         "assert err < 1e-5, err\n"
+        "# the same step as TWO graphs with the RCCL collectives issued eagerly between them (the N > 1 default)\n"
+        "from d3ga_amd.graph import CapturedCutStep\n"
+        "for p in params: p.grad = None\n"
+        "cut = CapturedCutStep(f.upstream, f.loss_from, f.grad_sync, params=params)\n"
+        "for _ in range(3):\n"
+        "    for p in params: p.grad.zero_()\n"
+        "    cut.replay()\n"
+        "torch.cuda.synchronize()\n"
+        "err2 = max(float((p.grad - r).abs().max() / (r.abs().max() + 1e-30)) for p, r in zip(params, ref))\n"
+        "assert err2 < 1e-5, err2\n"
         "dist.destroy_process_group()\n"
         "print('RCCL-GRAPH-OK', err)\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
