@@ -61,6 +61,19 @@ def _worker(rank, world, port, out):
         raised = "colors_precomp" in str(e) and "means3D" not in str(e).split("differ")[0]
     ok = ok and raised
     sync.verify_inputs({"colors_precomp": same + rank})          # verify_steps exhausted: no collective, no error
+    # deferred exchange (graph.CapturedCutStep): what the rasterizer's backward parks is reduced in place by exchange_parked,
+    # the gather buffer keeps its address from call to call, and the colours-precomp path needs no SH rebuild
+    flat_buf = torch.full((4 * 4,), float(rank + 1))
+    parts = {"means3D": flat_buf[:12].view(4, 3), "opacities": flat_buf[12:].view(4, 1)}
+    factor = torch.full((5, 3), float(10 * (rank + 1)))
+    sync.park(flat_buf, factor, parts, sh=None)
+    sync.exchange_parked()
+    first = sync.gathered.data_ptr()
+    ok = ok and torch.allclose(sync.parked_gradients()["means3D"], torch.full((4, 3), 1.5))          # mean of 1 and 2
+    ok = ok and torch.allclose(sync.gathered[:, 0, 0], torch.tensor([10.0, 20.0]))
+    flat_buf.fill_(float(rank + 3))
+    sync.exchange_parked()
+    ok = ok and sync.gathered.data_ptr() == first and torch.allclose(parts["opacities"], torch.full((4, 1), 3.5))
     out[rank] = bool(ok)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
