@@ -146,11 +146,14 @@ class Frame:
         return loss
 
 
-    def train_step(self, with_fields=False, pair=False):
+    def train_step(self, with_fields=False, pair=False, scale_weight=0.0):
         """The reference's training step renders twice (models/trainer.py:102-110): RGB, then a silhouette pass with a
         constant per-Gaussian colour on a black background; losses as in train.py:190-193 (L1 + SSIM on RGB, L1 on the
         silhouette).  with_fields: the cage-vertex offsets and the per-Gaussian (delta_bary, delta_rot, delta_scale) come
-        from the DeformationField / CanonicalField networks as in models/cage_net.py:197-215 instead of free parameters."""
+        from the DeformationField / CanonicalField networks as in models/cage_net.py:197-215 instead of free parameters.
+        scale_weight: weight of the reference's scale regulariser mean(scales^2) (cage_net.py:226; train.py:203 uses 175) on
+        the EFFECTIVE scales exp(scaling + delta_scale) -- without it the synthetic objective has a degenerate optimum,
+        screen-filling Gaussians (tools/soak.py)."""
         from d3ga_amd.cage_deform import cage_deform, lbs_cage
         from d3ga_amd.losses import l1_loss, l1_ssim
         from d3ga_amd.renderer import render, render_pair
@@ -173,11 +176,13 @@ class Frame:
             delta_node = self.deform_field(self.canon, self.pose)                                  # cage_net.py:197
             d_bary, d_rot, d_scale = self.canon_field(p["rotation"], p["scaling"], self.barys0, self.pose)   # :199-204
             tetpoints = lbs_cage(self.canon, delta_node, self.joint_mats, self.skin_idx, self.skin_w)
+            log_scales = p["scaling"] + d_scale
             means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad,
-                                      p["scaling"] + d_scale, p["rotation"] + d_rot, delta_barys=d_bary,
+                                      log_scales, p["rotation"] + d_rot, delta_barys=d_bary,
                                       scale_activation="exp")                                      # :213-230
         else:
             tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
+            log_scales = p["scaling"]
             means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad, p["scaling"],
                                       p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp")
         pkg = {"means3D": means, "cov3D_precomp": cov6, "opacity_logits": p["opacity"],
@@ -213,6 +218,8 @@ class Frame:
         lam = 0.2
         rgb_l1, rgb_ssim = l1_ssim(img, self.target)          # one fused kernel each way
         loss = (1.0 - lam) * rgb_l1 + lam * (1.0 - rgb_ssim) + l1_loss(sil, self.sil_target)
+        if scale_weight:
+            loss = loss + scale_weight * torch.exp(2.0 * log_scales).mean()          # cage_net.py:226, train.py:203
         loss.backward()
         return loss
 

@@ -17,8 +17,14 @@ with torch.no_grad():
     p = frame.params
     tp = lbs_cage(frame.canon, p["delta_node"] + 0.01 * torch.randn_like(p["delta_node"]), frame.joint_mats, frame.skin_idx, frame.skin_w)
     m, c = cage_deform(tp, frame.tetras, frame.tetra_id, frame.barys0, frame.canon_grad, p["scaling"] + 0.1, p["rotation"], scale_activation="exp")
-    frame.target = render(frame.batch, {"means3D": m, "cov3D_precomp": c, "opacities": torch.sigmoid(p["opacity"] + 0.5),
-                                        "shs": p["features"] * 0.8, "rgb": None, "sh_degree": frame.sh_degree}, frame.bg)["render"].clone()
+    tgt_pkg = {"means3D": m, "cov3D_precomp": c, "opacities": torch.sigmoid(p["opacity"] + 0.5),
+               "shs": p["features"] * 0.8, "rgb": None, "sh_degree": frame.sh_degree}
+    frame.target = render(frame.batch, tgt_pkg, frame.bg)["render"].clone()
+    # the silhouette target is the perturbed avatar's own coverage (white on black), not a threshold of the RGB target: over a
+    # white background that threshold is 1 everywhere and pulls every Gaussian across the whole screen
+    frame.sil_rgb = torch.ones(m.shape[0], 3, device=dev)
+    frame.bg0 = torch.zeros_like(frame.bg)
+    frame.sil_target = render(frame.batch, tgt_pkg, frame.bg0, colors_precomp=frame.sil_rgb)["render"].clone()
 frame.train_step(with_fields="color", pair=True)             # creates the networks
 params = list(frame.params.values()) + frame.field_params + [frame.color_feat, frame.frame_enc]
 lr = float(sys.argv[3]) if len(sys.argv) > 3 else 2e-4
@@ -27,11 +33,9 @@ names = list(frame.params.keys()) + [f"net{i}" for i in range(len(frame.field_pa
 losses, t0 = [], time.time()
 for it in range(steps):
     opt.zero_grad(set_to_none=True)
-    loss = frame.train_step(with_fields="color", pair=True)
-    # (train_step has already back-propagated the image losses; the reference's scale regulariser, cage_net.py:226, keeps the
-    #  synthetic objective from its degenerate optimum -- screen-filling Gaussians -- seen without it: D grew to P x tiles)
-    reg = 10.0 * torch.exp(2.0 * frame.params["scaling"]).mean()
-    reg.backward()
+    # with the reference's scale regulariser on the effective scales (cage_net.py:226, weight 175 as in train.py:203): without
+    # it the synthetic objective drifts to its degenerate optimum, screen-filling Gaussians (D -> P x tiles)
+    loss = frame.train_step(with_fields="color", pair=True, scale_weight=175.0)
     if os.environ.get("SOAK_TRACE"):
         torch.cuda.synchronize()
         bad = [n for n, q in zip(names, params) if q.grad is not None and not torch.isfinite(q.grad).all()]
