@@ -119,7 +119,11 @@ class Frame:
             self.views.append((b, torch.rand(3, self.wl.height, self.wl.width, generator=g).to(self.dev)))
         self.slot = CameraSlot(W, H, device=self.dev).set(self.batch)
         self.batch = dict(self.batch, camera_slot=self.slot)
-        self.target = self.target.clone()
+        self.target = self.target.clone()              # static buffer: the training-step variants copy their target into it
+        # the frame step reads its target through a TensorSlot: the n_views images are resident, a replay repoints the
+        # loss kernels (8 bytes) instead of copying 25 MB into a static buffer
+        from d3ga_amd.graph import TensorSlot
+        self.target_slot = TensorSlot(self.views[0][1])
         return self.views
 
     def upstream(self):
@@ -138,7 +142,8 @@ class Frame:
         from d3ga_amd.losses import l1_loss
         from d3ga_amd.renderer import render
         img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
-        return l1_loss(img, self.target)              # fused mean |img - target| (utils/loss_utils.py:29)
+        # fused mean |img - target| (utils/loss_utils.py:29); with camera_cycle() the target is whatever the slot names
+        return l1_loss(img, getattr(self, "target_slot", None) or self.target)
 
     def step(self):
         loss = self.loss_from(self.upstream())
@@ -572,6 +577,7 @@ def main():
             b, t = views[i % len(views)]
             frame.slot.set(b)
             frame.target.copy_(t, non_blocking=True)
+            frame.target_slot.set(t)
 
     def reduce_params():
         if not cut and world > 1:
@@ -633,7 +639,7 @@ def main():
         from d3ga_amd.graph import CapturedStep
         try:
             graph = CapturedStep(frame.step, params=list(frame.params.values()),
-                                 slots={"target": frame.target} if cycle else None, camera=frame.slot if cycle else None)
+                                 slots={"target": frame.target_slot} if cycle else None, camera=frame.slot if cycle else None)
         except Exception as e:  # noqa: BLE001
             if world == 1:
                 raise
@@ -899,8 +905,9 @@ def main():
             "roofline": roof, "kernels": kernels,
             "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 4),
             "step_ms": step_dist,
-            "launch_mode": ("hipGraph replay of ONE captured step; a new camera (matrices + FoV) and target image are written into "
-                            "its static slots before every replay" if graph is not None and cycle else
+            "launch_mode": ("hipGraph replay of ONE captured step; before every replay a new camera (matrices + FoV) is written into "
+                            "its static slot and the loss is pointed at that camera's resident target image (8-byte cell, "
+                            "d3ga_amd/graph.py: TensorSlot)" if graph is not None and cycle else
                             "two hipGraphs per step (up to the rasterizer's backward | the rest of the backward) with the gradient "
                             "exchange issued eagerly between them" if graph is not None and hasattr(graph, "graph_b") else
                             "hipGraph replay of one captured step" if graph is not None else "eager"),

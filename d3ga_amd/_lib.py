@@ -65,6 +65,8 @@ _SIGNATURES = {
     "d3ga_l1_mean_fwd": ([_i64, _vp, _vp, _vp, _vp], _i),
     "d3ga_l1_mean_fwd_ws": ([_i64, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_l1_mean_bwd": ([_i64, _vp, _vp, _vp, _vp, _vp], _i),
+    "d3ga_l1_mean_fwd_ws_cell": ([_i64, _vp, _vp, _vp, _vp, _vp], _i),
+    "d3ga_l1_mean_bwd_cell": ([_i64, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_mlp_panel_bytes": ([ctypes.c_int32, ctypes.c_int32], _i64),
     "d3ga_mlp_pack_weights": ([ctypes.c_int32, ctypes.c_int32, _vp, _i64, _i64, _vp, _vp], _i),
     "d3ga_mlp_linear": ([ctypes.c_int32] * 3 + [_vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp, _vp], _i),

@@ -52,10 +52,13 @@ __global__ __launch_bounds__(kBlock) void l1_mean_fwd_kernel(int64_t n4, int64_t
 
 // Two-stage form: one partial per workgroup (plain store), then ONE workgroup adds the partials in index order -- no zero
 // fill, no same-address atomics (2048 of them serialise for ~25 us), and the result does not depend on arrival order.
+// b_cell (optional): the address of `b` is read from device memory -- a captured step is pointed at another resident
+// target by rewriting that cell (d3ga_amd/graph.py: TensorSlot), without copying the image into a static buffer
 __global__ __launch_bounds__(kBlock) void l1_mean_partial_kernel(int64_t n4, int64_t n, const float *__restrict__ a,
-                                                                 const float *__restrict__ b, float inv_n,
-                                                                 float *__restrict__ partials) {
+                                                                 const float *__restrict__ b, const float *const *b_cell,
+                                                                 float inv_n, float *__restrict__ partials) {
     __shared__ float s_part[kBlock / 64];
+    if (b_cell) b = *b_cell;
     const float t = l1_block_sum(n4, n, a, b, inv_n, s_part);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
@@ -75,8 +78,10 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(int np, const floa
 }
 
 __global__ __launch_bounds__(kBlock) void l1_mean_bwd_kernel(int64_t n4, int64_t n, const float *__restrict__ a,
-                                                             const float *__restrict__ b, const float *__restrict__ g,
-                                                             float inv_n, float *__restrict__ grad_a) {
+                                                             const float *__restrict__ b, const float *const *b_cell,
+                                                             const float *__restrict__ g, float inv_n,
+                                                             float *__restrict__ grad_a) {
+    if (b_cell) b = *b_cell;
     const float s = g[0] * inv_n;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     auto sgn = [](float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); };
@@ -343,7 +348,8 @@ extern "C" int d3ga_l1_mean_fwd_ws(int64_t n, const float *a, const float *b, fl
     hipStream_t s = (hipStream_t)stream;
     const int64_t n4 = n / 4;
     const int np = loss_grid(n4, D3GA_LOSS_PARTIALS);
-    hipLaunchKernelGGL(l1_mean_partial_kernel, dim3(np), dim3(kBlock), 0, s, n4, n, a, b, 1.0f / (float)n, partials);
+    hipLaunchKernelGGL(l1_mean_partial_kernel, dim3(np), dim3(kBlock), 0, s, n4, n, a, b, (const float *const *)nullptr,
+                       1.0f / (float)n, partials);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, np, (const float *)partials, out);
     return check_launch(s, 0);
 }
@@ -355,8 +361,34 @@ extern "C" int d3ga_l1_mean_bwd(int64_t n, const float *a, const float *b, const
     if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad_a) & 15) return D3GA_E_CONFIG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t n4 = n / 4;
-    hipLaunchKernelGGL(l1_mean_bwd_kernel, dim3(loss_grid(n4, 2048)), dim3(kBlock), 0, s, n4, n, a, b, g, 1.0f / (float)n,
-                       grad_a);
+    hipLaunchKernelGGL(l1_mean_bwd_kernel, dim3(loss_grid(n4, 2048)), dim3(kBlock), 0, s, n4, n, a, b,
+                       (const float *const *)nullptr, g, 1.0f / (float)n, grad_a);
+    return check_launch(s, 0);
+}
+
+extern "C" int d3ga_l1_mean_fwd_ws_cell(int64_t n, const float *a, const float *const *b_cell, float *out, float *partials,
+                                        d3ga_stream_t stream) {
+    if (n <= 0) return D3GA_E_SIZE;
+    if (!a || !b_cell || !out || !partials) return D3GA_E_NULL;
+    if ((uintptr_t)a & 15) return D3GA_E_CONFIG;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n4 = n / 4;
+    const int np = loss_grid(n4, D3GA_LOSS_PARTIALS);
+    hipLaunchKernelGGL(l1_mean_partial_kernel, dim3(np), dim3(kBlock), 0, s, n4, n, a, (const float *)nullptr, b_cell,
+                       1.0f / (float)n, partials);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, np, (const float *)partials, out);
+    return check_launch(s, 0);
+}
+
+extern "C" int d3ga_l1_mean_bwd_cell(int64_t n, const float *a, const float *const *b_cell, const float *g, float *grad_a,
+                                     d3ga_stream_t stream) {
+    if (n <= 0) return D3GA_E_SIZE;
+    if (!a || !b_cell || !g || !grad_a) return D3GA_E_NULL;
+    if (((uintptr_t)a | (uintptr_t)grad_a) & 15) return D3GA_E_CONFIG;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(l1_mean_bwd_kernel, dim3(loss_grid(n4, 2048)), dim3(kBlock), 0, s, n4, n, a, (const float *)nullptr,
+                       b_cell, g, 1.0f / (float)n, grad_a);
     return check_launch(s, 0);
 }
 

@@ -15,9 +15,59 @@ device buffers ("slots") that the captured kernels read:
 
 Constraints (hipGraph): fixed shapes, fixed raster size (grid dimensions are baked), the binning capacity must be static
 (`rasterizer.set_capacity_policy("static", n)`, check `last_counters()["overflow"]` now and then), no host synchronisation
-inside `step_fn`.  Gradients land in the same static `.grad` tensors on every replay.
+inside `step_fn`.  Gradients land in the same static `.grad` tensors on every replay.  Do not keep the LOSS of an earlier eager
+step alive across the capture: it keeps that step's autograd nodes (created on the default stream) alive, autograd then
+synchronises the capture with the default stream, and ending the capture crashes inside the HIP runtime.
 """
 import torch
+
+
+class TensorSlot:
+    """A device cell that holds the ADDRESS of the tensor a captured kernel reads.
+
+    `CapturedStep(slots={"target": buf})` copies this step's target image into a static buffer before every replay (25 MB at
+    1080p).  When the candidates are resident anyway (the ground-truth images of the cameras of a capture rig), a kernel
+    can read the address instead: `slot.set(t)` repoints the cell with one asynchronous 8-byte copy, and ops that accept a
+    TensorSlot (`losses.l1_loss(img, slot)`) read `*cell` when they start.  Every tensor passed to `set` must have the
+    slot's shape, be float32, contiguous and 16-byte aligned, and must stay alive while replays that read it are in flight
+    (the slot keeps the last `_RING` alive itself)."""
+
+    _RING = 16
+
+    def __init__(self, first):
+        self.shape, self.device = tuple(first.shape), first.device
+        self.cell = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._stage = [torch.zeros(1, dtype=torch.int64) for _ in range(self._RING)]
+        if self.device.type == "cuda":
+            self._stage = [t.pin_memory() for t in self._stage]
+        self._events, self._alive, self._next = [None] * self._RING, [None] * self._RING, 0
+        self.current = None
+        self.set(first)
+
+    def numel(self):
+        n = 1
+        for d in self.shape:
+            n *= d
+        return n
+
+    def set(self, t):
+        if tuple(t.shape) != self.shape or t.dtype != torch.float32 or t.device != self.device or not t.is_contiguous():
+            raise ValueError(f"TensorSlot{self.shape}: got {tuple(t.shape)} {t.dtype} on {t.device} (contiguous float32 of the slot's shape)")
+        if t.data_ptr() % 16:
+            raise ValueError("TensorSlot: the tensor must be 16-byte aligned")
+        i = self._next
+        self._next = (i + 1) % self._RING
+        if self._events[i] is not None:
+            self._events[i].synchronize()              # the copy that last read this staging word has run
+        self._stage[i][0] = t.data_ptr()
+        self.cell.copy_(self._stage[i], non_blocking=True)
+        if self.cell.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[i] = ev
+        self._alive[i] = t
+        self.current = t
+        return self
 
 
 class CapturedStep:
@@ -54,7 +104,10 @@ class CapturedStep:
             self.camera.set(camera)
         for name, v in values.items():
             slot = self.slots[name]
-            slot.copy_(v if torch.is_tensor(v) else torch.as_tensor(v), non_blocking=True)
+            if isinstance(slot, TensorSlot):
+                slot.set(v)                                # repoint: 8 bytes instead of the tensor
+            else:
+                slot.copy_(v if torch.is_tensor(v) else torch.as_tensor(v), non_blocking=True)
         self.graph.replay()
         return self.result
 
@@ -139,7 +192,11 @@ class CapturedCutStep:
                 raise ValueError("this step was captured without a CameraSlot")
             self.camera.set(camera)
         for name, v in values.items():
-            self.slots[name].copy_(v if torch.is_tensor(v) else torch.as_tensor(v), non_blocking=True)
+            slot = self.slots[name]
+            if isinstance(slot, TensorSlot):
+                slot.set(v)
+            else:
+                slot.copy_(v if torch.is_tensor(v) else torch.as_tensor(v), non_blocking=True)
         self.graph_a.replay()
         self.sync.exchange_parked()
         self.graph_b.replay()

@@ -14,32 +14,48 @@ from ._lib import check, dptr, f32c16, require_cuda, stream_handle
 
 class _L1Mean(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, cell):
+        # cell: None, or the (1,) int64 device tensor of a graph.TensorSlot naming `b` (b is then only its current tensor)
         require_cuda(a, b)
         a = f32c16(a)
-        b = f32c16(b)
+        if cell is None:
+            b = f32c16(b)
         if a.shape != b.shape:
             raise ValueError(f"l1_loss: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
         # [0]: the loss; [4:]: one partial sum per workgroup (two-stage reduction: no zero fill, no atomics, reproducible)
         buf = torch.empty(4 + _lib.LOSS_PARTIALS, dtype=torch.float32, device=a.device)
         out = buf[0]
-        check(_lib.lib().d3ga_l1_mean_fwd_ws(a.numel(), dptr(a), dptr(b), dptr(out), dptr(buf[4:]), stream_handle()),
-              "d3ga_l1_mean_fwd_ws")
-        ctx.save_for_backward(a, b)
+        if cell is None:
+            check(_lib.lib().d3ga_l1_mean_fwd_ws(a.numel(), dptr(a), dptr(b), dptr(out), dptr(buf[4:]), stream_handle()),
+                  "d3ga_l1_mean_fwd_ws")
+            ctx.save_for_backward(a, b)
+        else:
+            check(_lib.lib().d3ga_l1_mean_fwd_ws_cell(a.numel(), dptr(a), dptr(cell), dptr(out), dptr(buf[4:]),
+                                                      stream_handle()), "d3ga_l1_mean_fwd_ws_cell")
+            ctx.save_for_backward(a, cell)
+        ctx.by_cell = cell is not None
         return out
 
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         ga = torch.empty_like(a)
+        if ctx.by_cell:
+            check(_lib.lib().d3ga_l1_mean_bwd_cell(a.numel(), dptr(a), dptr(b), dptr(f32c16(g)), dptr(ga), stream_handle()),
+                  "d3ga_l1_mean_bwd_cell")
+            return ga, None, None
         check(_lib.lib().d3ga_l1_mean_bwd(a.numel(), dptr(a), dptr(b), dptr(f32c16(g)), dptr(ga),
                                           stream_handle()), "d3ga_l1_mean_bwd")
-        return ga, (-ga if ctx.needs_input_grad[1] else None)
+        return ga, (-ga if ctx.needs_input_grad[1] else None), None
 
 
 def l1_loss(network_output, gt):
-    """mean |network_output - gt| (utils/loss_utils.py:29).  GPU tensors only."""
-    return _L1Mean.apply(network_output, gt)
+    """mean |network_output - gt| (utils/loss_utils.py:29).  GPU tensors only.  `gt` may be a `graph.TensorSlot`: the kernels
+    then read the target's address from the slot's device cell (a captured step follows `slot.set(image)` without a copy)."""
+    from .graph import TensorSlot
+    if isinstance(gt, TensorSlot):
+        return _L1Mean.apply(network_output, gt.current, gt.cell)
+    return _L1Mean.apply(network_output, gt, None)
 
 
 class _SSIM(torch.autograd.Function):

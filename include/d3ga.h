@@ -244,6 +244,13 @@ int d3ga_l1_mean_fwd(int64_t n, const float *a, const float *b, float *out, d3ga
 #define D3GA_LOSS_PARTIALS 2048
 int d3ga_l1_mean_fwd_ws(int64_t n, const float *a, const float *b, float *out, float *partials, d3ga_stream_t stream);
 int d3ga_l1_mean_bwd(int64_t n, const float *a, const float *b, const float *g, float *grad_a, d3ga_stream_t stream);
+/* The same two with `b` behind a device CELL: the kernels read its address from *b_cell (device memory) when they start.
+ * A captured hipGraph is pointed at another resident target image by rewriting that 8-byte cell instead of copying the
+ * image into a static buffer (d3ga_amd/graph.py: TensorSlot).  The tensor the cell names must be 16-byte aligned. */
+int d3ga_l1_mean_fwd_ws_cell(int64_t n, const float *a, const float *const *b_cell, float *out, float *partials,
+                             d3ga_stream_t stream);
+int d3ga_l1_mean_bwd_cell(int64_t n, const float *a, const float *const *b_cell, const float *g, float *grad_a,
+                          d3ga_stream_t stream);
 
 /* 11x11 Gaussian-window SSIM, mean over all channels and pixels.  Replaces utils/loss_utils.py:46-86 (ssim / _ssim with
  * window_size = 11, sigma = 1.5, zero padding 5, size_average = True; called at train.py:192).

@@ -782,6 +782,42 @@ def test_fused_sigmoid_opacity_matches_the_separate_activation():
     assert torch.equal(out, paste(fused.detach(), inp["batch"]["crop"]))
 
 
+def test_l1_loss_reads_its_target_through_a_tensor_slot():
+    """graph.TensorSlot: the loss kernels read the target's address from a device cell, so a captured step follows
+    `slot.set(other_image)` without any copy -- values and gradients equal the plain call on that image."""
+    from d3ga_amd.graph import CapturedStep, TensorSlot
+    from d3ga_amd.losses import l1_loss
+    torch.manual_seed(3)
+    imgs = [torch.rand(3, 37, 53, device=DEV) for _ in range(3)]
+    a = torch.rand(3, 37, 53, device=DEV, requires_grad=True)
+    slot = TensorSlot(imgs[0])
+    def eager(t):                                          # (a helper: no loss tensor -- hence no autograd node of `a` created
+        slot.set(t)                                        #  on this stream -- may outlive it into the capture below)
+        a.grad = None
+        l1_loss(a, slot).backward()
+        g_slot = a.grad.clone()
+        a.grad = None
+        ref = l1_loss(a, t)
+        ref.backward()
+        assert torch.equal(g_slot, a.grad) and float(l1_loss(a.detach(), slot)) == float(ref)
+    for t in imgs:
+        eager(t)
+
+    def step():
+        loss = l1_loss(a, slot)
+        loss.backward()
+        return loss
+    cap = CapturedStep(step, params=[a], slots={"target": slot})
+    for t in (imgs[2], imgs[1], imgs[2]):                  # replays: only the 8-byte cell changes
+        loss = cap.replay(target=t)
+        torch.cuda.synchronize()
+        want = (a.detach() - t).abs().mean()
+        assert abs(float(loss) - float(want)) < 1e-6
+        assert torch.equal(a.grad, torch.sign(a.detach() - t) / a.numel())
+    with pytest.raises(ValueError):
+        slot.set(torch.rand(3, 37, 52, device=DEV))
+
+
 def test_losses_accept_misaligned_views():
     """A contiguous VIEW with a storage offset that is not a multiple of 16 bytes (imgs[1] of a batch with odd H*W, x[1:])
     is a valid input of the reference's l1_loss / ssim; the vectorised kernels want 16-byte alignment, so the wrapper
