@@ -1,7 +1,9 @@
-"""Drop-in `tetra_sampler` package surface used by D3GA (lib/cage.py:17), served by d3ga_amd.
+"""Drop-in `tetra_sampler` package surface used by D3GA, served by d3ga_amd.
 
-Only the pieces on or next to the deform hot path are provided (Tetra, compute_bary).  `body_model.SMPLlayer`
-and `lbs.batch_rodrigues` (lib/smplman.py:9,16) need the licensed SMPL-X assets and are out of scope."""
+`Tetra`, `compute_bary` (lib/cage.py:17) are the pieces on / next to the deform hot path.  The submodules the reference
+also imports exist so that its modules load unchanged: `tetra_sampler.lbs.batch_rodrigues` (lib/smplman.py:16, asset-free,
+implemented) and `tetra_sampler.body_model.SMPLlayer` (lib/smplman.py:9: importable, raises on construction -- it needs
+the licensed SMPL-X assets, out of scope)."""
 from d3ga_amd.tetra import Tetra, compute_bary  # noqa: F401
 
 __all__ = ["Tetra", "compute_bary"]

@@ -192,3 +192,38 @@ def canonical_gradient(canon_points, tetras, tetra_id):
     c = canon_points[tetras.long()][tetra_id.long()]
     Dm = torch.stack([c[:, 3] - c[:, 0], c[:, 2] - c[:, 0], c[:, 1] - c[:, 0]], dim=2)
     return torch.linalg.inv(Dm)
+
+
+def batch_rodrigues(rot_vecs, epsilon=1e-8):
+    """Axis-angle vectors (B,3) -> rotation matrices (B,3,3): R = I + sin(t) K + (1 - cos(t)) K^2 with t = |r + eps|,
+    K = [r / t]x.  This is the helper `tetra_sampler.lbs.batch_rodrigues` the reference imports at lib/smplman.py:16 and
+    calls on the global rotation `Rh` (lib/smplman.py:167,203); tetra-sampler is un-vendored, so the published SMPL(-X)
+    convention is restated here (parity unpinned; pinned by its group properties in tests/test_abi_and_host.py).  Needs no
+    asset, runs on whatever device `rot_vecs` lives (init / per-pose glue, not a hot kernel)."""
+    if rot_vecs.dim() != 2 or rot_vecs.shape[1] != 3:
+        raise ValueError(f"batch_rodrigues expects (B,3) axis-angle vectors, got {tuple(rot_vecs.shape)}")
+    angle = torch.linalg.norm(rot_vecs + epsilon, dim=1, keepdim=True)        # (B,1); eps keeps the zero rotation finite
+    k = rot_vecs / angle
+    s, c = torch.sin(angle)[:, :, None], torch.cos(angle)[:, :, None]
+    z = torch.zeros_like(k[:, 0])
+    K = torch.stack([z, -k[:, 2], k[:, 1], k[:, 2], z, -k[:, 0], -k[:, 1], k[:, 0], z], dim=1).view(-1, 3, 3)
+    eye = torch.eye(3, dtype=rot_vecs.dtype, device=rot_vecs.device)[None]
+    return eye + s * K + (1.0 - c) * torch.bmm(K, K)
+
+
+class SMPLlayer(torch.nn.Module):
+    """Import-compatible placeholder for `tetra_sampler.body_model.SMPLlayer` (lib/smplman.py:9,68-74).
+
+    The SMPL-X body model needs the licensed SMPL-X asset files (`config.data.smplx_model`, the joint regressor) and is
+    OUT OF SCOPE here: the import succeeds so that the reference's modules load unchanged, constructing
+    the layer fails with an error that says what is missing.  Everything downstream of the body model -- the per-vertex
+    blend `Smplman.deform` (lib/smplman.py:155-171) -- is `d3ga_amd.cage_deform.lbs_cage` and takes the joint transforms
+    any SMPL-X implementation produces."""
+
+    def __init__(self, model_path=None, model_type="smplx", gender="neutral", use_joints=True, regressor_path=None, **kw):
+        super().__init__()
+        raise NotImplementedError(
+            "tetra_sampler.body_model.SMPLlayer is not provided by d3ga_amd: it requires the licensed SMPL-X model files "
+            f"(model_path={model_path!r}, regressor_path={regressor_path!r}) and the un-vendored tetra-sampler package "
+            "(github.com/Zielon/sampler).  Install that package for the body model; d3ga_amd replaces the deform / "
+            "rasterize path only (lbs_cage takes the joint transforms A and blend offsets any SMPL-X layer returns).")

@@ -1,6 +1,7 @@
 """CPU-side checks: the C-ABI library loads and exports every symbol include/d3ga.h declares; host logic
 (cameras, paste, boundary wiring, capacity sizing, tetra container) behaves like the reference's."""
 import ctypes
+import math
 import os
 import re
 
@@ -217,3 +218,65 @@ def test_ply_export_matches_the_reference_and_round_trips(tmp_path):
                      ("opacities", T("opacities")), ("scaling", T("scaling")), ("rotation", T("rotation"))):
         assert torch.equal(back[key], ref), key
     assert float(back["normals"].abs().max()) == 0.0
+
+
+def test_compat_packages_serve_the_reference_import_statements():
+    """The exact import statements of the reference's modules that touch the replaced packages
+    (renderer.py:13-16, lib/cage.py:17, lib/smplman.py:9,16, models/mesh_net.py:22, models/cage_net.py:66 (same as mesh_net))
+    resolve against compat/ -- INTEGRATION.md sec. 1 puts compat/ on sys.path."""
+    import importlib
+    import os
+    import sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "compat")
+    sys.path.insert(0, compat)
+    try:
+        for name in [m for m in sys.modules if m.split(".")[0] in ("tetra_sampler", "diff_gaussian_rasterization", "simple_knn")]:
+            del sys.modules[name]
+        ns = {}
+        exec("from diff_gaussian_rasterization import (\n    GaussianRasterizationSettings,\n    GaussianRasterizer,\n)", ns)   # renderer.py:13-16
+        exec("from tetra_sampler import Tetra, compute_bary", ns)               # lib/cage.py:17
+        exec("from tetra_sampler.body_model import SMPLlayer", ns)              # lib/smplman.py:9
+        exec("from tetra_sampler.lbs import batch_rodrigues", ns)               # lib/smplman.py:16
+        exec("from simple_knn._C import distCUDA2", ns)                         # models/mesh_net.py:22
+        import d3ga_amd.rasterizer as R
+        import d3ga_amd.tetra as T
+        import d3ga_amd.cage_deform as C
+        assert ns["GaussianRasterizer"] is R.GaussianRasterizer and ns["GaussianRasterizationSettings"] is R.GaussianRasterizationSettings
+        assert ns["Tetra"] is T.Tetra and ns["compute_bary"] is T.compute_bary and ns["distCUDA2"] is T.distCUDA2
+        assert ns["batch_rodrigues"] is C.batch_rodrigues
+        # the body model is importable but refuses to be built without the licensed SMPL-X assets (out of scope, SURVEY sec. 2)
+        with pytest.raises(NotImplementedError, match="SMPL-X"):
+            ns["SMPLlayer"]("assets/smplx", model_type="smplx", gender="neutral", use_joints=True, regressor_path="j.npy")
+        assert importlib.import_module("tetra_sampler.lbs").__all__ == ["batch_rodrigues"]
+    finally:
+        sys.path.remove(compat)
+
+
+def test_batch_rodrigues_known_answers():
+    """tetra_sampler.lbs.batch_rodrigues (lib/smplman.py:16,167,203) is un-vendored: pinned by what a rotation must satisfy.
+    Quarter turns about the axes, orthogonality / det +1, R(-r) = R(r)^T, the axis is fixed, composition of co-axial
+    rotations, the zero vector, agreement with the matrix exponential of the skew matrix, and differentiability."""
+    from d3ga_amd.cage_deform import batch_rodrigues
+    h = math.pi / 2
+    R = batch_rodrigues(torch.tensor([[h, 0, 0], [0, h, 0], [0, 0, h], [0, 0, 0]], dtype=torch.float64))
+    expect = torch.tensor([[[1, 0, 0], [0, 0, -1], [0, 1, 0]], [[0, 0, 1], [0, 1, 0], [-1, 0, 0]], [[0, -1, 0], [1, 0, 0], [0, 0, 1]],
+                           [[1, 0, 0], [0, 1, 0], [0, 0, 1]]], dtype=torch.float64)
+    assert (R - expect).abs().max() < 1e-7
+    g = torch.Generator().manual_seed(3)
+    r = torch.randn(64, 3, generator=g, dtype=torch.float64) * 1.3
+    R = batch_rodrigues(r)
+    eye = torch.eye(3, dtype=torch.float64)
+    assert (R @ R.transpose(1, 2) - eye).abs().max() < 1e-7 and (torch.linalg.det(R) - 1).abs().max() < 1e-7
+    assert (batch_rodrigues(-r) - R.transpose(1, 2)).abs().max() < 1e-7
+    assert (torch.einsum("bij,bj->bi", R, r) - r).abs().max() < 1e-6                  # the axis is an eigenvector
+    assert (batch_rodrigues(0.3 * r) @ batch_rodrigues(0.7 * r) - R).abs().max() < 1e-6
+    K = torch.zeros(64, 3, 3, dtype=torch.float64)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -r[:, 2], r[:, 1], r[:, 2], -r[:, 0], -r[:, 1], r[:, 0]
+    assert (torch.linalg.matrix_exp(K) - R).abs().max() < 1e-6
+    r32 = r[:8].float().requires_grad_(True)
+    out = batch_rodrigues(r32)
+    assert out.dtype == torch.float32 and out.shape == (8, 3, 3)
+    out.sum().backward()
+    assert torch.isfinite(r32.grad).all()
+    with pytest.raises(ValueError):
+        batch_rodrigues(torch.zeros(3))

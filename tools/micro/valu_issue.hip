@@ -20,12 +20,13 @@
 
 #define R16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
-enum Kind { K_FMA, K_MUL, K_PKFMA, K_ADD_DPP, K_MOV_DPP, K_EXP, K_RCP, K_CNDMASK, K_DSADD, K_DSREAD, K_MIX, K_EMPTY, K_CND_SGPR, K_CMP, K_CMPCND, K_BFI, K_MED3, K_COUNT };
+enum Kind { K_FMA, K_MUL, K_PKFMA, K_ADD_DPP, K_MOV_DPP, K_EXP, K_RCP, K_CNDMASK, K_DSADD, K_DSREAD, K_MIX, K_EMPTY, K_CND_SGPR, K_CMP, K_CMPCND, K_BFI, K_MED3, K_DSADD_ROT, K_DSADD_U32, K_DSADD_RTN, K_DSADD_16L, K_DSRMW, K_COUNT };
 static const char *kNames[K_COUNT] = {"v_fma_f32", "v_mul_f32", "v_pk_fma_f32", "v_add_f32_dpp(row_shr:1)", "v_mov_b32_dpp(quad_perm)",
                                       "v_exp_f32", "v_rcp_f32", "v_cndmask_b32", "ds_add_f32", "ds_read_b128(bcast)",
                                       "mix(8fma+4dpp+2exp+2cnd)", "empty-loop", "v_cndmask_b32_e64(sgpr mask)",
-                                      "v_cmp_ge_f32_e64->sgpr", "4x(cmp,fma,fma,cndmask)", "v_bfi_b32", "v_med3_f32"};
-static const int kPerBlock[K_COUNT] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 0, 64, 64, 64, 64, 64};
+                                      "v_cmp_ge_f32_e64->sgpr", "4x(cmp,fma,fma,cndmask)", "v_bfi_b32", "v_med3_f32", "ds_add_f32(16 rotating addresses)", "ds_add_u32(rotating)",
+                                     "ds_add_rtn_u32(rotating)", "ds_add_f32(rotating, 16 of 64 lanes)", "ds_read_b32+v_add+ds_write_b32(rotating)"};
+static const int kPerBlock[K_COUNT] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 0, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64};
 
 template <int KIND>
 __global__ __launch_bounds__(1024) void issue_kernel(float *out, unsigned long long *cyc, int iters, float seed) {
@@ -119,6 +120,41 @@ __global__ __launch_bounds__(1024) void issue_kernel(float *out, unsigned long l
 #define X(i) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
                 R16(X)
 #undef X
+            } else if constexpr (KIND == K_DSADD_ROT) {
+                // round 3: the same-address stream above measures a dependent chain per lane; here consecutive instructions
+                // hit 16 different dwords per lane (offset i * 4096), the pattern of an accumulator indexed by list position
+#define X(i) asm volatile("ds_add_f32 %0, %1 offset:" #i "*4096" : : "v"(lds_addr & 0xfffu), "v"(v[i]) : "memory");
+                R16(X)
+#undef X
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if constexpr (KIND == K_DSADD_U32) {
+#define X(i) asm volatile("ds_add_u32 %0, %1 offset:" #i "*4096" : : "v"(lds_addr & 0xfffu), "v"(v[i]) : "memory");
+                R16(X)
+#undef X
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if constexpr (KIND == K_DSADD_RTN) {
+#define X(i) asm volatile("ds_add_rtn_u32 %0, %1, %0 offset:" #i "*4096" : "+v"(v[i]) : "v"(lds_addr & 0xfffu) : "memory");
+                R16(X)
+#undef X
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if constexpr (KIND == K_DSADD_16L) {
+                if ((threadIdx.x & 63u) < 16u) {
+#define X(i) asm volatile("ds_add_f32 %0, %1 offset:" #i "*4096" : : "v"(lds_addr & 0xfffu), "v"(v[i]) : "memory");
+                    R16(X)
+#undef X
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if constexpr (KIND == K_DSRMW) {
+                float t0, t1, t2, t3;
+#define X(i) asm volatile("ds_read_b32 %0, %1 offset:" #i "*4096" : "=v"(t##i) : "v"(lds_addr & 0xfffu) : "memory");
+                X(0) X(1) X(2) X(3)
+#undef X
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                t0 += v[0]; t1 += v[1]; t2 += v[2]; t3 += v[3];
+#define X(i) asm volatile("ds_write_b32 %0, %1 offset:" #i "*4096" : : "v"(lds_addr & 0xfffu), "v"(t##i) : "memory");
+                X(0) X(1) X(2) X(3)
+#undef X
+                // 4 read + 4 write per rep, counted as 16 per rep below: multiply the reported cost by 4 for one RMW of a dword... see note
             } else if constexpr (KIND == K_MIX) {
                 // the proportions of the entry-per-lane compositing backward: 8 plain, 4 DPP, 2 transcendental, 2 selects
 #define F(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
@@ -191,6 +227,7 @@ int main(int argc, char **argv) {
 #define RUN(K) if (only < 0 || only == K) run<K>(out, cyc, num_cu);
     RUN(K_FMA) RUN(K_MUL) RUN(K_PKFMA) RUN(K_ADD_DPP) RUN(K_MOV_DPP) RUN(K_EXP) RUN(K_RCP) RUN(K_CNDMASK) RUN(K_DSADD) RUN(K_DSREAD)
     RUN(K_MIX) RUN(K_EMPTY) RUN(K_CND_SGPR) RUN(K_CMP) RUN(K_CMPCND) RUN(K_BFI) RUN(K_MED3)
+    RUN(K_DSADD_ROT) RUN(K_DSADD_U32) RUN(K_DSADD_RTN) RUN(K_DSADD_16L) RUN(K_DSRMW)
     hipDeviceSynchronize();
     return 0;
 }
