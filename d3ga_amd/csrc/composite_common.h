@@ -11,12 +11,27 @@ namespace d3ga {
 // D3GA_COMPOSITE_VARIANT (A/B knob, read once; the other bits selected kernels that no longer exist):
 //   bit 5 (32)  work-ordered dispatch: quadrants are handed out heaviest tile first (tile_order of the bin stage);
 //   bit 7 (128) exact ellipse / block-rectangle test behind the bounding-box test of the forward's culling.
-constexpr int kVariantOrdered = 32, kVariantExactCull = 128;
-constexpr int kDefaultCompositeVariant = kVariantOrdered | kVariantExactCull;
+//   bit 8 (256) backward: workgroup per tile with a tile-level merge of the gradient records (composite_bwd_tile_kernel).
+constexpr int kVariantOrdered = 32, kVariantExactCull = 128, kVariantTileMerge = 256;
+constexpr int kDefaultCompositeVariant = kVariantOrdered | kVariantExactCull | kVariantTileMerge;
 static inline int composite_variant() {
     static const int v = [] {
         const char *e = getenv("D3GA_COMPOSITE_VARIANT");
         return e ? atoi(e) : kDefaultCompositeVariant;
+    }();
+    return v;
+}
+static inline int composite_merge_slots() {        // A/B knob: slots of the tile-level merge cache (256 | 512 | 1024)
+    static const int v = [] {
+        const char *e = getenv("D3GA_MERGE_SLOTS");
+        return e ? atoi(e) : 512;
+    }();
+    return v;
+}
+static inline int composite_tile_assign() {        // A/B knob: block -> wavefront assignment of the tile kernel (0 quadrants, 1 interleaved)
+    static const int v = [] {
+        const char *e = getenv("D3GA_TILE_ASSIGN");
+        return e ? atoi(e) : 1;
     }();
     return v;
 }

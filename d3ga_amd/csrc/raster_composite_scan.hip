@@ -31,6 +31,13 @@
 #ifndef D3GA_SCAN_ABL
 #define D3GA_SCAN_ABL 0
 #endif
+// tile kernel only: 13 cache inserts but nothing leaves the CU; D3GA_TILE_WAVES: wavefronts per SIMD the register budget targets
+#ifndef D3GA_TILE_WAVES
+#define D3GA_TILE_WAVES 4
+#endif
+#ifndef D3GA_TILE_PRIO
+#define D3GA_TILE_PRIO 0
+#endif
 
 namespace d3ga {
 
@@ -92,6 +99,10 @@ __device__ __forceinline__ void scan_consume(ScanEntry &e, uint2 &pg) {
     asm volatile("" : "+v"(e.rgb.x), "+v"(e.rgb.y), "+v"(e.rgb.z), "+v"(pg.x), "+v"(pg.y));
     if constexpr (DUAL) asm volatile("" : "+v"(e.c2r), "+v"(e.c2g), "+v"(e.c2b));
 }
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 constexpr int kStageStride = 12;     // floats per entry in the flush staging area: nine values, the id, the list position, a pad
 constexpr uint32_t kNoGaussian = 0xffffffffu;   // id of a staged entry that was merged into a lower row's
@@ -338,6 +349,307 @@ __global__ __launch_bounds__(64, 4) void composite_bwd_scan_kernel(
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the same backward with a TILE-LEVEL merge of the gradient records (composite_bwd_tile_kernel).
+//
+// What bounds the kernel above is the number of 64-byte accumulator lines it sends to the memory-side atomic units
+// (DESIGN.md sec. 4); its in-wave merge only sees the four rows of one quadrant in one flush (28 % of the entries meet).
+// Here the four quadrant wavefronts of a tile form ONE 256-thread workgroup that shares a position-indexed accumulator in
+// LDS, so every copy of a Gaussian in the tile's 16 blocks meets before ONE line leaves the CU:
+//   * s_cache: S slots of 12 dwords {nine moments, Gaussian id, tag, pad}, slot = (list position - 1) mod S -- a
+//     direct-mapped cache keyed by the position in the tile's depth-ordered list.  The rows walk their lists back to front,
+//     so the live positions form a sliding window; a window wider than S only costs evictions, never correctness;
+//   * the tag word is also the slot's lock: a lane takes a slot with ONE returning integer LDS atomic (ds_wrxchg_rtn_b32;
+//     integer LDS atomics run at ~7 ns per wave instruction and SIMD, float ones at 322 ns -- tools/micro/valu_issue.hip,
+//     profiles/r03_lds_atomic.jsonl -- which is why the values are added with plain loads and stores under the lock);
+//     old tag == my position: add; empty: install; another position: install mine and send the resident to HBM (its rows
+//     have passed it, or the window exceeded S);  losers of a slot (a lower row's copy in the same instruction, another
+//     wavefront) retry -- the holder never waits for anybody, so the loop cannot deadlock;
+//   * no barriers after the start: the wavefronts stay independent (own early exits, own pace); the last one to finish
+//     (an LDS counter) publishes the whole cache, nine consecutive lanes per record as before.
+// Everything before the publish step is the kernel above, line for line (same splat_eval_q, same validity test).
+template <bool DUAL, int S>
+__global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kernel(
+    int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, uint64_t dcap, const float2 *__restrict__ xy,
+    const float4 *__restrict__ conic_o, const float4 *__restrict__ rgb_invd, const float *__restrict__ bg,
+    const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
+    float *__restrict__ acc, const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2,
+    const float *__restrict__ bg2, const float *__restrict__ dL_dpix2, const uint2 *__restrict__ blk_list,
+    const uint32_t *__restrict__ blk_count, int assign) {
+    static_assert((S & (S - 1)) == 0, "power of two");
+    constexpr int PIXF = DUAL ? 12 : 8;
+    constexpr int ROWF = 16 * PIXF + 4;
+    constexpr int kSlot = 12;                        // dwords per cache slot
+    constexpr uint32_t kLocked = 0xffffffffu;
+    const int tiles = gx * gy;
+    const int tile = tile_order ? ((int)blockIdx.x < tiles ? (int)tile_order[blockIdx.x] : -1) : ((int)blockIdx.x < tiles ? (int)blockIdx.x : -1);
+    if (tile < 0) return;                                  // uniform over the workgroup
+    const uint32_t begin = (uint32_t)min((uint64_t)tile_start[tile], dcap);
+    const uint32_t end = (uint32_t)min((uint64_t)tile_start[tile + 1], dcap);
+    if (begin >= end) return;                              // uniform: empty tile
+
+    __shared__ __attribute__((aligned(16))) float s_pix_all[4][4 * ROWF];
+    __shared__ __attribute__((aligned(16))) float s_dump_all[4][64 * 2 + 16 * PIXF];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cache[S * kSlot];
+    for (int i = threadIdx.x; i < S; i += 256) s_cache[i * kSlot + 10] = 0u;       // tags: every slot empty
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // block -> (wavefront, row).  assign 0: a wavefront takes the 2x2 blocks of one quadrant (the forward's grouping);
+    // assign 1: it takes the blocks (wave & 1) + 2 i, (wave >> 1) + 2 j -- 8 pixels apart, so its rows rarely hold the same
+    // Gaussian in the same group (copies that meet in ONE instruction serialise on the slot; copies in different wavefronts
+    // simply hit the cache).  The forward numbers a tile's blocks 4 * quadrant + (block within the quadrant).
+    const int row = lane >> 4, l16 = lane & 15;
+    const int bx = assign ? 2 * (row & 1) + (wave & 1) : 2 * (wave & 1) + (row & 1);
+    const int by = assign ? 2 * (row >> 1) + (wave >> 1) : 2 * (wave >> 1) + (row >> 1);
+    const int blk = 4 * ((bx >> 1) + 2 * (by >> 1)) + ((bx & 1) + 2 * (by & 1));
+    const int bx0 = (tile % gx) * kTile + 4 * bx, by0 = (tile / gx) * kTile + 4 * by;      // block origin in pixels
+    const int fq = lane / 9, fk = lane - 9 * fq;           // publish: lane -> (record within a group of 7, value)
+    const int fk_off = fk < 2 ? fk : fk + 1;               // acc layout 0,1 | 3,4,5 | 6 | 7,8,9
+    constexpr int kAccStride = D3GA_ACC_STRIDE;
+    float *const s_pix = s_pix_all[wave];
+    float *const s_dump = s_dump_all[wave];
+#ifdef D3GA_DIAG_COUNTERS
+    unsigned long long dg_install = 0, dg_hit = 0, dg_evict = 0, dg_trips = 0, dg_groups = 0;
+    const unsigned long long diag_t0 = __builtin_readcyclecounter(), diag_w0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    do {
+        const int px = bx0 + (l16 & 3), py = by0 + (l16 >> 2);
+        const bool inside = px < W && py < H;
+        const size_t pid = (size_t)py * W + px;
+        const size_t hw = (size_t)H * W;
+        const float T_final = inside ? final_T[pid] : 0.f;
+        const uint32_t last = inside ? n_contrib[pid] : 0u;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (inside) { g0 = dL_dpix[pid]; g1 = dL_dpix[hw + pid]; g2 = dL_dpix[2 * hw + pid]; }
+        float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+        if constexpr (DUAL) {
+            if (inside) { h0 = dL_dpix2[pid]; h1 = dL_dpix2[hw + pid]; h2 = dL_dpix2[2 * hw + pid]; }
+            bg_dot += bg2[0] * h0 + bg2[1] * h1 + bg2[2] * h2;
+        }
+        const uint32_t maxlast = wave_max_u32(last);
+        if (maxlast == 0) break;
+
+        float *const pixrow = s_pix + row * ROWF;
+        float *const wr_base = l16 == 15 ? pixrow : s_dump + 2 * lane;
+        {
+            float *rec = pixrow + l16 * PIXF;
+            *reinterpret_cast<float4 *>(rec) = make_float4(T_final, 0.f, g0, g1);
+            *reinterpret_cast<float4 *>(rec + 4) = make_float4(g2, T_final * bg_dot, __uint_as_float(last), 0.f);
+            if constexpr (DUAL) *reinterpret_cast<float4 *>(rec + 8) = make_float4(h0, h1, h2, 0.f);
+        }
+        const uint32_t blk_cap = end - begin;
+        // (the forward writes blk_count only for quadrants that start inside the image)
+        const bool quad_in = bx0 - 4 * (bx & 1) < W && by0 - 4 * (by & 1) < H;
+        const uint32_t cnt = quad_in ? blk_count[16 * (size_t)tile + blk] : 0u;
+        const uint2 *const list = blk_list + 16 * (size_t)begin + (size_t)blk * blk_cap;
+        const int ngroups = (int)((wave_max_u32(cnt) + 15u) >> 4);
+        const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+        const float bxr = (float)bx0, byr = (float)by0;
+        const int per = D3GA_SCAN_ABL == 12 ? 16 : (ngroups > 0 ? ((int)cnt + ngroups - 1) / ngroups : 0);      // rows paced to finish together (see above)
+        auto list_entry = [&](int g) -> uint2 {
+            const int idx = (int)cnt - 1 - per * g - l16;
+            uint2 v = list[max(idx, 0)];
+            v.x = (idx >= 0 && l16 < per) ? v.x : 0u;
+            return v;
+        };
+        ScanEntry e = scan_gather<DUAL>(list_entry(0), xy, conic_o, rgb_invd, colors2);
+        uint2 pg1 = list_entry(1);
+        __builtin_amdgcn_wave_barrier();
+
+        for (int g = 0; g < ngroups; ++g) {
+            ScanEntry nxt = scan_gather<DUAL>(pg1, xy, conic_o, rgb_invd, colors2);
+            uint2 pg2 = list_entry(g + 2);
+            const bool act = e.pos != 0u;
+            const float exr = e.xy.x - bxr, eyr = e.xy.y - byr;
+            const ConicQ cq = conic_q(e.co.x, e.co.y, e.co.z);
+            // Geometric moments with the weight gop = G dL/dalpha (the opacity factor is applied once per entry) and the pixel
+            // offsets k = 0..3 of a block line as compile-time constants: per line  A = sum gop, B = sum k gop, C = sum k^2 gop
+            // (7 instructions for 4 pixels), accumulated as sums of A, B, C, dy A, dy B, dy^2 A; the centred moments follow at the
+            // end of the group from dx = exr - k:  sum gop dx = exr SA - SB,  sum gop dx^2 = exr^2 SA - 2 exr SB + SC, ...
+            // (3.5 instructions per pixel step instead of 9: w, wx, wy and six accumulations).
+            float SA = 0.f, SB = 0.f, SC = 0.f, SyA = 0.f, SyB = 0.f, SyyA = 0.f, M6 = 0.f, M7 = 0.f, M8 = 0.f;
+#if D3GA_TILE_PRIO
+            {   // (the priority is an immediate)
+                const int left = ngroups - g;
+                if (left > 8) __builtin_amdgcn_s_setprio(3);
+                else if (left > 4) __builtin_amdgcn_s_setprio(2);
+                else if (left > 2) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
+#pragma unroll 1
+            for (int ky = 0; ky < (D3GA_SCAN_ABL == 8 ? 0 : 4); ++ky) {
+                const float *const pixq = pixrow + ky * 4 * PIXF;
+                float4 pa[4], pb[4], pc[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    pa[k] = *reinterpret_cast<const float4 *>(pixq + k * PIXF);
+                    pb[k] = *reinterpret_cast<const float4 *>(pixq + k * PIXF + 4);
+                    if constexpr (DUAL) pc[k] = *reinterpret_cast<const float4 *>(pixq + k * PIXF + 8);
+                }
+                const float dy = eyr - (float)ky;
+                const float tb = cq.b * dy, tc = (cq.c * dy) * dy;
+                float al[4], G[4], r[4], u[4], cgv[4], dx[4];
+                bool valid[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    dx[k] = exr - (float)k;
+                    bool ok;
+                    splat_eval_q(dx[k], tb, tc, cq.a, e.co.w, al[k], G[k], ok);
+                    valid[k] = ok & (e.pos <= __float_as_uint(pb[k].z));     // (a lane without an entry has opacity 0: never ok)
+                    al[k] = valid[k] ? al[k] : 0.f;
+                    r[k] = __builtin_amdgcn_rcpf(1.0f - al[k]);
+                    cgv[k] = e.rgb.x * pa[k].z + e.rgb.y * pa[k].w + e.rgb.z * pb[k].x;
+                    if constexpr (DUAL) cgv[k] += e.c2r * pc[k].x + e.c2g * pc[k].y + e.c2b * pc[k].z;
+                }
+                float p0 = r[0], p1 = r[1], p2 = r[2], p3 = r[3];
+                row_scan_mul4(p0, p1, p2, p3);
+                const float Ti[4] = {pa[0].x * p0, pa[1].x * p1, pa[2].x * p2, pa[3].x * p3};
+                float dch[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { dch[k] = al[k] * Ti[k]; u[k] = cgv[k] * dch[k]; }
+                float s0 = u[0], s1 = u[1], s2 = u[2], s3 = u[3];
+                row_scan_add4(s0, s1, s2, s3);
+                const float Sin[4] = {s0 + pa[0].y, s1 + pa[1].y, s2 + pa[2].y, s3 + pa[3].y};
+                float *const wq = wr_base + ky * 4 * PIXF;
+                float gop[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dLda = Ti[k] * cgv[k] - (Sin[k] - u[k] + pb[k].y) * r[k];
+                    gop[k] = valid[k] ? G[k] * dLda : 0.f;
+                    M6 += dch[k] * pa[k].z; M7 += dch[k] * pa[k].w; M8 += dch[k] * pb[k].x;
+                    *reinterpret_cast<float2 *>(wq + k * PIXF) = make_float2(Ti[k], Sin[k]);
+                }
+                const float A = (gop[0] + gop[1]) + (gop[2] + gop[3]);
+                const float B = fmaf(3.0f, gop[3], fmaf(2.0f, gop[2], gop[1]));
+                const float C = fmaf(9.0f, gop[3], fmaf(4.0f, gop[2], gop[1]));
+                SA += A; SB += B; SC += C;
+                SyA = fmaf(dy, A, SyA); SyB = fmaf(dy, B, SyB); SyyA = fmaf(dy * dy, A, SyyA);
+            }
+            const float M5 = SA, ow = e.co.w;
+            const float M0 = ow * (exr * SA - SB), M1 = ow * SyA;
+            const float M2 = ow * (exr * (exr * SA - 2.0f * SB) + SC), M3 = ow * (exr * SyA - SyB), M4 = ow * SyyA;
+            const float v0 = -(e.co.x * M0 + e.co.y * M1) * ddelx_dx;
+            const float v1 = -(e.co.z * M1 + e.co.y * M0) * ddely_dy;
+            const float4 va = make_float4(v0, v1, -0.5f * M2, -0.5f * M3), vb = make_float4(-0.5f * M4, M5, M6, M7);
+            scan_consume<DUAL>(nxt, pg2);
+            __builtin_amdgcn_wave_barrier();
+            // ---- merge into the tile's cache (see the header) ----
+            // One LDS round trip per attempt: the exchange that takes the slot and the (speculative) loads of its record
+            // are issued together -- LDS instructions of a wavefront execute in order, so the loads see the record as the
+            // lock holder owns it; a loser discards them.  Stores + the releasing tag store likewise need no wait.
+            const uint32_t saddr = (uint32_t)(uintptr_t)(lds_u32 *)(s_cache + ((e.pos - 1u) & (uint32_t)(S - 1)) * kSlot);
+            // an entry that touched no pixel has nothing but (exact) zeros: it stays out of the cache
+            const uint32_t anybits = (__float_as_uint(SA) | __float_as_uint(SB) | __float_as_uint(SC)) | (__float_as_uint(SyA) | __float_as_uint(SyB) | __float_as_uint(SyyA)) |
+                                     (__float_as_uint(M6) | __float_as_uint(M7) | __float_as_uint(M8));
+            bool pending = D3GA_SCAN_ABL == 1 ? (anybits == 0x12345u) : (D3GA_SCAN_ABL == 8 ? act : (anybits << 1) != 0u);
+#ifdef D3GA_DIAG_COUNTERS
+            dg_groups += 1;
+#endif
+            while (__builtin_amdgcn_ballot_w64(pending) != 0ull) {
+#ifdef D3GA_DIAG_COUNTERS
+                dg_trips += 1;
+#endif
+                // straight-line body (selects, no nested divergent regions and no state carried around the loop: the first
+                // version's phi copies and mask bookkeeping cost ~150 VALU instructions per attempt, PMC-measured)
+                uint32_t old;
+                f4 ca, cb;
+                u2 cc;
+                asm("" : "=v"(old), "=v"(ca), "=v"(cb), "=v"(cc));       // defined, arbitrary: lanes that are not pending never look
+                if (pending)
+                    asm volatile("ds_wrxchg_rtn_b32 %0, %4, %5 offset:40\n"
+                                 "ds_read_b128 %1, %4\n"
+                                 "ds_read_b128 %2, %4 offset:16\n"
+                                 "ds_read_b64 %3, %4 offset:32\n"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "+v"(old), "+v"(ca), "+v"(cb), "+v"(cc)
+                                 : "v"(saddr), "v"(kLocked)
+                                 : "memory");
+                const bool won = pending && old != kLocked;
+                const bool hit = won && old == e.pos;
+                const bool evi = won && !hit && old != 0u;
+#ifdef D3GA_DIAG_COUNTERS
+                if (hit) dg_hit += 1; else if (evi) dg_evict += 1; else if (won) dg_install += 1;
+#endif
+                const f4 ta = {va.x + (hit ? ca.x : 0.f), va.y + (hit ? ca.y : 0.f), va.z + (hit ? ca.z : 0.f), va.w + (hit ? ca.w : 0.f)};
+                const f4 tb4 = {vb.x + (hit ? cb.x : 0.f), vb.y + (hit ? cb.y : 0.f), vb.z + (hit ? cb.z : 0.f), vb.w + (hit ? cb.w : 0.f)};
+                const u2 tc = {__float_as_uint(M8 + (hit ? __uint_as_float(cc.x) : 0.f)), e.gid};
+                if (won)
+                    asm volatile("ds_write_b128 %0, %1\n"
+                                 "ds_write_b128 %0, %2 offset:16\n"
+                                 "ds_write_b64 %0, %3 offset:32\n"
+                                 "ds_write_b32 %0, %4 offset:40"
+                                 :
+                                 : "v"(saddr), "v"(ta), "v"(tb4), "v"(tc), "v"(e.pos)
+                                 : "memory");
+                pending = pending && !won;
+                const unsigned long long em = __builtin_amdgcn_ballot_w64(evi);
+                if (em != 0ull) {
+                    // wave-uniform and rare (the window of live positions exceeded S): the displaced records leave through the
+                    // dump area, up to 24 at a time, nine consecutive lanes per record like every publish of this kernel
+                    const int rank = lanes_below(em), total = (int)__popcll(em);
+                    for (int c0 = 0; c0 < total; c0 += 24) {
+                        if (evi && rank >= c0 && rank < c0 + 24) {
+                            float *st = s_dump + (rank - c0) * 10;
+                            st[0] = ca.x; st[1] = ca.y; st[2] = ca.z; st[3] = ca.w;
+                            st[4] = cb.x; st[5] = cb.y; st[6] = cb.z; st[7] = cb.w;
+                            st[8] = __uint_as_float(cc.x); st[9] = __uint_as_float(cc.y);
+                        }
+                        const int n = min(total - c0, 24);
+                        __builtin_amdgcn_wave_barrier();
+                        for (int base = 0; base < n; base += 7) {
+                            const int ent = base + fq;
+                            if (fq < 7 && ent < n) {
+                                const float val = s_dump[ent * 10 + fk];
+                                const uint32_t og = __float_as_uint(s_dump[ent * 10 + 9]);
+                                if (D3GA_SCAN_ABL != 13 && val != 0.f) atomicAdd(acc + kAccStride * (size_t)og + fk_off, val);
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+            e = nxt;
+            pg1 = pg2;
+        }
+    } while (false);
+
+#ifdef D3GA_DIAG_COUNTERS
+    {
+        atomicAdd(&g_diag_scan[3], dg_install); atomicAdd(&g_diag_scan[4], dg_hit); atomicAdd(&g_diag_scan[5], dg_evict);
+        if (lane == 0) {
+            atomicAdd(&g_diag_scan[6], dg_trips); atomicAdd(&g_diag_scan[7], dg_groups);
+            if (dg_groups) {
+                const unsigned long long slot = atomicAdd(&g_diag_scan[0], 1ull);
+                if (slot < 32768) {
+                    g_diag_waves[4 * slot] = diag_w0 | ((__builtin_readcyclecounter() - diag_t0) << 40);
+                    g_diag_waves[4 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+                    g_diag_waves[4 * slot + 2] = dg_groups | (dg_trips << 16) | ((unsigned long long)(end - begin) << 32);
+                    g_diag_waves[4 * slot + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(6164) & 15) << 32);
+                }
+            }
+        }
+    }
+#endif
+    // every wavefront of the tile is done: publish the cache, nine consecutive lanes per record, seven records per
+    // instruction, a quarter of the slots per wavefront.  (A wavefront that finishes early waits here; its workgroup keeps
+    // the LDS and the dispatch slot until the slowest quadrant is done anyway.)
+    __syncthreads();
+    if (D3GA_SCAN_ABL == 13 || D3GA_SCAN_ABL == 1) return;
+    for (int base = wave * 7; base < S; base += 28) {
+        const int ent = base + min(fq, 6);
+        const bool mine = fq < 7 && ent < S;
+        const uint32_t *const sl = s_cache + min(ent, S - 1) * kSlot;
+        const uint32_t tag = sl[10], gid = sl[9];
+        const float val = __uint_as_float(sl[fk]);
+        if (mine && tag != 0u && val != 0.f) atomicAdd(acc + kAccStride * (size_t)gid + fk_off, val);
+    }
+}
+
 #ifdef D3GA_DIAG
 extern "C" int d3ga_diag_scan_read(unsigned long long *out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_diag_scan), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
@@ -355,8 +667,23 @@ extern "C" int d3ga_diag_scan_waves(unsigned long long *out, int n) {      // n 
 int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, const BinBuf &bin, const GeomBuf &g,
                               const ImgBuf &im, int64_t d_capacity, const float *bg, const float *dL_dpix, float *acc,
                               bool ordered, const float *colors2, const float *bg2, const float *dL_dpix2, hipStream_t s) {
-    const dim3 grid(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy));
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
+    if (composite_variant() & kVariantTileMerge) {
+        // workgroup per tile, tile-level merge of the gradient records in LDS (composite_bwd_tile_kernel)
+        const dim3 tgrid(gx * gy);
+        const int S = composite_merge_slots();
+#define D3GA_LAUNCH_TILE(DUALV, SV)                                                                                          \
+        hipLaunchKernelGGL((composite_bwd_tile_kernel<DUALV, SV>), tgrid, dim3(256), 0, s, prm->W, prm->H, gx, gy, bin.tile_start, \
+                           (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc, order,   \
+                           colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, composite_tile_assign())
+        if (colors2) { if (S >= 512) D3GA_LAUNCH_TILE(true, 512); else D3GA_LAUNCH_TILE(true, 256); }
+        else if (S >= 1024) D3GA_LAUNCH_TILE(false, 1024);
+        else if (S >= 512) D3GA_LAUNCH_TILE(false, 512);
+        else D3GA_LAUNCH_TILE(false, 256);
+#undef D3GA_LAUNCH_TILE
+        return check_launch(s, prm->debug);
+    }
+    const dim3 grid(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy));
     if (colors2)
         hipLaunchKernelGGL(composite_bwd_scan_kernel<true>, grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,
                            (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc, order,

@@ -30,6 +30,31 @@ print("stage times of the measured step (ms):", {k: round(v[1], 4) for k, v in R
 R.stage_timer.enabled = False
 assert L.d3ga_diag_scan_read(out, 1) == 0
 w = int(out[0])
+if int(out[7]):      # tile-level merge kernel (round 3): cache statistics only
+    print({"active_waves": w, "installs": int(out[3]), "hits": int(out[4]), "evictions": int(out[5]), "lock_loop_trips": int(out[6]),
+           "wave_groups": int(out[7]), "trips_per_group": round(int(out[6]) / max(int(out[7]), 1), 3),
+           "lines_to_hbm": int(out[3]) + int(out[5])})
+    import numpy as np
+    n = min(w, 32768)
+    buf = (ctypes.c_ulonglong * (4 * n))()
+    assert L.d3ga_diag_scan_waves(buf, n) == 0
+    a = np.array(buf, dtype=np.uint64).reshape(n, 4)
+    t0 = (a[:, 0] & np.uint64((1 << 40) - 1)).astype(np.int64); t1 = (a[:, 1] & np.uint64((1 << 40) - 1)).astype(np.int64)
+    g = (a[:, 2] & np.uint64(0xffff)).astype(np.int64)
+    b = t0.min(); t0 -= b; t1 -= b
+    dur = t1 - t0
+    print("span (10 ns ticks)", int(t1.max()), "| active waves", n, "| groups: mean", round(float(g.mean()), 2), "max", int(g.max()),
+          "p50/p90/p99", [int(np.percentile(g, q)) for q in (50, 90, 99)])
+    print("start percentiles", [int(np.percentile(t0, q)) for q in (0, 25, 50, 75, 90, 100)], "end percentiles", [int(np.percentile(t1, q)) for q in (0, 25, 50, 75, 90, 100)])
+    print("ticks per group: median", float(np.median(dur / g)), "p10", float(np.percentile(dur / g, 10)), "p90", float(np.percentile(dur / g, 90)))
+    order = np.argsort(-t1)[:6]
+    print("last waves to end (end, start, groups, ticks/group):", [(int(t1[i]), int(t0[i]), int(g[i]), round(float(dur[i] / g[i]), 1)) for i in order])
+    order = np.argsort(-g)[:6]
+    print("heaviest waves (groups, start, end):", [(int(g[i]), int(t0[i]), int(t1[i])) for i in order])
+    for q in (0.1, 0.3, 0.5, 0.7, 0.8, 0.9, 0.95):
+        t = q * t1.max()
+        print(f"resident active waves at {q:.2f} of the span:", int(((t0 <= t) & (t1 > t)).sum()))
+    sys.exit(0)
 print('flushed entries with a gradient:', int(out[1]), '| of them also present in a lower row of the same flush:', int(out[2]))
 print("active waves", w)
 # per-wave timeline (s_memtime ticks): when do waves start / end, how long does a group take, how busy is each SIMD
