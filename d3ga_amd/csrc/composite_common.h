@@ -12,8 +12,9 @@ namespace d3ga {
 //   bit 5 (32)  work-ordered dispatch: quadrants are handed out heaviest tile first (tile_order of the bin stage);
 //   bit 7 (128) exact ellipse / block-rectangle test behind the bounding-box test of the forward's culling.
 //   bit 8 (256) backward: workgroup per tile with a tile-level merge of the gradient records (composite_bwd_tile_kernel).
-constexpr int kVariantOrdered = 32, kVariantExactCull = 128, kVariantTileMerge = 256;
-constexpr int kDefaultCompositeVariant = kVariantOrdered | kVariantExactCull | kVariantTileMerge;
+//   bit 9 (512) forward: two stages -- a quadrant-level bounding-box pass feeding batches of survivors (composite_fwd_q_kernel).
+constexpr int kVariantOrdered = 32, kVariantExactCull = 128, kVariantTileMerge = 256, kVariantTwoStage = 512;
+constexpr int kDefaultCompositeVariant = kVariantOrdered | kVariantExactCull | kVariantTileMerge | kVariantTwoStage;
 static inline int composite_variant() {
     static const int v = [] {
         const char *e = getenv("D3GA_COMPOSITE_VARIANT");

@@ -21,10 +21,12 @@ struct GeomBuf {
     uint2 *rect;        // P      tile rectangle packed: x = minx | miny<<16, y = maxx | maxy<<16
     uint8_t *clamped;   // P      bit c set: SH colour channel c was clamped at 0
     float *cov3D;       // P*6    3D covariance actually used (precomputed copy or from scale/rotation)
+    float4 *xyh;        // P      pixel-space centre | half extents of the alpha >= 1/255 ellipse's bounding box (splat_cull):
+                        //        the 16-byte record the compositing forward's first stage tests a list entry with
 };
 static inline int64_t geom_bytes(int64_t P) {
     return align256(4 * P) + align256(8 * P) + align256(16 * P) + align256(16 * P) + align256(8 * P) + align256(P) +
-           align256(24 * P);
+           align256(24 * P) + align256(16 * P);
 }
 static inline GeomBuf carve_geom(void *base, int64_t P) {
     char *p = (char *)base;
@@ -35,7 +37,8 @@ static inline GeomBuf carve_geom(void *base, int64_t P) {
     g.rgb_invd = (float4 *)p; p += align256(16 * P);
     g.rect = (uint2 *)p;      p += align256(8 * P);
     g.clamped = (uint8_t *)p; p += align256(P);
-    g.cov3D = (float *)p;
+    g.cov3D = (float *)p;     p += align256(24 * P);
+    g.xyh = (float4 *)p;
     return g;
 }
 

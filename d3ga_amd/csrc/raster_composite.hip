@@ -198,6 +198,227 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the same forward in TWO STAGES (composite_fwd_q_kernel).
+//
+// Only ~35 % of a tile list's entries reach a given 8x8 quadrant, but the kernel above pays the whole per-entry
+// overhead for all of them: three record gathers, the culling constants (one log, three rcp, two sqrt), the exact 4x4
+// block tests, the list building -- ~200 instructions per 64 entries, ~45 % of its instructions.  Here a first stage
+// walks the list 128 entries at a time with ONE 16-byte gather per entry (GeomBuf::xyh: centre | half extents of the
+// alpha >= 1/255 box, written by preprocess with the same splat_cull()) and a bounding-box test against the quadrant;
+// the survivors' (list position, id) go into a 256-entry ring in LDS.  The second stage -- the batch body of the kernel
+// above, unchanged: gathers, exact block tests, row lists, emission for the backward, blend -- runs on batches of 64
+// SURVIVORS, i.e. three times less often and with ~3x longer row lists per batch (better row balance, less padding).
+// A block-level hit implies the quadrant-level box hit (same extents, the blocks lie inside the quadrant), so the set of
+// (entry, block) pairs, the emitted lists and every pixel are identical to the kernel above.
+// Pipeline per batch: its gathers and the next stage-one loads are issued BEFORE the previous batch is blended.
+template <bool DUAL>
+__global__ __launch_bounds__(64) void composite_fwd_q_kernel(
+    int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+    uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
+    const float4 *__restrict__ rgb_invd, const float4 *__restrict__ xyh, const float *__restrict__ bg,
+    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
+    float *__restrict__ out_invdepth, const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2,
+    const float *__restrict__ bg2, float *__restrict__ out_color2, uint2 *__restrict__ blk_list,
+    uint32_t *__restrict__ blk_count, bool exact_cull) {
+    const Quad q = tile_order ? quad_of_block_ordered(gx, gx * gy, tile_order) : quad_of_block(gx, gy);
+    if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const RowGeom rg = row_geom(q, lane);
+    const bool inside = rg.px < W && rg.py < H;
+    const float fx = (float)rg.px, fy = (float)rg.py;
+    const float bx0 = (float)q.qx0, by0 = (float)q.qy0;
+    const uint32_t begin = (uint32_t)min((uint64_t)tile_start[q.tile], dcap);
+    const uint32_t end = (uint32_t)min((uint64_t)tile_start[q.tile + 1], dcap);
+    const uint32_t blk_cap = end - begin;
+    uint2 *const blk_base = blk_list ? blk_list + 16 * (size_t)begin + (size_t)(4 * q.quad) * blk_cap : nullptr;
+    uint32_t bc0 = 0, bc1 = 0, bc2 = 0, bc3 = 0;
+
+    __shared__ float4 s_co[65];
+    __shared__ float4 s_rgb[65];
+    __shared__ float4 s_xyp[65];
+    __shared__ float4 s_rgb2[DUAL ? 65 : 1];
+    __shared__ uint16_t s_list[4][64];
+    constexpr int kRing = 256;                            // survivors of stage one: (1-based list position, Gaussian id)
+    __shared__ uint2 s_ring[kRing];
+    if (threadIdx.x == 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_co[64] = z; s_rgb[64] = z; s_xyp[64] = z;
+        if constexpr (DUAL) s_rgb2[64] = z;
+    }
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    float E0 = 0.f, E1 = 0.f, E2 = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    // ---- stage one state: the list is consumed 128 entries at a time, lane l looks at entries sbase + l and sbase + 64 + l ----
+    uint32_t sbase = begin;                               // first list entry of the chunk whose records are in flight
+    uint32_t qhead = 0, qcount = 0;                       // ring: entries (qhead + i) % kRing, i < qcount (wave-uniform)
+    uint32_t g0 = 0, g1 = 0;                              // ids of the chunk in flight
+    float4 h0 = make_float4(0.f, 0.f, -1.f, 0.f), h1 = h0; // its xyh records
+    auto chunk_ids = [&](uint32_t base) {                 // 1st level: the ids (coalesced)
+        g0 = base + lane < end ? point_list[base + lane] : 0u;
+        g1 = base + 64 + lane < end ? point_list[base + 64 + lane] : 0u;
+    };
+    auto chunk_recs = [&]() { h0 = xyh[g0]; h1 = xyh[g1]; };       // 2nd level: the gathers (id 0 is always readable)
+    auto quad_hit = [&](const float4 &r) {                // NaN extents answer "relevant", like block_hits4
+        return !(r.z < 0.0f) && !(r.x + r.z < bx0) && !(r.x - r.z > bx0 + 7.0f) && !(r.y + r.w < by0) && !(r.y - r.w > by0 + 7.0f);
+    };
+    auto consume_chunk = [&]() {                          // test the chunk in flight, append its survivors in list order
+        const bool v0 = sbase + lane < end, v1 = sbase + 64 + lane < end;
+        const bool k0 = v0 && quad_hit(h0), k1 = v1 && quad_hit(h1);
+        const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+        const uint32_t n0 = (uint32_t)__popcll(m0);
+        if (k0) s_ring[(qhead + qcount + (uint32_t)lanes_below(m0)) % kRing] = make_uint2(sbase - begin + (uint32_t)lane + 1u, g0);
+        if (k1) s_ring[(qhead + qcount + n0 + (uint32_t)lanes_below(m1)) % kRing] = make_uint2(sbase - begin + 64u + (uint32_t)lane + 1u, g1);
+        qcount += n0 + (uint32_t)__popcll(m1);
+        sbase = min(sbase + 128u, end);
+    };
+    // ---- stage two state: the batch whose gathers are in flight ----
+    uint32_t bn = 0;                                      // its size (0: none)
+    uint2 bpg = make_uint2(0u, 0u);
+    float2 nxy = make_float2(0.f, 0.f);
+    float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = nco, nrgb2 = nco;
+    auto issue_batch = [&]() {                            // dequeue up to 64 survivors and gather their records
+        bn = min(qcount, 64u);
+        bpg = make_uint2(0u, 0u);
+        if ((uint32_t)lane < bn) {
+            bpg = s_ring[(qhead + (uint32_t)lane) % kRing];
+            nxy = xy[bpg.y]; nco = conic_o[bpg.y]; nrgb = rgb_invd[bpg.y];
+            if constexpr (DUAL) nrgb2 = make_float4(colors2[3 * (size_t)bpg.y], colors2[3 * (size_t)bpg.y + 1], colors2[3 * (size_t)bpg.y + 2], 0.f);
+        }
+        qhead = (qhead + bn) % kRing;
+        qcount -= bn;
+    };
+    auto fill = [&]() {                                   // stage one until a full batch is queued or the list is exhausted
+        while (qcount < 64u && sbase < end) {
+            consume_chunk();                              // (the ring holds < 64 + 128 entries)
+            if (sbase < end) { chunk_ids(sbase); chunk_recs(); }      // rarely taken twice in a row: dependent loads, not prefetched
+        }
+    };
+
+    if (begin < end) { chunk_ids(begin); chunk_recs(); }
+    __builtin_amdgcn_wave_barrier();
+    fill();
+    __builtin_amdgcn_wave_barrier();
+    issue_batch();
+    while (bn != 0u) {
+        // ---- stage two on the batch in flight (the body of composite_fwd_rows_kernel) ----
+        const float2 cxy = nxy;
+        const float4 cco = nco, crgb = nrgb, crgb2 = nrgb2;
+        const uint2 cpg = bpg;
+        const bool have = (uint32_t)lane < bn;
+        const SplatCull sc = splat_cull(cco.x, cco.y, cco.z, cco.w);
+        const float hx = have ? sc.hx : -1.0f, hy = sc.hy;
+        __builtin_amdgcn_wave_barrier();                  // previous batch's LDS reads are done (program order)
+        {
+            const ConicQ cq = conic_q(cco.x, cco.y, cco.z);
+            s_co[lane] = make_float4(cq.a, cq.b, cq.c, have ? cco.w : 0.f);
+            s_rgb[lane] = crgb;
+            s_xyp[lane] = make_float4(cxy.x, cxy.y, __uint_as_float(cpg.x), 0.f);
+            if constexpr (DUAL) s_rgb2[lane] = crgb2;
+        }
+        BlockHits bh = block_hits4(cxy.x, cxy.y, hx, hy, bx0, by0);
+        if (exact_cull) bh = block_hits4_exact(cxy.x, cxy.y, cco.x, cco.y, cco.z, sc, bx0, by0, bh);
+        unsigned long long m[4];
+        const int trip = build_row_lists(s_list, bh.r0, bh.r1, bh.r2, bh.r3, lane, m);
+        if (blk_base) {
+            const unsigned long long dm = __builtin_amdgcn_ballot_w64(done);
+            const uint2 rec = cpg;                        // 1-based list position, id
+            if ((dm & 0xffffull) != 0xffffull) {
+                if (bh.r0) blk_base[bc0 + (uint32_t)lanes_below(m[0])] = rec;
+                bc0 += (uint32_t)__popcll(m[0]);
+            }
+            if (((dm >> 16) & 0xffffull) != 0xffffull) {
+                if (bh.r1) blk_base[blk_cap + bc1 + (uint32_t)lanes_below(m[1])] = rec;
+                bc1 += (uint32_t)__popcll(m[1]);
+            }
+            if (((dm >> 32) & 0xffffull) != 0xffffull) {
+                if (bh.r2) blk_base[2 * (size_t)blk_cap + bc2 + (uint32_t)lanes_below(m[2])] = rec;
+                bc2 += (uint32_t)__popcll(m[2]);
+            }
+            if ((dm >> 48) != 0xffffull) {
+                if (bh.r3) blk_base[3 * (size_t)blk_cap + bc3 + (uint32_t)lanes_below(m[3])] = rec;
+                bc3 += (uint32_t)__popcll(m[3]);
+            }
+        }
+        // ---- the next batch: stage one from the chunk in flight, then its gathers and the next chunk's loads ----
+        fill();
+        __builtin_amdgcn_wave_barrier();                  // ring writes before the dequeue reads (program order)
+        issue_batch();
+        __builtin_amdgcn_wave_barrier();
+        // ---- blend ----
+        const uint16_t *const my_list = s_list[rg.row];
+        bool all_done = false;
+        for (int i = 0; i < trip; i += 2) {
+            const uint32_t o0 = my_list[i], o1 = my_list[i + 1];
+            const float4 e0xy = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_xyp) + o0);
+            const float4 e1xy = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_xyp) + o1);
+            const float4 e0co = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_co) + o0);
+            const float4 e1co = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_co) + o1);
+            const float4 e0rgb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rgb) + o0);
+            const float4 e1rgb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rgb) + o1);
+            float al0, G0, al1, G1;
+            bool ok0, ok1;
+            splat_eval_q(e0xy.x - fx, e0xy.y - fy, ConicQ{e0co.x, e0co.y, e0co.z}, e0co.w, al0, G0, ok0);
+            splat_eval_q(e1xy.x - fx, e1xy.y - fy, ConicQ{e1co.x, e1co.y, e1co.z}, e1co.w, al1, G1, ok1);
+            {
+                const bool act = ok0 && !done;
+                const float test_T = T * (1.0f - al0);
+                const bool keep = !(test_T < kTmin);
+                const bool bl = act && keep;
+                const float w = bl ? al0 * T : 0.f;
+                C0 += e0rgb.x * w; C1 += e0rgb.y * w; C2 += e0rgb.z * w; Dp += e0rgb.w * w;
+                if constexpr (DUAL) {
+                    const float4 u = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rgb2) + o0);
+                    E0 += u.x * w; E1 += u.y * w; E2 += u.z * w;
+                }
+                T = bl ? test_T : T;
+                last = bl ? __float_as_uint(e0xy.z) : last;
+                done = done || (act != bl);
+            }
+            {
+                const bool act = ok1 && !done;
+                const float test_T = T * (1.0f - al1);
+                const bool keep = !(test_T < kTmin);
+                const bool bl = act && keep;
+                const float w = bl ? al1 * T : 0.f;
+                C0 += e1rgb.x * w; C1 += e1rgb.y * w; C2 += e1rgb.z * w; Dp += e1rgb.w * w;
+                if constexpr (DUAL) {
+                    const float4 u = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rgb2) + o1);
+                    E0 += u.x * w; E1 += u.y * w; E2 += u.z * w;
+                }
+                T = bl ? test_T : T;
+                last = bl ? __float_as_uint(e1xy.z) : last;
+                done = done || (act != bl);
+            }
+            if (__builtin_amdgcn_ballot_w64(done) == ~0ull) { i = trip; all_done = true; }      // whole quadrant saturated
+        }
+        if (all_done) break;
+    }
+    if (inside) {
+        const size_t pid = (size_t)rg.py * W + rg.px;
+        const size_t hw = (size_t)H * W;
+        final_T[pid] = T;
+        n_contrib[pid] = last;
+        out_color[pid] = C0 + T * bg[0];
+        out_color[hw + pid] = C1 + T * bg[1];
+        out_color[2 * hw + pid] = C2 + T * bg[2];
+        if (out_invdepth) out_invdepth[pid] = Dp;
+        if constexpr (DUAL) {
+            out_color2[pid] = E0 + T * bg2[0];
+            out_color2[hw + pid] = E1 + T * bg2[1];
+            out_color2[2 * hw + pid] = E2 + T * bg2[2];
+        }
+    }
+    if (blk_count && (lane & 15) == 0) {
+        const int r = lane >> 4;
+        blk_count[16 * (size_t)q.tile + 4 * q.quad + r] = r == 0 ? bc0 : (r == 1 ? bc1 : (r == 2 ? bc2 : bc3));
+    }
+}
+
 }  // namespace d3ga
 
 using namespace d3ga;
@@ -216,6 +437,18 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
     const bool ordered = (composite_variant() & kVariantOrdered) != 0, exact = (composite_variant() & kVariantExactCull) != 0;
     const dim3 grid(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy));
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
+    if (composite_variant() & kVariantTwoStage) {
+        if (colors2)
+            hipLaunchKernelGGL(composite_fwd_q_kernel<true>, grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,
+                               bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,
+                               out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact);
+        else
+            hipLaunchKernelGGL(composite_fwd_q_kernel<false>, grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,
+                               bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,
+                               out_color, out_invdepth, order, (const float *)nullptr, (const float *)nullptr, (float *)nullptr,
+                               im.blk_list, im.blk_count, exact);
+        return check_launch(s, prm->debug);
+    }
     if (colors2)
         hipLaunchKernelGGL(composite_fwd_rows_kernel<true>, grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,
                            bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib,

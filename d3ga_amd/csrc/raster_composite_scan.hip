@@ -490,6 +490,9 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
                     pa[k] = *reinterpret_cast<const float4 *>(pixq + k * PIXF);
                     pb[k] = *reinterpret_cast<const float4 *>(pixq + k * PIXF + 4);
                     if constexpr (DUAL) pc[k] = *reinterpret_cast<const float4 *>(pixq + k * PIXF + 8);
+                    // the whole record is loaded HERE: left alone the compiler sinks the load of T_final (bg . g) into a
+                    // divergent region behind `valid` -- an LDS round trip in the middle of every block line
+                    asm volatile("" : "+v"(pb[k].x), "+v"(pb[k].y), "+v"(pb[k].z));
                 }
                 const float dy = eyr - (float)ky;
                 const float tb = cq.b * dy, tc = (cq.c * dy) * dy;

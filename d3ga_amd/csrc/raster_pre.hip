@@ -7,7 +7,7 @@
 // Gaussian: fwd 88 + 12 M).  The wide (P,M,3) SH arrays go through per-wavefront LDS slabs so that
 // global accesses are 16 B per lane and lane-contiguous; the camera matrices are wave-uniform and come through the
 // scalar cache.  No MFMA.
-#include "d3ga_internal.h"
+#include "composite_common.h"
 #include "raster_pre_body.h"
 
 namespace d3ga {
@@ -172,6 +172,10 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
                                                (uint32_t)sp.rect[2] | ((uint32_t)sp.rect[3] << 16))
                                   : make_uint2(0u, 0u);
         geom.conic_o[i] = make_float4(sp.conic[0], sp.conic[1], sp.conic[2], o.opacity);
+        {   // half extents of the splat's alpha >= 1/255 box, by the function the compositing stage culls with (bit-identical)
+            const SplatCull sc = splat_cull(sp.conic[0], sp.conic[1], sp.conic[2], o.opacity);
+            geom.xyh[i] = make_float4(sp.px, sp.py, sp.visible ? sc.hx : -1.0f, sc.hy);
+        }
         geom.rgb_invd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], sp.visible ? 1.0f / sp.depth : 0.f);
         geom.clamped[i] = o.clampmask;
         visible = sp.visible;
@@ -227,6 +231,7 @@ __global__ __launch_bounds__(kBlock) void recolor_kernel(d3ga_raster_params prm,
     dst.depth[i] = depth;
     dst.xy[i] = src.xy[i];
     dst.conic_o[i] = src.conic_o[i];
+    dst.xyh[i] = src.xyh[i];
     dst.rect[i] = rc;
 #pragma unroll
     for (int k = 0; k < 6; ++k) dst.cov3D[6 * (size_t)i + k] = src.cov3D[6 * (size_t)i + k];

@@ -35,23 +35,33 @@ def main():
     asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fno-gpu-rdc",
                           "-fno-slp-vectorize", "-S", "--cuda-device-only", SRC, "-o", "-"], capture_output=True, text=True, check=True).stdout
     lines = asm.split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN4d3ga25composite_bwd_scan_kernelILb0"))
+    kname = sys.argv[1] if len(sys.argv) > 1 else "_ZN4d3ga25composite_bwd_tile_kernelILb0ELi512"
+    start = next(i for i, l in enumerate(lines) if l.startswith(kname))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = lines[start:end]
-    d1 = next(i for i, l in enumerate(body) if "Loop Header: Depth=1" in l)
+    # the group loop = the depth-1 loop that contains the four-line loop (the kernel has small depth-1 loops in front of it)
+    d1 = next(i for i, l in enumerate(body) if "Loop Header: Depth=1" in l and any("Child Loop" in x for x in body[i + 1:i + 6]))
     counts = {"plain": 0, "dpp": 0, "trans": 0, "packed": 0, "vop3_other": 0}
     other = {"lds": 0, "vmem": 0, "salu": 0}
     depth = 1
+    first_d2 = True
+    seen_d2 = 0
     for l in body[d1:]:
-        if "Depth=2" in l and "Header" in l:
-            depth = 2
-        elif re.search(r"in Loop: Header=\S+ Depth=1", l):
-            depth = 1
+        if "Loop Header" in l and "Depth=2" in l:
+            seen_d2 += 1
+            first_d2 = seen_d2 == 1                          # the four-line pixel loop comes first; the insert loop is counted once per attempt
+        m = re.search(r"Depth=(\d)", l)
+        if m and ("Header" in l):
+            depth = int(m.group(1))
+        if "Depth=1" in l and "Loop Header" in l and l is not body[d1]:
+            break                                            # the next top-level loop (final publish)
         t = l.strip()
         if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
             continue
         op = t.split()[0]
-        w = 4 if depth == 2 else 1
+        if depth >= 3:
+            continue                                         # the rare displaced-record publish inside the insert loop
+        w = 4 if (depth == 2 and first_d2) else 1
         c = classify(op, t)
         if c:
             counts[c] += w
@@ -61,10 +71,10 @@ def main():
             other["vmem"] += w
         elif op.startswith("s_"):
             other["salu"] += w
-    out = {"kernel": "composite_bwd_scan_kernel<false>", "unit": "instructions per 16-entry group (inner loop x 4)", "counts": counts,
+    out = {"kernel": kname, "unit": "instructions per 16-entry group (pixel-line loop x 4, one insert attempt)", "counts": counts,
            "non_valu": other, "note": "vop3_other is priced at the v_cndmask_b32_e64 / v_cmp_*_e64 / v_med3 / v_bfi rate measured by "
            "tools/micro/valu_issue.hip (1.9 ns vs 1.2 ns for v_fma_f32 at 8 waves/SIMD)", "vop3_other_cycles": 3.8}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r02_composite_bwd_mix.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "r03_composite_bwd_mix.json"), "w"), indent=1)
     print(json.dumps(out))
 
 
