@@ -19,9 +19,11 @@ EXTRA = {"raster_composite_scan.hip": ["-fno-slp-vectorize"],
 if os.environ.get("D3GA_ALL_NOSLP"):                          # A/B: every translation unit
     FLAGS.append("-fno-slp-vectorize")
 if ABL:
-    FLAGS.append("-DD3GA_SCAN_ABL=" + ABL.split("w")[0].split("p")[0])
+    FLAGS.append("-DD3GA_SCAN_ABL=" + ABL.split("w")[0].split("p")[0].split("f")[0])
     if "w" in ABL:                         # e.g. D3GA_SCAN_ABL=0w5: no ablation, register budget for 5 wavefronts per SIMD
         FLAGS.append("-DD3GA_TILE_WAVES=" + ABL.split("w")[1])
+    if "f" in ABL:                         # e.g. D3GA_SCAN_ABL=0f6: two-stage forward with the register budget of 6 wavefronts per SIMD
+        FLAGS.append("-DD3GA_FWD_WAVES=" + ABL.split("f")[1])
     if "p" in ABL:                         # e.g. D3GA_SCAN_ABL=0p: s_setprio by remaining groups
         FLAGS.append("-DD3GA_TILE_PRIO=1")
 if os.environ.get("D3GA_DIAG"):            # diagnostic build (loop statistics and per-wave timeline, tools/diag_scan.py); never the shipped one

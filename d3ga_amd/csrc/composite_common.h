@@ -192,7 +192,8 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {       // every lan
 // so the blend loop needs neither a per-row count nor an index mask.  Returns the trip count (longest list); m[] are the
 // four hit masks.  (LDS instructions of one wavefront execute in order: the padding lands before the entries.)
 constexpr uint16_t kNullRec = 64 * 16;
-__device__ __forceinline__ int build_row_lists(uint16_t (*s_list)[64], bool r0, bool r1, bool r2, bool r3, int lane,
+constexpr int kListStride = 66;       // 64 entries + two null records: the blend loop reads its offsets one iteration ahead
+__device__ __forceinline__ int build_row_lists(uint16_t (*s_list)[kListStride], bool r0, bool r1, bool r2, bool r3, int lane,
                                                unsigned long long (&m)[4]) {
     m[0] = __ballot(r0); m[1] = __ballot(r1); m[2] = __ballot(r2); m[3] = __ballot(r3);
     s_list[0][lane] = kNullRec; s_list[1][lane] = kNullRec; s_list[2][lane] = kNullRec; s_list[3][lane] = kNullRec;

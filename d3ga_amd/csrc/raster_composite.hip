@@ -26,6 +26,11 @@
 
 #include "composite_common.h"
 
+// wavefronts per SIMD the register budget of the two-stage forward targets (A/B: build.py D3GA_SCAN_ABL=0f6)
+#ifndef D3GA_FWD_WAVES
+#define D3GA_FWD_WAVES 5
+#endif
+
 namespace d3ga {
 
 // DUAL: a second set of per-Gaussian colours (colors2, (P,3), read by Gaussian id) is blended with the same alphas into
@@ -60,12 +65,13 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
     __shared__ float4 s_rgb[65];
     __shared__ float4 s_xyp[65];
     __shared__ float4 s_rgb2[DUAL ? 65 : 1];
-    __shared__ uint16_t s_list[4][64];
+    __shared__ uint16_t s_list[4][kListStride];
     if (threadIdx.x == 0) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         s_co[64] = z; s_rgb[64] = z; s_xyp[64] = z;
         if constexpr (DUAL) s_rgb2[64] = z;
     }
+    if (threadIdx.x < 8) s_list[threadIdx.x >> 1][64 + (threadIdx.x & 1)] = kNullRec;
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     float E0 = 0.f, E1 = 0.f, E2 = 0.f;                    // DUAL: the second image
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
 // (entry, block) pairs, the emitted lists and every pixel are identical to the kernel above.
 // Pipeline per batch: its gathers and the next stage-one loads are issued BEFORE the previous batch is blended.
 template <bool DUAL>
-__global__ __launch_bounds__(64) void composite_fwd_q_kernel(
+__global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
     uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
     const float4 *__restrict__ rgb_invd, const float4 *__restrict__ xyh, const float *__restrict__ bg,
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(64) void composite_fwd_q_kernel(
     __shared__ float4 s_rgb[65];
     __shared__ float4 s_xyp[65];
     __shared__ float4 s_rgb2[DUAL ? 65 : 1];
-    __shared__ uint16_t s_list[4][64];
+    __shared__ uint16_t s_list[4][kListStride];
     constexpr int kRing = 256;                            // survivors of stage one: (1-based list position, Gaussian id)
     __shared__ uint2 s_ring[kRing];
     if (threadIdx.x == 0) {
@@ -247,6 +253,7 @@ __global__ __launch_bounds__(64) void composite_fwd_q_kernel(
         s_co[64] = z; s_rgb[64] = z; s_xyp[64] = z;
         if constexpr (DUAL) s_rgb2[64] = z;
     }
+    if (threadIdx.x < 8) s_list[threadIdx.x >> 1][64 + (threadIdx.x & 1)] = kNullRec;
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     float E0 = 0.f, E1 = 0.f, E2 = 0.f;
@@ -352,8 +359,10 @@ __global__ __launch_bounds__(64) void composite_fwd_q_kernel(
         // ---- blend ----
         const uint16_t *const my_list = s_list[rg.row];
         bool all_done = false;
+        uint32_t p0 = my_list[0], p1 = my_list[1];         // list offsets are read one iteration ahead: off the dependent chain
         for (int i = 0; i < trip; i += 2) {
-            const uint32_t o0 = my_list[i], o1 = my_list[i + 1];
+            const uint32_t o0 = p0, o1 = p1;
+            p0 = my_list[i + 2]; p1 = my_list[i + 3];      // (i + 3 <= 65: two null records behind the 64 entries)
             const float4 e0xy = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_xyp) + o0);
             const float4 e1xy = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_xyp) + o1);
             const float4 e0co = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_co) + o0);
