@@ -150,7 +150,7 @@ def _settings(inp, bg, sh_degree, mod=1.0):
         sh_degree=sh_degree, campos=inp["campos"].to(DEV), prefiltered=False, debug=False, antialiasing=False)
 
 
-def _oracle(inp, bg, gpix, sh_degree, use_sh=True, from_sr=False, mod=1.0, rots=None):
+def _oracle(inp, bg, gpix, sh_degree, use_sh=True, from_sr=False, mod=1.0, rots=None, mask=True):
     cam = inp["cam"]
     kw = dict(shs=_np(inp["shs"]), sh_degree=sh_degree) if use_sh else dict(colors_precomp=_np(inp["rgb"]))
     if from_sr:
@@ -160,7 +160,17 @@ def _oracle(inp, bg, gpix, sh_degree, use_sh=True, from_sr=False, mod=1.0, rots=
     color, radii, invd, ctx = rc.forward(_np(inp["means3D"]), _np(inp["opacities"]), _np(bg), cam["world_view_transform"],
                                          cam["full_proj_transform"], cam["camera_center"], cam["tanfovx"],
                                          cam["tanfovy"], inp["W"], inp["H"], **kw)
-    grads = rc.backward(ctx, _np(gpix)) if gpix is not None else None
+    grads = None
+    if gpix is not None:
+        # Round 3: `gpix` (CPU tensor) is zeroed IN PLACE on the oracle's marginal pixels before EITHER backward sees it, so
+        # that every Gaussian can be held to the strict element-wise bar (tests/util.py: Parity).  mask=False keeps the raw
+        # gradient (the one smoke test at the loose bar).
+        if mask:
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                Parity(ctx).mask(gpix)
+            ctx.gradient_masked = True
+        grads = rc.backward(ctx, _np(gpix))
     return color, radii, invd, ctx, grads
 
 
@@ -173,8 +183,8 @@ def _assert_grads(par, pairs, **kw):
     """pairs: (mine, oracle, name) of per-Gaussian tensors."""
     for mine, ref, what in pairs:
         ok, strict, loose, n = par.grads(_np(mine) if torch.is_tensor(mine) else mine, _np(ref) if torch.is_tensor(ref) else ref, **kw)
-        assert ok, (f"dL/d{what}: non-marginal Gaussians exceed |a-b| <= 1e-3|b| + 1e-6 max|b| by x{strict:.2f}; "
-                    f"{n} marginal Gaussians max-norm error {loose:.3e}")
+        assert ok, (f"dL/d{what}: strictly held Gaussians ({'all' if par.masked else 'non-marginal'}) exceed |a-b| <= 1e-3|b| + 1e-6 max|b| "
+                    f"by x{strict:.2f}; {n} loosely held Gaussians max-norm error {loose:.3e}")
 
 
 @pytest.mark.parametrize("name,scale_mult,deg", [("T0", 3.0, 3), ("T1", 2.0, 3), ("T1", 6.0, 1), ("C1", 1.0, 3)])
@@ -199,6 +209,25 @@ def test_rasterizer_sh_precomp_cov_forward_backward(name, scale_mult, deg):
     _assert_grads(par, ((means.grad, og["means3D"], "means3D"), (cov.grad, og["cov3D"], "cov3D"),
                         (op.grad, og["opacities"], "opacity"), (sh.grad, og["shs"], "sh"),
                         (m2d.grad, og["means2D"], "means2D")))
+
+
+def test_unmasked_gradients_smoke_at_the_loose_bar():
+    """The ONE comparison that keeps the raw incoming gradient on the marginal pixels (every other test zeroes it there,
+    tests/util.py: Parity): non-marginal Gaussians strict, Gaussians that touch a marginal pixel within 5 % of the largest
+    gradient -- a flipped alpha >= 1/255 or T < 1e-4 decision moves them by one pixel's worth of gradient at most."""
+    from d3ga_amd.rasterizer import GaussianRasterizer
+    inp = scene_inputs("C1")
+    bg = torch.tensor([1.0, 0.5, 0.2])
+    gpix = torch.randn(3, inp["H"], inp["W"], generator=torch.Generator().manual_seed(1))
+    means, cov, op, sh = (_cu(inp[k], True) for k in ("means3D", "cov6", "opacities", "shs"))
+    color, _, _ = GaussianRasterizer(_settings(inp, bg, 3))(means3D=means, means2D=None, opacities=op, shs=sh, cov3D_precomp=cov)
+    ocolor, _, _, ctx, og = _oracle(inp, bg, gpix, 3, mask=False)
+    par = Parity(ctx)
+    assert not par.masked and par.gauss.any()
+    _assert_image(par, _np(color), ocolor)
+    (color * gpix.to(DEV)).sum().backward()
+    _assert_grads(par, ((means.grad, og["means3D"], "means3D"), (cov.grad, og["cov3D"], "cov3D"),
+                        (op.grad, og["opacities"], "opacity"), (sh.grad, og["shs"], "sh")))
 
 
 def test_tile_lists_identical_to_oracle():
@@ -258,13 +287,14 @@ def test_render_boundary_end_to_end_with_crop_and_detach():
     from oracle.camera import paste
     par = Parity(ctx)
     par_crop = Parity.__new__(Parity)                    # the same masks seen through the crop window
-    par_crop.pix, par_crop.gauss = paste(par.pix[None], crop)[0], par.gauss
+    par_crop.pix, par_crop.gauss, par_crop.masked = paste(par.pix[None], crop)[0], par.gauss, False
     _assert_image(par_crop, _np(out), paste(ocolor, crop))
     target = torch.rand(out.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
-    (out - target).abs().mean().backward()
     gfull = torch.zeros(3, inp["H"], inp["W"])
     sub = paste(gfull, crop)
-    sub[:] = torch.sign(out.detach().cpu() - target.cpu()) / out.numel()
+    sub[:] = torch.sign(out.detach().cpu() - target.cpu()) / out.numel()      # dL/dimage of mean |out - target| ...
+    par.mask(gfull)                                                           # ... zeroed on the marginal pixels, both sides
+    (out * paste(gfull, crop).to(DEV)).sum().backward()
     og = rc.backward(ctx, _np(gfull))
     t64 = lambda t: t.detach().cpu().double().requires_grad_(True)
     tp64, b64, s64, r64 = t64(tp), t64(b), t64(s), t64(r)
@@ -382,7 +412,7 @@ def test_full_size_c3_against_oracle_and_properties():
     np.testing.assert_array_equal(_np(radii), oradii)
     assert cnt["D"] == rc.num_rendered(ctx)
     par = Parity(ctx)
-    print("marginal pixels", int(par.pix.sum()), "of", par.pix.size, "| marginal Gaussians", int(par.gauss.sum()), "of", par.gauss.size)
+    assert par.masked and par.pixel_share < 0.005          # C3: 0.2 % of the pixels are marginal -- and 72 % of the Gaussians touch one of them
     _assert_image(par, _np(color), ocolor)
     (color * gpix.to(DEV)).sum().backward()
     _assert_grads(par, ((means.grad, og["means3D"], "means3D"), (cov.grad, og["cov3D"], "cov3D"),
@@ -420,16 +450,16 @@ def test_baseline_configs_c2_c4_against_oracle(name, cx, cy):
     crop = inp["batch"]["crop"]
     assert out.shape == (3, int(crop[5]), int(crop[4]))
     gsub = torch.randn(out.shape, generator=torch.Generator().manual_seed(4))
-    (out * gsub.to(DEV)).sum().backward()
     gfull = torch.zeros(3, inp["H"], inp["W"])
     paste(gfull, crop)[:] = gsub
     # the oracle rasterizer gets the SAME Gaussians the HIP rasterizer got (the HIP deform's outputs; the deform itself is
     # checked against its own goldens): otherwise its ~1e-4 relative covariance differences move alpha at the thresholds
     inp_r = dict(inp, means3D=means.detach().cpu(), cov6=cov6.detach().cpu())
-    ocolor, _, _, ctx, og = _oracle(inp_r, bg, gfull, 3)
+    ocolor, _, _, ctx, og = _oracle(inp_r, bg, gfull, 3)          # masks gfull on the marginal pixels (in place)
+    (out * paste(gfull, crop).to(DEV)).sum().backward()
     par = Parity(ctx)
     par_crop = Parity.__new__(Parity)                    # the same masks seen through the crop window
-    par_crop.pix, par_crop.gauss = paste(par.pix[None], crop)[0], par.gauss
+    par_crop.pix, par_crop.gauss, par_crop.masked = paste(par.pix[None], crop)[0], par.gauss, par.masked
     _assert_image(par_crop, _np(out), paste(ocolor, crop))
     _assert_grads(par, ((sh.grad, og["shs"], "sh"), (op.grad, og["opacities"], "opacity")))
     t64 = lambda t: t.detach().cpu().double().requires_grad_(True)
@@ -441,7 +471,7 @@ def test_baseline_configs_c2_c4_against_oracle(name, cx, cy):
     vmask = np.zeros(tp.shape[0], bool)
     vmask[_np(sc["tetras"].long()[sc["tetra_id"].long()[torch.from_numpy(par.gauss)]]).reshape(-1)] = True
     par_v = Parity.__new__(Parity)
-    par_v.pix, par_v.gauss = par.pix, vmask
+    par_v.pix, par_v.gauss, par_v.masked = par.pix, vmask, par.masked
     _assert_grads(par_v, ((tp.grad, tp64.grad, "tetpoints"),))
 
 
@@ -759,6 +789,8 @@ def test_fused_sigmoid_opacity_matches_the_separate_activation():
     means, cov, sh = (_cu(inp[k], True) for k in ("means3D", "cov6", "shs"))
     lg_a, lg_b = _cu(logits, True), _cu(logits, True)
     st = _settings(inp, bg, 3)
+    inp_o = dict(inp, opacities=torch.sigmoid(logits))
+    ocolor, _, _, ctx, og = _oracle(inp_o, bg, gpix, 3)           # first: it masks gpix on the marginal pixels (in place)
     fused, _, _ = GaussianRasterizer(st, opacity_activation="sigmoid")(means3D=means, means2D=None, opacities=lg_a, shs=sh,
                                                                        cov3D_precomp=cov)
     (fused * gpix.to(DEV)).sum().backward()
@@ -766,8 +798,6 @@ def test_fused_sigmoid_opacity_matches_the_separate_activation():
     act = torch.sigmoid(lg_b)
     plain, _, _ = GaussianRasterizer(st)(means3D=means, means2D=None, opacities=act, shs=sh, cov3D_precomp=cov)
     (plain * gpix.to(DEV)).sum().backward()
-    inp_o = dict(inp, opacities=torch.sigmoid(logits))
-    ocolor, _, _, ctx, og = _oracle(inp_o, bg, gpix, 3)
     par = Parity(ctx)
     _assert_image(par, _np(fused), ocolor)
     _assert_image(par, _np(plain), ocolor)

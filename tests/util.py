@@ -39,16 +39,37 @@ class Parity:
     The algorithm is discontinuous where alpha crosses 1/255 and where T (1 - alpha) crosses 1e-4; two correct float32
     implementations can take different branches when the compared value sits within their rounding difference of the
     threshold.  The oracle reports exactly those places (`oracle.raster_c.margins`: per-pixel decision margins, and the
-    Gaussians that can contribute to a marginal pixel).  Everything else is held to the bars of BASELINE.md with NO
-    allowance:
-        image     non-marginal pixels     max |a - b| <= 1e-4            (zero outliers)
-        gradients non-marginal Gaussians  |a - b| <= 1e-3 |b| + 1e-6 max|b|   element-wise
-    Marginal pixels may move by one dropped / extra splat (<= alpha T <= 1/255 per decision, 8e-3 allowed), marginal
-    Gaussians by one pixel's worth of gradient (5 % of the largest gradient allowed)."""
+    Gaussians that can contribute to a marginal pixel).  Bars, with NO allowance outside those places:
+        image      non-marginal pixels   max |a - b| <= 1e-4            (zero outliers); marginal pixels 8e-3
+        gradients  EVERY Gaussian        |a - b| <= 1e-3 |b| + 1e-6 max|b|   element-wise
+    Round 3: pixels are independent in compositing and every gradient term of a pixel is linear in that pixel's incoming
+    dL/dpixel, so the tests ZERO the incoming gradient on the oracle's marginal pixels on both sides (`mask`): whatever
+    branch either implementation took there contributes exactly nothing, and 100 % of the Gaussians take the strict
+    bar (round 2 held the 12 % of the Gaussians that touch a marginal pixel at C3 to 5 % of the largest gradient only).
+    An unmasked comparison at that loose bar remains as a smoke check (`grads` on a Parity whose `masked` is False)."""
+
+    MAX_PIXEL_SHARE = 0.05          # a creeping epsilon would show up here first (C3: 0.2 % of the pixels; scenes of a few huge splats: 3 %)
 
     def __init__(self, ctx, eps_alpha=1e-5, eps_T=1e-3):
         from oracle import raster_c as rc
         self.pix, self.gauss = rc.margins(ctx, eps_alpha, eps_T)
+        self.masked = bool(getattr(ctx, "gradient_masked", False))
+        ps, gs = float(self.pix.mean()) if self.pix.size else 0.0, float(self.gauss.mean()) if self.gauss.size else 0.0
+        print(f"[parity] marginal pixels {int(self.pix.sum())}/{self.pix.size} ({100 * ps:.3f} %), Gaussians touching one "
+              f"{int(self.gauss.sum())}/{self.gauss.size} ({100 * gs:.1f} %), incoming gradient masked there: {self.masked}")
+        self.pixel_share, self.gauss_share = ps, gs
+        if self.pix.size >= 4096:                          # (tiny fuzz images: a handful of pixels is no statistic)
+            assert ps <= self.MAX_PIXEL_SHARE, f"the share of marginal pixels grew to {ps:.4f}: check eps"
+
+    def mask(self, gpix):
+        """Zero an incoming image gradient (3,H,W) (torch CPU tensor or numpy array) IN PLACE on the marginal pixels."""
+        if hasattr(gpix, "numpy"):
+            import torch
+            gpix[:, torch.from_numpy(self.pix)] = 0
+        else:
+            gpix[:, self.pix] = 0
+        self.masked = True
+        return gpix
 
     def image(self, img, ref, atol=1e-4, marginal_atol=8e-3):
         """-> (ok, max error on non-marginal pixels, max error on marginal pixels, number of marginal pixels)"""
@@ -59,15 +80,15 @@ class Parity:
         return bool(strict <= atol and loose <= marginal_atol), strict, loose, int(self.pix.sum())
 
     def grads(self, a, b, rtol=1e-3, atol_rel=1e-6, marginal_rtol=5e-2):
-        """per-Gaussian tensors (P, ...) -> (ok, worst excess ratio on non-marginal Gaussians (<= 1 passes), worst
-        max-norm error on marginal Gaussians, number of marginal Gaussians)"""
+        """per-Gaussian tensors (P, ...) -> (ok, worst excess ratio on the strictly held Gaussians (<= 1 passes), worst
+        max-norm error on the loosely held ones, their number).  masked: every Gaussian is held strictly."""
         b = np.asarray(b, np.float64)
         a = np.asarray(a, np.float64).reshape(b.shape)
         a, b = a.reshape(len(b), -1), b.reshape(len(b), -1)
         scale = np.abs(b).max() + 1e-300
         d = np.abs(a - b)
         excess = d / (rtol * np.abs(b) + atol_rel * scale)
-        m = self.gauss[:len(b)]
+        m = np.zeros(len(b), bool) if self.masked else self.gauss[:len(b)]
         strict = float(excess[~m].max()) if (~m).any() else 0.0
         loose = float(d[m].max() / scale) if m.any() else 0.0
         return bool(strict <= 1.0 and loose <= marginal_rtol), strict, loose, int(m.sum())
