@@ -14,12 +14,64 @@ device buffers ("slots") that the captured kernels read:
         step.replay(camera=frame, target=frame["image"])      # two async copies + one graph launch
 
 Constraints (hipGraph): fixed shapes, fixed raster size (grid dimensions are baked), the binning capacity must be static
-(`rasterizer.set_capacity_policy("static", n)`, check `last_counters()["overflow"]` now and then), no host synchronisation
-inside `step_fn`.  Gradients land in the same static `.grad` tensors on every replay.  Do not keep the LOSS of an earlier eager
+(`rasterizer.set_capacity_policy("static", n)`), no host synchronisation inside `step_fn`.  The frozen capacity is WATCHED:
+every `check_every` replays the rasterizer's 16-byte counter block is copied to pinned host memory asynchronously and looked
+at once it has arrived -- a trainer whose splats grow past the capacity gets a `CapacityOverflowError` within
+2 x check_every replays instead of silently truncated tile lists (`check_overflow()` asks synchronously).  Gradients land in the same static `.grad` tensors on every replay.  Do not keep the LOSS of an earlier eager
 step alive across the capture: it keeps that step's autograd nodes (created on the default stream) alive, autograd then
 synchronises the capture with the default stream, and ending the capture crashes inside the HIP runtime.
 """
 import torch
+
+
+class CapacityOverflowError(RuntimeError):
+    """A replayed step produced more (tile, Gaussian) duplicates than the binning capacity frozen into its graph."""
+
+
+class _OverflowWatch:
+    """Asynchronous look at the counter block (D, overflow flag, longest list, visible) of the rasterizer forward a captured
+    graph contains.  The block lives in the graph's private pool, so the tensor seen at capture time stays the one every
+    replay writes."""
+
+    def __init__(self, check_every):
+        from . import rasterizer
+        dev = torch.cuda.current_device()
+        ent = rasterizer._last.get(dev)
+        self.every = max(int(check_every), 1)
+        self.block = None if ent is None else ent[0][:16].view(torch.int32)
+        self.cap = None if ent is None else ent[1]
+        self.host = torch.zeros(4, dtype=torch.int32).pin_memory() if self.block is not None else None
+        self.event, self.count = None, 0
+
+    def _inspect(self):
+        d, flag = int(self.host[0]) & 0xFFFFFFFF, int(self.host[1])
+        self.event = None
+        if flag:
+            raise CapacityOverflowError(
+                f"captured step: {d} (tile, Gaussian) duplicates exceed the binning capacity {self.cap} frozen into the graph -- "
+                f"the tile lists of the last replays were truncated.  Re-capture with rasterizer.set_capacity_policy('static', n) "
+                f"for n >= {int(1.25 * d)}.")
+
+    def after_replay(self):
+        if self.block is None:
+            return
+        self.count += 1
+        if self.event is not None and self.event.query():
+            self._inspect()
+        if self.event is None and self.count % self.every == 0:
+            self.host.copy_(self.block, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+
+    def check_now(self):
+        if self.block is None:
+            return None
+        self.host.copy_(self.block, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        self.event = None
+        d = int(self.host[0]) & 0xFFFFFFFF
+        self._inspect()
+        return {"D": d, "capacity": self.cap, "max_tile": int(self.host[2]) & 0xFFFFFFFF}
 
 
 class TensorSlot:
@@ -71,7 +123,7 @@ class TensorSlot:
 
 
 class CapturedStep:
-    def __init__(self, step_fn, params=(), slots=None, camera=None, warmup=2):
+    def __init__(self, step_fn, params=(), slots=None, camera=None, warmup=2, check_every=16):
         """step_fn(): the whole step (forward, loss, backward[, optimizer]) reading its per-step inputs from `slots`
         (name -> static device tensor) and, for the camera, from `camera` (a cameras.CameraSlot placed in the batch).
         params: the leaves whose `.grad` the step produces -- their gradients are dropped between the warm-up steps and the
@@ -93,6 +145,12 @@ class CapturedStep:
         with torch.cuda.graph(self.graph):
             self.result = step_fn()
         torch.cuda.synchronize()
+        self._watch = _OverflowWatch(check_every)
+
+    def check_overflow(self):
+        """Synchronous look at the last replay's duplicate count: raises CapacityOverflowError, else returns
+        dict(D, capacity, max_tile) (None when the step contains no rasterizer forward)."""
+        return self._watch.check_now()
 
     def replay(self, camera=None, **values):
         """camera: a batch dict (R, T, FoVx, FoVy, width, height) written into the CameraSlot; values: name -> tensor / array
@@ -109,6 +167,7 @@ class CapturedStep:
             else:
                 slot.copy_(v if torch.is_tensor(v) else torch.as_tensor(v), non_blocking=True)
         self.graph.replay()
+        self._watch.after_replay()
         return self.result
 
 
@@ -134,7 +193,7 @@ class CapturedCutStep:
 
     _ALIASES = {"opacity_logits": "opacities", "rgb": "colors_precomp"}
 
-    def __init__(self, upstream, loss_fn, sync, params=(), slots=None, camera=None, warmup=2):
+    def __init__(self, upstream, loss_fn, sync, params=(), slots=None, camera=None, warmup=2, check_every=16):
         self.slots = dict(slots or {})
         self.camera = camera
         self.sync = sync
@@ -157,8 +216,12 @@ class CapturedCutStep:
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
                 self._from_the_cut(up)
             torch.cuda.synchronize()
+            self._watch = _OverflowWatch(check_every)
         finally:
             sync.deferred = was
+
+    def check_overflow(self):
+        return self._watch.check_now()
 
     @classmethod
     def _to_the_cut(cls, upstream, loss_fn):
@@ -200,4 +263,5 @@ class CapturedCutStep:
         self.graph_a.replay()
         self.sync.exchange_parked()
         self.graph_b.replay()
+        self._watch.after_replay()
         return self.result
