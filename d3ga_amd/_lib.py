@@ -24,7 +24,7 @@ class RasterParams(ctypes.Structure):
                 ("W", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
                 ("antialiasing", ctypes.c_int32), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
-                ("opacity_activation", ctypes.c_int32)]
+                ("opacity_activation", ctypes.c_int32), ("forward_only", ctypes.c_int32)]
 
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -45,6 +45,7 @@ _SIGNATURES = {
     "d3ga_raster_scratch_bytes": ([ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, ctypes.POINTER(_i64)], _i),
     "d3ga_raster_binning_layout": ([ctypes.c_int32, ctypes.c_int32, _i64, ctypes.POINTER(_i64)], _i),
     "d3ga_raster_img_layout": ([ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_i64)], _i),
+    "d3ga_raster_img_bytes": ([ctypes.c_int32, ctypes.c_int32, _i64, ctypes.c_int32], _i64),
     "d3ga_raster_preprocess": ([_prm] + [_vp] * 12 + [_i64, _vp, _vp], _i),
     "d3ga_raster_bin_sort": ([_prm, _vp, _vp, _i64, _vp], _i),
     "d3ga_raster_composite_fwd": ([_prm, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i),

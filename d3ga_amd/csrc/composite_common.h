@@ -165,8 +165,19 @@ __device__ __forceinline__ BlockHits block_hits4_exact(float cx, float cy, float
     const float fy0 = clamp3(0.f, ya0, yb0), fy1 = clamp3(0.f, ya1, yb1);
     const float tB = 2.0f * B;
     // min over dy in [ya, yb] of q(fx, dy)
-    auto qx = [&](float fx, float ya, float yb) { const float dy = clamp3(c.nbc * fx, ya, yb); return A * fx * fx + dy * (tB * fx + C * dy); };
-    auto qy = [&](float fy, float xa, float xb) { const float dx = clamp3(c.nba * fy, xa, xb); return C * fy * fy + dx * (tB * fy + A * dx); };
+    // q is a sum of cancelling terms (a splat a thousand pixels long: terms ~1e6, tau ~11): what is compared is q minus a bound
+    // on its float32 rounding error, 1e-6 x the sum of the terms' magnitudes, so that the test stays conservative for ANY
+    // footprint (the fixed 0.1 % + 1e-4 inflation of tau alone covers |terms| up to ~1e4 only)
+    auto qx = [&](float fx, float ya, float yb) {
+        const float dy = clamp3(c.nbc * fx, ya, yb);
+        const float t0 = A * fx * fx, t1 = tB * fx * dy, t2 = C * dy * dy;
+        return (t0 + t1 + t2) - 1e-6f * (fabsf(t0) + fabsf(t1) + fabsf(t2));
+    };
+    auto qy = [&](float fy, float xa, float xb) {
+        const float dx = clamp3(c.nba * fy, xa, xb);
+        const float t0 = C * fy * fy, t1 = tB * fy * dx, t2 = A * dx * dx;
+        return (t0 + t1 + t2) - 1e-6f * (fabsf(t0) + fabsf(t1) + fabsf(t2));
+    };
     BlockHits h;
     // (!(q > tau): NaNs answer "relevant", like the box test)
     h.r0 = box.r0 && !(fminf(qx(fx0, ya0, yb0), qy(fy0, xa0, xb0)) > c.tau);

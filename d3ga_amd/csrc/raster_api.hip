@@ -27,6 +27,12 @@ extern "C" int d3ga_raster_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_
     return D3GA_OK;
 }
 
+extern "C" int64_t d3ga_raster_img_bytes(int32_t W, int32_t H, int64_t d_capacity, int32_t forward_only) {
+    if (W <= 0 || H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
+    const int64_t tiles = (int64_t)tiles_x(W) * tiles_y(H);
+    return forward_only ? 2 * align256(4 * (int64_t)W * H) : img_bytes(W, H, tiles, d_capacity > 0 ? d_capacity : 1);
+}
+
 extern "C" int d3ga_raster_binning_layout(int32_t W, int32_t H, int64_t d_capacity, int64_t offsets[6]) {
     if (!offsets) return D3GA_E_NULL;
     if (W <= 0 || H <= 0 || d_capacity < 0) return D3GA_E_SIZE;

@@ -442,7 +442,8 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
     const int gx = tiles_x(prm->W), gy = tiles_y(prm->H);
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
-    const ImgBuf im = carve_img(img, prm->W, prm->H, (int64_t)gx * gy);
+    ImgBuf im = carve_img(img, prm->W, prm->H, (int64_t)gx * gy);
+    if (prm->forward_only) { im.blk_list = nullptr; im.blk_count = nullptr; }     // the buffer ends behind n_contrib
     const bool ordered = (composite_variant() & kVariantOrdered) != 0, exact = (composite_variant() & kVariantExactCull) != 0;
     const dim3 grid(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy));
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
@@ -488,6 +489,7 @@ static int composite_bwd_impl(const d3ga_raster_params *prm, const float *bg, co
                               const float *bg2, const float *dL_dpix2, d3ga_stream_t stream) {
     if (!prm) return D3GA_E_NULL;
     if (prm->P < 0 || prm->W <= 0 || prm->H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
+    if (prm->forward_only) return D3GA_E_CONFIG;          // the forward did not write the per-block lists
     if (prm->P == 0) return D3GA_OK;
     if (!bg || !geom || !binning || !img || !dL_dpix || !acc) return D3GA_E_NULL;
     if (colors2 && (!bg2 || !dL_dpix2)) return D3GA_E_NULL;

@@ -160,8 +160,9 @@ class ViewShardedGrads:
         # Deferred mode (d3ga_amd.graph.CapturedCutStep): the rasterizer's backward parks its outputs here instead of
         # exchanging them, so that the step can be captured as two hipGraphs with the collectives issued between them.
         self.deferred = False
-        self.pending = None           # dict: flat, factor, parts {input name -> gradient view of flat}, sh (rebuild arguments)
-        self.gathered = None
+        self.parked = []              # one entry per rasterizer backward of the step: dict(flat, factor, parts {input name ->
+                                      # gradient view of flat}, sh (rebuild arguments), gathered)
+        self.frozen = False           # set once a graph has captured the parked buffers: their shapes may not change any more
 
     def verify_inputs(self, named):
         """Collective.  `named`: dict name -> tensor (or None) entering the rasterizer on this rank.  Raises
@@ -218,33 +219,53 @@ class ViewShardedGrads:
             self._events.append(ev)
         return gathered
 
+    def begin_step(self):
+        """Deferred mode: forget the previous step's parked buffers (eager steps; a captured step keeps the buffers it was
+        captured with and never calls this again)."""
+        if self.frozen:
+            raise RuntimeError("ViewShardedGrads: the parked buffers are baked into a captured graph (CapturedCutStep); "
+                               "use another ViewShardedGrads for eager steps")
+        self.parked = []
+
     def park(self, flat, factor, parts, sh=None):
-        """Deferred mode, called by the rasterizer's backward: remember this step's buffers (static tensors when the
-        backward is being captured).  `parts`: rasterizer input name -> its gradient, a view of `flat`."""
-        self.pending = {"flat": flat, "factor": factor, "parts": parts, "sh": sh}
+        """Deferred mode, called by EVERY rasterizer backward of the step (the reference's step renders twice,
+        models/trainer.py:102-110): remember its buffers (static tensors when the backward is being captured).  `parts`:
+        rasterizer input name -> its gradient, a view of `flat`."""
+        self.parked.append({"flat": flat, "factor": factor, "parts": parts, "sh": sh, "gathered": None})
 
     def exchange_parked(self):
-        """Deferred mode, eager, between the two graphs: the collectives of `exchange` on the parked buffers."""
-        if self.pending is None:
+        """Deferred mode, eager, between the two graphs: the collectives of `exchange` on every parked entry.  While a graph
+        is being captured its first half has not run, so the collectives of that one call move unspecified (never read)
+        data -- an extra collective every rank issues alike."""
+        if not self.parked:
             raise RuntimeError("ViewShardedGrads.exchange_parked: no rasterizer backward has parked its gradients")
-        # the gather buffer is kept: a captured second half of the step reads it at a fixed address
-        self.gathered = self.exchange(self.pending["flat"], self.pending["factor"], out=self.gathered)
+        for e in self.parked:
+            want = None if e["factor"] is None else (self.world,) + tuple(e["factor"].shape)
+            if self.frozen and e["gathered"] is not None and tuple(e["gathered"].shape) != want:
+                raise RuntimeError(f"ViewShardedGrads: the gather buffer {tuple(e['gathered'].shape)} baked into the captured graph "
+                                   f"no longer fits {want} (the number of Gaussians or the world size changed): re-capture")
+            # the gather buffer is kept: a captured second half of the step reads it at a fixed address
+            e["gathered"] = self.exchange(e["flat"], e["factor"], out=e["gathered"])
 
     def parked_gradients(self):
-        """Deferred mode, after `exchange_parked` (capturable): rasterizer input name -> reduced gradient, with the SH block
-        rebuilt from the gathered factors (d3ga_sh_grad_from_views)."""
+        """Deferred mode, after `exchange_parked` (capturable): rasterizer input name -> reduced gradient summed over the
+        step's renders, with the SH block rebuilt from the gathered factors (d3ga_sh_grad_from_views)."""
         from . import _lib
         from ._lib import check, dptr, stream_handle
-        out = dict(self.pending["parts"])
-        sh = self.pending["sh"]
-        if sh is not None:
-            P, M, deg, means3D = sh["P"], sh["M"], sh["sh_degree"], sh["means3D"]
-            g_sh = torch.empty((P, M, 3), dtype=torch.float32, device=means3D.device)
-            g = self.gathered
-            check(_lib.lib().d3ga_sh_grad_from_views(P, M, deg, self.world, dptr(means3D), dptr(g), 3 * (P + 1),
-                                                     dptr(g[0, P]), 3 * (P + 1), self.scale, dptr(g_sh), stream_handle()),
-                  "d3ga_sh_grad_from_views")
-            out["shs"] = g_sh
+        out = {}
+        for e in self.parked:
+            mine = dict(e["parts"])
+            sh = e["sh"]
+            if sh is not None:
+                P, M, deg, means3D = sh["P"], sh["M"], sh["sh_degree"], sh["means3D"]
+                g_sh = torch.empty((P, M, 3), dtype=torch.float32, device=means3D.device)
+                g = e["gathered"]
+                check(_lib.lib().d3ga_sh_grad_from_views(P, M, deg, self.world, dptr(means3D), dptr(g), 3 * (P + 1),
+                                                         dptr(g[0, P]), 3 * (P + 1), self.scale, dptr(g_sh), stream_handle()),
+                      "d3ga_sh_grad_from_views")
+                mine["shs"] = g_sh
+            for k, v in mine.items():
+                out[k] = v if k not in out else out[k] + v
         return out
 
     def exchange_ms(self):

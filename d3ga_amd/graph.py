@@ -188,7 +188,11 @@ class CapturedCutStep:
 
     upstream() -> dict name -> tensor; the names the rasterizer differentiates are "means3D", "opacities" (also
     "opacity_logits"), "cov3D_precomp" | "scales" + "rotations", "shs" | "colors_precomp" (`rgb`); other entries are
-    passed through.  loss_fn(pkg) -> scalar loss; it must render with `grad_sync=sync`.
+    passed through.  loss_fn(pkg) -> scalar loss; it must render with `grad_sync=sync`; it may render more than once (the
+    reference's RGB + silhouette pass: every render parks its own buffers and is exchanged) and may add loss terms that
+    read package tensors directly (regularisers, energies): their gradients stay on the detached leaves and are added to the
+    reduced rasterizer gradients before graph B continues the backward.  Such extra terms must be view-independent, like
+    everything upstream of the cut (they are NOT reduced: identical on every rank by construction).
     """
 
     _ALIASES = {"opacity_logits": "opacities", "rgb": "colors_precomp"}
@@ -210,12 +214,14 @@ class CapturedCutStep:
             for p in params:
                 p.grad = None
             self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            sync.begin_step()
             with torch.cuda.graph(self.graph_a):
-                up, self.result = self._to_the_cut(upstream, loss_fn)
-            sync.exchange_parked()
+                up, pkg, self.result = self._to_the_cut(upstream, loss_fn)
+            sync.exchange_parked()             # (graph A has not run: this call's collectives move unspecified data, on every rank alike)
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
-                self._from_the_cut(up)
+                self._from_the_cut(up, pkg)
             torch.cuda.synchronize()
+            sync.frozen = True                 # the parked buffers are baked into the two graphs now
             self._watch = _OverflowWatch(check_every)
         finally:
             sync.deferred = was
@@ -223,29 +229,39 @@ class CapturedCutStep:
     def check_overflow(self):
         return self._watch.check_now()
 
-    @classmethod
-    def _to_the_cut(cls, upstream, loss_fn):
+    def _to_the_cut(self, upstream, loss_fn):
         up = upstream()
         pkg = {k: (v.detach().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() and v.requires_grad else v)
                for k, v in up.items()}
         loss = loss_fn(pkg)
         loss.backward()
-        return up, loss
+        return up, pkg, loss
 
-    def _from_the_cut(self, up):
+    def _from_the_cut(self, up, pkg):
+        """Everything that reached the cut goes on: the reduced rasterizer-input gradients of ALL renders of the step
+        (`parked_gradients`) PLUS whatever other loss terms left on the detached leaves (a regulariser on the scales, an
+        energy the package carries: models/cage_net.py:225-226, train.py:203) -- the rasterizer's backward returns nothing
+        to the leaves in deferred mode, so `leaf.grad` holds exactly those other terms."""
         grads = self.sync.parked_gradients()
         outs, gs = [], []
         for k, v in up.items():
+            if not (torch.is_tensor(v) and v.requires_grad):
+                continue
             g = grads.get(self._ALIASES.get(k, k))
-            if g is not None and torch.is_tensor(v) and v.requires_grad:
+            g = None if g is None else g.reshape(v.shape)
+            extra = pkg[k].grad if torch.is_tensor(pkg.get(k)) else None
+            if extra is not None:
+                g = extra if g is None else g + extra
+            if g is not None:
                 outs.append(v)
-                gs.append(g.reshape(v.shape))
+                gs.append(g)
         torch.autograd.backward(outs, gs)
 
     def _eager(self, upstream, loss_fn):
-        up, loss = self._to_the_cut(upstream, loss_fn)
+        self.sync.begin_step()
+        up, pkg, loss = self._to_the_cut(upstream, loss_fn)
         self.sync.exchange_parked()
-        self._from_the_cut(up)
+        self._from_the_cut(up, pkg)
         return loss
 
     def replay(self, camera=None, **values):

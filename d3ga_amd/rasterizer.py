@@ -102,10 +102,16 @@ class StageTimer:
 stage_timer = StageTimer()
 
 
-def _scratch(P, W, H, cap, device):
+def _scratch(P, W, H, cap, device, forward_only=False, binning=True):
+    """(geom, binning, img) byte tensors.  forward_only: the img buffer without the per-block lists of the backward
+    (128 B per duplicate of capacity -- several hundred MB per render at a few million duplicates); binning=False: None
+    for the binning buffer (a geometry-cache hit shares the first pass's)."""
     sizes = (ctypes.c_int64 * 3)()
-    check(_lib.lib().d3ga_raster_scratch_bytes(P, W, H, cap, sizes), "d3ga_raster_scratch_bytes")
-    return [torch.empty(int(s), dtype=torch.uint8, device=device) for s in sizes]
+    L = _lib.lib()
+    check(L.d3ga_raster_scratch_bytes(P, W, H, cap, sizes), "d3ga_raster_scratch_bytes")
+    img_bytes = int(L.d3ga_raster_img_bytes(W, H, cap, 1)) if forward_only else int(sizes[2])
+    new = lambda n: torch.empty(int(n), dtype=torch.uint8, device=device)
+    return [new(sizes[0]), new(sizes[1]) if binning else None, new(img_bytes)]
 
 
 def _f32(t, device):
@@ -193,10 +199,20 @@ class _RasterizeGaussians(torch.autograd.Function):
             colors2, bg2 = _f32(colors2.detach(), dev), _f32(bg2, dev)
         H, W = int(s.image_height), int(s.image_width)
         M = sh.shape[1] if sh is not None else 0
-        prm = RasterParams(P=P, M=M, sh_degree=int(s.sh_degree), W=W, H=H, tanfovx=float(s.tanfovx),
-                           tanfovy=float(s.tanfovy), scale_modifier=float(s.scale_modifier),
+        tfx, tfy = float(s.tanfovx), float(s.tanfovy)
+        if not (tfx > 0.0 and tfy > 0.0):
+            # tanfovx <= 0 is the in-band marker of a camera slot (cameras.CameraSlot): the kernels then read both tangents
+            # from campos[3], campos[4].  Anything else non-positive (or NaN) would make them read past a 3-float campos.
+            if not (tfx == 0.0 and tfy == 0.0 and campos.numel() >= 5):
+                raise ValueError(f"GaussianRasterizationSettings: tanfovx / tanfovy must be positive (got {tfx}, {tfy}); only a "
+                                 "camera slot (tanfovx = tanfovy = 0 with a 5-float campos: cameras.CameraSlot) reads them from the device")
+        # no input requires a gradient (inference, torch.no_grad): the forward skips the per-block lists of the backward
+        fwd_only = not any(ctx.needs_input_grad[:8])
+        prm = RasterParams(P=P, M=M, sh_degree=int(s.sh_degree), W=W, H=H, tanfovx=tfx,
+                           tanfovy=tfy, scale_modifier=float(s.scale_modifier),
                            antialiasing=int(bool(s.antialiasing)), prefiltered=int(bool(s.prefiltered)),
-                           debug=int(bool(s.debug)), opacity_activation=_ACTIVATIONS[opacity_activation])
+                           debug=int(bool(s.debug)), opacity_activation=_ACTIVATIONS[opacity_activation],
+                           forward_only=int(fwd_only))
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         invdepth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
@@ -210,7 +226,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         hit = _geom_cache.get(dev.index) if use_cache else None
         if hit is not None and hit["key"] == key:
             cap, binning, radii = hit["cap"], hit["binning"], hit["radii"]
-            geom, _unused, img = _scratch(P, W, H, cap, dev)     # img carries the per-block lists: sized by cap
+            geom, _unused, img = _scratch(P, W, H, cap, dev, fwd_only, binning=False)     # img carries the per-block lists: sized by cap
             st, pp = stream_handle(), ctypes.byref(prm)
             stage_timer.stage("recolor", lambda: check(L.d3ga_raster_recolor(
                 pp, dptr(means3D), dptr(sh), dptr(colors_precomp), dptr(campos), dptr(hit["geom"]), dptr(geom), st),
@@ -220,7 +236,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 "d3ga_raster_composite_fwd"))
             _last[dev.index] = (binning, cap)
         while hit is None or hit["key"] != key:
-            geom, binning, img = _scratch(P, W, H, cap, dev)
+            geom, binning, img = _scratch(P, W, H, cap, dev, fwd_only)
             if stage_timer.enabled or dual:
                 st, pp = stream_handle(), ctypes.byref(prm)
                 stage_timer.stage("preprocess", lambda: check(L.d3ga_raster_preprocess(
@@ -353,8 +369,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                     parts_by_name["colors_precomp"] = g_col
                 sync.park(flat, factor, parts_by_name,
                           None if factor is None else {"P": P, "M": prm.M, "sh_degree": prm.sh_degree, "means3D": means3D})
-                return (g_means3D, g_means2D if ctx.has_means2D else None, None, g_col if sh is None else None, g_opac,
-                        g_scales, g_rots, g_cov, None, None, None, None, None)
+                # the parked gradients come back REDUCED through graph.CapturedCutStep: returning them here as well would
+                # leave the unreduced copy on the (detached) leaves, where the step adds the other loss terms' gradients
+                return (None, g_means2D if ctx.has_means2D else None, None, None, None, None, None, None, None, None, None,
+                        None, None)
             gathered = sync.exchange(flat, factor)         # flat: summed (averaged) in place; gathered: (world, P+1, 3)
             if factor is not None:
                 g_sh = new(P, prm.M, 3)

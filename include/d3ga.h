@@ -112,6 +112,11 @@ typedef struct d3ga_raster_params {
      * (upstream's contract); D3GA_OPACITY_SIGMOID = `opacities` holds LOGITS, the sigmoid is applied on load in
      * d3ga_raster_preprocess and dL_dopacity of d3ga_raster_preprocess_bwd is the gradient w.r.t. the logit. */
     int32_t opacity_activation;
+    /* != 0: no backward will follow this forward (inference / no input requires a gradient): d3ga_raster_composite_fwd does
+     * not write the per-4x4-block lists its backward walks, and the img buffer only needs d3ga_raster_img_bytes(..., 1) bytes
+     * (2 x 4 B per pixel instead of + 128 B per duplicate of capacity).  Calling a backward entry point afterwards is an error
+     * (D3GA_E_CONFIG). */
+    int32_t forward_only;
 } d3ga_raster_params;
 #define D3GA_OPACITY_SIGMOID 1
 
@@ -119,6 +124,8 @@ typedef struct d3ga_raster_params {
  * binningBuffer / imgBuffer).  d_capacity = capacity in (tile,Gaussian) duplicates of the binning lists.
  * sizes[0]=geom, sizes[1]=binning, sizes[2]=img.  Buffers must be 256-byte aligned. */
 int d3ga_raster_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t d_capacity, int64_t sizes[3]);
+/* Bytes of the img buffer alone; forward_only != 0: without the per-block lists (d3ga_raster_params.forward_only). */
+int64_t d3ga_raster_img_bytes(int32_t W, int32_t H, int64_t d_capacity, int32_t forward_only);
 
 /* Byte offsets of the sections of the binning buffer, for inspection/tests:
  * offsets[0] counters (8 x u32), [1] tile_count (tiles x u32), [2] tile_start (tiles+1 x u32, exclusive prefix),

@@ -66,14 +66,33 @@ def _worker(rank, world, port, out):
     flat_buf = torch.full((4 * 4,), float(rank + 1))
     parts = {"means3D": flat_buf[:12].view(4, 3), "opacities": flat_buf[12:].view(4, 1)}
     factor = torch.full((5, 3), float(10 * (rank + 1)))
+    sync.begin_step()
     sync.park(flat_buf, factor, parts, sh=None)
+    # a second render of the same step (the reference's silhouette pass) parks its own buffers; the step's gradient of an
+    # input is the SUM over its renders
+    flat2 = torch.full((4 * 4,), float(10 * (rank + 1)))
+    sync.park(flat2, None, {"means3D": flat2[:12].view(4, 3), "opacities": flat2[12:].view(4, 1)}, sh=None)
     sync.exchange_parked()
-    first = sync.gathered.data_ptr()
-    ok = ok and torch.allclose(sync.parked_gradients()["means3D"], torch.full((4, 3), 1.5))          # mean of 1 and 2
-    ok = ok and torch.allclose(sync.gathered[:, 0, 0], torch.tensor([10.0, 20.0]))
+    first = sync.parked[0]["gathered"].data_ptr()
+    ok = ok and torch.allclose(sync.parked_gradients()["means3D"], torch.full((4, 3), 1.5 + 15.0))   # mean of 1, 2 + mean of 10, 20
+    ok = ok and torch.allclose(sync.parked[0]["gathered"][:, 0, 0], torch.tensor([10.0, 20.0])) and sync.parked[1]["gathered"] is None
     flat_buf.fill_(float(rank + 3))
+    flat2.zero_()
     sync.exchange_parked()
-    ok = ok and sync.gathered.data_ptr() == first and torch.allclose(parts["opacities"], torch.full((4, 1), 3.5))
+    ok = ok and sync.parked[0]["gathered"].data_ptr() == first and torch.allclose(parts["opacities"], torch.full((4, 1), 3.5))
+    # once a graph has captured the buffers their shapes are frozen: a changed gather shape is an error, not a silent reallocation
+    sync.frozen = True
+    sync.parked[0]["factor"] = torch.zeros(7, 3)
+    try:
+        sync.exchange_parked()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "re-capture" in str(e)
+    try:
+        sync.begin_step()
+        ok = False
+    except RuntimeError:
+        pass
     out[rank] = bool(ok)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -365,6 +365,41 @@ def test_edge_cases_empty_culled_and_errors():
              cov3D_precomp=inp["cov6"])                      # CPU tensors: no fallback
 
 
+def test_inference_render_skips_the_backward_lists_and_bad_fov_is_refused():
+    """(a) a render none of whose inputs requires a gradient must not allocate / write the per-block lists of the
+    backward (128 B per duplicate of capacity): same image bit for bit, img scratch = 8 B per pixel; the C ABI refuses a
+    backward after a forward_only forward.  (b) a non-positive / NaN tan(FoV) with an ordinary 3-float campos is an error,
+    not an out-of-bounds read of the camera slot."""
+    import ctypes
+    from d3ga_amd import _lib, rasterizer as R
+    inp = scene_inputs("T1", scale_mult=3.0)
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    args = dict(means3D=inp["means3D"].to(DEV), means2D=None, opacities=inp["opacities"].to(DEV), shs=inp["shs"].to(DEV),
+                cov3D_precomp=inp["cov6"].to(DEV))
+    rast = R.GaussianRasterizer(_settings(inp, bg, 3))
+    with torch.no_grad():
+        img_inf, radii_inf, _ = rast(**args)
+    args_g = dict(args, means3D=args["means3D"].clone().requires_grad_(True))
+    img_g, radii_g, _ = rast(**args_g)
+    assert torch.equal(img_inf, img_g.detach()) and torch.equal(radii_inf, radii_g)
+    img_g.sum().backward()
+    assert float(args_g["means3D"].grad.abs().max()) > 0
+    L = _lib.lib()
+    W, H, cap = inp["W"], inp["H"], 100_000
+    small, full = int(L.d3ga_raster_img_bytes(W, H, cap, 1)), int(L.d3ga_raster_img_bytes(W, H, cap, 0))
+    assert small <= 8 * W * H + 512 and full >= small + 128 * cap
+    prm = _lib.RasterParams(P=10, M=0, sh_degree=0, W=W, H=H, tanfovx=1.0, tanfovy=1.0, scale_modifier=1.0, antialiasing=0,
+                            prefiltered=0, debug=0, opacity_activation=0, forward_only=1)
+    buf = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
+    p = ctypes.c_void_p(buf.data_ptr())
+    assert L.d3ga_raster_composite_bwd(ctypes.byref(prm), p, p, p, 1000, p, p, p, None) == -3      # D3GA_E_CONFIG
+    # (b)
+    for bad in (0.0, -1.0, float("nan")):
+        st = _settings(inp, bg, 3)._replace(tanfovx=bad)
+        with pytest.raises(ValueError, match="tanfovx"):
+            R.GaussianRasterizer(st)(**args)
+
+
 def test_compute_bary_matches_oracle():
     from d3ga_amd.tetra import compute_bary
     inp = scene_inputs("T1")

@@ -286,6 +286,71 @@ def test_whole_step_with_the_exchange_captured_over_rccl_one_rank_group():
     assert out.returncode == 0 and "RCCL-GRAPH-OK" in out.stdout, (out.stdout[-500:], out.stderr[-2500:])
 
 
+def test_cut_step_keeps_every_gradient_two_renders_and_a_regulariser():
+    """the two-graph camera-sharded step must not drop gradients.  The reference's step renders TWICE
+    (RGB + silhouette, models/trainer.py:102-110) and adds loss terms that read package tensors directly (the scale
+    regulariser and the FEM energy the package carries, models/cage_net.py:225-226, train.py:203).  CapturedCutStep over a
+    one-rank RCCL group (identity collectives) must reproduce the plain eager step: both renders' rasterizer gradients
+    (each parked and exchanged), the regulariser's gradient on a rasterizer input, and the gradient of a package entry the
+    rasterizer never sees."""
+    import subprocess
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        f"os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='{_free_port()}', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "import bench\n"
+        "from d3ga_amd import rasterizer as R\n"
+        "from d3ga_amd.dist import ViewShardedGrads\n"
+        "from d3ga_amd.graph import CapturedCutStep\n"
+        "from d3ga_amd.losses import l1_loss\n"
+        "from d3ga_amd.renderer import render\n"
+        "dev = torch.device('cuda', 0)\n"
+        "f = bench.Frame('T1', dev, 0)\n"
+        "P = f.barys0.shape[0]\n"
+        "sil_rgb, bg0 = torch.ones(P, 3, device=dev), torch.zeros(3, device=dev)\n"
+        "sil_target = torch.rand(3, f.wl.height, f.wl.width, generator=torch.Generator().manual_seed(3)).to(dev)\n"
+        "def upstream():\n"
+        "    up = f.upstream()\n"
+        "    up['fm_energy'] = (f.params['delta_node'] ** 2).sum(dim=1)          # an entry the rasterizer never sees\n"
+        "    return up\n"
+        "def make_loss(sync):\n"
+        "    def loss_fn(pkg):\n"
+        "        img = render(f.batch, pkg, f.bg, grad_sync=sync)['render']\n"
+        "        sil = render(f.batch, pkg, bg0, colors_precomp=sil_rgb, grad_sync=sync)['render']\n"
+        "        return (l1_loss(img, f.target) + l1_loss(sil, sil_target) + 50.0 * (pkg['cov3D_precomp'] ** 2).mean()\n"
+        "                + 2.0 * pkg['fm_energy'].mean())\n"
+        "    return loss_fn\n"
+        "params = list(f.params.values())\n"
+        "for p in params: p.grad = None\n"
+        "loss = make_loss(None)(upstream()); loss.backward()\n"
+        "torch.cuda.synchronize()\n"
+        "ref = [None if p.grad is None else p.grad.clone() for p in params]\n"
+        "l_ref = float(loss.detach()); del loss\n"
+        "R.set_capacity_policy('static', int(R.last_counters()['D'] * 1.5) + 1024)\n"
+        "sync = ViewShardedGrads(); sync.always = True\n"
+        "for p in params: p.grad = None\n"
+        "cut = CapturedCutStep(upstream, make_loss(sync), sync, params=params)\n"
+        "assert len(sync.parked) == 2 and sync.frozen, 'both renders must park their gradients'\n"
+        "for _ in range(3):\n"
+        "    for p in params:\n"
+        "        if p.grad is not None: p.grad.zero_()\n"
+        "    l_cut = cut.replay()\n"
+        "torch.cuda.synchronize()\n"
+        "assert abs(float(l_cut) - l_ref) < 1e-5 * abs(l_ref)\n"
+        "errs = {}\n"
+        "for (k, p), r in zip(f.params.items(), ref):\n"
+        "    assert (p.grad is None) == (r is None), k\n"
+        "    if r is not None: errs[k] = float((p.grad - r).abs().max() / (r.abs().max() + 1e-30))\n"
+        "assert len(errs) >= 5 and max(errs.values()) < 2e-4, errs\n"
+        "assert cut.check_overflow()['D'] > 0\n"
+        "dist.destroy_process_group()\n"
+        "print('CUT-COMPLETE-OK', errs)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "CUT-COMPLETE-OK" in out.stdout, (out.stdout[-800:], out.stderr[-2500:])
+
+
 def _worker_color(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
