@@ -123,62 +123,74 @@ __device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__rest
 // wavefront from each work quantile instead of a random handful.
 __device__ __forceinline__ void tile_order_body(int tiles, const uint32_t *__restrict__ count,
                                                 uint32_t *__restrict__ order) {
+    // Round 3: ONE pass over the counts.  The bucket of a tile is its list length in units of 16 entries (the group size of
+    // the compositing backward), clipped at 254 -- a fixed map, so the maximum need not be known first (round 2 took the
+    // maximum, then built the histogram, then scattered: three dependent rounds of global loads on one workgroup, 10 us);
+    // every thread keeps its (up to) 8 counts in registers between the histogram and the scatter.  Lists of 4064+ entries
+    // share the first bucket: they are the heaviest tiles either way.
     __shared__ uint32_t s_hist[256];                      // buckets 0..254: non-empty tiles, longest lists first
     __shared__ uint32_t s_zero;                           // empty tiles (most of the image for an avatar): wavefront-
-    __shared__ uint32_t s_omax;                           // aggregated, thousands of same-address LDS atomics serialise
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;         // aggregated, thousands of same-address LDS atomics serialise
+    constexpr int kPer = 8;
     if (tid < 256) s_hist[tid] = 0;
-    if (tid == 0) { s_zero = 0; s_omax = 0; }
+    if (tid == 0) s_zero = 0;
     __syncthreads();
-    const int rounds = (tiles + kScanBlock - 1) / kScanBlock;
-    // the longest list: this workgroup runs BESIDE the scan workgroup (same launch), so it takes its own maximum
-    uint32_t mx = 0;
-    for (int r = 0; r < rounds; ++r) {
-        const int t = r * kScanBlock + tid;
-        mx = max(mx, t < tiles ? count[t] : 0u);
-    }
+    auto bucket = [](uint32_t c) { return 254u - min(c >> 4, 254u); };
+    for (int c0 = 0; c0 < tiles; c0 += kPer * kScanBlock) {               // (one trip up to 8192 tiles)
+        uint32_t c[kPer];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
-    if (lane == 0) atomicMax(&s_omax, mx);
-    __syncthreads();
-    mx = s_omax;
-    const int shift = mx >= 255u ? (32 - __clz((int)mx) - 8 + 1) : 0;      // (count >> shift) < 255
-    for (int r = 0; r < rounds; ++r) {
-        const int t = r * kScanBlock + tid;
-        const uint32_t c = t < tiles ? count[t] : 0u;
-        const bool zero = t < tiles && c == 0u;
-        const unsigned long long zm = __ballot(zero);
-        if (lane == 0 && zm) atomicAdd(&s_zero, (uint32_t)__popcll(zm));
-        if (t < tiles && c) atomicAdd(&s_hist[254u - min(c >> shift, 254u)], 1u);
-    }
-    __syncthreads();
-    if (tid < 64) {                                       // exclusive prefix of the buckets: 4 per lane + wave scan
-        uint32_t v[4], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] = (4 * tid + k < 255) ? s_hist[4 * tid + k] : 0u; sum += v[k]; }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t u = __shfl_up(incl, off);
-            if (tid >= off) incl += u;
+        for (int k = 0; k < kPer; ++k) {
+            const int t = c0 + k * kScanBlock + tid;
+            c[k] = t < tiles ? count[t] : 0xffffffffu;                    // 0xffffffff: no tile
         }
-        uint32_t run = incl - sum;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { s_hist[4 * tid + k] = run; run += v[k]; }   // [255] = number of non-empty tiles
-    }
-    __syncthreads();
-    if (tid == 0) s_zero = s_hist[255];                   // empty tiles follow the non-empty ones
-    __syncthreads();
-    for (int r = 0; r < rounds; ++r) {
-        const int t = r * kScanBlock + tid;
-        const uint32_t c = t < tiles ? count[t] : 0u;
-        const bool zero = t < tiles && c == 0u;
-        const unsigned long long zm = __ballot(zero);
-        uint32_t zbase = 0;
-        if (lane == 0 && zm) zbase = atomicAdd(&s_zero, (uint32_t)__popcll(zm));
-        zbase = (uint32_t)__shfl((int)zbase, 0);
-        if (zero) order[zbase + (uint32_t)__popcll(zm & ((1ull << lane) - 1ull))] = (uint32_t)t;
-        if (t < tiles && c) order[atomicAdd(&s_hist[254u - min(c >> shift, 254u)], 1u)] = (uint32_t)t;
+        for (int k = 0; k < kPer; ++k) {
+            const bool zero = c[k] == 0u;
+            const unsigned long long zm = __ballot(zero);
+            if (lane == 0 && zm) atomicAdd(&s_zero, (uint32_t)__popcll(zm));
+            if (c[k] != 0u && c[k] != 0xffffffffu) atomicAdd(&s_hist[bucket(c[k])], 1u);
+        }
+        if (c0 + kPer * kScanBlock < tiles) continue;                     // more than 8192 tiles: finish the histogram first
+        // ---- the common case: everything in registers; exclusive prefix of the buckets, then the scatter ----
+        __syncthreads();
+        if (tid < 64) {
+            uint32_t v[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = (4 * tid + k < 255) ? s_hist[4 * tid + k] : 0u; sum += v[k]; }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t u = __shfl_up(incl, off);
+                if (tid >= off) incl += u;
+            }
+            uint32_t run = incl - sum;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s_hist[4 * tid + k] = run; run += v[k]; }   // [255] = number of non-empty tiles
+        }
+        __syncthreads();
+        if (tid == 0) s_zero = s_hist[255];               // empty tiles follow the non-empty ones
+        __syncthreads();
+        for (int c1 = 0; c1 < tiles; c1 += kPer * kScanBlock) {
+            if (c0 != 0) {                                // more than one chunk (> 8192 tiles): the registers hold one chunk only
+#pragma unroll
+                for (int k = 0; k < kPer; ++k) {
+                    const int t = c1 + k * kScanBlock + tid;
+                    c[k] = t < tiles ? count[t] : 0xffffffffu;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                const int t = c1 + k * kScanBlock + tid;
+                const bool zero = c[k] == 0u;
+                const unsigned long long zm = __ballot(zero);
+                uint32_t zbase = 0;
+                if (lane == 0 && zm) zbase = atomicAdd(&s_zero, (uint32_t)__popcll(zm));
+                zbase = (uint32_t)__shfl((int)zbase, 0);
+                if (zero) order[zbase + (uint32_t)__popcll(zm & ((1ull << lane) - 1ull))] = (uint32_t)t;
+                if (c[k] != 0u && c[k] != 0xffffffffu) order[atomicAdd(&s_hist[bucket(c[k])], 1u)] = (uint32_t)t;
+            }
+        }
+        // (c0 was the last chunk: the loop ends)
     }
 }
 
@@ -548,7 +560,9 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
     hipLaunchKernelGGL((tile_sort_lds_kernel<256, kSortSmall>), dim3(tiles), dim3(256), 0, s, bin.tile_start, bin.keys,
                        bin.point_list, (uint64_t)d_capacity);
     D3GA_TRY(check_launch(s, prm->debug));
-    // long lists: persistent grids driven by the device-side work lists (empty for avatar-sized scenes)
+    // longer lists: persistent grids driven by the device-side work lists (empty for avatar-sized scenes), 256 workgroups each.
+    // (Round 3 also tried sorting the 2049..4096 class inside the per-tile kernel, in segments: one launch less, but a single
+    // 256-thread workgroup then takes 2.5x as long as any other -- 13 -> 21 us for that kernel at C3, no net gain; reverted.)
     {   // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (function attributes are per device)
         static bool attr_set[64] = {};
         int dev = 0;
@@ -559,13 +573,13 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
             attr_set[dev] = true;
         }
     }
-    const int lgrid = tiles < 1024 ? tiles : 1024;
+    const int lgrid = tiles < 256 ? tiles : 256;
     hipLaunchKernelGGL((tile_sort_lds_list_kernel<512, kSortMid>), dim3(lgrid), dim3(512), sort_lds_bytes(kSortMid, 512), s,
                        bin.tile_start, bin.keys, bin.point_list, (uint64_t)d_capacity, bin.mid_tiles,
                        bin.counters + D3GA_CNT_MID, (uint64_t *)nullptr, (const uint32_t *)nullptr,
                        (const uint32_t *)nullptr);
     D3GA_TRY(check_launch(s, prm->debug));
-    hipLaunchKernelGGL((tile_sort_lds_list_kernel<1024, kSortLarge>), dim3(lgrid < 512 ? lgrid : 512), dim3(1024),
+    hipLaunchKernelGGL((tile_sort_lds_list_kernel<1024, kSortLarge>), dim3(lgrid), dim3(1024),
                        sort_lds_bytes(kSortLarge, 1024, true), s, bin.tile_start, bin.keys, bin.point_list,
                        (uint64_t)d_capacity, bin.big_tiles, bin.counters + D3GA_CNT_BIG, bin.keys,
                        (const uint32_t *)bin.huge_tiles, (const uint32_t *)(bin.counters + D3GA_CNT_HUGE));
