@@ -62,6 +62,9 @@ def parse():
                     help="sensitivity: multiply the Gaussians' world-space scales (D/P grows ~quadratically)")
     ap.add_argument("--fill", type=float, default=0.85,
                     help="sensitivity: fraction of the image height the 1.8 m body fills (0.85 = SURVEY sec. 8d recipe)")
+    ap.add_argument("--no-fused-l1", action="store_true",
+                    help="render() and l1_loss() as two operators instead of d3ga_amd.renderer.render_l1 (same loss and gradients; "
+                         "the gradient image then makes a round trip through HBM)")
     ap.add_argument("--init-timing", action="store_true",
                     help="also time the init-time helpers at the workload's size: compute_bary (point -> tet + barycentrics, "
                          "lib/cage.py:325-327) and the 3-NN scale seed (models/cage_net.py:66), uniform grid vs exhaustive")
@@ -138,12 +141,17 @@ class Frame:
         return {"means3D": means, "cov3D_precomp": cov6, "opacity_logits": p["opacity"],
                 "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
 
+    fused_l1 = True                 # --no-fused-l1: render() + l1_loss() as two operators (a (3,H,W) gradient image in between)
+
     def loss_from(self, pkg):
         from d3ga_amd.losses import l1_loss
-        from d3ga_amd.renderer import render
+        from d3ga_amd.renderer import render, render_l1
+        # mean |img - target| (utils/loss_utils.py:29); with camera_cycle() the target is whatever the slot names
+        target = getattr(self, "target_slot", None) or self.target
+        if self.fused_l1:           # the same loss and gradients from ONE operator: dL/dimage is formed inside the compositing backward
+            return render_l1(self.batch, pkg, self.bg, target, grad_sync=self.grad_sync)["l1"]
         img = render(self.batch, pkg, self.bg, grad_sync=self.grad_sync)["render"]
-        # fused mean |img - target| (utils/loss_utils.py:29); with camera_cycle() the target is whatever the slot names
-        return l1_loss(img, getattr(self, "target_slot", None) or self.target)
+        return l1_loss(img, target)
 
     def step(self):
         loss = self.loss_from(self.upstream())
@@ -556,6 +564,7 @@ def main():
     if args.pmc and world == 1:
         collect_pmc(args)
     frame = Frame(args.workload, dev, view_index=rank % 8, scale_mult=args.scale_mult, fill=args.fill)
+    frame.fused_l1 = not args.no_fused_l1
     flat = ddist.GradReducer(list(frame.params.values()))
     cut = world > 1 and args.reduce == "cut"
     if args.force_cut and world == 1:

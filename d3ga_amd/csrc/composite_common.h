@@ -11,10 +11,8 @@ namespace d3ga {
 // D3GA_COMPOSITE_VARIANT (A/B knob, read once; the other bits selected kernels that no longer exist):
 //   bit 5 (32)  work-ordered dispatch: quadrants are handed out heaviest tile first (tile_order of the bin stage);
 //   bit 7 (128) exact ellipse / block-rectangle test behind the bounding-box test of the forward's culling.
-//   bit 8 (256) backward: workgroup per tile with a tile-level merge of the gradient records (composite_bwd_tile_kernel).
-//   bit 9 (512) forward: two stages -- a quadrant-level bounding-box pass feeding batches of survivors (composite_fwd_q_kernel).
-constexpr int kVariantOrdered = 32, kVariantExactCull = 128, kVariantTileMerge = 256, kVariantTwoStage = 512;
-constexpr int kDefaultCompositeVariant = kVariantOrdered | kVariantExactCull | kVariantTileMerge | kVariantTwoStage;
+constexpr int kVariantOrdered = 32, kVariantExactCull = 128;
+constexpr int kDefaultCompositeVariant = kVariantOrdered | kVariantExactCull;
 static inline int composite_variant() {
     static const int v = [] {
         const char *e = getenv("D3GA_COMPOSITE_VARIANT");
@@ -36,9 +34,13 @@ static inline int composite_tile_assign() {        // A/B knob: block -> wavefro
     }();
     return v;
 }
+// L1 image loss fused into the compositing backward: image (3,H,W) = the forward's colour output, target (or the device
+// cell that holds its address: graph.TensorSlot), g_loss = dL/dloss (device scalar), inv_n = 1 / (3 H W); image == null: off
+struct L1Source { const float *image, *target; const float *const *target_cell; const float *g_loss; float inv_n; };
 int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, const BinBuf &bin, const GeomBuf &g,
                               const ImgBuf &im, int64_t d_capacity, const float *bg, const float *dL_dpix, float *acc,
-                              bool ordered, const float *colors2, const float *bg2, const float *dL_dpix2, hipStream_t s);
+                              bool ordered, const float *colors2, const float *bg2, const float *dL_dpix2, const L1Source &l1,
+                              hipStream_t s);
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll

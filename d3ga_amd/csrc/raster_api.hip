@@ -81,3 +81,20 @@ extern "C" int d3ga_raster_backward(const d3ga_raster_params *prm, const float *
                                       campos, geom, acc, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors,
                                       dL_dcov3D, dL_dscales, dL_drots, stream);
 }
+
+extern "C" int d3ga_raster_backward_l1(const d3ga_raster_params *prm, const float *means3D, const float *shs,
+                                       const float *scales, const float *rotations, const float *cov3D_precomp,
+                                       const float *viewmatrix, const float *projmatrix, const float *campos,
+                                       const float *bg, const void *geom, const void *binning, int64_t d_capacity,
+                                       const void *img, const float *image, const float *target, const void *target_cell,
+                                       const float *g_loss, const float *dL_dpix, float *acc, float *dL_dmeans3D,
+                                       float *dL_dmeans2D, float *dL_dopacity, float *dL_dsh, float *dL_dcolors,
+                                       float *dL_dcov3D, float *dL_dscales, float *dL_drots, d3ga_stream_t stream) {
+    if (prm && prm->P > 0 && acc)
+        D3GA_HIP(zero_async(acc, sizeof(float) * D3GA_ACC_STRIDE * (size_t)prm->P, (hipStream_t)stream));
+    D3GA_TRY(d3ga_raster_composite_bwd_l1(prm, bg, geom, binning, d_capacity, img, image, target, target_cell, g_loss, dL_dpix,
+                                          acc, stream));
+    return d3ga_raster_preprocess_bwd(prm, means3D, shs, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                                      campos, geom, acc, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dsh, dL_dcolors,
+                                      dL_dcov3D, dL_dscales, dL_drots, stream);
+}

@@ -37,174 +37,6 @@ namespace d3ga {
 // out_color2 over bg2 -- the reference's training step renders every package twice with identical geometry and opacities
 // (RGB, then the silhouette colours on black: models/trainer.py:102-110); alpha, T, the culled lists and the early exit
 // are shared, the second image costs three more FMAs per (pixel, entry).
-template <bool DUAL>
-__global__ __launch_bounds__(64) void composite_fwd_rows_kernel(
-    int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
-    uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
-    const float4 *__restrict__ rgb_invd, const float *__restrict__ bg, float *__restrict__ final_T,
-    uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_invdepth,
-    const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2, const float *__restrict__ bg2,
-    float *__restrict__ out_color2, uint2 *__restrict__ blk_list, uint32_t *__restrict__ blk_count, bool exact_cull) {
-    const Quad q = tile_order ? quad_of_block_ordered(gx, gx * gy, tile_order) : quad_of_block(gx, gy);
-    if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
-    const int lane = threadIdx.x & 63;
-    const RowGeom rg = row_geom(q, lane);
-    const bool inside = rg.px < W && rg.py < H;
-    const float fx = (float)rg.px, fy = (float)rg.py;
-    const float bx0 = (float)q.qx0, by0 = (float)q.qy0;
-    const uint32_t begin = (uint32_t)min((uint64_t)tile_start[q.tile], dcap);
-    const uint32_t end = (uint32_t)min((uint64_t)tile_start[q.tile + 1], dcap);
-    // culled per-block lists for the backward (ImgBuf): block 4*quad + r of this tile, capacity end - begin each
-    const uint32_t blk_cap = end - begin;
-    uint2 *const blk_base = blk_list ? blk_list + 16 * (size_t)begin + (size_t)(4 * q.quad) * blk_cap : nullptr;
-    uint32_t bc0 = 0, bc1 = 0, bc2 = 0, bc3 = 0;           // entries emitted per row so far (wave-uniform)
-
-    // wave-private slabs of the staged batch, 16 B per entry each (slot 64: the null record the lists are padded with):
-    // conic with the constants folded in | opacity;  colour | 1/depth;  centre | 1-based list position
-    __shared__ float4 s_co[65];
-    __shared__ float4 s_rgb[65];
-    __shared__ float4 s_xyp[65];
-    __shared__ float4 s_rgb2[DUAL ? 65 : 1];
-    __shared__ uint16_t s_list[4][kListStride];
-    if (threadIdx.x == 0) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_co[64] = z; s_rgb[64] = z; s_xyp[64] = z;
-        if constexpr (DUAL) s_rgb2[64] = z;
-    }
-    if (threadIdx.x < 8) s_list[threadIdx.x >> 1][64 + (threadIdx.x & 1)] = kNullRec;
-
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    float E0 = 0.f, E1 = 0.f, E2 = 0.f;                    // DUAL: the second image
-    uint32_t last = 0;
-    bool done = !inside;
-
-    float2 nxy = make_float2(0.f, 0.f);
-    float4 nco = make_float4(0.f, 0.f, 0.f, 0.f), nrgb = make_float4(0.f, 0.f, 0.f, 0.f), nrgb2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t ng = 0;
-    if (begin + lane < end) {
-        const uint32_t g = point_list[begin + lane];
-        ng = g;
-        nxy = xy[g]; nco = conic_o[g]; nrgb = rgb_invd[g];
-        if constexpr (DUAL) nrgb2 = make_float4(colors2[3 * (size_t)g], colors2[3 * (size_t)g + 1], colors2[3 * (size_t)g + 2], 0.f);
-    }
-    for (uint32_t base = begin; base < end; base += 64) {
-        const float2 cxy = nxy;
-        const float4 cco = nco, crgb = nrgb, crgb2 = nrgb2;
-        const uint32_t cg = ng;
-        const bool have = base + lane < end;
-        const uint32_t nb = base + 64;
-        if (nb + lane < end) {
-            const uint32_t g = point_list[nb + lane];
-            ng = g;
-            nxy = xy[g]; nco = conic_o[g]; nrgb = rgb_invd[g];
-            if constexpr (DUAL) nrgb2 = make_float4(colors2[3 * (size_t)g], colors2[3 * (size_t)g + 1], colors2[3 * (size_t)g + 2], 0.f);
-        }
-        const SplatCull sc = splat_cull(cco.x, cco.y, cco.z, cco.w);
-        const float hx = have ? sc.hx : -1.0f, hy = sc.hy;
-        __builtin_amdgcn_wave_barrier();                  // previous batch's LDS reads are done (program order)
-        {   // the blend reads the conic with its constants folded in (splat_eval_q)
-            const ConicQ cq = conic_q(cco.x, cco.y, cco.z);
-            s_co[lane] = make_float4(cq.a, cq.b, cq.c, cco.w);
-            s_rgb[lane] = crgb;
-            s_xyp[lane] = make_float4(cxy.x, cxy.y, __uint_as_float(base - begin + (uint32_t)lane + 1u), 0.f);
-            if constexpr (DUAL) s_rgb2[lane] = crgb2;
-        }
-        BlockHits bh = block_hits4(cxy.x, cxy.y, hx, hy, bx0, by0);
-        if (exact_cull) bh = block_hits4_exact(cxy.x, cxy.y, cco.x, cco.y, cco.z, sc, bx0, by0, bh);
-        unsigned long long m[4];
-        const int trip = build_row_lists(s_list, bh.r0, bh.r1, bh.r2, bh.r3, lane, m);
-        if (blk_base) {
-            // rows whose 16 pixels are all saturated (or outside the image) will not use this batch in the backward
-            const unsigned long long dm = __builtin_amdgcn_ballot_w64(done);
-            const uint2 rec = make_uint2(base - begin + (uint32_t)lane + 1u, cg);          // 1-based list position, id
-            if ((dm & 0xffffull) != 0xffffull) {
-                if (bh.r0) blk_base[bc0 + (uint32_t)lanes_below(m[0])] = rec;
-                bc0 += (uint32_t)__popcll(m[0]);
-            }
-            if (((dm >> 16) & 0xffffull) != 0xffffull) {
-                if (bh.r1) blk_base[blk_cap + bc1 + (uint32_t)lanes_below(m[1])] = rec;
-                bc1 += (uint32_t)__popcll(m[1]);
-            }
-            if (((dm >> 32) & 0xffffull) != 0xffffull) {
-                if (bh.r2) blk_base[2 * (size_t)blk_cap + bc2 + (uint32_t)lanes_below(m[2])] = rec;
-                bc2 += (uint32_t)__popcll(m[2]);
-            }
-            if ((dm >> 48) != 0xffffull) {
-                if (bh.r3) blk_base[3 * (size_t)blk_cap + bc3 + (uint32_t)lanes_below(m[3])] = rec;
-                bc3 += (uint32_t)__popcll(m[3]);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const uint16_t *const my_list = s_list[rg.row];
-        for (int i = 0; i < trip; i += 2) {
-            // two list positions per iteration, straight-line; a row whose list is exhausted reads the null record.
-            // (i + 1 <= 63: trip <= 64)  One ds_read_u16 yields the address of everything the entry needs.
-            const uint32_t o0 = my_list[i], o1 = my_list[i + 1];
-            const float4 e0xy = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_xyp) + o0);
-            const float4 e1xy = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_xyp) + o1);
-            const float4 e0co = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_co) + o0);
-            const float4 e1co = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_co) + o1);
-            const float4 e0rgb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rgb) + o0);
-            const float4 e1rgb = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rgb) + o1);
-            float al0, G0, al1, G1;
-            bool ok0, ok1;
-            splat_eval_q(e0xy.x - fx, e0xy.y - fy, ConicQ{e0co.x, e0co.y, e0co.z}, e0co.w, al0, G0, ok0);
-            splat_eval_q(e1xy.x - fx, e1xy.y - fy, ConicQ{e1co.x, e1co.y, e1co.z}, e1co.w, al1, G1, ok1);
-            {
-                const bool act = ok0 && !done;
-                const float test_T = T * (1.0f - al0);
-                const bool keep = !(test_T < kTmin);       // the entry that would saturate the pixel is not blended
-                const bool bl = act && keep;
-                const float w = bl ? al0 * T : 0.f;
-                C0 += e0rgb.x * w; C1 += e0rgb.y * w; C2 += e0rgb.z * w; Dp += e0rgb.w * w;
-                if constexpr (DUAL) {
-                    const float4 u = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rgb2) + o0);
-                    E0 += u.x * w; E1 += u.y * w; E2 += u.z * w;
-                }
-                T = bl ? test_T : T;
-                last = bl ? __float_as_uint(e0xy.z) : last;                  // 1-based position in the FULL tile list
-                done = done || (act != bl);                                  // act && !keep as a mask XOR: no second compare
-            }
-            {
-                const bool act = ok1 && !done;
-                const float test_T = T * (1.0f - al1);
-                const bool keep = !(test_T < kTmin);
-                const bool bl = act && keep;
-                const float w = bl ? al1 * T : 0.f;
-                C0 += e1rgb.x * w; C1 += e1rgb.y * w; C2 += e1rgb.z * w; Dp += e1rgb.w * w;
-                if constexpr (DUAL) {
-                    const float4 u = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rgb2) + o1);
-                    E0 += u.x * w; E1 += u.y * w; E2 += u.z * w;
-                }
-                T = bl ? test_T : T;
-                last = bl ? __float_as_uint(e1xy.z) : last;
-                done = done || (act != bl);
-            }
-            if (__builtin_amdgcn_ballot_w64(done) == ~0ull) { i = trip; base = end; }      // whole quadrant saturated
-        }
-    }
-    if (inside) {
-        const size_t pid = (size_t)rg.py * W + rg.px;
-        const size_t hw = (size_t)H * W;
-        final_T[pid] = T;
-        n_contrib[pid] = last;
-        out_color[pid] = C0 + T * bg[0];
-        out_color[hw + pid] = C1 + T * bg[1];
-        out_color[2 * hw + pid] = C2 + T * bg[2];
-        if (out_invdepth) out_invdepth[pid] = Dp;
-        if constexpr (DUAL) {
-            out_color2[pid] = E0 + T * bg2[0];
-            out_color2[hw + pid] = E1 + T * bg2[1];
-            out_color2[2 * hw + pid] = E2 + T * bg2[2];
-        }
-    }
-    if (blk_count && (lane & 15) == 0) {
-        const int r = lane >> 4;
-        blk_count[16 * (size_t)q.tile + 4 * q.quad + r] = r == 0 ? bc0 : (r == 1 ? bc1 : (r == 2 ? bc2 : bc3));
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 3: the same forward in TWO STAGES (composite_fwd_q_kernel).
 //
@@ -447,25 +279,13 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
     const bool ordered = (composite_variant() & kVariantOrdered) != 0, exact = (composite_variant() & kVariantExactCull) != 0;
     const dim3 grid(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy));
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
-    if (composite_variant() & kVariantTwoStage) {
-        if (colors2)
-            hipLaunchKernelGGL(composite_fwd_q_kernel<true>, grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,
-                               bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,
-                               out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact);
-        else
-            hipLaunchKernelGGL(composite_fwd_q_kernel<false>, grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,
-                               bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,
-                               out_color, out_invdepth, order, (const float *)nullptr, (const float *)nullptr, (float *)nullptr,
-                               im.blk_list, im.blk_count, exact);
-        return check_launch(s, prm->debug);
-    }
     if (colors2)
-        hipLaunchKernelGGL(composite_fwd_rows_kernel<true>, grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,
-                           bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib,
+        hipLaunchKernelGGL(composite_fwd_q_kernel<true>, grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,
+                           bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,
                            out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact);
     else
-        hipLaunchKernelGGL(composite_fwd_rows_kernel<false>, grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,
-                           bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib,
+        hipLaunchKernelGGL(composite_fwd_q_kernel<false>, grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,
+                           bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,
                            out_color, out_invdepth, order, (const float *)nullptr, (const float *)nullptr, (float *)nullptr,
                            im.blk_list, im.blk_count, exact);
     return check_launch(s, prm->debug);
@@ -486,30 +306,45 @@ extern "C" int d3ga_raster_composite_fwd2(const d3ga_raster_params *prm, const f
 
 static int composite_bwd_impl(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, const void *img, const float *dL_dpix, float *acc, const float *colors2,
-                              const float *bg2, const float *dL_dpix2, d3ga_stream_t stream) {
+                              const float *bg2, const float *dL_dpix2, const L1Source &l1, d3ga_stream_t stream) {
     if (!prm) return D3GA_E_NULL;
     if (prm->P < 0 || prm->W <= 0 || prm->H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
     if (prm->forward_only) return D3GA_E_CONFIG;          // the forward did not write the per-block lists
     if (prm->P == 0) return D3GA_OK;
-    if (!bg || !geom || !binning || !img || !dL_dpix || !acc) return D3GA_E_NULL;
+    if (!bg || !geom || !binning || !img || !acc) return D3GA_E_NULL;
+    if (!dL_dpix && !l1.image) return D3GA_E_NULL;        // some incoming gradient: an image, the fused L1 term, or both
+    if (l1.image && (!(l1.target || l1.target_cell) || !l1.g_loss)) return D3GA_E_NULL;
     if (colors2 && (!bg2 || !dL_dpix2)) return D3GA_E_NULL;
     const int gx = tiles_x(prm->W), gy = tiles_y(prm->H);
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
     const ImgBuf im = carve_img(const_cast<void *>(img), prm->W, prm->H, (int64_t)gx * gy);
     return launch_composite_bwd_scan(prm, gx, gy, bin, g, im, d_capacity, bg, dL_dpix, acc,
-                                     (composite_variant() & kVariantOrdered) != 0, colors2, bg2, dL_dpix2, (hipStream_t)stream);
+                                     (composite_variant() & kVariantOrdered) != 0, colors2, bg2, dL_dpix2, l1, (hipStream_t)stream);
 }
+
+static const L1Source kNoL1 = {nullptr, nullptr, nullptr, nullptr, 0.f};
 
 extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const float *bg, const void *geom,
                                          const void *binning, int64_t d_capacity, const void *img,
                                          const float *dL_dpix, float *acc, d3ga_stream_t stream) {
-    return composite_bwd_impl(prm, bg, geom, binning, d_capacity, img, dL_dpix, acc, nullptr, nullptr, nullptr, stream);
+    if (!dL_dpix) return prm && prm->P == 0 ? D3GA_OK : D3GA_E_NULL;
+    return composite_bwd_impl(prm, bg, geom, binning, d_capacity, img, dL_dpix, acc, nullptr, nullptr, nullptr, kNoL1, stream);
 }
 
 extern "C" int d3ga_raster_composite_bwd2(const d3ga_raster_params *prm, const float *bg, const float *bg2, const void *geom,
                                           const float *colors2, const void *binning, int64_t d_capacity, const void *img,
                                           const float *dL_dpix, const float *dL_dpix2, float *acc, d3ga_stream_t stream) {
-    if (!colors2) return D3GA_E_NULL;
-    return composite_bwd_impl(prm, bg, geom, binning, d_capacity, img, dL_dpix, acc, colors2, bg2, dL_dpix2, stream);
+    if (!colors2 || !dL_dpix) return D3GA_E_NULL;
+    return composite_bwd_impl(prm, bg, geom, binning, d_capacity, img, dL_dpix, acc, colors2, bg2, dL_dpix2, kNoL1, stream);
+}
+
+extern "C" int d3ga_raster_composite_bwd_l1(const d3ga_raster_params *prm, const float *bg, const void *geom,
+                                            const void *binning, int64_t d_capacity, const void *img, const float *image,
+                                            const float *target, const void *target_cell, const float *g_loss,
+                                            const float *dL_dpix, float *acc, d3ga_stream_t stream) {
+    if (!prm) return D3GA_E_NULL;
+    if (!image) return D3GA_E_NULL;
+    const L1Source l1 = {image, target, (const float *const *)target_cell, g_loss, 1.0f / (3.0f * (float)prm->W * (float)prm->H)};
+    return composite_bwd_impl(prm, bg, geom, binning, d_capacity, img, dL_dpix, acc, nullptr, nullptr, nullptr, l1, stream);
 }

@@ -182,7 +182,7 @@ def _empty_to_none(t):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, grad_sync=None, colors2=None, bg2=None, opacity_activation=None):
+                raster_settings, grad_sync=None, colors2=None, bg2=None, opacity_activation=None, l1_target=None):
         s = raster_settings
         require_cuda(means3D)
         dev = means3D.device
@@ -281,10 +281,30 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_sync.verify_inputs({"means3D": means3D, "opacities": opacities, "colors_precomp": colors_precomp,
                                      "shs": sh, "cov3D_precomp": cov3Ds_precomp, "scales": scales, "rotations": rotations})
         ctx.dual = dual
+        # fused L1 image loss (rasterize_gaussians_l1): the loss VALUE is one reduction kernel over the image; its gradient is
+        # formed inside the compositing backward (d3ga_raster_backward_l1), no (3,H,W) gradient image is written or read
+        ctx.l1 = l1_target is not None and P > 0 and not dual
+        l1_t = l1_cell = loss = None
+        if l1_target is not None:
+            from .graph import TensorSlot
+            l1_t = l1_target.current if isinstance(l1_target, TensorSlot) else _f32(l1_target, dev)
+            l1_cell = l1_target.cell if isinstance(l1_target, TensorSlot) else None
+            if tuple(l1_t.shape) != (3, H, W):
+                raise ValueError(f"rasterize_gaussians_l1: the target must be (3, {H}, {W}), got {tuple(l1_t.shape)}")
+            buf = torch.empty(4 + _lib.LOSS_PARTIALS, dtype=torch.float32, device=dev)
+            loss = buf[0]
+            if l1_cell is None:
+                check(L.d3ga_l1_mean_fwd_ws(color.numel(), dptr(color), dptr(l1_t), dptr(loss), dptr(buf[4:]), stream_handle()),
+                      "d3ga_l1_mean_fwd_ws")
+            else:
+                check(L.d3ga_l1_mean_fwd_ws_cell(color.numel(), dptr(color), dptr(l1_cell), dptr(loss), dptr(buf[4:]),
+                                                 stream_handle()), "d3ga_l1_mean_fwd_ws_cell")
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img,
-                              colors2, bg2)
+                              colors2, bg2, color if ctx.l1 else None, l1_t if ctx.l1 else None, l1_cell if ctx.l1 else None)
         ctx.mark_non_differentiable(radii, invdepth)
         ctx.set_materialize_grads(False)                 # no zero-filled (P,) / (H,W) gradients for radii / invdepth per step
+        if l1_target is not None:
+            return color, radii, invdepth, loss
         if dual:
             return color, radii, invdepth, color2
         if empty_pair:
@@ -294,10 +314,15 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, _grad_radii, _grad_invdepth, grad_color2=None):
         (means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img, colors2,
-         bg2) = ctx.saved_tensors
+         bg2, image, l1_t, l1_cell) = ctx.saved_tensors
         prm, dev, P = ctx.prm, means3D.device, means3D.shape[0]
         dual = ctx.dual
-        if grad_color is None:                           # only the second image was used
+        g_loss = None
+        if ctx.l1:                                       # the 4th output was the fused L1 loss: its incoming gradient
+            g_loss, grad_color2 = grad_color2, None
+            if g_loss is not None:
+                g_loss = _f32(g_loss, dev).reshape(1)
+        if grad_color is None and g_loss is None:        # only the second image was used (or nothing at all)
             grad_color = torch.zeros((3, prm.H, prm.W), dtype=torch.float32, device=dev)
         grad_color = _f32(grad_color, dev)
         if dual:
@@ -341,6 +366,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 stage_timer.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd2(
                     pp, dptr(bg), dptr(bg2), dptr(geom), dptr(colors2), dptr(binning), ctx.cap, dptr(img), dptr(grad_color),
                     dptr(grad_color2), dptr(acc), st), "d3ga_raster_composite_bwd2"))
+            elif g_loss is not None:
+                stage_timer.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd_l1(
+                    pp, dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img), dptr(image), dptr(l1_t), dptr(l1_cell),
+                    dptr(g_loss), dptr(grad_color), dptr(acc), st), "d3ga_raster_composite_bwd_l1"))
             else:
                 stage_timer.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd(
                     pp, dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img), dptr(grad_color), dptr(acc), st),
@@ -349,6 +378,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                 pp, dptr(means3D), dptr(sh), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp), dptr(view), dptr(proj),
                 dptr(campos), dptr(geom), dptr(acc), dptr(g_means3D), dptr(g_means2D), dptr(g_opac), dptr(g_sh),
                 dptr(g_col), dptr(g_cov), dptr(g_scales), dptr(g_rots), st), "d3ga_raster_preprocess_bwd"))
+        elif g_loss is not None:
+            check(L.d3ga_raster_backward_l1(
+                ctypes.byref(prm), dptr(means3D), dptr(sh), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp),
+                dptr(view), dptr(proj), dptr(campos), dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img),
+                dptr(image), dptr(l1_t), dptr(l1_cell), dptr(g_loss), dptr(grad_color), dptr(acc), dptr(g_means3D),
+                dptr(g_means2D), dptr(g_opac), dptr(g_sh), dptr(g_col), dptr(g_cov), dptr(g_scales), dptr(g_rots),
+                stream_handle()), "d3ga_raster_backward_l1")
         else:
             check(L.d3ga_raster_backward(
                 ctypes.byref(prm), dptr(means3D), dptr(sh), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp),
@@ -372,7 +408,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 # the parked gradients come back REDUCED through graph.CapturedCutStep: returning them here as well would
                 # leave the unreduced copy on the (detached) leaves, where the step adds the other loss terms' gradients
                 return (None, g_means2D if ctx.has_means2D else None, None, None, None, None, None, None, None, None, None,
-                        None, None)
+                        None, None, None)
             gathered = sync.exchange(flat, factor)         # flat: summed (averaged) in place; gathered: (world, P+1, 3)
             if factor is not None:
                 g_sh = new(P, prm.M, 3)
@@ -381,7 +417,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                 stream_handle()), "d3ga_sh_grad_from_views")
                 g_col = None
         return (g_means3D, g_means2D if ctx.has_means2D else None, g_sh, g_col, g_opac, g_scales, g_rots, g_cov, None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 _ACTIVATIONS = {None: 0, "none": 0, "sigmoid": 1}       # D3GA_OPACITY_SIGMOID
@@ -393,6 +429,16 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     models/cage_net.py:247 runs inside the per-Gaussian kernels, forward and backward."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, grad_sync, None, None, opacity_activation)
+
+
+def rasterize_gaussians_l1(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                           raster_settings, target, grad_sync=None, opacity_activation=None):
+    """The render AND its L1 image loss (utils/loss_utils.py:29: mean |image - target|) from one operator (extension):
+    returns (color, radii, invdepth, loss).  The gradient of `loss` is formed per pixel inside the compositing backward,
+    so no (3,H,W) gradient image is written or read (one full-image kernel and 50 MB of traffic less per frame at 1080p);
+    `color` stays differentiable as usual and both gradients add.  `target`: (3,H,W) tensor or a `graph.TensorSlot`."""
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings, grad_sync, None, None, opacity_activation, target)
 
 
 def rasterize_gaussians_pair(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -4,7 +4,7 @@ solid_bg=True, fast=False, detach=[]) -> {"render": (3,H',W')}` (renderer.py:69-
 import torch
 
 from .cameras import batch_to_camera
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_pair
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_l1, rasterize_gaussians_pair
 
 bg_colors = {"white": (1.0, 1.0, 1.0), "black": (0.0, 0.0, 0.0)}
 
@@ -43,8 +43,22 @@ def render_pair(batch, pkg, bg_color, colors2, bg_color2, grad_sync=None):
     return out
 
 
+def render_l1(batch, pkg, bg_color, target, grad_sync=None):
+    """`render(batch, pkg, bg_color)` and `l1_loss(render, target)` (utils/loss_utils.py:29, train.py:190) from one operator:
+    -> {"render": (3,H',W'), "l1": scalar}.  Same image, same loss, same gradients as the two calls; the loss gradient is
+    formed inside the compositing backward instead of travelling through a (3,H,W) gradient image.  `target`: a tensor of
+    the render's shape or a `graph.TensorSlot`.  With an off-centre crop (lib/batch.py:186-198: the loss lives on the cropped
+    window, not on the raster) the two calls are made instead."""
+    crop = batch["crop"]
+    if int(crop[4]) != int(batch["width"]) or int(crop[5]) != int(batch["height"]):
+        from .losses import l1_loss
+        img = render(batch, pkg, bg_color, grad_sync=grad_sync)["render"]
+        return {"render": img, "l1": l1_loss(img, target)}
+    return render(batch, pkg, bg_color, grad_sync=grad_sync, _l1=target)
+
+
 def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_bg=True, fast=False, detach=[],
-           grad_sync=None, _pair=None):
+           grad_sync=None, _pair=None, _l1=None):
     means3D = pkg["means3D"]
     # a cameras.CameraSlot in the batch: the camera is read from its static device buffer (graph-capturable step that
     # follows the trainer's camera-per-step, d3ga_amd/graph.py)
@@ -105,6 +119,10 @@ def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_
         img, _radii, _invd, img2 = rasterize_gaussians_pair(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                                             cov3D_precomp, settings, _pair[0], _pair[1], grad_sync, act)
         return {"render": paste(img, crop), "render2": paste(img2, crop)}
+    if _l1 is not None:
+        img, _radii, _invd, loss = rasterize_gaussians_l1(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                                          cov3D_precomp, settings, _l1, grad_sync, act)
+        return {"render": img, "l1": loss}
     rasterizer = GaussianRasterizer(raster_settings=settings)
     rasterizer.opacity_activation = act
     if grad_sync is not None:                       # extension over upstream's constructor: set only when asked for

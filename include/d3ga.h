@@ -183,6 +183,23 @@ int d3ga_raster_composite_fwd2(const d3ga_raster_params *prm, const float *bg, c
 int d3ga_raster_composite_bwd2(const d3ga_raster_params *prm, const float *bg, const float *bg2, const void *geom,
                                const float *colors2, const void *binning, int64_t d_capacity, const void *img,
                                const float *dL_dpix, const float *dL_dpix2, float *acc, d3ga_stream_t stream);
+
+/* L1 image loss fused into the backward (extension; the loss of SURVEY sec. 8d's frame, utils/loss_utils.py:29 l1_loss =
+ * mean |image - target|): the compositing backward forms dL/dpixel = g_loss[0] / (3 W H) * sign(image - target) (+ dL_dpix
+ * when given, else NULL) per pixel, instead of reading a (3,H,W) gradient image that a separate kernel had to write.
+ * image = the forward's out_color; target (3,H,W), or target_cell = device cell holding its address (graph.TensorSlot);
+ * g_loss = dL/dloss (device scalar).  d3ga_raster_backward_l1 = clear + this + d3ga_raster_preprocess_bwd. */
+int d3ga_raster_composite_bwd_l1(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
+                                 int64_t d_capacity, const void *img, const float *image, const float *target,
+                                 const void *target_cell, const float *g_loss, const float *dL_dpix, float *acc,
+                                 d3ga_stream_t stream);
+int d3ga_raster_backward_l1(const d3ga_raster_params *prm, const float *means3D, const float *shs, const float *scales,
+                            const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                            const float *projmatrix, const float *campos, const float *bg, const void *geom,
+                            const void *binning, int64_t d_capacity, const void *img, const float *image,
+                            const float *target, const void *target_cell, const float *g_loss, const float *dL_dpix,
+                            float *acc, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dsh,
+                            float *dL_dcolors, float *dL_dcov3D, float *dL_dscales, float *dL_drots, d3ga_stream_t stream);
 /* Re-render of the SAME geometry (same means3D / covariance / opacities / camera / image size) with other colours: the
  * reference's training step renders an RGB and a silhouette pass from one package (models/trainer.py:102-110).
  * Copies the geometry records of geom_src (a d3ga_raster_preprocess result) to geom_dst and evaluates only the colour

@@ -746,6 +746,47 @@ def test_fused_l1_loss_matches_torch():
         assert torch.allclose(a.grad, gref, atol=1e-12)
 
 
+def test_render_l1_equals_render_plus_l1_loss():
+    """renderer.render_l1 (the L1 image loss fused into the rasterizer's backward, d3ga_raster_backward_l1) against the two
+    operators it replaces: the same image bit for bit, the same loss, the same gradients (float atomics: summation order only),
+    with the target given as a tensor and through a graph.TensorSlot, and with an extra loss term on the image so that both
+    incoming gradients (image + fused L1) add inside the compositing backward."""
+    from d3ga_amd.graph import TensorSlot
+    from d3ga_amd.losses import l1_loss
+    from d3ga_amd.renderer import render, render_l1
+    inp = scene_inputs("C1")
+    bg = torch.tensor([0.9, 0.8, 0.7], device=DEV)
+    target = torch.rand(3, inp["H"], inp["W"], generator=torch.Generator().manual_seed(8)).to(DEV)
+    wimg = torch.randn(3, inp["H"], inp["W"], generator=torch.Generator().manual_seed(9)).to(DEV) * 1e-6
+    leaves = lambda: {k: _cu(inp[k], True) for k in ("means3D", "cov6", "opacities", "shs")}
+    pkg_of = lambda l: {"means3D": l["means3D"], "cov3D_precomp": l["cov6"], "opacities": l["opacities"], "shs": l["shs"], "rgb": None,
+                        "sh_degree": 3}
+    for extra in (False, True):
+        a = leaves()
+        img_a = render(inp["batch"], pkg_of(a), bg)["render"]
+        loss_a = l1_loss(img_a, target) * 3.0 + ((img_a * wimg).sum() if extra else 0.0)
+        loss_a.backward()
+        for tgt in (target, TensorSlot(target)):
+            b = leaves()
+            out = render_l1(inp["batch"], pkg_of(b), bg, tgt)
+            assert torch.equal(out["render"], img_a)
+            loss_b = out["l1"] * 3.0 + ((out["render"] * wimg).sum() if extra else 0.0)
+            assert abs(float(loss_b.detach()) - float(loss_a.detach())) <= 1e-6 * abs(float(loss_a.detach()))
+            loss_b.backward()
+            for k in a:
+                ref = a[k].grad
+                assert float((b[k].grad - ref).abs().max() / (ref.abs().max() + 1e-30)) < 2e-4, (extra, k)
+    # an off-centre crop: the loss lives on the cropped window -> the two-operator path is taken (same results by construction)
+    inp_c = scene_inputs("T1", scale_mult=3.0, cx=70, cy=60)
+    c = {k: _cu(inp_c[k], True) for k in ("means3D", "cov6", "opacities", "shs")}
+    crop = inp_c["batch"]["crop"]
+    tgt_c = torch.rand(3, int(crop[5]), int(crop[4]), device=DEV)
+    out = render_l1(inp_c["batch"], pkg_of(c), bg, tgt_c)
+    assert tuple(out["render"].shape) == tuple(tgt_c.shape)
+    out["l1"].backward()
+    assert float(c["means3D"].grad.abs().max()) > 0
+
+
 def test_captured_step_follows_the_camera_of_every_replay():
     """d3ga_amd.graph.CapturedStep + cameras.CameraSlot: ONE captured hipGraph of the whole step (deform -> render -> L1 ->
     backward), replayed with camera k and target k written into static slots, equals the eager step with camera k -- for 8
