@@ -62,6 +62,9 @@ def parse():
                     help="sensitivity: multiply the Gaussians' world-space scales (D/P grows ~quadratically)")
     ap.add_argument("--fill", type=float, default=0.85,
                     help="sensitivity: fraction of the image height the 1.8 m body fills (0.85 = SURVEY sec. 8d recipe)")
+    ap.add_argument("--fresh-scratch", action="store_true",
+                    help="allocate and clear the backward's gradient accumulator per call instead of keeping a self-clearing one "
+                         "(rasterizer.set_accumulator_policy)")
     ap.add_argument("--no-fused-l1", action="store_true",
                     help="render() and l1_loss() as two operators instead of d3ga_amd.renderer.render_l1 (same loss and gradients; "
                          "the gradient image then makes a round trip through HBM)")
@@ -565,6 +568,8 @@ def main():
         collect_pmc(args)
     frame = Frame(args.workload, dev, view_index=rank % 8, scale_mult=args.scale_mult, fill=args.fill)
     frame.fused_l1 = not args.no_fused_l1
+    if not args.fresh_scratch:
+        R.set_accumulator_policy("persistent")         # one training stream: the accumulator cleans itself
     flat = ddist.GradReducer(list(frame.params.values()))
     cut = world > 1 and args.reduce == "cut"
     if args.force_cut and world == 1:

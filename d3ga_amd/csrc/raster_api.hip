@@ -74,7 +74,7 @@ extern "C" int d3ga_raster_backward(const d3ga_raster_params *prm, const float *
                                     const void *img, const float *dL_dpix, float *acc, float *dL_dmeans3D,
                                     float *dL_dmeans2D, float *dL_dopacity, float *dL_dsh, float *dL_dcolors,
                                     float *dL_dcov3D, float *dL_dscales, float *dL_drots, d3ga_stream_t stream) {
-    if (prm && prm->P > 0 && acc)
+    if (prm && prm->P > 0 && acc && !prm->acc_self_clearing)
         D3GA_HIP(zero_async(acc, sizeof(float) * D3GA_ACC_STRIDE * (size_t)prm->P, (hipStream_t)stream));
     D3GA_TRY(d3ga_raster_composite_bwd(prm, bg, geom, binning, d_capacity, img, dL_dpix, acc, stream));
     return d3ga_raster_preprocess_bwd(prm, means3D, shs, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
@@ -90,7 +90,7 @@ extern "C" int d3ga_raster_backward_l1(const d3ga_raster_params *prm, const floa
                                        const float *g_loss, const float *dL_dpix, float *acc, float *dL_dmeans3D,
                                        float *dL_dmeans2D, float *dL_dopacity, float *dL_dsh, float *dL_dcolors,
                                        float *dL_dcov3D, float *dL_dscales, float *dL_drots, d3ga_stream_t stream) {
-    if (prm && prm->P > 0 && acc)
+    if (prm && prm->P > 0 && acc && !prm->acc_self_clearing)
         D3GA_HIP(zero_async(acc, sizeof(float) * D3GA_ACC_STRIDE * (size_t)prm->P, (hipStream_t)stream));
     D3GA_TRY(d3ga_raster_composite_bwd_l1(prm, bg, geom, binning, d_capacity, img, image, target, target_cell, g_loss, dL_dpix,
                                           acc, stream));

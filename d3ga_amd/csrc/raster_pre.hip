@@ -288,6 +288,18 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
         rc = geom.rect[i];
         const float4 *ap = reinterpret_cast<const float4 *>(acc + D3GA_ACC_STRIDE * (size_t)i);
         a0 = ap[0]; a1 = ap[1]; a2 = ap[2];
+        if (prm.acc_self_clearing) {
+            // the caller keeps this buffer for the next backward: leave the record as we found the untouched ones, all zero
+            // (only records the compositing backward wrote are written back: 48 of their 64 bytes)
+            const uint32_t any = (__float_as_uint(a0.x) | __float_as_uint(a0.y) | __float_as_uint(a0.z) | __float_as_uint(a0.w)) |
+                                 (__float_as_uint(a1.x) | __float_as_uint(a1.y) | __float_as_uint(a1.z) | __float_as_uint(a1.w)) |
+                                 (__float_as_uint(a2.x) | __float_as_uint(a2.y) | __float_as_uint(a2.z) | __float_as_uint(a2.w));
+            if (any) {
+                float4 *wp = const_cast<float4 *>(ap);
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                wp[0] = z; wp[1] = z; wp[2] = z;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 6; ++k) c6[k] = geom.cov3D[6 * (size_t)i + k];
         clampmask = geom.clamped[i];

@@ -56,6 +56,51 @@ def set_capacity_policy(mode, capacity=0):
     _policy["static"] = int(capacity)
 
 
+# ------------------------------------------------------------------------------------------------------------
+# screen-space gradient accumulator of the backward
+# ------------------------------------------------------------------------------------------------------------
+_acc_policy = {"persistent": False}
+_acc_cache = {}      # (device index, P) -> zeroed (P, ACC_STRIDE) buffer kept between backwards
+
+
+def set_accumulator_policy(mode):
+    """"fresh" (default): every backward allocates its accumulator and clears it (a 64 B x P fill kernel).
+    "persistent": ONE accumulator per (device, P) is kept between backwards; the per-Gaussian backward kernel leaves it all
+    zero again (d3ga_raster_params.acc_self_clearing), so no clear is ever launched.  Valid when all rasterizer backwards
+    of the process on that device are ordered on one stream (a training loop, or captured steps replayed on it) -- two
+    backwards in flight on different streams would share the buffer."""
+    if mode not in ("fresh", "persistent"):
+        raise ValueError(mode)
+    _acc_policy["persistent"] = mode == "persistent"
+    if mode == "fresh":
+        _acc_cache.clear()
+
+
+def l1_mean_forward(image, target, cell, out, dev):
+    """mean |image - target| into `out` (device scalar): one partial sum per workgroup, then one workgroup adds them (index
+    order: reproducible)."""
+    L = _lib.lib()
+    ws = torch.empty(_lib.LOSS_PARTIALS, dtype=torch.float32, device=dev)
+    if cell is None:
+        check(L.d3ga_l1_mean_fwd_ws(image.numel(), dptr(image), dptr(target), dptr(out), dptr(ws), stream_handle()), "d3ga_l1_mean_fwd_ws")
+    else:
+        check(L.d3ga_l1_mean_fwd_ws_cell(image.numel(), dptr(image), dptr(cell), dptr(out), dptr(ws), stream_handle()),
+              "d3ga_l1_mean_fwd_ws_cell")
+
+
+def _accumulator(P, dev):
+    """-> (buffer, self_clearing)"""
+    if not _acc_policy["persistent"] or P == 0:
+        return torch.empty((P, _lib.ACC_STRIDE), dtype=torch.float32, device=dev), False
+    key = (dev.index, P)
+    buf = _acc_cache.get(key)
+    if buf is None:
+        if len(_acc_cache) > 8:
+            _acc_cache.clear()
+        buf = _acc_cache[key] = torch.zeros((P, _lib.ACC_STRIDE), dtype=torch.float32, device=dev)
+    return buf, True
+
+
 def last_counters(device=None):
     """dict(D, overflow, max_tile, visible) of the most recent forward on `device` (synchronises)."""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
@@ -291,14 +336,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             l1_cell = l1_target.cell if isinstance(l1_target, TensorSlot) else None
             if tuple(l1_t.shape) != (3, H, W):
                 raise ValueError(f"rasterize_gaussians_l1: the target must be (3, {H}, {W}), got {tuple(l1_t.shape)}")
-            buf = torch.empty(4 + _lib.LOSS_PARTIALS, dtype=torch.float32, device=dev)
-            loss = buf[0]
-            if l1_cell is None:
-                check(L.d3ga_l1_mean_fwd_ws(color.numel(), dptr(color), dptr(l1_t), dptr(loss), dptr(buf[4:]), stream_handle()),
-                      "d3ga_l1_mean_fwd_ws")
-            else:
-                check(L.d3ga_l1_mean_fwd_ws_cell(color.numel(), dptr(color), dptr(l1_cell), dptr(loss), dptr(buf[4:]),
-                                                 stream_handle()), "d3ga_l1_mean_fwd_ws_cell")
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            l1_mean_forward(color, l1_t, l1_cell, loss, dev)
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img,
                               colors2, bg2, color if ctx.l1 else None, l1_t if ctx.l1 else None, l1_cell if ctx.l1 else None)
         ctx.mark_non_differentiable(radii, invdepth)
@@ -328,7 +367,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         if dual:
             grad_color2 = (torch.zeros_like(grad_color) if grad_color2 is None else _f32(grad_color2, dev))
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        acc = new(P, _lib.ACC_STRIDE)
+        acc, self_clearing = _accumulator(P, dev)
+        if self_clearing != bool(prm.acc_self_clearing):
+            prm = RasterParams(**{f: getattr(prm, f) for f, _ in RasterParams._fields_})       # (ctx.prm is shared with a retained graph)
+            prm.acc_self_clearing = int(self_clearing)
         from_sr = cov3Ds_precomp is None
         sync = ctx.grad_sync
         if sync is None:
@@ -361,7 +403,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         L = _lib.lib()
         if stage_timer.enabled or dual:
             st, pp = stream_handle(), ctypes.byref(prm)
-            acc.zero_()
+            if not self_clearing:
+                acc.zero_()
             if dual:
                 stage_timer.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd2(
                     pp, dptr(bg), dptr(bg2), dptr(geom), dptr(colors2), dptr(binning), ctx.cap, dptr(img), dptr(grad_color),

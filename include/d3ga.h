@@ -117,6 +117,11 @@ typedef struct d3ga_raster_params {
      * (2 x 4 B per pixel instead of + 128 B per duplicate of capacity).  Calling a backward entry point afterwards is an error
      * (D3GA_E_CONFIG). */
     int32_t forward_only;
+    /* != 0: `acc` of the backward entry points is a buffer the CALLER keeps from call to call and guarantees to be all zero
+     * on entry: d3ga_raster_backward / _l1 then skip their clear (a 64 B x P fill kernel per backward) and
+     * d3ga_raster_preprocess_bwd zero-fills every record it consumed, so that the buffer is all zero again when it returns.
+     * All backwards sharing one such buffer must be ordered on one stream. */
+    int32_t acc_self_clearing;
 } d3ga_raster_params;
 #define D3GA_OPACITY_SIGMOID 1
 

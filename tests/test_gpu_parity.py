@@ -787,6 +787,40 @@ def test_render_l1_equals_render_plus_l1_loss():
     assert float(c["means3D"].grad.abs().max()) > 0
 
 
+def test_persistent_self_clearing_accumulator():
+    """rasterizer.set_accumulator_policy("persistent"): the backward's (P,16) accumulator is kept between calls and left all
+    zero by the per-Gaussian backward kernel (d3ga_raster_params.acc_self_clearing: no clear kernel).  Same loss and
+    gradients as the default policy, step after step, with two renders per step, and the buffer really is clean."""
+    from d3ga_amd import rasterizer as R
+    from d3ga_amd.renderer import render, render_l1
+    inp = scene_inputs("C1")
+    bg = torch.tensor([0.9, 0.8, 0.7], device=DEV)
+    target = torch.rand(3, inp["H"], inp["W"], generator=torch.Generator().manual_seed(8)).to(DEV)
+    sil = torch.ones(inp["means3D"].shape[0], 3, device=DEV)
+
+    def step():
+        l = {k: _cu(inp[k], True) for k in ("means3D", "cov6", "opacities", "shs")}
+        pkg = {"means3D": l["means3D"], "cov3D_precomp": l["cov6"], "opacities": l["opacities"], "shs": l["shs"], "rgb": None, "sh_degree": 3}
+        out = render_l1(inp["batch"], pkg, bg, target)
+        s2 = render(inp["batch"], pkg, torch.zeros(3, device=DEV), colors_precomp=sil)["render"]
+        loss = out["l1"] + 0.1 * s2.mean()
+        loss.backward()
+        return float(loss.detach()), {k: v.grad.clone() for k, v in l.items()}
+    l_ref, g_ref = step()
+    R.set_accumulator_policy("persistent")
+    try:
+        for it in range(4):
+            l, g = step()
+            assert abs(l - l_ref) <= 1e-6 * abs(l_ref), (it, l, l_ref)
+            for k in g:
+                assert float((g[k] - g_ref[k]).abs().max() / (g_ref[k].abs().max() + 1e-30)) < 2e-4, (it, k)
+            torch.cuda.synchronize()
+            assert len(R._acc_cache) == 1 and all(int(torch.count_nonzero(b)) == 0 for b in R._acc_cache.values())
+    finally:
+        R.set_accumulator_policy("fresh")
+    assert not R._acc_cache
+
+
 def test_captured_step_follows_the_camera_of_every_replay():
     """d3ga_amd.graph.CapturedStep + cameras.CameraSlot: ONE captured hipGraph of the whole step (deform -> render -> L1 ->
     backward), replayed with camera k and target k written into static slots, equals the eager step with camera k -- for 8
