@@ -674,6 +674,37 @@ def main():
             frame.step()
         reduce_params()
 
+    # N > 1: the N = 1 step of THIS run, on every rank, before the group step is timed -- the same frame without the exchange,
+    # ONE captured hipGraph, K replays with this rank's camera (slowest rank counts).  `distributed.efficiency` = n1 / N-step
+    # time is then a statement of the run itself (weak scaling: every rank renders one view either way).
+    n1_ms = None
+    if world > 1 or args.force_cut:
+        from d3ga_amd.graph import CapturedStep
+        keep_sync, frame.grad_sync = frame.grad_sync, None
+        try:
+            for _ in range(2):
+                flat.zero(); frame.step()
+            torch.cuda.synchronize()
+            cap1 = CapturedStep(frame.step, params=list(frame.params.values()))
+            for _ in range(3):
+                cap1.replay()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                cap1.replay()
+            barrier()
+            t_n1 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            if world > 1:
+                torch.distributed.all_reduce(t_n1, op=torch.distributed.ReduceOp.MAX)
+            n1_ms = 1e3 * float(t_n1) / args.steps
+            cap1.check_overflow()
+            del cap1
+        except Exception as e:  # noqa: BLE001  (the reference number must never take the N > 1 line down)
+            exchange_note = (exchange_note or "") + f" in-run N=1 reference failed ({type(e).__name__}: {e})"
+        finally:
+            frame.grad_sync = keep_sync
+            flat.zero()
+
     if graph is not None and hasattr(graph, "graph_b"):
         # Two graphs + eager collectives, or everything eager?  The two-graph step saves the host ~0.45 ms of launches per step
         # but pays two graph launches; which one wins depends on the size (measured on one GPU over a one-rank nccl group: C3
@@ -812,6 +843,18 @@ def main():
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist_info = None
+    if world == 1 and args.force_cut and cut:
+        frame.grad_sync.exchange_ms()
+        for _ in range(5):
+            one_step()
+        ex_ms = frame.grad_sync.exchange_ms()
+        step_ms_all = 1e3 * dt / args.steps
+        dist_info = {"nranks_seen": 1, "n1_ms_per_step": None if n1_ms is None else round(n1_ms, 4),
+                     "efficiency": None if n1_ms is None else round(n1_ms / step_ms_all, 4),
+                     "exchange_ms": None if ex_ms is None else round(ex_ms, 4),
+                     "compute_ms": None if ex_ms is None else round(step_ms_all - ex_ms, 4),
+                     "note": "--force-cut on ONE GPU: the collectives are identities; efficiency here = what the camera-sharded step "
+                             "costs per rank apart from the wire time (launch mode, SH rebuild, parked buffers)"}
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         # compute / exchange split of the N > 1 step: HIP events around every exchange (dist.ViewShardedGrads timing) resp.
@@ -834,7 +877,12 @@ def main():
             torch.cuda.synchronize()
             ex_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
         step_ms_all = 1e3 * float(tmax.item()) / args.steps
-        dist_info = {"nranks_seen": int(ones.item()), "exchange_ms": None if ex_ms is None else round(ex_ms, 4),
+        dist_info = {"nranks_seen": int(ones.item()),
+                     "n1_ms_per_step": None if n1_ms is None else round(n1_ms, 4),
+                     "efficiency": None if n1_ms is None else round(n1_ms / step_ms_all, 4),
+                     "efficiency_note": "weak scaling of this run: (N = 1 captured step of the same frame, timed on every rank just before, "
+                                        "slowest rank) / (N-rank step); 1.0 = the exchange and the N > 1 launch mode cost nothing",
+                     "exchange_ms": None if ex_ms is None else round(ex_ms, 4),
                      "compute_ms": None if ex_ms is None else round(step_ms_all - ex_ms, 4),
                      "note": "exchange_ms: HIP events around the collectives of one step (all-reduce + all-gather in flight "
                              "together); compute_ms = ms_per_step - exchange_ms (the exchange is not overlapped with compute)"}
@@ -925,7 +973,9 @@ def main():
                             "two hipGraphs per step (up to the rasterizer's backward | the rest of the backward) with the gradient "
                             "exchange issued eagerly between them" if graph is not None and hasattr(graph, "graph_b") else
                             "hipGraph replay of one captured step" if graph is not None else "eager"),
-            **({"distributed": dist_info} if dist_info else {}),
+            **({"distributed": dict(dist_info, launch_mode=("two hipGraphs around the eager exchange" if graph is not None and hasattr(graph, "graph_b")
+                                                             else "one hipGraph incl. the collectives" if graph is not None else "eager"))}
+               if dist_info else {}),
             **({"grad_exchange_note": exchange_note} if exchange_note else {}),
             "stage_events": "separate eager pass, same K steps" if graph is not None else "none" if args.no_stage_events else "separate eager pass",
         }
