@@ -27,7 +27,7 @@ static inline int composite_merge_slots() {        // A/B knob: slots of the til
     }();
     return v;
 }
-static inline int composite_tile_assign() {        // A/B knob: block -> wavefront assignment of the tile kernel (0 quadrants, 1 interleaved)
+static inline int composite_tile_assign() {        // A/B knob: block -> wavefront assignment of the tile kernel (0 quadrants, 1 interleaved, 2 by list length)
     static const int v = [] {
         const char *e = getenv("D3GA_TILE_ASSIGN");
         return e ? atoi(e) : 1;

@@ -147,6 +147,22 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     __shared__ __attribute__((aligned(16))) float s_dump_all[4][64 * 2 + 16 * PIXF];
     __shared__ __attribute__((aligned(16))) uint32_t s_cache[S * kSlot];
     for (int i = threadIdx.x; i < S; i += 256) s_cache[i * kSlot + 10] = 0u;       // tags: every slot empty
+    __shared__ uint8_t s_perm[16];                          // assign 2: the tile's 16 blocks by descending list length
+    if (assign == 2 && threadIdx.x < 16) {
+        const int b = threadIdx.x, tx0 = (tile % gx) * kTile, ty0 = (tile / gx) * kTile;
+        auto count_of = [&](int j) -> uint32_t {            // (the forward writes the counts of quadrants that start inside the image)
+            const int q = j >> 2;
+            return (tx0 + ((q & 1) << 3) < W && ty0 + ((q >> 1) << 3) < H) ? blk_count[16 * (size_t)tile + j] : 0u;
+        };
+        const uint32_t mine = count_of(b);
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t c = count_of(j);
+            rank += (c > mine || (c == mine && j < b)) ? 1 : 0;
+        }
+        s_perm[rank] = (uint8_t)b;
+    }
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -154,9 +170,17 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     // assign 1: it takes the blocks (wave & 1) + 2 i, (wave >> 1) + 2 j -- 8 pixels apart, so its rows rarely hold the same
     // Gaussian in the same group (copies that meet in ONE instruction serialise on the slot; copies in different wavefronts
     // simply hit the cache).  The forward numbers a tile's blocks 4 * quadrant + (block within the quadrant).
+    // assign 2 (default): the four blocks of SIMILAR list length -- ranks 4 g .. 4 g + 3 of the tile's blocks sorted by length,
+    // g = (wave + workgroup) mod 4.  A wavefront runs as many groups as its longest row needs, so rows of unequal length pad
+    // (quadrants: 57.5 k wave-groups at C3, interleaved 59.3 k, against 49 k row-groups / 4); and rotating g with the workgroup
+    // index gives every SIMD of a CU (wave w of a workgroup runs on SIMD w) one wavefront of each weight class.
     const int row = lane >> 4, l16 = lane & 15;
-    const int bx = assign ? 2 * (row & 1) + (wave & 1) : 2 * (wave & 1) + (row & 1);
-    const int by = assign ? 2 * (row >> 1) + (wave >> 1) : 2 * (wave >> 1) + (row >> 1);
+    int bx = assign ? 2 * (row & 1) + (wave & 1) : 2 * (wave & 1) + (row & 1);
+    int by = assign ? 2 * (row >> 1) + (wave >> 1) : 2 * (wave >> 1) + (row >> 1);
+    if (assign == 2) {
+        const int b = s_perm[4 * ((wave + (int)blockIdx.x) & 3) + row], q = b >> 2, r = b & 3;
+        bx = 2 * (q & 1) + (r & 1); by = 2 * (q >> 1) + (r >> 1);
+    }
     const int blk = 4 * ((bx >> 1) + 2 * (by >> 1)) + ((bx & 1) + 2 * (by & 1));
     const int bx0 = (tile % gx) * kTile + 4 * bx, by0 = (tile / gx) * kTile + 4 * by;      // block origin in pixels
     const int fq = lane / 9, fk = lane - 9 * fq;           // publish: lane -> (record within a group of 7, value)
