@@ -279,8 +279,36 @@ def collect_pmc(args):
     if out:
         os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
         suffix = "" if (args.scale_mult == 1.0 and args.fill == 0.85) else f"_s{args.scale_mult:g}_f{args.fill:g}"
+        out["_meta"] = {"lib_sha256": lib_sha256(), "command": "bench.py --pmc (separate rocprofv3 --pmc passes of the same command)",
+                        "workload": args.workload}
         json.dump(out, open(os.path.join(ROOT, "profiles", f"pmc_{args.workload}{suffix}.json"), "w"), indent=1)
     return out
+
+
+def lib_sha256():
+    """sha256 of the libd3ga_hip.so this process runs -- PMC summaries are stamped with it, so that a bench line can say whether
+    the counters it quotes were collected on the library it timed (`roofline.traffic_stale`)."""
+    import hashlib
+    from d3ga_amd import _lib
+    try:
+        return hashlib.sha256(open(_lib._PATH, "rb").read()).hexdigest()
+    except Exception:
+        return None
+
+
+def pmc_summary(workload, suffix=""):
+    """(dict kernel -> counters, source path, stale?) of the newest PMC summary for this workload: profiles/pmc_<wl>.json (written
+    by `bench.py --pmc` in this checkout) or the newest committed profiles/rNN_pmc_<wl>.json."""
+    import glob
+    cands = [os.path.join(ROOT, "profiles", f"pmc_{workload}{suffix}.json")]
+    cands += sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_{workload}{suffix}.json")), reverse=True)
+    for pj in cands:
+        if os.path.exists(pj):
+            d = json.load(open(pj))
+            meta = d.pop("_meta", {})
+            stale = meta.get("lib_sha256") != lib_sha256()
+            return d, os.path.relpath(pj, ROOT), stale
+    return {}, None, None
 
 
 def valu_issue_model():
@@ -291,7 +319,8 @@ def valu_issue_model():
         cal = {(r["kind"], r["waves_per_simd"]): r for r in json.load(open(os.path.join(ROOT, "profiles", "r02_valu_issue_pmc.json")))}
         cyc = lambda kind: cal[(kind, 8)]["cycles_per_wave_inst_per_simd"]
         cost = {"plain": cyc("v_fma_f32"), "dpp": cyc("v_add_f32_dpp"), "trans": cyc("v_exp_f32"), "packed": cyc("v_pk_fma_f32")}
-        mix = json.load(open(os.path.join(ROOT, "profiles", "r02_composite_bwd_mix.json")))
+        mixes = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_composite_bwd_mix.json"))
+        mix = json.load(open(os.path.join(ROOT, "profiles", mixes[-1])))
         cost["vop3_other"] = mix.get("vop3_other_cycles", 1.6 * cost["plain"])
         n = sum(mix["counts"].values())
         avg = sum(mix["counts"][k] * cost[k] for k in mix["counts"]) / n
@@ -371,18 +400,44 @@ def deform_gpu_comparison(frame, reps=50):
                               torch.exp(p["scaling"]), p["rotation"])
         (m.sum() + c.sum()).backward()
 
-    res = {}
-    for name, fn in (("fused_hip_ms", fused), ("unfused_torch_gpu_ms", unfused)):
-        for _ in range(10):
-            fn()
-        torch.cuda.synchronize()
+    def timed(fn):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        res[name] = round(e0.elapsed_time(e1) / reps, 4)
+        return round(e0.elapsed_time(e1) / reps, 4)
+
+    res = {}
+    for name, fn in (("fused_hip_ms", fused), ("unfused_torch_gpu_ms", unfused)):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        res[name] = timed(fn)
+    res["fused_hip_note"] = "eager: a host-bound loop (its ~63 us of kernels sit inside ~0.2 ms of Python launches and ATen sums)"
+    # the same two legs as captured hipGraphs: what the GPU needs, without the host
+    for name, fn in (("fused_hip_graph_ms", fused), ("unfused_torch_gpu_graph_ms", unfused)):
+        try:
+            for q in p.values():
+                q.grad = None
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for q in p.values():
+                q.grad = None
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            g.replay()
+            torch.cuda.synchronize()
+            res[name] = timed(g.replay)
+            del g
+        except Exception as e:  # noqa: BLE001
+            res[name] = f"capture failed: {type(e).__name__}"
     for q in p.values():
         q.grad = None
     return res
@@ -907,31 +962,22 @@ def main():
         # HBM traffic of the compositing kernels from the committed rocprofv3 --pmc passes of this same command
         # (bench.py --pmc -> profiles/pmc_<workload>.json): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH doubled per the gfx950
         # correction of MI355X_MICROARCH.md.  None when no PMC summary for this workload is present.
-        pmc_traffic, pmc_lds, pmc_valu, pmc_busy = {}, {}, {}, {}
-        try:
-            pj = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
-            if os.path.exists(pj):
-                for kname, c in json.load(open(pj)).items():
-                    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                        short = re.sub(r"_(rows\d*|scan)", "", kname.split("::")[-1].split("_kernel")[0])
-                        pmc_traffic[short] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
-                        if c.get("SQ_LDS_IDX_ACTIVE"):     # LDS bank-conflict cycles / LDS-active cycles
-                            pmc_lds[short] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
-                        if c.get("SQ_INSTS_VALU"):
-                            pmc_valu[short] = int(c["SQ_INSTS_VALU"])
-        except Exception:
-            pmc_traffic = {}
-        roof = None
-        pmc_all = {}
+        pmc_traffic, pmc_lds, pmc_valu, pmc_all, pmc_src, pmc_stale = {}, {}, {}, {}, None, None
         try:
             suffix = "" if (args.scale_mult == 1.0 and args.fill == 0.85) else f"_s{args.scale_mult:g}_f{args.fill:g}"
-            pj = os.path.join(ROOT, "profiles", f"pmc_{args.workload}{suffix}.json")
-            if os.path.exists(pj):
-                for kname, c in json.load(open(pj)).items():
-                    short = re.sub(r"_(rows\d*|scan)", "", kname.split("::")[-1].split("_kernel")[0])
-                    pmc_all[short] = c
+            raw, pmc_src, pmc_stale = pmc_summary(args.workload, suffix)
+            for kname, c in raw.items():
+                short = re.sub(r"_(rows\d*|scan|tile|q)(<.*)?$", "", kname.split("::")[-1].split("_kernel")[0])
+                pmc_all[short] = c
+                if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    pmc_traffic[short] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+                    if c.get("SQ_LDS_IDX_ACTIVE"):     # LDS bank-conflict cycles / LDS-active cycles
+                        pmc_lds[short] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
+                    if c.get("SQ_INSTS_VALU"):
+                        pmc_valu[short] = int(c["SQ_INSTS_VALU"])
         except Exception:
-            pmc_all = {}
+            pmc_traffic, pmc_all = {}, {}
+        roof = None
         comp = [k for k in ("composite_bwd", "composite_fwd") if k in kernels]
         if comp:
             k = max(comp, key=lambda n: kernels[n]["ms"])
@@ -939,8 +985,10 @@ def main():
                     "unit": "GB/s", "frac": kernels[k]["frac_hbm_peak"], "traffic": pmc_traffic.get(k),
                     "lds_bank_conflict_per_lds_active": pmc_lds.get(k), "valu_wave_instructions": pmc_valu.get(k),
                     "alg_bytes_per_launch": alg[k], "avg_ms": kernels[k]["ms"],
-                    "traffic_source": ("profiles/pmc_%s.json (bench.py --pmc: separate rocprofv3 --pmc passes of this command; "
-                                       "(2 x FETCH_SIZE + WRITE_SIZE) KiB)" % args.workload) if pmc_traffic.get(k) else None}
+                    "traffic_source": ("%s (bench.py --pmc: separate rocprofv3 --pmc passes of this command; "
+                                       "(2 x FETCH_SIZE + WRITE_SIZE) KiB)" % pmc_src) if pmc_traffic.get(k) else None,
+                    # True: the counters were collected on another build of libd3ga_hip.so than the one timed here
+                    "traffic_stale": pmc_stale if pmc_traffic.get(k) else None}
             # VALU issue share, calibrated: wave-instructions x the kernel's average issue cost (static mix
             # of its loop x the measured cycles of each instruction class) / (1024 SIMDs x launch cycles at the measured clock)
             c = pmc_all.get(k, {})
@@ -948,6 +996,11 @@ def main():
             if k == "composite_bwd" and avg_cyc and c.get("SQ_INSTS_VALU") and c.get("GRBM_GUI_ACTIVE"):
                 launch_cycles = c["GRBM_GUI_ACTIVE"] / 8.0               # summed over the 8 XCDs
                 roof["valu_frac"] = round(c["SQ_INSTS_VALU"] * avg_cyc / (1024.0 * launch_cycles), 4)
+                # the issue floor of the launch: every VALU wave-instruction at its calibrated cost on 1024 SIMDs at the peak clock --
+                # what the kernel would take if nothing but instruction issue limited it (the distance to the 0.40 target as a number)
+                floor_us = c["SQ_INSTS_VALU"] * avg_cyc / (1024.0 * 2.4e9) * 1e6
+                roof["valu_floor_us"] = round(floor_us, 1)
+                roof["frac_at_valu_floor"] = round(alg[k] / (floor_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                 roof["valu_model"] = {"avg_cycles_per_valu_instruction": round(avg_cyc, 3), **model,
                                       "source": "tools/micro/valu_issue.hip (profiles/r02_valu_issue_pmc.json) x tools/isa_mix.py"}
         out = {

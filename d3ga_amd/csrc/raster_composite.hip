@@ -51,7 +51,9 @@ namespace d3ga {
 // A block-level hit implies the quadrant-level box hit (same extents, the blocks lie inside the quadrant), so the set of
 // (entry, block) pairs, the emitted lists and every pixel are identical to the kernel above.
 // Pipeline per batch: its gathers and the next stage-one loads are issued BEFORE the previous batch is blended.
-template <bool DUAL>
+// DEPTH: the inverse-depth image of branch dr_aa is accumulated and written (the D3GA renderer uses the colour only:
+// renderer.py:141 takes [0]; without it the blend loop is one FMA per entry shorter and 4 B per pixel are not written)
+template <bool DUAL, bool DEPTH>
 __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
     uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
@@ -211,7 +213,8 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
                 const bool keep = !(test_T < kTmin);
                 const bool bl = act && keep;
                 const float w = bl ? al0 * T : 0.f;
-                C0 += e0rgb.x * w; C1 += e0rgb.y * w; C2 += e0rgb.z * w; Dp += e0rgb.w * w;
+                C0 += e0rgb.x * w; C1 += e0rgb.y * w; C2 += e0rgb.z * w;
+                if constexpr (DEPTH) Dp += e0rgb.w * w;
                 if constexpr (DUAL) {
                     const float4 u = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rgb2) + o0);
                     E0 += u.x * w; E1 += u.y * w; E2 += u.z * w;
@@ -226,7 +229,8 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
                 const bool keep = !(test_T < kTmin);
                 const bool bl = act && keep;
                 const float w = bl ? al1 * T : 0.f;
-                C0 += e1rgb.x * w; C1 += e1rgb.y * w; C2 += e1rgb.z * w; Dp += e1rgb.w * w;
+                C0 += e1rgb.x * w; C1 += e1rgb.y * w; C2 += e1rgb.z * w;
+                if constexpr (DEPTH) Dp += e1rgb.w * w;
                 if constexpr (DUAL) {
                     const float4 u = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_rgb2) + o1);
                     E0 += u.x * w; E1 += u.y * w; E2 += u.z * w;
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
         out_color[pid] = C0 + T * bg[0];
         out_color[hw + pid] = C1 + T * bg[1];
         out_color[2 * hw + pid] = C2 + T * bg[2];
-        if (out_invdepth) out_invdepth[pid] = Dp;
+        if constexpr (DEPTH) out_invdepth[pid] = Dp;
         if constexpr (DUAL) {
             out_color2[pid] = E0 + T * bg2[0];
             out_color2[hw + pid] = E1 + T * bg2[1];
@@ -279,15 +283,13 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
     const bool ordered = (composite_variant() & kVariantOrdered) != 0, exact = (composite_variant() & kVariantExactCull) != 0;
     const dim3 grid(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy));
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
-    if (colors2)
-        hipLaunchKernelGGL(composite_fwd_q_kernel<true>, grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,
-                           bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,
-                           out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact);
-    else
-        hipLaunchKernelGGL(composite_fwd_q_kernel<false>, grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,
-                           bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,
-                           out_color, out_invdepth, order, (const float *)nullptr, (const float *)nullptr, (float *)nullptr,
-                           im.blk_list, im.blk_count, exact);
+#define D3GA_LAUNCH_FWD(DUALV, DEPTHV)                                                                                          \
+    hipLaunchKernelGGL((composite_fwd_q_kernel<DUALV, DEPTHV>), grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,       \
+                       bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,     \
+                       out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact)
+    if (colors2) { if (out_invdepth) D3GA_LAUNCH_FWD(true, true); else D3GA_LAUNCH_FWD(true, false); }
+    else { if (out_invdepth) D3GA_LAUNCH_FWD(false, true); else D3GA_LAUNCH_FWD(false, false); }
+#undef D3GA_LAUNCH_FWD
     return check_launch(s, prm->debug);
 }
 

@@ -227,7 +227,8 @@ def _empty_to_none(t):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, grad_sync=None, colors2=None, bg2=None, opacity_activation=None, l1_target=None):
+                raster_settings, grad_sync=None, colors2=None, bg2=None, opacity_activation=None, l1_target=None,
+                want_invdepth=True):
         s = raster_settings
         require_cuda(means3D)
         dev = means3D.device
@@ -259,7 +260,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                            debug=int(bool(s.debug)), opacity_activation=_ACTIVATIONS[opacity_activation],
                            forward_only=int(fwd_only))
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-        invdepth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        # the inverse-depth image of branch dr_aa: on request only (renderer.render* use the colour alone, renderer.py:141)
+        invdepth = torch.empty((1, H, W), dtype=torch.float32, device=dev) if want_invdepth else None
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         L = _lib.lib()
         static = _policy["mode"] == "static"
@@ -340,7 +342,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             l1_mean_forward(color, l1_t, l1_cell, loss, dev)
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img,
                               colors2, bg2, color if ctx.l1 else None, l1_t if ctx.l1 else None, l1_cell if ctx.l1 else None)
-        ctx.mark_non_differentiable(radii, invdepth)
+        ctx.mark_non_differentiable(*((radii, invdepth) if invdepth is not None else (radii,)))
         ctx.set_materialize_grads(False)                 # no zero-filled (P,) / (H,W) gradients for radii / invdepth per step
         if l1_target is not None:
             return color, radii, invdepth, loss
@@ -451,7 +453,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 # the parked gradients come back REDUCED through graph.CapturedCutStep: returning them here as well would
                 # leave the unreduced copy on the (detached) leaves, where the step adds the other loss terms' gradients
                 return (None, g_means2D if ctx.has_means2D else None, None, None, None, None, None, None, None, None, None,
-                        None, None, None)
+                        None, None, None, None)
             gathered = sync.exchange(flat, factor)         # flat: summed (averaged) in place; gathered: (world, P+1, 3)
             if factor is not None:
                 g_sh = new(P, prm.M, 3)
@@ -460,36 +462,36 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                 stream_handle()), "d3ga_sh_grad_from_views")
                 g_col = None
         return (g_means3D, g_means2D if ctx.has_means2D else None, g_sh, g_col, g_opac, g_scales, g_rots, g_cov, None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 _ACTIVATIONS = {None: 0, "none": 0, "sigmoid": 1}       # D3GA_OPACITY_SIGMOID
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, grad_sync=None, opacity_activation=None):
+                        raster_settings, grad_sync=None, opacity_activation=None, want_invdepth=True):
     """opacity_activation="sigmoid" (extension over upstream): `opacities` holds the raw logits and the sigmoid of
     models/cage_net.py:247 runs inside the per-Gaussian kernels, forward and backward."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, grad_sync, None, None, opacity_activation)
+                                     cov3Ds_precomp, raster_settings, grad_sync, None, None, opacity_activation, None, want_invdepth)
 
 
 def rasterize_gaussians_l1(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                           raster_settings, target, grad_sync=None, opacity_activation=None):
+                           raster_settings, target, grad_sync=None, opacity_activation=None, want_invdepth=True):
     """The render AND its L1 image loss (utils/loss_utils.py:29: mean |image - target|) from one operator (extension):
     returns (color, radii, invdepth, loss).  The gradient of `loss` is formed per pixel inside the compositing backward,
     so no (3,H,W) gradient image is written or read (one full-image kernel and 50 MB of traffic less per frame at 1080p);
     `color` stays differentiable as usual and both gradients add.  `target`: (3,H,W) tensor or a `graph.TensorSlot`."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, grad_sync, None, None, opacity_activation, target)
+                                     cov3Ds_precomp, raster_settings, grad_sync, None, None, opacity_activation, target, want_invdepth)
 
 
 def rasterize_gaussians_pair(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                             raster_settings, colors2, bg2, grad_sync=None, opacity_activation=None):
+                             raster_settings, colors2, bg2, grad_sync=None, opacity_activation=None, want_invdepth=True):
     """Two images from ONE pass: the usual one and `colors2` (P,3; constants, no gradient) blended with the same alphas over
     `bg2`.  Returns (color, radii, invdepth, color2).  Gradients of both images reach the geometry and the opacities."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, grad_sync, colors2, bg2, opacity_activation)
+                                     cov3Ds_precomp, raster_settings, grad_sync, colors2, bg2, opacity_activation, None, want_invdepth)
 
 
 class GaussianRasterizer(nn.Module):
@@ -501,6 +503,7 @@ class GaussianRasterizer(nn.Module):
         self.raster_settings = raster_settings
         self.grad_sync = grad_sync
         self.opacity_activation = opacity_activation      # "sigmoid": `opacities` are logits (fused D8 activation)
+        self.want_invdepth = True                         # False: [2] of the result is None (the forward skips the depth image)
 
     def markVisible(self, positions):
         """Boolean (P,) mask: view-space z > 0.2 (upstream _C.mark_visible)."""
@@ -524,7 +527,7 @@ class GaussianRasterizer(nn.Module):
         if self.raster_settings.antialiasing:
             raise NotImplementedError("antialiasing=True is not implemented (the D3GA renderer passes False, renderer.py:92)")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   self.raster_settings, self.grad_sync, self.opacity_activation)
+                                   self.raster_settings, self.grad_sync, self.opacity_activation, self.want_invdepth)
 
 
 def last_tile_lists(W, H, device=None):

@@ -117,14 +117,16 @@ def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_
 
     if _pair is not None:
         img, _radii, _invd, img2 = rasterize_gaussians_pair(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                                            cov3D_precomp, settings, _pair[0], _pair[1], grad_sync, act)
+                                                            cov3D_precomp, settings, _pair[0], _pair[1], grad_sync, act,
+                                                            want_invdepth=False)
         return {"render": paste(img, crop), "render2": paste(img2, crop)}
     if _l1 is not None:
         img, _radii, _invd, loss = rasterize_gaussians_l1(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                                          cov3D_precomp, settings, _l1, grad_sync, act)
+                                                          cov3D_precomp, settings, _l1, grad_sync, act, want_invdepth=False)
         return {"render": img, "l1": loss}
     rasterizer = GaussianRasterizer(raster_settings=settings)
     rasterizer.opacity_activation = act
+    rasterizer.want_invdepth = False                # only [0] of the rasterizer's outputs is used here (renderer.py:141)
     if grad_sync is not None:                       # extension over upstream's constructor: set only when asked for
         rasterizer.grad_sync = grad_sync
     if measure_time:

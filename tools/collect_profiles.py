@@ -17,16 +17,14 @@ for name in ("fetch", "write", "sq", "lds", "grbm"):
     for k, v in d.items():
         out.setdefault(k, {}).update({c: round(sum(x) / len(x), 1) for c, x in v.items()})
 if out:
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"pmc_{wl}.json"), "w"), indent=1)
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{wl}.json"), "w"), indent=1)
-for f in glob.glob(os.path.join(ROOT, "gpurun_out", "prof", "*kernel_stats.csv")):
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", "prof", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_bench_{wl}_kernel_stats.csv"))
 b = os.path.join(ROOT, "gpurun_out", "bench.log")
 if os.path.exists(b) and os.path.getsize(b) > 10:
     shutil.copy(b, os.path.join(ROOT, "profiles", f"{tag}_bench_{wl}.json"))
 pj = os.path.join(ROOT, "gpurun_out", f"pmc_{wl}.json")          # written by `bench.py --pmc` on the GPU box (tools/gpu_evidence.sh)
-if os.path.exists(pj):
-    shutil.copy(pj, os.path.join(ROOT, "profiles", f"pmc_{wl}.json"))
+if os.path.exists(pj):       # ONE tracked copy per round (bench.py reads the newest rNN_pmc_<wl>.json; it carries the library's sha256)
     shutil.copy(pj, os.path.join(ROOT, "profiles", f"{tag}_pmc_{wl}.json"))
 for name in ("C3_s2", "C3_s4", "C3_fill"):                       # sensitivity lines
     b = os.path.join(ROOT, "gpurun_out", f"bench_{name}.log")

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/pytest_gpu.log
 tail -1 gpurun_out/pytest_gpu.log
 timeout 1500 python bench.py --pmc --init-timing > gpurun_out/bench.log 2> gpurun_out/bench.err
-cp profiles/pmc_C3.json gpurun_out/pmc_C3.json 2>/dev/null
+cp profiles/pmc_C3.json gpurun_out/pmc_C3.json 2>/dev/null; rm -f profiles/pmc_C3.json
 cut -c1-400 gpurun_out/bench.log
 rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-train-step > "$GRAFT_REPO_ROOT/gpurun_out/bench_prof.log" 2> "$GRAFT_REPO_ROOT/gpurun_out/bench_prof.err" )
