@@ -123,13 +123,13 @@ class Frame:
             b = self.syn.make_batch(self.wl.width, self.wl.height, azimuth=2 * math.pi * v / self.n_views, camera_id=v, fill=self.fill)
             g = torch.Generator().manual_seed(100 + v)
             self.views.append((b, torch.rand(3, self.wl.height, self.wl.width, generator=g).to(self.dev)))
-        self.slot = CameraSlot(W, H, device=self.dev).set(self.batch)
+        self.slot = CameraSlot(W, H, device=self.dev, cells=1).set(self.batch)      # cell 0: the address of this step's target
         self.batch = dict(self.batch, camera_slot=self.slot)
         self.target = self.target.clone()              # static buffer: the training-step variants copy their target into it
         # the frame step reads its target through a TensorSlot: the n_views images are resident, a replay repoints the
         # loss kernels (8 bytes) instead of copying 25 MB into a static buffer
         from d3ga_amd.graph import TensorSlot
-        self.target_slot = TensorSlot(self.views[0][1])
+        self.target_slot = TensorSlot(self.views[0][1], arena=self.slot, index=0)      # travels with the camera's H2D copy
         return self.views
 
     def upstream(self):
@@ -644,9 +644,9 @@ def main():
     def set_view(i):
         if cycle:
             b, t = views[i % len(views)]
-            frame.slot.set(b)
             frame.target.copy_(t, non_blocking=True)
             frame.target_slot.set(t)
+            frame.slot.set(b)                         # one H2D copy: camera + the target's address
 
     def reduce_params():
         if not cut and world > 1:

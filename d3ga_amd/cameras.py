@@ -80,18 +80,29 @@ class CameraSlot:
     stream; put `batch["camera_slot"] = slot` into the batch handed to `render()`."""
 
     _RING = 16
+    _CAM_BYTES = 224                                          # 53 floats, padded to a multiple of 8 bytes for the cells behind
 
-    def __init__(self, width, height, device="cuda"):
+    def __init__(self, width, height, device="cuda", cells=0):
+        """cells: number of 8-byte ADDRESS CELLS kept behind the camera in the same device buffer (`cell(i)`): a
+        `graph.TensorSlot(first, arena=slot, index=i)` then lives there, and `set()` moves the camera AND the cells with the ONE
+        host-to-device copy it makes anyway (a step that repoints its target image needs one copy per replay instead of two)."""
         self.image_width, self.image_height = int(width), int(height)
         dev = torch.device(device)
-        self.matrices = torch.zeros(53, dtype=torch.float32, device=dev)
+        self.n_cells = int(cells)
+        nbytes = self._CAM_BYTES + 8 * self.n_cells
+        self.buffer = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self.matrices = self.buffer[:212].view(torch.float32)
+        self.cells = self.buffer[self._CAM_BYTES:].view(torch.int64) if self.n_cells else None
         # pinned staging ring: the host runs many steps ahead of the GPU, so a staging buffer may only be rewritten once the
         # asynchronous copy that reads it has executed (an event per slot of the ring)
-        self._ring = [torch.zeros(53, dtype=torch.float32) for _ in range(self._RING)]
+        self._ring = [torch.zeros(nbytes, dtype=torch.uint8) for _ in range(self._RING)]
         self._events = [None] * self._RING
         self._next = 0
         if dev.type == "cuda":
             self._ring = [t.pin_memory() for t in self._ring]
+        self._host_cam = torch.zeros(53, dtype=torch.float32)   # what the device holds / will hold: re-sent with every copy
+        self._host_cells = torch.zeros(max(self.n_cells, 1), dtype=torch.int64)
+        self._cells_dirty = False
         self.world_view_transform = self.matrices[0:16].view(4, 4)
         self.projection_matrix = self.matrices[16:32].view(4, 4)
         self.full_proj_transform = self.matrices[32:48].view(4, 4)
@@ -99,25 +110,44 @@ class CameraSlot:
         self.tanfovx = self.tanfovy = 0.0                      # marker: read them from the buffer
         self.znear, self.zfar = ZNEAR, ZFAR
 
-    def set(self, batch):
-        if int(batch["width"]) != self.image_width or int(batch["height"]) != self.image_height:
-            raise ValueError(f"CameraSlot is {self.image_width}x{self.image_height}; the batch is "
-                             f"{batch['width']}x{batch['height']} (one slot / captured step per raster size)")
-        host = Camera.pack_host(batch["R"], batch["T"], batch["FoVx"], batch["FoVy"])
+    def cell(self, i):
+        """(1,) int64 device view of address cell i (for graph.TensorSlot)."""
+        if not 0 <= i < self.n_cells:
+            raise IndexError(f"CameraSlot has {self.n_cells} address cells")
+        return self.cells[i:i + 1]
+
+    def stage_cell(self, i, address):
+        """Host side of a TensorSlot living in this slot: the address goes out with the next `set()` / `flush()`."""
+        self._host_cells[i] = int(address)
+        self._cells_dirty = True
+
+    def flush(self):
+        """One asynchronous H2D copy of camera + cells from a pinned staging buffer, on the current stream."""
         i = self._next
         self._next = (i + 1) % self._RING
         if self._events[i] is not None:
             self._events[i].synchronize()                      # the copy that last read this staging buffer has run
         stage = self._ring[i]
-        stage[:51] = torch.from_numpy(host)
-        stage[51] = math.tan(float(batch["FoVx"]) * 0.5)
-        stage[52] = math.tan(float(batch["FoVy"]) * 0.5)
-        self.matrices.copy_(stage, non_blocking=True)
-        if self.matrices.is_cuda:
+        stage[:212].view(torch.float32).copy_(self._host_cam)
+        if self.n_cells:
+            stage[self._CAM_BYTES:].view(torch.int64).copy_(self._host_cells[:self.n_cells])
+        self.buffer.copy_(stage, non_blocking=True)
+        self._cells_dirty = False
+        if self.buffer.is_cuda:
             ev = torch.cuda.Event()
             ev.record()
             self._events[i] = ev
         return self
+
+    def set(self, batch):
+        if int(batch["width"]) != self.image_width or int(batch["height"]) != self.image_height:
+            raise ValueError(f"CameraSlot is {self.image_width}x{self.image_height}; the batch is "
+                             f"{batch['width']}x{batch['height']} (one slot / captured step per raster size)")
+        host = Camera.pack_host(batch["R"], batch["T"], batch["FoVx"], batch["FoVy"])
+        self._host_cam[:51] = torch.from_numpy(host)
+        self._host_cam[51] = math.tan(float(batch["FoVx"]) * 0.5)
+        self._host_cam[52] = math.tan(float(batch["FoVy"]) * 0.5)
+        return self.flush()
 
 
 _cache = OrderedDict()

@@ -86,15 +86,24 @@ class TensorSlot:
 
     _RING = 16
 
-    def __init__(self, first):
+    def __init__(self, first, arena=None, index=0):
+        """arena / index: keep the cell inside a `cameras.CameraSlot(..., cells=n)` -- `set()` then only stages the address on the
+        host and the slot's next `set(batch)` / `flush()` carries it to the device together with the camera (one H2D copy per
+        replay instead of two; `CapturedStep.replay` orders the two calls)."""
         self.shape, self.device = tuple(first.shape), first.device
-        self.cell = torch.zeros(1, dtype=torch.int64, device=self.device)
-        self._stage = [torch.zeros(1, dtype=torch.int64) for _ in range(self._RING)]
-        if self.device.type == "cuda":
-            self._stage = [t.pin_memory() for t in self._stage]
+        self.arena, self.index = arena, int(index)
+        if arena is not None:
+            self.cell = arena.cell(self.index)
+        else:
+            self.cell = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self._stage = [torch.zeros(1, dtype=torch.int64) for _ in range(self._RING)]
+            if self.device.type == "cuda":
+                self._stage = [t.pin_memory() for t in self._stage]
         self._events, self._alive, self._next = [None] * self._RING, [None] * self._RING, 0
         self.current = None
         self.set(first)
+        if arena is not None:
+            arena.flush()
 
     def numel(self):
         n = 1
@@ -109,17 +118,41 @@ class TensorSlot:
             raise ValueError("TensorSlot: the tensor must be 16-byte aligned")
         i = self._next
         self._next = (i + 1) % self._RING
-        if self._events[i] is not None:
-            self._events[i].synchronize()              # the copy that last read this staging word has run
-        self._stage[i][0] = t.data_ptr()
-        self.cell.copy_(self._stage[i], non_blocking=True)
-        if self.cell.is_cuda:
-            ev = torch.cuda.Event()
-            ev.record()
-            self._events[i] = ev
-        self._alive[i] = t
+        if self.arena is not None:
+            self.arena.stage_cell(self.index, t.data_ptr())    # travels with the arena's next copy
+        else:
+            if self._events[i] is not None:
+                self._events[i].synchronize()              # the copy that last read this staging word has run
+            self._stage[i][0] = t.data_ptr()
+            self.cell.copy_(self._stage[i], non_blocking=True)
+            if self.cell.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+                self._events[i] = ev
+        self._alive[i] = t                                 # (the last _RING targets stay alive: replays in flight read them)
         self.current = t
         return self
+
+
+def _update_slots(step, camera, values):
+    """Per-replay inputs: tensors first (a TensorSlot that lives in a CameraSlot only stages its address), then the camera,
+    whose ONE host-to-device copy carries the staged cells along; arenas that were touched without a camera are flushed."""
+    if camera is not None and step.camera is None:
+        raise ValueError("this step was captured without a CameraSlot")
+    dirty = []
+    for name, v in values.items():
+        slot = step.slots[name]
+        if isinstance(slot, TensorSlot):
+            slot.set(v)                                    # repoint: 8 bytes instead of the tensor
+            if slot.arena is not None and slot.arena not in dirty:
+                dirty.append(slot.arena)
+        else:
+            slot.copy_(v if torch.is_tensor(v) else torch.as_tensor(v), non_blocking=True)
+    if camera is not None:
+        step.camera.set(camera)
+        dirty = [a for a in dirty if a is not step.camera]
+    for a in dirty:
+        a.flush()
 
 
 class CapturedStep:
@@ -156,16 +189,7 @@ class CapturedStep:
         """camera: a batch dict (R, T, FoVx, FoVy, width, height) written into the CameraSlot; values: name -> tensor / array
         copied into the slot of that name.  Everything is enqueued on the current stream; returns what step_fn returned at
         capture time (static tensors holding this replay's results once the stream reaches them)."""
-        if camera is not None:
-            if self.camera is None:
-                raise ValueError("this step was captured without a CameraSlot")
-            self.camera.set(camera)
-        for name, v in values.items():
-            slot = self.slots[name]
-            if isinstance(slot, TensorSlot):
-                slot.set(v)                                # repoint: 8 bytes instead of the tensor
-            else:
-                slot.copy_(v if torch.is_tensor(v) else torch.as_tensor(v), non_blocking=True)
+        _update_slots(self, camera, values)
         self.graph.replay()
         self._watch.after_replay()
         return self.result
@@ -266,16 +290,7 @@ class CapturedCutStep:
 
     def replay(self, camera=None, **values):
         """As CapturedStep.replay; the two collectives are issued on the current stream between the two graph launches."""
-        if camera is not None:
-            if self.camera is None:
-                raise ValueError("this step was captured without a CameraSlot")
-            self.camera.set(camera)
-        for name, v in values.items():
-            slot = self.slots[name]
-            if isinstance(slot, TensorSlot):
-                slot.set(v)
-            else:
-                slot.copy_(v if torch.is_tensor(v) else torch.as_tensor(v), non_blocking=True)
+        _update_slots(self, camera, values)
         self.graph_a.replay()
         self.sync.exchange_parked()
         self.graph_b.replay()

@@ -956,6 +956,27 @@ def test_l1_loss_reads_its_target_through_a_tensor_slot():
         assert torch.equal(a.grad, torch.sign(a.detach() - t) / a.numel())
     with pytest.raises(ValueError):
         slot.set(torch.rand(3, 37, 52, device=DEV))
+    # round 3: the cell can live inside a CameraSlot -- its address then travels with the camera's one H2D copy
+    from d3ga_amd import synthetic as syn
+    from d3ga_amd.cameras import CameraSlot
+    b0 = syn.make_batch(53, 37, azimuth=0.3)
+    cam = CameraSlot(b0["width"], b0["height"], device=DEV, cells=2)
+    cam.set(b0)
+    slot2 = TensorSlot(imgs[0], arena=cam, index=1)
+    ref_cam = cam.matrices.clone()
+
+    def step2():
+        loss = l1_loss(a, slot2)
+        loss.backward()
+        return loss
+    a.grad = None
+    cap2 = CapturedStep(step2, params=[a], slots={"target": slot2}, camera=cam)
+    for k, t in enumerate((imgs[1], imgs[2], imgs[0])):
+        loss = cap2.replay(camera=b0, target=t) if k != 1 else cap2.replay(target=t)     # with and without a camera update
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float((a.detach() - t).abs().mean())) < 1e-6
+        assert torch.equal(a.grad, torch.sign(a.detach() - t) / a.numel())
+        assert int(cam.cells[1]) == t.data_ptr() and int(cam.cells[0]) == 0 and torch.equal(cam.matrices, ref_cam)
 
 
 def test_losses_accept_misaligned_views():
