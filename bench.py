@@ -62,6 +62,9 @@ def parse():
                     help="sensitivity: multiply the Gaussians' world-space scales (D/P grows ~quadratically)")
     ap.add_argument("--fill", type=float, default=0.85,
                     help="sensitivity: fraction of the image height the 1.8 m body fills (0.85 = SURVEY sec. 8d recipe)")
+    ap.add_argument("--views-per-rank", type=int, default=1,
+                    help="N>1 (or --force-cut): every rank renders k views of the pose per step and the gradients of all of them leave "
+                         "in ONE exchange (the deform runs once per rank and step); value counts N x k frames per step")
     ap.add_argument("--fresh-scratch", action="store_true",
                     help="allocate and clear the backward's gradient accumulator per call instead of keeping a self-clearing one "
                          "(rasterizer.set_accumulator_policy)")
@@ -150,6 +153,12 @@ class Frame:
         from d3ga_amd.losses import l1_loss
         from d3ga_amd.renderer import render, render_l1
         # mean |img - target| (utils/loss_utils.py:29); with camera_cycle() the target is whatever the slot names
+        if getattr(self, "my_views", None):     # --views-per-rank k: k cameras of the pose, one package, the mean of their losses
+            tot = None
+            for b, t in self.my_views:
+                l = render_l1(b, pkg, self.bg, t, grad_sync=self.grad_sync)["l1"]
+                tot = l if tot is None else tot + l
+            return tot / len(self.my_views)
         target = getattr(self, "target_slot", None) or self.target
         if self.fused_l1:           # the same loss and gradients from ONE operator: dL/dimage is formed inside the compositing backward
             return render_l1(self.batch, pkg, self.bg, target, grad_sync=self.grad_sync)["l1"]
@@ -238,6 +247,22 @@ class Frame:
             loss = loss + scale_weight * torch.exp(2.0 * log_scales).mean()          # cage_net.py:226, train.py:203
         loss.backward()
         return loss
+
+
+class _CutShim:
+    """What CapturedCutStep's eager flow needs of `self` (used unbound for the k-views-per-rank eager step)."""
+    _ALIASES = {"opacity_logits": "opacities", "rgb": "colors_precomp"}
+
+    def __init__(self, sync):
+        self.sync = sync
+
+    def _to_the_cut(self, upstream, loss_fn):
+        from d3ga_amd.graph import CapturedCutStep
+        return CapturedCutStep._to_the_cut(self, upstream, loss_fn)
+
+    def _from_the_cut(self, up, pkg):
+        from d3ga_amd.graph import CapturedCutStep
+        return CapturedCutStep._from_the_cut(self, up, pkg)
 
 
 def collect_pmc(args):
@@ -623,6 +648,16 @@ def main():
         collect_pmc(args)
     frame = Frame(args.workload, dev, view_index=rank % 8, scale_mult=args.scale_mult, fill=args.fill)
     frame.fused_l1 = not args.no_fused_l1
+    kv = max(int(args.views_per_rank), 1)
+    if kv > 1:
+        if world == 1 and not args.force_cut:
+            raise SystemExit("--views-per-rank applies to the camera-sharded step (N > 1, or --force-cut on one GPU)")
+        nv = max(8, world * kv)
+        frame.my_views = []
+        for j in range(kv):
+            v = (rank * kv + j) % nv
+            b = frame.syn.make_batch(frame.wl.width, frame.wl.height, azimuth=2 * math.pi * v / nv, camera_id=v, fill=args.fill)
+            frame.my_views.append((b, torch.rand(3, frame.wl.height, frame.wl.width, generator=torch.Generator().manual_seed(100 + v)).to(dev)))
     if not args.fresh_scratch:
         R.set_accumulator_policy("persistent")         # one training stream: the accumulator cleans itself
     flat = ddist.GradReducer(list(frame.params.values()))
@@ -632,9 +667,25 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=0, world_size=1)
         cut, args.fixed_camera = True, True
+    cut_eager = [None]        # views-per-rank > 1: the eager step goes through the cut-step flow as well (ONE exchange per step)
     if cut:
         frame.grad_sync = ddist.ViewShardedGrads(timing=True)   # gradients leave the rasterizer already averaged over the ranks
         frame.grad_sync.always = args.force_cut
+        if kv > 1:
+            from d3ga_amd.graph import CapturedCutStep
+            eager_sync = ddist.ViewShardedGrads(timing=True)   # its own instance: the captured variant freezes the buffers of the other
+            eager_sync.always = args.force_cut
+
+            def _cut_eager():                                  # upstream once | k renders to the cut | one exchange | the rest
+                keep, frame.grad_sync = frame.grad_sync, eager_sync
+                eager_sync.deferred = True
+                try:
+                    CapturedCutStep._eager(_CutShim(eager_sync), frame.upstream, frame.loss_from)
+                finally:
+                    eager_sync.deferred = False
+                    frame.grad_sync = keep
+            cut_eager[0] = _cut_eager
+            cut_eager.append(eager_sync)
     # N = 1: the step follows the trainer -- a NEW camera and target every step (datasets/actorshq_dataset.py:229), written
     # into the static slots of ONE captured hipGraph (d3ga_amd/graph.py).  N > 1: every rank keeps its own view (camera
     # sharding: the views of one pose are spread over the ranks).
@@ -657,7 +708,10 @@ def main():
     def one_step():
         set_view(step_no[0]); step_no[0] += 1
         flat.zero()
-        frame.step()
+        if cut_eager[0] is not None:
+            cut_eager[0]()
+        else:
+            frame.step()
         reduce_params()
 
     def barrier():
@@ -726,7 +780,10 @@ def main():
         else:
             set_view(i)
             flat.zero()
-            frame.step()
+            if cut_eager[0] is not None:
+                cut_eager[0]()
+            else:
+                frame.step()
         reduce_params()
 
     # N > 1: the N = 1 step of THIS run, on every rank, before the group step is timed -- the same frame without the exchange,
@@ -899,10 +956,11 @@ def main():
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist_info = None
     if world == 1 and args.force_cut and cut:
-        frame.grad_sync.exchange_ms()
+        tsync = cut_eager[1] if len(cut_eager) > 1 else frame.grad_sync
+        tsync.exchange_ms()
         for _ in range(5):
             one_step()
-        ex_ms = frame.grad_sync.exchange_ms()
+        ex_ms = tsync.exchange_ms()
         step_ms_all = 1e3 * dt / args.steps
         dist_info = {"nranks_seen": 1, "n1_ms_per_step": None if n1_ms is None else round(n1_ms, 4),
                      "efficiency": None if n1_ms is None else round(n1_ms / step_ms_all, 4),
@@ -918,10 +976,11 @@ def main():
         torch.distributed.all_reduce(ones)
         ex_ms = None
         if cut:
-            frame.grad_sync.exchange_ms()                      # drop what the timed region recorded
+            tsync = cut_eager[1] if len(cut_eager) > 1 else frame.grad_sync
+            tsync.exchange_ms()                                # drop what the timed region recorded
             for _ in range(5):
                 one_step()
-            ex_ms = frame.grad_sync.exchange_ms()
+            ex_ms = tsync.exchange_ms()
         else:
             evs = []
             for _ in range(5):
@@ -1005,14 +1064,14 @@ def main():
                                       "source": "tools/micro/valu_issue.hip (profiles/r02_valu_issue_pmc.json) x tools/isa_mix.py"}
         out = {
             "metric": "fwd+bwd frames/sec @500k Gaussians 1920x1080" if args.workload == "C3" else f"fwd+bwd frames/sec ({wl.name})",
-            "value": round(world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": round(world * kv * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.name + ("" if (args.scale_mult == 1.0 and args.fill == 0.85) else
                                               f" [sensitivity: scales x{args.scale_mult:g}, body fills {args.fill:g} of the image height]"),
                        "gaussians": P, "width": W, "height": H, "sh_degree": wl.sh_degree,
                        "duplicates_D": D, "max_tile_list": cnt_end["max_tile"], "visible": cnt_end["visible"],
-                       "views_per_step": world, "parallelism": f"camera-sharded dp{world}",
+                       "views_per_step": world * kv, "views_per_rank": kv, "parallelism": f"camera-sharded dp{world}",
                        "grad_exchange": ("none" if world == 1 else "cut: all-reduce of the rasterizer-input gradients + "
                                          "all-gather of the factored SH gradient" if cut else "per-parameter all-reduce"),
                        "grad_exchange_bytes_per_rank": (0 if world == 1 else frame.grad_sync.bytes_last if cut

@@ -573,8 +573,10 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
             attr_set[dev] = true;
         }
     }
-    const int lgrid = tiles < 256 ? tiles : 256;
-    hipLaunchKernelGGL((tile_sort_lds_list_kernel<512, kSortMid>), dim3(lgrid), dim3(512), sort_lds_bytes(kSortMid, 512), s,
+    // (48 KB of LDS: three workgroups of the 2049..4096 class fit a CU -- at 4K with 2M Gaussians thousands of tiles are in it;
+    //  96 KB: one workgroup of the larger class per CU)
+    const int lgrid = tiles < 256 ? tiles : 256, mgrid = tiles < 768 ? tiles : 768;
+    hipLaunchKernelGGL((tile_sort_lds_list_kernel<512, kSortMid>), dim3(mgrid), dim3(512), sort_lds_bytes(kSortMid, 512), s,
                        bin.tile_start, bin.keys, bin.point_list, (uint64_t)d_capacity, bin.mid_tiles,
                        bin.counters + D3GA_CNT_MID, (uint64_t *)nullptr, (const uint32_t *)nullptr,
                        (const uint32_t *)nullptr);

@@ -234,18 +234,53 @@ class ViewShardedGrads:
         self.parked.append({"flat": flat, "factor": factor, "parts": parts, "sh": sh, "gathered": None})
 
     def exchange_parked(self):
-        """Deferred mode, eager, between the two graphs: the collectives of `exchange` on every parked entry.  While a graph
-        is being captured its first half has not run, so the collectives of that one call move unspecified (never read)
-        data -- an extra collective every rank issues alike."""
+        """Deferred mode, eager, between the two graphs: ONE all-reduce per distinct buffer layout -- the parked buffers of a
+        step's renders that share a layout (k views per rank, or the reference's two renders of one package when both use the
+        same colour path) are first added locally into the first of them -- plus one all-gather per SH render (every view has
+        its own directions).  While a graph is being captured its first half has not run, so the collectives of that one call
+        move unspecified (never read) data -- an extra exchange every rank issues alike."""
         if not self.parked:
             raise RuntimeError("ViewShardedGrads.exchange_parked: no rasterizer backward has parked its gradients")
+        ev = None
+        if self.timing and self.parked[0]["flat"].is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        heads = {}
         for e in self.parked:
-            want = None if e["factor"] is None else (self.world,) + tuple(e["factor"].shape)
-            if self.frozen and e["gathered"] is not None and tuple(e["gathered"].shape) != want:
-                raise RuntimeError(f"ViewShardedGrads: the gather buffer {tuple(e['gathered'].shape)} baked into the captured graph "
-                                   f"no longer fits {want} (the number of Gaussians or the world size changed): re-capture")
-            # the gather buffer is kept: a captured second half of the step reads it at a fixed address
-            e["gathered"] = self.exchange(e["flat"], e["factor"], out=e["gathered"])
+            key = (e["flat"].numel(), tuple(sorted((k, tuple(v.shape)) for k, v in e["parts"].items())))
+            head = heads.setdefault(key, e)
+            e["head"] = head
+            if head is not e:
+                head["flat"].add_(e["flat"])               # local sum: one collective for all renders of this layout
+        works, self.bytes_last = [], 0
+        for e in self.parked:
+            if e["head"] is e:
+                works.append(dist.all_reduce(e["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.bytes_last += e["flat"].numel() * 4
+            f = e["factor"]
+            if f is not None:
+                want = (self.world,) + tuple(f.shape)
+                if e["gathered"] is not None and tuple(e["gathered"].shape) != want:
+                    if self.frozen:
+                        raise RuntimeError(f"ViewShardedGrads: the gather buffer {tuple(e['gathered'].shape)} baked into the captured "
+                                           f"graph no longer fits {want} (the number of Gaussians or the world size changed): re-capture")
+                    e["gathered"] = None
+                if e["gathered"] is None:                  # kept afterwards: a captured second half reads it at a fixed address
+                    e["gathered"] = torch.empty(want, dtype=f.dtype, device=f.device)
+                try:
+                    works.append(dist.all_gather_into_tensor(e["gathered"], f, group=self.group, async_op=True))
+                except (RuntimeError, NotImplementedError):      # backends without the flat variant
+                    works.append(dist.all_gather(list(e["gathered"].unbind(0)), f, group=self.group, async_op=True))
+                self.bytes_last += f.numel() * 4
+        for w in works:
+            w.wait()
+        if self.scale != 1.0:
+            for e in self.parked:
+                if e["head"] is e:
+                    e["flat"].mul_(self.scale)
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
 
     def parked_gradients(self):
         """Deferred mode, after `exchange_parked` (capturable): rasterizer input name -> reduced gradient summed over the
@@ -254,7 +289,7 @@ class ViewShardedGrads:
         from ._lib import check, dptr, stream_handle
         out = {}
         for e in self.parked:
-            mine = dict(e["parts"])
+            mine = dict(e["parts"]) if e.get("head", e) is e else {}       # (a merged entry's parts are inside its head's sum)
             sh = e["sh"]
             if sh is not None:
                 P, M, deg, means3D = sh["P"], sh["M"], sh["sh_degree"], sh["means3D"]
