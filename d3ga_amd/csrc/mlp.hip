@@ -44,6 +44,8 @@ template <class F, int... Is>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <class F>
 __device__ __forceinline__ void static_for_16(F &&f) { static_for_impl(f, std::make_integer_sequence<int, 16>{}); }
+template <class F>
+__device__ __forceinline__ void static_for_4(F &&f) { static_for_impl(f, std::make_integer_sequence<int, 4>{}); }
 
 // two f32 -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32); element 0 in the low half
 __device__ __forceinline__ uint32_t bf16_pack(float a, float b) {
@@ -562,6 +564,365 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_ws_kernel(int P, int N, int 
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: ONE kernel per field network (forward) -- the activations never leave the registers.
+//
+// The per-layer kernel above writes every 128-wide activation to HBM and the next launch reads it back (512 MB per
+// hidden layer at 500k rows: the forward is HBM-bound).  Here a wavefront keeps ITS 32 rows through all the layers:
+//   * the product is taken TRANSPOSED, Y^T = W X^T: the first MFMA operand is a 32 x 16 tile of the weights (rows =
+//     output features), the second one the activations (columns = the wavefront's 32 batch rows).  The result tile then
+//     has the batch row on the lane (n = lane & 31) and 16 features in its registers, m = 32 t + 8 (r >> 2) + 4 (lane >> 5)
+//     + (r & 3) -- and that is, up to a fixed permutation of the features, exactly the layout the SECOND operand of the next
+//     layer wants (lane = batch row, 8 consecutive k per k-step and lane half).  The permutation is baked into the order
+//     in which the next layer's weights are packed (chain panel: k-slot j of lane half h in k-step s is input feature
+//     16 s + 8 (j >> 2) + 4 h + (j & 3)), so register r of output tile t simply IS slot 16 t + r of the next layer's input:
+//     no transpose, no LDS round trip, no HBM round trip between the layers;
+//   * same exact 3-way bf16 split and the same six products (smallest first) as the per-layer kernel: the activations are
+//     split in registers right before they are used, the weights once per weight version by d3ga_mlp_pack_chain;
+//   * shapes: every layer but the last is 128 wide (the reference's fields: n_nodes = 128, models/mlp.py:50-69), the
+//     first takes K0 <= 128 inputs, the last has NTL = ceil(N / 32) output tiles (a template parameter).  Everything
+//     else goes through the per-layer kernels (the host side decides);
+//   * a workgroup = 4 wavefronts (one per SIMD) = 128 rows per step; two workgroups per CU run out of phase and cover each
+//     other's epilogues and waits.  The weights stream through LDS in chunks of two k-steps (3 planes x 2 x NT KB <= 24 KB),
+//     two slots, loaded by LDS-DMA (global_load_lds_dwordx4: no registers) one chunk ahead of the MFMAs; one barrier per
+//     chunk;
+//   * what the backward needs is still written: every layer's output (the input of the next layer's weight gradient) and
+//     one sign bit per activation -- the same arrays, in the same layout, as the per-layer forward produces, so the
+//     existing backward (input-gradient GEMMs + wgrad) runs unchanged.  The output tile goes through a per-wavefront LDS
+//     tile so that the stores are 128-byte rows, not 32 scattered 16-byte pieces.  What disappears is every READ of an
+//     activation in the forward.
+struct ChainLayer {
+    const uint4 *panel;      // d3ga_mlp_pack_chain: [plane][k-step][tile][lane] units of 8 bf16, then 128 floats of bias
+    float *out;              // (P, N) layer output (after the activation)
+    uint32_t *sign;          // (P, ceil(N / 32)) sign words or null
+    int K, N;
+    float slope;             // leaky_relu slope behind this layer (1: none)
+};
+constexpr int kChainMaxLayers = 8;
+struct ChainArgs { ChainLayer layer[kChainMaxLayers]; int L; int abl; };
+#ifndef D3GA_CHAIN_WAVES
+#define D3GA_CHAIN_WAVES 8
+#endif
+constexpr int kChainWaves = D3GA_CHAIN_WAVES;
+constexpr int kChainThreads = 64 * kChainWaves;    // 4 wavefronts (one per SIMD), 32 rows each
+constexpr int kChainRows = 32 * kChainWaves;
+// k-steps of a chain panel: padded to an even number (a chunk is always two k-steps; the padding weights are zero)
+__host__ __device__ constexpr int chain_ksteps(int K) { return 2 * ((K + 31) / 32); }
+__host__ __device__ constexpr int chain_panel_units(int K, int N) { return 3 * chain_ksteps(K) * ((N + 31) / 32) * 64; }
+
+// chain panel of one layer: unit (plane, s, t, lane = 32 h + i) = the 8 bf16 pieces of weight(f_j, o), o = 32 t + i,
+// f_j = 16 s + 8 (j >> 2) + 4 h + (j & 3), weight(k, n) = W[k * ld_k + n * ld_n]; zero past K / N.
+// The panel ends in the layer's bias: 128 floats, zero past N (one 512-byte piece for the kernel's LDS copy).
+__global__ __launch_bounds__(kBlock) void pack_chain_kernel(int K, int N, const float *__restrict__ W, int64_t ld_k, int64_t ld_n,
+                                                            const float *__restrict__ bias, uint4 *__restrict__ panel) {
+    const int KS = chain_ksteps(K), NT = (N + 31) / 32;
+    const int u = blockIdx.x * kBlock + threadIdx.x;
+    if (u < 128) reinterpret_cast<float *>(panel + (size_t)3 * KS * NT * 64)[u] = (bias && u < N) ? bias[u] : 0.f;
+    if (u >= KS * NT * 64) return;
+    const int lane = u & 63, t = (u >> 6) % NT, sk = (u >> 6) / NT;
+    const int h = lane >> 5, o = 32 * t + (lane & 31);
+    uint32_t q[3][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int ja = 2 * jj, jb = ja + 1;
+        const int fa = 16 * sk + 8 * (ja >> 2) + 4 * h + (ja & 3), fb = 16 * sk + 8 * (jb >> 2) + 4 * h + (jb & 3);
+        const float wa = (fa < K && o < N) ? W[fa * ld_k + o * ld_n] : 0.f;
+        const float wb = (fb < K && o < N) ? W[fb * ld_k + o * ld_n] : 0.f;
+        bf16_split2(wa, wb, q[0][jj], q[1][jj], q[2][jj]);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) panel[(size_t)pl * (KS * NT * 64) + u] = make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
+}
+
+constexpr int kChainSlotUnits = 3 * 2 * 4 * 64;          // one chunk: [plane][2 k-steps][NT tiles][lane] units, <= 24 KB
+constexpr int kChainSlots = 2;                           // the current chunk and the next one
+constexpr int kChainStageLd = 36;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void global_void;
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef float f32x4_ev __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_ev __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) Float4U { float v[4]; };      // a 16-byte load that is only 4-byte aligned
+// 16 bytes of LDS behind the compiler's back: its wait-count pass puts s_waitcnt vmcnt(0) in front of LDS accesses it relates
+// to the LDS-DMA, i.e. every output tile's stores would complete before the next tile starts.  These buffers are ordered
+// against the DMA by the workgroup barrier (bias) or are private to the wavefront (the transposition tile).
+__device__ __forceinline__ float4 lds_read16_opaque(const float *p) {
+    f32x4_ev v;
+    const uint32_t a = (uint32_t)(uintptr_t)(lds_f32 *)p;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+// four of them, one wait
+__device__ __forceinline__ void lds_read16x4_opaque(const float *p0, const float *p1, const float *p2, const float *p3, float4 (&o)[4]) {
+    f32x4_ev v0, v1, v2, v3;
+    const uint32_t a0 = (uint32_t)(uintptr_t)(lds_f32 *)p0, a1 = (uint32_t)(uintptr_t)(lds_f32 *)p1,
+                   a2 = (uint32_t)(uintptr_t)(lds_f32 *)p2, a3 = (uint32_t)(uintptr_t)(lds_f32 *)p3;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+    o[0] = make_float4(v0[0], v0[1], v0[2], v0[3]);
+    o[1] = make_float4(v1[0], v1[1], v1[2], v1[3]);
+    o[2] = make_float4(v2[0], v2[1], v2[2], v2[3]);
+    o[3] = make_float4(v3[0], v3[1], v3[2], v3[3]);
+}
+__device__ __forceinline__ void lds_write16_opaque(float *p, float4 v) {
+    const uint32_t a = (uint32_t)(uintptr_t)(lds_f32 *)p;
+    const f32x4_ev w = {v.x, v.y, v.z, v.w};
+    asm volatile("ds_write_b128 %0, %1" : : "v"(a), "v"(w) : "memory");
+}
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from `src` (per lane) to LDS at `dst` (wave-uniform) + lane x 16.  Inline assembly
+// on purpose: the compiler's wait-count pass treats the builtin form conservatively (s_waitcnt vmcnt(0) between two DMAs and
+// in front of LDS accesses it cannot tell apart), which serialises exactly what this is for.  The kernel waits for the DMA
+// itself (chain_sync).  Extra outstanding operations the compiler does not know of only make its own vmcnt waits stricter.
+__device__ __forceinline__ void lds_dma16(const void *src, const void *dst, int lanes32 = 0) {
+    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const lds_f32 *)dst);
+    uint32_t m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "s"(la), "v"(src) : "memory");
+}
+// workgroup barrier that also waits for this wavefront's DMA (and everything else it has in flight)
+__device__ __forceinline__ void chain_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+// the two halves of it, for the end of a layer: the DMA wait goes BEFORE the epilogue, so that the barrier behind the
+// epilogue does not wait for the epilogue's stores
+__device__ __forceinline__ void chain_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void chain_barrier_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// LDS-DMA of chunk c (k-steps 2c, 2c + 1) of a layer's panel (KS k-steps, NT tiles) into a slot: 6 NT pieces of 1 KB, dealt
+// round robin to the 4 wavefronts; with c == 0 also the bias tail (512 bytes).  No registers involved.
+template <int NT>
+__device__ __forceinline__ void chain_issue(const uint4 *panel, int KS, int c, uint4 *slot, float *bias_dst, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < (6 * NT + kChainWaves - 1) / kChainWaves; ++i) {
+        const int q = wave + kChainWaves * i;              // (scalar)
+        if (q < 6 * NT) {
+            const int pl = q / (2 * NT), rem = q - pl * (2 * NT);
+            lds_dma16(panel + ((size_t)(pl * KS + 2 * c) * NT + rem) * 64 + lane, slot + q * 64);
+        }
+    }
+    if (c == 0 && wave == 0 && lane < 32) lds_dma16(panel + (size_t)3 * KS * NT * 64 + lane, bias_dst);
+}
+
+// The MFMAs of one chunk: k-steps S0, S0 + 1 of the layer against the activations in registers 8 S0 .. 8 S0 + 15.
+template <int NT, int S0>
+__device__ __forceinline__ void chain_chunk(const uint4 *slot, const float (&act)[64], f32x16 (&acc)[4], int lane) {
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        uint32_t b0[4], b1[4], b2[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) bf16_split2(act[8 * (S0 + sl) + 2 * jj], act[8 * (S0 + sl) + 2 * jj + 1], b0[jj], b1[jj], b2[jj]);
+        const bf16x8_t x0 = __builtin_bit_cast(bf16x8_t, make_uint4(b0[0], b0[1], b0[2], b0[3]));
+        const bf16x8_t x1 = __builtin_bit_cast(bf16x8_t, make_uint4(b1[0], b1[1], b1[2], b1[3]));
+        const bf16x8_t x2 = __builtin_bit_cast(bf16x8_t, make_uint4(b2[0], b2[1], b2[2], b2[3]));
+        constexpr int pstride = 2 * NT * 64;               // units per plane in the slot
+        if constexpr (NT == 1) {
+            const uint4 *wa = slot + sl * 64 + lane;
+            const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, wa[0]), a1 = __builtin_bit_cast(bf16x8_t, wa[pstride]),
+                           a2 = __builtin_bit_cast(bf16x8_t, wa[2 * pstride]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x2, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x1, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, x0, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x1, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x0, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x0, acc[0], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int tp = 0; tp < NT; tp += 2) {           // two tiles at a time: their accumulators are independent
+                const uint4 *wa = slot + (sl * NT + tp) * 64 + lane, *wb = wa + 64;
+                const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, wa[0]), a1 = __builtin_bit_cast(bf16x8_t, wa[pstride]),
+                               a2 = __builtin_bit_cast(bf16x8_t, wa[2 * pstride]);
+                const bf16x8_t c0 = __builtin_bit_cast(bf16x8_t, wb[0]), c1 = __builtin_bit_cast(bf16x8_t, wb[pstride]),
+                               c2 = __builtin_bit_cast(bf16x8_t, wb[2 * pstride]);
+                // smallest products first (weights = first operand: output features on the rows)
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x2, acc[tp], 0, 0, 0);
+                acc[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, x2, acc[tp + 1], 0, 0, 0);
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x1, acc[tp], 0, 0, 0);
+                acc[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x1, acc[tp + 1], 0, 0, 0);
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, x0, acc[tp], 0, 0, 0);
+                acc[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, x0, acc[tp + 1], 0, 0, 0);
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x1, acc[tp], 0, 0, 0);
+                acc[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, x1, acc[tp + 1], 0, 0, 0);
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x0, acc[tp], 0, 0, 0);
+                acc[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x0, acc[tp + 1], 0, 0, 0);
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x0, acc[tp], 0, 0, 0);
+                acc[tp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, x0, acc[tp + 1], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// Layer epilogue: bias, activation, sign bits; register r of tile t = feature 32 t + 8 (r >> 2) + 4 h + (r & 3) of row n.
+// KEEP: the outputs become the next layer's input registers.
+template <int NT, bool KEEP>
+__device__ __forceinline__ void chain_epilogue(const ChainLayer &Ly, const float *bias_l, float *s_stage, int P, int row0, int lane,
+                                               const f32x16 (&acc)[4], float (&act)[64], int abl) {
+    const int h = lane >> 5, n = lane & 31;
+    const float slope = Ly.slope;
+    const int N = Ly.N;
+    const bool vec = (N & 3) == 0;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(Ly.out, 0, (int)((uint32_t)P * (uint32_t)N * 4u), 0x00020000);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        uint32_t word = 0u;
+        float4 bqs[4];
+        lds_read16x4_opaque(bias_l + 32 * t + 4 * h, bias_l + 32 * t + 8 + 4 * h, bias_l + 32 * t + 16 + 4 * h, bias_l + 32 * t + 24 + 4 * h, bqs);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bq = bqs[q];
+            float y[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = acc[t][4 * q + c] + (c == 0 ? bq.x : (c == 1 ? bq.y : (c == 2 ? bq.z : bq.w)));
+                const bool pos = v > 0.f;
+                word |= pos ? (1u << (8 * q + 4 * h + c)) : 0u;
+                v = pos ? v : slope * v;
+                y[c] = v;
+                if constexpr (KEEP) act[16 * t + 4 * q + c] = v;       // = slot 16 t + r of the next layer's second operand
+            }
+            // rows are on the lanes here: a direct store would touch 32 lines per instruction.  Through the wavefront's LDS
+            // tile instead ([row][feature]), read back with the features on the lanes
+            lds_write16_opaque(s_stage + n * kChainStageLd + 8 * q + 4 * h, make_float4(y[0], y[1], y[2], y[3]));
+        }
+        float4 yvs[4];
+        {
+            const float *sp = s_stage + (lane >> 3) * kChainStageLd + 4 * (lane & 7);
+            lds_read16x4_opaque(sp, sp + 8 * kChainStageLd, sp + 16 * kChainStageLd, sp + 24 * kChainStageLd, yvs);
+        }
+        if (vec) {                                           // (uniform) bounds-checked buffer stores: rows past P fall out in hardware
+            const uint32_t voff = (((uint32_t)(row0 + (lane >> 3)) * (uint32_t)N) + 32 * t + 4 * (lane & 7)) * 4u;
+            if (!(abl & 1)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)             // 8 rows per instruction, 128 contiguous bytes each
+                    if (32 * t + 4 * (lane & 7) < N)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_ev, yvs[i]), rsrc, voff + (uint32_t)(8 * i * N * 4), 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = 8 * i + (lane >> 3), m0 = 32 * t + 4 * (lane & 7);
+                const float4 yv = yvs[i];
+                if (row0 + rr < P && !(abl & 1)) {
+                    float *dst = Ly.out + (size_t)(row0 + rr) * N + m0;
+                    if (m0 < N) dst[0] = yv.x;
+                    if (m0 + 1 < N) dst[1] = yv.y;
+                    if (m0 + 2 < N) dst[2] = yv.z;
+                    if (m0 + 3 < N) dst[3] = yv.w;
+                }
+            }
+        }
+        if (Ly.sign) {                                       // (uniform) the two lane halves hold complementary bits of the word
+            word |= (uint32_t)__shfl_xor((int)word, 32);
+            if (h == 0 && row0 + n < P && !(abl & 16)) Ly.sign[(size_t)(row0 + n) * NT + t] = word;
+        }
+    }
+}
+
+template <int NTL>
+__global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int K0, const float *__restrict__ X, ChainArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem_chain[];
+    uint4 *const s_slot0 = reinterpret_cast<uint4 *>(smem_chain);
+    float *s_bias = reinterpret_cast<float *>(smem_chain + (size_t)kChainSlots * kChainSlotUnits * 16);       // [layer parity][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, n = lane & 31;
+    const int nblocks = (P + kChainRows - 1) / kChainRows;
+    float *s_stage = s_bias + 256 + wave * (32 * kChainStageLd);      // the wavefront's transposition tile: 32 rows x (32 + 4) floats
+    const int L = args.L, abl = args.abl;
+    const int KS0 = chain_ksteps(K0), nch0 = KS0 / 2;
+    auto slot = [&](int g) { return s_slot0 + (size_t)g * kChainSlotUnits; };
+    // chunk (l, c): layers 0 .. L - 2 have 4 output tiles, the last one NTL; layer 0 has nch0 chunks, the others 4
+    auto issue = [&](int l, int c, int g) {
+        if (abl & 2) return;
+        const uint4 *panel = args.layer[l].panel;
+        const int KS = l == 0 ? KS0 : 8;
+        if (l == L - 1) chain_issue<NTL>(panel, KS, c, slot(g), s_bias + (l & 1) * 128, wave, lane);
+        else chain_issue<4>(panel, KS, c, slot(g), s_bias + (l & 1) * 128, wave, lane);
+    };
+    if ((int)blockIdx.x < nblocks) issue(0, 0, 0);
+    chain_sync();                                          // chunk 0 is in place
+    int g = 0;
+    for (int rb = (int)blockIdx.x; rb < nblocks; rb += (int)gridDim.x) {
+        const int row0 = rb * kChainRows + wave * 32;
+        const uint32_t rowc = (uint32_t)(row0 + n < P ? row0 + n : P - 1);
+        float act[64];
+        {   // the wavefront's 32 input rows, straight into the second-operand order of layer 0.  Branch-free (every load in
+            // flight before the first wait): a group of 4 features that runs past the row is read from the row's last 16
+            // bytes instead (K0 >= 4) and shifted into place
+            const float *xr = X + (size_t)rowc * (uint32_t)K0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                Float4U raw[8];
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    const int f0 = 8 * (8 * half + v) + 4 * h;
+                    raw[v] = *reinterpret_cast<const Float4U *>(xr + min(f0, K0 - 4));
+                }
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    const int u = 8 * half + v, f0 = 8 * u + 4 * h, sh = f0 - min(f0, K0 - 4);       // 0 inside the row
+                    const float r0 = raw[v].v[0], r1 = raw[v].v[1], r2 = raw[v].v[2], r3 = raw[v].v[3];
+                    act[4 * u + 0] = sh == 0 ? r0 : (sh == 1 ? r1 : (sh == 2 ? r2 : (sh == 3 ? r3 : 0.f)));
+                    act[4 * u + 1] = sh == 0 ? r1 : (sh == 1 ? r2 : (sh == 2 ? r3 : 0.f));
+                    act[4 * u + 2] = sh == 0 ? r2 : (sh == 1 ? r3 : 0.f);
+                    act[4 * u + 3] = sh == 0 ? r3 : 0.f;
+                }
+            }
+        }
+        const bool more_blocks = rb + (int)gridDim.x < nblocks;
+        f32x16 acc[4];
+        // ---- layers 0 .. L - 2: 128 outputs
+        for (int l = 0; l + 1 < L; ++l) {
+            const int nch = l == 0 ? nch0 : 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            static_for_4([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if (c < nch) {                              // (uniform)
+                    // the next chunk goes into the other slot: every wavefront finished reading it before the barrier that
+                    // ended the previous chunk
+                    if (c + 1 < nch) issue(l, c + 1, g ^ 1);
+                    else issue(l + 1, 0, g ^ 1);
+                    if (!(abl & 4)) chain_chunk<4, 2 * c>(slot(g), act, acc, lane);
+                    if (c + 1 < nch) {
+                        chain_sync();      // this slot is free again, and the next chunk's DMA has landed
+                        g ^= 1;
+                    }
+                }
+            });
+            chain_wait_dma();         // the next layer's first chunk (and bias): this wavefront's pieces have landed
+            chain_epilogue<4, true>(args.layer[l], s_bias + (l & 1) * 128, s_stage, P, row0, lane, acc, act, abl);
+            chain_barrier_only();     // ... everybody's have, and the layer's last slot is free; the stores stay in flight
+            g ^= 1;
+        }
+        // ---- the last layer: NTL output tiles, 128 inputs
+        {
+            const int l = L - 1;
+#pragma unroll
+            for (int t = 0; t < NTL; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            static_for_4([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if (c + 1 < 4) issue(l, c + 1, g ^ 1);
+                else if (more_blocks) issue(0, 0, g ^ 1);
+                if (!(abl & 4)) chain_chunk<NTL, 2 * c>(slot(g), act, acc, lane);
+                if (c + 1 < 4) {
+                    chain_sync();
+                    g ^= 1;
+                }
+            });
+            chain_wait_dma();
+            chain_epilogue<NTL, false>(args.layer[l], s_bias + (l & 1) * 128, s_stage, P, row0, lane, acc, act, abl);
+            chain_barrier_only();
+            g ^= 1;
+        }
+    }
+}
+
 }  // namespace d3ga
 
 using namespace d3ga;
@@ -717,4 +1078,68 @@ extern "C" int d3ga_mlp_wgrad(int32_t P, int32_t N, int32_t K, const float *dpre
 extern "C" int d3ga_mlp_wgrad_acc(int32_t P, int32_t N, int32_t K, const float *dpre, const float *X, float *dW, float *db,
                                   d3ga_stream_t stream) {
     return mlp_wgrad_launch(P, N, K, dpre, X, dW, db, false, stream);
+}
+
+
+extern "C" int64_t d3ga_mlp_chain_panel_bytes(int32_t K, int32_t n_out) {
+    if (K < 1 || K > 128 || n_out < 1 || n_out > 128) return D3GA_E_SIZE;
+    return (int64_t)d3ga::chain_panel_units(K, n_out) * 16 + 512;
+}
+
+extern "C" int d3ga_mlp_pack_chain(int32_t K, int32_t n_out, const float *W, int64_t ld_k, int64_t ld_n, const float *bias,
+                                   void *panel, d3ga_stream_t stream) {
+    if (K < 1 || K > 128 || n_out < 1 || n_out > 128) return D3GA_E_SIZE;
+    if (!W || !panel) return D3GA_E_NULL;
+    if ((uintptr_t)panel & 15) return D3GA_E_CONFIG;
+    hipStream_t s = (hipStream_t)stream;
+    const int units = d3ga::chain_panel_units(K, n_out) / 3;          // (>= 64 >= ... the first workgroup also writes the 128 bias floats)
+    static_assert(d3ga::kBlock >= 128, "the bias tail is written by the first workgroup");
+    hipLaunchKernelGGL(d3ga::pack_chain_kernel, dim3((units + d3ga::kBlock - 1) / d3ga::kBlock), dim3(d3ga::kBlock), 0, s, K, n_out, W,
+                       ld_k, ld_n, bias, reinterpret_cast<uint4 *>(panel));
+    return d3ga::check_launch(s, 0);
+}
+
+extern "C" int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t L, const int32_t *Ks, const int32_t *Ns,
+                                  const void *const *panels, const float *slopes, float *const *outs, uint32_t *const *signs,
+                                  d3ga_stream_t stream) {
+    using namespace d3ga;
+    if (P < 0 || L < 1 || L > kChainMaxLayers || K0 < 1 || K0 > 128) return D3GA_E_SIZE;
+    if (P == 0) return D3GA_OK;
+    if (!X || !Ks || !Ns || !panels || !slopes || !outs || !signs) return D3GA_E_NULL;
+    ChainArgs a;
+    a.L = L;
+    int k_prev = K0;
+    for (int l = 0; l < L; ++l) {
+        if (Ks[l] != k_prev || Ns[l] < 1 || Ns[l] > 128) return D3GA_E_SIZE;      // layer l consumes what layer l - 1 produced
+        if (!panels[l] || !outs[l]) return D3GA_E_NULL;
+        if (((uintptr_t)panels[l] | (uintptr_t)outs[l]) & 15) return D3GA_E_CONFIG;
+        if ((int64_t)P * Ns[l] >= (1ll << 30) || (int64_t)P * Ks[l] >= (1ll << 30)) return D3GA_E_SIZE;     // (byte offsets in 32 bits)
+        a.layer[l] = ChainLayer{reinterpret_cast<const uint4 *>(panels[l]), outs[l], signs[l], Ks[l], Ns[l], slopes[l]};
+        k_prev = Ns[l];
+    }
+    // shapes the kernel is built for (everything else: the per-layer kernels): >= 2 layers, all but the last 128 wide
+    if (L < 2 || K0 < 4) return D3GA_E_CONFIG;
+    for (int l = 0; l + 1 < L; ++l) if (Ns[l] != 128) return D3GA_E_CONFIG;
+    const int ntl = (Ns[L - 1] + 31) / 32;
+    if (ntl == 3) return D3GA_E_CONFIG;
+    static const int abl = getenv("D3GA_CHAIN_ABL") ? atoi(getenv("D3GA_CHAIN_ABL")) : 0;      // timing ablations (wrong results)
+    a.abl = abl;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)kChainSlots * kChainSlotUnits * 16 + (2 * 128 + (kChainThreads / 64) * 32 * kChainStageLd) * sizeof(float);
+    static bool attr[64] = {};
+    int dev = 0;
+    D3GA_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr[dev]) {
+        D3GA_HIP(hipFuncSetAttribute((const void *)chain_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        D3GA_HIP(hipFuncSetAttribute((const void *)chain_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        D3GA_HIP(hipFuncSetAttribute((const void *)chain_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr[dev] = true;
+    }
+    const int nblocks = (P + kChainRows - 1) / kChainRows;
+    static const int grid_cap = getenv("D3GA_CHAIN_GRID") ? atoi(getenv("D3GA_CHAIN_GRID")) : 2048 / kChainWaves;
+    const dim3 grid(nblocks < grid_cap ? nblocks : grid_cap), block(kChainThreads);
+    if (ntl == 1) hipLaunchKernelGGL(chain_fwd_kernel<1>, grid, block, lds, s, P, K0, X, a);
+    else if (ntl == 2) hipLaunchKernelGGL(chain_fwd_kernel<2>, grid, block, lds, s, P, K0, X, a);
+    else hipLaunchKernelGGL(chain_fwd_kernel<4>, grid, block, lds, s, P, K0, X, a);
+    return check_launch(s, 0);
 }

@@ -54,6 +54,54 @@ def _panel(weight, transpose):
     return hit[0]
 
 
+_chain_panels = {}
+_FUSED = {"enabled": __import__("os").environ.get("D3GA_MLP_FUSED", "1") != "0"}
+
+
+def set_fused_forward(enabled):
+    """A/B switch: one launch per trunk (d3ga_mlp_chain_fwd, the default) or one per layer (d3ga_mlp_linear)."""
+    _FUSED["enabled"] = bool(enabled)
+
+
+def _chain_panel(weight, bias):
+    """The layer's weights (and bias) in the operand order of the fused trunk kernel (d3ga_mlp_pack_chain: the k order carries
+    the feature permutation that lets a layer's output registers be the next layer's operand as they are).  Cached like `_panel`."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()),
+           None if bias is None else (bias.data_ptr(), bias._version))
+    hit = _chain_panels.get(key)
+    if hit is None:
+        if len(_chain_panels) > 64:
+            _chain_panels.clear()
+        w = weight.detach()
+        if w.dtype != torch.float32:
+            w = w.float()
+        N, K = w.shape
+        s_n, s_k = w.stride()
+        nbytes = _lib.lib().d3ga_mlp_chain_panel_bytes(K, N)
+        p = torch.empty(nbytes // 4, dtype=torch.int32, device=w.device)
+        b = None if bias is None else bias.detach().float().contiguous()
+        check(_lib.lib().d3ga_mlp_pack_chain(K, N, dptr(w), s_k, s_n, dptr(b), dptr(p), stream_handle()), "d3ga_mlp_pack_chain")
+        hit = (p, weight.detach(), w, None if bias is None else bias.detach())     # (detached aliases keep the storage alive: see _panel)
+        _chain_panels[key] = hit
+    return hit[0]
+
+
+def _chain_forward(h, weights, biases, slopes, track):
+    """All layers in ONE launch: -> (outputs of every layer, sign words of every layer or None)."""
+    L, P, dev = len(weights), h.shape[0], h.device
+    Ks = (ctypes.c_int32 * L)(*[w.shape[1] for w in weights])
+    Ns = (ctypes.c_int32 * L)(*[w.shape[0] for w in weights])
+    panels = [_chain_panel(w, b) for w, b in zip(weights, biases)]
+    outs = [torch.empty((P, w.shape[0]), dtype=torch.float32, device=dev) for w in weights]
+    signs = [torch.empty((P, (w.shape[0] + 31) // 32), dtype=torch.int32, device=dev) if (track and sl != 1.0) else None
+             for w, sl in zip(weights, slopes)]
+    vp = ctypes.c_void_p
+    arr = lambda ts: (vp * L)(*[dptr(t) for t in ts])
+    check(_lib.lib().d3ga_mlp_chain_fwd(P, h.shape[1], dptr(h), L, Ks, Ns, arr(panels), (ctypes.c_float * L)(*[float(v) for v in slopes]),
+                                        arr(outs), arr(signs), stream_handle()), "d3ga_mlp_chain_fwd")
+    return outs, signs
+
+
 def _linear(x, panel, bias, slope, n_out, want_sign=False, mask_bits=None, mask_slope=1.0):
     P, K = x.shape
     y = torch.empty((P, n_out), dtype=torch.float32, device=x.device)
@@ -76,7 +124,17 @@ class _Chain(torch.autograd.Function):
         h = f32c16(x)
         acts, signs = [h], []
         track = any(ctx.needs_input_grad)                      # (grad mode is off inside forward: ask the node instead)
-        for w, b, slope in zip(weights, biases, slopes):
+        fused = (_FUSED["enabled"] and 2 <= len(weights) <= 8 and 0 < h.shape[0] < (1 << 23) and 4 <= h.shape[1] <= 128
+                 and all(w.shape[0] == 128 for w in weights[:-1]) and (weights[-1].shape[0] + 31) // 32 in (1, 2, 4)
+                 and all(weights[i].shape[1] == (h.shape[1] if i == 0 else weights[i - 1].shape[0]) for i in range(len(weights))))
+        if fused:                                              # the whole trunk in one launch: activations stay in registers
+            outs, signs = _chain_forward(h, weights, biases, slopes, track)
+            acts += outs
+            h = outs[-1]
+            weights_loop = ()
+        else:
+            weights_loop = zip(weights, biases, slopes)
+        for w, b, slope in weights_loop:
             N, K = w.shape
             if h.shape[1] != K or K > 128 or N > 128:
                 raise ValueError(f"linear_act: x (P,{h.shape[1]}) weight {tuple(w.shape)}: need matching K <= 128 and N <= 128")
