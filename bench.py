@@ -592,7 +592,11 @@ def field_mlp_bench(args):
     flops = 3 * 2.0 * P * (11 * 128 + 3 * 128 * 128 + 128 * 11)         # forward + input-gradient + weight-gradient GEMMs
     # algorithmic bytes per row (f32 = 4 B): every GEMM reads its row operand(s) and writes its result once; sign bits 16 B
     widths = [11, 128, 128, 128, 128, 11]                                # 109 -> 128 x4 -> 11 with the 98 pose columns folded
-    fwd_b = sum(4 * (a + b) for a, b in zip(widths[:-1], widths[1:])) + 16 * 4
+    from d3ga_amd import mlp as _mlp
+    fused_fwd = bool(_mlp._FUSED["enabled"])
+    # fused forward (one launch per trunk): the input is read once, every layer's output is written once, nothing is read back
+    fwd_b = (4 * widths[0] + sum(4 * b for b in widths[1:]) + 16 * 4) if fused_fwd \
+        else sum(4 * (a + b) for a, b in zip(widths[:-1], widths[1:])) + 16 * 4
     dx_b = sum(4 * (a + b) for a, b in zip(widths[:-1], widths[1:])) + 16 * 4
     wg_b = sum(4 * (a + b) for a, b in zip(widths[:-1], widths[1:]))
     hbm_bytes = float(P) * (fwd_b + dx_b + wg_b)
@@ -601,7 +605,7 @@ def field_mlp_bench(args):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"CanonicalField over the Gaussians of {args.workload}", "rows": P},
            # the split-bf16 products (6 per f32 product, 16x the f32 MFMA rate) leave the layers HBM-bound
-           "roofline": {"kernel": "linear_kernel + wgrad_kernel", "bound": "hbm", "achieved": round(hbm_bytes / (ms * 1e-3) / 1e9, 1),
+           "roofline": {"kernel": ("chain_fwd_kernel + " if fused_fwd else "") + "linear_kernel + wgrad_kernel", "fused_forward": fused_fwd, "bound": "hbm", "achieved": round(hbm_bytes / (ms * 1e-3) / 1e9, 1),
                         "peak": 8000.0, "unit": "GB/s", "frac": round(hbm_bytes / (ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
                         "f32_equivalent_tflops": round(flops / (ms * 1e-3) / 1e12, 2), "f32_mfma_peak_tflops": 157.3,
                         "arithmetic": "exact 3-way bf16 split of every f32 operand, 6 products on v_mfma_f32_32x32x16_bf16, "

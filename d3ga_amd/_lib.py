@@ -75,8 +75,8 @@ _SIGNATURES = {
     "d3ga_mlp_pack_weights": ([ctypes.c_int32, ctypes.c_int32, _vp, _i64, _i64, _vp, _vp], _i),
     "d3ga_mlp_linear": ([ctypes.c_int32] * 3 + [_vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp, _vp], _i),
     "d3ga_mlp_chain_panel_bytes": ([ctypes.c_int32, ctypes.c_int32], _i64),
-    "d3ga_mlp_pack_chain": ([ctypes.c_int32, ctypes.c_int32, _vp, _i64, _i64, _vp, _vp, _vp], _i),
-    "d3ga_mlp_chain_fwd": ([ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32] + [_vp] * 6 + [_vp], _i),
+    "d3ga_mlp_pack_chain": ([ctypes.c_int32, ctypes.c_int32, _vp, _i64, _i64, _vp, _vp], _i),
+    "d3ga_mlp_chain_fwd": ([ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32] + [_vp] * 9 + [_vp], _i),
     "d3ga_mlp_wgrad": ([ctypes.c_int32] * 3 + [_vp] * 4 + [_vp], _i),
     "d3ga_mlp_wgrad_acc": ([ctypes.c_int32] * 3 + [_vp] * 4 + [_vp], _i),
     "d3ga_field_heads_fwd": ([ctypes.c_int32] * 3 + [_vp, _vp, _vp, _vp, _vp, _vp], _i),

@@ -596,8 +596,11 @@ struct ChainLayer {
     const uint4 *panel;      // d3ga_mlp_pack_chain: [plane][k-step][tile][lane] units of 8 bf16, then 128 floats of bias
     float *out;              // (P, N) layer output (after the activation)
     uint32_t *sign;          // (P, ceil(N / 32)) sign words or null
+    const uint32_t *mask;    // (P, ceil(N / 32)) sign words of ANOTHER chain or null: out (.)= bit ? 1 : mask_slope  (the
+                             // backward's input-gradient chain: this layer's output is the pre-activation gradient below it)
     int K, N;
     float slope;             // leaky_relu slope behind this layer (1: none)
+    float mask_slope;
 };
 constexpr int kChainMaxLayers = 8;
 struct ChainArgs { ChainLayer layer[kChainMaxLayers]; int L; int abl; };
@@ -613,12 +616,13 @@ __host__ __device__ constexpr int chain_panel_units(int K, int N) { return 3 * c
 
 // chain panel of one layer: unit (plane, s, t, lane = 32 h + i) = the 8 bf16 pieces of weight(f_j, o), o = 32 t + i,
 // f_j = 16 s + 8 (j >> 2) + 4 h + (j & 3), weight(k, n) = W[k * ld_k + n * ld_n]; zero past K / N.
-// The panel ends in the layer's bias: 128 floats, zero past N (one 512-byte piece for the kernel's LDS copy).
+// The panel ends in room for the layer's bias: 128 floats, zero past N (one 512-byte piece for the kernel's LDS copy), written
+// by every d3ga_mlp_chain_fwd call (chain_bias_kernel): a bias is an activation-like input (the fields fold the pose into it),
+// not part of the weight version the panel is cached under.
 __global__ __launch_bounds__(kBlock) void pack_chain_kernel(int K, int N, const float *__restrict__ W, int64_t ld_k, int64_t ld_n,
-                                                            const float *__restrict__ bias, uint4 *__restrict__ panel) {
+                                                            uint4 *__restrict__ panel) {
     const int KS = chain_ksteps(K), NT = (N + 31) / 32;
     const int u = blockIdx.x * kBlock + threadIdx.x;
-    if (u < 128) reinterpret_cast<float *>(panel + (size_t)3 * KS * NT * 64)[u] = (bias && u < N) ? bias[u] : 0.f;
     if (u >= KS * NT * 64) return;
     const int lane = u & 63, t = (u >> 6) % NT, sk = (u >> 6) / NT;
     const int h = lane >> 5, o = 32 * t + (lane & 31);
@@ -633,6 +637,12 @@ __global__ __launch_bounds__(kBlock) void pack_chain_kernel(int K, int N, const 
     }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) panel[(size_t)pl * (KS * NT * 64) + u] = make_uint4(q[pl][0], q[pl][1], q[pl][2], q[pl][3]);
+}
+
+struct ChainBiasArgs { const float *bias[kChainMaxLayers]; float *tail[kChainMaxLayers]; int N[kChainMaxLayers]; };
+__global__ __launch_bounds__(128) void chain_bias_kernel(ChainBiasArgs a) {
+    const int l = blockIdx.x, u = threadIdx.x;
+    a.tail[l][u] = (a.bias[l] && u < a.N[l]) ? a.bias[l][u] : 0.f;
 }
 
 constexpr int kChainSlotUnits = 3 * 2 * 4 * 64;          // one chunk: [plane][2 k-steps][NT tiles][lane] units, <= 24 KB
@@ -758,9 +768,10 @@ __device__ __forceinline__ void chain_chunk(const uint4 *slot, const float (&act
 // KEEP: the outputs become the next layer's input registers.
 template <int NT, bool KEEP>
 __device__ __forceinline__ void chain_epilogue(const ChainLayer &Ly, const float *bias_l, float *s_stage, int P, int row0, int lane,
-                                               const f32x16 (&acc)[4], float (&act)[64], int abl) {
+                                               const f32x16 (&acc)[4], float (&act)[64], const uint32_t (&mw)[4], int abl) {
     const int h = lane >> 5, n = lane & 31;
-    const float slope = Ly.slope;
+    const float slope = Ly.slope, mslope = Ly.mask_slope;
+    const bool masked = Ly.mask != nullptr;
     const int N = Ly.N;
     const bool vec = (N & 3) == 0;
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(Ly.out, 0, (int)((uint32_t)P * (uint32_t)N * 4u), 0x00020000);
@@ -779,6 +790,7 @@ __device__ __forceinline__ void chain_epilogue(const ChainLayer &Ly, const float
                 const bool pos = v > 0.f;
                 word |= pos ? (1u << (8 * q + 4 * h + c)) : 0u;
                 v = pos ? v : slope * v;
+                if (masked) v = (mw[t] >> (8 * q + 4 * h + c)) & 1u ? v : mslope * v;       // (uniform branch)
                 y[c] = v;
                 if constexpr (KEEP) act[16 * t + 4 * q + c] = v;       // = slot 16 t + r of the next layer's second operand
             }
@@ -824,21 +836,25 @@ template <int NTL>
 __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int K0, const float *__restrict__ X, ChainArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem_chain[];
     uint4 *const s_slot0 = reinterpret_cast<uint4 *>(smem_chain);
-    float *s_bias = reinterpret_cast<float *>(smem_chain + (size_t)kChainSlots * kChainSlotUnits * 16);       // [layer parity][128]
+    float *s_bias = reinterpret_cast<float *>(smem_chain + (size_t)kChainSlots * kChainSlotUnits * 16);       // [3][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, n = lane & 31;
     const int nblocks = (P + kChainRows - 1) / kChainRows;
-    float *s_stage = s_bias + 256 + wave * (32 * kChainStageLd);      // the wavefront's transposition tile: 32 rows x (32 + 4) floats
+    float *s_stage = s_bias + 3 * 128 + wave * (32 * kChainStageLd);      // the wavefront's transposition tile: 32 rows x (32 + 4) floats
     const int L = args.L, abl = args.abl;
     const int KS0 = chain_ksteps(K0), nch0 = KS0 / 2;
     auto slot = [&](int g) { return s_slot0 + (size_t)g * kChainSlotUnits; };
+    // bias buffers: a layer's bias arrives with its first chunk, i.e. during the last chunk of the layer before -- for layer 0
+    // of the NEXT row block that is the last layer of this one, whose epilogue is still to come.  Layers 0 .. L - 2 alternate
+    // between two buffers, the last layer has its own.
+    auto bias_of = [&](int l) { return s_bias + (l == L - 1 ? 2 : (l & 1)) * 128; };
     // chunk (l, c): layers 0 .. L - 2 have 4 output tiles, the last one NTL; layer 0 has nch0 chunks, the others 4
     auto issue = [&](int l, int c, int g) {
         if (abl & 2) return;
         const uint4 *panel = args.layer[l].panel;
         const int KS = l == 0 ? KS0 : 8;
-        if (l == L - 1) chain_issue<NTL>(panel, KS, c, slot(g), s_bias + (l & 1) * 128, wave, lane);
-        else chain_issue<4>(panel, KS, c, slot(g), s_bias + (l & 1) * 128, wave, lane);
+        if (l == L - 1) chain_issue<NTL>(panel, KS, c, slot(g), bias_of(l), wave, lane);
+        else chain_issue<4>(panel, KS, c, slot(g), bias_of(l), wave, lane);
     };
     if ((int)blockIdx.x < nblocks) issue(0, 0, 0);
     chain_sync();                                          // chunk 0 is in place
@@ -851,6 +867,14 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
             // flight before the first wait): a group of 4 features that runs past the row is read from the row's last 16
             // bytes instead (K0 >= 4) and shifted into place
             const float *xr = X + (size_t)rowc * (uint32_t)K0;
+            if (K0 < 4) {                                  // (uniform) up to three inputs: element loads
+#pragma unroll
+                for (int u = 0; u < 64; ++u) act[u] = 0.f;
+                const float e0 = xr[0], e1 = xr[K0 > 1 ? 1 : 0], e2 = xr[K0 > 2 ? 2 : 0];
+                act[0] = h == 0 ? e0 : 0.f;
+                act[1] = (h == 0 && K0 > 1) ? e1 : 0.f;
+                act[2] = (h == 0 && K0 > 2) ? e2 : 0.f;
+            } else
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 Float4U raw[8];
@@ -872,6 +896,13 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
         }
         const bool more_blocks = rb + (int)gridDim.x < nblocks;
         f32x16 acc[4];
+        uint32_t mw[4] = {0u, 0u, 0u, 0u};                 // the row's mask words of the current layer (backward chain)
+        auto load_mask = [&](const ChainLayer &Ly, int nt) {          // issued one chunk before the epilogue that uses them
+            if (!Ly.mask) return;
+            const uint32_t *mp = Ly.mask + (size_t)rowc * nt;
+            if (nt == 4) { const uint4 q = *reinterpret_cast<const uint4 *>(mp); mw[0] = q.x; mw[1] = q.y; mw[2] = q.z; mw[3] = q.w; }
+            else for (int t = 0; t < nt; ++t) mw[t] = mp[t];
+        };
         // ---- layers 0 .. L - 2: 128 outputs
         for (int l = 0; l + 1 < L; ++l) {
             const int nch = l == 0 ? nch0 : 4;
@@ -885,7 +916,10 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
                     // the next chunk goes into the other slot: every wavefront finished reading it before the barrier that
                     // ended the previous chunk
                     if (c + 1 < nch) issue(l, c + 1, g ^ 1);
-                    else issue(l + 1, 0, g ^ 1);
+                    else {
+                        issue(l + 1, 0, g ^ 1);
+                        load_mask(args.layer[l], 4);
+                    }
                     if (!(abl & 4)) chain_chunk<4, 2 * c>(slot(g), act, acc, lane);
                     if (c + 1 < nch) {
                         chain_sync();      // this slot is free again, and the next chunk's DMA has landed
@@ -894,7 +928,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
                 }
             });
             chain_wait_dma();         // the next layer's first chunk (and bias): this wavefront's pieces have landed
-            chain_epilogue<4, true>(args.layer[l], s_bias + (l & 1) * 128, s_stage, P, row0, lane, acc, act, abl);
+            chain_epilogue<4, true>(args.layer[l], bias_of(l), s_stage, P, row0, lane, acc, act, mw, abl);
             chain_barrier_only();     // ... everybody's have, and the layer's last slot is free; the stores stay in flight
             g ^= 1;
         }
@@ -908,7 +942,10 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
             static_for_4([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
                 if (c + 1 < 4) issue(l, c + 1, g ^ 1);
-                else if (more_blocks) issue(0, 0, g ^ 1);
+                else {
+                    if (more_blocks) issue(0, 0, g ^ 1);
+                    load_mask(args.layer[l], NTL);
+                }
                 if (!(abl & 4)) chain_chunk<NTL, 2 * c>(slot(g), act, acc, lane);
                 if (c + 1 < 4) {
                     chain_sync();
@@ -916,7 +953,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
                 }
             });
             chain_wait_dma();
-            chain_epilogue<NTL, false>(args.layer[l], s_bias + (l & 1) * 128, s_stage, P, row0, lane, acc, act, abl);
+            chain_epilogue<NTL, false>(args.layer[l], bias_of(l), s_stage, P, row0, lane, acc, act, mw, abl);
             chain_barrier_only();
             g ^= 1;
         }
@@ -1086,27 +1123,28 @@ extern "C" int64_t d3ga_mlp_chain_panel_bytes(int32_t K, int32_t n_out) {
     return (int64_t)d3ga::chain_panel_units(K, n_out) * 16 + 512;
 }
 
-extern "C" int d3ga_mlp_pack_chain(int32_t K, int32_t n_out, const float *W, int64_t ld_k, int64_t ld_n, const float *bias,
-                                   void *panel, d3ga_stream_t stream) {
+extern "C" int d3ga_mlp_pack_chain(int32_t K, int32_t n_out, const float *W, int64_t ld_k, int64_t ld_n, void *panel,
+                                   d3ga_stream_t stream) {
     if (K < 1 || K > 128 || n_out < 1 || n_out > 128) return D3GA_E_SIZE;
     if (!W || !panel) return D3GA_E_NULL;
     if ((uintptr_t)panel & 15) return D3GA_E_CONFIG;
     hipStream_t s = (hipStream_t)stream;
-    const int units = d3ga::chain_panel_units(K, n_out) / 3;          // (>= 64 >= ... the first workgroup also writes the 128 bias floats)
-    static_assert(d3ga::kBlock >= 128, "the bias tail is written by the first workgroup");
+    const int units = d3ga::chain_panel_units(K, n_out) / 3;
     hipLaunchKernelGGL(d3ga::pack_chain_kernel, dim3((units + d3ga::kBlock - 1) / d3ga::kBlock), dim3(d3ga::kBlock), 0, s, K, n_out, W,
-                       ld_k, ld_n, bias, reinterpret_cast<uint4 *>(panel));
+                       ld_k, ld_n, reinterpret_cast<uint4 *>(panel));
     return d3ga::check_launch(s, 0);
 }
 
 extern "C" int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t L, const int32_t *Ks, const int32_t *Ns,
-                                  const void *const *panels, const float *slopes, float *const *outs, uint32_t *const *signs,
+                                  void *const *panels, const float *const *biases, const float *slopes, float *const *outs,
+                                  uint32_t *const *signs, const uint32_t *const *masks, const float *mask_slopes,
                                   d3ga_stream_t stream) {
     using namespace d3ga;
     if (P < 0 || L < 1 || L > kChainMaxLayers || K0 < 1 || K0 > 128) return D3GA_E_SIZE;
     if (P == 0) return D3GA_OK;
     if (!X || !Ks || !Ns || !panels || !slopes || !outs || !signs) return D3GA_E_NULL;
     ChainArgs a;
+    ChainBiasArgs ba;
     a.L = L;
     int k_prev = K0;
     for (int l = 0; l < L; ++l) {
@@ -1114,18 +1152,23 @@ extern "C" int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t
         if (!panels[l] || !outs[l]) return D3GA_E_NULL;
         if (((uintptr_t)panels[l] | (uintptr_t)outs[l]) & 15) return D3GA_E_CONFIG;
         if ((int64_t)P * Ns[l] >= (1ll << 30) || (int64_t)P * Ks[l] >= (1ll << 30)) return D3GA_E_SIZE;     // (byte offsets in 32 bits)
-        a.layer[l] = ChainLayer{reinterpret_cast<const uint4 *>(panels[l]), outs[l], signs[l], Ks[l], Ns[l], slopes[l]};
+        a.layer[l] = ChainLayer{reinterpret_cast<const uint4 *>(panels[l]), outs[l], signs[l], masks ? masks[l] : nullptr, Ks[l], Ns[l],
+                                slopes[l], (masks && masks[l] && mask_slopes) ? mask_slopes[l] : 1.f};
+        if (masks && masks[l] && (Ns[l] + 31) / 32 == 4 && ((uintptr_t)masks[l] & 15)) return D3GA_E_CONFIG;
+        ba.bias[l] = biases ? biases[l] : nullptr;
+        ba.tail[l] = reinterpret_cast<float *>(reinterpret_cast<char *>(panels[l]) + (size_t)chain_panel_units(Ks[l], Ns[l]) * 16);
+        ba.N[l] = Ns[l];
         k_prev = Ns[l];
     }
     // shapes the kernel is built for (everything else: the per-layer kernels): >= 2 layers, all but the last 128 wide
-    if (L < 2 || K0 < 4) return D3GA_E_CONFIG;
+    if (L < 2) return D3GA_E_CONFIG;
     for (int l = 0; l + 1 < L; ++l) if (Ns[l] != 128) return D3GA_E_CONFIG;
     const int ntl = (Ns[L - 1] + 31) / 32;
     if (ntl == 3) return D3GA_E_CONFIG;
     static const int abl = getenv("D3GA_CHAIN_ABL") ? atoi(getenv("D3GA_CHAIN_ABL")) : 0;      // timing ablations (wrong results)
     a.abl = abl;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)kChainSlots * kChainSlotUnits * 16 + (2 * 128 + (kChainThreads / 64) * 32 * kChainStageLd) * sizeof(float);
+    const size_t lds = (size_t)kChainSlots * kChainSlotUnits * 16 + (3 * 128 + (kChainThreads / 64) * 32 * kChainStageLd) * sizeof(float);
     static bool attr[64] = {};
     int dev = 0;
     D3GA_HIP(hipGetDevice(&dev));
@@ -1135,6 +1178,7 @@ extern "C" int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t
         D3GA_HIP(hipFuncSetAttribute((const void *)chain_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr[dev] = true;
     }
+    hipLaunchKernelGGL(chain_bias_kernel, dim3(L), dim3(128), 0, s, ba);          // this call's biases into the panels' tails
     const int nblocks = (P + kChainRows - 1) / kChainRows;
     static const int grid_cap = getenv("D3GA_CHAIN_GRID") ? atoi(getenv("D3GA_CHAIN_GRID")) : 2048 / kChainWaves;
     const dim3 grid(nblocks < grid_cap ? nblocks : grid_cap), block(kChainThreads);

@@ -63,11 +63,12 @@ def set_fused_forward(enabled):
     _FUSED["enabled"] = bool(enabled)
 
 
-def _chain_panel(weight, bias):
-    """The layer's weights (and bias) in the operand order of the fused trunk kernel (d3ga_mlp_pack_chain: the k order carries
-    the feature permutation that lets a layer's output registers be the next layer's operand as they are).  Cached like `_panel`."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()),
-           None if bias is None else (bias.data_ptr(), bias._version))
+def _chain_panel(weight, transposed=False):
+    """The layer's weights in the operand order of the fused trunk kernel (d3ga_mlp_pack_chain: the k order carries the
+    feature permutation that lets a layer's output registers be the next layer's operand as they are) + 512 bytes of room for
+    the bias, which every call writes itself.  transposed: the panel of W^T (the backward's input-gradient chain).  Cached
+    per weight version like `_panel`."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()), bool(transposed))
     hit = _chain_panels.get(key)
     if hit is None:
         if len(_chain_panels) > 64:
@@ -77,29 +78,43 @@ def _chain_panel(weight, bias):
             w = w.float()
         N, K = w.shape
         s_n, s_k = w.stride()
+        if transposed:                                     # y = x W: inputs run over W's rows, outputs over its columns
+            N, K, s_n, s_k = K, N, s_k, s_n
         nbytes = _lib.lib().d3ga_mlp_chain_panel_bytes(K, N)
         p = torch.empty(nbytes // 4, dtype=torch.int32, device=w.device)
-        b = None if bias is None else bias.detach().float().contiguous()
-        check(_lib.lib().d3ga_mlp_pack_chain(K, N, dptr(w), s_k, s_n, dptr(b), dptr(p), stream_handle()), "d3ga_mlp_pack_chain")
-        hit = (p, weight.detach(), w, None if bias is None else bias.detach())     # (detached aliases keep the storage alive: see _panel)
+        check(_lib.lib().d3ga_mlp_pack_chain(K, N, dptr(w), s_k, s_n, dptr(p), stream_handle()), "d3ga_mlp_pack_chain")
+        hit = (p, weight.detach(), w)              # (detached aliases keep the storage alive: see _panel)
         _chain_panels[key] = hit
     return hit[0]
 
 
-def _chain_forward(h, weights, biases, slopes, track):
-    """All layers in ONE launch: -> (outputs of every layer, sign words of every layer or None)."""
-    L, P, dev = len(weights), h.shape[0], h.device
-    Ks = (ctypes.c_int32 * L)(*[w.shape[1] for w in weights])
-    Ns = (ctypes.c_int32 * L)(*[w.shape[0] for w in weights])
-    panels = [_chain_panel(w, b) for w, b in zip(weights, biases)]
-    outs = [torch.empty((P, w.shape[0]), dtype=torch.float32, device=dev) for w in weights]
-    signs = [torch.empty((P, (w.shape[0] + 31) // 32), dtype=torch.int32, device=dev) if (track and sl != 1.0) else None
-             for w, sl in zip(weights, slopes)]
+def _chain_shapes_ok(P, k0, widths):
+    """What d3ga_mlp_chain_fwd is built for: >= 2 layers, all but the last 128 wide, k0 <= 128, last 1..64 or 97..128."""
+    return (_FUSED["enabled"] and 2 <= len(widths) <= 8 and 0 < P < (1 << 23) and 1 <= k0 <= 128
+            and all(n == 128 for n in widths[:-1]) and (widths[-1] + 31) // 32 in (1, 2, 4))
+
+
+def _chain_run(h, panels, dims, biases, slopes, want_signs, masks=None, mask_slopes=None):
+    """ONE launch for a chain of layers: dims = [(K, N), ...] -> (outputs of every layer, sign words per layer or None)."""
+    L, P, dev = len(panels), h.shape[0], h.device
+    Ks = (ctypes.c_int32 * L)(*[k for k, _ in dims])
+    Ns = (ctypes.c_int32 * L)(*[n for _, n in dims])
+    bs = [None if b is None else b.detach().float().contiguous() for b in biases]
+    outs = [torch.empty((P, n), dtype=torch.float32, device=dev) for _, n in dims]
+    signs = [torch.empty((P, (n + 31) // 32), dtype=torch.int32, device=dev) if ws else None for (_, n), ws in zip(dims, want_signs)]
     vp = ctypes.c_void_p
     arr = lambda ts: (vp * L)(*[dptr(t) for t in ts])
-    check(_lib.lib().d3ga_mlp_chain_fwd(P, h.shape[1], dptr(h), L, Ks, Ns, arr(panels), (ctypes.c_float * L)(*[float(v) for v in slopes]),
-                                        arr(outs), arr(signs), stream_handle()), "d3ga_mlp_chain_fwd")
+    fl = lambda vs: (ctypes.c_float * L)(*[float(v) for v in vs])
+    check(_lib.lib().d3ga_mlp_chain_fwd(P, h.shape[1], dptr(h), L, Ks, Ns, arr(panels), arr(bs), fl(slopes), arr(outs), arr(signs),
+                                        None if masks is None else arr(masks), None if mask_slopes is None else fl(mask_slopes),
+                                        stream_handle()), "d3ga_mlp_chain_fwd")
     return outs, signs
+
+
+def _chain_forward(h, weights, biases, slopes, track):
+    """All layers of a trunk in ONE launch: -> (outputs of every layer, sign words of every layer or None)."""
+    return _chain_run(h, [_chain_panel(w) for w in weights], [(w.shape[1], w.shape[0]) for w in weights], biases, slopes,
+                      [track and sl != 1.0 for sl in slopes])
 
 
 def _linear(x, panel, bias, slope, n_out, want_sign=False, mask_bits=None, mask_slope=1.0):
@@ -124,8 +139,7 @@ class _Chain(torch.autograd.Function):
         h = f32c16(x)
         acts, signs = [h], []
         track = any(ctx.needs_input_grad)                      # (grad mode is off inside forward: ask the node instead)
-        fused = (_FUSED["enabled"] and 2 <= len(weights) <= 8 and 0 < h.shape[0] < (1 << 23) and 4 <= h.shape[1] <= 128
-                 and all(w.shape[0] == 128 for w in weights[:-1]) and (weights[-1].shape[0] + 31) // 32 in (1, 2, 4)
+        fused = (_chain_shapes_ok(h.shape[0], h.shape[1], [w.shape[0] for w in weights])
                  and all(weights[i].shape[1] == (h.shape[1] if i == 0 else weights[i - 1].shape[0]) for i in range(len(weights))))
         if fused:                                              # the whole trunk in one launch: activations stay in registers
             outs, signs = _chain_forward(h, weights, biases, slopes, track)
@@ -166,21 +180,45 @@ class _Chain(torch.autograd.Function):
         for a, b in sizes:
             offs.append((o, o + a))
             o += a + b
+        # the input-gradient chain dPre_{L-1} = dy -> dPre_{L-2} -> ... -> dPre_0 [-> dx]: one launch when the shapes allow
+        # (the same kernel as the forward: transposed weights, the sign words of the forward as masks, no bias)
+        dpres = [None] * L
+        dpres[L - 1] = dpre
+        want_dx = bool(ctx.needs_input_grad[0])
+        chain_layers = list(range(L - 1, 0, -1)) + ([0] if want_dx else [])       # layer i maps dPre_i -> dPre_{i-1} (or dx)
+        widths = [weights[i].shape[1] for i in chain_layers]
+        if L >= 2 and _chain_shapes_ok(dpre.shape[0], dpre.shape[1], widths):
+            masks = [ctx.signs[i - 1] if (i > 0 and ctx.slopes[i - 1] != 1.0) else None for i in chain_layers]
+            mslopes = [ctx.slopes[i - 1] if i > 0 else 1.0 for i in chain_layers]
+            outs, _ = _chain_run(dpre, [_chain_panel(weights[i], True) for i in chain_layers],
+                                 [(weights[i].shape[0], weights[i].shape[1]) for i in chain_layers], [None] * len(chain_layers),
+                                 [1.0] * len(chain_layers), [False] * len(chain_layers), masks, mslopes)
+            for i, o in zip(chain_layers, outs):
+                if i > 0:
+                    dpres[i - 1] = o
+                else:
+                    dx = o
+            fused_bwd = True
+        else:
+            fused_bwd = False
         for i in range(L - 1, -1, -1):
             w, x_in = weights[i], acts[i]
             N, K = w.shape
             need_w, need_b = need[i]
+            dpre = dpres[i]
             if need_w or need_b:                              # dW += dPre^T X (a reduction over all rows), db += column sums
                 dw = flat[offs[i][0]:offs[i][1]].view(N, K)
                 db = flat[offs[i][1]:offs[i][1] + N] if need_b else None
                 check(_lib.lib().d3ga_mlp_wgrad_acc(dpre.shape[0], N, K, dptr(dpre), dptr(x_in), dptr(dw), dptr(db),
                                                     stream_handle()), "d3ga_mlp_wgrad_acc")
                 grads[2 * i], grads[2 * i + 1] = (dw if need_w else None), db
+            if fused_bwd:
+                continue
             if i > 0:                                         # dPre of the layer below: (dPre W) (.) act'_{i-1}(h_i)
                 below = ctx.slopes[i - 1]
-                dpre = _linear(dpre, _panel(w, False), None, 1.0, K, mask_bits=ctx.signs[i - 1] if below != 1.0 else None,
-                               mask_slope=below)[0]
-            elif ctx.needs_input_grad[0]:
+                dpres[i - 1] = _linear(dpre, _panel(w, False), None, 1.0, K, mask_bits=ctx.signs[i - 1] if below != 1.0 else None,
+                                       mask_slope=below)[0]
+            elif want_dx:
                 dx = _linear(dpre, _panel(w, False), None, 1.0, K)[0]
         return (dx, None, *grads)
 

@@ -352,16 +352,21 @@ int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const v
 /* One launch for a whole trunk (forward): h_{l+1} = act_l(h_l W_l^T + b_l), l = 0..L-1, with the activations kept in the
  * registers of the wavefront that owns the rows -- no activation is read back between the layers.  Same
  * arithmetic as d3ga_mlp_linear (exact 3-way bf16 split, six products, f32 accumulate).  Layer l: Ks[l] inputs (= Ns[l-1];
- * Ks[0] = K0 <= 128), Ns[l] <= 128 outputs, panels[l] = its weights AND bias (bias may be NULL = none) packed by
- * d3ga_mlp_pack_chain (d3ga_mlp_chain_panel_bytes), leaky_relu slope slopes[l] (1 = none) applied to its output; outs[l] (P, Ns[l]) receives that output and
+ * Ks[0] = K0 <= 128), Ns[l] <= 128 outputs, panels[l] = its weights packed by d3ga_mlp_pack_chain (d3ga_mlp_chain_panel_bytes;
+ * the call writes biases[l] -- or zeros: biases / biases[l] may be NULL -- into the 512-byte tail of panels[l], which is why
+ * the panels are not const), leaky_relu slope slopes[l] (1 = none) applied to its output; outs[l] (P, Ns[l]) receives that output and
  * signs[l] (or NULL) one bit per output element (P, ceil(Ns[l]/32)) words, bit c of word b = out[row][32 b + c] > 0 before the
- * slope -- exactly what d3ga_mlp_linear writes, so the per-layer backward applies unchanged.  L <= 8. */
+ * slope -- exactly what d3ga_mlp_linear writes, so the per-layer backward applies unchanged.  L <= 8.
+ * The same launch runs the BACKWARD's input-gradient chain: X = the gradient at the trunk's output, panels[l] = the transposed
+ * weights (d3ga_mlp_pack_chain with ld_k / ld_n swapped, bias NULL), slopes[l] = 1, masks[l] (or NULL; masks itself may be
+ * NULL) = the sign words the forward wrote for the layer BELOW output l: outs[l] (.)= bit ? 1 : mask_slopes[l] -- outs[l] is
+ * then that layer's pre-activation gradient (d3ga_mlp_linear's mask_bits).  Supported shapes: L >= 2, every layer but the
+ * last 128 wide, K0 <= 128, the last one 1..64 or 97..128 wide; D3GA_E_CONFIG otherwise (use d3ga_mlp_linear). */
 int64_t d3ga_mlp_chain_panel_bytes(int32_t K, int32_t n_out);
-int d3ga_mlp_pack_chain(int32_t K, int32_t n_out, const float *W, int64_t ld_k, int64_t ld_n, const float *bias, void *panel,
-                        d3ga_stream_t stream);
+int d3ga_mlp_pack_chain(int32_t K, int32_t n_out, const float *W, int64_t ld_k, int64_t ld_n, void *panel, d3ga_stream_t stream);
 int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t L, const int32_t *Ks, const int32_t *Ns,
-                       const void *const *panels, const float *slopes, float *const *outs, uint32_t *const *signs,
-                       d3ga_stream_t stream);
+                       void *const *panels, const float *const *biases, const float *slopes, float *const *outs,
+                       uint32_t *const *signs, const uint32_t *const *masks, const float *mask_slopes, d3ga_stream_t stream);
 /* Weight and bias gradient of that layer: dW (N,K) = dPre^T . X, db (N) = column sums of dPre (db may be NULL);
  * dPre (P,N) = the gradient at the layer's pre-activation (see above), X (P,K) the layer's input.  Both outputs are zeroed by the call; partial sums meet through float atomics. */
 int d3ga_mlp_wgrad(int32_t P, int32_t N, int32_t K, const float *dpre, const float *X, float *dW, float *db,

@@ -166,6 +166,69 @@ def test_chain_matches_torch_autograd(P, widths):
         assert rel_err(b.grad.cpu().numpy(), br.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("P,widths,bias", [(700, [11, 128, 128, 128, 128, 11], True), (257, [3, 128, 128, 1], True),
+                                          (1000, [80, 128, 128, 64], False), (513, [45, 128, 128, 128], True),
+                                          (33, [128, 128, 3], True), (4099, [1, 128, 40], True),
+                                          (140003, [11, 128, 128, 128, 11], True), (70001, [45, 128, 128, 3], True)])
+def test_fused_trunk_matches_per_layer_and_f64(P, widths, bias):
+    """The one-launch trunk (d3ga_mlp_chain_fwd: forward, and the backward's input-gradient chain through the same kernel with
+    transposed weights and the forward's sign words as masks) on the shapes it is built for -- hidden width 128, 1 / 2 / 4
+    output tiles, fewer than four inputs, ragged row counts, more row blocks than workgroups (> 65536 rows: the persistent
+    workgroups then prefetch the next block's first chunk and bias behind the last layer) -- against the per-layer kernels (same arithmetic: agreement to
+    summation order) and against torch f64 autograd.  Ends with the stale-bias case: the SAME weights with another bias."""
+    from d3ga_amd import mlp as M
+    g = torch.Generator().manual_seed(P + sum(widths))
+    x = torch.randn(P, widths[0], generator=g)
+    layers = [(torch.randn(b, a, generator=g) / a ** 0.5, torch.randn(b, generator=g) if bias else None)
+              for a, b in zip(widths[:-1], widths[1:])]
+    slopes = [0.1] * (len(layers) - 1) + [1.0]
+    up = torch.randn(P, widths[-1], generator=g)
+
+    def run(fused, layers_dev):
+        M.set_fused_forward(fused)
+        try:
+            xd = x.to(DEV).requires_grad_(True)
+            y = M.mlp_chain(xd, layers_dev, slopes)
+            y.backward(up.to(DEV))
+            return y.detach().cpu(), xd.grad.cpu(), [(w.grad.cpu(), None if b is None else b.grad.cpu()) for w, b in layers_dev]
+        finally:
+            M.set_fused_forward(True)
+
+    mk = lambda: [(w.to(DEV).requires_grad_(True), None if b is None else b.to(DEV).requires_grad_(True)) for w, b in layers]
+    yf, gxf, gwf = run(True, mk())
+    yu, gxu, gwu = run(False, mk())
+    np.testing.assert_allclose(yf.numpy(), yu.numpy(), rtol=2e-6, atol=2e-6)
+    # a pre-activation within rounding of 0 may take the other sign in the other kernel and its row then the other slope
+    # (test_chain_fuzz): count such rows, hold everything else to rounding
+    du = (gxf.double() - gxu.double()).abs().amax(1) / (gxu.abs().max().double() + 1e-30)
+    flipped_u = int((du > 2e-6).sum())
+    assert flipped_u <= max(1, P // 20000), (flipped_u, float(du.max()))
+    for (a, ab), (b, bb) in zip(gwf, gwu):
+        assert rel_err(a.numpy(), b.numpy()) < (1e-5 if not flipped_u else 2e-3)
+        if ab is not None:
+            assert rel_err(ab.numpy(), bb.numpy()) < (1e-5 if not flipped_u else 2e-3)
+    xr = x.double().requires_grad_(True)
+    lr = [(w.double().requires_grad_(True), None if b is None else b.double().requires_grad_(True)) for w, b in layers]
+    h = xr
+    for (w, b), sl in zip(lr, slopes):
+        h = torch.nn.functional.leaky_relu(torch.nn.functional.linear(h, w, b), sl)
+    h.backward(up.double())
+    np.testing.assert_allclose(yf.numpy(), h.detach().numpy(), rtol=1e-5, atol=1e-5)
+    d = (gxf.double() - xr.grad).abs().amax(1) / (xr.grad.abs().max() + 1e-30)
+    assert int((d > 2e-5).sum()) <= max(1, P // 500), float(d.max())          # (rows at the leaky_relu kink: see test_chain_fuzz)
+    if bias:                                               # the bias is an input of the call, not part of the cached weight panel
+        ld = mk()
+        y1 = M.mlp_chain(x.to(DEV), ld, slopes).detach().cpu()
+        with torch.no_grad():
+            other = [(w, torch.full_like(b, 0.25)) for w, b in ld]        # same weight tensors (same cache entries), new biases
+        y2 = M.mlp_chain(x.to(DEV), other, slopes).detach().cpu()
+        h2 = x.double()
+        for (w, _), sl in zip(layers, slopes):
+            h2 = torch.nn.functional.leaky_relu(torch.nn.functional.linear(h2, w.double(), torch.full((w.shape[0],), 0.25).double()), sl)
+        np.testing.assert_allclose(y1.numpy(), yf.numpy(), rtol=0, atol=0)
+        np.testing.assert_allclose(y2.numpy(), h2.numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_CHAIN_FUZZ_FIRST", "0")),
                                        int(os.environ.get("D3GA_CHAIN_FUZZ_N", "6"))))
 def test_chain_fuzz(seed):
