@@ -766,7 +766,9 @@ __device__ __forceinline__ void chain_chunk(const uint4 *slot, const float (&act
 
 // Layer epilogue: bias, activation, sign bits; register r of tile t = feature 32 t + 8 (r >> 2) + 4 h + (r & 3) of row n.
 // KEEP: the outputs become the next layer's input registers.
-template <int NT, bool KEEP>
+// BWD (the backward's input-gradient chain): no bias, no activation, no sign bits out; the output is multiplied by
+// (bit ? 1 : mask_slope) from the forward's sign words of the layer below (mw) where the layer has a mask.
+template <int NT, bool KEEP, bool BWD>
 __device__ __forceinline__ void chain_epilogue(const ChainLayer &Ly, const float *bias_l, float *s_stage, int P, int row0, int lane,
                                                const f32x16 (&acc)[4], float (&act)[64], const uint32_t (&mw)[4], int abl) {
     const int h = lane >> 5, n = lane & 31;
@@ -779,18 +781,24 @@ __device__ __forceinline__ void chain_epilogue(const ChainLayer &Ly, const float
     for (int t = 0; t < NT; ++t) {
         uint32_t word = 0u;
         float4 bqs[4];
-        lds_read16x4_opaque(bias_l + 32 * t + 4 * h, bias_l + 32 * t + 8 + 4 * h, bias_l + 32 * t + 16 + 4 * h, bias_l + 32 * t + 24 + 4 * h, bqs);
+        if constexpr (!BWD)
+            lds_read16x4_opaque(bias_l + 32 * t + 4 * h, bias_l + 32 * t + 8 + 4 * h, bias_l + 32 * t + 16 + 4 * h, bias_l + 32 * t + 24 + 4 * h, bqs);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 bq = bqs[q];
             float y[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float v = acc[t][4 * q + c] + (c == 0 ? bq.x : (c == 1 ? bq.y : (c == 2 ? bq.z : bq.w)));
-                const bool pos = v > 0.f;
-                word |= pos ? (1u << (8 * q + 4 * h + c)) : 0u;
-                v = pos ? v : slope * v;
-                if (masked) v = (mw[t] >> (8 * q + 4 * h + c)) & 1u ? v : mslope * v;       // (uniform branch)
+                float v;
+                if constexpr (BWD) {
+                    v = acc[t][4 * q + c];
+                    if (masked) v = (mw[t] & (1u << (8 * q + 4 * h + c))) ? v : mslope * v;       // (uniform branch)
+                } else {
+                    const float4 bq = bqs[q];
+                    v = acc[t][4 * q + c] + (c == 0 ? bq.x : (c == 1 ? bq.y : (c == 2 ? bq.z : bq.w)));
+                    const bool pos = v > 0.f;
+                    word |= pos ? (1u << (8 * q + 4 * h + c)) : 0u;
+                    v = pos ? v : slope * v;
+                }
                 y[c] = v;
                 if constexpr (KEEP) act[16 * t + 4 * q + c] = v;       // = slot 16 t + r of the next layer's second operand
             }
@@ -825,14 +833,14 @@ __device__ __forceinline__ void chain_epilogue(const ChainLayer &Ly, const float
                 }
             }
         }
-        if (Ly.sign) {                                       // (uniform) the two lane halves hold complementary bits of the word
+        if (!BWD && Ly.sign) {                               // (uniform) the two lane halves hold complementary bits of the word
             word |= (uint32_t)__shfl_xor((int)word, 32);
             if (h == 0 && row0 + n < P && !(abl & 16)) Ly.sign[(size_t)(row0 + n) * NT + t] = word;
         }
     }
 }
 
-template <int NTL>
+template <int NTL, bool BWD>
 __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int K0, const float *__restrict__ X, ChainArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem_chain[];
     uint4 *const s_slot0 = reinterpret_cast<uint4 *>(smem_chain);
@@ -928,7 +936,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
                 }
             });
             chain_wait_dma();         // the next layer's first chunk (and bias): this wavefront's pieces have landed
-            chain_epilogue<4, true>(args.layer[l], bias_of(l), s_stage, P, row0, lane, acc, act, mw, abl);
+            chain_epilogue<4, true, BWD>(args.layer[l], bias_of(l), s_stage, P, row0, lane, acc, act, mw, abl);
             chain_barrier_only();     // ... everybody's have, and the layer's last slot is free; the stores stay in flight
             g ^= 1;
         }
@@ -953,7 +961,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
                 }
             });
             chain_wait_dma();
-            chain_epilogue<NTL, false>(args.layer[l], bias_of(l), s_stage, P, row0, lane, acc, act, mw, abl);
+            chain_epilogue<NTL, false, BWD>(args.layer[l], bias_of(l), s_stage, P, row0, lane, acc, act, mw, abl);
             chain_barrier_only();
             g ^= 1;
         }
@@ -1173,17 +1181,28 @@ extern "C" int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t
     int dev = 0;
     D3GA_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr[dev]) {
-        D3GA_HIP(hipFuncSetAttribute((const void *)chain_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        D3GA_HIP(hipFuncSetAttribute((const void *)chain_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        D3GA_HIP(hipFuncSetAttribute((const void *)chain_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const void *ks[6] = {(const void *)chain_fwd_kernel<1, false>, (const void *)chain_fwd_kernel<2, false>, (const void *)chain_fwd_kernel<4, false>,
+                             (const void *)chain_fwd_kernel<1, true>, (const void *)chain_fwd_kernel<2, true>, (const void *)chain_fwd_kernel<4, true>};
+        for (const void *k : ks) D3GA_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr[dev] = true;
     }
     hipLaunchKernelGGL(chain_bias_kernel, dim3(L), dim3(128), 0, s, ba);          // this call's biases into the panels' tails
     const int nblocks = (P + kChainRows - 1) / kChainRows;
     static const int grid_cap = getenv("D3GA_CHAIN_GRID") ? atoi(getenv("D3GA_CHAIN_GRID")) : 2048 / kChainWaves;
     const dim3 grid(nblocks < grid_cap ? nblocks : grid_cap), block(kChainThreads);
-    if (ntl == 1) hipLaunchKernelGGL(chain_fwd_kernel<1>, grid, block, lds, s, P, K0, X, a);
-    else if (ntl == 2) hipLaunchKernelGGL(chain_fwd_kernel<2>, grid, block, lds, s, P, K0, X, a);
-    else hipLaunchKernelGGL(chain_fwd_kernel<4>, grid, block, lds, s, P, K0, X, a);
+    // the backward's chain: no bias, no activation, no sign output anywhere -- its own instantiation without that arithmetic
+    bool bwd = masks != nullptr;
+    for (int l = 0; l < L && bwd; ++l) bwd = !signs[l] && slopes[l] == 1.f && !(biases && biases[l]);
+    if (masks && !bwd)                                     // masks together with bias / activation / sign output: not built
+        for (int l = 0; l < L; ++l) if (masks[l]) return D3GA_E_CONFIG;
+    if (bwd) {
+        if (ntl == 1) hipLaunchKernelGGL((chain_fwd_kernel<1, true>), grid, block, lds, s, P, K0, X, a);
+        else if (ntl == 2) hipLaunchKernelGGL((chain_fwd_kernel<2, true>), grid, block, lds, s, P, K0, X, a);
+        else hipLaunchKernelGGL((chain_fwd_kernel<4, true>), grid, block, lds, s, P, K0, X, a);
+    } else {
+        if (ntl == 1) hipLaunchKernelGGL((chain_fwd_kernel<1, false>), grid, block, lds, s, P, K0, X, a);
+        else if (ntl == 2) hipLaunchKernelGGL((chain_fwd_kernel<2, false>), grid, block, lds, s, P, K0, X, a);
+        else hipLaunchKernelGGL((chain_fwd_kernel<4, false>), grid, block, lds, s, P, K0, X, a);
+    }
     return check_launch(s, 0);
 }

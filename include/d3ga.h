@@ -360,7 +360,8 @@ int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const v
  * The same launch runs the BACKWARD's input-gradient chain: X = the gradient at the trunk's output, panels[l] = the transposed
  * weights (d3ga_mlp_pack_chain with ld_k / ld_n swapped, bias NULL), slopes[l] = 1, masks[l] (or NULL; masks itself may be
  * NULL) = the sign words the forward wrote for the layer BELOW output l: outs[l] (.)= bit ? 1 : mask_slopes[l] -- outs[l] is
- * then that layer's pre-activation gradient (d3ga_mlp_linear's mask_bits).  Supported shapes: L >= 2, every layer but the
+ * then that layer's pre-activation gradient (d3ga_mlp_linear's mask_bits); a call with masks must have no bias, no activation
+ * (slopes 1) and no sign output on any layer.  Supported shapes: L >= 2, every layer but the
  * last 128 wide, K0 <= 128, the last one 1..64 or 97..128 wide; D3GA_E_CONFIG otherwise (use d3ga_mlp_linear). */
 int64_t d3ga_mlp_chain_panel_bytes(int32_t K, int32_t n_out);
 int d3ga_mlp_pack_chain(int32_t K, int32_t n_out, const float *W, int64_t ld_k, int64_t ld_n, void *panel, d3ga_stream_t stream);
