@@ -11,7 +11,7 @@ for abl in ${ABLS:-0 1 2 4 8 16 17 3 7 31}; do for grid in ${GRIDS:-512}; do exp
 import csv,glob,sys
 for f in glob.glob('/tmp/prof_abl/**/*kernel_stats.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'chain_fwd' in r['Name']: print('abl', sys.argv[1], 'grid', __import__('os').environ.get('D3GA_CHAIN_GRID'), r['Calls'], round(float(r['AverageNs'])/1000,1), 'us')
+        if "chain_fwd" in r["Name"] and "false" in r["Name"]: print('abl', sys.argv[1], 'grid', __import__('os').environ.get('D3GA_CHAIN_GRID'), r['Calls'], round(float(r['AverageNs'])/1000,1), 'us')
 PY
 done; done
 cat $R/gpurun_out/mlp_abl.log
