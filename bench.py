@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--force-cut", action="store_true",
                     help="diagnostic, one GPU: run the N>1 step (cut exchange over a one-rank nccl group, two hipGraphs) to "
                          "measure what the camera-sharded step costs per rank apart from the wire time")
+    ap.add_argument("--watchdog", type=float, default=180.0,
+                    help="N > 1: seconds after which device work that has not completed (a collective that never returns) "
+                         "ends this rank with exit code 124 instead of hanging the job (0: off)")
     ap.add_argument("--graph-collectives", action="store_true",
                     help="N>1: capture the step INCLUDING the gradient exchange (RCCL collectives) in the hipGraph")
     ap.add_argument("--fixed-camera", action="store_true",
@@ -789,6 +792,14 @@ def main():
             else:
                 frame.step()
         reduce_params()
+        if watchdog is not None:
+            watchdog.arm(("step", i))
+
+    # a rank whose device work never completes (a collective a peer never joined) ends with exit code 124 instead of hanging
+    watchdog = None
+    if world > 1 and args.watchdog > 0 and dev.type == "cuda":
+        from d3ga_amd.graph import ReplayWatchdog
+        watchdog = ReplayWatchdog(timeout_s=args.watchdog)
 
     # N > 1: the N = 1 step of THIS run, on every rank, before the group step is timed -- the same frame without the exchange,
     # ONE captured hipGraph, K replays with this rank's camera (slowest rank counts).  `distributed.efficiency` = n1 / N-step
@@ -1003,7 +1014,8 @@ def main():
                      "exchange_ms": None if ex_ms is None else round(ex_ms, 4),
                      "compute_ms": None if ex_ms is None else round(step_ms_all - ex_ms, 4),
                      "note": "exchange_ms: HIP events around the collectives of one step (all-reduce + all-gather in flight "
-                             "together); compute_ms = ms_per_step - exchange_ms (the exchange is not overlapped with compute)"}
+                             "together); compute_ms = ms_per_step - exchange_ms (the exchange is not overlapped with compute)",
+                     "watchdog_s": args.watchdog if watchdog is not None else None}
     dt = float(tmax.item())
 
     if rank == 0:

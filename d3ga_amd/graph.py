@@ -296,3 +296,61 @@ class CapturedCutStep:
         self.graph_b.replay()
         self._watch.after_replay()
         return self.result
+
+
+
+class ReplayWatchdog:
+    """A deadline for asynchronous device work that contains collectives -- a captured step with RCCL nodes
+    (`bench.py --graph-collectives`) or the eager exchange between the two graphs of `CapturedCutStep`.  A peer that died, or
+    ranks that disagree about the collectives of a step, do not raise: the GPU simply never finishes and the job hangs until
+    somebody kills it.  `arm(tag)` records an event on the current stream (one event record per call, nothing else on the hot
+    path); a daemon thread polls the armed events and, when one is still pending `timeout_s` after it was armed, calls
+    `on_timeout(tag, seconds)` -- by default it reports rank and tag on stderr and ends the process with exit code 124, so a
+    launcher (torchrun) sees a failed rank and tears the group down instead of waiting for ever.
+    `event_factory` is injectable for tests (anything with record() and query())."""
+
+    def __init__(self, timeout_s=120.0, poll_s=0.05, on_timeout=None, event_factory=None):
+        import collections
+        import threading
+        self.timeout_s, self.poll_s = float(timeout_s), float(poll_s)
+        self.on_timeout = on_timeout or self._abort
+        self._factory = event_factory or (lambda: torch.cuda.Event())
+        self._pending = collections.deque()
+        self._lock = threading.Lock()
+        self._stop = threading.Event()
+        self.fired = None
+        self._thread = threading.Thread(target=self._run, name="d3ga-replay-watchdog", daemon=True)
+        self._thread.start()
+
+    def arm(self, tag=None):
+        import time
+        ev = self._factory()
+        ev.record()
+        with self._lock:
+            self._pending.append((ev, tag, time.monotonic()))
+            while len(self._pending) > 64:                 # (only the oldest pending event matters: work completes in order)
+                self._pending.popleft()
+
+    def _run(self):
+        import time
+        while not self._stop.wait(self.poll_s):
+            with self._lock:
+                while self._pending and self._pending[0][0].query():
+                    self._pending.popleft()
+                head = self._pending[0] if self._pending else None
+            if head is not None and time.monotonic() - head[2] > self.timeout_s and self.fired is None:
+                self.fired = (head[1], time.monotonic() - head[2])
+                self.on_timeout(*self.fired)
+
+    @staticmethod
+    def _abort(tag, seconds):
+        import os
+        import sys
+        rank = os.environ.get("RANK", "0")
+        print(f"[d3ga watchdog] rank {rank}: device work armed as {tag!r} still pending after {seconds:.1f} s -- a collective "
+              f"that never completes (dead peer or mismatched collectives); aborting this rank", file=sys.stderr, flush=True)
+        os._exit(124)
+
+    def close(self):
+        self._stop.set()
+        self._thread.join(timeout=1.0)

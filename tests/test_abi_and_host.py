@@ -280,3 +280,31 @@ def test_batch_rodrigues_known_answers():
     assert torch.isfinite(r32.grad).all()
     with pytest.raises(ValueError):
         batch_rodrigues(torch.zeros(3))
+
+
+
+def test_replay_watchdog_fires_on_a_stuck_event_only():
+    """graph.ReplayWatchdog: an armed event that completes is forgotten; one that stays pending past the deadline calls
+    on_timeout once with its tag (fake events: no GPU involved)."""
+    import time
+    from d3ga_amd.graph import ReplayWatchdog
+
+    class Ev:
+        done = True
+        def record(self): pass
+        def query(self): return Ev.done
+
+    hits = []
+    wd = ReplayWatchdog(timeout_s=0.15, poll_s=0.01, on_timeout=lambda tag, s: hits.append((tag, s)), event_factory=Ev)
+    try:
+        for i in range(5):
+            wd.arm(("step", i))
+        time.sleep(0.3)
+        assert hits == []                                  # everything completed in time
+        Ev.done = False
+        wd.arm(("step", 5))
+        time.sleep(0.4)
+        assert len(hits) == 1 and hits[0][0] == ("step", 5) and hits[0][1] > 0.15
+        assert wd.fired is not None
+    finally:
+        wd.close()
