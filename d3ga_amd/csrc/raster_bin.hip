@@ -563,6 +563,8 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
     // longer lists: persistent grids driven by the device-side work lists (empty for avatar-sized scenes), 256 workgroups each.
     // (Round 3 also tried sorting the 2049..4096 class inside the per-tile kernel, in segments: one launch less, but a single
     // 256-thread workgroup then takes 2.5x as long as any other -- 13 -> 21 us for that kernel at C3, no net gain; reverted.)
+    // (... and running the two list kernels on a side stream beside the per-tile kernel -- fork / join events, parallel graph
+    // branches under capture: the events cost more than the overlap saves, bin+sort 49 -> 64 us eager, step 0.409 -> 0.422 ms.)
     {   // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (function attributes are per device)
         static bool attr_set[64] = {};
         int dev = 0;
