@@ -717,10 +717,11 @@ __device__ __forceinline__ void chain_issue(const uint4 *panel, int KS, int c, u
 }
 
 // The MFMAs of one chunk: k-steps S0, S0 + 1 of the layer against the activations in registers 8 S0 .. 8 S0 + 15.
-template <int NT, int S0>
-__device__ __forceinline__ void chain_chunk(const uint4 *slot, const float (&act)[64], f32x16 (&acc)[4], int lane) {
+template <int NT, int S0, class Mid>
+__device__ __forceinline__ void chain_chunk(const uint4 *slot, const float (&act)[64], f32x16 (&acc)[4], int lane, Mid &&mid) {
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
+        if (sl == 1) mid();                                // (between the two k-steps: the second half of the wavefronts starts its DMA here)
         uint32_t b0[4], b1[4], b2[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) bf16_split2(act[8 * (S0 + sl) + 2 * jj], act[8 * (S0 + sl) + 2 * jj + 1], b0[jj], b1[jj], b2[jj]);
@@ -851,6 +852,7 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
     float *s_stage = s_bias + 3 * 128 + wave * (32 * kChainStageLd);      // the wavefront's transposition tile: 32 rows x (32 + 4) floats
     const int L = args.L, abl = args.abl;
     const int KS0 = chain_ksteps(K0), nch0 = KS0 / 2;
+    const bool early = wave < kChainWaves / 2 || (abl & 32);           // (abl 32: every wavefront at the start of the chunk)
     auto slot = [&](int g) { return s_slot0 + (size_t)g * kChainSlotUnits; };
     // bias buffers: a layer's bias arrives with its first chunk, i.e. during the last chunk of the layer before -- for layer 0
     // of the NEXT row block that is the last layer of this one, whose epilogue is still to come.  Layers 0 .. L - 2 alternate
@@ -923,12 +925,17 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
                 if (c < nch) {                              // (uniform)
                     // the next chunk goes into the other slot: every wavefront finished reading it before the barrier that
                     // ended the previous chunk
-                    if (c + 1 < nch) issue(l, c + 1, g ^ 1);
-                    else {
-                        issue(l + 1, 0, g ^ 1);
-                        load_mask(args.layer[l], 4);
-                    }
-                    if (!(abl & 4)) chain_chunk<4, 2 * c>(slot(g), act, acc, lane);
+                    // the DMA instructions hold the issuing wavefront for a long time (measured: ~100 us of the kernel whatever
+                    // the source, the depth of the prefetch or the piece size); the two wavefronts of a SIMD (w and w + 4)
+                    // therefore issue theirs half a chunk apart, so that one of them always feeds the matrix pipe
+                    auto next = [&]() {
+                        if (c + 1 < nch) issue(l, c + 1, g ^ 1);
+                        else issue(l + 1, 0, g ^ 1);
+                    };
+                    if (early) next();
+                    if (c + 1 >= nch) load_mask(args.layer[l], 4);
+                    if (!(abl & 4)) chain_chunk<4, 2 * c>(slot(g), act, acc, lane, [&]() { if (!early) next(); });
+                    else if (!early) next();
                     if (c + 1 < nch) {
                         chain_sync();      // this slot is free again, and the next chunk's DMA has landed
                         g ^= 1;
@@ -949,12 +956,14 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             static_for_4([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                if (c + 1 < 4) issue(l, c + 1, g ^ 1);
-                else {
-                    if (more_blocks) issue(0, 0, g ^ 1);
-                    load_mask(args.layer[l], NTL);
-                }
-                if (!(abl & 4)) chain_chunk<NTL, 2 * c>(slot(g), act, acc, lane);
+                auto next = [&]() {
+                    if (c + 1 < 4) issue(l, c + 1, g ^ 1);
+                    else if (more_blocks) issue(0, 0, g ^ 1);
+                };
+                if (early) next();
+                if (c + 1 >= 4) load_mask(args.layer[l], NTL);
+                if (!(abl & 4)) chain_chunk<NTL, 2 * c>(slot(g), act, acc, lane, [&]() { if (!early) next(); });
+                else if (!early) next();
                 if (c + 1 < 4) {
                     chain_sync();
                     g ^= 1;
