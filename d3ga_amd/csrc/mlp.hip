@@ -740,8 +740,19 @@ __device__ __forceinline__ void chain_chunk(const uint4 *slot, const float (&act
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x0, acc[0], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x0, acc[0], 0, 0, 0);
         } else {
+            if constexpr (NT & 1) {                        // odd tile count: the last tile on its own
+                const uint4 *wa = slot + (sl * NT + NT - 1) * 64 + lane;
+                const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, wa[0]), a1 = __builtin_bit_cast(bf16x8_t, wa[pstride]),
+                               a2 = __builtin_bit_cast(bf16x8_t, wa[2 * pstride]);
+                acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x2, acc[NT - 1], 0, 0, 0);
+                acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x1, acc[NT - 1], 0, 0, 0);
+                acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, x0, acc[NT - 1], 0, 0, 0);
+                acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x1, acc[NT - 1], 0, 0, 0);
+                acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x0, acc[NT - 1], 0, 0, 0);
+                acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x0, acc[NT - 1], 0, 0, 0);
+            }
 #pragma unroll
-            for (int tp = 0; tp < NT; tp += 2) {           // two tiles at a time: their accumulators are independent
+            for (int tp = 0; tp + 1 < NT; tp += 2) {       // two tiles at a time: their accumulators are independent
                 const uint4 *wa = slot + (sl * NT + tp) * 64 + lane, *wb = wa + 64;
                 const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, wa[0]), a1 = __builtin_bit_cast(bf16x8_t, wa[pstride]),
                                a2 = __builtin_bit_cast(bf16x8_t, wa[2 * pstride]);
@@ -1181,7 +1192,6 @@ extern "C" int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t
     if (L < 2) return D3GA_E_CONFIG;
     for (int l = 0; l + 1 < L; ++l) if (Ns[l] != 128) return D3GA_E_CONFIG;
     const int ntl = (Ns[L - 1] + 31) / 32;
-    if (ntl == 3) return D3GA_E_CONFIG;
     static const int abl = getenv("D3GA_CHAIN_ABL") ? atoi(getenv("D3GA_CHAIN_ABL")) : 0;      // timing ablations (wrong results)
     a.abl = abl;
     hipStream_t s = (hipStream_t)stream;
@@ -1190,8 +1200,9 @@ extern "C" int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t
     int dev = 0;
     D3GA_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr[dev]) {
-        const void *ks[6] = {(const void *)chain_fwd_kernel<1, false>, (const void *)chain_fwd_kernel<2, false>, (const void *)chain_fwd_kernel<4, false>,
-                             (const void *)chain_fwd_kernel<1, true>, (const void *)chain_fwd_kernel<2, true>, (const void *)chain_fwd_kernel<4, true>};
+        const void *ks[8] = {(const void *)chain_fwd_kernel<1, false>, (const void *)chain_fwd_kernel<2, false>, (const void *)chain_fwd_kernel<3, false>,
+                             (const void *)chain_fwd_kernel<4, false>, (const void *)chain_fwd_kernel<1, true>, (const void *)chain_fwd_kernel<2, true>,
+                             (const void *)chain_fwd_kernel<3, true>, (const void *)chain_fwd_kernel<4, true>};
         for (const void *k : ks) D3GA_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr[dev] = true;
     }
@@ -1207,10 +1218,12 @@ extern "C" int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t
     if (bwd) {
         if (ntl == 1) hipLaunchKernelGGL((chain_fwd_kernel<1, true>), grid, block, lds, s, P, K0, X, a);
         else if (ntl == 2) hipLaunchKernelGGL((chain_fwd_kernel<2, true>), grid, block, lds, s, P, K0, X, a);
+        else if (ntl == 3) hipLaunchKernelGGL((chain_fwd_kernel<3, true>), grid, block, lds, s, P, K0, X, a);
         else hipLaunchKernelGGL((chain_fwd_kernel<4, true>), grid, block, lds, s, P, K0, X, a);
     } else {
         if (ntl == 1) hipLaunchKernelGGL((chain_fwd_kernel<1, false>), grid, block, lds, s, P, K0, X, a);
         else if (ntl == 2) hipLaunchKernelGGL((chain_fwd_kernel<2, false>), grid, block, lds, s, P, K0, X, a);
+        else if (ntl == 3) hipLaunchKernelGGL((chain_fwd_kernel<3, false>), grid, block, lds, s, P, K0, X, a);
         else hipLaunchKernelGGL((chain_fwd_kernel<4, false>), grid, block, lds, s, P, K0, X, a);
     }
     return check_launch(s, 0);

@@ -89,9 +89,9 @@ def _chain_panel(weight, transposed=False):
 
 
 def _chain_shapes_ok(P, k0, widths):
-    """What d3ga_mlp_chain_fwd is built for: >= 2 layers, all but the last 128 wide, k0 <= 128, last 1..64 or 97..128."""
+    """What d3ga_mlp_chain_fwd is built for: >= 2 layers, all but the last 128 wide, k0 <= 128, last <= 128."""
     return (_FUSED["enabled"] and 2 <= len(widths) <= 8 and 0 < P < (1 << 23) and 1 <= k0 <= 128
-            and all(n == 128 for n in widths[:-1]) and (widths[-1] + 31) // 32 in (1, 2, 4))
+            and all(n == 128 for n in widths[:-1]) and 1 <= widths[-1] <= 128)
 
 
 def _chain_run(h, panels, dims, biases, slopes, want_signs, masks=None, mask_slopes=None):

@@ -362,7 +362,7 @@ int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const v
  * NULL) = the sign words the forward wrote for the layer BELOW output l: outs[l] (.)= bit ? 1 : mask_slopes[l] -- outs[l] is
  * then that layer's pre-activation gradient (d3ga_mlp_linear's mask_bits); a call with masks must have no bias, no activation
  * (slopes 1) and no sign output on any layer.  Supported shapes: L >= 2, every layer but the
- * last 128 wide, K0 <= 128, the last one 1..64 or 97..128 wide; D3GA_E_CONFIG otherwise (use d3ga_mlp_linear). */
+ * last 128 wide, K0 <= 128, the last one <= 128 wide; D3GA_E_CONFIG otherwise (use d3ga_mlp_linear). */
 int64_t d3ga_mlp_chain_panel_bytes(int32_t K, int32_t n_out);
 int d3ga_mlp_pack_chain(int32_t K, int32_t n_out, const float *W, int64_t ld_k, int64_t ld_n, void *panel, d3ga_stream_t stream);
 int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t L, const int32_t *Ks, const int32_t *Ns,

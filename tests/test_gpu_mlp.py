@@ -169,7 +169,8 @@ def test_chain_matches_torch_autograd(P, widths):
 @pytest.mark.parametrize("P,widths,bias", [(700, [11, 128, 128, 128, 128, 11], True), (257, [3, 128, 128, 1], True),
                                           (1000, [80, 128, 128, 64], False), (513, [45, 128, 128, 128], True),
                                           (33, [128, 128, 3], True), (4099, [1, 128, 40], True),
-                                          (140003, [11, 128, 128, 128, 11], True), (70001, [45, 128, 128, 3], True)])
+                                          (140003, [11, 128, 128, 128, 11], True), (70001, [45, 128, 128, 3], True),
+                                          (901, [80, 128, 128, 128, 128, 4], True), (77, [96, 128, 80], False)])
 def test_fused_trunk_matches_per_layer_and_f64(P, widths, bias):
     """The one-launch trunk (d3ga_mlp_chain_fwd: forward, and the backward's input-gradient chain through the same kernel with
     transposed weights and the forward's sign words as masks) on the shapes it is built for -- hidden width 128, 1 / 2 / 4
