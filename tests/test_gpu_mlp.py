@@ -276,6 +276,48 @@ def test_chain_fuzz(seed):
             assert rel_err(b.grad.cpu().numpy(), br.grad.numpy()) < wtol, tag
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_FUSED_FUZZ_FIRST", "0")),
+                                       int(os.environ.get("D3GA_FUSED_FUZZ_N", "8"))))
+def test_fused_trunk_fuzz(seed):
+    """Random trunks of the shapes the one-launch kernel takes (2-6 layers, hidden width 128, 1..128 inputs, 1..128 outputs,
+    with / without bias, slopes 0.1 / 0.01 / none on the hidden layers, 1..3000 rows and now and then more rows than the grid
+    covers in one pass) against torch f64 autograd -- forward, input gradient (the same kernel run backwards) and every weight
+    gradient.  A long campaign: D3GA_FUSED_FUZZ_N=600."""
+    from d3ga_amd import mlp as M
+    rng = np.random.default_rng(9000 + seed)
+    P = int(rng.choice([1, 31, 32, 33, 255, 256, 257, 1000, int(rng.integers(1, 3000)), int(rng.integers(65537, 90000)) if seed % 7 == 3 else 64]))
+    L = int(rng.integers(2, 7))
+    pick = lambda: int(rng.choice([1, 2, 3, 4, 5, 11, 16, 31, 32, 33, 45, 64, 65, 80, 96, 97, 127, 128, int(rng.integers(1, 129))]))
+    widths = [pick()] + [128] * (L - 1) + [pick()]
+    slopes = [float(rng.choice([0.1, 0.01, 1.0])) for _ in range(L - 1)] + [float(rng.choice([1.0, 1.0, 0.1]))]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(P, widths[0], generator=g)
+    layers = [(torch.randn(b, a, generator=g) / a ** 0.5, torch.randn(b, generator=g) if rng.random() < 0.8 else None)
+              for a, b in zip(widths[:-1], widths[1:])]
+    up = torch.randn(P, widths[-1], generator=g)
+    assert M._chain_shapes_ok(P, widths[0], widths[1:])    # (the fused path is the one under test)
+    xr = x.double().requires_grad_(True)
+    lr = [(w.double().requires_grad_(True), None if b is None else b.double().requires_grad_(True)) for w, b in layers]
+    h = xr
+    for (w, b), sl in zip(lr, slopes):
+        h = torch.nn.functional.leaky_relu(torch.nn.functional.linear(h, w, b), sl)
+    h.backward(up.double())
+    xd = x.to(DEV).requires_grad_(True)
+    ld = [(w.to(DEV).requires_grad_(True), None if b is None else b.to(DEV).requires_grad_(True)) for w, b in layers]
+    y = M.mlp_chain(xd, ld, slopes)
+    y.backward(up.to(DEV))
+    tag = (seed, P, widths, slopes)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), h.detach().numpy(), rtol=2e-5, atol=2e-5, err_msg=str(tag))
+    d = (xd.grad.cpu().double() - xr.grad).abs().amax(1) / (xr.grad.abs().max() + 1e-30)
+    flipped = int((d > 2e-5).sum())                        # rows at a leaky_relu kink (see test_chain_fuzz)
+    assert flipped <= max(1, P // 500), (tag, flipped, float(d.max()))
+    wtol = 5e-2 if flipped else 2e-3
+    for (w, b), (wr, br) in zip(ld, lr):
+        assert rel_err(w.grad.cpu().numpy(), wr.grad.numpy()) < wtol, tag
+        if b is not None:
+            assert rel_err(b.grad.cpu().numpy(), br.grad.numpy()) < wtol, tag
+
+
 def test_field_networks_survive_stream_capture():
     """CanonicalField + ColorField forward + backward captured in a hipGraph replay to the eager gradients.  (Regression:
     the split-weight cache used to pin the `first.weight[:, n_pose:]` VIEW itself, a tensor that carries the grad_fn of an
