@@ -311,7 +311,8 @@ def test_fused_trunk_fuzz(seed):
     d = (xd.grad.cpu().double() - xr.grad).abs().amax(1) / (xr.grad.abs().max() + 1e-30)
     flipped = int((d > 2e-5).sum())                        # rows at a leaky_relu kink (see test_chain_fuzz)
     assert flipped <= max(1, P // 500), (tag, flipped, float(d.max()))
-    wtol = 5e-2 if flipped else 2e-3
+    # a flipped row moves the weight gradients below it by up to its share of the sum (seed 504: one of 32 rows, 12 %)
+    wtol = min(0.5, max(5e-2, 8.0 * flipped / P)) if flipped else 2e-3
     for (w, b), (wr, br) in zip(ld, lr):
         assert rel_err(w.grad.cpu().numpy(), wr.grad.numpy()) < wtol, tag
         if b is not None:
