@@ -18,6 +18,8 @@ EXTRA = {"raster_composite_scan.hip": ["-fno-slp-vectorize"],
          "raster_composite.hip": ["-fno-slp-vectorize"]}      # forward 117 -> 103 us at C3: packed f32 ops cost 2x, plus their shuffles
 if os.environ.get("D3GA_CHAIN_WAVES"):                        # A/B: wavefronts per workgroup of the fused field-network kernel
     FLAGS.append("-DD3GA_CHAIN_WAVES=" + os.environ["D3GA_CHAIN_WAVES"])
+if os.environ.get("D3GA_CHAIN_CS"):                           # A/B: k-steps per weight chunk of the fused field-network kernel
+    FLAGS.append("-DD3GA_CHAIN_CS=" + os.environ["D3GA_CHAIN_CS"])
 if os.environ.get("D3GA_ALL_NOSLP"):                          # A/B: every translation unit
     FLAGS.append("-fno-slp-vectorize")
 if ABL:

@@ -645,7 +645,12 @@ __global__ __launch_bounds__(128) void chain_bias_kernel(ChainBiasArgs a) {
     a.tail[l][u] = (a.bias[l] && u < a.N[l]) ? a.bias[l][u] : 0.f;
 }
 
-constexpr int kChainSlotUnits = 3 * 2 * 4 * 64;          // one chunk: [plane][2 k-steps][NT tiles][lane] units, <= 24 KB
+#ifndef D3GA_CHAIN_CS
+#define D3GA_CHAIN_CS 2
+#endif
+constexpr int kChainCS = D3GA_CHAIN_CS;                   // k-steps per chunk (2 or 4; layer 0's last chunk may hold 2 of 4)
+static_assert(kChainCS == 2 || kChainCS == 4, "chunk = 2 or 4 k-steps");
+constexpr int kChainSlotUnits = 3 * kChainCS * 4 * 64;   // one chunk: [plane][k-steps][NT tiles][lane] units, <= 24 / 48 KB
 constexpr int kChainSlots = 2;                           // the current chunk and the next one
 constexpr int kChainStageLd = 36;
 typedef __attribute__((address_space(3))) void lds_void;
@@ -703,32 +708,33 @@ __device__ __forceinline__ void chain_barrier_only() { asm volatile("s_waitcnt l
 
 // LDS-DMA of chunk c (k-steps 2c, 2c + 1) of a layer's panel (KS k-steps, NT tiles) into a slot: 6 NT pieces of 1 KB, dealt
 // round robin to the 4 wavefronts; with c == 0 also the bias tail (512 bytes).  No registers involved.
-template <int NT>
-__device__ __forceinline__ void chain_issue(const uint4 *panel, int KS, int c, uint4 *slot, float *bias_dst, int wave, int lane) {
+template <int NT, int NS>
+__device__ __forceinline__ void chain_issue(const uint4 *panel, int KS, int s0, uint4 *slot, float *bias_dst, int wave, int lane) {
+    constexpr int pieces = 3 * NS * NT;                    // 1 KB each: [plane][k-step s0 .. s0 + NS)[tile]
 #pragma unroll
-    for (int i = 0; i < (6 * NT + kChainWaves - 1) / kChainWaves; ++i) {
+    for (int i = 0; i < (pieces + kChainWaves - 1) / kChainWaves; ++i) {
         const int q = wave + kChainWaves * i;              // (scalar)
-        if (q < 6 * NT) {
-            const int pl = q / (2 * NT), rem = q - pl * (2 * NT);
-            lds_dma16(panel + ((size_t)(pl * KS + 2 * c) * NT + rem) * 64 + lane, slot + q * 64);
+        if (q < pieces) {
+            const int pl = q / (NS * NT), rem = q - pl * (NS * NT);
+            lds_dma16(panel + ((size_t)(pl * KS + s0) * NT + rem) * 64 + lane, slot + q * 64);
         }
     }
-    if (c == 0 && wave == 0 && lane < 32) lds_dma16(panel + (size_t)3 * KS * NT * 64 + lane, bias_dst);
+    if (s0 == 0 && wave == 0 && lane < 32) lds_dma16(panel + (size_t)3 * KS * NT * 64 + lane, bias_dst);
 }
 
-// The MFMAs of one chunk: k-steps S0, S0 + 1 of the layer against the activations in registers 8 S0 .. 8 S0 + 15.
-template <int NT, int S0, class Mid>
+// The MFMAs of one chunk: k-steps S0 .. S0 + NS - 1 of the layer against the activations in registers 8 S0 .. 8 (S0 + NS) - 1.
+template <int NT, int S0, int NS, class Mid>
 __device__ __forceinline__ void chain_chunk(const uint4 *slot, const float (&act)[64], f32x16 (&acc)[4], int lane, Mid &&mid) {
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-        if (sl == 1) mid();                                // (between the two k-steps: the second half of the wavefronts starts its DMA here)
+    for (int sl = 0; sl < NS; ++sl) {
+        if (sl == NS / 2) mid();                           // (half way: the second half of the wavefronts starts its DMA here)
         uint32_t b0[4], b1[4], b2[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) bf16_split2(act[8 * (S0 + sl) + 2 * jj], act[8 * (S0 + sl) + 2 * jj + 1], b0[jj], b1[jj], b2[jj]);
         const bf16x8_t x0 = __builtin_bit_cast(bf16x8_t, make_uint4(b0[0], b0[1], b0[2], b0[3]));
         const bf16x8_t x1 = __builtin_bit_cast(bf16x8_t, make_uint4(b1[0], b1[1], b1[2], b1[3]));
         const bf16x8_t x2 = __builtin_bit_cast(bf16x8_t, make_uint4(b2[0], b2[1], b2[2], b2[3]));
-        constexpr int pstride = 2 * NT * 64;               // units per plane in the slot
+        constexpr int pstride = NS * NT * 64;              // units per plane in the slot
         if constexpr (NT == 1) {
             const uint4 *wa = slot + sl * 64 + lane;
             const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, wa[0]), a1 = __builtin_bit_cast(bf16x8_t, wa[pstride]),
@@ -862,20 +868,24 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
     const int nblocks = (P + kChainRows - 1) / kChainRows;
     float *s_stage = s_bias + 3 * 128 + wave * (32 * kChainStageLd);      // the wavefront's transposition tile: 32 rows x (32 + 4) floats
     const int L = args.L, abl = args.abl;
-    const int KS0 = chain_ksteps(K0), nch0 = KS0 / 2;
+    const int KS0 = chain_ksteps(K0), nch0 = (KS0 + kChainCS - 1) / kChainCS;
+    constexpr int kNch = 8 / kChainCS;                     // chunks of a 128-input layer
     const bool early = wave < kChainWaves / 2 || (abl & 32);           // (abl 32: every wavefront at the start of the chunk)
     auto slot = [&](int g) { return s_slot0 + (size_t)g * kChainSlotUnits; };
     // bias buffers: a layer's bias arrives with its first chunk, i.e. during the last chunk of the layer before -- for layer 0
     // of the NEXT row block that is the last layer of this one, whose epilogue is still to come.  Layers 0 .. L - 2 alternate
     // between two buffers, the last layer has its own.
     auto bias_of = [&](int l) { return s_bias + (l == L - 1 ? 2 : (l & 1)) * 128; };
-    // chunk (l, c): layers 0 .. L - 2 have 4 output tiles, the last one NTL; layer 0 has nch0 chunks, the others 4
+    // chunk (l, c) = k-steps [CS c, CS c + ns): layers 0 .. L - 2 have 4 output tiles, the last one NTL; layer 0 has nch0
+    // chunks (its last one may hold 2 k-steps of 4), the others 8 / CS full ones
     auto issue = [&](int l, int c, int g) {
         if (abl & 2) return;
         const uint4 *panel = args.layer[l].panel;
         const int KS = l == 0 ? KS0 : 8;
-        if (l == L - 1) chain_issue<NTL>(panel, KS, c, slot(g), bias_of(l), wave, lane);
-        else chain_issue<4>(panel, KS, c, slot(g), bias_of(l), wave, lane);
+        const bool full = kChainCS == 2 || KS - kChainCS * c >= kChainCS;
+        if (l == L - 1) chain_issue<NTL, kChainCS>(panel, KS, kChainCS * c, slot(g), bias_of(l), wave, lane);
+        else if (full) chain_issue<4, kChainCS>(panel, KS, kChainCS * c, slot(g), bias_of(l), wave, lane);
+        else chain_issue<4, 2>(panel, KS, kChainCS * c, slot(g), bias_of(l), wave, lane);
     };
     if ((int)blockIdx.x < nblocks) issue(0, 0, 0);
     chain_sync();                                          // chunk 0 is in place
@@ -926,14 +936,15 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
         };
         // ---- layers 0 .. L - 2: 128 outputs
         for (int l = 0; l + 1 < L; ++l) {
-            const int nch = l == 0 ? nch0 : 4;
+            const int nch = l == 0 ? nch0 : kNch;
+            const int KS = l == 0 ? KS0 : 8;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             static_for_4([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                if (c < nch) {                              // (uniform)
+                if (c < kNch && c < nch) {                  // (uniform)
                     // the next chunk goes into the other slot: every wavefront finished reading it before the barrier that
                     // ended the previous chunk
                     // the DMA instructions hold the issuing wavefront for a long time (measured: ~100 us of the kernel whatever
@@ -945,8 +956,10 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
                     };
                     if (early) next();
                     if (c + 1 >= nch) load_mask(args.layer[l], 4);
-                    if (!(abl & 4)) chain_chunk<4, 2 * c>(slot(g), act, acc, lane, [&]() { if (!early) next(); });
-                    else if (!early) next();
+                    const bool full = kChainCS == 2 || KS - kChainCS * c >= kChainCS;      // (layer 0's last chunk: 2 of 4 k-steps)
+                    if (abl & 4) { if (!early) next(); }
+                    else if (full) chain_chunk<4, kChainCS * c, kChainCS>(slot(g), act, acc, lane, [&]() { if (!early) next(); });
+                    else chain_chunk<4, kChainCS * c, 2>(slot(g), act, acc, lane, [&]() { if (!early) next(); });
                     if (c + 1 < nch) {
                         chain_sync();      // this slot is free again, and the next chunk's DMA has landed
                         g ^= 1;
@@ -967,17 +980,19 @@ __global__ __launch_bounds__(kChainThreads, 2) void chain_fwd_kernel(int P, int 
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             static_for_4([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                auto next = [&]() {
-                    if (c + 1 < 4) issue(l, c + 1, g ^ 1);
-                    else if (more_blocks) issue(0, 0, g ^ 1);
-                };
-                if (early) next();
-                if (c + 1 >= 4) load_mask(args.layer[l], NTL);
-                if (!(abl & 4)) chain_chunk<NTL, 2 * c>(slot(g), act, acc, lane, [&]() { if (!early) next(); });
-                else if (!early) next();
-                if (c + 1 < 4) {
-                    chain_sync();
-                    g ^= 1;
+                if constexpr (c < kNch) {
+                    auto next = [&]() {
+                        if (c + 1 < kNch) issue(l, c + 1, g ^ 1);
+                        else if (more_blocks) issue(0, 0, g ^ 1);
+                    };
+                    if (early) next();
+                    if (c + 1 >= kNch) load_mask(args.layer[l], NTL);
+                    if (!(abl & 4)) chain_chunk<NTL, kChainCS * c, kChainCS>(slot(g), act, acc, lane, [&]() { if (!early) next(); });
+                    else if (!early) next();
+                    if (c + 1 < kNch) {
+                        chain_sync();
+                        g ^= 1;
+                    }
                 }
             });
             chain_wait_dma();
