@@ -126,8 +126,20 @@ def margins(ctx, eps_alpha=1e-5, eps_T=1e-3):
     return pix.astype(bool), gs[:k["P"]].astype(bool)
 
 
-def backward(ctx, dL_dpix):
-    """Returns dict of numpy grads: means3D, means2D(P,3), shs|colors, opacities(P,1), scales, rotations, cov3D."""
+def backward(ctx, dL_dpix, sum_noise=None):
+    """Returns dict of numpy grads: means3D, means2D(P,3), shs|colors, opacities(P,1), scales, rotations, cov3D.
+    sum_noise=(gamma, pattern): conditioning probe -- every per-Gaussian pixel sum is moved by +- gamma x (sum of the absolute
+    values of its terms) before the chain behind it runs (ro_set_sum_noise); the difference to the plain result bounds what the
+    error of a float32 sum (gamma ~ depth x eps) does to each output element."""
+    L = lib()
+    L.ro_set_sum_noise.argtypes = [ctypes.c_double, ctypes.c_int]
+    L.ro_set_sum_noise.restype = None
+    if sum_noise is not None:
+        L.ro_set_sum_noise(float(sum_noise[0]), int(sum_noise[1]))
+        try:
+            return backward(ctx, dL_dpix)
+        finally:
+            L.ro_set_sum_noise(0.0, 0)
     k = ctx.keep
     P, M = k["P"], k["M"]
     dL_dpix = _f(dL_dpix)

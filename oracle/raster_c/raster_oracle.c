@@ -296,7 +296,13 @@ ro_ctx *ro_forward(int P, int M, int deg, int W, int H, const float *means3D, co
                     float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                     if (power > 0.0f) continue;
                     float alpha = fminf(0.99f, co[3] * expf(power));
-                    m_alpha = fminf(m_alpha, fabsf(alpha * 255.0f - 1.0f));
+                    /* distance to the threshold in units of what float32 can resolve HERE: the quadratic form is a sum of
+                     * cancelling terms, its rounding error ~3 eps (|A dx^2| + |C dy^2| + |2 B dx dy|) / 2 is the RELATIVE error of
+                     * alpha -- 1e-7 per unit of term magnitude, i.e. 0.02 eps_alpha per unit at the eps_alpha = 1e-5 the tests
+                     * use: nothing for ordinary splats (terms <= 10), x20 for a frame-filling one 100 px off its centre
+                     * (terms ~1e3; fuzz seed 2446: a flip at relative distance 6e-5 there) */
+                    float tmag = 0.5f * (fabsf(co[0] * dx * dx) + fabsf(co[2] * dy * dy)) + fabsf(co[1] * dx * dy);
+                    m_alpha = fminf(m_alpha, fabsf(alpha * 255.0f - 1.0f) / (1.0f + 0.02f * tmag));
                     if (alpha < 1.0f / 255.0f) continue;
                     float test_T = T * (1 - alpha);
                     m_T = fminf(m_T, fabsf(test_T * 10000.0f - 1.0f));
@@ -322,7 +328,8 @@ ro_ctx *ro_forward(int P, int M, int deg, int W, int H, const float *means3D, co
  * T (1 - alpha) < 1e-4 ends the pixel.  Two correct float32 implementations (different exp, different FMA contraction
  * in the quadratic form) disagree on such a decision whenever the compared value sits within their rounding difference
  * of the threshold; the pixel then moves by up to alpha T <= 1/255 and so do the gradients of the Gaussians on it.  A
- * pixel is MARGINAL when some alpha it evaluated lies within eps_alpha (relative) of 1/255 or some test_T within eps_T
+ * pixel is MARGINAL when some alpha it evaluated lies within eps_alpha (relative, scaled up by the magnitude of the terms of
+ * its quadratic form where that is large: see the forward) of 1/255 or some test_T within eps_T
  * (relative) of 1e-4; a Gaussian is marginal when it can contribute (alpha >= (1 - eps_alpha)/255) to a marginal pixel
  * -- a flipped decision changes T for everything behind it and the colour accumulated behind everything before it.
  * pix_flag (H*W) and gauss_flag (P) receive 0/1.  Parity tests hold every NON-marginal pixel / Gaussian to the strict
@@ -360,6 +367,15 @@ static void atomic_addd(double *p, double v) {
     *p += v;
 }
 
+static double g_sum_noise_sigma = 0.0;
+static int g_sum_noise_pattern = 0;
+void ro_set_sum_noise(double sigma, int pattern) { g_sum_noise_sigma = sigma; g_sum_noise_pattern = pattern; }
+static double noise_sign(int slot, int pattern) {
+    uint32_t h = (uint32_t)slot * 2654435761u ^ ((uint32_t)pattern + 1u) * 0x9E3779B9u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return (h & 1u) ? 1.0 : -1.0;
+}
+
 /* Backward.  dL_dpix (3,H,W).  All outputs must be zero-initialised by the caller; NULL where not applicable. */
 void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const float *scales, const float *rots,
                  const float *dL_dpix, float *dL_dmeans3D, float *dL_dmeans2D /*P,3*/, float *dL_dsh,
@@ -369,6 +385,12 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
     double *dL_drgb = (double *)calloc((size_t)(P > 0 ? P : 1), 24);
     double *dL_dm2 = (double *)calloc((size_t)(P > 0 ? P : 1), 16);
     double *dL_dop = (double *)calloc((size_t)(P > 0 ? P : 1), 8);
+    /* conditioning probe only: the sums of the ABSOLUTE values of the same terms */
+    const int probe = g_sum_noise_sigma != 0.0;
+    double *ab_conic = (double *)calloc((size_t)(probe && P > 0 ? P : 1), 32);
+    double *ab_rgb = (double *)calloc((size_t)(probe && P > 0 ? P : 1), 24);
+    double *ab_m2 = (double *)calloc((size_t)(probe && P > 0 ? P : 1), 16);
+    double *ab_op = (double *)calloc((size_t)(probe && P > 0 ? P : 1), 8);
     float *dL_dcov = dL_dcov3D ? dL_dcov3D : (float *)calloc((size_t)(P > 0 ? P : 1), 24);
 
 #pragma omp parallel for schedule(dynamic, 4)
@@ -402,6 +424,7 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
                         last_color[ch] = col;
                         dL_dalpha += (col - accum[ch]) * dLp[ch];
                         atomic_addd(&dL_drgb[3 * g + ch], dch * dLp[ch]);
+                        if (probe) atomic_addd(&ab_rgb[3 * g + ch], fabsf(dch * dLp[ch]));
                     }
                     dL_dalpha *= T;
                     last_alpha = alpha;
@@ -416,10 +439,33 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
                     atomic_addd(&dL_dconic[4 * g + 1], -0.5f * gdx * dy * dL_dG); /* HALF of dL/dB; doubled below */
                     atomic_addd(&dL_dconic[4 * g + 3], -0.5f * gdy * dy * dL_dG);
                     atomic_addd(&dL_dop[g], G * dL_dalpha);
+                    if (probe) {
+                        atomic_addd(&ab_m2[2 * g], fabsf(dL_dG * dG_ddelx * 0.5f * W));
+                        atomic_addd(&ab_m2[2 * g + 1], fabsf(dL_dG * dG_ddely * 0.5f * H));
+                        atomic_addd(&ab_conic[4 * g], fabsf(0.5f * gdx * dx * dL_dG));
+                        atomic_addd(&ab_conic[4 * g + 1], fabsf(0.5f * gdx * dy * dL_dG));
+                        atomic_addd(&ab_conic[4 * g + 3], fabsf(0.5f * gdy * dy * dL_dG));
+                        atomic_addd(&ab_op[g], fabsf(G * dL_dalpha));
+                    }
                 }
             }
     }
 
+    /* Conditioning probe (tests/util.py: conditioning_noise): every per-Gaussian pixel sum is moved by +- gamma x (the sum of
+     * the absolute values of its terms), sign from a hash of (slot, pattern) -- the textbook bound on the error of a float32
+     * sum taken in any order (gamma = depth x eps), which a GPU implementation and upstream's float atomics carry in these
+     * sums while this oracle sums in double.  How far the OUTPUTS move under it measures how ill-conditioned the chain behind
+     * the sums is for that Gaussian (a frame-filling splat: the terms of dL/dconic carry dx^2 ~ 1e4 and alternate in sign, and
+     * the conic -> cov2D step cancels again).  gamma = 0: off. */
+    if (probe) {
+        for (int i = 0; i < P; i++) {
+            for (int k = 0; k < 4; k++) dL_dconic[4 * i + k] += g_sum_noise_sigma * ab_conic[4 * i + k] * noise_sign(4 * i + k, g_sum_noise_pattern);
+            for (int k = 0; k < 3; k++) dL_drgb[3 * i + k] += g_sum_noise_sigma * ab_rgb[3 * i + k] * noise_sign(3 * i + k + 101, g_sum_noise_pattern);
+            for (int k = 0; k < 2; k++) dL_dm2[2 * i + k] += g_sum_noise_sigma * ab_m2[2 * i + k] * noise_sign(2 * i + k + 202, g_sum_noise_pattern);
+            dL_dop[i] += g_sum_noise_sigma * ab_op[i] * noise_sign(i + 303, g_sum_noise_pattern);
+        }
+    }
+    free(ab_conic); free(ab_rgb); free(ab_m2); free(ab_op);
     for (int i = 0; i < P; i++) {
         dL_dmeans2D[3 * i] = (float)dL_dm2[2 * i]; dL_dmeans2D[3 * i + 1] = (float)dL_dm2[2 * i + 1];
         dL_dopacity[i] = (float)dL_dop[i];
@@ -443,6 +489,15 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
             float b = TS[0] * T[3] + TS[1] * T[4] + TS[2] * T[5];
             float cc = TS[3] * T[3] + TS[4] * T[4] + TS[5] * T[5] + 0.3f;
             float dcx = (float)dL_dconic[4 * i], dcy = (float)dL_dconic[4 * i + 1], dcz = (float)dL_dconic[4 * i + 3];
+            if (g_sum_noise_sigma != 0.0) {
+                /* conditioning probe, second part: the cov2D entries carry their own float32 rounding (2 ulp here), and the
+                 * step behind them -- d conic / d cov2D, written with (denom - a c) = -b^2 as upstream writes it -- cancels
+                 * catastrophically for a splat hundreds of pixels wide (a c ~ 1e8 against b^2): two float32 evaluations of
+                 * this chain that round differently disagree by what this perturbation shows */
+                a *= 1.0f + 2.4e-7f * (float)noise_sign(7 * i + 1, g_sum_noise_pattern);
+                b *= 1.0f + 2.4e-7f * (float)noise_sign(7 * i + 2, g_sum_noise_pattern);
+                cc *= 1.0f + 2.4e-7f * (float)noise_sign(7 * i + 3, g_sum_noise_pattern);
+            }
             float denom = a * cc - b * b;
             float d2inv = 1.0f / ((denom * denom) + 0.0000001f);
             float dL_da = 0, dL_db = 0, dL_dc = 0;

@@ -8,7 +8,7 @@ import torch
 from oracle import bary as ob
 from oracle import deform as od
 from oracle import raster_c as rc
-from util import Parity, rel_err, scene_inputs
+from util import Parity, conditioning_noise, rel_err, scene_inputs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -1371,12 +1371,17 @@ def test_fuzz_ragged_sizes_and_argument_paths(seed):
     (color * gpix.to(DEV)).sum().backward()
     names = {"means3D": "means3D", "opacities": "opacities", "shs": "shs", "colors_precomp": "colors",
              "cov3D_precomp": "cov3D", "scales": "scales", "rotations": "rotations"}
+    # scale_mult up to 8 makes splats that fill these small frames: the chain behind their pixel sums is ill-conditioned in
+    # float32 (tests/util.py: conditioning_noise), and the element-wise bar is widened by exactly what the error bound of a
+    # float32 sum (16 eps x sum |terms|) in those sums does to each element -- nothing for ordinary splats
+    noise = None                                           # (six more oracle backward passes: only when the plain bar fails)
     for k, t in args.items():
         ref = og[names[k]]
         if np.abs(ref).max() == 0:
             assert float(t.grad.abs().max()) == 0
-        else:
-            _assert_grads(par, ((t.grad, ref, k),))
+        elif not par.grads(_np(t.grad), ref)[0]:
+            noise = conditioning_noise(ctx, _np(gpix), og) if noise is None else noise
+            _assert_grads(par, ((t.grad, ref, k),), noise=noise[names[k]])
 
 
 def test_nan_and_inf_inputs_are_contained():

@@ -127,8 +127,8 @@ def test_front_to_back_order_and_termination():
 
 
 def test_decision_margins_flag_threshold_pixels_and_their_gaussians():
-    """oracle.raster_c.margins: a pixel is marginal when an evaluated alpha sits within eps of 1/255 (or a test_T within eps of
-    1e-4); a Gaussian is marginal when it can contribute to such a pixel.  Checked against a direct evaluation."""
+    """oracle.raster_c.margins: a pixel is marginal when an evaluated alpha sits within eps (scaled by 1 + 0.02 x the magnitude of
+    the quadratic form's terms: its float32 rounding is the relative error of alpha) of 1/255 (or a test_T within eps of 1e-4); a Gaussian is marginal when it can contribute to such a pixel.  Checked against a direct evaluation."""
     W = H = 33
     fov = 0.6
     f = W / (2 * math.tan(fov / 2))
@@ -143,7 +143,8 @@ def test_decision_margins_flag_threshold_pixels_and_their_gaussians():
     s2 = (f * sigma / z) ** 2 + 0.3
     ys, xs = np.mgrid[0:H, 0:W]
     alpha = np.minimum(0.99, o * np.exp(-0.5 * ((xs - 16.0) ** 2 + (ys - 16.0) ** 2) / s2))
-    rel = np.abs(alpha * 255.0 - 1.0)
+    tmag = 0.5 * ((xs - 16.0) ** 2 + (ys - 16.0) ** 2) / s2            # magnitude of the quadratic form's terms (B = 0 here)
+    rel = np.abs(alpha * 255.0 - 1.0) / (1.0 + 0.02 * tmag)            # distance in units of what float32 resolves there
     inside = np.hypot(xs - 16.0, ys - 16.0) <= radii[0] + 16          # pixels whose tile holds the splat at all
     for eps in (0.5, 0.05):
         pix, gs = rc.margins(ctx, eps_alpha=eps, eps_T=0.0)

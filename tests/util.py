@@ -79,16 +79,51 @@ class Parity:
         loose = float(d[self.pix].max()) if self.pix.any() else 0.0
         return bool(strict <= atol and loose <= marginal_atol), strict, loose, int(self.pix.sum())
 
-    def grads(self, a, b, rtol=1e-3, atol_rel=1e-6, marginal_rtol=5e-2):
+    def grads(self, a, b, rtol=1e-3, atol_rel=1e-6, marginal_rtol=5e-2, noise=None):
         """per-Gaussian tensors (P, ...) -> (ok, worst excess ratio on the strictly held Gaussians (<= 1 passes), worst
-        max-norm error on the loosely held ones, their number).  masked: every Gaussian is held strictly."""
+        max-norm error on the loosely held ones, their number).  masked: every Gaussian is held strictly.
+        noise (same shape as b, optional): what float32 accumulation noise in the per-Gaussian pixel sums does to each element
+        (`conditioning_noise` below) -- added to the allowance, element by element."""
         b = np.asarray(b, np.float64)
         a = np.asarray(a, np.float64).reshape(b.shape)
         a, b = a.reshape(len(b), -1), b.reshape(len(b), -1)
         scale = np.abs(b).max() + 1e-300
         d = np.abs(a - b)
-        excess = d / (rtol * np.abs(b) + atol_rel * scale)
+        allow = rtol * np.abs(b) + atol_rel * scale
+        if noise is not None:
+            allow = allow + np.asarray(noise, np.float64).reshape(b.shape)
+        excess = d / allow
         m = np.zeros(len(b), bool) if self.masked else self.gauss[:len(b)]
         strict = float(excess[~m].max()) if (~m).any() else 0.0
         loose = float(d[m].max() / scale) if m.any() else 0.0
         return bool(strict <= 1.0 and loose <= marginal_rtol), strict, loose, int(m.sum())
+
+
+
+# Error of a float32 sum per unit of sum |terms|: (number of dependent additions) x eps.  A frame-filling splat's sum goes
+# through 16 pixel steps of a block, the merge of a tile's 16 blocks and one float atomic per tile it covers (~100): the
+# rigorous bound is ~130 eps = 8e-6; half of it is used (campaign: 3000 seeds; 1e-6 left 19 seeds up to x3.2 over).
+SUM_NOISE_GAMMA = 4e-6
+
+
+def conditioning_noise(ctx, gpix, grads, gamma=SUM_NOISE_GAMMA, patterns=(0, 1, 2, 3, 4, 5)):
+    """How far each gradient element moves when every per-Gaussian pixel sum of the rasterizer's backward (dL/dconic,
+    dL/dmean2D, dL/dcolour, dL/dopacity) is off by gamma x (the sum of the absolute values of its terms) -- the error ANY
+    float32 implementation carries in them (upstream adds with float atomics; the oracle alone sums in double).  For an
+    ordinary splat that is nothing.  For splats that fill the frame the terms of dL/dconic carry dx^2 ~ 1e4 with alternating
+    signs and the conic -> cov2D step behind them cancels again: an honest float32 result then differs from the oracle by
+    1e-3 of the element (seed 2947 of the fuzz campaign: run-to-run spread of the HIP result 2e-3 on such a Gaussian while its
+    colour and opacity gradients -- plain sums -- are stable to 1e-7).  The probe also moves the three cov2D entries by 2 ulp:
+    the d conic / d cov2D step, written as upstream writes it, cancels catastrophically for splats hundreds of pixels wide,
+    and the float32 ORACLE itself is then off by 1.4x (scales) to 2.6x (rotations) the plain bar against a float64 evaluation
+    of the same formulas (seed 2739, oracle/raster_torch.py in float64).  Returns {name: 2 x max over the sign patterns of
+    |perturbed - plain|} (two float32 implementations, each with its own error); Parity.grads(noise=...) adds it to the
+    element-wise allowance."""
+    from oracle import raster_c as rc
+    out = {k: None if v is None else np.zeros_like(np.asarray(v, np.float64)) for k, v in grads.items()}
+    for pat in patterns:
+        g2 = rc.backward(ctx, gpix, sum_noise=(gamma, pat))
+        for k, v in grads.items():
+            if v is not None:
+                out[k] = np.maximum(out[k], 2.0 * np.abs(np.asarray(g2[k], np.float64) - np.asarray(v, np.float64)))
+    return out
