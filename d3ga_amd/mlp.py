@@ -32,9 +32,12 @@ def _panel(weight, transpose):
     GEMM, which contracts over the layer's outputs (input n_layer, output k_layer: weight[n_layer][k_layer]).  Cached per
     (storage, version): an optimizer step bumps the version and the next call re-packs (one tiny launch)."""
     key = (weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()), transpose)
-    hit = _panels.get(key)
+    # Under stream capture the pack itself must be IN the graph: a cache hit would bake today's panel into a graph that is
+    # replayed after an optimizer has changed the weights in place (no version check can run at replay time).
+    capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()
+    hit = None if capturing else _panels.get(key)
     if hit is None:
-        if len(_panels) > 64:
+        if len(_panels) > 64 and not capturing:
             _panels.clear()
         w = weight.detach()
         if w.dtype != torch.float32:
@@ -50,7 +53,8 @@ def _panel(weight, transpose):
         # holds the weight's STORAGE alive (its address cannot be recycled) through detached aliases: a cached view that
         # still carried the grad_fn of an earlier forward made PyTorch-ROCm 2.10 crash in capture_end() of a later capture
         hit = (p, weight.detach(), w)
-        _panels[key] = hit
+        if not capturing:
+            _panels[key] = hit
     return hit[0]
 
 
@@ -69,9 +73,10 @@ def _chain_panel(weight, transposed=False):
     the bias, which every call writes itself.  transposed: the panel of W^T (the backward's input-gradient chain).  Cached
     per weight version like `_panel`."""
     key = (weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()), bool(transposed))
-    hit = _chain_panels.get(key)
+    capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()      # (see _panel: the pack goes into the graph)
+    hit = None if capturing else _chain_panels.get(key)
     if hit is None:
-        if len(_chain_panels) > 64:
+        if len(_chain_panels) > 64 and not capturing:
             _chain_panels.clear()
         w = weight.detach()
         if w.dtype != torch.float32:
@@ -84,7 +89,8 @@ def _chain_panel(weight, transposed=False):
         p = torch.empty(nbytes // 4, dtype=torch.int32, device=w.device)
         check(_lib.lib().d3ga_mlp_pack_chain(K, N, dptr(w), s_k, s_n, dptr(p), stream_handle()), "d3ga_mlp_pack_chain")
         hit = (p, weight.detach(), w)              # (detached aliases keep the storage alive: see _panel)
-        _chain_panels[key] = hit
+        if not capturing:
+            _chain_panels[key] = hit
     return hit[0]
 
 

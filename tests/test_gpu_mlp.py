@@ -362,6 +362,60 @@ def test_field_networks_survive_stream_capture():
         assert rel_err(t.grad.cpu().numpy(), r.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_captured_trunk_follows_in_place_weight_updates(fused):
+    """A hipGraph of a trunk must repack its weight panels at every replay: an optimizer changes the weights IN PLACE between
+    replays, and a panel cached at capture time would silently keep the old network (the cache is keyed by the tensor's version,
+    which nothing can check at replay time).  Replay after `w += delta` against the eager result with the new weights."""
+    from d3ga_amd import mlp as M
+    M.set_fused_forward(fused)
+    try:
+        g = torch.Generator().manual_seed(3)
+        P = 777
+        x = torch.randn(P, 11, generator=g).to(DEV)
+        layers = [(torch.randn(b, a, generator=g).div(a ** 0.5).to(DEV).requires_grad_(True), torch.randn(b, generator=g).to(DEV).requires_grad_(True))
+                  for a, b in ((11, 128), (128, 128), (128, 7))]
+        slopes = [0.1, 0.1, 1.0]
+        up = torch.randn(P, 7, generator=g).to(DEV)
+
+        def step():
+            for w, b in layers:
+                w.grad = None; b.grad = None
+            y = M.mlp_chain(x, layers, slopes)
+            y.backward(up)
+            return y.detach()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for w, b in layers:
+            w.grad = None; b.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            y_static = step()
+        graph.replay()
+        torch.cuda.synchronize()
+        with torch.no_grad():                              # what an optimizer does
+            for w, b in layers:
+                w.add_(0.05 * torch.randn(w.shape, generator=g).to(DEV))
+                b.mul_(0.5)
+        graph.replay()
+        torch.cuda.synchronize()
+        y_cap = y_static.clone()
+        gw_cap = [layers[i][0].grad.clone() for i in range(3)]
+        y_eager = step().clone()
+        torch.cuda.synchronize()
+        assert rel_err(y_cap.cpu().numpy(), y_eager.cpu().numpy()) < 1e-6
+        for i in range(3):
+            assert rel_err(gw_cap[i].cpu().numpy(), layers[i][0].grad.cpu().numpy()) < 1e-5
+    finally:
+        M.set_fused_forward(True)
+
+
 @pytest.mark.parametrize("spread", [0.0, 4.0])
 def test_split_bf16_products_have_f32_accuracy(spread):
     """The dense layer splits every f32 operand exactly into three bf16 pieces and keeps six of the nine cross products
