@@ -1090,7 +1090,8 @@ def main():
         out = {
             "metric": "fwd+bwd frames/sec @500k Gaussians 1920x1080" if args.workload == "C3" else f"fwd+bwd frames/sec ({wl.name})",
             "value": round(world * kv * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "settle_steps": max(0, args.settle), "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+            "warmup": args.warmup, "settle_steps": max(0, args.settle), "lib_sha256": lib_sha256(),
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.name + ("" if (args.scale_mult == 1.0 and args.fill == 0.85) else
                                               f" [sensitivity: scales x{args.scale_mult:g}, body fills {args.fill:g} of the image height]"),
