@@ -55,11 +55,34 @@ __device__ __forceinline__ uint32_t bf16_pack(float a, float b) {
 __device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 // x = p0 + p1 + p2 exactly (each piece a bf16; the subtractions are exact)
+// The residuals come from v_dot2c_f32_bf16 (acc += a.lo b.lo + a.hi b.hi) with b = (-1, 0) / (0, -1): x - float(piece) in ONE
+// instruction instead of unpack + subtract -- 7 VALU per pair of values instead of 11.  On this hardware an MFMA and a VALU
+// instruction of different wavefronts do not overlap on a SIMD (tools/micro/mfma_valu_overlap.hip: 72 + 97 -> 162 us), so every
+// VALU instruction of these kernels costs matrix time.  Exact: the product with -1 is exact, the other one is a true zero, and
+// x - piece is representable (the piece is x rounded to 8 significant bits).
+#ifndef D3GA_SPLIT_DOT2
+#define D3GA_SPLIT_DOT2 1
+#endif
 __device__ __forceinline__ void bf16_split2(float x, float y, uint32_t &p0, uint32_t &p1, uint32_t &p2) {
+#if D3GA_SPLIT_DOT2
+    // (-1, 0) and (0, -1) as packed bf16 in SGPRs the compiler cannot see through: written as constants it encodes (-1, 0) as
+    // the INLINE constant -1.0, which this instruction does not read as a bf16 pair (every result was garbage)
+    uint32_t k_lo = 0x0000BF80u, k_hi = 0xBF800000u;
+    asm volatile("" : "+s"(k_lo), "+s"(k_hi));
+    const bf16x2_t m_lo = __builtin_bit_cast(bf16x2_t, k_lo), m_hi = __builtin_bit_cast(bf16x2_t, k_hi);
+    p0 = bf16_pack(x, y);
+    const float r0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p0), m_lo, x, false);
+    const float r1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p0), m_hi, y, false);
+    p1 = bf16_pack(r0, r1);
+    const float s0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p1), m_lo, r0, false);
+    const float s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, p1), m_hi, r1, false);
+    p2 = bf16_pack(s0, s1);
+#else
     p0 = bf16_pack(x, y);
     const float r0 = x - bf16_lo(p0), r1 = y - bf16_hi(p0);
     p1 = bf16_pack(r0, r1);
     p2 = bf16_pack(r0 - bf16_lo(p1), r1 - bf16_hi(p1));
+#endif
 }
 
 // Weight planes for linear_kernel: unit (plane, kk, half, nb, n32) = the 8 bf16 pieces w[k = 16 kk + 8 half + j][n = 32 nb + n32],
