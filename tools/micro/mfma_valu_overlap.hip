@@ -6,13 +6,24 @@
 #include <cstdio>
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
-__global__ __launch_bounds__(512) void k(int mode, int n_mfma, int n_valu, float *out) {
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+__global__ __launch_bounds__(512) void k(int mode, int n_mfma, int n_valu, float *out, int small) {
     const int wave = threadIdx.x >> 6;
     float r = 0.f;
     if (wave < 4) {
         if (mode & 1) {
             bf16x8_t a, b;
             for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(threadIdx.x + i); b[i] = (__bf16)(float)(i + 1); }
+            if (small) {                                    // 16x16x32: 4 passes, 4 accumulator registers
+                f32x4 d0 = {0}, d1 = {0}, d2 = {0}, d3 = {0};
+                for (int i = 0; i < 2 * n_mfma; i += 4) {
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, d1, 0, 0, 0);
+                    d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, d2, 0, 0, 0);
+                    d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, d3, 0, 0, 0);
+                }
+                r = d0[0] + d1[1] + d2[2] + d3[3];
+            } else {
             f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
             for (int i = 0; i < n_mfma; i += 4) {
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
@@ -21,6 +32,7 @@ __global__ __launch_bounds__(512) void k(int mode, int n_mfma, int n_valu, float
                 c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
             }
             r = c0[0] + c1[1] + c2[2] + c3[3];
+            }
         }
     } else if (mode & 2) {
         float x0 = threadIdx.x, x1 = 1.f, x2 = 2.f, x3 = 3.f, x4 = 4.f, x5 = 5.f, x6 = 6.f, x7 = 7.f;
@@ -37,14 +49,15 @@ int main() {
     float *out; hipMalloc(&out, 4096);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int n_mfma = 4096, n_valu = 32768;      // 4096 x 32 cycles = 131k cycles; 32768 x 4 cycles = 131k cycles
+    for (int small : {0, 1})
     for (int mode : {1, 2, 3, 1, 2, 3}) {
-        hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, mode, n_mfma, n_valu, out);
+        hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, mode, n_mfma, n_valu, out, small);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, mode, n_mfma, n_valu, out);
+        hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, mode, n_mfma, n_valu, out, small);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("mode %d (%s): %.1f us\n", mode, mode == 1 ? "MFMA only" : mode == 2 ? "VALU only" : "both", 1e3f * ms);
+        printf("%s mode %d (%s): %.1f us\n", small ? "16x16x32" : "32x32x16", mode, mode == 1 ? "MFMA only" : mode == 2 ? "VALU only" : "both", 1e3f * ms);
     }
     return 0;
 }
