@@ -7,6 +7,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PATH = os.environ.get("D3GA_LIB_PATH") or os.path.join(_HERE, "libd3ga_hip.so")
 _lib = None
 ACC_STRIDE = 16          # D3GA_ACC_STRIDE (include/d3ga.h): floats per Gaussian in the screen-space gradient accumulator
+# Bumped by every graph replay (graph.CapturedStep / CapturedCutStep): a replayed optimizer updates weights IN PLACE without
+# touching their `_version`, so host-side caches keyed by (data_ptr, _version) -- the packed weight panels of mlp.py --
+# carry this epoch in their key as well (eager forward -> replays with in-graph Adam -> eager forward used stale panels).
+replay_epoch = [0]
 LOSS_PARTIALS = 2048     # D3GA_LOSS_PARTIALS (include/d3ga.h): floats of scratch behind a two-stage loss reduction
 
 
@@ -35,6 +39,7 @@ _prm = ctypes.POINTER(RasterParams)
 _SIGNATURES = {
     "d3ga_version": ([], _i),
     "d3ga_status_string": ([_i], ctypes.c_char_p),
+    "d3ga_debug_defaults": ([ctypes.POINTER(ctypes.c_int32)], _i),
     "d3ga_lbs_cage_fwd": ([_i, _i] + [_vp] * 8 + [_vp], _i),
     "d3ga_lbs_cage_bwd": ([_i, _i] + [_vp] * 6 + [_vp], _i),
     "d3ga_cage_deform_fwd": ([_i] + [_vp] * 9 + [_vp], _i),
@@ -110,8 +115,21 @@ def lib():
             fn.restype = res
         if L.d3ga_version() != 100:
             raise D3GAError(f"libd3ga_hip.so version {L.d3ga_version()} does not match the Python layer (100)")
+        info = (ctypes.c_int32 * 8)()
+        L.d3ga_debug_defaults(info)
+        if info[0] != 0 and os.environ.get("D3GA_ALLOW_ABLATION") != "1":
+            raise D3GAError(f"{_PATH} is a timing-ablation build (D3GA_SCAN_ABL={info[0]}): its results are wrong by design. "
+                            "Set D3GA_ALLOW_ABLATION=1 to load it for a timing run.")
         _lib = L
     return _lib
+
+
+def debug_defaults():
+    """d3ga_debug_defaults() as a dict: what the loaded library runs by default and with the current environment."""
+    info = (ctypes.c_int32 * 8)()
+    check(lib().d3ga_debug_defaults(info), "d3ga_debug_defaults")
+    return {"scan_abl": info[0], "diag": info[1], "composite_variant": (info[2], info[3]),
+            "merge_slots": (info[4], info[5]), "tile_assign": (info[6], info[7])}
 
 
 def check(status, what):

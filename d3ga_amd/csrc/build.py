@@ -8,7 +8,11 @@ SOURCES = ["deform.hip", "raster_pre.hip", "raster_bin.hip", "raster_composite.h
 HEADERS = ["d3ga_math.h", "d3ga_internal.h", "raster_pre_body.h", "composite_common.h", os.path.join("..", "..", "include", "d3ga.h")]
 ABL = os.environ.get("D3GA_SCAN_ABL")       # timing ablation of the compositing backward (wrong results): own objects + .so
 DIAG = os.environ.get("D3GA_DIAG") or (("abl" + ABL) if ABL else None)          # diagnostic build: its own objects and its own .so (D3GA_LIB_PATH selects it)
-OUT = os.path.join(HERE, "..", (f"libd3ga_hip_abl{ABL}.so" if ABL else "libd3ga_hip_diag.so") if DIAG else "libd3ga_hip.so")
+# Diagnostic / ablation builds never land in the package directory: tools/_build/ (git-ignored, travels with gpurun).
+# _lib.py refuses an ablation build (d3ga_debug_defaults()[0] != 0: WRONG results by design) unless D3GA_ALLOW_ABLATION=1.
+DIAG_DIR = os.path.abspath(os.path.join(HERE, "..", "..", "tools", "_build"))
+OUT = (os.path.join(DIAG_DIR, f"libd3ga_hip_abl{ABL}.so" if ABL else "libd3ga_hip_diag.so") if DIAG
+       else os.path.join(HERE, "..", "libd3ga_hip.so"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
 # per-source extras.  The entry-per-lane compositing backward is VALU-issue bound; SLP-packing its scalar f32 chains into
@@ -45,7 +49,7 @@ def _newer(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, (f"build_abl{ABL}" if ABL else "build_diag") if DIAG else "build")
+    objdir = os.path.join(DIAG_DIR, f"obj_abl{ABL}" if ABL else "obj_diag") if DIAG else os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     objs = []

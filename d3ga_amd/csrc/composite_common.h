@@ -20,17 +20,21 @@ static inline int composite_variant() {
     }();
     return v;
 }
+constexpr int kDefaultMergeSlots = 512;
 static inline int composite_merge_slots() {        // A/B knob: slots of the tile-level merge cache (256 | 512 | 1024)
     static const int v = [] {
         const char *e = getenv("D3GA_MERGE_SLOTS");
-        return e ? atoi(e) : 512;
+        return e ? atoi(e) : kDefaultMergeSlots;
     }();
     return v;
 }
-static inline int composite_tile_assign() {        // A/B knob: block -> wavefront assignment of the tile kernel (0 quadrants, 1 interleaved, 2 by list length)
+// block -> wavefront assignment of the backward's tile kernel: 0 quadrants, 1 interleaved (blocks 8 px apart), 2 by list
+// length (the default: DESIGN.md sec. 4; d3ga_debug_defaults() reports what THIS library runs and a test pins it)
+constexpr int kDefaultTileAssign = 2;
+static inline int composite_tile_assign() {        // A/B knob (D3GA_TILE_ASSIGN)
     static const int v = [] {
         const char *e = getenv("D3GA_TILE_ASSIGN");
-        return e ? atoi(e) : 1;
+        return e ? atoi(e) : kDefaultTileAssign;
     }();
     return v;
 }

@@ -1217,7 +1217,9 @@ extern "C" int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t
         if (Ks[l] != k_prev || Ns[l] < 1 || Ns[l] > 128) return D3GA_E_SIZE;      // layer l consumes what layer l - 1 produced
         if (!panels[l] || !outs[l]) return D3GA_E_NULL;
         if (((uintptr_t)panels[l] | (uintptr_t)outs[l]) & 15) return D3GA_E_CONFIG;
-        if ((int64_t)P * Ns[l] >= (1ll << 30) || (int64_t)P * Ks[l] >= (1ll << 30)) return D3GA_E_SIZE;     // (byte offsets in 32 bits)
+        // byte offsets in 32 bits -- INCLUDING the rows >= P of the last row block, which rely on the hardware bounds check:
+        // their offsets must not wrap past 2^32 into the buffer's valid range
+        if (((int64_t)P + d3ga::kChainRows) * Ns[l] >= (1ll << 30) || ((int64_t)P + d3ga::kChainRows) * Ks[l] >= (1ll << 30)) return D3GA_E_SIZE;
         a.layer[l] = ChainLayer{reinterpret_cast<const uint4 *>(panels[l]), outs[l], signs[l], masks ? masks[l] : nullptr, Ks[l], Ns[l],
                                 slopes[l], (masks && masks[l] && mask_slopes) ? mask_slopes[l] : 1.f};
         if (masks && masks[l] && (Ns[l] + 31) / 32 == 4 && ((uintptr_t)masks[l] & 15)) return D3GA_E_CONFIG;

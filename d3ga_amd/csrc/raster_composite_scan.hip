@@ -490,6 +490,21 @@ __global__ void row_scan_selftest_kernel(const float *__restrict__ in, float *__
 
 }  // namespace d3ga
 
+// What this build of the library runs by default (and with the current environment): see include/d3ga.h.
+extern "C" int d3ga_debug_defaults(int32_t out[8]) {
+    if (!out) return D3GA_E_NULL;
+    out[0] = D3GA_SCAN_ABL;                     // != 0: a timing ablation -- results are WRONG by design (_lib.py refuses it)
+#ifdef D3GA_DIAG
+    out[1] = 1;
+#else
+    out[1] = 0;
+#endif
+    out[2] = d3ga::kDefaultCompositeVariant; out[3] = d3ga::composite_variant();
+    out[4] = d3ga::kDefaultMergeSlots;       out[5] = d3ga::composite_merge_slots();
+    out[6] = d3ga::kDefaultTileAssign;       out[7] = d3ga::composite_tile_assign();
+    return D3GA_OK;
+}
+
 extern "C" int d3ga_selftest_row_scan(int n, const float *in, float *out, d3ga_stream_t stream) {
     if (n <= 0 || (n % 256) != 0) return D3GA_E_SIZE;
     if (!in || !out) return D3GA_E_NULL;

@@ -23,55 +23,85 @@ synchronises the capture with the default stream, and ending the capture crashes
 """
 import torch
 
+from . import _lib
+
 
 class CapacityOverflowError(RuntimeError):
     """A replayed step produced more (tile, Gaussian) duplicates than the binning capacity frozen into its graph."""
 
 
-class _OverflowWatch:
-    """Asynchronous look at the counter block (D, overflow flag, longest list, visible) of the rasterizer forward a captured
-    graph contains.  The block lives in the graph's private pool, so the tensor seen at capture time stays the one every
-    replay writes."""
+class _capture_forwards:
+    """Context manager: collects (binning tensor, capacity) of EVERY rasterizer forward issued inside (the renders a
+    captured graph contains: RGB + silhouette, k views per rank, several packages)."""
 
-    def __init__(self, check_every):
+    def __enter__(self):
         from . import rasterizer
-        dev = torch.cuda.current_device()
-        ent = rasterizer._last.get(dev)
+        self._mod, self._prev = rasterizer, rasterizer._capture_log
+        rasterizer._capture_log = self.log = []
+        return self.log
+
+    def __exit__(self, *exc):
+        self._mod._capture_log = self._prev
+        return False
+
+
+class _OverflowWatch:
+    """Asynchronous look at the counter blocks (D, overflow flag, longest list, visible) of ALL rasterizer forwards a captured
+    graph contains (`forwards`: the list `_capture_forwards` collected during the capture -- ADVICE r3: the first version
+    watched only the LAST forward seen, so a truncated RGB render in front of a silhouette render went unreported, and a
+    step without any render read a stale block of an earlier eager call).  The blocks live in the graph's private pool, so
+    the tensors seen at capture time stay the ones every replay writes."""
+
+    def __init__(self, check_every, forwards):
         self.every = max(int(check_every), 1)
-        self.block = None if ent is None else ent[0][:16].view(torch.int32)
-        self.cap = None if ent is None else ent[1]
-        self.host = torch.zeros(4, dtype=torch.int32).pin_memory() if self.block is not None else None
+        seen, self.blocks, self.caps = set(), [], []
+        for binning, cap in forwards:
+            if binning.data_ptr() in seen:      # (geometry_reuse: the second render shares the first one's binning buffer)
+                continue
+            seen.add(binning.data_ptr())
+            self.blocks.append(binning[:16].view(torch.int32))
+            self.caps.append(cap)
+        n = len(self.blocks)
+        self.host = torch.zeros(max(n, 1), 4, dtype=torch.int32).pin_memory() if n else None
         self.event, self.count = None, 0
 
+    def _copy(self):
+        for i, b in enumerate(self.blocks):
+            self.host[i].copy_(b, non_blocking=True)
+
     def _inspect(self):
-        d, flag = int(self.host[0]) & 0xFFFFFFFF, int(self.host[1])
         self.event = None
-        if flag:
-            raise CapacityOverflowError(
-                f"captured step: {d} (tile, Gaussian) duplicates exceed the binning capacity {self.cap} frozen into the graph -- "
-                f"the tile lists of the last replays were truncated.  Re-capture with rasterizer.set_capacity_policy('static', n) "
-                f"for n >= {int(1.25 * d)}.")
+        for i, cap in enumerate(self.caps):
+            d, flag = int(self.host[i, 0]) & 0xFFFFFFFF, int(self.host[i, 1])
+            if flag:
+                raise CapacityOverflowError(
+                    f"captured step, render {i} of {len(self.caps)}: {d} (tile, Gaussian) duplicates exceed the binning capacity {cap} "
+                    f"frozen into the graph -- the tile lists of the last replays were truncated.  Re-capture with "
+                    f"rasterizer.set_capacity_policy('static', n) for n >= {int(1.25 * d)}.")
 
     def after_replay(self):
-        if self.block is None:
+        if not self.blocks:
             return
         self.count += 1
         if self.event is not None and self.event.query():
             self._inspect()
         if self.event is None and self.count % self.every == 0:
-            self.host.copy_(self.block, non_blocking=True)
+            self._copy()
             self.event = torch.cuda.Event()
             self.event.record()
 
     def check_now(self):
-        if self.block is None:
+        """dict(D, capacity, max_tile) of the render with the most duplicates (+ "renders": one dict per render)."""
+        if not self.blocks:
             return None
-        self.host.copy_(self.block, non_blocking=True)
+        self._copy()
         torch.cuda.current_stream().synchronize()
-        self.event = None
-        d = int(self.host[0]) & 0xFFFFFFFF
         self._inspect()
-        return {"D": d, "capacity": self.cap, "max_tile": int(self.host[2]) & 0xFFFFFFFF}
+        per = [{"D": int(self.host[i, 0]) & 0xFFFFFFFF, "capacity": self.caps[i], "max_tile": int(self.host[i, 2]) & 0xFFFFFFFF}
+               for i in range(len(self.caps))]
+        worst = dict(max(per, key=lambda r: r["D"]))
+        worst["renders"] = per
+        return worst
 
 
 class TensorSlot:
@@ -175,10 +205,10 @@ class CapturedStep:
         for p in params:
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with _capture_forwards() as forwards, torch.cuda.graph(self.graph):
             self.result = step_fn()
         torch.cuda.synchronize()
-        self._watch = _OverflowWatch(check_every)
+        self._watch = _OverflowWatch(check_every, forwards)
 
     def check_overflow(self):
         """Synchronous look at the last replay's duplicate count: raises CapacityOverflowError, else returns
@@ -191,6 +221,7 @@ class CapturedStep:
         capture time (static tensors holding this replay's results once the stream reaches them)."""
         _update_slots(self, camera, values)
         self.graph.replay()
+        _lib.replay_epoch[0] += 1          # caches keyed by a tensor's version counter: a replay may have written it in place
         self._watch.after_replay()
         return self.result
 
@@ -239,14 +270,14 @@ class CapturedCutStep:
                 p.grad = None
             self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             sync.begin_step()
-            with torch.cuda.graph(self.graph_a):
+            with _capture_forwards() as forwards, torch.cuda.graph(self.graph_a):
                 up, pkg, self.result = self._to_the_cut(upstream, loss_fn)
             sync.exchange_parked()             # (graph A has not run: this call's collectives move unspecified data, on every rank alike)
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
                 self._from_the_cut(up, pkg)
             torch.cuda.synchronize()
             sync.frozen = True                 # the parked buffers are baked into the two graphs now
-            self._watch = _OverflowWatch(check_every)
+            self._watch = _OverflowWatch(check_every, forwards)
         finally:
             sync.deferred = was
 
@@ -294,6 +325,7 @@ class CapturedCutStep:
         self.graph_a.replay()
         self.sync.exchange_parked()
         self.graph_b.replay()
+        _lib.replay_epoch[0] += 1
         self._watch.after_replay()
         return self.result
 
@@ -327,9 +359,11 @@ class ReplayWatchdog:
         ev = self._factory()
         ev.record()
         with self._lock:
-            self._pending.append((ev, tag, time.monotonic()))
-            while len(self._pending) > 64:                 # (only the oldest pending event matters: work completes in order)
-                self._pending.popleft()
+            # Work completes in order, so only the OLDEST pending event decides; when 64 are pending (a hung device with the
+            # host still arming) the NEW event is dropped -- trimming from the left kept moving the head's arm time forward
+            # and the timeout fired late or never.
+            if len(self._pending) < 64:
+                self._pending.append((ev, tag, time.monotonic()))
 
     def _run(self):
         import time

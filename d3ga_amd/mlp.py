@@ -31,7 +31,7 @@ def _panel(weight, transpose):
     forward (weight is (N,K) as in nn.Linear: weight of input k for output n = weight[n][k]); False: the input-gradient
     GEMM, which contracts over the layer's outputs (input n_layer, output k_layer: weight[n_layer][k_layer]).  Cached per
     (storage, version): an optimizer step bumps the version and the next call re-packs (one tiny launch)."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()), transpose)
+    key = (_lib.replay_epoch[0], weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()), transpose)
     # Under stream capture the pack itself must be IN the graph: a cache hit would bake today's panel into a graph that is
     # replayed after an optimizer has changed the weights in place (no version check can run at replay time).
     capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()
@@ -72,7 +72,7 @@ def _chain_panel(weight, transposed=False):
     feature permutation that lets a layer's output registers be the next layer's operand as they are) + 512 bytes of room for
     the bias, which every call writes itself.  transposed: the panel of W^T (the backward's input-gradient chain).  Cached
     per weight version like `_panel`."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()), bool(transposed))
+    key = (_lib.replay_epoch[0], weight.data_ptr(), weight._version, tuple(weight.shape), tuple(weight.stride()), bool(transposed))
     capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()      # (see _panel: the pack goes into the graph)
     hit = None if capturing else _chain_panels.get(key)
     if hit is None:

@@ -45,6 +45,7 @@ class GaussianRasterizationSettings(NamedTuple):
 _policy = {"mode": "auto", "static": 0}
 _hwm = {}            # device index -> high-water mark of D
 _last = {}           # device index -> (binning tensor, capacity) of the most recent forward (for last_counters)
+_capture_log = None  # while graph.CapturedStep / CapturedCutStep capture: list of (binning tensor, capacity) of EVERY forward issued
 
 
 def set_capacity_policy(mode, capacity=0):
@@ -282,6 +283,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 pp, dptr(bg), dptr(geom), dptr(binning), cap, dptr(img), dptr(color), dptr(invdepth), st),
                 "d3ga_raster_composite_fwd"))
             _last[dev.index] = (binning, cap)
+            if _capture_log is not None:
+                _capture_log.append((binning, cap))
         while hit is None or hit["key"] != key:
             geom, binning, img = _scratch(P, W, H, cap, dev, fwd_only)
             if stage_timer.enabled or dual:
@@ -307,6 +310,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                             dptr(img), cap, dptr(color), dptr(radii), dptr(invdepth), stream_handle()),
                       "d3ga_raster_forward")
             _last[dev.index] = (binning, cap)
+            if _capture_log is not None:
+                _capture_log.append((binning, cap))
             if static:
                 break
             cnt = binning[:32].view(torch.int32)[:2].cpu().tolist()       # host sync (upstream: num_rendered)

@@ -34,6 +34,12 @@ typedef void *d3ga_stream_t; /* hipStream_t */
 
 int d3ga_version(void);
 const char *d3ga_status_string(int status);
+/* What this build runs (host only, no device work).  out[0] = D3GA_SCAN_ABL the library was compiled with (0 = product;
+ * anything else is a TIMING ABLATION whose results are wrong by design -- the Python layer refuses such a library unless
+ * D3GA_ALLOW_ABLATION=1), out[1] = 1 for a diagnostic (counter) build, then (compiled default, value in effect with the
+ * current environment) pairs: out[2..3] D3GA_COMPOSITE_VARIANT, out[4..5] D3GA_MERGE_SLOTS, out[6..7] D3GA_TILE_ASSIGN
+ * (block -> wavefront assignment of the compositing backward: 0 quadrants, 1 interleaved, 2 by list length). */
+int d3ga_debug_defaults(int32_t out[8]);
 
 /* ---------------------------------------------------------------------------------------------------------
  * D0  Linear blend skinning of cage vertices (K-sparse weights).

@@ -31,6 +31,27 @@ def test_library_exports_every_declared_symbol():
     assert L.d3ga_status_string(-3) == b"unsupported argument combination"
 
 
+def test_library_defaults_are_the_ones_design_md_states():
+    """docs and binary disagreed about the backward's block -> wavefront assignment.  DESIGN.md carries a
+    machine-readable table of the library's knob defaults; the shipped .so must report exactly those (and must not be a
+    diagnostic or ablation build)."""
+    from d3ga_amd import _lib
+    env = {k: os.environ.pop(k) for k in ("D3GA_COMPOSITE_VARIANT", "D3GA_MERGE_SLOTS", "D3GA_TILE_ASSIGN") if k in os.environ}
+    try:
+        d = _lib.debug_defaults()
+    finally:
+        os.environ.update(env)
+    assert d["scan_abl"] == 0 and d["diag"] == 0, d
+    doc = open(os.path.join(ROOT, "DESIGN.md")).read()
+    stated = dict(re.findall(r"^\| `(D3GA_[A-Z_]+)` \| (\d+) \|", doc, flags=re.M))
+    assert {"D3GA_COMPOSITE_VARIANT", "D3GA_MERGE_SLOTS", "D3GA_TILE_ASSIGN"} <= set(stated), stated
+    assert int(stated["D3GA_COMPOSITE_VARIANT"]) == d["composite_variant"][0]
+    assert int(stated["D3GA_MERGE_SLOTS"]) == d["merge_slots"][0]
+    assert int(stated["D3GA_TILE_ASSIGN"]) == d["tile_assign"][0] == 2      # blocks dealt to wavefronts by list length
+    if not env:
+        assert d["tile_assign"][1] == d["tile_assign"][0] and d["merge_slots"][1] == d["merge_slots"][0]
+
+
 def test_scratch_sizing_and_layout_no_gpu_needed():
     import d3ga_amd
     L = d3ga_amd.lib()

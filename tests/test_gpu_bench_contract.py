@@ -54,3 +54,25 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["views_per_step"] == 2
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) / d["value"] < 0.02          # whole-job frames / max-over-ranks time
     assert d["config"]["grad_exchange"].startswith("cut") and d["config"]["grad_exchange_bytes_per_rank"] > 0
+
+
+def test_bench_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset -- the way the driver starts the N = 1 run -- must start two ranks itself
+    (re-exec under torch.distributed.run) and report them: a line labelled n_gpus 2 from one rank would waste a scaling slot."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
+           "--single-device", "--workload", "C1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["distributed"]["nranks_seen"] == 2 and d["config"]["views_per_step"] == 2
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--single-device", "--workload", "C1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]

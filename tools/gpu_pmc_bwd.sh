@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 pmc() {  # lib tag, pass name, counters...
   lib=$1; name=$2; shift; shift
   rm -rf gpurun_out/pmcb_${lib}_$name
-  ( cd /tmp && D3GA_LIB_PATH=$GRAFT_REPO_ROOT/d3ga_amd/libd3ga_hip${lib:+_$lib}.so timeout 600 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "${KREGEX:-composite_bwd}" --output-format csv \
+  ( cd /tmp && D3GA_ALLOW_ABLATION=1 D3GA_LIB_PATH=$( [ -n "$lib" ] && echo $GRAFT_REPO_ROOT/tools/_build/libd3ga_hip_$lib.so || echo $GRAFT_REPO_ROOT/d3ga_amd/libd3ga_hip.so ) timeout 600 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "${KREGEX:-composite_bwd}" --output-format csv \
       -d "$GRAFT_REPO_ROOT/gpurun_out/pmcb_${lib}_$name" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 3 --no-cpu-baseline --no-train-step --no-stage-events --no-graph --fixed-camera \
       > "$GRAFT_REPO_ROOT/gpurun_out/pmcb_${lib}_$name.log" 2>&1 )
 }
