@@ -68,6 +68,7 @@ _SIGNATURES = {
     "d3ga_sh_grad_from_views": ([ctypes.c_int32] * 4 + [_vp, _vp, _i64, _vp, _i64, ctypes.c_float, _vp, _vp], _i),
     "d3ga_compute_bary": ([_i, _i] + [_vp] * 5 + [_vp], _i),
     "d3ga_selftest_row_scan": ([_i, _vp, _vp, _vp], _i),
+    "d3ga_selftest_alpha": ([ctypes.c_int32, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_knn3_mean_dist2": ([_i, _vp, _vp, _vp], _i),
     "d3ga_compute_bary_grid": ([_i] + [_vp] * 9 + [_vp], _i),
     "d3ga_knn3_mean_dist2_grid": ([_i] + [_vp] * 6 + [_vp], _i),

@@ -11,7 +11,8 @@ DIAG = os.environ.get("D3GA_DIAG") or (("abl" + ABL) if ABL else None)          
 # Diagnostic / ablation builds never land in the package directory: tools/_build/ (git-ignored, travels with gpurun).
 # _lib.py refuses an ablation build (d3ga_debug_defaults()[0] != 0: WRONG results by design) unless D3GA_ALLOW_ABLATION=1.
 DIAG_DIR = os.path.abspath(os.path.join(HERE, "..", "..", "tools", "_build"))
-OUT = (os.path.join(DIAG_DIR, f"libd3ga_hip_abl{ABL}.so" if ABL else "libd3ga_hip_diag.so") if DIAG
+_DIAG_TAG = "diag" if os.environ.get("D3GA_DIAG") in (None, "counters") else os.environ["D3GA_DIAG"]
+OUT = (os.path.join(DIAG_DIR, f"libd3ga_hip_abl{ABL}.so" if ABL else f"libd3ga_hip_{_DIAG_TAG}.so") if DIAG
        else os.path.join(HERE, "..", "libd3ga_hip.so"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
@@ -35,8 +36,8 @@ if ABL:
     if "p" in ABL:                         # e.g. D3GA_SCAN_ABL=0p: s_setprio by remaining groups
         FLAGS.append("-DD3GA_TILE_PRIO=1")
 if os.environ.get("D3GA_DIAG"):            # diagnostic build (loop statistics and per-wave timeline, tools/diag_scan.py); never the shipped one
-    FLAGS.append("-DD3GA_DIAG")
-    if os.environ.get("D3GA_DIAG") == "counters":
+    FLAGS += ["-DD3GA_DIAG", "-DD3GA_DIAG_TIMELINE"]       # D3GA_DIAG=timeline: per-wave start / end / trip counts only (few registers)
+    if os.environ.get("D3GA_DIAG") == "counters":          # + loop statistics (lane efficiency, cache hits, ...): perturbs the timing
         FLAGS.append("-DD3GA_DIAG_COUNTERS")
 
 
@@ -49,7 +50,7 @@ def _newer(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(DIAG_DIR, f"obj_abl{ABL}" if ABL else "obj_diag") if DIAG else os.path.join(HERE, "build")
+    objdir = os.path.join(DIAG_DIR, f"obj_abl{ABL}" if ABL else f"obj_{_DIAG_TAG}") if DIAG else os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     objs = []

@@ -38,6 +38,17 @@ static inline int composite_tile_assign() {        // A/B knob (D3GA_TILE_ASSIGN
     }();
     return v;
 }
+// A/B knob (D3GA_FWD_LDS_TOTAL / D3GA_BWD_LDS_TOTAL, bytes): pad a kernel's LDS allocation up to this total with dynamic shared
+// memory -- limits the workgroups resident per CU (160 KB / total) without touching the code: fewer, faster waves per SIMD
+// and more dispatch rounds (the hardware dispatcher hands out workgroups in launch order as slots free up).  0 / unset: no pad.
+static inline unsigned lds_pad_bytes(const void *kernel, const char *env_name) {
+    const char *e = getenv(env_name);
+    const long total = e ? atol(e) : 0;
+    if (total <= 0) return 0u;
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, kernel) != hipSuccess) return 0u;
+    return total > (long)a.sharedSizeBytes ? (unsigned)(total - (long)a.sharedSizeBytes) : 0u;
+}
 // L1 image loss fused into the compositing backward: image (3,H,W) = the forward's colour output, target (or the device
 // cell that holds its address: graph.TensorSlot), g_loss = dL/dloss (device scalar), inv_n = 1 / (3 H W); image == null: off
 struct L1Source { const float *image, *target; const float *const *target_cell; const float *g_loss; float inv_n; };

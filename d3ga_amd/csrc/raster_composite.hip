@@ -33,6 +33,14 @@
 
 namespace d3ga {
 
+#ifdef D3GA_DIAG
+// diagnostic build only (tools/diag_fwd.py): [0] active waves, [1] stage-one chunks, [2] stage-two batches, [3] blend-loop
+// iterations (two list positions each), [4] sum of the row lists' lengths = (entry, block) pairs, [5] blended (entry, pixel) pairs,
+// [6] survivors of stage one, [7] tile-list entries looked at
+__device__ unsigned long long g_diag_fwd[8];
+__device__ unsigned long long g_diag_fwd_waves[32768 * 4];    // per active wave: start, end (s_memrealtime), iterations | batches << 32, list length
+#endif
+
 // DUAL: a second set of per-Gaussian colours (colors2, (P,3), read by Gaussian id) is blended with the same alphas into
 // out_color2 over bg2 -- the reference's training step renders every package twice with identical geometry and opacities
 // (RGB, then the silhouette colours on black: models/trainer.py:102-110); alpha, T, the culled lists and the early exit
@@ -89,6 +97,13 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     }
     if (threadIdx.x < 8) s_list[threadIdx.x >> 1][64 + (threadIdx.x & 1)] = kNullRec;
 
+#ifdef D3GA_DIAG_COUNTERS
+    unsigned long long df_chunks = 0, df_pairs = 0, df_blend = 0, df_surv = 0;
+#endif
+#ifdef D3GA_DIAG_TIMELINE
+    unsigned long long df_batches = 0, df_iters = 0, df_blend_ticks = 0;
+    const unsigned long long df_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     float E0 = 0.f, E1 = 0.f, E2 = 0.f;
     uint32_t last = 0;
@@ -115,6 +130,9 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
         if (k0) s_ring[(qhead + qcount + (uint32_t)lanes_below(m0)) % kRing] = make_uint2(sbase - begin + (uint32_t)lane + 1u, g0);
         if (k1) s_ring[(qhead + qcount + n0 + (uint32_t)lanes_below(m1)) % kRing] = make_uint2(sbase - begin + 64u + (uint32_t)lane + 1u, g1);
         qcount += n0 + (uint32_t)__popcll(m1);
+#ifdef D3GA_DIAG_COUNTERS
+        df_chunks += 1; df_surv += n0 + (uint32_t)__popcll(m1);
+#endif
         sbase = min(sbase + 128u, end);
     };
     // ---- stage two state: the batch whose gathers are in flight ----
@@ -165,6 +183,12 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
         if (exact_cull) bh = block_hits4_exact(cxy.x, cxy.y, cco.x, cco.y, cco.z, sc, bx0, by0, bh);
         unsigned long long m[4];
         const int trip = build_row_lists(s_list, bh.r0, bh.r1, bh.r2, bh.r3, lane, m);
+#ifdef D3GA_DIAG_TIMELINE
+        df_batches += 1;
+#endif
+#ifdef D3GA_DIAG_COUNTERS
+        df_pairs += __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
+#endif
         if (blk_base) {
             const unsigned long long dm = __builtin_amdgcn_ballot_w64(done);
             const uint2 rec = cpg;                        // 1-based list position, id
@@ -193,6 +217,9 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
         // ---- blend ----
         const uint16_t *const my_list = s_list[rg.row];
         bool all_done = false;
+#ifdef D3GA_DIAG_TIMELINE
+        const unsigned long long df_tb = __builtin_amdgcn_s_memrealtime();
+#endif
         uint32_t p0 = my_list[0], p1 = my_list[1];         // list offsets are read one iteration ahead: off the dependent chain
         for (int i = 0; i < trip; i += 2) {
             const uint32_t o0 = p0, o1 = p1;
@@ -222,6 +249,9 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
                 T = bl ? test_T : T;
                 last = bl ? __float_as_uint(e0xy.z) : last;
                 done = done || (act != bl);
+#ifdef D3GA_DIAG_COUNTERS
+                df_blend += __popcll(__builtin_amdgcn_ballot_w64(bl));
+#endif
             }
             {
                 const bool act = ok1 && !done;
@@ -238,9 +268,18 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
                 T = bl ? test_T : T;
                 last = bl ? __float_as_uint(e1xy.z) : last;
                 done = done || (act != bl);
+#ifdef D3GA_DIAG_COUNTERS
+                df_blend += __popcll(__builtin_amdgcn_ballot_w64(bl));
+#endif
+#ifdef D3GA_DIAG_TIMELINE
+                df_iters += 1;
+#endif
             }
             if (__builtin_amdgcn_ballot_w64(done) == ~0ull) { i = trip; all_done = true; }      // whole quadrant saturated
         }
+#ifdef D3GA_DIAG_TIMELINE
+        df_blend_ticks += __builtin_amdgcn_s_memrealtime() - df_tb;
+#endif
         if (all_done) break;
     }
     if (inside) {
@@ -262,11 +301,67 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
         const int r = lane >> 4;
         blk_count[16 * (size_t)q.tile + 4 * q.quad + r] = r == 0 ? bc0 : (r == 1 ? bc1 : (r == 2 ? bc2 : bc3));
     }
+#ifdef D3GA_DIAG_COUNTERS
+    if (lane == 0 && end > begin) {
+        atomicAdd(&g_diag_fwd[1], df_chunks); atomicAdd(&g_diag_fwd[4], df_pairs); atomicAdd(&g_diag_fwd[5], df_blend);
+        atomicAdd(&g_diag_fwd[6], df_surv); atomicAdd(&g_diag_fwd[7], (unsigned long long)(sbase - begin));
+    }
+#endif
+#ifdef D3GA_DIAG_TIMELINE
+    if (lane == 0 && end > begin && blockIdx.x < 32768) {   // no atomics: a returning same-address atomic per wave serialises at the memory side and would BE the timeline
+        const unsigned long long df_t1 = __builtin_amdgcn_s_memrealtime();
+        const size_t slot = blockIdx.x;
+        g_diag_fwd_waves[4 * slot] = df_t0; g_diag_fwd_waves[4 * slot + 1] = df_t1;
+        g_diag_fwd_waves[4 * slot + 2] = df_iters | (df_batches << 32); g_diag_fwd_waves[4 * slot + 3] = (unsigned long long)(end - begin) | (df_blend_ticks << 32);
+    }
+#endif
+}
+
+// test hook (d3ga_selftest_alpha): the forward's OWN evaluation of alpha for listed (Gaussian, pixel) pairs -- conic_q() of the
+// geometry record, splat_eval_q() on (centre - pixel) exactly as the blend loop forms them -- so that a parity test can hand
+// the product's alpha >= 1/255 decisions to the oracle at the pairs where two float32 exps may disagree
+__global__ void alpha_selftest_kernel(int n, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
+                                      const int32_t *__restrict__ gid, const int32_t *__restrict__ px, const int32_t *__restrict__ py,
+                                      uint8_t *__restrict__ ok_out, float *__restrict__ alpha_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 c = xy[gid[i]];
+    const float4 co = conic_o[gid[i]];
+    const ConicQ q = conic_q(co.x, co.y, co.z);
+    float al, G;
+    bool ok;
+    splat_eval_q(c.x - (float)px[i], c.y - (float)py[i], q, co.w, al, G, ok);
+    ok_out[i] = ok ? 1 : 0;
+    if (alpha_out) alpha_out[i] = al;
 }
 
 }  // namespace d3ga
 
 using namespace d3ga;
+
+extern "C" int d3ga_selftest_alpha(int32_t P, const void *geom, int n, const int32_t *gid, const int32_t *px, const int32_t *py,
+                                   uint8_t *ok, float *alpha, d3ga_stream_t stream) {
+    if (P <= 0 || n < 0) return D3GA_E_SIZE;
+    if (n == 0) return D3GA_OK;
+    if (!geom || !gid || !px || !py || !ok) return D3GA_E_NULL;
+    const GeomBuf g = carve_geom(const_cast<void *>(geom), P);
+    hipLaunchKernelGGL(d3ga::alpha_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, g.xy, g.conic_o, gid, px, py, ok, alpha);
+    return check_launch((hipStream_t)stream, 0);
+}
+
+#ifdef D3GA_DIAG
+extern "C" int d3ga_diag_fwd_read(unsigned long long *out8, unsigned long long *waves, int n, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_diag_fwd), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (waves && n > 0 && hipMemcpyFromSymbol(waves, HIP_SYMBOL(g_diag_fwd_waves), sizeof(unsigned long long) * 4 * (size_t)n) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag_fwd), z, sizeof(z)) != hipSuccess) return 1;
+        void *w = nullptr;
+        if (hipGetSymbolAddress(&w, HIP_SYMBOL(g_diag_fwd_waves)) != hipSuccess || hipMemset(w, 0, sizeof(unsigned long long) * 4 * 32768) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, void *img, float *out_color, float *out_invdepth, const float *colors2,
@@ -284,7 +379,8 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
     const dim3 grid(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy));
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
 #define D3GA_LAUNCH_FWD(DUALV, DEPTHV)                                                                                          \
-    hipLaunchKernelGGL((composite_fwd_q_kernel<DUALV, DEPTHV>), grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, bin.tile_start,       \
+    hipLaunchKernelGGL((composite_fwd_q_kernel<DUALV, DEPTHV>), grid, dim3(64),                                                     \
+                       lds_pad_bytes((const void *)composite_fwd_q_kernel<DUALV, DEPTHV>, "D3GA_FWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
                        bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,     \
                        out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact)
     if (colors2) { if (out_invdepth) D3GA_LAUNCH_FWD(true, true); else D3GA_LAUNCH_FWD(true, false); }

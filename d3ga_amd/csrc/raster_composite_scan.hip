@@ -89,7 +89,7 @@ __device__ __forceinline__ ScanEntry scan_gather(uint2 pg, const float2 *__restr
 }
 
 #ifdef D3GA_DIAG
-__device__ unsigned long long g_diag_scan[8];     // diagnostic build only (tools/diag_scan.py): loop statistics of the kernel below
+__device__ unsigned long long g_diag_scan[16];    // diagnostic build only (tools/diag_scan.py): loop statistics of the kernel below
 __device__ unsigned long long g_diag_waves[32768 * 4];   // per active wave: s_memtime at start / end, groups, HW_ID | XCC_ID << 32
 #endif
 // forces the compiler's s_waitcnt for these registers HERE (an empty asm that reads them)
@@ -132,10 +132,13 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     const float *__restrict__ bg2, const float *__restrict__ dL_dpix2, const uint2 *__restrict__ blk_list,
     const uint32_t *__restrict__ blk_count, int assign, L1Source l1) {
     static_assert((S & (S - 1)) == 0, "power of two");
+    constexpr int NW = 4;                            // wavefronts per tile (three, the third walking two sets of blocks: measured, slower -- DESIGN.md sec. 4)
     constexpr int PIXF = DUAL ? 12 : 8;
     constexpr int ROWF = 16 * PIXF + 4;
     constexpr int kSlot = 12;                        // dwords per cache slot
     constexpr uint32_t kLocked = 0xffffffffu;
+    const bool early_exit_off = (assign & 8) != 0;         // A/B: bit 3 of D3GA_TILE_ASSIGN keeps every wavefront until the tile is done
+    assign &= 7;
     const int tiles = gx * gy;
     const int tile = tile_order ? ((int)blockIdx.x < tiles ? (int)tile_order[blockIdx.x] : -1) : ((int)blockIdx.x < tiles ? (int)blockIdx.x : -1);
     if (tile < 0) return;                                  // uniform over the workgroup
@@ -143,10 +146,12 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     const uint32_t end = (uint32_t)min((uint64_t)tile_start[tile + 1], dcap);
     if (begin >= end) return;                              // uniform: empty tile
 
-    __shared__ __attribute__((aligned(16))) float s_pix_all[4][4 * ROWF];
-    __shared__ __attribute__((aligned(16))) float s_dump_all[4][64 * 2 + 16 * PIXF];
+    __shared__ __attribute__((aligned(16))) float s_pix_all[NW][4 * ROWF];
+    __shared__ __attribute__((aligned(16))) float s_dump_all[NW][64 * 2 + 16 * PIXF];
     __shared__ __attribute__((aligned(16))) uint32_t s_cache[S * kSlot];
-    for (int i = threadIdx.x; i < S; i += 256) s_cache[i * kSlot + 10] = 0u;       // tags: every slot empty
+    for (int i = threadIdx.x; i < S; i += 64 * NW) s_cache[i * kSlot + 10] = 0u;   // tags: every slot empty
+    __shared__ uint32_t s_arrived;                          // wavefronts of this tile that are done (the last one publishes the cache)
+    if (threadIdx.x == 0) s_arrived = 0u;
     __shared__ uint8_t s_perm[16];                          // assign 2: the tile's 16 blocks by descending list length
     if (assign == 2 && threadIdx.x < 16) {
         const int b = threadIdx.x, tx0 = (tile % gx) * kTile, ty0 = (tile / gx) * kTile;
@@ -175,25 +180,28 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     // (quadrants: 57.5 k wave-groups at C3, interleaved 59.3 k, against 49 k row-groups / 4); and rotating g with the workgroup
     // index gives every SIMD of a CU (wave w of a workgroup runs on SIMD w) one wavefront of each weight class.
     const int row = lane >> 4, l16 = lane & 15;
-    int bx = assign ? 2 * (row & 1) + (wave & 1) : 2 * (wave & 1) + (row & 1);
-    int by = assign ? 2 * (row >> 1) + (wave >> 1) : 2 * (wave >> 1) + (row >> 1);
-    if (assign == 2) {
-        const int b = s_perm[4 * ((wave + (int)blockIdx.x) & 3) + row], q = b >> 2, r = b & 3;
-        bx = 2 * (q & 1) + (r & 1); by = 2 * (q >> 1) + (r >> 1);
-    }
-    const int blk = 4 * ((bx >> 1) + 2 * (by >> 1)) + ((bx & 1) + 2 * (by & 1));
-    const int bx0 = (tile % gx) * kTile + 4 * bx, by0 = (tile / gx) * kTile + 4 * by;      // block origin in pixels
     const int fq = lane / 9, fk = lane - 9 * fq;           // publish: lane -> (record within a group of 7, value)
     const int fk_off = fk < 2 ? fk : fk + 1;               // acc layout 0,1 | 3,4,5 | 6 | 7,8,9
     constexpr int kAccStride = D3GA_ACC_STRIDE;
     float *const s_pix = s_pix_all[wave];
     float *const s_dump = s_dump_all[wave];
 #ifdef D3GA_DIAG_COUNTERS
-    unsigned long long dg_install = 0, dg_hit = 0, dg_evict = 0, dg_trips = 0, dg_groups = 0;
+    unsigned long long dg_install = 0, dg_hit = 0, dg_evict = 0, dg_valid = 0, dg_entries = 0, dg_rowgroups = 0;
+#endif
+#ifdef D3GA_DIAG_TIMELINE
+    unsigned long long dg_trips = 0, dg_groups = 0;
     const unsigned long long diag_t0 = __builtin_readcyclecounter(), diag_w0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
     do {
+        int bx = assign ? 2 * (row & 1) + (wave & 1) : 2 * (wave & 1) + (row & 1);
+        int by = assign ? 2 * (row >> 1) + (wave >> 1) : 2 * (wave >> 1) + (row >> 1);
+        if (assign == 2) {
+            const int b = s_perm[4 * ((wave + (int)blockIdx.x) & 3) + row], q = b >> 2, r = b & 3;
+            bx = 2 * (q & 1) + (r & 1); by = 2 * (q >> 1) + (r >> 1);
+        }
+        const int blk = 4 * ((bx >> 1) + 2 * (by >> 1)) + ((bx & 1) + 2 * (by & 1));
+        const int bx0 = (tile % gx) * kTile + 4 * bx, by0 = (tile / gx) * kTile + 4 * by;      // block origin in pixels
         const int px = bx0 + (l16 & 3), py = by0 + (l16 >> 2);
         const bool inside = px < W && py < H;
         const size_t pid = (size_t)py * W + px;
@@ -292,6 +300,9 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
                     bool ok;
                     splat_eval_q(dx[k], tb, tc, cq.a, e.co.w, al[k], G[k], ok);
                     valid[k] = ok & (e.pos <= __float_as_uint(pb[k].z));     // (a lane without an entry has opacity 0: never ok)
+#ifdef D3GA_DIAG_COUNTERS
+                    dg_valid += valid[k] ? 1 : 0;          // lane efficiency: valid (entry, pixel) pairs / issued lane slots
+#endif
                     al[k] = valid[k] ? al[k] : 0.f;
                     r[k] = __builtin_amdgcn_rcpf(1.0f - al[k]);
                     cgv[k] = e.rgb.x * pa[k].z + e.rgb.y * pa[k].w + e.rgb.z * pb[k].x;
@@ -338,11 +349,15 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
             const uint32_t anybits = (__float_as_uint(SA) | __float_as_uint(SB) | __float_as_uint(SC)) | (__float_as_uint(SyA) | __float_as_uint(SyB) | __float_as_uint(SyyA)) |
                                      (__float_as_uint(M6) | __float_as_uint(M7) | __float_as_uint(M8));
             bool pending = D3GA_SCAN_ABL == 1 ? (anybits == 0x12345u) : (D3GA_SCAN_ABL == 8 ? act : (anybits << 1) != 0u);
-#ifdef D3GA_DIAG_COUNTERS
+#ifdef D3GA_DIAG_TIMELINE
             dg_groups += 1;
 #endif
-            while (__builtin_amdgcn_ballot_w64(pending) != 0ull) {
 #ifdef D3GA_DIAG_COUNTERS
+            dg_entries += act ? 1 : 0;
+            dg_rowgroups += (act && l16 == 0) ? 1 : 0;
+#endif
+            while (__builtin_amdgcn_ballot_w64(pending) != 0ull) {
+#ifdef D3GA_DIAG_TIMELINE
                 dg_trips += 1;
 #endif
                 // straight-line body (selects, no nested divergent regions and no state carried around the loop: the first
@@ -410,28 +425,32 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     } while (false);
 
 #ifdef D3GA_DIAG_COUNTERS
-    {
-        atomicAdd(&g_diag_scan[3], dg_install); atomicAdd(&g_diag_scan[4], dg_hit); atomicAdd(&g_diag_scan[5], dg_evict);
-        if (lane == 0) {
-            atomicAdd(&g_diag_scan[6], dg_trips); atomicAdd(&g_diag_scan[7], dg_groups);
-            if (dg_groups) {
-                const unsigned long long slot = atomicAdd(&g_diag_scan[0], 1ull);
-                if (slot < 32768) {
-                    g_diag_waves[4 * slot] = diag_w0 | ((__builtin_readcyclecounter() - diag_t0) << 40);
-                    g_diag_waves[4 * slot + 1] = __builtin_amdgcn_s_memrealtime();
-                    g_diag_waves[4 * slot + 2] = dg_groups | (dg_trips << 16) | ((unsigned long long)(end - begin) << 32);
-                    g_diag_waves[4 * slot + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(6164) & 15) << 32);
-                }
-            }
-        }
+    atomicAdd(&g_diag_scan[3], dg_install); atomicAdd(&g_diag_scan[4], dg_hit); atomicAdd(&g_diag_scan[5], dg_evict);
+    atomicAdd(&g_diag_scan[8], dg_valid); atomicAdd(&g_diag_scan[9], dg_entries); atomicAdd(&g_diag_scan[10], dg_rowgroups);
+#endif
+#ifdef D3GA_DIAG_TIMELINE
+    if (lane == 0 && dg_groups && blockIdx.x < 8192) {      // no atomics here: returning same-address atomics serialise at the memory side and would BE the timeline
+        const unsigned long long diag_w1 = __builtin_amdgcn_s_memrealtime();
+        const size_t slot = 4 * (size_t)blockIdx.x + wave;
+        g_diag_waves[4 * slot] = diag_w0 | ((__builtin_readcyclecounter() - diag_t0) << 40);
+        g_diag_waves[4 * slot + 1] = diag_w1;
+        g_diag_waves[4 * slot + 2] = dg_groups | (dg_trips << 16) | ((unsigned long long)(end - begin) << 32);
+        g_diag_waves[4 * slot + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)(__builtin_amdgcn_s_getreg(6164) & 15) << 32);
     }
 #endif
-    // every wavefront of the tile is done: publish the cache, nine consecutive lanes per record, seven records per
-    // instruction, a quarter of the slots per wavefront.  (A wavefront that finishes early waits here; its workgroup keeps
-    // the LDS and the dispatch slot until the slowest quadrant is done anyway.)
-    __syncthreads();
+    // Publish.  A wavefront that is done LEAVES (its registers and wave slot go to the next workgroup: a tile's four
+    // wavefronts take 5..18 groups, and with a closing barrier all four slots stayed occupied until the slowest was done --
+    // the second dispatch round of the launch then started at half of the kernel's span, tools/diag_scan.py); the LAST one
+    // to arrive (one returning integer LDS atomic per wavefront; LDS operations of a wavefront execute in order, so every
+    // insert of a wavefront is complete when its arrival is counted) sends the whole cache to HBM, nine consecutive lanes
+    // per record, seven records per instruction.
     if (D3GA_SCAN_ABL == 13 || D3GA_SCAN_ABL == 1) return;
-    for (int base = wave * 7; base < S; base += 28) {
+    uint32_t arrived = 0u;
+    if (lane == 0) arrived = atomicAdd(&s_arrived, 1u);
+    arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+    if (arrived != (uint32_t)(NW - 1) && !early_exit_off) return;
+    if (early_exit_off) { __syncthreads(); if (wave != 0) return; }
+    for (int base = 0; base < S; base += 7) {
         const int ent = base + min(fq, 6);
         const bool mine = fq < 7 && ent < S;
         const uint32_t *const sl = s_cache + min(ent, S - 1) * kSlot;
@@ -442,11 +461,13 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
 }
 
 #ifdef D3GA_DIAG
-extern "C" int d3ga_diag_scan_read(unsigned long long *out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_diag_scan), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+extern "C" int d3ga_diag_scan_read(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag_scan), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag_scan), z, sizeof(z)) != hipSuccess) return 1;
+        void *w = nullptr;
+        if (hipGetSymbolAddress(&w, HIP_SYMBOL(g_diag_waves)) != hipSuccess || hipMemset(w, 0, sizeof(unsigned long long) * 4 * 32768) != hipSuccess) return 1;
     }
     return 0;
 }
@@ -463,8 +484,9 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
     const dim3 tgrid(gx * gy);
     const int S = composite_merge_slots();
-#define D3GA_LAUNCH_TILE(DUALV, SV)                                                                                          \
-    hipLaunchKernelGGL((composite_bwd_tile_kernel<DUALV, SV>), tgrid, dim3(256), 0, s, prm->W, prm->H, gx, gy, bin.tile_start, \
+#define D3GA_LAUNCH_TILE(DUALV, SV)                                                                                           \
+    hipLaunchKernelGGL((composite_bwd_tile_kernel<DUALV, SV>), tgrid, dim3(256),                                               \
+                       lds_pad_bytes((const void *)composite_bwd_tile_kernel<DUALV, SV>, "D3GA_BWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
                        (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc, order,   \
                        colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, composite_tile_assign(), l1)
     if (colors2) { if (S >= 512) D3GA_LAUNCH_TILE(true, 512); else D3GA_LAUNCH_TILE(true, 256); }

@@ -45,6 +45,7 @@ class GaussianRasterizationSettings(NamedTuple):
 _policy = {"mode": "auto", "static": 0}
 _hwm = {}            # device index -> high-water mark of D
 _last = {}           # device index -> (binning tensor, capacity) of the most recent forward (for last_counters)
+_last_img = {}       # device index -> (img scratch tensor, W, H) of the most recent forward (for last_termination)
 _capture_log = None  # while graph.CapturedStep / CapturedCutStep capture: list of (binning tensor, capacity) of EVERY forward issued
 
 
@@ -345,6 +346,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise ValueError(f"rasterize_gaussians_l1: the target must be (3, {H}, {W}), got {tuple(l1_t.shape)}")
             loss = torch.empty((), dtype=torch.float32, device=dev)
             l1_mean_forward(color, l1_t, l1_cell, loss, dev)
+        _last_img[dev.index] = (img, W, H, geom, P)
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img,
                               colors2, bg2, color if ctx.l1 else None, l1_t if ctx.l1 else None, l1_cell if ctx.l1 else None)
         ctx.mark_non_differentiable(*((radii, invdepth) if invdepth is not None else (radii,)))
@@ -540,6 +542,33 @@ def last_tile_lists(W, H, device=None):
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     binning, cap = _last[dev]
     return tile_lists(binning, W, H, cap)
+
+
+def last_termination(device=None):
+    """(final_T (H,W) float32, n_contrib (H,W) int32) of the most recent forward on `device`: the per-pixel termination the
+    backward reads (views into the forward's image scratch, layout from d3ga_raster_img_layout; inspection / tests -- the
+    shared-decision parity test hands them to the oracle's backward)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    img, W, H = _last_img[dev][:3]
+    off = (ctypes.c_int64 * 2)()
+    check(_lib.lib().d3ga_raster_img_layout(W, H, off), "d3ga_raster_img_layout")
+    n = 4 * W * H
+    return (img[off[0]:off[0] + n].view(torch.float32).view(H, W), img[off[1]:off[1] + n].view(torch.int32).view(H, W))
+
+
+def last_alpha_decisions(gid, px, py, device=None):
+    """(ok (n,) bool, alpha (n,) float32): the compositing forward's own alpha and "touches the pixel" decision for the listed
+    (Gaussian, pixel) pairs over the geometry records of the most recent forward (d3ga_selftest_alpha; tests)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    geom, P = _last_img[dev][3:5]
+    d = geom.device
+    gid, px, py = (torch.as_tensor(t, dtype=torch.int32).to(d).contiguous() for t in (gid, px, py))
+    n = gid.numel()
+    ok = torch.zeros(max(n, 1), dtype=torch.uint8, device=d)
+    alpha = torch.zeros(max(n, 1), dtype=torch.float32, device=d)
+    check(_lib.lib().d3ga_selftest_alpha(P, dptr(geom), n, dptr(gid), dptr(px), dptr(py), dptr(ok), dptr(alpha), stream_handle()),
+          "d3ga_selftest_alpha")
+    return ok[:n].bool(), alpha[:n]
 
 
 def tile_lists(binning, W, H, d_capacity):

@@ -309,6 +309,12 @@ int d3ga_ssim_l1_bwd(int32_t C, int32_t H, int32_t W, const float *img1, const f
  * 256; in (n) -> out (8n): for element i (lane l of its row), out[8i+k] = sum over lanes <= l of (k+1) in, k < 4, and
  * out[8i+4+k] = product over lanes <= l of (1 + (k+1)/8 in). */
 int d3ga_selftest_row_scan(int n, const float *in, float *out, d3ga_stream_t stream);
+/* Test hook, not part of the drop-in surface: the compositing forward's own alpha evaluation (and its "touches the pixel"
+ * decision: power <= 0 and alpha >= 1/255) for n listed pairs (Gaussian gid[i], pixel (px[i], py[i])) over the geometry
+ * records `geom` of a forward with P Gaussians.  ok (n) u8; alpha (n) f32 or NULL.  Lets a parity test share the product's
+ * threshold decisions with the oracle (tests/test_gpu_parity.py: shared decisions). */
+int d3ga_selftest_alpha(int32_t P, const void *geom, int n, const int32_t *gid, const int32_t *px, const int32_t *py,
+                        uint8_t *ok, float *alpha, d3ga_stream_t stream);
 
 int d3ga_compute_bary(int P, int T, const float *points, const float *tetra_corners, float *barys,
                       int32_t *tetra_id, uint8_t *active, d3ga_stream_t stream);

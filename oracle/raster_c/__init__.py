@@ -126,6 +126,56 @@ def margins(ctx, eps_alpha=1e-5, eps_T=1e-3):
     return pix.astype(bool), gs[:k["P"]].astype(bool)
 
 
+def set_termination(ctx, final_T, n_contrib):
+    """Shared decisions: replace the context's per-pixel termination (final_T (H,W) f32, n_contrib (H,W) i32) with the ones
+    another implementation's forward produced; `backward` then walks exactly those entries (ro_set_termination)."""
+    k = ctx.keep
+    fT = np.ascontiguousarray(final_T, dtype=np.float32).reshape(k["H"], k["W"])
+    nc = np.ascontiguousarray(n_contrib, dtype=np.int32).reshape(k["H"], k["W"])
+    lib().ro_set_termination(ctypes.c_void_p(ctx.handle), _p(fT), _p(nc))
+
+
+def alpha_marginal(ctx, eps_alpha=1e-5):
+    """(P,) bool: Gaussians with an alpha within eps_alpha (relative) of 1/255 on some pixel, at a list position the backward
+    walks there -- the only discontinuous decision left once the termination is shared (ro_alpha_marginal)."""
+    k = ctx.keep
+    gs = np.zeros(max(k["P"], 1), np.uint8)
+    L = lib()
+    L.ro_alpha_marginal.restype = ctypes.c_int64
+    L.ro_alpha_marginal(ctypes.c_void_p(ctx.handle), ctypes.c_float(eps_alpha), _p(gs))
+    return gs[:k["P"]].astype(bool)
+
+
+def alpha_band_pairs(ctx, eps_alpha=1e-4):
+    """(gid (n,) i32, pix (n,) i32 = py * W + px): every (Gaussian, pixel) pair the backward walks whose alpha lies within
+    eps_alpha of 1/255 (ro_alpha_band_pairs), sorted by (pix, gid)."""
+    L = lib()
+    L.ro_alpha_band_pairs.restype = ctypes.c_int64
+    cap = 1 << 16
+    while True:
+        gid, pix = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        n = int(L.ro_alpha_band_pairs(ctypes.c_void_p(ctx.handle), ctypes.c_float(eps_alpha), ctypes.c_int64(cap), _p(gid), _p(pix)))
+        if n <= cap:
+            break
+        cap = n
+    gid, pix = gid[:n], pix[:n]
+    order = np.lexsort((gid, pix))
+    return np.ascontiguousarray(gid[order]), np.ascontiguousarray(pix[order])
+
+
+def set_alpha_overrides(ctx, gid, pix, ok):
+    """Shared alpha decisions: `backward` takes ok[i] (blended or not) for pair (gid[i], pix[i]) instead of its own
+    alpha >= 1/255 test (ro_set_alpha_overrides; pairs sorted by (pix, gid) as alpha_band_pairs returns them)."""
+    gid = np.ascontiguousarray(gid, np.int32); pix = np.ascontiguousarray(pix, np.int32); ok = np.ascontiguousarray(ok, np.uint8)
+    assert len(gid) == len(pix) == len(ok)
+    if len(gid) > 1:
+        key = pix.astype(np.int64) * (1 << 31) + gid
+        assert (np.diff(key) > 0).all(), "pairs must be unique and sorted by (pix, gid)"
+    L = lib()
+    L.ro_set_alpha_overrides.restype = None
+    L.ro_set_alpha_overrides(ctypes.c_void_p(ctx.handle), ctypes.c_int64(len(gid)), _p(gid), _p(pix), _p(ok))
+
+
 def backward(ctx, dL_dpix, sum_noise=None):
     """Returns dict of numpy grads: means3D, means2D(P,3), shs|colors, opacities(P,1), scales, rotations, cov3D.
     sum_noise=(gamma, pattern): conditioning probe -- every per-Gaussian pixel sum is moved by +- gamma x (sum of the absolute

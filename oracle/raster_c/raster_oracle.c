@@ -50,6 +50,10 @@ typedef struct {
     /* decision margins (see ro_marginal): per pixel the smallest relative distance of any evaluated alpha to the
      * 1/255 cut-off and of any test_T to the 1e-4 cut-off */
     float *margin_alpha, *margin_T;
+    /* shared alpha decisions (ro_set_alpha_overrides): n pairs sorted by (pixel, Gaussian), 1 = the pair is blended */
+    int64_t ovr_n;
+    int *ovr_pix, *ovr_gid;
+    uint8_t *ovr_ok, *ovr_has; /* ovr_has: H*W, 1 where a pixel has an override */
 } ro_ctx;
 
 static void xform4x3(const float *m, const float *p, float *o) {
@@ -154,6 +158,7 @@ void ro_free(ro_ctx *c) {
     free(c->depth); free(c->xy); free(c->conic_o); free(c->rgb); free(c->cov3D); free(c->radii);
     free(c->clamped); free(c->rect); free(c->tile_start); free(c->point_list); free(c->final_T); free(c->n_contrib);
     free(c->margin_alpha); free(c->margin_T);
+    free(c->ovr_pix); free(c->ovr_gid); free(c->ovr_ok); free(c->ovr_has);
     free(c);
 }
 
@@ -359,6 +364,103 @@ int64_t ro_marginal(const ro_ctx *c, float eps_alpha, float eps_T, uint8_t *pix_
     return n;
 }
 
+/* Shared decisions.  ro_backward reads the per-pixel termination (final_T, n_contrib) from the context.
+ * A parity test may replace the oracle's own with the ones the implementation under test produced in ITS forward: both
+ * backwards then walk the same entries of every pixel, whatever side of T (1 - alpha) < 1e-4 either forward fell on, and
+ * the comparison needs no mask on the incoming gradient.  What stays implementation-specific is the per-entry
+ * alpha >= 1/255 decision (two float32 exps): ro_alpha_marginal reports the Gaussians it can affect. */
+void ro_set_termination(ro_ctx *c, const float *final_T, const int *n_contrib) {
+    memcpy(c->final_T, final_T, 4 * (size_t)c->W * c->H);
+    memcpy(c->n_contrib, n_contrib, 4 * (size_t)c->W * c->H);
+}
+
+/* gauss_flag[g] = 1 iff Gaussian g, on some pixel and at a list position the backward walks there (<= n_contrib, as the
+ * context holds it NOW), has an alpha within eps_alpha of 1/255 (relative; in units of what float32 resolves at that pixel,
+ * the forward's rule).  Returns the number of flagged Gaussians. */
+int64_t ro_alpha_marginal(const ro_ctx *c, float eps_alpha, uint8_t *gauss_flag) {
+    const int W = c->W, H = c->H, tiles = c->gx * c->gy;
+    memset(gauss_flag, 0, (size_t)(c->P > 0 ? c->P : 1));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int t = 0; t < tiles; t++) {
+        int tx = t % c->gx, ty = t / c->gx;
+        int64_t s = c->tile_start[t];
+        for (int py = ty * TILE; py < ty * TILE + TILE && py < H; py++)
+            for (int px = tx * TILE; px < tx * TILE + TILE && px < W; px++) {
+                size_t pid = (size_t)py * W + px;
+                int64_t lim = s + c->n_contrib[pid];
+                if (lim > c->tile_start[t + 1]) lim = c->tile_start[t + 1];
+                for (int64_t k = s; k < lim; k++) {
+                    int g = c->point_list[k];
+                    float dx = c->xy[2 * g] - (float)px, dy = c->xy[2 * g + 1] - (float)py;
+                    const float *co = c->conic_o + 4 * g;
+                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 1e-5f) continue;
+                    float alpha = fminf(0.99f, co[3] * expf(power));
+                    float tmag = 0.5f * (fabsf(co[0] * dx * dx) + fabsf(co[2] * dy * dy)) + fabsf(co[1] * dx * dy);
+                    if (fabsf(alpha * 255.0f - 1.0f) / (1.0f + 0.02f * tmag) < eps_alpha) gauss_flag[g] = 1;   /* (benign race: all writers store 1) */
+                }
+            }
+    }
+    int64_t n = 0;
+    for (int i = 0; i < c->P; i++) n += gauss_flag[i];
+    return n;
+}
+
+/* The (Gaussian, pixel) pairs whose alpha lies within eps_alpha of 1/255 (same measure as ro_alpha_marginal), at list positions
+ * the backward walks.  gid / pix receive up to max_n pairs (pix = py * W + px); returns the number found (may exceed max_n). */
+int64_t ro_alpha_band_pairs(const ro_ctx *c, float eps_alpha, int64_t max_n, int *gid, int *pix) {
+    const int W = c->W, H = c->H, tiles = c->gx * c->gy;
+    int64_t n = 0;
+    for (int t = 0; t < tiles; t++) {
+        int tx = t % c->gx, ty = t / c->gx;
+        int64_t s = c->tile_start[t];
+        for (int py = ty * TILE; py < ty * TILE + TILE && py < H; py++)
+            for (int px = tx * TILE; px < tx * TILE + TILE && px < W; px++) {
+                size_t pid = (size_t)py * W + px;
+                int64_t lim = s + c->n_contrib[pid];
+                if (lim > c->tile_start[t + 1]) lim = c->tile_start[t + 1];
+                for (int64_t k = s; k < lim; k++) {
+                    int g = c->point_list[k];
+                    float dx = c->xy[2 * g] - (float)px, dy = c->xy[2 * g + 1] - (float)py;
+                    const float *co = c->conic_o + 4 * g;
+                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 1e-5f) continue;
+                    float alpha = fminf(0.99f, co[3] * expf(power));
+                    float tmag = 0.5f * (fabsf(co[0] * dx * dx) + fabsf(co[2] * dy * dy)) + fabsf(co[1] * dx * dy);
+                    if (fabsf(alpha * 255.0f - 1.0f) / (1.0f + 0.02f * tmag) < eps_alpha) {
+                        if (n < max_n) { gid[n] = g; pix[n] = (int)pid; }
+                        n++;
+                    }
+                }
+            }
+    }
+    return n;
+}
+
+/* Shared alpha decisions: for the listed (Gaussian, pixel) pairs ro_backward takes `ok` (1: the pair is blended with the
+ * alpha this oracle computes, 0: skipped) instead of its own alpha >= 1/255 test -- the decisions of the implementation
+ * under test at exactly the pairs where two float32 exps may disagree.  The pairs MUST be sorted by (pix, gid) (the order
+ * ro_alpha_band_pairs produces per pixel is list order: the wrapper sorts).  n = 0 clears. */
+void ro_set_alpha_overrides(ro_ctx *c, int64_t n, const int *gid, const int *pix, const uint8_t *ok) {
+    free(c->ovr_pix); free(c->ovr_gid); free(c->ovr_ok); free(c->ovr_has);
+    c->ovr_pix = c->ovr_gid = NULL; c->ovr_ok = c->ovr_has = NULL; c->ovr_n = 0;
+    if (n <= 0) return;
+    c->ovr_n = n;
+    c->ovr_pix = (int *)malloc(4 * (size_t)n); c->ovr_gid = (int *)malloc(4 * (size_t)n); c->ovr_ok = (uint8_t *)malloc((size_t)n);
+    c->ovr_has = (uint8_t *)calloc((size_t)c->W * c->H, 1);
+    memcpy(c->ovr_pix, pix, 4 * (size_t)n); memcpy(c->ovr_gid, gid, 4 * (size_t)n); memcpy(c->ovr_ok, ok, (size_t)n);
+    for (int64_t i = 0; i < n; i++) c->ovr_has[pix[i]] = 1;
+}
+/* -1: no override for the pair, else 0 / 1 */
+static int alpha_override(const ro_ctx *c, int pid, int g) {
+    int64_t lo = 0, hi = c->ovr_n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) / 2;
+        if (c->ovr_pix[mid] < pid || (c->ovr_pix[mid] == pid && c->ovr_gid[mid] < g)) lo = mid + 1; else hi = mid;
+    }
+    return (lo < c->ovr_n && c->ovr_pix[lo] == pid && c->ovr_gid[lo] == g) ? (int)c->ovr_ok[lo] : -1;
+}
+
 /* Per-Gaussian sums over pixels are accumulated in DOUBLE: the terms are the float32 values a tile splatter
  * produces, but their sum is then independent of the summation order (the GPU sums them in a different order, and
  * a float32 running sum over 10^3..10^4 signed terms carries ~1e-3 relative noise of its own). */
@@ -414,7 +516,8 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
                     if (power > 0.0f) continue;
                     float G = expf(power);
                     float alpha = fminf(0.99f, co[3] * G);
-                    if (alpha < 1.0f / 255.0f) continue;
+                    int forced = (c->ovr_n && c->ovr_has[pid]) ? alpha_override(c, (int)pid, g) : -1;
+                    if (forced < 0 ? (alpha < 1.0f / 255.0f) : !forced) continue;
                     T = T / (1.f - alpha);
                     float dch = alpha * T;
                     float dL_dalpha = 0.f;

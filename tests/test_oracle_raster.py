@@ -158,3 +158,78 @@ def test_decision_margins_flag_threshold_pixels_and_their_gaussians():
     pix, gs = rc.margins(ctx, eps_alpha=1e-9, eps_T=0.0)
     assert not pix.any() and not gs.any()
     assert inside.any()
+
+
+def test_shared_termination_and_alpha_marginal_hooks():
+    """The hooks of the shared-decision parity test (tests/test_gpu_parity.py): handing the oracle its OWN termination changes
+    nothing; truncating one pixel's n_contrib removes exactly the entries behind it from that pixel's backward; the
+    alpha-marginal flags grow with eps, vanish at eps = 0 and are a subset of `margins()`' Gaussian flags."""
+    inp = scene_inputs("T1", scale_mult=2.0)
+    cam, W, H = inp["cam"], inp["W"], inp["H"]
+    bg = np.array([1.0, 0.5, 0.2], np.float32)
+    gpix = np.random.default_rng(3).standard_normal((3, H, W)).astype(np.float32)
+    _, _, _, ctx = rc.forward(_np(inp["means3D"]), _np(inp["opacities"]), bg, cam["world_view_transform"],
+                              cam["full_proj_transform"], cam["camera_center"], cam["tanfovx"], cam["tanfovy"], W, H,
+                              cov3D_precomp=_np(inp["cov6"]), shs=_np(inp["shs"]), sh_degree=3)
+    g0 = rc.backward(ctx, gpix)
+    own = rc.geom(ctx)
+    rc.set_termination(ctx, own["final_T"], own["n_contrib"])
+    g1 = rc.backward(ctx, gpix)
+    for k in g0:
+        if g0[k] is not None:
+            assert np.array_equal(g0[k], g1[k]), k
+    # one deep pixel gives up everything: only Gaussians of its tile may change, and something does change
+    py, px = np.unravel_index(int(own["n_contrib"].argmax()), own["n_contrib"].shape)
+    nc = own["n_contrib"].copy()
+    nc[py, px] = 0
+    rc.set_termination(ctx, own["final_T"], nc)
+    g2 = rc.backward(ctx, gpix)
+    changed = np.flatnonzero(np.abs(g2["opacities"] - g0["opacities"]).reshape(-1) > 0)
+    start, plist = rc.tile_lists(ctx)
+    t = (py // 16) * ((W + 15) // 16) + px // 16
+    assert len(changed) > 0 and set(changed.tolist()) <= set(plist[start[t]:start[t + 1]].tolist())
+    rc.set_termination(ctx, own["final_T"], own["n_contrib"])
+    none, few, many = rc.alpha_marginal(ctx, 0.0), rc.alpha_marginal(ctx, 1e-3), rc.alpha_marginal(ctx, 1e-1)
+    assert not none.any() and many.sum() > few.sum() > 0 and not (few & ~many).any()
+    _, gm = rc.margins(ctx, 1e-3, 0.0)
+    assert not (few & ~gm).any()
+
+
+def test_alpha_override_hooks():
+    """`alpha_band_pairs` / `set_alpha_overrides` (shared alpha decisions of the GPU parity test): overriding the band pairs
+    with the oracle's OWN decisions changes nothing; flipping ONE decision changes that pair's Gaussian and only Gaussians of
+    the same tile; clearing restores the plain backward."""
+    inp = scene_inputs("T1", scale_mult=2.0)
+    cam, W, H = inp["cam"], inp["W"], inp["H"]
+    bg = np.array([1.0, 0.5, 0.2], np.float32)
+    gpix = np.random.default_rng(5).standard_normal((3, H, W)).astype(np.float32)
+    _, _, _, ctx = rc.forward(_np(inp["means3D"]), _np(inp["opacities"]), bg, cam["world_view_transform"],
+                              cam["full_proj_transform"], cam["camera_center"], cam["tanfovx"], cam["tanfovy"], W, H,
+                              cov3D_precomp=_np(inp["cov6"]), shs=_np(inp["shs"]), sh_degree=3)
+    g0 = rc.backward(ctx, gpix)
+    gid, pix = rc.alpha_band_pairs(ctx, 5e-2)
+    assert len(gid) > 10 and (np.diff(pix.astype(np.int64) * (1 << 31) + gid) > 0).all()
+    geom = rc.geom(ctx)
+    dx, dy = geom["xy"][gid, 0] - (pix % W).astype(np.float32), geom["xy"][gid, 1] - (pix // W).astype(np.float32)
+    co = geom["conic_o"][gid]
+    power = np.float32(-0.5) * (co[:, 0] * dx * dx + co[:, 2] * dy * dy) - co[:, 1] * dx * dy
+    alpha = np.minimum(np.float32(0.99), co[:, 3] * np.exp(power))
+    sure = np.abs(alpha * 255.0 - 1.0) > 1e-4            # (numpy's exp vs libm's expf: stay off the exact threshold)
+    gid, pix, alpha, power = gid[sure], pix[sure], alpha[sure], power[sure]
+    own = ((power <= 0) & (alpha >= 1.0 / 255.0)).astype(np.uint8)
+    rc.set_alpha_overrides(ctx, gid, pix, own)
+    g1 = rc.backward(ctx, gpix)
+    for k in g0:
+        if g0[k] is not None:
+            assert np.array_equal(g0[k], g1[k]), k
+    i = int(np.flatnonzero(own == 1)[0])
+    flipped = own.copy(); flipped[i] = 0
+    rc.set_alpha_overrides(ctx, gid, pix, flipped)
+    g2 = rc.backward(ctx, gpix)
+    changed = np.flatnonzero(np.abs(g2["opacities"] - g0["opacities"]).reshape(-1) > 0)
+    start, plist = rc.tile_lists(ctx)
+    t = (int(pix[i]) // W // 16) * ((W + 15) // 16) + (int(pix[i]) % W) // 16
+    assert gid[i] in changed and set(changed.tolist()) <= set(plist[start[t]:start[t + 1]].tolist())
+    rc.set_alpha_overrides(ctx, gid[:0], pix[:0], own[:0])
+    g3 = rc.backward(ctx, gpix)
+    assert np.array_equal(g0["means3D"], g3["means3D"])

@@ -17,7 +17,7 @@ for _ in range(30):                      # clocks up, allocator warm
         p.grad = None
     f.step()
 torch.cuda.synchronize()
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 16)()
 assert L.d3ga_diag_scan_read(out, 1) == 0
 for p in f.params.values():
     p.grad = None
@@ -28,25 +28,37 @@ f.step()
 torch.cuda.synchronize()
 print("stage times of the measured step (ms):", {k: round(v[1], 4) for k, v in R.stage_timer.summary().items()})
 R.stage_timer.enabled = False
-assert L.d3ga_diag_scan_read(out, 1) == 0
-w = int(out[0])
-if int(out[7]):      # tile-level merge kernel (round 3): cache statistics only
-    print({"active_waves": w, "installs": int(out[3]), "hits": int(out[4]), "evictions": int(out[5]), "lock_loop_trips": int(out[6]),
-           "wave_groups": int(out[7]), "trips_per_group": round(int(out[6]) / max(int(out[7]), 1), 3),
-           "lines_to_hbm": int(out[3]) + int(out[5])})
-    import numpy as np
-    n = min(w, 32768)
-    buf = (ctypes.c_ulonglong * (4 * n))()
-    assert L.d3ga_diag_scan_waves(buf, n) == 0
-    a = np.array(buf, dtype=np.uint64).reshape(n, 4)
+assert L.d3ga_diag_scan_read(out, 0) == 0
+import numpy as np
+NW = 32768
+buf = (ctypes.c_ulonglong * (4 * NW))()
+assert L.d3ga_diag_scan_waves(buf, NW) == 0
+a = np.array(buf, dtype=np.uint64).reshape(NW, 4)
+a = a[a[:, 1] != 0]                      # (records are indexed by workgroup and wave, no atomics: inactive waves stay zero)
+n = w = len(a)
+if n:      # tile-level merge kernel (rounds 3+)
     t0 = (a[:, 0] & np.uint64((1 << 40) - 1)).astype(np.int64); t1 = (a[:, 1] & np.uint64((1 << 40) - 1)).astype(np.int64)
-    g = (a[:, 2] & np.uint64(0xffff)).astype(np.int64)
+    g = (a[:, 2] & np.uint64(0xffff)).astype(np.int64); trips = ((a[:, 2] >> np.uint64(16)) & np.uint64(0xffff)).astype(np.int64)
+    wave_groups = int(g.sum())
+    print({"active_waves": w, "installs": int(out[3]), "hits": int(out[4]), "evictions": int(out[5]), "lock_loop_trips": int(trips.sum()),
+           "wave_groups": wave_groups, "trips_per_group": round(int(trips.sum()) / max(wave_groups, 1), 3),
+           "lines_to_hbm": int(out[3]) + int(out[5])})
+    if int(out[8]):      # D3GA_DIAG=counters: lane efficiency = valid (entry, pixel) pairs / issued lane slots (wave groups x 64 lanes x 16 pixel steps)
+        print({"valid_pixel_pairs": int(out[8]), "entry_block_pairs": int(out[9]), "row_groups": int(out[10]),
+               "lane_efficiency": round(int(out[8]) / (wave_groups * 1024.0), 4),
+               "valid_pixels_per_entry_block_pair": round(int(out[8]) / max(int(out[9]), 1), 3),
+               "row_balance(4*wave_groups/row_groups)": round(4.0 * wave_groups / max(int(out[10]), 1), 3)})
     b = t0.min(); t0 -= b; t1 -= b
     dur = t1 - t0
     print("span (10 ns ticks)", int(t1.max()), "| active waves", n, "| groups: mean", round(float(g.mean()), 2), "max", int(g.max()),
           "p50/p90/p99", [int(np.percentile(g, q)) for q in (50, 90, 99)])
     print("start percentiles", [int(np.percentile(t0, q)) for q in (0, 25, 50, 75, 90, 100)], "end percentiles", [int(np.percentile(t1, q)) for q in (0, 25, 50, 75, 90, 100)])
+    print("wave duration (ticks): p50/p90/p99/max", [int(np.percentile(dur, q)) for q in (50, 90, 99, 100)])
     print("ticks per group: median", float(np.median(dur / g)), "p10", float(np.percentile(dur / g, 10)), "p90", float(np.percentile(dur / g, 90)))
+    early = t0 < 0.05 * t1.max()
+    print("waves that start in the first 5 % of the span:", int(early.sum()), "| their ticks per group by groups-of-the-wave quartile:",
+          [round(float(np.median((dur / g)[early & (g >= lo) & (g <= hi)])), 1) if (early & (g >= lo) & (g <= hi)).any() else None
+           for lo, hi in ((1, 4), (5, 8), (9, 12), (13, 99))])
     order = np.argsort(-t1)[:6]
     print("last waves to end (end, start, groups, ticks/group):", [(int(t1[i]), int(t0[i]), int(g[i]), round(float(dur[i] / g[i]), 1)) for i in order])
     order = np.argsort(-g)[:6]
