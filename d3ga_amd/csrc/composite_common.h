@@ -28,17 +28,6 @@ static inline int composite_merge_slots() {        // A/B knob: slots of the til
     }();
     return v;
 }
-// depth segments of the backward (1 | 2 | 4, D3GA_BWD_SEGMENTS): the forward leaves nseg - 1 checkpoints per quadrant, the
-// backward runs one workgroup per (tile, segment).  Read once: forward and backward of a process always agree.
-constexpr int kDefaultSegments = 1;
-static inline int composite_segments() {
-    static const int v = [] {
-        const char *e = getenv("D3GA_BWD_SEGMENTS");
-        const int n = e ? atoi(e) : kDefaultSegments;
-        return n >= 4 ? 4 : (n >= 2 ? 2 : 1);
-    }();
-    return v;
-}
 // block -> wavefront assignment of the backward's tile kernel: 0 quadrants, 1 interleaved (blocks 8 px apart), 2 by list
 // length (the default: DESIGN.md sec. 4; d3ga_debug_defaults() reports what THIS library runs and a test pins it)
 constexpr int kDefaultTileAssign = 2;
@@ -67,8 +56,6 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
                               const ImgBuf &im, int64_t d_capacity, const float *bg, const float *dL_dpix, float *acc,
                               bool ordered, const float *colors2, const float *bg2, const float *dL_dpix2, const L1Source &l1,
                               hipStream_t s);
-// what the forward writes for the depth segments of the backward (ImgBuf; all null / nseg 1: nothing)
-struct SegOut { uint32_t *blk_split; float4 *cfinal, *ckpt, *cfinal2, *ckpt2; int nseg; };
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll

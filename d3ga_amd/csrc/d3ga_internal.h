@@ -83,21 +83,10 @@ struct ImgBuf {
     // list of block b of a tile whose depth-sorted list is [begin, end) occupies blk_list[16*begin + b*(end-begin) ...],
     // blk_count[16*tile + b] entries {1-based position in the tile list, Gaussian index}, front to back.
     uint32_t *blk_count;   // 16 * tiles
-    // Depth segments of the backward (round 4; raster_composite_scan.hip): the forward leaves up to kMaxSegments - 1 CHECKPOINTS
-    // per 8x8 quadrant while it walks the tile list -- per pixel the transmittance and the colour accumulated so far (and the
-    // second image's colour), per block the number of list entries emitted so far -- so that the backward can start in the
-    // middle of a list: one workgroup per (tile, segment) instead of one per tile.
-    uint32_t *blk_split;   // (kMaxSegments - 1) * 16 * tiles   entries of block b emitted when checkpoint k was taken
-    float4 *cfinal;        // H*W      colour accumulated at the end (without the background term)
-    float4 *ckpt;          // (kMaxSegments - 1) * H*W   {T, C0, C1, C2} at checkpoint k
-    float4 *cfinal2;       // H*W      second image (render_pair)
-    float4 *ckpt2;         // (kMaxSegments - 1) * H*W   {E0, E1, E2, -}
     uint2 *blk_list;       // 16 * d_capacity
 };
-constexpr int kMaxSegments = 4;
 static inline int64_t img_bytes(int64_t W, int64_t H, int64_t tiles, int64_t dcap) {
-    return 2 * align256(4 * W * H) + align256(64 * tiles) + align256((kMaxSegments - 1) * 64 * tiles) +
-           2 * (align256(16 * W * H) + align256((kMaxSegments - 1) * 16 * W * H)) + align256(128 * dcap);
+    return 2 * align256(4 * W * H) + align256(64 * tiles) + align256(128 * dcap);
 }
 static inline ImgBuf carve_img(void *base, int64_t W, int64_t H, int64_t tiles) {
     ImgBuf i;
@@ -105,11 +94,6 @@ static inline ImgBuf carve_img(void *base, int64_t W, int64_t H, int64_t tiles) 
     i.final_T = (float *)p;        p += align256(4 * W * H);
     i.n_contrib = (uint32_t *)p;   p += align256(4 * W * H);
     i.blk_count = (uint32_t *)p;   p += align256(64 * tiles);
-    i.blk_split = (uint32_t *)p;   p += align256((kMaxSegments - 1) * 64 * tiles);
-    i.cfinal = (float4 *)p;        p += align256(16 * W * H);
-    i.ckpt = (float4 *)p;          p += align256((kMaxSegments - 1) * 16 * W * H);
-    i.cfinal2 = (float4 *)p;       p += align256(16 * W * H);
-    i.ckpt2 = (float4 *)p;         p += align256((kMaxSegments - 1) * 16 * W * H);
     i.blk_list = (uint2 *)p;
     return i;
 }

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
     float *__restrict__ out_invdepth, const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2,
     const float *__restrict__ bg2, float *__restrict__ out_color2, uint2 *__restrict__ blk_list,
-    uint32_t *__restrict__ blk_count, bool exact_cull, SegOut seg) {
+    uint32_t *__restrict__ blk_count, bool exact_cull) {
     const Quad q = tile_order ? quad_of_block_ordered(gx, gx * gy, tile_order) : quad_of_block(gx, gy);
     if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
     const int lane = threadIdx.x & 63;
@@ -82,10 +82,6 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     const uint32_t blk_cap = end - begin;
     uint2 *const blk_base = blk_list ? blk_list + 16 * (size_t)begin + (size_t)(4 * q.quad) * blk_cap : nullptr;
     uint32_t bc0 = 0, bc1 = 0, bc2 = 0, bc3 = 0;
-    // depth segments of the backward (ImgBuf): checkpoint kc is taken after the first batch whose last entry lies at or behind
-    // list position ceil(L kc / nseg) -- per pixel the running (T, colour), per block the entries emitted so far
-    const int nseg = blk_base ? seg.nseg : 1;
-    int kc = 1;
 
     __shared__ float4 s_co[65];
     __shared__ float4 s_rgb[65];
@@ -162,18 +158,6 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
         }
     };
 
-    const size_t hw_px = (size_t)H * W;
-    const size_t pid_px = (size_t)rg.py * W + rg.px;
-    auto take_checkpoint = [&](int k) {                   // k = 1 .. nseg - 1
-        if (inside) {
-            seg.ckpt[(size_t)(k - 1) * hw_px + pid_px] = make_float4(T, C0, C1, C2);
-            if constexpr (DUAL) seg.ckpt2[(size_t)(k - 1) * hw_px + pid_px] = make_float4(E0, E1, E2, 0.f);
-        }
-        if ((lane & 15) == 0) {
-            const int r = lane >> 4;
-            seg.blk_split[((size_t)(k - 1) * gx * gy + q.tile) * 16 + 4 * q.quad + r] = r == 0 ? bc0 : (r == 1 ? bc1 : (r == 2 ? bc2 : bc3));
-        }
-    };
     if (begin < end) { chunk_ids(begin); chunk_recs(); }
     __builtin_amdgcn_wave_barrier();
     fill();
@@ -185,7 +169,6 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
         const float4 cco = nco, crgb = nrgb, crgb2 = nrgb2;
         const uint2 cpg = bpg;
         const bool have = (uint32_t)lane < bn;
-        const uint32_t cbn = bn;
         const SplatCull sc = splat_cull(cco.x, cco.y, cco.z, cco.w);
         const float hx = have ? sc.hx : -1.0f, hy = sc.hy;
         __builtin_amdgcn_wave_barrier();                  // previous batch's LDS reads are done (program order)
@@ -297,21 +280,7 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
 #ifdef D3GA_DIAG_TIMELINE
         df_blend_ticks += __builtin_amdgcn_s_memrealtime() - df_tb;
 #endif
-        if (nseg > 1 && !all_done) {
-            // 1-based list position of the batch's last entry: everything up to it is blended (or culled) for every pixel
-            const uint32_t bpos = (uint32_t)__builtin_amdgcn_readlane((int)cpg.x, (int)cbn - 1);
-            while (kc < nseg && (uint64_t)bpos * (uint32_t)nseg >= (uint64_t)blk_cap * (uint32_t)kc) { take_checkpoint(kc); ++kc; }
-        }
         if (all_done) break;
-    }
-    if (nseg > 1) {
-        // checkpoints the walk never reached (list exhausted or quadrant saturated first): the final state -- the segments
-        // behind them are empty -- and the colour accumulated at the end, from which the backward forms "colour behind"
-        for (; kc < nseg; ++kc) take_checkpoint(kc);
-        if (inside && end > begin) {
-            seg.cfinal[pid_px] = make_float4(C0, C1, C2, 0.f);
-            if constexpr (DUAL) seg.cfinal2[pid_px] = make_float4(E0, E1, E2, 0.f);
-        }
     }
     if (inside) {
         const size_t pid = (size_t)rg.py * W + rg.px;
@@ -405,16 +374,15 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
     ImgBuf im = carve_img(img, prm->W, prm->H, (int64_t)gx * gy);
-    if (prm->forward_only) { im.blk_list = nullptr; im.blk_count = nullptr; im.blk_split = nullptr; im.cfinal = im.ckpt = im.cfinal2 = im.ckpt2 = nullptr; }     // the buffer ends behind n_contrib
+    if (prm->forward_only) { im.blk_list = nullptr; im.blk_count = nullptr; }     // the buffer ends behind n_contrib
     const bool ordered = (composite_variant() & kVariantOrdered) != 0, exact = (composite_variant() & kVariantExactCull) != 0;
     const dim3 grid(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy));
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
-    const SegOut segout = {im.blk_split, im.cfinal, im.ckpt, im.cfinal2, im.ckpt2, im.blk_list ? composite_segments() : 1};
 #define D3GA_LAUNCH_FWD(DUALV, DEPTHV)                                                                                          \
     hipLaunchKernelGGL((composite_fwd_q_kernel<DUALV, DEPTHV>), grid, dim3(64),                                                     \
                        lds_pad_bytes((const void *)composite_fwd_q_kernel<DUALV, DEPTHV>, "D3GA_FWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
                        bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,     \
-                       out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact, segout)
+                       out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact)
     if (colors2) { if (out_invdepth) D3GA_LAUNCH_FWD(true, true); else D3GA_LAUNCH_FWD(true, false); }
     else { if (out_invdepth) D3GA_LAUNCH_FWD(false, true); else D3GA_LAUNCH_FWD(false, false); }
 #undef D3GA_LAUNCH_FWD

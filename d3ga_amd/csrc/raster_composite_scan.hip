@@ -90,7 +90,7 @@ __device__ __forceinline__ ScanEntry scan_gather(uint2 pg, const float2 *__restr
 
 #ifdef D3GA_DIAG
 __device__ unsigned long long g_diag_scan[16];    // diagnostic build only (tools/diag_scan.py): loop statistics of the kernel below
-__device__ unsigned long long g_diag_waves[131072 * 4];   // per active wave: s_memtime at start / end, groups, HW_ID | XCC_ID << 32
+__device__ unsigned long long g_diag_waves[32768 * 4];   // per active wave: s_memtime at start / end, groups, HW_ID | XCC_ID << 32
 #endif
 // forces the compiler's s_waitcnt for these registers HERE (an empty asm that reads them)
 template <bool DUAL>
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
     float *__restrict__ acc, const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2,
     const float *__restrict__ bg2, const float *__restrict__ dL_dpix2, const uint2 *__restrict__ blk_list,
-    const uint32_t *__restrict__ blk_count, int assign, L1Source l1, SegOut sg) {
+    const uint32_t *__restrict__ blk_count, int assign, L1Source l1) {
     static_assert((S & (S - 1)) == 0, "power of two");
     constexpr int NW = 4;                            // wavefronts per tile (three, the third walking two sets of blocks: measured, slower -- DESIGN.md sec. 4)
     constexpr int PIXF = DUAL ? 12 : 8;
@@ -139,26 +139,12 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     constexpr uint32_t kLocked = 0xffffffffu;
     const bool early_exit_off = (assign & 8) != 0;         // A/B: bit 3 of D3GA_TILE_ASSIGN keeps every wavefront until the tile is done
     assign &= 7;
-    // Depth segments (round 4): one workgroup per (tile, segment) -- workgroup b works on segment b % nseg of the tile of rank
-    // b / nseg; segment s of a block's list = the entries the forward had emitted between its checkpoints s and s + 1
-    // (ImgBuf::blk_split), its pixels start from checkpoint s + 1 (the last segment: from the final state).
     const int tiles = gx * gy;
-    const int nseg = sg.nseg, seg = nseg > 1 ? (int)(blockIdx.x % (unsigned)nseg) : 0;
-    const int trank = nseg > 1 ? (int)(blockIdx.x / (unsigned)nseg) : (int)blockIdx.x;
-    const int tile = tile_order ? (trank < tiles ? (int)tile_order[trank] : -1) : (trank < tiles ? trank : -1);
+    const int tile = tile_order ? ((int)blockIdx.x < tiles ? (int)tile_order[blockIdx.x] : -1) : ((int)blockIdx.x < tiles ? (int)blockIdx.x : -1);
     if (tile < 0) return;                                  // uniform over the workgroup
     const uint32_t begin = (uint32_t)min((uint64_t)tile_start[tile], dcap);
     const uint32_t end = (uint32_t)min((uint64_t)tile_start[tile + 1], dcap);
     if (begin >= end) return;                              // uniform: empty tile
-    const int tx0 = (tile % gx) * kTile, ty0 = (tile / gx) * kTile;
-    // [lo, hi) of block j's list in this segment (the forward writes counts and splits of quadrants that start inside the image)
-    auto seg_range = [&](int j, uint32_t &lo, uint32_t &hi) {
-        const int q = j >> 2;
-        lo = hi = 0u;
-        if (!(tx0 + ((q & 1) << 3) < W && ty0 + ((q >> 1) << 3) < H)) return;
-        hi = (seg < nseg - 1) ? sg.blk_split[((size_t)seg * tiles + tile) * 16 + j] : blk_count[16 * (size_t)tile + j];
-        lo = seg > 0 ? sg.blk_split[((size_t)(seg - 1) * tiles + tile) * 16 + j] : 0u;
-    };
 
     __shared__ __attribute__((aligned(16))) float s_pix_all[NW][4 * ROWF];
     __shared__ __attribute__((aligned(16))) float s_dump_all[NW][64 * 2 + 16 * PIXF];
@@ -168,8 +154,11 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     if (threadIdx.x == 0) s_arrived = 0u;
     __shared__ uint8_t s_perm[16];                          // assign 2: the tile's 16 blocks by descending list length
     if (assign == 2 && threadIdx.x < 16) {
-        const int b = threadIdx.x;
-        auto count_of = [&](int j) -> uint32_t { uint32_t lo, hi; seg_range(j, lo, hi); return hi - lo; };
+        const int b = threadIdx.x, tx0 = (tile % gx) * kTile, ty0 = (tile / gx) * kTile;
+        auto count_of = [&](int j) -> uint32_t {            // (the forward writes the counts of quadrants that start inside the image)
+            const int q = j >> 2;
+            return (tx0 + ((q & 1) << 3) < W && ty0 + ((q >> 1) << 3) < H) ? blk_count[16 * (size_t)tile + j] : 0u;
+        };
         const uint32_t mine = count_of(b);
         int rank = 0;
 #pragma unroll
@@ -212,7 +201,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
             bx = 2 * (q & 1) + (r & 1); by = 2 * (q >> 1) + (r >> 1);
         }
         const int blk = 4 * ((bx >> 1) + 2 * (by >> 1)) + ((bx & 1) + 2 * (by & 1));
-        const int bx0 = tx0 + 4 * bx, by0 = ty0 + 4 * by;      // block origin in pixels
+        const int bx0 = (tile % gx) * kTile + 4 * bx, by0 = (tile / gx) * kTile + 4 * by;      // block origin in pixels
         const int px = bx0 + (l16 & 3), py = by0 + (l16 >> 2);
         const bool inside = px < W && py < H;
         const size_t pid = (size_t)py * W + px;
@@ -239,31 +228,20 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
         }
         const uint32_t maxlast = wave_max_u32(last);
         if (maxlast == 0) break;
-        // state behind this segment: transmittance after its last entry, and (colour blended behind it) . dL/dpixel
-        float T_start = T_final, S_start = 0.f;
-        if (seg < nseg - 1 && inside) {
-            const float4 ck = sg.ckpt[(size_t)seg * hw + pid], cf = sg.cfinal[pid];
-            T_start = ck.x;
-            S_start = g0 * (cf.x - ck.y) + g1 * (cf.y - ck.z) + g2 * (cf.z - ck.w);
-            if constexpr (DUAL) {
-                const float4 ck2 = sg.ckpt2[(size_t)seg * hw + pid], cf2 = sg.cfinal2[pid];
-                S_start += h0 * (cf2.x - ck2.x) + h1 * (cf2.y - ck2.y) + h2 * (cf2.z - ck2.z);
-            }
-        }
 
         float *const pixrow = s_pix + row * ROWF;
         float *const wr_base = l16 == 15 ? pixrow : s_dump + 2 * lane;
         {
             float *rec = pixrow + l16 * PIXF;
-            *reinterpret_cast<float4 *>(rec) = make_float4(T_start, S_start, g0, g1);
+            *reinterpret_cast<float4 *>(rec) = make_float4(T_final, 0.f, g0, g1);
             *reinterpret_cast<float4 *>(rec + 4) = make_float4(g2, T_final * bg_dot, __uint_as_float(last), 0.f);
             if constexpr (DUAL) *reinterpret_cast<float4 *>(rec + 8) = make_float4(h0, h1, h2, 0.f);
         }
         const uint32_t blk_cap = end - begin;
-        uint32_t seg_lo, seg_hi;
-        seg_range(blk, seg_lo, seg_hi);
-        const uint32_t cnt = seg_hi - seg_lo;              // this segment's entries of the block's list: [seg_lo, seg_hi)
-        const uint2 *const list = blk_list + 16 * (size_t)begin + (size_t)blk * blk_cap + seg_lo;
+        // (the forward writes blk_count only for quadrants that start inside the image)
+        const bool quad_in = bx0 - 4 * (bx & 1) < W && by0 - 4 * (by & 1) < H;
+        const uint32_t cnt = quad_in ? blk_count[16 * (size_t)tile + blk] : 0u;
+        const uint2 *const list = blk_list + 16 * (size_t)begin + (size_t)blk * blk_cap;
         const int ngroups = (int)((wave_max_u32(cnt) + 15u) >> 4);
         const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
         const float bxr = (float)bx0, byr = (float)by0;
@@ -451,7 +429,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     atomicAdd(&g_diag_scan[8], dg_valid); atomicAdd(&g_diag_scan[9], dg_entries); atomicAdd(&g_diag_scan[10], dg_rowgroups);
 #endif
 #ifdef D3GA_DIAG_TIMELINE
-    if (lane == 0 && dg_groups && blockIdx.x < 32768) {      // no atomics here: returning same-address atomics serialise at the memory side and would BE the timeline
+    if (lane == 0 && dg_groups && blockIdx.x < 8192) {      // no atomics here: returning same-address atomics serialise at the memory side and would BE the timeline
         const unsigned long long diag_w1 = __builtin_amdgcn_s_memrealtime();
         const size_t slot = 4 * (size_t)blockIdx.x + wave;
         g_diag_waves[4 * slot] = diag_w0 | ((__builtin_readcyclecounter() - diag_t0) << 40);
@@ -489,11 +467,11 @@ extern "C" int d3ga_diag_scan_read(unsigned long long *out16, int reset) {
         unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag_scan), z, sizeof(z)) != hipSuccess) return 1;
         void *w = nullptr;
-        if (hipGetSymbolAddress(&w, HIP_SYMBOL(g_diag_waves)) != hipSuccess || hipMemset(w, 0, sizeof(unsigned long long) * 4 * 131072) != hipSuccess) return 1;
+        if (hipGetSymbolAddress(&w, HIP_SYMBOL(g_diag_waves)) != hipSuccess || hipMemset(w, 0, sizeof(unsigned long long) * 4 * 32768) != hipSuccess) return 1;
     }
     return 0;
 }
-extern "C" int d3ga_diag_scan_waves(unsigned long long *out, int n) {      // n <= 131072 records of 4 words
+extern "C" int d3ga_diag_scan_waves(unsigned long long *out, int n) {      // n <= 32768 records of 4 words
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_waves), sizeof(unsigned long long) * 4 * (size_t)n) != hipSuccess;
 }
 #endif
@@ -504,14 +482,13 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
                               hipStream_t s) {
     // workgroup per tile, heaviest tiles first (tile_order of the bin stage); S = slots of the tile's merge cache
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
-    const SegOut sg = {im.blk_split, im.cfinal, im.ckpt, im.cfinal2, im.ckpt2, composite_segments()};
-    const dim3 tgrid(gx * gy * sg.nseg);
+    const dim3 tgrid(gx * gy);
     const int S = composite_merge_slots();
 #define D3GA_LAUNCH_TILE(DUALV, SV)                                                                                           \
     hipLaunchKernelGGL((composite_bwd_tile_kernel<DUALV, SV>), tgrid, dim3(256),                                               \
                        lds_pad_bytes((const void *)composite_bwd_tile_kernel<DUALV, SV>, "D3GA_BWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
                        (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc, order,   \
-                       colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, composite_tile_assign(), l1, sg)
+                       colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, composite_tile_assign(), l1)
     if (colors2) { if (S >= 512) D3GA_LAUNCH_TILE(true, 512); else D3GA_LAUNCH_TILE(true, 256); }
     else if (S >= 1024) D3GA_LAUNCH_TILE(false, 1024);
     else if (S >= 512) D3GA_LAUNCH_TILE(false, 512);

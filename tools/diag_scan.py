@@ -30,7 +30,7 @@ print("stage times of the measured step (ms):", {k: round(v[1], 4) for k, v in R
 R.stage_timer.enabled = False
 assert L.d3ga_diag_scan_read(out, 0) == 0
 import numpy as np
-NW = 131072
+NW = 32768
 buf = (ctypes.c_ulonglong * (4 * NW))()
 assert L.d3ga_diag_scan_waves(buf, NW) == 0
 a = np.array(buf, dtype=np.uint64).reshape(NW, 4)
