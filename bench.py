@@ -45,6 +45,12 @@ def parse():
                     help="N>1 gradient exchange: 'cut' = summed at the rasterizer's inputs with the SH gradient in factored "
                          "form (dist.ViewShardedGrads); 'params' = one all-reduce per parameter tensor (dist.GradReducer)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the 2-render training-step variant")
+    ap.add_argument("--train-step", choices=("color",), default=None,
+                    help="instead of the frame: the reference's REAL training step (configs/actorshq_actor02.yml, use_shs false) -- two "
+                         "renders, DeformationField / CanonicalField / ColorField, L1 + SSIM + silhouette + scale regulariser, "
+                         "clip_grad_norm_, Adam -- on N ranks, one view per rank, with the parameter gradients averaged by per-bucket "
+                         "asynchronous all-reduces issued while the backward still runs (dist.BucketedGradReducer).  BASELINE "
+                         "config 4; default workload C4 (135k Gaussians, 748x1022)")
     ap.add_argument("--field-mlp", action="store_true",
                     help="instead of the frame: the per-Gaussian CanonicalField network (SURVEY sec. 8f rank 1) forward + "
                          "backward at the workload's Gaussian count, roofline against the f32 MFMA peak")
@@ -635,6 +641,132 @@ def field_mlp_bench(args):
     print(json.dumps(out))
 
 
+def color_train_bench(args):
+    """`--train-step color`: BASELINE configs[3] -- the actor02-shaped training step on N ranks (camera sharding, parameter-level
+    gradient exchange: the rasterizer's inputs are view-dependent there, so the cut exchange of the SH frame is invalid)."""
+    from d3ga_amd import dist as ddist
+    if args.single_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, local, world = ddist.init_process_group(args.backend)
+    if world != max(args.gpus, 1):
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a line under the wrong N", file=sys.stderr)
+        sys.exit(3)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    if world > 1 and not args.single_device and torch.cuda.device_count() < world:
+        sys.exit(3)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import d3ga_amd
+    d3ga_amd.lib()
+    from d3ga_amd import rasterizer as R
+    wl_name = args.workload if args.workload != "C3" or "--workload" in sys.argv else "C4"
+    frame = Frame(wl_name, dev, view_index=rank % 8)
+    R.set_accumulator_policy("persistent")
+    kw = dict(with_fields="color", pair=True, scale_weight=175.0)
+    frame.train_step(**kw)                                 # creates the three networks (seeded: identical on every rank), sizes the scratch
+    cnt = R.last_counters()
+    d_max = torch.tensor([float(cnt["D"])], device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(d_max, op=torch.distributed.ReduceOp.MAX)
+    R.set_capacity_policy("static", int(2.0 * float(d_max.item())) + 4096)      # (the avatar is OPTIMISED here: its splats grow)
+    p = frame.params
+    nets = {"color_field": list(frame.color_field.parameters()), "canonical_field": list(frame.canon_field.parameters()),
+            "deformation_field": list(frame.deform_field.parameters())}
+    # buckets in the order their gradients complete in the backward (the colour network sits last in the forward)
+    buckets = [nets["color_field"], [frame.color_feat], [frame.frame_enc], nets["canonical_field"], [p["rotation"]], [p["scaling"]],
+               nets["deformation_field"]]
+    leaves = [q for b in buckets for q in b]
+    red = ddist.BucketedGradReducer(buckets, timing=True)
+    opt = torch.optim.Adam(leaves, lr=1e-4)
+    losses = []
+
+    def one_step():
+        red.begin_step()
+        loss = frame.train_step(**kw)
+        red.finish()
+        torch.nn.utils.clip_grad_norm_(leaves, 1.0)       # AFTER the reduce (models/trainer.py:188)
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # N = 1 reference on every rank (identical replicas afterwards: the parameters are restored)
+    state = [q.detach().clone() for q in leaves]
+    n1_ms = None
+    if world > 1:
+        active = red._active
+        red._active = lambda: False                        # the N = 1 step of the same frame: hooks count, nothing goes on the wire
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(5, args.steps // 5)):
+            one_step()
+        torch.cuda.synchronize()
+        n1 = torch.tensor([1e3 * (time.perf_counter() - t0) / max(5, args.steps // 5)], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(n1, op=torch.distributed.ReduceOp.MAX)
+        n1_ms = float(n1.item())
+        red._active = active
+        with torch.no_grad():
+            for q, q0 in zip(leaves, state):
+                q.copy_(q0)
+        opt = torch.optim.Adam(leaves, lr=1e-4)
+    for _ in range(args.warmup):
+        one_step()
+    red.exchange_ms()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(one_step().detach())
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    ones = torch.ones(1, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(ones)
+    ex_ms = red.exchange_ms()
+    # replicas must stay bit-identical: every rank applied the same averaged gradients to the same parameters
+    chk = torch.stack([q.detach().double().sum() for q in leaves] + [q.detach().double().abs().sum() for q in leaves])
+    same = True
+    if world > 1:
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        same = bool(torch.equal(lo, hi))
+    ms = 1e3 * float(tmax.item()) / args.steps
+    ls = torch.stack(losses).float().cpu()
+    if rank == 0:
+        wl = frame.wl
+        out = {"metric": "training steps (views)/sec, actor02-shaped step: 2 renders + Deformation/Canonical/ColorField + L1/SSIM/silhouette + Adam",
+               "value": round(world * 1e3 / ms, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic", "lib_sha256": lib_sha256(),
+               "config": {"workload": f"{wl_name}: {wl.n_gaussians} Gaussians, {frame.batch['width']}x{frame.batch['height']}, use_shs false "
+                                      f"(configs/actorshq_actor02.yml), one view per rank", "views_per_step": world,
+                          "parallelism": f"camera-sharded dp{world}", "grad_exchange": "per-bucket asynchronous all-reduce of ALL parameter "
+                          "gradients from post-accumulate hooks (dist.BucketedGradReducer): the rasterizer's inputs are view-dependent",
+                          "grad_exchange_bytes_per_rank": red.nbytes(), "buckets": len(red.buckets)},
+               "roofline": None, "cpu_baseline": None,
+               "loss_first_last": [round(float(ls[:5].mean()), 5), round(float(ls[-5:].mean()), 5)], "loss_finite": bool(torch.isfinite(ls).all()),
+               "replicas_identical": same, "launch_mode": "eager",
+               "distributed": {"nranks_seen": int(ones.item()), "n1_ms_per_step": None if n1_ms is None else round(n1_ms, 4),
+                               "efficiency": None if n1_ms is None else round(n1_ms / ms, 4),
+                               "bucket_ms": None if ex_ms is None else round(ex_ms, 4),
+                               "note": "bucket_ms: mean HIP-event time from a bucket's launch to its averaged gradients (upper bound of the "
+                                       "exposed wire time: early buckets complete behind the rest of the backward)"}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        if int(ones.item()) != world or not same:
+            sys.exit(4)
+
+
 def _self_launch(n):
     """`python bench.py --gpus N` WITHOUT a launcher (WORLD_SIZE unset): re-exec this command line under
     `python -m torch.distributed.run`, one rank per GPU, exactly as the driver launches N > 1 -- a plain invocation must
@@ -658,6 +790,8 @@ def main():
         return field_mlp_bench(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_cut:
         sys.exit(_self_launch(args.gpus))
+    if args.train_step == "color":
+        return color_train_bench(args)
     from d3ga_amd import dist as ddist
     if args.single_device:
         os.environ["LOCAL_RANK"] = "0"

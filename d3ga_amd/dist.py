@@ -311,3 +311,123 @@ class ViewShardedGrads:
         ms = [a.elapsed_time(b) for a, b in self._events]
         self._events = []
         return sum(ms) / len(ms)
+
+
+class BucketedGradReducer:
+    """Parameter-level gradient averaging that OVERLAPS with the backward: one asynchronous all-reduce per bucket, issued from
+    post-accumulate hooks the moment the last gradient of the bucket has been written ("bucketed all-reduce
+    launched from autograd post-accumulate hooks").
+
+    This is the exchange for configurations whose rasterizer inputs are VIEW-DEPENDENT -- the reference's main configuration
+    (configs/actorshq_actor02.yml: use_shs false; colour and opacity from ColorField(view_dir, camera / frame encodings),
+    models/cage_net.py:232-258) -- where `ViewShardedGrads`' cut is invalid and every parameter gradient has to be summed.
+
+        red = BucketedGradReducer([color_field.parameters(), canon_field.parameters(), [color_feat], ...])
+        for step in ...:
+            red.begin_step()                  # drops the gradients (autograd then hands every parameter a fresh tensor: no zero fill)
+            loss.backward()                   # hooks fire: ColorField's bucket is on the wire while the deform backward still runs
+            red.finish()                      # waits for the collectives, divides by the world size
+            clip_grad_norm_(...); optimizer.step()        # AFTER the reduce (models/trainer.py:188)
+
+    A bucket of ONE tensor is reduced in place (the (P,64) colour features: 35 MB at 135k Gaussians -- no staging copy); a
+    bucket of several tensors (the ~10 weights and biases of a network, ~0.3 MB) goes through one flat staging buffer: one
+    collective instead of ten.  Buckets are reduced in the order their gradients complete, which is the same on every rank
+    (the same autograd graph), so the collectives match up.  `finish()` raises if a bucket never completed (a parameter
+    that took no part in the loss): silently skipping it would desynchronise the ranks' collectives.
+    No-op exchange (hooks still count) when torch.distributed is not initialised or the world size is 1, unless `always`."""
+
+    def __init__(self, buckets, group=None, always=False, timing=False):
+        self.group, self.always, self.timing = group, always, timing
+        self.buckets = []
+        for b in buckets:
+            ps = [p for p in b if p.requires_grad]
+            if ps:
+                self.buckets.append(ps)
+        self._flat = [None if len(b) == 1 else torch.empty(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
+                      for b in self.buckets]
+        self._left, self._work, self._events = [0] * len(self.buckets), [], []
+        self._handles = []
+        for i, b in enumerate(self.buckets):
+            for p in b:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        self.begin_step()
+
+    def _active(self):
+        return self.always or (dist.is_initialized() and dist.get_world_size(self.group) > 1)
+
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def nbytes(self):
+        return 4 * sum(p.numel() for b in self.buckets for p in b)
+
+    def _make_hook(self, i):
+        def hook(_param):
+            self._left[i] -= 1
+            if self._left[i] == 0:
+                self._launch(i)
+        return hook
+
+    def _launch(self, i):
+        if not self._active():
+            return
+        b = self.buckets[i]
+        if self.timing:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if len(b) == 1:
+            t = b[0].grad
+        else:
+            t = self._flat[i]
+            torch._foreach_copy_(list(t.split([p.numel() for p in b])), [p.grad.reshape(-1) for p in b])
+        w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if dist.is_initialized() else None
+        self._work.append((i, w, e0 if self.timing else None))
+
+    def begin_step(self):
+        for b in self.buckets:
+            for p in b:
+                p.grad = None
+        self._left = [len(b) for b in self.buckets]
+        self._work = []
+
+    def finish(self):
+        """Wait for every bucket's collective and turn the sums into means.  Returns the number of buckets reduced."""
+        if any(n != 0 for n in self._left):
+            missing = [i for i, n in enumerate(self._left) if n != 0]
+            raise RuntimeError(f"BucketedGradReducer.finish(): buckets {missing} did not receive all their gradients in this backward "
+                               "(a parameter outside the loss?): their collectives were not issued")
+        if not self._active():
+            return 0
+        inv = 1.0 / float(self.world())
+        for i, w, e0 in self._work:
+            if w is not None:
+                w.wait()
+            b = self.buckets[i]
+            if len(b) == 1:
+                b[0].grad.mul_(inv)
+            else:
+                parts = list(self._flat[i].split([p.numel() for p in b]))
+                torch._foreach_mul_(parts, inv)
+                torch._foreach_copy_([p.grad.reshape(-1) for p in b], parts)
+            if e0 is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self._events.append((e0, e1))
+        n = len(self._work)
+        self._work = []
+        return n
+
+    def exchange_ms(self):
+        """Mean milliseconds from a bucket's launch to its averaged gradients (HIP events; `timing=True`) since the last call --
+        an upper bound of the exposed wire time: buckets launched early complete behind the rest of the backward."""
+        if not self._events:
+            return None
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._events) / len(self._events)
+        self._events = []
+        return ms
+
+    def close(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

@@ -113,6 +113,78 @@ def test_flat_grad_allreduce_two_ranks():
         assert dict(out) == {0: True, 1: True}
 
 
+def _bucket_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from d3ga_amd import dist as dd
+    dd.init_process_group(backend="gloo")
+    torch.manual_seed(0)                                   # identical replicas
+    net_a, net_b = torch.nn.Linear(6, 8), torch.nn.Linear(8, 3)
+    feat = torch.randn(20, 6, requires_grad=True)
+    unused = torch.randn(3, requires_grad=True)
+    red = dd.BucketedGradReducer([net_b.parameters(), net_a.parameters(), [feat]])
+    order = []
+    launch = red._launch
+    red._launch = lambda i: (order.append(i), launch(i))[1]
+    ok = True
+    for step in range(3):
+        # a "view-dependent" loss: the ranks see different cameras (inputs scaled by rank + 1)
+        def loss_of(view):
+            x = feat * (view + 1.0)
+            return (net_b(torch.tanh(net_a(x))) ** 2).mean()
+        red.begin_step()
+        ok = ok and all(p.grad is None for p in net_a.parameters())
+        loss_of(rank).backward()
+        ok = ok and red.finish() == 3
+        mine = [p.grad.clone() for p in list(net_a.parameters()) + list(net_b.parameters()) + [feat]]
+        # the sequential two-view mean on this rank alone
+        for p in list(net_a.parameters()) + list(net_b.parameters()) + [feat]:
+            p.grad = None
+        red.close()
+        ((loss_of(0) + loss_of(1)) / world).backward()
+        ref = [p.grad.clone() for p in list(net_a.parameters()) + list(net_b.parameters()) + [feat]]
+        ok = ok and all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(mine, ref))
+        red = dd.BucketedGradReducer([net_b.parameters(), net_a.parameters(), [feat]])
+        launch = red._launch
+        red._launch = lambda i, launch=launch: (order.append(i), launch(i))[1]
+    # buckets go on the wire in the order their gradients complete: the last layer's first (overlap with the rest of the backward)
+    ok = ok and order[:3][0] == 0 and sorted(order[:3]) == [0, 1, 2]
+    # a bucket that never completes is an error on every rank, not a silent skip
+    red.close()
+    red = dd.BucketedGradReducer([net_a.parameters(), [unused]])
+    red.begin_step()
+    (net_a(feat) ** 2).mean().backward()
+    try:
+        red.finish()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "buckets [1]" in str(e)
+    for _, w, _ in red._work:                             # (the completed bucket's collective is in flight on both ranks: drain it)
+        w.wait()
+    out[rank] = bool(ok)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_bucketed_grad_reducer_two_ranks():
+    """BucketedGradReducer (the exchange of the ColorField configuration: view-dependent rasterizer inputs): per-bucket asynchronous
+    all-reduces from post-accumulate hooks give the mean over the ranks' views, equal to the sequential two-view mean."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        out = m.dict()
+        procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        assert dict(out) == {0: True, 1: True}
+
+
 def test_shard_views_covers_everything():
     from d3ga_amd.dist import shard_views
     for n, w in ((8, 8), (8, 2), (5, 2), (3, 4)):

@@ -76,3 +76,20 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
            "--backend", "gloo", "--single-device", "--workload", "C1", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_color_train_step_two_ranks():
+    """BASELINE configs[3] entry point: `bench.py --train-step color --gpus 2` (self-launched, both ranks on the test box's one
+    GPU over gloo): the actor02-shaped step with all three field networks, parameter gradients averaged by per-bucket
+    asynchronous all-reduces; every rank counted, replicas bit-identical after the optimised steps, loss finite."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--train-step", "color", "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--backend", "gloo", "--single-device", "--workload", "C1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["distributed"]["nranks_seen"] == 2 and d["replicas_identical"] is True and d["loss_finite"] is True
+    assert d["config"]["views_per_step"] == 2 and d["config"]["buckets"] == 7 and d["config"]["grad_exchange_bytes_per_rank"] > 0
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) / d["value"] < 0.02

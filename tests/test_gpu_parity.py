@@ -1276,6 +1276,102 @@ def test_full_size_c5_properties_without_an_oracle():
     assert rel_err(_np(m.grad), -3.0 * _np(g1)) < 1e-4
 
 
+def test_c5_window_against_the_oracle():
+    """Oracle parity ABOVE C3 size: BASELINE configs[4] (2M Gaussians, 8 cages, 3840x2160) is rendered in
+    full by the HIP path; the CPU oracle gets only the Gaussians whose footprint can reach a 64 x 64-tile window around the
+    longest tile list of the frame (chosen independently of the HIP lists: projected centre +- (radius + 1) px), renders the
+    same full-size frame from them, and inside the window everything must agree: radii, the depth-ordered tile lists bit for
+    bit (the 2049+ / 4097+ sort classes on a natural scene, not an inflated one), every non-marginal pixel to 1e-4, and --
+    with an incoming gradient that is zero outside the window, so that only window pixels contribute on either side -- the
+    gradients of every Gaussian of the subset on the strict element-wise bar; Gaussians outside the subset must get
+    exactly zero."""
+    from d3ga_amd import rasterizer as R
+    from d3ga_amd import synthetic as syn
+    from d3ga_amd.cage_deform import cage_deform, canonical_gradient, lbs_cage
+    from d3ga_amd.cameras import batch_to_camera
+    import time
+    sc = syn.make_scene("C5")
+    wl = sc["workload"]
+    W, H = wl.width, wl.height
+    d = lambda t: t.to(DEV)
+    tetras, tid = d(sc["tetras"]), d(sc["tetra_id"])
+    tp = lbs_cage(d(sc["canon_points"]), d(sc["delta_node"]), d(sc["joint_mats"]), d(sc["skin_idx"]), d(sc["skin_w"]))
+    cg = canonical_gradient(d(sc["canon_points"]), tetras, tid).contiguous()
+    with torch.no_grad():
+        means0, cov0 = cage_deform(tp, tetras, tid, d(sc["barys"]), cg, d(sc["scaling"]), d(sc["rotation"]), scale_activation="exp")
+    P = means0.shape[0]
+    means, cov = means0.clone().requires_grad_(True), cov0.clone().requires_grad_(True)
+    op = torch.sigmoid(d(sc["opacity_logit"])).detach().requires_grad_(True)
+    col = torch.rand(P, 3, generator=torch.Generator().manual_seed(2)).to(DEV).requires_grad_(True)
+    m2d = torch.zeros_like(means, requires_grad=True)
+    b = syn.make_batch(W, H)
+    cam = batch_to_camera(b, device=DEV)
+    bg = torch.tensor([0.2, 0.4, 0.1])
+    st = R.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg.to(DEV), scale_modifier=1.0,
+        viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=0, campos=cam.camera_center,
+        prefiltered=False, debug=False)
+    color, radii, _ = R.GaussianRasterizer(st)(means3D=means, means2D=m2d, opacities=op, colors_precomp=col, cov3D_precomp=cov)
+    cnt = R.last_counters()
+    assert not cnt["overflow"] and cnt["max_tile"] > 2048, cnt
+    start, plist, _ = R.last_tile_lists(W, H)
+    start, plist = _np(start), _np(plist)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    # window: 64 x 64 tiles around the longest list
+    t_max = int(np.argmax(start[1:] - start[:-1]))
+    WT = 64
+    tx0 = int(np.clip(t_max % gx - WT // 2, 0, gx - WT)); ty0 = int(np.clip(t_max // gx - WT // 2, 0, gy - WT))
+    x0, y0, x1, y1 = 16 * tx0, 16 * ty0, min(16 * (tx0 + WT), W), min(16 * (ty0 + WT), H)      # pixels [x0, x1) x [y0, y1)
+    # subset, independent of the HIP lists: projected centre (float64, the reference's conventions) +- (radius + 1) px meets the window
+    m64 = _np(means0).astype(np.float64)
+    proj = _np(cam.full_proj_transform).astype(np.float64)
+    hom = np.concatenate([m64, np.ones((P, 1))], 1) @ proj
+    ndc = hom[:, :2] / (hom[:, 3:4] + 1e-7)
+    cx, cy = ((ndc[:, 0] + 1) * W - 1) * 0.5, ((ndc[:, 1] + 1) * H - 1) * 0.5
+    rr = _np(radii).astype(np.float64) + 1.0
+    sub = (_np(radii) > 0) & (cx + rr >= x0) & (cx - rr <= x1 - 1) & (cy + rr >= y0) & (cy - rr <= y1 - 1)
+    ids = np.flatnonzero(sub)
+    print(f"[C5 window] tiles ({tx0}..{tx0 + WT - 1}, {ty0}..{ty0 + WT - 1}), longest list {cnt['max_tile']}, subset {len(ids)}/{P} Gaussians, D {cnt['D']}")
+    assert 50_000 < len(ids) < P
+    gpix = torch.zeros(3, H, W)
+    gpix[:, y0:y1, x0:x1] = torch.randn(3, y1 - y0, x1 - x0, generator=torch.Generator().manual_seed(9))
+    t0 = time.time()
+    ocolor, oradii, _, ctx = rc.forward(_np(means0)[ids], _np(op)[ids], _np(bg), _np(cam.world_view_transform), _np(cam.full_proj_transform),
+                                        _np(cam.camera_center), float(cam.tanfovx), float(cam.tanfovy), W, H, cov3D_precomp=_np(cov0)[ids],
+                                        colors_precomp=_np(col)[ids])
+    np.testing.assert_array_equal(_np(radii)[ids], oradii)
+    par = Parity(ctx)
+    par.mask(gpix)                                        # (zeroes the marginal pixels of the oracle's frame in place)
+    og = rc.backward(ctx, _np(gpix))
+    print("[C5 window] oracle forward + backward seconds", round(time.time() - t0, 1))
+    # tile lists of the window, bit for bit
+    ostart, olist = rc.tile_lists(ctx)
+    n_long = 0
+    for ty in range(ty0, ty0 + WT):
+        for tx in range(tx0, tx0 + WT):
+            t = ty * gx + tx
+            mine = plist[start[t]:start[t + 1]]
+            ref = ids[olist[ostart[t]:ostart[t + 1]]]
+            assert len(mine) == len(ref) and np.array_equal(mine, ref), (tx, ty, len(mine), len(ref))
+            n_long += len(mine) > 2048
+    assert n_long >= 1
+    # image inside the window
+    win = (slice(None), slice(y0, y1), slice(x0, x1))
+    parw = Parity.__new__(Parity)
+    parw.pix, parw.gauss, parw.masked = par.pix[y0:y1, x0:x1], par.gauss, True
+    _assert_image(parw, _np(color)[win], ocolor[win])
+    # gradients: only window pixels contribute on either side
+    (color * gpix.to(DEV)).sum().backward()
+    outside = np.ones(P, bool); outside[ids] = False
+    for t in (means.grad, cov.grad, op.grad, col.grad, m2d.grad):
+        assert float(t[torch.from_numpy(outside).to(DEV)].abs().max()) == 0.0
+    pars = Parity.__new__(Parity)
+    pars.pix, pars.gauss, pars.masked = par.pix, par.gauss, True
+    _assert_grads(pars, ((means.grad[ids], og["means3D"], "means3D"), (cov.grad[ids], og["cov3D"], "cov3D"),
+                         (op.grad[ids], og["opacities"], "opacity"), (col.grad[ids], og["colors"], "colors"),
+                         (m2d.grad[ids], og["means2D"], "means2D")))
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_LOSS_FUZZ_N", "5"))))
 def test_losses_fuzz(seed):
     """l1_loss, ssim and the fused l1_ssim pair at random image sizes (1..300 px per side: every ragged border of the

@@ -390,6 +390,25 @@ def _worker_color(rank, world, port, out):
     torch.cuda.synchronize()
     err = {k: rel_err(p.grad.cpu().numpy(), want[k].cpu().numpy()) for k, p in leaves(mine).items() if k in want}
     assert len(err) >= 20 and all(p.grad is not None for k, p in leaves(mine).items() if k in want)
+    # 3. the same reduction OVERLAPPED with the backward (bench.py --train-step color): per-bucket asynchronous all-reduces from
+    #    post-accumulate hooks, pair render
+    mine = bench.Frame("T1", dev, view_index=rank)
+    mine.train_step(with_fields="color", pair=True)      # (creates the networks)
+    lv = leaves(mine)
+    used = {k: q for k, q in lv.items() if k in want}
+    nets = [list(mine.color_field.parameters()), list(mine.canon_field.parameters()), list(mine.deform_field.parameters())]
+    in_nets = {id(q) for b in nets for q in b}
+    buckets = nets + [[q] for q in used.values() if id(q) not in in_nets]
+    red2 = dd.BucketedGradReducer(buckets)
+    red2.begin_step()
+    mine.train_step(with_fields="color", pair=True)
+    n_reduced = red2.finish()
+    torch.cuda.synchronize()
+    err2 = {k: rel_err(q.grad.cpu().numpy(), want[k].cpu().numpy()) for k, q in used.items()}
+    assert n_reduced == len(buckets)
+    for k, v in err2.items():
+        if v > err.get(k, 0):
+            err[k] = v
     out[rank] = (refused, max(err.values()), max(err, key=err.get))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
