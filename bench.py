@@ -65,7 +65,12 @@ def parse():
                     help="N > 1: seconds after which device work that has not completed (a collective that never returns) "
                          "ends this rank with exit code 124 instead of hanging the job (0: off)")
     ap.add_argument("--graph-collectives", action="store_true",
-                    help="N>1: capture the step INCLUDING the gradient exchange (RCCL collectives) in the hipGraph")
+                    help="N>1: capture the step INCLUDING the gradient exchange (RCCL collectives) in the hipGraph and use it "
+                         "unconditionally (no probe)")
+    ap.add_argument("--no-graph-collectives", action="store_true",
+                    help="N>1: never capture a collective (default since round 4: ONE hipGraph incl. the RCCL collectives is probed "
+                         "first -- 3 replays must reproduce the eager step's gradients on every rank, under the watchdog -- and kept "
+                         "when it is the fastest; this flag restores the round-3 choice between two graphs and eager)")
     ap.add_argument("--fixed-camera", action="store_true",
                     help="N=1: replay the captured step with ONE camera / target (round-1 behaviour) instead of writing a new "
                          "camera and target into the step's slots before every replay")
@@ -914,12 +919,19 @@ def main():
     # --graph-collectives captures them too (RCCL supports capture; verified here only on a one-rank group,
     # tests/test_gpu_view_sharded.py -- the 8-GPU run keeps the conservative default).
     graph = None
+    graph_one = None            # candidate: ONE hipGraph of the whole N > 1 step, the RCCL collectives captured (probed below)
     if not args.no_graph and cut and not args.graph_collectives and not args.single_device:
         # (--single-device puts several ranks on ONE GPU for functional checks: their graph launches are time-sliced by the
         # driver in ~100 ms quanta and every later launch of the process suffers -- eager there)
         # N > 1 with the cut exchange: TWO graphs, the collectives issued eagerly between them (d3ga_amd/graph.py:
         # CapturedCutStep) -- no collective is captured, and the step is no longer bound by the host
-        from d3ga_amd.graph import CapturedCutStep
+        from d3ga_amd.graph import CapturedCutStep, CapturedStep
+        if not args.no_graph_collectives and torch.distributed.get_backend() == "nccl":
+            try:          # (k views per rank: the eager cut flow -- upstream once, k renders, ONE exchange, the rest -- in one graph)
+                graph_one = CapturedStep(cut_eager[0] if cut_eager[0] is not None else frame.step, params=list(frame.params.values()))
+            except Exception as e:  # noqa: BLE001
+                exchange_note = (exchange_note or "") + f" one-graph capture incl. the collectives failed ({type(e).__name__}: {e});"
+                graph_one = None
         try:
             graph = CapturedCutStep(frame.upstream, frame.loss_from, frame.grad_sync, params=list(frame.params.values()))
             exchange_note = (exchange_note or "") + " step captured as two hipGraphs around the eager exchange"
@@ -994,11 +1006,16 @@ def main():
             frame.grad_sync = keep_sync
             flat.zero()
 
-    if graph is not None and hasattr(graph, "graph_b"):
-        # Two graphs + eager collectives, or everything eager?  The two-graph step saves the host ~0.45 ms of launches per step
-        # but pays two graph launches; which one wins depends on the size (measured on one GPU over a one-rank nccl group: C3
-        # 0.61 vs 0.57 ms, the smaller configurations the other way round).  Time both (all ranks in step, slowest rank counts)
-        # and keep the faster.
+    if (graph is not None and hasattr(graph, "graph_b")) or graph_one is not None:
+        # Which launch mode for the N > 1 step?  (a) ONE hipGraph incl. the collectives (0.436 vs 0.419 ms for the N = 1 step at
+        # C3 over a one-rank RCCL group: 0.96 per rank), (b) two graphs around the eager exchange (0.55), (c) eager (0.56).
+        # (a) is accepted only when 3 replays reproduce the EAGER step's gradients on EVERY rank (checksums, agreed with an
+        # all-reduce); a captured collective that hangs instead ends the rank through the watchdog (exit code 124).  All three are
+        # then timed (ranks in step, slowest rank counts) and the fastest is kept.
+        def grad_fingerprint():
+            gs = [p.grad for p in frame.params.values() if p.grad is not None]
+            return torch.stack([g.double().abs().sum() for g in gs] + [g.double().sum() for g in gs])
+
         def probe(g, n=12):
             nonlocal graph
             keep, graph = graph, g
@@ -1014,10 +1031,33 @@ def main():
                 torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
             graph = keep
             return float(dt) / n
-        t_two, t_eager = probe(graph), probe(None)
-        exchange_note = (exchange_note or "") + f" (probe: two-graph {1e3 * t_two:.3f} ms/step, eager {1e3 * t_eager:.3f} ms/step: kept the faster)"
-        if t_eager < t_two:
-            graph = None
+        cands = {}
+        if graph_one is not None:
+            keep, graph = graph, None
+            for _ in range(2):
+                timed_step()                                # the eager step of this rank's view: the reference gradients
+            torch.cuda.synchronize()
+            want = grad_fingerprint()
+            graph = graph_one
+            for _ in range(3):
+                timed_step()
+            torch.cuda.synchronize()
+            got = grad_fingerprint()
+            graph = keep
+            agree = torch.tensor([1.0 if bool(((got - want).abs() <= 1e-4 * want.abs().max() + 1e-12).all()) else 0.0], device=dev)
+            if world > 1:
+                torch.distributed.all_reduce(agree, op=torch.distributed.ReduceOp.MIN)
+            if float(agree) == 1.0:
+                cands["one hipGraph incl. the collectives"] = graph_one
+            else:
+                exchange_note = (exchange_note or "") + " one-graph step incl. the collectives did NOT reproduce the eager gradients on every rank: dropped;"
+        if graph is not None and hasattr(graph, "graph_b"):
+            cands["two hipGraphs around the eager exchange"] = graph
+        cands["eager"] = None
+        times = {k: probe(g) for k, g in cands.items()}
+        best = min(times, key=times.get)
+        exchange_note = (exchange_note or "") + " (probe: " + ", ".join(f"{k} {1e3 * v:.3f} ms/step" for k, v in times.items()) + f": kept {best})"
+        graph = cands[best]
 
     # Python's cyclic GC: the first full collection of the (large) post-import heap costs ~40 ms and lands wherever it likes --
     # seen as one 3 ms/step outlier in an eager loop of 1.4 ms steps.  Collect now and freeze the survivors.
@@ -1265,7 +1305,8 @@ def main():
             "roofline": roof, "kernels": kernels,
             "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 4),
             "step_ms": step_dist,
-            "launch_mode": ("hipGraph replay of ONE captured step; before every replay a new camera (matrices + FoV) is written into "
+            "launch_mode": ("ONE hipGraph of the N > 1 step, the RCCL collectives captured (probed against the eager step on every rank)"
+                            if graph is not None and graph is graph_one else "hipGraph replay of ONE captured step; before every replay a new camera (matrices + FoV) is written into "
                             "its static slot and the loss is pointed at that camera's resident target image (8-byte cell, "
                             "d3ga_amd/graph.py: TensorSlot)" if graph is not None and cycle else
                             "two hipGraphs per step (up to the rasterizer's backward | the rest of the backward) with the gradient "

@@ -196,7 +196,7 @@ class ViewShardedGrads:
         """Sums `flat` over the ranks in place (times `scale`); gathers `factor` (P+1,3) of every rank into a
         (world, P+1, 3) tensor (returned; `out` if given; None without `factor`).  Both collectives are in flight together."""
         ev = None
-        if self.timing and flat.is_cuda:
+        if self.timing and flat.is_cuda and not torch.cuda.is_current_stream_capturing():     # (an event recorded into a graph cannot be timed)
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         works = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
@@ -242,7 +242,7 @@ class ViewShardedGrads:
         if not self.parked:
             raise RuntimeError("ViewShardedGrads.exchange_parked: no rasterizer backward has parked its gradients")
         ev = None
-        if self.timing and self.parked[0]["flat"].is_cuda:
+        if self.timing and self.parked[0]["flat"].is_cuda and not torch.cuda.is_current_stream_capturing():
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         heads = {}
@@ -372,7 +372,8 @@ class BucketedGradReducer:
         if not self._active():
             return
         b = self.buckets[i]
-        if self.timing:
+        timed = self.timing and b[0].is_cuda and not torch.cuda.is_current_stream_capturing()
+        if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
         if len(b) == 1:
@@ -381,7 +382,7 @@ class BucketedGradReducer:
             t = self._flat[i]
             torch._foreach_copy_(list(t.split([p.numel() for p in b])), [p.grad.reshape(-1) for p in b])
         w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if dist.is_initialized() else None
-        self._work.append((i, w, e0 if self.timing else None))
+        self._work.append((i, w, e0 if timed else None))
 
     def begin_step(self):
         for b in self.buckets:

@@ -26,6 +26,14 @@ import torch
 from . import _lib
 
 
+# Stream-capture error mode.  The default ("global") makes a HIP call from ANY thread illegal while a capture is in progress --
+# and a process that holds an RCCL process group has such a thread: ProcessGroupNCCL's watchdog polls the events of earlier
+# collectives (hipEventQuery).  Seen in round 4: "operation not permitted when stream is capturing" from the watchdog thread,
+# which then terminates the process (intermittent: it depends on whether an eager collective is still being retired when a
+# later capture starts).  "thread_local" restricts the check to the capturing thread.
+_CAPTURE_MODE = "thread_local"
+
+
 class CapacityOverflowError(RuntimeError):
     """A replayed step produced more (tile, Gaussian) duplicates than the binning capacity frozen into its graph."""
 
@@ -205,7 +213,7 @@ class CapturedStep:
         for p in params:
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
-        with _capture_forwards() as forwards, torch.cuda.graph(self.graph):
+        with _capture_forwards() as forwards, torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
             self.result = step_fn()
         torch.cuda.synchronize()
         self._watch = _OverflowWatch(check_every, forwards)
@@ -270,10 +278,10 @@ class CapturedCutStep:
                 p.grad = None
             self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             sync.begin_step()
-            with _capture_forwards() as forwards, torch.cuda.graph(self.graph_a):
+            with _capture_forwards() as forwards, torch.cuda.graph(self.graph_a, capture_error_mode=_CAPTURE_MODE):
                 up, pkg, self.result = self._to_the_cut(upstream, loss_fn)
             sync.exchange_parked()             # (graph A has not run: this call's collectives move unspecified data, on every rank alike)
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._from_the_cut(up, pkg)
             torch.cuda.synchronize()
             sync.frozen = True                 # the parked buffers are baked into the two graphs now
