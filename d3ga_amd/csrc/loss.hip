@@ -6,6 +6,8 @@
 //               backward; here one LDS-tiled separable pass each way.
 #include "d3ga_internal.h"
 
+#include <stdlib.h>
+
 namespace d3ga {
 
 __device__ __forceinline__ float wave_sum_loss(float v) {
@@ -320,6 +322,268 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int C, int H, int W, int 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 4: the same SSIM as a MARCH down the image (ssim_march_*_kernel).
+//
+// The tiled kernels above re-load a (16+10) x (32+10) halo per 16 x 32 outputs (2.1x the pixels), idle a third of their
+// threads in the horizontal pass and synchronise three times per tile: 123 + 63 us at 1080p against ~25 us of HBM traffic.
+// Here a workgroup owns a vertical strip: thread = one input COLUMN (256 columns, 244 of them outputs + the 5-pixel halo on
+// both sides + 2 idle), and it walks down a segment of output rows (ssim_march_rows):
+//   A. vertical pass in REGISTERS: every thread keeps the last 11 rows of its column (x, y -- or the three derivative maps
+//      of the backward) in a register ring and forms the vertically convolved maps of the finished row (the products x^2,
+//      y^2, xy are formed on the fly: 7 instructions per tap for five maps) -- no LDS, every input pixel is loaded once per
+//      strip (vertical halo: 10 rows per segment);
+//   B. the convolved rows go to LDS, four rows at a time;
+//   C. horizontal pass + the per-pixel formulas: thread = (row of the four, 4 adjacent output columns): four 16-byte LDS
+//      reads per map feed 4 x 11 taps, the SSIM terms / the gradient of those four pixels are formed and stored (16-byte
+//      stores when the image allows).
+// HBM traffic per pixel and channel: forward 8 B x (1 + 10 / rows) + 12 B, backward 12 B x (1 + 10 / rows) + 8 B + 4 B.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMarchW = 256;                 // threads = input columns of a strip
+constexpr int kMarchUse = 244;               // output columns of a strip (61 groups of 4); kMarchUse + 10 <= kMarchW
+constexpr int kMarchGroups = kMarchUse / 4;
+constexpr int kMarchLd = 264;                // floats per LDS row (16-byte reads run 2 floats past the 14 a group needs)
+
+template <int NMAP>
+__device__ __forceinline__ void march_htaps(const float *row, int g, const float (&w)[11], float (&o)[4]) {
+    float v[16];
+    load16(row + 4 * g, v);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        a0 = fmaf(w[k], v[k], a0); a1 = fmaf(w[k], v[k + 1], a1); a2 = fmaf(w[k], v[k + 2], a2); a3 = fmaf(w[k], v[k + 3], a3);
+    }
+    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+    __builtin_amdgcn_sched_barrier(0);      // one map at a time: left alone the scheduler issues the LDS reads of all maps up front (196 VGPRs)
+}
+
+__global__ __launch_bounds__(kMarchW) void ssim_march_fwd_kernel(int C, int H, int W, int strips, int segs, int seg_rows,
+                                                                  const float *__restrict__ img1, const float *__restrict__ img2,
+                                                                  float inv_n, float *__restrict__ out, float *__restrict__ Dm,
+                                                                  float *__restrict__ Dq1, float *__restrict__ Dq12,
+                                                                  float *__restrict__ out_l1, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) float s_v[8][5][kMarchLd];      // two buffers of four rows: ONE barrier per group
+    __shared__ float s_part[8];
+    const int tid = threadIdx.x;
+    float w[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) w[k] = c_ssim_w[k];
+    float local = 0.f, local_l1 = 0.f;
+    const int nitems = C * strips * segs;
+    if (tid < 5 * 8 * (kMarchLd - kMarchW)) {              // the pad columns behind the 256 written ones: zero once
+        const int r = tid / (5 * (kMarchLd - kMarchW)), q = tid % (5 * (kMarchLd - kMarchW));
+        s_v[r][q / (kMarchLd - kMarchW)][kMarchW + q % (kMarchLd - kMarchW)] = 0.f;
+    }
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int c = item / (strips * segs), r = item - c * strips * segs;
+        const int sy = r / strips, sx = r - sy * strips;
+        const float *p1 = img1 + (size_t)c * H * W, *p2 = img2 + (size_t)c * H * W;
+        const size_t plane = (size_t)c * H * W;
+        const int gx = sx * kMarchUse - kSsimHalo + tid;   // this thread's input column
+        const bool col_in = gx >= 0 && gx < W;
+        const bool col_out = tid >= kSsimHalo && tid < kSsimHalo + kMarchUse && gx < W;      // an output column of this strip
+        const int y0 = sy * seg_rows;
+        const int nout = min(seg_rows, H - y0);
+        float rx[11], ry[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) { rx[k] = 0.f; ry[k] = 0.f; }
+        auto load_row = [&](int ri, float &x, float &y) {  // input row ri of the segment: image row y0 - 5 + ri
+            const int gy = y0 - kSsimHalo + ri;
+            const bool in = col_in && gy >= 0 && gy < H;
+            x = in ? p1[(size_t)gy * W + gx] : 0.f;
+            y = in ? p2[(size_t)gy * W + gx] : 0.f;
+        };
+        // the NEXT four input rows are in flight while the current four are convolved (one row ahead did not cover the
+        // load latency: a row is ~0.5 us of work per wavefront)
+        float nx[4], ny[4], cx[4], cy[4];
+        const int nin = nout + 2 * kSsimHalo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_row(j, nx[j], ny[j]);
+        for (int ri = 0; ri < nin; ++ri) {
+            if ((ri & 3) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cx[j] = nx[j]; cy[j] = ny[j]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ri + 4 + j < nin) load_row(ri + 4 + j, nx[j], ny[j]);
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) { rx[k] = rx[k + 1]; ry[k] = ry[k + 1]; }
+            {
+                const int j = ri & 3;
+                rx[10] = j == 0 ? cx[0] : (j == 1 ? cx[1] : (j == 2 ? cx[2] : cx[3]));
+                ry[10] = j == 0 ? cy[0] : (j == 1 ? cy[1] : (j == 2 ? cy[2] : cy[3]));
+            }
+            if (ri < 2 * kSsimHalo) continue;              // ring not full yet
+            const int orow = ri - 2 * kSsimHalo;           // output row of the segment; its centre sample is ring slot 5
+            float sx1 = 0.f, sy1 = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float wx = w[k] * rx[k], wy = w[k] * ry[k];
+                sx1 += wx; sy1 += wy;
+                sxx = fmaf(wx, rx[k], sxx); syy = fmaf(wy, ry[k], syy); sxy = fmaf(wx, ry[k], sxy);
+            }
+            const int slot = orow & 3, buf = orow & 4;     // (buffer 0 / 4: the group's four rows)
+            s_v[buf + slot][0][tid] = sx1; s_v[buf + slot][1][tid] = sy1; s_v[buf + slot][2][tid] = sxx; s_v[buf + slot][3][tid] = syy; s_v[buf + slot][4][tid] = sxy;
+            if (col_out) local_l1 += fabsf(rx[5] - ry[5]);                                   // fused L1
+            if (slot != 3 && orow != nout - 1) continue;
+            __syncthreads();
+            // ---- horizontal pass + SSIM of up to four rows: thread = (row slot, 4 adjacent output columns) ----
+            if (tid < 4 * kMarchGroups) {
+                const int rs = tid / kMarchGroups, g = tid - rs * kMarchGroups;
+                const int gy = y0 + (orow & ~3) + rs, ox = sx * kMarchUse + 4 * g;
+                if (rs <= slot && ox < W) {
+                    float mu1[4], mu2[4], q1[4], q2[4], q12[4];
+                    march_htaps<5>(s_v[buf + rs][0], g, w, mu1);
+                    march_htaps<5>(s_v[buf + rs][1], g, w, mu2);
+                    march_htaps<5>(s_v[buf + rs][2], g, w, q1);
+                    march_htaps<5>(s_v[buf + rs][3], g, w, q2);
+                    march_htaps<5>(s_v[buf + rs][4], g, w, q12);
+                    float dm[4], ds1[4], ds12[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float s1 = q1[j] - mu1[j] * mu1[j], s2 = q2[j] - mu2[j] * mu2[j], s12 = q12[j] - mu1[j] * mu2[j];
+                        const float A = 2.f * mu1[j] * mu2[j] + kSsimC1, B = 2.f * s12 + kSsimC2;
+                        const float Dd = mu1[j] * mu1[j] + mu2[j] * mu2[j] + kSsimC1, E = s1 + s2 + kSsimC2;
+                        const float iD = 1.0f / Dd, iE = 1.0f / E;
+                        const float val = A * B * iD * iE;
+                        ds1[j] = -val * iE;
+                        ds12[j] = 2.f * A * iD * iE;
+                        const float d_mu1 = 2.f * mu2[j] * B * iD * iE - 2.f * mu1[j] * val * iD;
+                        dm[j] = d_mu1 - 2.f * mu1[j] * ds1[j] - mu2[j] * ds12[j];
+                        if (ox + j < W) local += val;
+                    }
+                    if (Dm) {
+                        const size_t o = plane + (size_t)gy * W + ox;
+                        if (vec_ok && ox + 3 < W) {
+                            *reinterpret_cast<float4 *>(Dm + o) = make_float4(dm[0], dm[1], dm[2], dm[3]);
+                            *reinterpret_cast<float4 *>(Dq1 + o) = make_float4(ds1[0], ds1[1], ds1[2], ds1[3]);
+                            *reinterpret_cast<float4 *>(Dq12 + o) = make_float4(ds12[0], ds12[1], ds12[2], ds12[3]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (ox + j < W) { Dm[o + j] = dm[j]; Dq1[o + j] = ds1[j]; Dq12[o + j] = ds12[j]; }
+                        }
+                    }
+                }
+            }
+            // (no second barrier: the next group writes the OTHER buffer, and its own barrier orders this group's reads
+            // before the writes of the group after it)
+        }
+        __syncthreads();                                  // (next item: both buffers are rewritten from row 0 on)
+    }
+    local = wave_sum_loss(local);
+    local_l1 = wave_sum_loss(local_l1);
+    if ((tid & 63) == 0) { s_part[tid >> 6] = local; s_part[4 + (tid >> 6)] = local_l1; }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(out, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * inv_n);
+        if (out_l1) atomicAdd(out_l1, (s_part[4] + s_part[5] + s_part[6] + s_part[7]) * inv_n);
+    }
+}
+
+__global__ __launch_bounds__(kMarchW) void ssim_march_bwd_kernel(int C, int H, int W, int strips, int segs, int seg_rows,
+                                                                  const float *__restrict__ img1, const float *__restrict__ img2,
+                                                                  const float *__restrict__ Dm, const float *__restrict__ Dq1,
+                                                                  const float *__restrict__ Dq12, const float *__restrict__ g,
+                                                                  const float *__restrict__ g_l1, float inv_n,
+                                                                  float *__restrict__ grad1, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) float s_v[8][3][kMarchLd];
+    const int tid = threadIdx.x;
+    float w[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) w[k] = c_ssim_w[k];
+    const float scale = g[0] * inv_n;
+    const float scale_l1 = g_l1 ? g_l1[0] * inv_n : 0.f;
+    const int nitems = C * strips * segs;
+    if (tid < 3 * 8 * (kMarchLd - kMarchW)) {
+        const int r = tid / (3 * (kMarchLd - kMarchW)), q = tid % (3 * (kMarchLd - kMarchW));
+        s_v[r][q / (kMarchLd - kMarchW)][kMarchW + q % (kMarchLd - kMarchW)] = 0.f;
+    }
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int c = item / (strips * segs), r = item - c * strips * segs;
+        const int sy = r / strips, sx = r - sy * strips;
+        const size_t plane = (size_t)c * H * W;
+        const int gx = sx * kMarchUse - kSsimHalo + tid;
+        const bool col_in = gx >= 0 && gx < W;
+        const int y0 = sy * seg_rows;
+        const int nout = min(seg_rows, H - y0);
+        float ra[11], rb[11], rd[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) { ra[k] = 0.f; rb[k] = 0.f; rd[k] = 0.f; }
+        auto load_row = [&](int ri, float &a, float &b, float &d) {
+            const int gy = y0 - kSsimHalo + ri;
+            const bool in = col_in && gy >= 0 && gy < H;
+            const size_t o = plane + (size_t)gy * W + gx;
+            a = in ? Dm[o] : 0.f; b = in ? Dq1[o] : 0.f; d = in ? Dq12[o] : 0.f;
+        };
+        float na[4], nb[4], nd[4], ca[4], cb[4], cd[4];
+        const int nin = nout + 2 * kSsimHalo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_row(j, na[j], nb[j], nd[j]);
+        for (int ri = 0; ri < nin; ++ri) {
+            if ((ri & 3) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ca[j] = na[j]; cb[j] = nb[j]; cd[j] = nd[j]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ri + 4 + j < nin) load_row(ri + 4 + j, na[j], nb[j], nd[j]);
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) { ra[k] = ra[k + 1]; rb[k] = rb[k + 1]; rd[k] = rd[k + 1]; }
+            {
+                const int j = ri & 3;
+                ra[10] = j == 0 ? ca[0] : (j == 1 ? ca[1] : (j == 2 ? ca[2] : ca[3]));
+                rb[10] = j == 0 ? cb[0] : (j == 1 ? cb[1] : (j == 2 ? cb[2] : cb[3]));
+                rd[10] = j == 0 ? cd[0] : (j == 1 ? cd[1] : (j == 2 ? cd[2] : cd[3]));
+            }
+            if (ri < 2 * kSsimHalo) continue;
+            const int orow = ri - 2 * kSsimHalo;
+            float sa = 0.f, sb = 0.f, sd = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) { sa = fmaf(w[k], ra[k], sa); sb = fmaf(w[k], rb[k], sb); sd = fmaf(w[k], rd[k], sd); }
+            const int slot = orow & 3, buf = orow & 4;
+            s_v[buf + slot][0][tid] = sa; s_v[buf + slot][1][tid] = sb; s_v[buf + slot][2][tid] = sd;
+            if (slot != 3 && orow != nout - 1) continue;
+            __syncthreads();
+            if (tid < 4 * kMarchGroups) {
+                const int rs = tid / kMarchGroups, gq = tid - rs * kMarchGroups;
+                const int gy = y0 + (orow & ~3) + rs, ox = sx * kMarchUse + 4 * gq;
+                if (rs <= slot && ox < W) {
+                    float a[4], b[4], d[4];
+                    march_htaps<3>(s_v[buf + rs][0], gq, w, a);
+                    march_htaps<3>(s_v[buf + rs][1], gq, w, b);
+                    march_htaps<3>(s_v[buf + rs][2], gq, w, d);
+                    const size_t o = plane + (size_t)gy * W + ox;
+                    float x[4], y[4], outv[4];
+                    if (vec_ok && ox + 3 < W) {
+                        const float4 xv = *reinterpret_cast<const float4 *>(img1 + o), yv = *reinterpret_cast<const float4 *>(img2 + o);
+                        x[0] = xv.x; x[1] = xv.y; x[2] = xv.z; x[3] = xv.w; y[0] = yv.x; y[1] = yv.y; y[2] = yv.z; y[3] = yv.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { x[j] = ox + j < W ? img1[o + j] : 0.f; y[j] = ox + j < W ? img2[o + j] : 0.f; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float df = x[j] - y[j];
+                        outv[j] = scale * (a[j] + 2.f * x[j] * b[j] + y[j] * d[j]) + scale_l1 * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+                    }
+                    if (vec_ok && ox + 3 < W) *reinterpret_cast<float4 *>(grad1 + o) = make_float4(outv[0], outv[1], outv[2], outv[3]);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (ox + j < W) grad1[o + j] = outv[j];
+                    }
+                }
+            }
+            // (no second barrier: the next group writes the OTHER buffer, and its own barrier orders this group's reads
+            // before the writes of the group after it)
+        }
+        __syncthreads();                                  // (next item: both buffers are rewritten from row 0 on)
+    }
+}
+
 }  // namespace d3ga
 
 using namespace d3ga;
@@ -395,6 +659,32 @@ extern "C" int d3ga_l1_mean_bwd_cell(int64_t n, const float *a, const float *con
 }
 
 static inline int ssim_grid(int ntiles, int cap) { return ntiles < 1 ? 1 : (ntiles > cap ? cap : ntiles); }
+// Rows per strip segment of the marching kernels: a launch runs in ROUNDS of (CUs x resident workgroups) items, an item costs
+// (rows + 10) input rows -- pick the multiple of 4 that minimises rounds x (rows + 10) (at 1080p x 3 channels and 768 slots:
+// 36 rows = 720 items in one round; 32 rows = 816 items, i.e. a second round for 48 of them: measured 1.6x slower).
+static int ssim_march_rows(const void *kernel, int C, int H, int strips) {
+    int per_cu = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kMarchW, 0) != hipSuccess || per_cu < 1) per_cu = 3;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const long slots = (long)per_cu * cus;
+    int best = 32;
+    double best_cost = 1e30;
+    for (int rows = 16; rows <= 128; rows += 4) {
+        const long items = (long)C * strips * ((H + rows - 1) / rows);
+        const double cost = (double)((items + slots - 1) / slots) * (rows + 2 * kSsimHalo);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = rows; }
+    }
+    return best;
+}
+static inline int ssim_impl() {          // A/B knob D3GA_SSIM_IMPL: 0 the LDS-tiled kernels, 1 (default) the marching kernels
+    static const int v = [] {
+        const char *e = getenv("D3GA_SSIM_IMPL");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
 
 extern "C" int d3ga_ssim_l1_fwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *out,
                                 float *Dm, float *Dq1, float *Dq12, float *out_l1, d3ga_stream_t stream) {
@@ -404,6 +694,19 @@ extern "C" int d3ga_ssim_l1_fwd(int32_t C, int32_t H, int32_t W, const float *im
     hipStream_t s = (hipStream_t)stream;
     D3GA_HIP(zero_async(out, sizeof(float), s));
     if (out_l1) D3GA_HIP(zero_async(out_l1, sizeof(float), s));
+    if (ssim_impl() == 1) {
+        const int strips = (W + kMarchUse - 1) / kMarchUse;
+        static int rows_cache[4] = {0, 0, 0, 0};            // (C, H, strips) -> rows: the occupancy query is not free
+        if (rows_cache[0] != C || rows_cache[1] != H || rows_cache[2] != strips) {
+            rows_cache[3] = ssim_march_rows((const void *)ssim_march_fwd_kernel, C, H, strips);
+            rows_cache[0] = C; rows_cache[1] = H; rows_cache[2] = strips;
+        }
+        const int seg_rows = rows_cache[3], segs = (H + seg_rows - 1) / seg_rows;
+        const int vec_ok = (W % 4 == 0) && !(((uintptr_t)Dm | (uintptr_t)Dq1 | (uintptr_t)Dq12) & 15);
+        hipLaunchKernelGGL(ssim_march_fwd_kernel, dim3(ssim_grid(C * strips * segs, 4096)), dim3(kMarchW), 0, s, C, H, W, strips, segs, seg_rows,
+                           img1, img2, 1.0f / ((float)C * (float)H * (float)W), out, Dm, Dq1, Dq12, out_l1, vec_ok);
+        return check_launch(s, 0);
+    }
     const int tx = (W + kSsimTW - 1) / kSsimTW, ty = (H + kSsimTH - 1) / kSsimTH;
     // persistent grid: every workgroup ends with ONE atomic on the result word (same-address atomics serialise)
     hipLaunchKernelGGL(ssim_fwd_kernel, dim3(ssim_grid(C * tx * ty, 2048)), dim3(256), 0, s, C, H, W, tx, ty, img1, img2,
@@ -422,6 +725,19 @@ extern "C" int d3ga_ssim_l1_bwd(int32_t C, int32_t H, int32_t W, const float *im
     if (C <= 0 || H <= 0 || W <= 0) return D3GA_E_SIZE;
     if (!img1 || !img2 || !Dm || !Dq1 || !Dq12 || !g || !grad_img1) return D3GA_E_NULL;
     hipStream_t s = (hipStream_t)stream;
+    if (ssim_impl() == 1) {
+        const int strips = (W + kMarchUse - 1) / kMarchUse;
+        static int rows_cache[4] = {0, 0, 0, 0};
+        if (rows_cache[0] != C || rows_cache[1] != H || rows_cache[2] != strips) {
+            rows_cache[3] = ssim_march_rows((const void *)ssim_march_bwd_kernel, C, H, strips);
+            rows_cache[0] = C; rows_cache[1] = H; rows_cache[2] = strips;
+        }
+        const int seg_rows = rows_cache[3], segs = (H + seg_rows - 1) / seg_rows;
+        const int vec_ok = (W % 4 == 0) && !(((uintptr_t)img1 | (uintptr_t)img2 | (uintptr_t)grad_img1) & 15);
+        hipLaunchKernelGGL(ssim_march_bwd_kernel, dim3(ssim_grid(C * strips * segs, 8192)), dim3(kMarchW), 0, s, C, H, W, strips, segs, seg_rows,
+                           img1, img2, Dm, Dq1, Dq12, g, g_l1, 1.0f / ((float)C * (float)H * (float)W), grad_img1, vec_ok);
+        return check_launch(s, 0);
+    }
     const int tx = (W + kSsimTW - 1) / kSsimTW, ty = (H + kSsimTH - 1) / kSsimTH;
     hipLaunchKernelGGL(ssim_bwd_kernel, dim3(ssim_grid(C * tx * ty, 8192)), dim3(256), 0, s, C, H, W, tx, ty, img1, img2,
                        Dm, Dq1, Dq12, g, g_l1, 1.0f / ((float)C * (float)H * (float)W), grad_img1);
