@@ -370,6 +370,24 @@ def valu_issue_model():
         return None, None
 
 
+def lane_efficiency(workload):
+    """Lane efficiency of the two compositing kernels -- useful (entry, pixel) pairs / issued lane slots -- from the newest
+    profiles/r*_composite_diag_<workload>.json (tools/diag_scan.py / tools/diag_fwd.py on the counter build of the library:
+    the product build carries no counters).  None when no such file exists."""
+    try:
+        pd = os.path.join(ROOT, "profiles")
+        f = sorted(x for x in os.listdir(pd) if x.endswith(f"_composite_diag_{workload}.json"))
+        if not f:
+            return None
+        d = json.load(open(os.path.join(pd, f[-1])))
+        return {"backward": d["backward"].get("lane_efficiency"), "forward": d["forward"].get("lane_efficiency"),
+                "definition": "useful (entry, pixel) pairs / lane slots issued by the pixel-step (backward: wave groups x 64 lanes x 16 steps) "
+                              "and blend (forward: iterations x 2 entries x 64 lanes) loops", "source": "profiles/" + f[-1],
+                "valid_pairs": d["backward"].get("valid_entry_pixel_pairs")}
+    except Exception:
+        return None
+
+
 def init_timing(frame):
     """SURVEY sec. 8f-3 at the workload's size: every Gaussian located in the canonical cage (compute_bary) and the 3-nearest-
     neighbour scale seed over the Gaussian centres, uniform-grid search against the exhaustive kernels (same outputs)."""
@@ -1286,7 +1304,12 @@ def main():
                 roof["valu_floor_us"] = round(floor_us, 1)
                 roof["frac_at_valu_floor"] = round(alg[k] / (floor_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                 roof["valu_model"] = {"avg_cycles_per_valu_instruction": round(avg_cyc, 3), **model,
-                                      "source": "tools/micro/valu_issue.hip (profiles/r02_valu_issue_pmc.json) x tools/isa_mix.py"}
+                                      "source": "issue cost per instruction class: tools/micro/valu_issue.hip (profiles/r02_valu_issue_pmc.json -- a "
+                                                "property of the chip, not of a build) x the static mix of THIS round's kernel "
+                                                "(tools/isa_mix.py -> the newest profiles/r*_composite_bwd_mix.json)"}
+            le = lane_efficiency(args.workload)
+            if le:
+                roof["lane_efficiency"] = le
         out = {
             "metric": "fwd+bwd frames/sec @500k Gaussians 1920x1080" if args.workload == "C3" else f"fwd+bwd frames/sec ({wl.name})",
             "value": round(world * kv * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,

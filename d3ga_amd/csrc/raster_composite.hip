@@ -312,7 +312,8 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
         const unsigned long long df_t1 = __builtin_amdgcn_s_memrealtime();
         const size_t slot = blockIdx.x;
         g_diag_fwd_waves[4 * slot] = df_t0; g_diag_fwd_waves[4 * slot + 1] = df_t1;
-        g_diag_fwd_waves[4 * slot + 2] = df_iters | (df_batches << 32); g_diag_fwd_waves[4 * slot + 3] = (unsigned long long)(end - begin) | (df_blend_ticks << 32);
+        g_diag_fwd_waves[4 * slot + 2] = df_iters | (df_batches << 32); g_diag_fwd_waves[4 * slot + 3] = (unsigned long long)min(end - begin, 0xfffffu) | ((df_blend_ticks & 0xfffffull) << 20) |
+                                         ((unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xffff) << 40) | ((unsigned long long)(__builtin_amdgcn_s_getreg(6164) & 15) << 56);
     }
 #endif
 }

@@ -43,6 +43,12 @@ if n:      # tile-level merge kernel (rounds 3+)
     print({"active_waves": w, "installs": int(out[3]), "hits": int(out[4]), "evictions": int(out[5]), "lock_loop_trips": int(trips.sum()),
            "wave_groups": wave_groups, "trips_per_group": round(int(trips.sum()) / max(wave_groups, 1), 3),
            "lines_to_hbm": int(out[3]) + int(out[5])})
+    summary = {"workload": wl, "kernel": "composite_bwd_tile_kernel", "lib_sha256": __import__("hashlib").sha256(open(_lib._PATH, "rb").read()).hexdigest(),
+               "active_waves": w, "wave_groups": wave_groups, "lock_loop_trips_per_group": round(int(trips.sum()) / max(wave_groups, 1), 3)}
+    if int(out[8]):
+        summary.update({"valid_entry_pixel_pairs": int(out[8]), "entry_block_pairs": int(out[9]), "row_groups": int(out[10]),
+                        "lane_slots": wave_groups * 1024, "lane_efficiency": round(int(out[8]) / (wave_groups * 1024.0), 4),
+                        "merge_cache": {"installs": int(out[3]), "hits": int(out[4]), "evictions": int(out[5]), "lines_to_hbm": int(out[3]) + int(out[5])}})
     if int(out[8]):      # D3GA_DIAG=counters: lane efficiency = valid (entry, pixel) pairs / issued lane slots (wave groups x 64 lanes x 16 pixel steps)
         print({"valid_pixel_pairs": int(out[8]), "entry_block_pairs": int(out[9]), "row_groups": int(out[10]),
                "lane_efficiency": round(int(out[8]) / (wave_groups * 1024.0), 4),
@@ -63,9 +69,18 @@ if n:      # tile-level merge kernel (rounds 3+)
     print("last waves to end (end, start, groups, ticks/group):", [(int(t1[i]), int(t0[i]), int(g[i]), round(float(dur[i] / g[i]), 1)) for i in order])
     order = np.argsort(-g)[:6]
     print("heaviest waves (groups, start, end):", [(int(g[i]), int(t0[i]), int(t1[i])) for i in order])
+    res = {}
     for q in (0.1, 0.3, 0.5, 0.7, 0.8, 0.9, 0.95):
         t = q * t1.max()
-        print(f"resident active waves at {q:.2f} of the span:", int(((t0 <= t) & (t1 > t)).sum()))
+        res[str(q)] = int(((t0 <= t) & (t1 > t)).sum())
+        print(f"resident active waves at {q:.2f} of the span:", res[str(q)])
+    summary.update({"span_us": round(t1.max() / 100.0, 2), "wave_duration_us_p50_p90_max": [round(float(np.percentile(dur, q)) / 100.0, 2) for q in (50, 90, 100)],
+                    "wave_start_us_p50_p90": [round(float(np.percentile(t0, q)) / 100.0, 2) for q in (50, 90)],
+                    "groups_per_wave_mean_p90_max": [round(float(g.mean()), 2), int(np.percentile(g, 90)), int(g.max())],
+                    "resident_waves_at_fraction_of_span": res})
+    if len(sys.argv) > 2:
+        import json
+        json.dump(summary, open(sys.argv[2], "w"), indent=1)
     sys.exit(0)
 print('flushed entries with a gradient:', int(out[1]), '| of them also present in a lower row of the same flush:', int(out[2]))
 print("active waves", w)
