@@ -1194,6 +1194,11 @@ def main():
         # the reference's main configuration (configs/actorshq_actor02.yml: use_shs false): ColorField supplies colour
         # and opacity as well
         train["with_field_and_color_networks_ms_per_step"] = timed_train(with_fields="color")
+        try:          # the same two steps as ONE captured hipGraph each (a captured figure for the real configuration)
+            train["with_field_and_color_networks_captured_ms_per_step"] = timed_train(captured=True, with_fields="color")
+            train["render_pair_with_field_and_color_networks_captured_ms_per_step"] = timed_train(captured=True, pair=True, with_fields="color")
+        except Exception as e:  # noqa: BLE001
+            train["captured_networks_error"] = repr(e)
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist_info = None

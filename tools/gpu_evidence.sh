@@ -36,3 +36,9 @@ for wl in C3 C4; do
   timeout 600 python bench.py --field-mlp --workload $wl --steps 50 --warmup 10 > gpurun_out/bench_field_mlp_$wl.log 2> gpurun_out/bench_field_mlp_$wl.err
 done
 bash tools/prof_step.sh color > gpurun_out/prof_step_color_summary.txt 2>&1
+# round 4: BASELINE config 4 entry point at N = 1 (the N > 1 launches are the driver's) and the camera-sharded step's per-rank cost
+timeout 900 python bench.py --train-step color --steps 100 --warmup 10 2> gpurun_out/bench_color_train.err | grep "^{" > gpurun_out/bench_color_train.log
+for k in 1 2 4; do
+  timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train-step --force-cut --views-per-rank $k 2>> gpurun_out/force_cut.err | grep "^{" > gpurun_out/force_cut_C3_k$k.log
+done
+timeout 600 python bench.py --workload C4 --steps 100 --warmup 10 --no-cpu-baseline --no-train-step --force-cut 2>> gpurun_out/force_cut.err | grep "^{" > gpurun_out/force_cut_C4_k1.log
