@@ -1,27 +1,23 @@
-// raster_composite.hip -- alpha compositing forward for gfx950 and the entry points of both directions (SURVEY.md
-// sec. 8a rows R4, R5; the backward kernel is raster_composite_scan.hip).
+// raster_composite.hip -- alpha compositing forward for gfx950 (composite_fwd_q_kernel) and the C entry points of both
+// directions (the backward kernel is raster_composite_scan.hip).
 //
-// Wavefront-autonomous design.  The unit of work is ONE 64-lane wavefront = one 8x8-pixel quadrant of a 16x16 tile
-// (workgroup = one wavefront: no barriers, independent early-out, 4x finer load balancing than a workgroup per
-// tile); each of its four 16-lane DPP rows owns a 4x4-pixel block.  A wavefront walks its tile's depth-ordered list 64
-// entries at a time:
-//   1. every lane gathers ONE entry's record (xy, conic+opacity, rgb+1/depth: three 8/16-byte loads; the next batch is
-//      in flight while the current one is blended), parks it in a wave-private LDS slab and tests it against the four
-//      blocks: bounding box of the alpha >= 1/255 ellipse, then the exact ellipse / rectangle test;
-//   2. the survivors are compacted into four per-row index lists in LDS (four ballots) AND appended to the four blocks'
-//      culled lists in the ImgBuf (1-based list position, Gaussian id) -- the backward walks exactly these;
-//   3. iteration i makes row r blend the i-th and (i+1)-th entry of its own list, straight-line and front to back
-//      (records fetched with per-row broadcast ds_reads); the wavefront stops when all 64 pixels are saturated (T < 1e-4).
-// A 4x4 block is touched by ~1.6x fewer list entries than an 8x8 quadrant (C3: 160 against 251 iterations per quadrant).
-// Culled entries provably contribute nothing (alpha < 1/255 on every pixel of the block), so the result is identical
-// to walking the full tile list; list positions (n_contrib) are kept as positions in the FULL list.
-//
-// Work -> XCD mapping: the dispatcher places workgroup b on XCD b % 8 (observed, speed only).  quad_of_block() hands
-// the four quadrants of a tile and its horizontal neighbours -- which share most of their Gaussians -- to the same XCD,
-// i.e. the same 4 MiB L2; quad_of_block_ordered() does the same over the heaviest-first tile order of the bin stage.
-//
-// History: the 64-lane kernels (one ballot per quadrant) and the row-segmented backward of round 1
-// were removed when the entry-per-lane backward replaced them; profiles/r01_* are their measurements.
+// Unit of work: ONE 64-lane wavefront = one 8x8-pixel quadrant of a 16x16 tile (workgroup = one wavefront: no barriers,
+// independent early-out); each of its four 16-lane DPP rows owns a 4x4-pixel block.  Two stages:
+//   1. the tile's depth-ordered list is walked 128 entries at a time with ONE 16-byte gather per entry (GeomBuf::xyh: centre |
+//      half extents of the alpha >= 1/255 box, written by preprocess with the same splat_cull()) and a box test against the
+//      quadrant; the survivors' (1-based list position, Gaussian id) go into a 256-entry ring in LDS;
+//   2. batches of 64 SURVIVORS: every lane gathers one entry's records (xy, conic + opacity, colour + 1/depth; the next
+//      batch and the next stage-one chunk are in flight while the current batch is blended), parks them in a wave-private
+//      LDS slab, tests the entry against the four blocks (box, then the exact ellipse / rectangle test), the hits are
+//      compacted into four per-row lists of slab offsets (four ballots) AND appended to the blocks' culled lists in the
+//      ImgBuf -- the backward walks exactly these; then iteration i makes row r blend the i-th and (i+1)-th entry of ITS
+//      list, straight-line and front to back (records through per-row broadcast ds_reads, offsets read one iteration ahead);
+//      the wavefront stops when all 64 pixels are saturated (T < 1e-4).
+// Culled entries provably contribute nothing (alpha < 1/255 on every pixel of the block), so the result is identical to
+// walking the full tile list; list positions (n_contrib) stay positions in the FULL list.
+// Dispatch: quad_of_block_ordered() hands the quadrants out heaviest tile first (tile_order of the bin stage), the four
+// quadrants of a tile on one XCD (workgroup b lands on XCD b % 8: observed, speed only).
+// Numbers, history and the negative results (persistent workers, dispatch orders, occupancy): DESIGN.md sec. 4.
 #include <stdlib.h>
 
 #include "composite_common.h"
@@ -45,20 +41,6 @@ __device__ unsigned long long g_diag_fwd_waves[32768 * 4];    // per active wave
 // out_color2 over bg2 -- the reference's training step renders every package twice with identical geometry and opacities
 // (RGB, then the silhouette colours on black: models/trainer.py:102-110); alpha, T, the culled lists and the early exit
 // are shared, the second image costs three more FMAs per (pixel, entry).
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 3: the same forward in TWO STAGES (composite_fwd_q_kernel).
-//
-// Only ~35 % of a tile list's entries reach a given 8x8 quadrant, but the kernel above pays the whole per-entry
-// overhead for all of them: three record gathers, the culling constants (one log, three rcp, two sqrt), the exact 4x4
-// block tests, the list building -- ~200 instructions per 64 entries, ~45 % of its instructions.  Here a first stage
-// walks the list 128 entries at a time with ONE 16-byte gather per entry (GeomBuf::xyh: centre | half extents of the
-// alpha >= 1/255 box, written by preprocess with the same splat_cull()) and a bounding-box test against the quadrant;
-// the survivors' (list position, id) go into a 256-entry ring in LDS.  The second stage -- the batch body of the kernel
-// above, unchanged: gathers, exact block tests, row lists, emission for the backward, blend -- runs on batches of 64
-// SURVIVORS, i.e. three times less often and with ~3x longer row lists per batch (better row balance, less padding).
-// A block-level hit implies the quadrant-level box hit (same extents, the blocks lie inside the quadrant), so the set of
-// (entry, block) pairs, the emitted lists and every pixel are identical to the kernel above.
-// Pipeline per batch: its gathers and the next stage-one loads are issued BEFORE the previous batch is blended.
 // DEPTH: the inverse-depth image of branch dr_aa is accumulated and written (the D3GA renderer uses the colour only:
 // renderer.py:141 takes [0]; without it the blend loop is one FMA per entry shorter and 4 B per pixel are not written)
 template <bool DUAL, bool DEPTH>
@@ -164,7 +146,7 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     __builtin_amdgcn_wave_barrier();
     issue_batch();
     while (bn != 0u) {
-        // ---- stage two on the batch in flight (the body of composite_fwd_rows_kernel) ----
+        // ---- stage two on the batch in flight ----
         const float2 cxy = nxy;
         const float4 cco = nco, crgb = nrgb, crgb2 = nrgb2;
         const uint2 cpg = bpg;

@@ -1,33 +1,30 @@
-// raster_composite_scan.hip -- compositing backward, entry-per-lane ("scan") formulation.
+// raster_composite_scan.hip -- compositing backward: composite_bwd_tile_kernel.
 //
-// The round-1 backward gave every LANE a pixel and every ITERATION a list entry, like the forward: the nine partial
-// derivatives of that entry then had to be summed across the 16 lanes of the row (32 DPP instructions per iteration) and
-// meet in an LDS accumulator, and only ~8 of the 16 lanes of a row are inside the entry's footprint.
-// Here the roles are swapped.  A 16-lane DPP row still owns one 4x4 pixel block and walks that block's culled list (which
-// the FORWARD wrote: ImgBuf::blk_list), but 16 consecutive list entries sit in the 16 lanes and the row steps through the
-// block's 16 pixels:
+// Entry per lane, workgroup per tile.  The forward (raster_composite.hip) leaves, per 4x4 pixel block, the culled list of
+// the entries that can touch it (ImgBuf::blk_list: {1-based position in the tile list, Gaussian index}).  Here
+//   * one 256-thread workgroup owns a 16x16 tile; each of its four wavefronts takes four blocks (the tile's 16 blocks sorted
+//     by list length, ranks 4g .. 4g+3 per wavefront: kDefaultTileAssign) and each 16-lane DPP row walks ITS block's list
+//     back to front, 16 consecutive entries in its 16 lanes ("group"), stepping through the block's 16 pixels;
 //   * what couples the entries at one pixel is the transmittance T_i = T_final / prod_{j >= i}(1 - alpha_j) and the colour
-//     blended behind entry i, S_i = sum_{j > i} (c_j . dL/dpixel) alpha_j T_j  -- two PREFIX SCANS over the lanes in
-//     back-to-front order (4 row_shr DPP steps each), with the pixel's running (T, S) carried from group to group through
-//     a 32-byte LDS record per pixel;
-//   * dL/dalpha_i = T_i (c_i . g) - (S_i + T_final (bg . g)) / (1 - alpha_i)   -- algebraically upstream's recurrence
-//     (accum_rec = last_alpha last_color + (1 - last_alpha) accum_rec), evaluated without the serial chain;
-//   * every lane accumulates the nine moments of ITS entry over the 16 pixels in registers: no cross-lane reduction, no
-//     LDS atomics.  After the 16 steps the per-entry constants are applied once (conic, -1/2, NDC scale) and the group is
-//     published through an LDS transpose: nine consecutive lanes write one entry (36 contiguous bytes, two memory-side
-//     atomic requests), seven entries per instruction.
-//   * what bounds the kernel is the number of 64-byte accumulator lines it sends to the memory-side atomic units (DESIGN.md
-//     sec. 4: with the arithmetic removed it takes as long), so the four rows are paced to reach the same depth together and
-//     the copies of a Gaussian that meet in one flush are merged in LDS first (28 % of the entries at C3).
-// Instructions per (entry, 4x4 block) pair: ~16 x 58 / 16 + ~7 = 65, against ~100 per (entry, block) visit before -- and a
-// visit used to occupy a whole wavefront iteration in which on average 2.6 of the 4 rows had an entry at all.
-// alpha is evaluated by the same splat_eval_q() as the forward and the validity test is the forward's (power <= 0,
-// alpha >= 1/255, list position <= the pixel's n_contrib), so the set of (pixel, entry) pairs is exactly the forward's.
+//     blended behind entry i, S_i = sum_{j > i} (c_j . dL/dpixel) alpha_j T_j -- two PREFIX SCANS over the row (row_shr:1,2,4,8,
+//     four pixels interleaved by hand), the pixel's running (T, S) carried from group to group in a 32-byte LDS record;
+//     dL/dalpha_i = T_i (c_i . g) - (S_i + T_final (bg . g)) / (1 - alpha_i): algebraically upstream's accum_rec recurrence;
+//   * every lane accumulates the nine moments of ITS entry over the 16 pixels in registers (no cross-lane reduction); the
+//     geometric ones as per-line constant-offset sums, centred once per group;
+//   * the records of a tile's 16 blocks meet in a position-keyed MERGE CACHE in LDS (S slots of 12 dwords, slot =
+//     (position - 1) mod S; the tag word is the slot's lock, taken with ONE returning integer LDS atomic per attempt --
+//     float LDS atomics are 46x slower on this part) before one 64-byte accumulator line per (tile, Gaussian) leaves the CU
+//     as float atomics; displaced records (live window wider than S) leave early;
+//   * a wavefront that is done leaves; the last one of the tile to arrive (an LDS counter) publishes the cache;
+//   * alpha is evaluated by the same splat_eval_q() as the forward and the validity test is the forward's (power <= 0,
+//     alpha >= 1/255, list position <= the pixel's n_contrib): the set of (pixel, entry) pairs is exactly the forward's.
+// Optionally the L1 image-loss gradient is formed per pixel here (d3ga_raster_backward_l1) and a second image's gradient
+// is folded in (DUAL: render_pair).  Numbers, history and the negative results: DESIGN.md sec. 4.
 #include "composite_common.h"
 
-// D3GA_SCAN_ABL: timing ablations of the kernel below (diagnostic builds only, results are WRONG; tools/gpu_ablate.sh):
-//   1 no atomics | 6 one of the four pixel lines and no atomics | 7 plain stores instead of atomics |
-//   8 every atomic but no pixel steps | 11 no merge of the rows' duplicates | 12 rows not paced
+// D3GA_SCAN_ABL: timing ablations of the kernel below (ablation builds only -- tools/_build/, results are WRONG, the Python
+// layer refuses them unless D3GA_ALLOW_ABLATION=1; tools/gpu_ablate.sh):
+//   1 nothing leaves the CU and no inserts | 8 every insert but no pixel steps | 12 rows not paced | 13 inserts but nothing leaves the CU
 #ifndef D3GA_SCAN_ABL
 #define D3GA_SCAN_ABL 0
 #endif
@@ -104,25 +101,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 3: the same backward with a TILE-LEVEL merge of the gradient records (composite_bwd_tile_kernel).
-//
-// What bounds the kernel above is the number of 64-byte accumulator lines it sends to the memory-side atomic units
-// (DESIGN.md sec. 4); its in-wave merge only sees the four rows of one quadrant in one flush (28 % of the entries meet).
-// Here the four quadrant wavefronts of a tile form ONE 256-thread workgroup that shares a position-indexed accumulator in
-// LDS, so every copy of a Gaussian in the tile's 16 blocks meets before ONE line leaves the CU:
-//   * s_cache: S slots of 12 dwords {nine moments, Gaussian id, tag, pad}, slot = (list position - 1) mod S -- a
-//     direct-mapped cache keyed by the position in the tile's depth-ordered list.  The rows walk their lists back to front,
-//     so the live positions form a sliding window; a window wider than S only costs evictions, never correctness;
-//   * the tag word is also the slot's lock: a lane takes a slot with ONE returning integer LDS atomic (ds_wrxchg_rtn_b32;
-//     integer LDS atomics run at ~7 ns per wave instruction and SIMD, float ones at 322 ns -- tools/micro/valu_issue.hip,
-//     profiles/r03_lds_atomic.jsonl -- which is why the values are added with plain loads and stores under the lock);
-//     old tag == my position: add; empty: install; another position: install mine and send the resident to HBM (its rows
-//     have passed it, or the window exceeded S);  losers of a slot (a lower row's copy in the same instruction, another
-//     wavefront) retry -- the holder never waits for anybody, so the loop cannot deadlock;
-//   * no barriers after the start: the wavefronts stay independent (own early exits, own pace); the last one to finish
-//     (an LDS counter) publishes the whole cache, nine consecutive lanes per record as before.
-// Everything before the publish step is the kernel above, line for line (same splat_eval_q, same validity test).
+// DUAL: a second image rendered with the same alphas (render_pair); S: slots of the tile's merge cache (see the file header).
 template <bool DUAL, int S>
 __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, uint64_t dcap, const float2 *__restrict__ xy,
