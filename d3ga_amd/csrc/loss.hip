@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int C, int H, int W, int 
 constexpr int kMarchW = 256;                 // threads = input columns of a strip
 constexpr int kMarchUse = 244;               // output columns of a strip (61 groups of 4); kMarchUse + 10 <= kMarchW
 constexpr int kMarchGroups = kMarchUse / 4;
-constexpr int kMarchLd = 264;                // floats per LDS row (16-byte reads run 2 floats past the 14 a group needs)
+constexpr int kMarchLd = 256;                // floats per LDS row (group 60 reads columns 240..255: nothing runs past the row)
 
 template <int NMAP>
 __device__ __forceinline__ void march_htaps(const float *row, int g, const float (&w)[11], float (&o)[4]) {
@@ -358,13 +358,13 @@ __device__ __forceinline__ void march_htaps(const float *row, int g, const float
     __builtin_amdgcn_sched_barrier(0);      // one map at a time: left alone the scheduler issues the LDS reads of all maps up front (196 VGPRs)
 }
 
-__global__ __launch_bounds__(kMarchW) void ssim_march_fwd_kernel(int C, int H, int W, int strips, int segs, int seg_rows,
+__global__ __launch_bounds__(kMarchW, 4) void ssim_march_fwd_kernel(int C, int H, int W, int strips, int segs, int seg_rows,
                                                                   const float *__restrict__ img1, const float *__restrict__ img2,
                                                                   float inv_n, float *__restrict__ out, float *__restrict__ Dm,
                                                                   float *__restrict__ Dq1, float *__restrict__ Dq12,
                                                                   float *__restrict__ out_l1, int vec_ok) {
-    __shared__ __attribute__((aligned(16))) float s_v[8][5][kMarchLd];      // two buffers of four rows: ONE barrier per group
-    __shared__ float s_part[8];
+    __shared__ __attribute__((aligned(16))) float s_v[8][5][kMarchLd];      // two buffers of four rows: ONE barrier per group (40 KB: four workgroups per CU)
+    float *const s_part = &s_v[0][0][0];                   // (the loss partials reuse it at the very end)
     const int tid = threadIdx.x;
     float w[11];
 #pragma unroll
@@ -385,49 +385,43 @@ __global__ __launch_bounds__(kMarchW) void ssim_march_fwd_kernel(int C, int H, i
         const bool col_out = tid >= kSsimHalo && tid < kSsimHalo + kMarchUse && gx < W;      // an output column of this strip
         const int y0 = sy * seg_rows;
         const int nout = min(seg_rows, H - y0);
-        float rx[11], ry[11];
-#pragma unroll
-        for (int k = 0; k < 11; ++k) { rx[k] = 0.f; ry[k] = 0.f; }
+        // a window of 14 input rows of this column in registers: FOUR output rows per group (rows i .. i + 10, i = 0..3), then the
+        // window moves down by four (10 register moves per map and group instead of 10 per ROW for an 11-row ring) and the four
+        // rows loaded meanwhile take the free places
+        float rx[14], ry[14];
         auto load_row = [&](int ri, float &x, float &y) {  // input row ri of the segment: image row y0 - 5 + ri
             const int gy = y0 - kSsimHalo + ri;
             const bool in = col_in && gy >= 0 && gy < H;
             x = in ? p1[(size_t)gy * W + gx] : 0.f;
             y = in ? p2[(size_t)gy * W + gx] : 0.f;
         };
-        // the NEXT four input rows are in flight while the current four are convolved (one row ahead did not cover the
-        // load latency: a row is ~0.5 us of work per wavefront)
-        float nx[4], ny[4], cx[4], cy[4];
-        const int nin = nout + 2 * kSsimHalo;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) load_row(j, nx[j], ny[j]);
-        for (int ri = 0; ri < nin; ++ri) {
-            if ((ri & 3) == 0) {
+        for (int k = 0; k < 14; ++k) load_row(k, rx[k], ry[k]);
+        float nx[4], ny[4];
+        const int ngroups = (nout + 3) >> 2;
+        for (int grp = 0; grp < ngroups; ++grp) {
+            const int orow0 = 4 * grp, slot = min(3, nout - 1 - orow0), buf = (grp & 1) << 2;      // slot: last valid row of the group
+            const int orow = orow0 + slot;
+            if (grp + 1 < ngroups) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { cx[j] = nx[j]; cy[j] = ny[j]; }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (ri + 4 + j < nin) load_row(ri + 4 + j, nx[j], ny[j]);
+                for (int j = 0; j < 4; ++j) load_row(orow0 + 14 + j, nx[j], ny[j]);    // the next group's new rows: in flight during this group
             }
 #pragma unroll
-            for (int k = 0; k < 10; ++k) { rx[k] = rx[k + 1]; ry[k] = ry[k + 1]; }
-            {
-                const int j = ri & 3;
-                rx[10] = j == 0 ? cx[0] : (j == 1 ? cx[1] : (j == 2 ? cx[2] : cx[3]));
-                ry[10] = j == 0 ? cy[0] : (j == 1 ? cy[1] : (j == 2 ? cy[2] : cy[3]));
-            }
-            if (ri < 2 * kSsimHalo) continue;              // ring not full yet
-            const int orow = ri - 2 * kSsimHalo;           // output row of the segment; its centre sample is ring slot 5
-            float sx1 = 0.f, sy1 = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+            for (int i = 0; i < 4; ++i) {
+                float sx1 = 0.f, sy1 = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float wx = w[k] * rx[k], wy = w[k] * ry[k];
-                sx1 += wx; sy1 += wy;
-                sxx = fmaf(wx, rx[k], sxx); syy = fmaf(wy, ry[k], syy); sxy = fmaf(wx, ry[k], sxy);
+                for (int k = 0; k < 11; ++k) {
+                    const float wx = w[k] * rx[i + k], wy = w[k] * ry[i + k];
+                    sx1 += wx; sy1 += wy;
+                    sxx = fmaf(wx, rx[i + k], sxx); syy = fmaf(wy, ry[i + k], syy); sxy = fmaf(wx, ry[i + k], sxy);
+                }
+                s_v[buf + i][0][tid] = sx1; s_v[buf + i][1][tid] = sy1; s_v[buf + i][2][tid] = sxx; s_v[buf + i][3][tid] = syy; s_v[buf + i][4][tid] = sxy;
+                if (col_out && i <= slot) local_l1 += fabsf(rx[i + 5] - ry[i + 5]);           // fused L1
             }
-            const int slot = orow & 3, buf = orow & 4;     // (buffer 0 / 4: the group's four rows)
-            s_v[buf + slot][0][tid] = sx1; s_v[buf + slot][1][tid] = sy1; s_v[buf + slot][2][tid] = sxx; s_v[buf + slot][3][tid] = syy; s_v[buf + slot][4][tid] = sxy;
-            if (col_out) local_l1 += fabsf(rx[5] - ry[5]);                                   // fused L1
-            if (slot != 3 && orow != nout - 1) continue;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) { rx[k] = rx[k + 4]; ry[k] = ry[k + 4]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { rx[10 + j] = nx[j]; ry[10 + j] = ny[j]; }
             __syncthreads();
             // ---- horizontal pass + SSIM of up to four rows: thread = (row slot, 4 adjacent output columns) ----
             if (tid < 4 * kMarchGroups) {
@@ -446,7 +440,7 @@ __global__ __launch_bounds__(kMarchW) void ssim_march_fwd_kernel(int C, int H, i
                         const float s1 = q1[j] - mu1[j] * mu1[j], s2 = q2[j] - mu2[j] * mu2[j], s12 = q12[j] - mu1[j] * mu2[j];
                         const float A = 2.f * mu1[j] * mu2[j] + kSsimC1, B = 2.f * s12 + kSsimC2;
                         const float Dd = mu1[j] * mu1[j] + mu2[j] * mu2[j] + kSsimC1, E = s1 + s2 + kSsimC2;
-                        const float iD = 1.0f / Dd, iE = 1.0f / E;
+                        const float iD = __builtin_amdgcn_rcpf(Dd), iE = __builtin_amdgcn_rcpf(E);      // (1 ulp; a full-precision divide is ~10 instructions, eight of them per thread and group)
                         const float val = A * B * iD * iE;
                         ds1[j] = -val * iE;
                         ds12[j] = 2.f * A * iD * iE;
@@ -509,43 +503,35 @@ __global__ __launch_bounds__(kMarchW) void ssim_march_bwd_kernel(int C, int H, i
         const bool col_in = gx >= 0 && gx < W;
         const int y0 = sy * seg_rows;
         const int nout = min(seg_rows, H - y0);
-        float ra[11], rb[11], rd[11];
-#pragma unroll
-        for (int k = 0; k < 11; ++k) { ra[k] = 0.f; rb[k] = 0.f; rd[k] = 0.f; }
+        float ra[14], rb[14], rd[14];
         auto load_row = [&](int ri, float &a, float &b, float &d) {
             const int gy = y0 - kSsimHalo + ri;
             const bool in = col_in && gy >= 0 && gy < H;
             const size_t o = plane + (size_t)gy * W + gx;
             a = in ? Dm[o] : 0.f; b = in ? Dq1[o] : 0.f; d = in ? Dq12[o] : 0.f;
         };
-        float na[4], nb[4], nd[4], ca[4], cb[4], cd[4];
-        const int nin = nout + 2 * kSsimHalo;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) load_row(j, na[j], nb[j], nd[j]);
-        for (int ri = 0; ri < nin; ++ri) {
-            if ((ri & 3) == 0) {
+        for (int k = 0; k < 14; ++k) load_row(k, ra[k], rb[k], rd[k]);
+        float na[4], nb[4], nd[4];
+        const int ngroups = (nout + 3) >> 2;
+        for (int grp = 0; grp < ngroups; ++grp) {
+            const int orow0 = 4 * grp, slot = min(3, nout - 1 - orow0), buf = (grp & 1) << 2;
+            const int orow = orow0 + slot;
+            if (grp + 1 < ngroups) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { ca[j] = na[j]; cb[j] = nb[j]; cd[j] = nd[j]; }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (ri + 4 + j < nin) load_row(ri + 4 + j, na[j], nb[j], nd[j]);
+                for (int j = 0; j < 4; ++j) load_row(orow0 + 14 + j, na[j], nb[j], nd[j]);
             }
 #pragma unroll
-            for (int k = 0; k < 10; ++k) { ra[k] = ra[k + 1]; rb[k] = rb[k + 1]; rd[k] = rd[k + 1]; }
-            {
-                const int j = ri & 3;
-                ra[10] = j == 0 ? ca[0] : (j == 1 ? ca[1] : (j == 2 ? ca[2] : ca[3]));
-                rb[10] = j == 0 ? cb[0] : (j == 1 ? cb[1] : (j == 2 ? cb[2] : cb[3]));
-                rd[10] = j == 0 ? cd[0] : (j == 1 ? cd[1] : (j == 2 ? cd[2] : cd[3]));
-            }
-            if (ri < 2 * kSsimHalo) continue;
-            const int orow = ri - 2 * kSsimHalo;
-            float sa = 0.f, sb = 0.f, sd = 0.f;
+            for (int i = 0; i < 4; ++i) {
+                float sa = 0.f, sb = 0.f, sd = 0.f;
 #pragma unroll
-            for (int k = 0; k < 11; ++k) { sa = fmaf(w[k], ra[k], sa); sb = fmaf(w[k], rb[k], sb); sd = fmaf(w[k], rd[k], sd); }
-            const int slot = orow & 3, buf = orow & 4;
-            s_v[buf + slot][0][tid] = sa; s_v[buf + slot][1][tid] = sb; s_v[buf + slot][2][tid] = sd;
-            if (slot != 3 && orow != nout - 1) continue;
+                for (int k = 0; k < 11; ++k) { sa = fmaf(w[k], ra[i + k], sa); sb = fmaf(w[k], rb[i + k], sb); sd = fmaf(w[k], rd[i + k], sd); }
+                s_v[buf + i][0][tid] = sa; s_v[buf + i][1][tid] = sb; s_v[buf + i][2][tid] = sd;
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) { ra[k] = ra[k + 4]; rb[k] = rb[k + 4]; rd[k] = rd[k + 4]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ra[10 + j] = na[j]; rb[10 + j] = nb[j]; rd[10 + j] = nd[j]; }
             __syncthreads();
             if (tid < 4 * kMarchGroups) {
                 const int rs = tid / kMarchGroups, gq = tid - rs * kMarchGroups;
