@@ -701,7 +701,8 @@ def color_train_bench(args):
                nets["deformation_field"]]
     leaves = [q for b in buckets for q in b]
     red = ddist.BucketedGradReducer(buckets, timing=True)
-    opt = torch.optim.Adam(leaves, lr=1e-4)
+    make_opt = lambda: torch.optim.Adam(leaves, lr=1e-4, capturable=True)       # (capturable: the step may live in a hipGraph)
+    opt = make_opt()
     losses = []
 
     def one_step():
@@ -717,7 +718,26 @@ def color_train_bench(args):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # N = 1 reference on every rank (identical replicas afterwards: the parameters are restored)
+    can_capture = not args.no_graph and not args.single_device and (world == 1 or (torch.distributed.get_backend() == "nccl" and not args.no_graph_collectives))
+
+    def try_capture(tag):
+        """ONE hipGraph of one_step, or None; N > 1: only when every rank captured."""
+        cap = None
+        if can_capture:
+            from d3ga_amd.graph import CapturedStep
+            try:
+                cap = CapturedStep(one_step, params=leaves)
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: capture of the {tag} failed ({type(e).__name__}: {e}); eager", file=sys.stderr)
+            if world > 1:
+                ok = torch.tensor([1.0 if cap is not None else 0.0], device=dev)
+                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+                if float(ok) == 0.0:
+                    cap = None
+        return cap
+
+    # N = 1 reference on every rank, in the SAME launch mode as the N-rank step (identical replicas afterwards: the parameters
+    # are restored and the optimiser is new)
     state = [q.detach().clone() for q in leaves]
     n1_ms = None
     if world > 1:
@@ -725,26 +745,44 @@ def color_train_bench(args):
         red._active = lambda: False                        # the N = 1 step of the same frame: hooks count, nothing goes on the wire
         for _ in range(3):
             one_step()
+        cap1 = try_capture("N = 1 reference step")
+        run1 = (lambda: cap1.replay()) if cap1 is not None else one_step
+        for _ in range(3):
+            run1()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(max(5, args.steps // 5)):
-            one_step()
+            run1()
         torch.cuda.synchronize()
         n1 = torch.tensor([1e3 * (time.perf_counter() - t0) / max(5, args.steps // 5)], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(n1, op=torch.distributed.ReduceOp.MAX)
         n1_ms = float(n1.item())
+        del cap1
         red._active = active
         with torch.no_grad():
             for q, q0 in zip(leaves, state):
                 q.copy_(q0)
-        opt = torch.optim.Adam(leaves, lr=1e-4)
+        opt = make_opt()
     for _ in range(args.warmup):
         one_step()
+    # The eager step is bound by the host at this size (~150 launches: 3.6-4.6 ms against ~2 ms of GPU work at C4): capture the WHOLE
+    # training step -- forward, backward with the per-bucket collectives issued from its hooks, clip, Adam -- in ONE hipGraph.
+    # N > 1: over RCCL only (as for the frame's step: --no-graph-collectives keeps it eager); every rank must have captured.
+    cap, launch_mode = try_capture("training step"), "eager"
+    if cap is not None:
+        launch_mode = "ONE hipGraph of the whole training step (forward, backward with the bucket collectives, clip_grad_norm_, Adam)"
+
+    def timed_step():
+        if cap is not None:
+            return cap.replay()
+        return one_step()
+    for _ in range(3):
+        timed_step()
     red.exchange_ms()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(one_step().detach())
+        losses.append(timed_step().detach().clone())
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -776,7 +814,7 @@ def color_train_bench(args):
                           "grad_exchange_bytes_per_rank": red.nbytes(), "buckets": len(red.buckets)},
                "roofline": None, "cpu_baseline": None,
                "loss_first_last": [round(float(ls[:5].mean()), 5), round(float(ls[-5:].mean()), 5)], "loss_finite": bool(torch.isfinite(ls).all()),
-               "replicas_identical": same, "launch_mode": "eager",
+               "replicas_identical": same, "launch_mode": launch_mode,
                "distributed": {"nranks_seen": int(ones.item()), "n1_ms_per_step": None if n1_ms is None else round(n1_ms, 4),
                                "efficiency": None if n1_ms is None else round(n1_ms / ms, 4),
                                "bucket_ms": None if ex_ms is None else round(ex_ms, 4),
@@ -1024,6 +1062,14 @@ def main():
             frame.grad_sync = keep_sync
             flat.zero()
 
+    if world > 1 and cut and not args.no_graph and not args.single_device:
+        # the candidates must be the same on every rank (a rank whose capture failed would skip collectives the others issue)
+        have = torch.tensor([1.0 if graph_one is not None else 0.0, 1.0 if (graph is not None and hasattr(graph, "graph_b")) else 0.0], device=dev)
+        torch.distributed.all_reduce(have, op=torch.distributed.ReduceOp.MIN)
+        if float(have[0]) == 0.0:
+            graph_one = None
+        if float(have[1]) == 0.0 and graph is not None and hasattr(graph, "graph_b"):
+            graph = None
     if (graph is not None and hasattr(graph, "graph_b")) or graph_one is not None:
         # Which launch mode for the N > 1 step?  (a) ONE hipGraph incl. the collectives (0.436 vs 0.419 ms for the N = 1 step at
         # C3 over a one-rank RCCL group: 0.96 per rank), (b) two graphs around the eager exchange (0.55), (c) eager (0.56).
