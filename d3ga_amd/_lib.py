@@ -56,6 +56,7 @@ _SIGNATURES = {
     "d3ga_raster_bin_sort": ([_prm, _vp, _vp, _i64, _vp], _i),
     "d3ga_raster_composite_fwd": ([_prm, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i),
     "d3ga_raster_composite_bwd": ([_prm, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i),
+    "d3ga_raster_composite_bwd_depth": ([_prm, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_raster_composite_fwd2": ([_prm, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_raster_composite_bwd2": ([_prm, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_raster_preprocess_bwd": ([_prm] + [_vp] * 18 + [_vp], _i),

@@ -55,7 +55,7 @@ struct L1Source { const float *image, *target; const float *const *target_cell; 
 int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, const BinBuf &bin, const GeomBuf &g,
                               const ImgBuf &im, int64_t d_capacity, const float *bg, const float *dL_dpix, float *acc,
                               bool ordered, const float *colors2, const float *bg2, const float *dL_dpix2, const L1Source &l1,
-                              hipStream_t s);
+                              hipStream_t s, const float *dL_dinvd = nullptr);
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll

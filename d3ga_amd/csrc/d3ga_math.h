@@ -298,6 +298,7 @@ struct Splat {
     float conic[3];
     int radius;
     int rect[4];           // tile rectangle [minx, miny, maxx, maxy)
+    float aa;              // antialiasing: sqrt(max(2.5e-5, det(cov2D) / det(cov2D + 0.3 I))), the factor on the opacity (1: off)
 };
 
 D3GA_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -310,10 +311,12 @@ D3GA_HD void tile_rect(float px, float py, float radius, int gx, int gy, int rec
     rect[3] = clampi((int)((py + radius + kTile - 1) / kTile), 0, gy);
 }
 
+constexpr float kAaFloor = 0.000025f;   // [UPSTREAM-RECALL] branch dr_aa: h_convolution_scaling = sqrt(max(0.000025, det_cov / det_cov_plus_h_cov))
 D3GA_HD Splat project_gaussian(V3 mean, const float c6[6], const float *view, const float *proj, int W, int H,
-                               float tanfovx, float tanfovy) {
+                               float tanfovx, float tanfovy, bool antialiasing = false) {
     D3GA_NO_CONTRACT
     Splat s;
+    s.aa = 1.0f;
     s.visible = false; s.radius = 0; s.depth = 0.f; s.px = s.py = 0.f;
     s.conic[0] = s.conic[1] = s.conic[2] = 0.f;
     s.rect[0] = s.rect[1] = s.rect[2] = s.rect[3] = 0;
@@ -325,9 +328,11 @@ D3GA_HD Splat project_gaussian(V3 mean, const float c6[6], const float *view, co
     const Ewa e = ewa_matrix(view, mean, fx, fy, tanfovx, tanfovy);
     float TS[6], a, b, c;
     cov2d(e.T, c6, TS, a, b, c);
+    const float det0 = a * c - b * b;     // before the dilation: the antialiasing factor compensates the energy the dilation adds
     a += kDilate; c += kDilate;
     const float det = a * c - b * b;
     if (det == 0.0f) return s;
+    if (antialiasing) s.aa = sqrtf(fmaxf(kAaFloor, det0 / det));
     const float inv = 1.0f / det;
     const float mid = 0.5f * (a + c);
     const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
@@ -405,20 +410,38 @@ D3GA_HD void sh_basis_grad(int deg, float x, float y, float z, float Bx[16], flo
 // R6 per-Gaussian backward pieces
 // ---------------------------------------------------------------------------------------------------------
 // conic gradient (dA, dB/2, dC) -> dL/dcov3D (6, accumulated with =) and dL/dmean (view-space chain, through T)
+// antialiasing: g_op_scaled = dL/d(opacity x aa) and the activated opacity as stored (opacity x aa); the factor's own
+// gradient dL/daa = g_op_scaled x opacity flows into the covariance through det(cov2D) / det(cov2D + 0.3 I); *aa_out = aa
 D3GA_HD void cov2d_bwd(V3 mean, const float c6[6], const float *view, int W, int H, float tanfovx, float tanfovy,
-                       float dA, float dBh, float dC, float g6[6], float gmean[3]) {
+                       float dA, float dBh, float dC, float g6[6], float gmean[3], bool antialiasing = false,
+                       float g_op_scaled = 0.f, float op_scaled = 0.f, float *aa_out = nullptr) {
     const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
     const Ewa e = ewa_matrix(view, mean, fx, fy, tanfovx, tanfovy);
     const float *T = e.T;
     float TS[6], a, b, c;
     cov2d(T, c6, TS, a, b, c);
+    const float a0 = a, c0 = c;
     a += kDilate; c += kDilate;
     const float denom = a * c - b * b;
     const float d2 = 1.0f / (denom * denom + 0.0000001f);
     // conic = (c, -b, a)/denom ; dBh is half of dL/dB
-    const float ga = d2 * (-c * c * dA + 2.f * b * c * dBh + (denom - a * c) * dC);
-    const float gc = d2 * (-a * a * dC + 2.f * a * b * dBh + (denom - a * c) * dA);
-    const float gb = d2 * 2.f * (b * c * dA - (denom + 2.f * b * b) * dBh + a * b * dC);
+    float ga = d2 * (-c * c * dA + 2.f * b * c * dBh + (denom - a * c) * dC);
+    float gc = d2 * (-a * a * dC + 2.f * a * b * dBh + (denom - a * c) * dA);
+    float gb = d2 * 2.f * (b * c * dA - (denom + 2.f * b * b) * dBh + a * b * dC);
+    if (aa_out) *aa_out = 1.0f;
+    if (antialiasing) {
+        // rho = (a0 c0 - b^2) / ((a0 + w)(c0 + w) - b^2), aa = sqrt(max(floor, rho));  with D = the dilated determinant:
+        //   d rho / d a0 = w (w c0 + c0^2 + b^2) / D^2,  d rho / d c0 = w (w a0 + a0^2 + b^2) / D^2,  d rho / d b = -2 w b (w + a0 + c0) / D^2
+        const float rho = (a0 * c0 - b * b) / denom;
+        const float aa = sqrtf(fmaxf(kAaFloor, rho));
+        if (aa_out) *aa_out = aa;
+        const float g_aa = g_op_scaled * (op_scaled / aa);            // dL/daa = dL/d(opacity aa) x opacity
+        const float g_rho = rho <= kAaFloor ? 0.f : g_aa / (2.f * aa);
+        const float k = g_rho * kDilate / (denom * denom);
+        ga += k * (kDilate * c0 + c0 * c0 + b * b);
+        gc += k * (kDilate * a0 + a0 * a0 + b * b);
+        gb += -2.f * k * b * (kDilate + a0 + c0);
+    }
     g6[0] = T[0] * T[0] * ga + T[0] * T[3] * gb + T[3] * T[3] * gc;
     g6[3] = T[1] * T[1] * ga + T[1] * T[4] * gb + T[4] * T[4] * gc;
     g6[5] = T[2] * T[2] * ga + T[2] * T[5] * gb + T[5] * T[5] * gc;

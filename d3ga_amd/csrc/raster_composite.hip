@@ -387,13 +387,14 @@ extern "C" int d3ga_raster_composite_fwd2(const d3ga_raster_params *prm, const f
 
 static int composite_bwd_impl(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, const void *img, const float *dL_dpix, float *acc, const float *colors2,
-                              const float *bg2, const float *dL_dpix2, const L1Source &l1, d3ga_stream_t stream) {
+                              const float *bg2, const float *dL_dpix2, const L1Source &l1, d3ga_stream_t stream,
+                              const float *dL_dinvd = nullptr) {
     if (!prm) return D3GA_E_NULL;
     if (prm->P < 0 || prm->W <= 0 || prm->H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
     if (prm->forward_only) return D3GA_E_CONFIG;          // the forward did not write the per-block lists
     if (prm->P == 0) return D3GA_OK;
     if (!bg || !geom || !binning || !img || !acc) return D3GA_E_NULL;
-    if (!dL_dpix && !l1.image) return D3GA_E_NULL;        // some incoming gradient: an image, the fused L1 term, or both
+    if (!dL_dpix && !l1.image && !dL_dinvd) return D3GA_E_NULL;        // some incoming gradient: an image, the fused L1 term, the inverse depth
     if (l1.image && (!(l1.target || l1.target_cell) || !l1.g_loss)) return D3GA_E_NULL;
     if (colors2 && (!bg2 || !dL_dpix2)) return D3GA_E_NULL;
     const int gx = tiles_x(prm->W), gy = tiles_y(prm->H);
@@ -401,7 +402,7 @@ static int composite_bwd_impl(const d3ga_raster_params *prm, const float *bg, co
     const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
     const ImgBuf im = carve_img(const_cast<void *>(img), prm->W, prm->H, (int64_t)gx * gy);
     return launch_composite_bwd_scan(prm, gx, gy, bin, g, im, d_capacity, bg, dL_dpix, acc,
-                                     (composite_variant() & kVariantOrdered) != 0, colors2, bg2, dL_dpix2, l1, (hipStream_t)stream);
+                                     (composite_variant() & kVariantOrdered) != 0, colors2, bg2, dL_dpix2, l1, (hipStream_t)stream, dL_dinvd);
 }
 
 static const L1Source kNoL1 = {nullptr, nullptr, nullptr, nullptr, 0.f};
@@ -411,6 +412,14 @@ extern "C" int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const fl
                                          const float *dL_dpix, float *acc, d3ga_stream_t stream) {
     if (!dL_dpix) return prm && prm->P == 0 ? D3GA_OK : D3GA_E_NULL;
     return composite_bwd_impl(prm, bg, geom, binning, d_capacity, img, dL_dpix, acc, nullptr, nullptr, nullptr, kNoL1, stream);
+}
+
+extern "C" int d3ga_raster_composite_bwd_depth(const d3ga_raster_params *prm, const float *bg, const void *geom,
+                                               const void *binning, int64_t d_capacity, const void *img,
+                                               const float *dL_dpix, const float *dL_dinvdepth, float *acc,
+                                               d3ga_stream_t stream) {
+    if (!dL_dpix && !dL_dinvdepth) return prm && prm->P == 0 ? D3GA_OK : D3GA_E_NULL;
+    return composite_bwd_impl(prm, bg, geom, binning, d_capacity, img, dL_dpix, acc, nullptr, nullptr, nullptr, kNoL1, stream, dL_dinvdepth);
 }
 
 extern "C" int d3ga_raster_composite_bwd2(const d3ga_raster_params *prm, const float *bg, const float *bg2, const void *geom,

@@ -102,14 +102,17 @@ typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 // DUAL: a second image rendered with the same alphas (render_pair); S: slots of the tile's merge cache (see the file header).
-template <bool DUAL, int S>
+// INVD: the inverse-depth image of branch dr_aa takes part as a fourth channel (its "colour" is the entry's 1 / depth): the
+// incoming dL/dinvdepth joins c . g, and the entry's dL/d(1/depth) = sum alpha T dL/dinvdepth is a tenth accumulated value
+// (the pad word of the cache slot, float 10 of the accumulator record).
+template <bool DUAL, int S, bool INVD = false>
 __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, uint64_t dcap, const float2 *__restrict__ xy,
     const float4 *__restrict__ conic_o, const float4 *__restrict__ rgb_invd, const float *__restrict__ bg,
     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
     float *__restrict__ acc, const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2,
     const float *__restrict__ bg2, const float *__restrict__ dL_dpix2, const uint2 *__restrict__ blk_list,
-    const uint32_t *__restrict__ blk_count, int assign, L1Source l1) {
+    const uint32_t *__restrict__ blk_count, int assign, L1Source l1, const float *__restrict__ dL_dinvd) {
     static_assert((S & (S - 1)) == 0, "power of two");
     constexpr int NW = 4;                            // wavefronts per tile (three, the third walking two sets of blocks: measured, slower -- DESIGN.md sec. 4)
     constexpr int PIXF = DUAL ? 12 : 8;
@@ -159,8 +162,9 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     // (quadrants: 57.5 k wave-groups at C3, interleaved 59.3 k, against 49 k row-groups / 4); and rotating g with the workgroup
     // index gives every SIMD of a CU (wave w of a workgroup runs on SIMD w) one wavefront of each weight class.
     const int row = lane >> 4, l16 = lane & 15;
-    const int fq = lane / 9, fk = lane - 9 * fq;           // publish: lane -> (record within a group of 7, value)
-    const int fk_off = fk < 2 ? fk : fk + 1;               // acc layout 0,1 | 3,4,5 | 6 | 7,8,9
+    constexpr int kVals = INVD ? 10 : 9, kPerInst = 64 / kVals;           // publish: values per record, records per instruction
+    const int fq = lane / kVals, fk = lane - kVals * fq;   // lane -> (record within a group of 7 (6), value)
+    const int fk_off = fk < 2 ? fk : fk + 1;               // acc layout 0,1 | 3,4,5 | 6 | 7,8,9 | 10 (dL/d(1/depth), INVD)
     constexpr int kAccStride = D3GA_ACC_STRIDE;
     float *const s_pix = s_pix_all[wave];
     float *const s_dump = s_dump_all[wave];
@@ -213,7 +217,9 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
         {
             float *rec = pixrow + l16 * PIXF;
             *reinterpret_cast<float4 *>(rec) = make_float4(T_final, 0.f, g0, g1);
-            *reinterpret_cast<float4 *>(rec + 4) = make_float4(g2, T_final * bg_dot, __uint_as_float(last), 0.f);
+            float gd = 0.f;
+            if constexpr (INVD) gd = inside ? dL_dinvd[pid] : 0.f;
+            *reinterpret_cast<float4 *>(rec + 4) = make_float4(g2, T_final * bg_dot, __uint_as_float(last), gd);
             if constexpr (DUAL) *reinterpret_cast<float4 *>(rec + 8) = make_float4(h0, h1, h2, 0.f);
         }
         const uint32_t blk_cap = end - begin;
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
             // (7 instructions for 4 pixels), accumulated as sums of A, B, C, dy A, dy B, dy^2 A; the centred moments follow at the
             // end of the group from dx = exr - k:  sum gop dx = exr SA - SB,  sum gop dx^2 = exr^2 SA - 2 exr SB + SC, ...
             // (3.5 instructions per pixel step instead of 9: w, wx, wy and six accumulations).
-            float SA = 0.f, SB = 0.f, SC = 0.f, SyA = 0.f, SyB = 0.f, SyyA = 0.f, M6 = 0.f, M7 = 0.f, M8 = 0.f;
+            float SA = 0.f, SB = 0.f, SC = 0.f, SyA = 0.f, SyB = 0.f, SyyA = 0.f, M6 = 0.f, M7 = 0.f, M8 = 0.f, M9 = 0.f;
 #if D3GA_TILE_PRIO
             {   // (the priority is an immediate)
                 const int left = ngroups - g;
@@ -268,6 +274,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
                     // the whole record is loaded HERE: left alone the compiler sinks the load of T_final (bg . g) into a
                     // divergent region behind `valid` -- an LDS round trip in the middle of every block line
                     asm volatile("" : "+v"(pb[k].x), "+v"(pb[k].y), "+v"(pb[k].z));
+                    if constexpr (INVD) asm volatile("" : "+v"(pb[k].w));
                 }
                 const float dy = eyr - (float)ky;
                 const float tb = cq.b * dy, tc = (cq.c * dy) * dy;
@@ -286,6 +293,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
                     r[k] = __builtin_amdgcn_rcpf(1.0f - al[k]);
                     cgv[k] = e.rgb.x * pa[k].z + e.rgb.y * pa[k].w + e.rgb.z * pb[k].x;
                     if constexpr (DUAL) cgv[k] += e.c2r * pc[k].x + e.c2g * pc[k].y + e.c2b * pc[k].z;
+                    if constexpr (INVD) cgv[k] = fmaf(e.rgb.w, pb[k].w, cgv[k]);
                 }
                 float p0 = r[0], p1 = r[1], p2 = r[2], p3 = r[3];
                 row_scan_mul4(p0, p1, p2, p3);
@@ -303,6 +311,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
                     const float dLda = Ti[k] * cgv[k] - (Sin[k] - u[k] + pb[k].y) * r[k];
                     gop[k] = valid[k] ? G[k] * dLda : 0.f;
                     M6 += dch[k] * pa[k].z; M7 += dch[k] * pa[k].w; M8 += dch[k] * pb[k].x;
+                    if constexpr (INVD) M9 = fmaf(dch[k], pb[k].w, M9);
                     *reinterpret_cast<float2 *>(wq + k * PIXF) = make_float2(Ti[k], Sin[k]);
                 }
                 const float A = (gop[0] + gop[1]) + (gop[2] + gop[3]);
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
             const uint32_t saddr = (uint32_t)(uintptr_t)(lds_u32 *)(s_cache + ((e.pos - 1u) & (uint32_t)(S - 1)) * kSlot);
             // an entry that touched no pixel has nothing but (exact) zeros: it stays out of the cache
             const uint32_t anybits = (__float_as_uint(SA) | __float_as_uint(SB) | __float_as_uint(SC)) | (__float_as_uint(SyA) | __float_as_uint(SyB) | __float_as_uint(SyyA)) |
-                                     (__float_as_uint(M6) | __float_as_uint(M7) | __float_as_uint(M8));
+                                     (__float_as_uint(M6) | __float_as_uint(M7) | __float_as_uint(M8) | __float_as_uint(M9));
             bool pending = D3GA_SCAN_ABL == 1 ? (anybits == 0x12345u) : (D3GA_SCAN_ABL == 8 ? act : (anybits << 1) != 0u);
 #ifdef D3GA_DIAG_TIMELINE
             dg_groups += 1;
@@ -345,6 +354,20 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
                 f4 ca, cb;
                 u2 cc;
                 asm("" : "=v"(old), "=v"(ca), "=v"(cb), "=v"(cc));       // defined, arbitrary: lanes that are not pending never look
+                float c9 = 0.f;
+                if constexpr (INVD) {
+                    asm("" : "=v"(c9));
+                    if (pending)
+                        asm volatile("ds_wrxchg_rtn_b32 %0, %5, %6 offset:40\n"
+                                     "ds_read_b128 %1, %5\n"
+                                     "ds_read_b128 %2, %5 offset:16\n"
+                                     "ds_read_b64 %3, %5 offset:32\n"
+                                     "ds_read_b32 %4, %5 offset:44\n"
+                                     "s_waitcnt lgkmcnt(0)"
+                                     : "+v"(old), "+v"(ca), "+v"(cb), "+v"(cc), "+v"(c9)
+                                     : "v"(saddr), "v"(kLocked)
+                                     : "memory");
+                } else
                 if (pending)
                     asm volatile("ds_wrxchg_rtn_b32 %0, %4, %5 offset:40\n"
                                  "ds_read_b128 %1, %4\n"
@@ -363,6 +386,10 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
                 const f4 ta = {va.x + (hit ? ca.x : 0.f), va.y + (hit ? ca.y : 0.f), va.z + (hit ? ca.z : 0.f), va.w + (hit ? ca.w : 0.f)};
                 const f4 tb4 = {vb.x + (hit ? cb.x : 0.f), vb.y + (hit ? cb.y : 0.f), vb.z + (hit ? cb.z : 0.f), vb.w + (hit ? cb.w : 0.f)};
                 const u2 tc = {__float_as_uint(M8 + (hit ? __uint_as_float(cc.x) : 0.f)), e.gid};
+                if constexpr (INVD) {
+                    const float t9 = M9 + (hit ? c9 : 0.f);
+                    if (won) asm volatile("ds_write_b32 %0, %1 offset:44" : : "v"(saddr), "v"(t9) : "memory");      // (before the tag store below releases the slot)
+                }
                 if (won)
                     asm volatile("ds_write_b128 %0, %1\n"
                                  "ds_write_b128 %0, %2 offset:16\n"
@@ -377,20 +404,20 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
                     // wave-uniform and rare (the window of live positions exceeded S): the displaced records leave through the
                     // dump area, up to 24 at a time, nine consecutive lanes per record like every publish of this kernel
                     const int rank = lanes_below(em), total = (int)__popcll(em);
-                    for (int c0 = 0; c0 < total; c0 += 24) {
-                        if (evi && rank >= c0 && rank < c0 + 24) {
-                            float *st = s_dump + (rank - c0) * 10;
+                    for (int c0 = 0; c0 < total; c0 += 20) {
+                        if (evi && rank >= c0 && rank < c0 + 20) {
+                            float *st = s_dump + (rank - c0) * 12;
                             st[0] = ca.x; st[1] = ca.y; st[2] = ca.z; st[3] = ca.w;
                             st[4] = cb.x; st[5] = cb.y; st[6] = cb.z; st[7] = cb.w;
-                            st[8] = __uint_as_float(cc.x); st[9] = __uint_as_float(cc.y);
+                            st[8] = __uint_as_float(cc.x); st[9] = c9; st[10] = __uint_as_float(cc.y);      // value 9: dL/d(1/depth) (INVD), word 10: Gaussian id
                         }
-                        const int n = min(total - c0, 24);
+                        const int n = min(total - c0, 20);
                         __builtin_amdgcn_wave_barrier();
-                        for (int base = 0; base < n; base += 7) {
+                        for (int base = 0; base < n; base += kPerInst) {
                             const int ent = base + fq;
-                            if (fq < 7 && ent < n) {
-                                const float val = s_dump[ent * 10 + fk];
-                                const uint32_t og = __float_as_uint(s_dump[ent * 10 + 9]);
+                            if (fq < kPerInst && ent < n) {
+                                const float val = s_dump[ent * 12 + fk];
+                                const uint32_t og = __float_as_uint(s_dump[ent * 12 + 10]);
                                 if (D3GA_SCAN_ABL != 13 && val != 0.f) atomicAdd(acc + kAccStride * (size_t)og + fk_off, val);
                             }
                         }
@@ -429,12 +456,12 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
     if (arrived != (uint32_t)(NW - 1) && !early_exit_off) return;
     if (early_exit_off) { __syncthreads(); if (wave != 0) return; }
-    for (int base = 0; base < S; base += 7) {
-        const int ent = base + min(fq, 6);
-        const bool mine = fq < 7 && ent < S;
+    for (int base = 0; base < S; base += kPerInst) {
+        const int ent = base + min(fq, kPerInst - 1);
+        const bool mine = fq < kPerInst && ent < S;
         const uint32_t *const sl = s_cache + min(ent, S - 1) * kSlot;
         const uint32_t tag = sl[10], gid = sl[9];
-        const float val = __uint_as_float(sl[fk]);
+        const float val = __uint_as_float(sl[fk < 9 ? fk : 11]);
         if (mine && tag != 0u && val != 0.f) atomicAdd(acc + kAccStride * (size_t)gid + fk_off, val);
     }
 }
@@ -458,20 +485,23 @@ extern "C" int d3ga_diag_scan_waves(unsigned long long *out, int n) {      // n 
 int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, const BinBuf &bin, const GeomBuf &g,
                               const ImgBuf &im, int64_t d_capacity, const float *bg, const float *dL_dpix, float *acc,
                               bool ordered, const float *colors2, const float *bg2, const float *dL_dpix2, const L1Source &l1,
-                              hipStream_t s) {
+                              hipStream_t s, const float *dL_dinvd) {
     // workgroup per tile, heaviest tiles first (tile_order of the bin stage); S = slots of the tile's merge cache
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
     const dim3 tgrid(gx * gy);
     const int S = composite_merge_slots();
-#define D3GA_LAUNCH_TILE(DUALV, SV)                                                                                           \
-    hipLaunchKernelGGL((composite_bwd_tile_kernel<DUALV, SV>), tgrid, dim3(256),                                               \
-                       lds_pad_bytes((const void *)composite_bwd_tile_kernel<DUALV, SV>, "D3GA_BWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
+#define D3GA_LAUNCH_TILE(DUALV, SV, INVDV)                                                                                    \
+    hipLaunchKernelGGL((composite_bwd_tile_kernel<DUALV, SV, INVDV>), tgrid, dim3(256),                                        \
+                       lds_pad_bytes((const void *)composite_bwd_tile_kernel<DUALV, SV, INVDV>, "D3GA_BWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
                        (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc, order,   \
-                       colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, composite_tile_assign(), l1)
-    if (colors2) { if (S >= 512) D3GA_LAUNCH_TILE(true, 512); else D3GA_LAUNCH_TILE(true, 256); }
-    else if (S >= 1024) D3GA_LAUNCH_TILE(false, 1024);
-    else if (S >= 512) D3GA_LAUNCH_TILE(false, 512);
-    else D3GA_LAUNCH_TILE(false, 256);
+                       colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, composite_tile_assign(), l1, dL_dinvd)
+    if (dL_dinvd) {                                          // inverse-depth gradient (branch dr_aa): single-image launches only
+        if (colors2) return D3GA_E_CONFIG;
+        if (S >= 512) D3GA_LAUNCH_TILE(false, 512, true); else D3GA_LAUNCH_TILE(false, 256, true);
+    } else if (colors2) { if (S >= 512) D3GA_LAUNCH_TILE(true, 512, false); else D3GA_LAUNCH_TILE(true, 256, false); }
+    else if (S >= 1024) D3GA_LAUNCH_TILE(false, 1024, false);
+    else if (S >= 512) D3GA_LAUNCH_TILE(false, 512, false);
+    else D3GA_LAUNCH_TILE(false, 256, false);
 #undef D3GA_LAUNCH_TILE
     return check_launch(s, prm->debug);
 }

@@ -411,7 +411,6 @@ static int validate(const d3ga_raster_params *prm) {
     if (!prm) return D3GA_E_NULL;
     if (prm->P < 0 || prm->W <= 0 || prm->H <= 0 || prm->M < 0 || prm->M > 16) return D3GA_E_SIZE;
     if (prm->sh_degree < 0 || prm->sh_degree > 3) return D3GA_E_CONFIG;
-    if (prm->antialiasing) return D3GA_E_CONFIG;
     if (((prm->W + kTile - 1) / kTile) > 65535 || ((prm->H + kTile - 1) / kTile) > 65535) return D3GA_E_SIZE;
     return D3GA_OK;
 }

@@ -57,7 +57,7 @@ D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float 
                             rotations[4 * (size_t)i + 3]};
         cov3d_from_scale_rot(s, prm.scale_modifier, q, o.c6);
     }
-    o.sp = project_gaussian(mean, o.c6, viewmatrix, projmatrix, prm.W, prm.H, prm.tanfovx, prm.tanfovy);
+    o.sp = project_gaussian(mean, o.c6, viewmatrix, projmatrix, prm.W, prm.H, prm.tanfovx, prm.tanfovy, prm.antialiasing != 0);
     o.rgb[0] = o.rgb[1] = o.rgb[2] = 0.f;
     o.clampmask = 0;
     o.opacity = 0.f;
@@ -70,6 +70,7 @@ D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float 
         o.opacity = 0.f;
         return o;
     }
+    o.opacity *= o.sp.aa;                    // antialiasing (branch dr_aa): what the compositing stage sees is opacity x h_convolution_scaling
     if (colors_precomp) {
         o.rgb[0] = colors_precomp[3 * (size_t)i]; o.rgb[1] = colors_precomp[3 * (size_t)i + 1];
         o.rgb[2] = colors_precomp[3 * (size_t)i + 2];
@@ -104,9 +105,15 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
     float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const V3 mean = ld3(means3D, i);
     const int nbM = prm.M;
+    float aa = 1.0f;
     if (visible) {
-        cov2d_bwd(mean, c6, viewmatrix, prm.W, prm.H, prm.tanfovx, prm.tanfovy, a[3], a[4], a[5], g6, gmean);
+        cov2d_bwd(mean, c6, viewmatrix, prm.W, prm.H, prm.tanfovx, prm.tanfovy, a[3], a[4], a[5], g6, gmean,
+                  prm.antialiasing != 0, a[6], act_opacity, &aa);
         project_bwd(mean, projmatrix, a[0], a[1], gmean);
+        // inverse depth (branch dr_aa): a[10] = dL/d(1/z) of this Gaussian, z its view-space depth; d(1/z)/dmean = -view_z / z^2
+        const float z = viewmatrix[2] * mean.x + viewmatrix[6] * mean.y + viewmatrix[10] * mean.z + viewmatrix[14];
+        const float gz = -a[10] / (z * z);
+        gmean[0] += viewmatrix[2] * gz; gmean[1] += viewmatrix[6] * gz; gmean[2] += viewmatrix[10] * gz;
     }
     // SH colour path (sh_row != null).  dsh_row == null selects the FACTORED output used by the view-sharded gradient
     // exchange (d3ga_sh_grad_from_views): the clamp-masked dL/dcolour is written to dL_dcolors instead of the rank-1
@@ -156,7 +163,11 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
         dL_dmeans2D[3 * (size_t)i] = a[0]; dL_dmeans2D[3 * (size_t)i + 1] = a[1]; dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
     }
     // act_opacity: the activated opacity the forward stored (conic_o.w); sigmoid' = s (1 - s)
-    if (dL_dopacity) dL_dopacity[i] = prm.opacity_activation == D3GA_OPACITY_SIGMOID ? a[6] * act_opacity * (1.0f - act_opacity) : a[6];
+    // (antialiasing: the stored opacity is opacity x aa; a[6] is the gradient w.r.t. that product)
+    if (dL_dopacity) {
+        const float op = act_opacity / aa, g_op = a[6] * aa;
+        dL_dopacity[i] = prm.opacity_activation == D3GA_OPACITY_SIGMOID ? g_op * op * (1.0f - op) : g_op;
+    }
     if (dL_dcov3D) {
         for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = g6[k];
     }

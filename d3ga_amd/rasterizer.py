@@ -349,7 +349,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         _last_img[dev.index] = (img, W, H, geom, P)
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img,
                               colors2, bg2, color if ctx.l1 else None, l1_t if ctx.l1 else None, l1_cell if ctx.l1 else None)
-        ctx.mark_non_differentiable(*((radii, invdepth) if invdepth is not None else (radii,)))
+        # (the inverse-depth image IS differentiable, as on branch dr_aa: with set_materialize_grads(False) an unused one costs nothing)
+        ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)                 # no zero-filled (P,) / (H,W) gradients for radii / invdepth per step
         if l1_target is not None:
             return color, radii, invdepth, loss
@@ -370,7 +371,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_loss, grad_color2 = grad_color2, None
             if g_loss is not None:
                 g_loss = _f32(g_loss, dev).reshape(1)
-        if grad_color is None and g_loss is None:        # only the second image was used (or nothing at all)
+        g_invd = None
+        if _grad_invdepth is not None:                   # a loss on the inverse-depth image (branch dr_aa's depth regularisation)
+            if dual or ctx.l1:
+                raise NotImplementedError("a gradient of the inverse-depth image is implemented for the single-image rasterizer call only "
+                                          "(not for rasterize_gaussians_pair / rasterize_gaussians_l1)")
+            g_invd = _f32(_grad_invdepth, dev).reshape(prm.H, prm.W)
+        if grad_color is None and g_loss is None and g_invd is None:        # only the second image was used (or nothing at all)
             grad_color = torch.zeros((3, prm.H, prm.W), dtype=torch.float32, device=dev)
         grad_color = _f32(grad_color, dev)
         if dual:
@@ -410,7 +417,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 factor = new(P + 1, 3)
                 g_col = factor[:P]
         L = _lib.lib()
-        if stage_timer.enabled or dual:
+        if stage_timer.enabled or dual or g_invd is not None:
             st, pp = stream_handle(), ctypes.byref(prm)
             if not self_clearing:
                 acc.zero_()
@@ -418,6 +425,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 stage_timer.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd2(
                     pp, dptr(bg), dptr(bg2), dptr(geom), dptr(colors2), dptr(binning), ctx.cap, dptr(img), dptr(grad_color),
                     dptr(grad_color2), dptr(acc), st), "d3ga_raster_composite_bwd2"))
+            elif g_invd is not None:
+                stage_timer.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd_depth(
+                    pp, dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img), dptr(grad_color), dptr(g_invd), dptr(acc), st),
+                    "d3ga_raster_composite_bwd_depth"))
             elif g_loss is not None:
                 stage_timer.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd_l1(
                     pp, dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img), dptr(image), dptr(l1_t), dptr(l1_cell),
@@ -531,8 +542,6 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or (
                 (scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-        if self.raster_settings.antialiasing:
-            raise NotImplementedError("antialiasing=True is not implemented (the D3GA renderer passes False, renderer.py:92)")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings, self.grad_sync, self.opacity_activation, self.want_invdepth)
 

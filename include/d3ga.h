@@ -111,7 +111,7 @@ typedef struct d3ga_raster_params {
                              * memory, campos[3] and campos[4] (campos is then 5 floats), so that a captured hipGraph can be
                              * replayed with another camera by rewriting one device buffer (d3ga_amd/cameras.py:CameraSlot) */
     float scale_modifier;
-    int32_t antialiasing; /* must be 0 (renderer.py:92) */
+    int32_t antialiasing; /* branch dr_aa [UPSTREAM-RECALL]: opacity x sqrt(max(2.5e-5, det(cov2D) / det(cov2D + 0.3 I))); D3GA passes 0 (renderer.py:92) */
     int32_t prefiltered;  /* accepted, ignored (renderer.py:90) */
     int32_t debug;        /* !=0: synchronise + check after every kernel (renderer.py:91 passes 0) */
     /* D8 (models/cage_net.py:139-159, 247-249: opacity = sigmoid(opacities)): 0 = `opacities` holds activated values
@@ -175,13 +175,20 @@ int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const float *bg, co
                               d3ga_stream_t stream);
 /* R5 back-to-front compositing backward.  dL_dpix (3,H,W).  Accumulates (atomically) into acc (P, D3GA_ACC_STRIDE) float,
  * which the CALLER must have zeroed (d3ga_raster_backward does it itself): [0..2] dL/dmean2D (x,y in NDC-scaled units, z
- * unused), [3..5] dL/dconic (a, b/2, c), [6] dL/dopacity, [7..9] dL/dcolor, [10..15] pad.  One record = one 64-byte line:
+ * unused), [3..5] dL/dconic (a, b/2, c), [6] dL/dopacity, [7..9] dL/dcolor, [10] dL/d(1/depth) (d3ga_raster_composite_bwd_depth), [11..15] pad.  One record = one 64-byte line:
  * the nine float atomics of a (tile, Gaussian) contribution then meet the memory side as ONE request (with the former
  * 48-byte stride half of the records straddled two lines: compositing backward 246 -> 185 us at C3). */
 #define D3GA_ACC_STRIDE 16
 int d3ga_raster_composite_bwd(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, const void *img, const float *dL_dpix, float *acc,
                               d3ga_stream_t stream);
+/* The same with the gradient of the inverse-depth image of branch dr_aa [UPSTREAM-RECALL]: dL_dinvdepth (H,W) | NULL, dL_dpix
+ * (3,H,W) | NULL (at least one).  The inverse depth takes part as a fourth channel whose per-Gaussian "colour" is 1 / depth:
+ * acc[10] receives dL/d(1/depth) = sum alpha T dL/dinvdepth, which d3ga_raster_preprocess_bwd chains into dL/dmeans3D
+ * (always: the slot is zero otherwise). */
+int d3ga_raster_composite_bwd_depth(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
+                                    int64_t d_capacity, const void *img, const float *dL_dpix, const float *dL_dinvdepth,
+                                    float *acc, d3ga_stream_t stream);
 
 /* Two images from one pass (an extension over upstream's rasterizer; the reference's training step renders every package
  * twice with the same geometry and opacities -- RGB, then constant silhouette colours on black, models/trainer.py:102-110):

@@ -66,9 +66,11 @@ class Context:
 
 def forward(means3D, opacities, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, W, H,
             cov3D_precomp=None, scales=None, rotations=None, scale_modifier=1.0,
-            shs=None, colors_precomp=None, sh_degree=0):
-    """numpy in / numpy out.  Returns (color (3,H,W), radii (P,), invdepth (H,W), ctx)."""
+            shs=None, colors_precomp=None, sh_degree=0, antialiasing=False):
+    """numpy in / numpy out.  Returns (color (3,H,W), radii (P,), invdepth (H,W), ctx).
+    antialiasing: branch dr_aa's opacity compensation of the 0.3 px dilation [UPSTREAM-RECALL] (ro_set_antialiasing)."""
     L = lib()
+    L.ro_set_antialiasing(ctypes.c_int(1 if antialiasing else 0))
     means3D = _f(means3D)
     P = means3D.shape[0]
     opacities, bg = _f(opacities).reshape(-1), _f(bg)
@@ -83,6 +85,7 @@ def forward(means3D, opacities, bg, viewmatrix, projmatrix, campos, tanfovx, tan
                      _p(means3D), _p(shs), _p(colors_precomp), _p(opacities), _p(scales), _p(rotations),
                      ctypes.c_float(scale_modifier), _p(cov3D_precomp), _p(viewmatrix), _p(projmatrix), _p(campos),
                      ctypes.c_float(tanfovx), ctypes.c_float(tanfovy), _p(bg), _p(color), _p(radii), _p(invd))
+    L.ro_set_antialiasing(ctypes.c_int(0))
     ctx = Context(h, dict(means3D=means3D, shs=shs, scales=scales, rotations=rotations, P=P, M=M, W=W, H=H,
                           has_sh=shs is not None, from_sr=cov3D_precomp is None))
     return color, radii, invd, ctx
@@ -176,8 +179,9 @@ def set_alpha_overrides(ctx, gid, pix, ok):
     L.ro_set_alpha_overrides(ctypes.c_void_p(ctx.handle), ctypes.c_int64(len(gid)), _p(gid), _p(pix), _p(ok))
 
 
-def backward(ctx, dL_dpix, sum_noise=None):
+def backward(ctx, dL_dpix, sum_noise=None, dL_dinvdepth=None):
     """Returns dict of numpy grads: means3D, means2D(P,3), shs|colors, opacities(P,1), scales, rotations, cov3D.
+    dL_dinvdepth (H,W): gradient of the inverse-depth image (branch dr_aa; ro_set_invdepth_grad), added to dL_dpix's.
     sum_noise=(gamma, pattern): conditioning probe -- every per-Gaussian pixel sum is moved by +- gamma x (sum of the absolute
     values of its terms) before the chain behind it runs (ro_set_sum_noise); the difference to the plain result bounds what the
     error of a float32 sum (gamma ~ depth x eps) does to each output element."""
@@ -187,7 +191,7 @@ def backward(ctx, dL_dpix, sum_noise=None):
     if sum_noise is not None:
         L.ro_set_sum_noise(float(sum_noise[0]), int(sum_noise[1]))
         try:
-            return backward(ctx, dL_dpix)
+            return backward(ctx, dL_dpix, dL_dinvdepth=dL_dinvdepth)
         finally:
             L.ro_set_sum_noise(0.0, 0)
     k = ctx.keep
@@ -199,7 +203,13 @@ def backward(ctx, dL_dpix, sum_noise=None):
     g["colors"] = None if k["has_sh"] else np.zeros((P, 3), np.float32)
     g["scales"] = np.zeros((P, 3), np.float32) if k["from_sr"] else None
     g["rotations"] = np.zeros((P, 4), np.float32) if k["from_sr"] else None
-    lib().ro_backward(ctypes.c_void_p(ctx.handle), _p(k["means3D"]), _p(k["shs"]), _p(k["scales"]), _p(k["rotations"]),
-                      _p(dL_dpix), _p(g["means3D"]), _p(g["means2D"]), _p(g["shs"]), _p(g["colors"]),
-                      _p(g["opacities"]), _p(g["scales"]), _p(g["rotations"]), _p(g["cov3D"]))
+    gd = None if dL_dinvdepth is None else np.ascontiguousarray(dL_dinvdepth, dtype=np.float32).reshape(k["H"], k["W"])
+    lib().ro_set_invdepth_grad.restype = None
+    lib().ro_set_invdepth_grad(_p(gd))
+    try:
+        lib().ro_backward(ctypes.c_void_p(ctx.handle), _p(k["means3D"]), _p(k["shs"]), _p(k["scales"]), _p(k["rotations"]),
+                          _p(dL_dpix), _p(g["means3D"]), _p(g["means2D"]), _p(g["shs"]), _p(g["colors"]),
+                          _p(g["opacities"]), _p(g["scales"]), _p(g["rotations"]), _p(g["cov3D"]))
+    finally:
+        lib().ro_set_invdepth_grad(None)
     return g

@@ -50,6 +50,9 @@ typedef struct {
     /* decision margins (see ro_marginal): per pixel the smallest relative distance of any evaluated alpha to the
      * 1/255 cut-off and of any test_T to the 1e-4 cut-off */
     float *margin_alpha, *margin_T;
+    int antialiasing;    /* ro_set_antialiasing at ro_forward time */
+    float *aa;           /* P: the antialiasing factor h (1 when off) */
+    float *op_raw;       /* P: the opacity as given (conic_o[3] = op_raw x h) */
     /* shared alpha decisions (ro_set_alpha_overrides): n pairs sorted by (pixel, Gaussian), 1 = the pair is blended */
     int64_t ovr_n;
     int *ovr_pix, *ovr_gid;
@@ -153,11 +156,20 @@ void ro_set_threads(int n) { (void)n; }
 int ro_max_threads(void) { return 1; }
 #endif
 
+/* Branch dr_aa [UPSTREAM-RECALL].  ro_set_antialiasing(1) before ro_forward: the opacity the compositing stage sees is
+ * opacity x h, h = sqrt(max(0.000025, det(cov2D) / det(cov2D + 0.3 I))) (kept per Gaussian in the context; ro_backward chains it).
+ * ro_set_invdepth_grad(g | NULL) before ro_backward: g (H,W) = dL/d(out_invdepth), a fourth channel whose per-Gaussian value is
+ * 1 / depth. */
+static int g_antialiasing = 0;
+static const float *g_dL_dinvdepth = NULL;
+void ro_set_antialiasing(int on) { g_antialiasing = on != 0; }
+void ro_set_invdepth_grad(const float *g) { g_dL_dinvdepth = g; }
+
 void ro_free(ro_ctx *c) {
     if (!c) return;
     free(c->depth); free(c->xy); free(c->conic_o); free(c->rgb); free(c->cov3D); free(c->radii);
     free(c->clamped); free(c->rect); free(c->tile_start); free(c->point_list); free(c->final_T); free(c->n_contrib);
-    free(c->margin_alpha); free(c->margin_T);
+    free(c->margin_alpha); free(c->margin_T); free(c->aa); free(c->op_raw);
     free(c->ovr_pix); free(c->ovr_gid); free(c->ovr_ok); free(c->ovr_has);
     free(c);
 }
@@ -194,6 +206,7 @@ ro_ctx *ro_forward(int P, int M, int deg, int W, int H, const float *means3D, co
     c->depth = (float *)calloc(Pn, 4); c->xy = (float *)calloc(Pn, 8); c->conic_o = (float *)calloc(Pn, 16);
     c->rgb = (float *)calloc(Pn, 12); c->cov3D = (float *)calloc(Pn, 24); c->radii = (int *)calloc(Pn, 4);
     c->clamped = (uint8_t *)calloc(Pn, 3); c->rect = (int *)calloc(Pn, 16);
+    c->antialiasing = g_antialiasing; c->aa = (float *)calloc(Pn, 4); c->op_raw = (float *)calloc(Pn, 4);
     int tiles = c->gx * c->gy;
     int64_t *counts = (int64_t *)calloc((size_t)tiles + 1, 8);
 
@@ -220,9 +233,11 @@ ro_ctx *ro_forward(int P, int M, int deg, int W, int H, const float *means3D, co
         float a = TS[0] * T[0] + TS[1] * T[1] + TS[2] * T[2];
         float b = TS[0] * T[3] + TS[1] * T[4] + TS[2] * T[5];
         float cc = TS[3] * T[3] + TS[4] * T[4] + TS[5] * T[5];
+        float det0 = a * cc - b * b;
         a += 0.3f; cc += 0.3f;
         float det = a * cc - b * b;
         if (det == 0.0f) continue;
+        float h_aa = c->antialiasing ? sqrtf(fmaxf(0.000025f, det0 / det)) : 1.0f;
         float det_inv = 1.f / det;
         float conic[3] = {cc * det_inv, -b * det_inv, a * det_inv};
         float mid = 0.5f * (a + cc);
@@ -243,7 +258,8 @@ ro_ctx *ro_forward(int P, int M, int deg, int W, int H, const float *means3D, co
         c->radii[i] = (int)rad;
         c->xy[2 * i] = pix[0]; c->xy[2 * i + 1] = pix[1];
         c->conic_o[4 * i] = conic[0]; c->conic_o[4 * i + 1] = conic[1]; c->conic_o[4 * i + 2] = conic[2];
-        c->conic_o[4 * i + 3] = opacities[i];
+        c->conic_o[4 * i + 3] = opacities[i] * h_aa;
+        c->aa[i] = h_aa; c->op_raw[i] = opacities[i];
         c->rect[4 * i] = rminx; c->rect[4 * i + 1] = rminy; c->rect[4 * i + 2] = rmaxx; c->rect[4 * i + 3] = rmaxy;
     }
     memcpy(radii_out, c->radii, sizeof(int) * P);
@@ -487,6 +503,8 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
     double *dL_drgb = (double *)calloc((size_t)(P > 0 ? P : 1), 24);
     double *dL_dm2 = (double *)calloc((size_t)(P > 0 ? P : 1), 16);
     double *dL_dop = (double *)calloc((size_t)(P > 0 ? P : 1), 8);
+    double *dL_dinvd = (double *)calloc((size_t)(P > 0 ? P : 1), 8);       /* dL/d(1/depth) per Gaussian (ro_set_invdepth_grad) */
+    const float *gdepth = g_dL_dinvdepth;
     /* conditioning probe only: the sums of the ABSOLUTE values of the same terms */
     const int probe = g_sum_noise_sigma != 0.0;
     double *ab_conic = (double *)calloc((size_t)(probe && P > 0 ? P : 1), 32);
@@ -506,6 +524,8 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
                 float T = T_final;
                 int last = c->n_contrib[pid];
                 float accum[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_alpha = 0.f;
+                float accum_d = 0.f, last_invd = 0.f;
+                const float dLd = gdepth ? gdepth[pid] : 0.f;
                 float dLp[3] = {dL_dpix[pid], dL_dpix[(size_t)H * W + pid], dL_dpix[(size_t)2 * H * W + pid]};
                 float bg_dot = c->bg[0] * dLp[0] + c->bg[1] * dLp[1] + c->bg[2] * dLp[2];
                 for (int64_t k = s + last - 1; k >= s; k--) {
@@ -528,6 +548,13 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
                         dL_dalpha += (col - accum[ch]) * dLp[ch];
                         atomic_addd(&dL_drgb[3 * g + ch], dch * dLp[ch]);
                         if (probe) atomic_addd(&ab_rgb[3 * g + ch], fabsf(dch * dLp[ch]));
+                    }
+                    if (gdepth) {
+                        float invd = 1.f / c->depth[g];
+                        accum_d = last_alpha * last_invd + (1.f - last_alpha) * accum_d;
+                        last_invd = invd;
+                        dL_dalpha += (invd - accum_d) * dLd;
+                        atomic_addd(&dL_dinvd[g], dch * dLd);
                     }
                     dL_dalpha *= T;
                     last_alpha = alpha;
@@ -571,7 +598,7 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
     free(ab_conic); free(ab_rgb); free(ab_m2); free(ab_op);
     for (int i = 0; i < P; i++) {
         dL_dmeans2D[3 * i] = (float)dL_dm2[2 * i]; dL_dmeans2D[3 * i + 1] = (float)dL_dm2[2 * i + 1];
-        dL_dopacity[i] = (float)dL_dop[i];
+        dL_dopacity[i] = (float)dL_dop[i] * c->aa[i];      /* dL_dop: w.r.t. opacity x h */
     }
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < P; i++) {
@@ -608,6 +635,19 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
                 dL_da = d2inv * (-cc * cc * dcx + 2 * b * cc * dcy + (denom - a * cc) * dcz);
                 dL_dc = d2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * cc) * dcx);
                 dL_db = d2inv * 2 * (b * cc * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
+                if (c->antialiasing) {
+                    /* h = sqrt(max(floor, rho)), rho = (x y - z^2) / ((x + w)(y + w) - z^2) with x, y the UNdilated diagonal:
+                     * d rho/dx = w (w y + y^2 + z^2) / D^2, d rho/dy = w (w x + x^2 + z^2) / D^2, d rho/dz = -2 w z (w + x + y) / D^2 */
+                    float x = a - 0.3f, y = cc - 0.3f, z = b, w = 0.3f;
+                    float rho = (x * y - z * z) / denom;
+                    float h = sqrtf(fmaxf(0.000025f, rho));
+                    float g_h = (float)dL_dop[i] * c->op_raw[i];
+                    float g_rho = rho <= 0.000025f ? 0.f : g_h / (2.f * h);
+                    float k = g_rho * w / (denom * denom);
+                    dL_da += k * (w * y + y * y + z * z);
+                    dL_dc += k * (w * x + x * x + z * z);
+                    dL_db += -2.f * k * z * (w + x + y);
+                }
                 float *o = dL_dcov + 6 * i;
                 /* symmetric 6-vector: off-diagonal entries receive the summed gradient */
                 o[0] += T[0] * T[0] * dL_da + T[0] * T[3] * dL_db + T[3] * T[3] * dL_dc;
@@ -641,6 +681,13 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
             dmean[0] += v[0] * dtx + v[1] * dty + v[2] * dtz;
             dmean[1] += v[4] * dtx + v[5] * dty + v[6] * dtz;
             dmean[2] += v[8] * dtx + v[9] * dty + v[10] * dtz;
+        }
+        /* ---- inverse depth -> mean3D: d(1/z)/dmean = -view_z / z^2 ---- */
+        if (gdepth) {
+            const float *v = c->view;
+            float z = c->depth[i];
+            float gz = -(float)dL_dinvd[i] / (z * z);
+            dmean[0] += v[2] * gz; dmean[1] += v[6] * gz; dmean[2] += v[10] * gz;
         }
         /* ---- mean2D -> mean3D through the perspective projection ---- */
         {
@@ -760,6 +807,6 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
             dL_drots[4 * i] = dr; dL_drots[4 * i + 1] = dx_; dL_drots[4 * i + 2] = dy_; dL_drots[4 * i + 3] = dz_;
         }
     }
-    free(dL_dconic); free(dL_drgb); free(dL_dm2); free(dL_dop);
+    free(dL_dconic); free(dL_drgb); free(dL_dm2); free(dL_dop); free(dL_dinvd);
     if (!dL_dcov3D) free(dL_dcov);
 }

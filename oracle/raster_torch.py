@@ -69,8 +69,9 @@ def _quat_rot_nonorm(q):
 
 def preprocess(means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, W, H,
                cov3D_precomp=None, scales=None, rotations=None, scale_modifier=1.0,
-               shs=None, colors_precomp=None, sh_degree=0):
-    """Per-Gaussian stage R1.  viewmatrix/projmatrix are the reference's TRANSPOSED 4x4 (row-vector) matrices."""
+               shs=None, colors_precomp=None, sh_degree=0, antialiasing=False):
+    """Per-Gaussian stage R1.  viewmatrix/projmatrix are the reference's TRANSPOSED 4x4 (row-vector) matrices.
+    antialiasing (branch dr_aa, [UPSTREAM-RECALL]): opacity x sqrt(max(0.000025, det(cov2D) / det(cov2D + 0.3 I)))."""
     dt = means3D.dtype
     P = means3D.shape[0]
     V = viewmatrix.to(dt)
@@ -105,6 +106,7 @@ def preprocess(means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanf
     Wr = V[:3, :3].transpose(0, 1)                                        # world->view rotation
     Tm = Jm @ Wr                                                          # (P,2,3)
     cov2 = Tm @ Sigma @ Tm.transpose(1, 2)
+    det0 = cov2[:, 0, 0] * cov2[:, 1, 1] - cov2[:, 0, 1] * cov2[:, 0, 1]
     a = cov2[:, 0, 0] + 0.3
     b = cov2[:, 0, 1]
     c = cov2[:, 1, 1] + 0.3
@@ -135,7 +137,10 @@ def preprocess(means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanf
         d = d / torch.sqrt((d * d).sum(1, keepdim=True))
         rgb = torch.clamp(eval_sh(sh_degree, shs, d) + 0.5, min=0.0)
 
-    return dict(xy=torch.stack([px, py], 1), depth=depth, conic=conic, opacity=opacities.reshape(-1), rgb=rgb,
+    opac = opacities.reshape(-1)
+    if antialiasing:
+        opac = opac * torch.sqrt(torch.clamp(det0 / det_safe, min=0.000025))
+    return dict(xy=torch.stack([px, py], 1), depth=depth, conic=conic, opacity=opac, rgb=rgb,
                 radii=torch.where(valid, radius, torch.zeros_like(radius)).to(torch.int32),
                 rect=(rminx, rminy, rmaxx, rmaxy), valid=valid, tiles_touched=torch.where(valid, touched, 0 * touched))
 
@@ -154,7 +159,7 @@ def composite(pre, bg, W, H, pixel_chunk=4096, return_aux=False):
     conic = pre["conic"][idx]
     opac = pre["opacity"][idx]
     rgb = pre["rgb"][idx]
-    invd = 1.0 / pre["depth"][idx].detach()
+    invd = 1.0 / pre["depth"][idx]           # differentiable: branch dr_aa back-propagates a loss on the inverse-depth image
     rminx, rminy, rmaxx, rmaxy = [r[idx] for r in pre["rect"]]
 
     ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
@@ -201,9 +206,9 @@ def composite(pre, bg, W, H, pixel_chunk=4096, return_aux=False):
 
 def rasterize(means3D, opacities, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, W, H,
               cov3D_precomp=None, scales=None, rotations=None, scale_modifier=1.0,
-              shs=None, colors_precomp=None, sh_degree=0, pixel_chunk=4096, return_aux=False):
+              shs=None, colors_precomp=None, sh_degree=0, pixel_chunk=4096, return_aux=False, antialiasing=False):
     pre = preprocess(means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, W, H,
-                     cov3D_precomp, scales, rotations, scale_modifier, shs, colors_precomp, sh_degree)
+                     cov3D_precomp, scales, rotations, scale_modifier, shs, colors_precomp, sh_degree, antialiasing)
     out = composite(pre, bg, W, H, pixel_chunk, return_aux)
     if return_aux:
         return out + (pre,)

@@ -211,6 +211,54 @@ def test_rasterizer_sh_precomp_cov_forward_backward(name, scale_mult, deg):
                         (m2d.grad, og["means2D"], "means2D")))
 
 
+@pytest.mark.parametrize("name,scale_mult,aa,depth_loss,from_sr", [("T1", 2.0, True, True, False), ("C1", 1.0, True, False, True),
+                                                                   ("C1", 1.0, False, True, False), ("T0", 3.0, True, True, True)])
+def test_antialiasing_and_inverse_depth_gradient(name, scale_mult, aa, depth_loss, from_sr):
+    """Branch dr_aa's extras ([UPSTREAM-RECALL]; D3GA passes antialiasing=False and keeps only [0] of the outputs -- completeness of
+    the drop-in surface): `antialiasing=True` scales every opacity by sqrt(max(2.5e-5, det(cov2D) / det(cov2D + 0.3 I))) (forward,
+    and its chain into the covariance in the backward), and the inverse-depth image is differentiable (a fourth channel of the
+    compositing backward, d(1/z)/dmean behind it).  HIP against the C oracle (whose hand-derived chain is checked against
+    autograd in tests/test_oracle_raster.py): image, inverse depth, all gradients, both covariance paths."""
+    from d3ga_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    inp = scene_inputs(name, scale_mult=scale_mult)
+    bg = torch.tensor([0.2, 0.7, 0.4])
+    gen = torch.Generator().manual_seed(3)
+    gpix = torch.randn(3, inp["H"], inp["W"], generator=gen)
+    gd = torch.randn(inp["H"], inp["W"], generator=gen) if depth_loss else None
+    st = _settings(inp, bg, 3)._replace(antialiasing=aa)
+    means, op, sh = (_cu(inp[k], True) for k in ("means3D", "opacities", "shs"))
+    q = torch.nn.functional.normalize(inp["scene"]["rotation"]) * 0.9
+    if from_sr:
+        sc, rot = _cu(inp["scales"], True), _cu(q, True)
+        kw, okw = dict(scales=sc, rotations=rot), dict(scales=_np(inp["scales"]), rotations=_np(q))
+    else:
+        cov = _cu(inp["cov6"], True)
+        kw, okw = dict(cov3D_precomp=cov), dict(cov3D_precomp=_np(inp["cov6"]))
+    color, radii, invd = GaussianRasterizer(st)(means3D=means, means2D=None, opacities=op, shs=sh, **kw)
+    cam = inp["cam"]
+    ocolor, oradii, oinvd, ctx = rc.forward(_np(inp["means3D"]), _np(inp["opacities"]), _np(bg), cam["world_view_transform"],
+                                            cam["full_proj_transform"], cam["camera_center"], cam["tanfovx"], cam["tanfovy"],
+                                            inp["W"], inp["H"], shs=_np(inp["shs"]), sh_degree=3, antialiasing=aa, **okw)
+    np.testing.assert_array_equal(_np(radii), oradii)
+    par = Parity(ctx)
+    par.mask(gpix)
+    if gd is not None:
+        gd[torch.from_numpy(par.pix)] = 0
+    og = rc.backward(ctx, _np(gpix), dL_dinvdepth=None if gd is None else _np(gd))
+    _assert_image(par, _np(color), ocolor)
+    _assert_image(par, _np(invd)[0], oinvd, what="invdepth", marginal_atol=2e-2)
+    loss = (color * gpix.to(DEV)).sum()
+    if gd is not None:
+        loss = loss + (invd[0] * gd.to(DEV)).sum()
+    loss.backward()
+    pairs = [(means.grad, og["means3D"], "means3D"), (op.grad, og["opacities"], "opacities"), (sh.grad, og["shs"], "shs")]
+    pairs += [(sc.grad, og["scales"], "scales"), (rot.grad, og["rotations"], "rotations")] if from_sr else [(cov.grad, og["cov3D"], "cov3D")]
+    bad = [p for p in pairs if not par.grads(_np(p[0]), p[1])[0]]
+    noise = conditioning_noise(ctx, _np(gpix), {k: og[k] for _, _, k in bad}) if (bad and gd is None) else {}
+    for mine, ref, what in pairs:
+        _assert_grads(par, ((mine, ref, what),), noise=noise.get(what))
+
+
 def test_unmasked_gradients_smoke_at_the_loose_bar():
     """The ONE comparison that keeps the raw incoming gradient on the marginal pixels (every other test zeroes it there,
     tests/util.py: Parity): non-marginal Gaussians strict, Gaussians that touch a marginal pixel within 5 % of the largest

@@ -233,3 +233,45 @@ def test_alpha_override_hooks():
     rc.set_alpha_overrides(ctx, gid[:0], pix[:0], own[:0])
     g3 = rc.backward(ctx, gpix)
     assert np.array_equal(g0["means3D"], g3["means3D"])
+
+
+def test_antialiasing_and_invdepth_gradient_c_oracle_matches_autograd_oracle():
+    """Branch dr_aa's two extras ([UPSTREAM-RECALL], D3GA itself passes antialiasing=False and drops the depth image): the
+    opacity compensation h = sqrt(max(2.5e-5, det(cov2D) / det(cov2D + 0.3 I))) and a loss on the inverse-depth image.  The
+    hand-derived C backward (d h / d cov2D, the fourth channel of the compositing backward, d(1/z)/dmean) against autograd."""
+    inp = scene_inputs("T0", scale_mult=2.0)
+    cam, W, H = inp["cam"], inp["W"], inp["H"]
+    bg = torch.tensor([0.3, 0.6, 0.1])
+    gen = torch.Generator().manual_seed(5)
+    gpix, gd = torch.randn(3, H, W, generator=gen), torch.randn(H, W, generator=gen)
+    dt = torch.float64
+    leaf = lambda t: t.to(dt).clone().requires_grad_(True)
+    m, o, c6, sh = leaf(inp["means3D"]), leaf(inp["opacities"]), leaf(inp["cov6"]), leaf(inp["shs"])
+    col, fT, nc, invd, pre = rt.rasterize(m, o, bg, inp["view"], inp["proj"], inp["campos"], cam["tanfovx"], cam["tanfovy"], W, H,
+                                          cov3D_precomp=c6, shs=sh, sh_degree=3, return_aux=True, antialiasing=True)
+    ((col * gpix.to(dt)).sum() + (invd * gd.to(dt)).sum()).backward()
+    ccol, radii, cinv, ctx = rc.forward(_np(inp["means3D"]), _np(inp["opacities"]), _np(bg), cam["world_view_transform"],
+                                        cam["full_proj_transform"], cam["camera_center"], cam["tanfovx"], cam["tanfovy"], W, H,
+                                        cov3D_precomp=_np(inp["cov6"]), shs=_np(inp["shs"]), sh_degree=3, antialiasing=True)
+    g = rc.backward(ctx, _np(gpix), dL_dinvdepth=_np(gd))
+    assert np.abs(ccol - _np(col)).max() < 1e-5 and np.abs(cinv - _np(invd)).max() < 1e-5
+    # the factor does something here: the same scene without it renders differently
+    ccol0, _, _, ctx0 = rc.forward(_np(inp["means3D"]), _np(inp["opacities"]), _np(bg), cam["world_view_transform"],
+                                   cam["full_proj_transform"], cam["camera_center"], cam["tanfovx"], cam["tanfovy"], W, H,
+                                   cov3D_precomp=_np(inp["cov6"]), shs=_np(inp["shs"]), sh_degree=3)
+    assert np.abs(ccol0 - ccol).max() > 1e-3
+    for k, t in (("means3D", m), ("opacities", o), ("cov3D", c6), ("shs", sh)):
+        assert rel_err(g[k], _np(t.grad)) < 5e-5, (k, rel_err(g[k], _np(t.grad)))
+    # and each extra on its own: inverse depth without antialiasing, antialiasing without a depth loss
+    for aa, use_d in ((False, True), (True, False)):
+        for t in (m, o, c6, sh):
+            t.grad = None
+        col, fT, nc, invd, pre = rt.rasterize(m, o, bg, inp["view"], inp["proj"], inp["campos"], cam["tanfovx"], cam["tanfovy"], W, H,
+                                              cov3D_precomp=c6, shs=sh, sh_degree=3, return_aux=True, antialiasing=aa)
+        ((col * gpix.to(dt)).sum() + ((invd * gd.to(dt)).sum() if use_d else 0.0)).backward()
+        _, _, _, ctx = rc.forward(_np(inp["means3D"]), _np(inp["opacities"]), _np(bg), cam["world_view_transform"],
+                                  cam["full_proj_transform"], cam["camera_center"], cam["tanfovx"], cam["tanfovy"], W, H,
+                                  cov3D_precomp=_np(inp["cov6"]), shs=_np(inp["shs"]), sh_degree=3, antialiasing=aa)
+        g = rc.backward(ctx, _np(gpix), dL_dinvdepth=_np(gd) if use_d else None)
+        for k, t in (("means3D", m), ("opacities", o), ("cov3D", c6), ("shs", sh)):
+            assert rel_err(g[k], _np(t.grad)) < 5e-5, (aa, use_d, k, rel_err(g[k], _np(t.grad)))
