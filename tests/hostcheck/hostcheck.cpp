@@ -99,14 +99,14 @@ void hc_preprocess_bwd(const d3ga_raster_params *prm, const float *means3D, cons
                        const float *rots, const float *view, const float *proj, const float *campos,
                        const int32_t *radii, const float *cov3D, const uint8_t *clamped, const float *acc,
                        float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dsh, float *dL_dcolors,
-                       float *dL_dcov3D, float *dL_dscales, float *dL_drots) {
+                       float *dL_dcov3D, float *dL_dscales, float *dL_drots, const float *act_opacity) {
     const float zeros[12] = {0};
     for (int i = 0; i < prm->P; ++i) {
         const bool vis = radii[i] > 0;
         preprocess_bwd_one(*prm, i, vis, means3D, shs ? shs + (size_t)3 * prm->M * i : nullptr, scales, rots, view, proj,
                            campos, cov3D + 6 * (size_t)i, clamped[i], vis ? acc + D3GA_ACC_STRIDE * (size_t)i : zeros, dL_dmeans3D,
                            dL_dmeans2D, dL_dopacity, dL_dsh ? dL_dsh + (size_t)3 * prm->M * i : nullptr, dL_dcolors,
-                           dL_dcov3D, dL_dscales, dL_drots);
+                           dL_dcov3D, dL_dscales, dL_drots, act_opacity ? act_opacity[i] : 0.f);
     }
 }
 

@@ -68,10 +68,10 @@ def test_fem_energy_vs_oracle(hostcheck, golden):
     assert rel_err(gt, _np(tp_t.grad)) < 1e-4
 
 
-def _prm(inp, M, deg, mod=1.0):
+def _prm(inp, M, deg, mod=1.0, antialiasing=0):
     return RasterParams(P=inp["means3D"].shape[0], M=M, sh_degree=deg, W=inp["W"], H=inp["H"],
                         tanfovx=inp["cam"]["tanfovx"], tanfovy=inp["cam"]["tanfovy"], scale_modifier=mod,
-                        antialiasing=0, prefiltered=0, debug=0)
+                        antialiasing=antialiasing, prefiltered=0, debug=0)
 
 
 def _run_pre(hostcheck, inp, prm, shs=None, colors=None, cov=None, scales=None, rots=None):
@@ -111,7 +111,7 @@ def test_preprocess_forward_vs_oracles(hostcheck):
     np.testing.assert_array_equal(o["rect"][vis], rect[vis])
 
 
-def _bwd_case(hostcheck, inp, prm, use_sh, from_sr, seed):
+def _bwd_case(hostcheck, inp, prm, use_sh, from_sr, seed, invdepth=False):
     """Feed the same accumulated screen-space gradients to the product's per-Gaussian backward and to an
     autograd evaluation of the oracle's preprocess stage."""
     P = prm.P
@@ -125,6 +125,8 @@ def _bwd_case(hostcheck, inp, prm, use_sh, from_sr, seed):
     vis = o["radii"] > 0
     acc = np.zeros((P, 16), np.float32)       # D3GA_ACC_STRIDE
     acc[:, [0, 1, 3, 4, 5, 6, 7, 8, 9]] = rng.normal(size=(P, 9)).astype(np.float32)
+    if invdepth:
+        acc[:, 10] = rng.normal(size=P).astype(np.float32)
     acc[~vis] = 0
     outs = dict(m3=np.zeros((P, 3), np.float32), m2=np.zeros((P, 3), np.float32), op=np.zeros((P, 1), np.float32),
                 sh=np.zeros((P, 16, 3), np.float32) if use_sh else None,
@@ -135,7 +137,7 @@ def _bwd_case(hostcheck, inp, prm, use_sh, from_sr, seed):
                                 ptr(_np(inp["view"])), ptr(_np(inp["proj"])), ptr(_np(inp["campos"])), ptr(o["radii"]),
                                 ptr(o["cov3D"]), ptr(o["clamped"]), ptr(acc), ptr(outs["m3"]), ptr(outs["m2"]),
                                 ptr(outs["op"]), ptr(outs["sh"]), ptr(outs["col"]), ptr(outs["cov"]), ptr(outs["sc"]),
-                                ptr(outs["ro"]))
+                                ptr(outs["ro"]), ptr(np.ascontiguousarray(o["conic_o"][:, 3])))
     # oracle: autograd through preprocess with a linear functional reproducing `acc`
     dd = torch.float64
     m = inp["means3D"].to(dd).requires_grad_(True)
@@ -153,13 +155,17 @@ def _bwd_case(hostcheck, inp, prm, use_sh, from_sr, seed):
     else:
         col_t = inp["rgb"].to(dd).requires_grad_(True)
         kw.update(colors_precomp=col_t)
-    pre = rt.preprocess(m, inp["opacities"].to(dd), inp["view"], inp["proj"], inp["campos"], prm.tanfovx, prm.tanfovy,
-                        prm.W, prm.H, **kw)
+    op_t = inp["opacities"].to(dd).requires_grad_(True)
+    pre = rt.preprocess(m, op_t, inp["view"], inp["proj"], inp["campos"], prm.tanfovx, prm.tanfovy,
+                        prm.W, prm.H, antialiasing=bool(prm.antialiasing), **kw)
     a = torch.from_numpy(acc).to(dd)
     # mean2D gradient is expressed in NDC-scaled units: d(pixel)/d(ndc) = 0.5*W  => pixel-space grad = a / (0.5 W)
     L = (pre["xy"][:, 0] * a[:, 0] / (0.5 * prm.W)).sum() + (pre["xy"][:, 1] * a[:, 1] / (0.5 * prm.H)).sum()
     L = L + (pre["conic"][:, 0] * a[:, 3]).sum() + (pre["conic"][:, 1] * 2.0 * a[:, 4]).sum() + (pre["conic"][:, 2] * a[:, 5]).sum()
-    L = L + (pre["rgb"] * a[:, 7:10]).sum()
+    L = L + (pre["rgb"] * a[:, 7:10]).sum() + (pre["opacity"] * a[:, 6]).sum()
+    if invdepth:
+        visible = torch.from_numpy(vis)
+        L = L + ((1.0 / pre["depth"][visible]) * a[visible, 10]).sum()
     L.backward()
     assert rel_err(outs["m3"], _np(m.grad)) < 1e-3
     if use_sh:
@@ -172,7 +178,10 @@ def _bwd_case(hostcheck, inp, prm, use_sh, from_sr, seed):
     else:
         assert rel_err(outs["cov"], _np(c_t.grad)) < 1e-3
     np.testing.assert_array_equal(outs["m2"][:, :2], acc[:, :2])
-    np.testing.assert_array_equal(outs["op"][:, 0], acc[:, 6])
+    if prm.antialiasing:
+        assert rel_err(outs["op"][:, 0], _np(op_t.grad).reshape(-1)) < 1e-5
+    else:
+        np.testing.assert_array_equal(outs["op"][:, 0], acc[:, 6])
 
 
 def test_preprocess_backward_sh_precomputed_cov(hostcheck):
@@ -184,6 +193,28 @@ def test_preprocess_backward_sh_precomputed_cov(hostcheck):
 def test_preprocess_backward_colors_scale_rot(hostcheck):
     inp = scene_inputs("T1", scale_mult=3.0)
     _bwd_case(hostcheck, inp, _prm(inp, 0, 0, mod=1.3), use_sh=False, from_sr=True, seed=3)
+
+
+def test_preprocess_backward_antialiasing_and_inverse_depth(hostcheck):
+    """Branch dr_aa: the opacity seen by compositing is opacity x sqrt(max(2.5e-5, det / det_dilated)) -- its chain into
+    cov3D / mean / opacity -- and acc[10] = dL/d(1/z) chains into the mean.  Small Gaussians (scale_mult 0.3) put the
+    factor well below one; large ones leave it near one."""
+    for mult, seed in ((0.3, 5), (3.0, 6)):
+        inp = scene_inputs("T1", scale_mult=mult)
+        _bwd_case(hostcheck, inp, _prm(inp, 16, 2, antialiasing=1), use_sh=True, from_sr=False, seed=seed, invdepth=True)
+        _bwd_case(hostcheck, inp, _prm(inp, 0, 0, mod=1.2, antialiasing=1), use_sh=False, from_sr=True, seed=seed + 10,
+                  invdepth=True)
+    # forward: the stored opacity is the product
+    inp = scene_inputs("T1", scale_mult=0.3)
+    prm = _prm(inp, 16, 3, antialiasing=1)
+    o = _run_pre(hostcheck, inp, prm, shs=_np(inp["shs"]), cov=_np(inp["cov6"]))
+    pre = rt.preprocess(inp["means3D"].double(), inp["opacities"].double(), inp["view"], inp["proj"], inp["campos"],
+                        prm.tanfovx, prm.tanfovy, prm.W, prm.H, cov3D_precomp=inp["cov6"].double(), shs=inp["shs"].double(),
+                        sh_degree=3, antialiasing=True)
+    vis = o["radii"] > 0
+    ratio = o["conic_o"][vis, 3] / _np(inp["opacities"]).reshape(-1)[vis]
+    assert ratio.min() < 0.5 and ratio.max() <= 1.0
+    np.testing.assert_allclose(o["conic_o"][vis, 3], _np(pre["opacity"])[vis], rtol=2e-4)
 
 
 def test_preprocess_backward_with_clamped_sh_and_frustum_edge(hostcheck):
