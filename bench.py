@@ -183,7 +183,12 @@ class Frame:
 
     def step(self):
         loss = self.loss_from(self.upstream())
-        loss.backward()
+        # dL/dloss = 1 from a persistent device scalar: `loss.backward()` alone makes autograd fill a fresh ones_like(loss) --
+        # one more kernel node per step (4.6 us of the captured step at C3, profiles/r04_bench_C3_kernel_stats.csv)
+        one = getattr(self, "_one", None)
+        if one is None or one.device != loss.device:
+            one = self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        loss.backward(one)
         return loss
 
 

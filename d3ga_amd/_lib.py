@@ -62,6 +62,7 @@ _SIGNATURES = {
     "d3ga_raster_preprocess_bwd": ([_prm] + [_vp] * 18 + [_vp], _i),
     "d3ga_raster_forward": ([_prm] + [_vp] * 14 + [_i64, _vp, _vp, _vp, _vp], _i),
     "d3ga_raster_backward": ([_prm] + [_vp] * 11 + [_i64] + [_vp] * 11 + [_vp], _i),
+    "d3ga_raster_composite_fwd_l1": ([_prm, _vp, _vp, _vp, _i64] + [_vp] * 7 + [_vp], _i),
     "d3ga_raster_composite_bwd_l1": ([_prm, _vp, _vp, _vp, _i64] + [_vp] * 7 + [_vp], _i),
     "d3ga_raster_backward_l1": ([_prm] + [_vp] * 11 + [_i64] + [_vp] * 15 + [_vp], _i),
     "d3ga_raster_recolor": ([_prm] + [_vp] * 6 + [_vp], _i),

@@ -52,6 +52,11 @@ static inline unsigned lds_pad_bytes(const void *kernel, const char *env_name) {
 // L1 image loss fused into the compositing backward: image (3,H,W) = the forward's colour output, target (or the device
 // cell that holds its address: graph.TensorSlot), g_loss = dL/dloss (device scalar), inv_n = 1 / (3 H W); image == null: off
 struct L1Source { const float *image, *target; const float *const *target_cell; const float *g_loss; float inv_n; };
+// L1 VALUE fused into the compositing forward (d3ga_raster_composite_fwd_l1): every quadrant wavefront leaves
+// sum |colour - target| * inv_n of its pixels in partials[4 * tile + quadrant]; partials == null: off
+struct L1Value { const float *target; const float *const *target_cell; float *partials; float inv_n; };
+// loss.hip: out[0] = sum of np partials, added in a fixed order by one workgroup
+void launch_sum_partials(int np, const float *partials, float *out, hipStream_t s);
 int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, const BinBuf &bin, const GeomBuf &g,
                               const ImgBuf &im, int64_t d_capacity, const float *bg, const float *dL_dpix, float *acc,
                               bool ordered, const float *colors2, const float *bg2, const float *dL_dpix2, const L1Source &l1,

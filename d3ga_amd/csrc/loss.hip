@@ -79,6 +79,31 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(int np, const floa
     }
 }
 
+// the same for many partials (one per quadrant of the compositing forward: 4 x tiles): 1024 threads, 16-byte loads
+__global__ __launch_bounds__(1024) void sum_partials_wide_kernel(int np, const float *__restrict__ partials, float *__restrict__ out) {
+    __shared__ float s_part[16];
+    float acc = 0.f;
+    const int np4 = np >> 2;
+    for (int i = threadIdx.x; i < np4; i += 1024) {
+        const float4 v = reinterpret_cast<const float4 *>(partials)[i];
+        acc += (v.x + v.y) + (v.z + v.w);
+    }
+    for (int i = 4 * np4 + threadIdx.x; i < np; i += 1024) acc += partials[i];
+    acc = wave_sum_loss(acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s_part[w];
+        out[0] = t;
+    }
+}
+void launch_sum_partials(int np, const float *partials, float *out, hipStream_t s) {
+    if (np > 4096) hipLaunchKernelGGL(sum_partials_wide_kernel, dim3(1), dim3(1024), 0, s, np, partials, out);
+    else hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, s, np, partials, out);
+}
+
 // (Round 3 also tried ONE launch -- the last workgroup to arrive, found through an arrival counter, adds the partials: the
 // ~2000 same-address counter atomics serialise at the memory side, 34 us against 10 + 4.6 us for the two launches; removed.)
 __global__ __launch_bounds__(kBlock) void l1_mean_bwd_kernel(int64_t n4, int64_t n, const float *__restrict__ a,

@@ -43,7 +43,8 @@ __device__ unsigned long long g_diag_fwd_waves[32768 * 4];    // per active wave
 // are shared, the second image costs three more FMAs per (pixel, entry).
 // DEPTH: the inverse-depth image of branch dr_aa is accumulated and written (the D3GA renderer uses the colour only:
 // renderer.py:141 takes [0]; without it the blend loop is one FMA per entry shorter and 4 B per pixel are not written)
-template <bool DUAL, bool DEPTH>
+// L1V: the L1 loss value against a target image is formed here as well (d3ga_raster_composite_fwd_l1; never with DUAL)
+template <bool DUAL, bool DEPTH, bool L1V>
 __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
     uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
@@ -51,9 +52,13 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
     float *__restrict__ out_invdepth, const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2,
     const float *__restrict__ bg2, float *__restrict__ out_color2, uint2 *__restrict__ blk_list,
-    uint32_t *__restrict__ blk_count, bool exact_cull) {
+    uint32_t *__restrict__ blk_count, bool exact_cull, L1Value l1v) {
     const Quad q = tile_order ? quad_of_block_ordered(gx, gx * gy, tile_order) : quad_of_block(gx, gy);
-    if (!q.valid || q.qx0 >= W || q.qy0 >= H) return;     // wave-uniform
+    if (!q.valid) return;                                 // wave-uniform
+    if (q.qx0 >= W || q.qy0 >= H) {                       // a quadrant without pixels: its L1 partial is zero
+        if (L1V && threadIdx.x == 0) l1v.partials[4 * (size_t)q.tile + q.quad] = 0.f;
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const RowGeom rg = row_geom(q, lane);
     const bool inside = rg.px < W && rg.py < H;
@@ -62,6 +67,16 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     const uint32_t begin = (uint32_t)min((uint64_t)tile_start[q.tile], dcap);
     const uint32_t end = (uint32_t)min((uint64_t)tile_start[q.tile + 1], dcap);
     const uint32_t blk_cap = end - begin;
+    // fused L1 value: the target's pixel is requested NOW and used after the blend loop.  (Measured at C3: the launch grows
+    // from 73.8 to 80.6 us, the separate pass it replaces took 10.3 us.  Letting quadrant 0 of an EMPTY tile -- 27 000 of the
+    // 32 640 quadrants of an avatar frame -- take the whole tile with 16-byte loads: 86.7 us, slower; loads at the end of the
+    // wavefront instead of here: the same.)
+    float tg0 = 0.f, tg1 = 0.f, tg2 = 0.f;
+    if (L1V && inside) {
+        const float *tg = l1v.target_cell ? *l1v.target_cell : l1v.target;
+        const size_t pid = (size_t)rg.py * W + rg.px, hw = (size_t)H * W;
+        tg0 = tg[pid]; tg1 = tg[hw + pid]; tg2 = tg[2 * hw + pid];
+    }
     uint2 *const blk_base = blk_list ? blk_list + 16 * (size_t)begin + (size_t)(4 * q.quad) * blk_cap : nullptr;
     uint32_t bc0 = 0, bc1 = 0, bc2 = 0, bc3 = 0;
 
@@ -264,6 +279,14 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
 #endif
         if (all_done) break;
     }
+    if constexpr (L1V) {
+        // fused L1 value (d3ga_raster_composite_fwd_l1): every quadrant leaves sum |colour - target| / n of its pixels; the
+        // launcher's second kernel adds the partials in index order (reproducible), no pass over the finished image
+        float d = inside ? fabsf(C0 + T * bg[0] - tg0) + fabsf(C1 + T * bg[1] - tg1) + fabsf(C2 + T * bg[2] - tg2) : 0.f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off);
+        if (lane == 0) l1v.partials[4 * (size_t)q.tile + q.quad] = d * l1v.inv_n;
+    }
     if (inside) {
         const size_t pid = (size_t)rg.py * W + rg.px;
         const size_t hw = (size_t)H * W;
@@ -346,9 +369,10 @@ extern "C" int d3ga_diag_fwd_read(unsigned long long *out8, unsigned long long *
 }
 #endif
 
+static const L1Value kNoL1Value = {nullptr, nullptr, nullptr, 0.f};
 static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, void *img, float *out_color, float *out_invdepth, const float *colors2,
-                              const float *bg2, float *out_color2, d3ga_stream_t stream) {
+                              const float *bg2, float *out_color2, d3ga_stream_t stream, const L1Value &l1v = kNoL1Value) {
     if (!prm || !bg || !geom || !binning || !img || !out_color) return D3GA_E_NULL;
     if (prm->P < 0 || prm->W <= 0 || prm->H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
     if (colors2 && (!bg2 || !out_color2)) return D3GA_E_NULL;
@@ -361,13 +385,15 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
     const bool ordered = (composite_variant() & kVariantOrdered) != 0, exact = (composite_variant() & kVariantExactCull) != 0;
     const dim3 grid(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy));
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
-#define D3GA_LAUNCH_FWD(DUALV, DEPTHV)                                                                                          \
-    hipLaunchKernelGGL((composite_fwd_q_kernel<DUALV, DEPTHV>), grid, dim3(64),                                                     \
-                       lds_pad_bytes((const void *)composite_fwd_q_kernel<DUALV, DEPTHV>, "D3GA_FWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
+#define D3GA_LAUNCH_FWD(DUALV, DEPTHV, L1VV)                                                                                    \
+    hipLaunchKernelGGL((composite_fwd_q_kernel<DUALV, DEPTHV, L1VV>), grid, dim3(64),                                               \
+                       lds_pad_bytes((const void *)composite_fwd_q_kernel<DUALV, DEPTHV, L1VV>, "D3GA_FWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
                        bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,     \
-                       out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact)
-    if (colors2) { if (out_invdepth) D3GA_LAUNCH_FWD(true, true); else D3GA_LAUNCH_FWD(true, false); }
-    else { if (out_invdepth) D3GA_LAUNCH_FWD(false, true); else D3GA_LAUNCH_FWD(false, false); }
+                       out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact, l1v)
+    if (colors2 && l1v.partials) return D3GA_E_CONFIG;
+    if (colors2) { if (out_invdepth) D3GA_LAUNCH_FWD(true, true, false); else D3GA_LAUNCH_FWD(true, false, false); }
+    else if (l1v.partials) { if (out_invdepth) D3GA_LAUNCH_FWD(false, true, true); else D3GA_LAUNCH_FWD(false, false, true); }
+    else { if (out_invdepth) D3GA_LAUNCH_FWD(false, true, false); else D3GA_LAUNCH_FWD(false, false, false); }
 #undef D3GA_LAUNCH_FWD
     return check_launch(s, prm->debug);
 }
@@ -376,6 +402,19 @@ extern "C" int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const fl
                                          const void *binning, int64_t d_capacity, void *img, float *out_color,
                                          float *out_invdepth, d3ga_stream_t stream) {
     return composite_fwd_impl(prm, bg, geom, binning, d_capacity, img, out_color, out_invdepth, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int d3ga_raster_composite_fwd_l1(const d3ga_raster_params *prm, const float *bg, const void *geom,
+                                            const void *binning, int64_t d_capacity, void *img, float *out_color,
+                                            float *out_invdepth, const float *target, const void *target_cell,
+                                            float *loss, float *partials, d3ga_stream_t stream) {
+    if (!prm || !loss || !partials || (!target && !target_cell)) return D3GA_E_NULL;
+    if (prm->W <= 0 || prm->H <= 0) return D3GA_E_SIZE;
+    const L1Value l1v = {target, (const float *const *)target_cell, partials, 1.0f / (3.0f * (float)prm->W * (float)prm->H)};
+    D3GA_TRY(composite_fwd_impl(prm, bg, geom, binning, d_capacity, img, out_color, out_invdepth, nullptr, nullptr, nullptr,
+                                stream, l1v));
+    launch_sum_partials(4 * tiles_x(prm->W) * tiles_y(prm->H), partials, loss, (hipStream_t)stream);
+    return check_launch((hipStream_t)stream, prm->debug);
 }
 
 extern "C" int d3ga_raster_composite_fwd2(const d3ga_raster_params *prm, const float *bg, const float *bg2, const void *geom,

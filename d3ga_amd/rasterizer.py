@@ -14,6 +14,7 @@ reading `num_rendered`) and the call is repeated with a larger buffer in the rar
 ``set_capacity_policy("static", n)`` nothing is read back (graph-capturable; caller checks `last_counters()`).
 """
 import ctypes
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -76,6 +77,10 @@ def set_accumulator_policy(mode):
     _acc_policy["persistent"] = mode == "persistent"
     if mode == "fresh":
         _acc_cache.clear()
+
+
+# D3GA_L1_VALUE=separate: the L1 value from its own pass over the finished image (rounds 1-3; kept for A/B runs)
+_l1_policy = {"fused_value": os.environ.get("D3GA_L1_VALUE", "fused") != "separate"}
 
 
 def l1_mean_forward(image, target, cell, out, dev):
@@ -262,6 +267,28 @@ class _RasterizeGaussians(torch.autograd.Function):
                            debug=int(bool(s.debug)), opacity_activation=_ACTIVATIONS[opacity_activation],
                            forward_only=int(fwd_only))
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        # fused L1 image loss (rasterize_gaussians_l1): the loss VALUE is formed by the compositing forward while the colours
+        # are in registers (d3ga_raster_composite_fwd_l1: one partial per quadrant, then one small sum), its gradient inside
+        # the compositing backward (d3ga_raster_backward_l1): no pass over the image, no (3,H,W) gradient image
+        l1_t = l1_cell = loss = None
+        if l1_target is not None:
+            from .graph import TensorSlot
+            l1_t = l1_target.current if isinstance(l1_target, TensorSlot) else _f32(l1_target, dev)
+            l1_cell = l1_target.cell if isinstance(l1_target, TensorSlot) else None
+            if tuple(l1_t.shape) != (3, H, W):
+                raise ValueError(f"rasterize_gaussians_l1: the target must be (3, {H}, {W}), got {tuple(l1_t.shape)}")
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+        l1_in_fwd = l1_target is not None and P > 0 and colors2 is None and _l1_policy["fused_value"]
+
+        def composite_fwd_single(L, pp, geom, binning, cap, img, st):
+            if l1_in_fwd:
+                ws = torch.empty(4 * ((W + 15) // 16) * ((H + 15) // 16), dtype=torch.float32, device=dev)
+                check(L.d3ga_raster_composite_fwd_l1(pp, dptr(bg), dptr(geom), dptr(binning), cap, dptr(img), dptr(color),
+                                                     dptr(invdepth), dptr(None if l1_cell is not None else l1_t), dptr(l1_cell),
+                                                     dptr(loss), dptr(ws), st), "d3ga_raster_composite_fwd_l1")
+            else:
+                check(L.d3ga_raster_composite_fwd(pp, dptr(bg), dptr(geom), dptr(binning), cap, dptr(img), dptr(color),
+                                                  dptr(invdepth), st), "d3ga_raster_composite_fwd")
         # the inverse-depth image of branch dr_aa: on request only (renderer.render* use the colour alone, renderer.py:141)
         invdepth = torch.empty((1, H, W), dtype=torch.float32, device=dev) if want_invdepth else None
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
@@ -280,15 +307,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             stage_timer.stage("recolor", lambda: check(L.d3ga_raster_recolor(
                 pp, dptr(means3D), dptr(sh), dptr(colors_precomp), dptr(campos), dptr(hit["geom"]), dptr(geom), st),
                 "d3ga_raster_recolor"))
-            stage_timer.stage("composite_fwd", lambda: check(L.d3ga_raster_composite_fwd(
-                pp, dptr(bg), dptr(geom), dptr(binning), cap, dptr(img), dptr(color), dptr(invdepth), st),
-                "d3ga_raster_composite_fwd"))
+            stage_timer.stage("composite_fwd", lambda: composite_fwd_single(L, pp, geom, binning, cap, img, st))
             _last[dev.index] = (binning, cap)
             if _capture_log is not None:
                 _capture_log.append((binning, cap))
         while hit is None or hit["key"] != key:
             geom, binning, img = _scratch(P, W, H, cap, dev, fwd_only)
-            if stage_timer.enabled or dual:
+            if stage_timer.enabled or dual or l1_in_fwd:
                 st, pp = stream_handle(), ctypes.byref(prm)
                 stage_timer.stage("preprocess", lambda: check(L.d3ga_raster_preprocess(
                     pp, dptr(means3D), dptr(sh), dptr(colors_precomp), dptr(opacities), dptr(scales), dptr(rotations),
@@ -301,9 +326,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                         pp, dptr(bg), dptr(bg2), dptr(geom), dptr(colors2), dptr(binning), cap, dptr(img), dptr(color),
                         dptr(color2), dptr(invdepth), st), "d3ga_raster_composite_fwd2"))
                 else:
-                    stage_timer.stage("composite_fwd", lambda: check(L.d3ga_raster_composite_fwd(
-                        pp, dptr(bg), dptr(geom), dptr(binning), cap, dptr(img), dptr(color), dptr(invdepth), st),
-                        "d3ga_raster_composite_fwd"))
+                    stage_timer.stage("composite_fwd", lambda: composite_fwd_single(L, pp, geom, binning, cap, img, st))
             else:
                 check(L.d3ga_raster_forward(ctypes.byref(prm), dptr(means3D), dptr(sh), dptr(colors_precomp),
                                             dptr(opacities), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp),
@@ -334,17 +357,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_sync.verify_inputs({"means3D": means3D, "opacities": opacities, "colors_precomp": colors_precomp,
                                      "shs": sh, "cov3D_precomp": cov3Ds_precomp, "scales": scales, "rotations": rotations})
         ctx.dual = dual
-        # fused L1 image loss (rasterize_gaussians_l1): the loss VALUE is one reduction kernel over the image; its gradient is
-        # formed inside the compositing backward (d3ga_raster_backward_l1), no (3,H,W) gradient image is written or read
         ctx.l1 = l1_target is not None and P > 0 and not dual
-        l1_t = l1_cell = loss = None
-        if l1_target is not None:
-            from .graph import TensorSlot
-            l1_t = l1_target.current if isinstance(l1_target, TensorSlot) else _f32(l1_target, dev)
-            l1_cell = l1_target.cell if isinstance(l1_target, TensorSlot) else None
-            if tuple(l1_t.shape) != (3, H, W):
-                raise ValueError(f"rasterize_gaussians_l1: the target must be (3, {H}, {W}), got {tuple(l1_t.shape)}")
-            loss = torch.empty((), dtype=torch.float32, device=dev)
+        if l1_target is not None and not l1_in_fwd:      # P == 0 (the image is its background) or D3GA_L1_VALUE=separate
             l1_mean_forward(color, l1_t, l1_cell, loss, dev)
         _last_img[dev.index] = (img, W, H, geom, P)
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, view, proj, campos, bg, geom, binning, img,

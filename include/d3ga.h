@@ -207,6 +207,13 @@ int d3ga_raster_composite_bwd2(const d3ga_raster_params *prm, const float *bg, c
  * when given, else NULL) per pixel, instead of reading a (3,H,W) gradient image that a separate kernel had to write.
  * image = the forward's out_color; target (3,H,W), or target_cell = device cell holding its address (graph.TensorSlot);
  * g_loss = dL/dloss (device scalar).  d3ga_raster_backward_l1 = clear + this + d3ga_raster_preprocess_bwd. */
+/* ... and its VALUE fused into the compositing forward (round 4): d3ga_raster_composite_fwd plus loss[0] = mean |out_color -
+ * target|.  Every quadrant wavefront adds |colour - target| of its 64 pixels while the colours are still in registers and
+ * leaves one partial (partials: at least 4 * ceil(W/16) * ceil(H/16) floats, scratch); a second one-workgroup kernel adds the
+ * partials in index order (bit-reproducible).  Replaces the pass over the finished image (d3ga_l1_mean_fwd_ws). */
+int d3ga_raster_composite_fwd_l1(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
+                                 int64_t d_capacity, void *img, float *out_color, float *out_invdepth, const float *target,
+                                 const void *target_cell, float *loss, float *partials, d3ga_stream_t stream);
 int d3ga_raster_composite_bwd_l1(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                                  int64_t d_capacity, const void *img, const float *image, const float *target,
                                  const void *target_cell, const float *g_loss, const float *dL_dpix, float *acc,

@@ -19,7 +19,7 @@ if not f:
 rows = list(csv.DictReader(open(f[0])))
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 print("==", name)
-for r in rows[:14]:
+for r in rows[:22]:
     print(f'{r["Name"][:70]:70s} calls {r["Calls"]:>5s} avg_us {float(r["AverageNs"])/1e3:8.2f} total_ms {float(r["TotalDurationNs"])/1e6:8.3f}')
 PY
 done
