@@ -494,6 +494,15 @@ static double noise_sign(int slot, int pattern) {
     return (h & 1u) ? 1.0 : -1.0;
 }
 
+/* pattern >= 1000: ONE of the 13 perturbed quantities of a Gaussian at a time (kind = pattern - 1000: the four dL/dconic sums,
+ * three colour sums, two mean2D sums, the opacity sum, the three cov2D entries), sign +1 -- the chain behind the sums is
+ * per Gaussian and first-order linear in these, so the sum over the 13 kinds of |effect| is the effect of the WORST sign
+ * combination (tests/util.py: conditioning_noise); a handful of random patterns only samples it. */
+static double noise_sign_k(int kind, int slot, int pattern) {
+    if (pattern >= 1000) return pattern - 1000 == kind ? 1.0 : 0.0;
+    return noise_sign(slot, pattern);
+}
+
 /* Backward.  dL_dpix (3,H,W).  All outputs must be zero-initialised by the caller; NULL where not applicable. */
 void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const float *scales, const float *rots,
                  const float *dL_dpix, float *dL_dmeans3D, float *dL_dmeans2D /*P,3*/, float *dL_dsh,
@@ -589,10 +598,10 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
      * the conic -> cov2D step cancels again).  gamma = 0: off. */
     if (probe) {
         for (int i = 0; i < P; i++) {
-            for (int k = 0; k < 4; k++) dL_dconic[4 * i + k] += g_sum_noise_sigma * ab_conic[4 * i + k] * noise_sign(4 * i + k, g_sum_noise_pattern);
-            for (int k = 0; k < 3; k++) dL_drgb[3 * i + k] += g_sum_noise_sigma * ab_rgb[3 * i + k] * noise_sign(3 * i + k + 101, g_sum_noise_pattern);
-            for (int k = 0; k < 2; k++) dL_dm2[2 * i + k] += g_sum_noise_sigma * ab_m2[2 * i + k] * noise_sign(2 * i + k + 202, g_sum_noise_pattern);
-            dL_dop[i] += g_sum_noise_sigma * ab_op[i] * noise_sign(i + 303, g_sum_noise_pattern);
+            for (int k = 0; k < 4; k++) dL_dconic[4 * i + k] += g_sum_noise_sigma * ab_conic[4 * i + k] * noise_sign_k(k, 4 * i + k, g_sum_noise_pattern);
+            for (int k = 0; k < 3; k++) dL_drgb[3 * i + k] += g_sum_noise_sigma * ab_rgb[3 * i + k] * noise_sign_k(4 + k, 3 * i + k + 101, g_sum_noise_pattern);
+            for (int k = 0; k < 2; k++) dL_dm2[2 * i + k] += g_sum_noise_sigma * ab_m2[2 * i + k] * noise_sign_k(7 + k, 2 * i + k + 202, g_sum_noise_pattern);
+            dL_dop[i] += g_sum_noise_sigma * ab_op[i] * noise_sign_k(9, i + 303, g_sum_noise_pattern);
         }
     }
     free(ab_conic); free(ab_rgb); free(ab_m2); free(ab_op);
@@ -624,9 +633,9 @@ void ro_backward(const ro_ctx *c, const float *means3D, const float *shs, const 
                  * step behind them -- d conic / d cov2D, written with (denom - a c) = -b^2 as upstream writes it -- cancels
                  * catastrophically for a splat hundreds of pixels wide (a c ~ 1e8 against b^2): two float32 evaluations of
                  * this chain that round differently disagree by what this perturbation shows */
-                a *= 1.0f + 2.4e-7f * (float)noise_sign(7 * i + 1, g_sum_noise_pattern);
-                b *= 1.0f + 2.4e-7f * (float)noise_sign(7 * i + 2, g_sum_noise_pattern);
-                cc *= 1.0f + 2.4e-7f * (float)noise_sign(7 * i + 3, g_sum_noise_pattern);
+                a *= 1.0f + 2.4e-7f * (float)noise_sign_k(10, 7 * i + 1, g_sum_noise_pattern);
+                b *= 1.0f + 2.4e-7f * (float)noise_sign_k(11, 7 * i + 2, g_sum_noise_pattern);
+                cc *= 1.0f + 2.4e-7f * (float)noise_sign_k(12, 7 * i + 3, g_sum_noise_pattern);
             }
             float denom = a * cc - b * b;
             float d2inv = 1.0f / ((denom * denom) + 0.0000001f);

@@ -1,6 +1,11 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -q -x -k "l1 or L1" 2>&1 | tail -8
-bash tools/gpu_kstats.sh "fused:D3GA_X=0" 2>&1 | grep -E "^==|composite_fwd|sum_partials|l1_mean"
-BENCH_ARGS="" bash tools/gpu_ab_env.sh "fused:D3GA_X=0 separate:D3GA_L1_VALUE=separate" 2>&1 | tail -12 | cut -c1-220
+: > gpurun_out/fuzz50_loop.log
+for i in $(seq 1 40); do
+  D3GA_FUZZ_SCENE=C1 D3GA_FUZZ_N=200 timeout 300 python -m pytest tests -m gpu -q -x --tb=short -k "fuzz_ragged and (49] or 50])" > gpurun_out/fuzz50_one.log 2>&1
+  if grep -q "failed" gpurun_out/fuzz50_one.log; then echo "== run $i FAILED" >> gpurun_out/fuzz50_loop.log; grep -v "^\.\.\.\." gpurun_out/fuzz50_one.log | tail -40 >> gpurun_out/fuzz50_loop.log; else echo "run $i ok" >> gpurun_out/fuzz50_loop.log; fi
+done
+tail -50 gpurun_out/fuzz50_loop.log
+
+
