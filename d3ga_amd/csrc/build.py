@@ -7,15 +7,21 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["deform.hip", "raster_pre.hip", "raster_bin.hip", "raster_composite.hip", "raster_composite_scan.hip", "raster_api.hip", "bary.hip", "loss.hip", "mlp.hip", "encoding.hip"]
 HEADERS = ["d3ga_math.h", "d3ga_internal.h", "raster_pre_body.h", "composite_common.h", os.path.join("..", "..", "include", "d3ga.h")]
 ABL = os.environ.get("D3GA_SCAN_ABL")       # timing ablation of the compositing backward (wrong results): own objects + .so
-DIAG = os.environ.get("D3GA_DIAG") or (("abl" + ABL) if ABL else None)          # diagnostic build: its own objects and its own .so (D3GA_LIB_PATH selects it)
+VARIANT = os.environ.get("D3GA_VARIANT")    # A/B build of compile-time knobs: "tag:-DNAME=value,-DOTHER=value" -> tools/_build/libd3ga_hip_<tag>.so (correct results)
+DIAG = os.environ.get("D3GA_DIAG") or (("abl" + ABL) if ABL else None) or (("var" + VARIANT.split(":")[0]) if VARIANT else None)          # diagnostic build: its own objects and its own .so (D3GA_LIB_PATH selects it)
 # Diagnostic / ablation builds never land in the package directory: tools/_build/ (git-ignored, travels with gpurun).
 # _lib.py refuses an ablation build (d3ga_debug_defaults()[0] != 0: WRONG results by design) unless D3GA_ALLOW_ABLATION=1.
 DIAG_DIR = os.path.abspath(os.path.join(HERE, "..", "..", "tools", "_build"))
-_DIAG_TAG = "diag" if os.environ.get("D3GA_DIAG") in (None, "counters") else os.environ["D3GA_DIAG"]
+_DIAG_TAG = (VARIANT.split(":")[0] if (VARIANT and not os.environ.get("D3GA_DIAG") and not ABL) else
+             "diag" if os.environ.get("D3GA_DIAG") in (None, "counters") else os.environ["D3GA_DIAG"])
+if VARIANT:
+    FLAGS_VARIANT = [f for f in VARIANT.split(":", 1)[1].split(",") if f]
+else:
+    FLAGS_VARIANT = []
 OUT = (os.path.join(DIAG_DIR, f"libd3ga_hip_abl{ABL}.so" if ABL else f"libd3ga_hip_{_DIAG_TAG}.so") if DIAG
        else os.path.join(HERE, "..", "libd3ga_hip.so"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + FLAGS_VARIANT
 # per-source extras.  The entry-per-lane compositing backward is VALU-issue bound; SLP-packing its scalar f32 chains into
 # v_pk_* costs ~35 register shuffles per 4 pixels (ISA inspected) and a v_pk_fma_f32 issues in 4.2 cycles against 2.4 for a
 # v_fma_f32 (tools/micro/valu_issue.hip), so the vectoriser is off for the two compositing files.

@@ -74,15 +74,24 @@ __device__ __forceinline__ void sh_rows48_store(const float *slab, float *__rest
     }
 }
 
-// forward staging (see preprocess_kernel): half of a wavefront's rows at a time
-constexpr int kShHalfSlab = 32 * kShRow;
-constexpr size_t kShHalfLdsBytes = (size_t)(kBlock / 64) * kShHalfSlab * sizeof(float);      // 26,624 B per block
+// forward staging (see preprocess_kernel): kShPassRows of a wavefront's 64 rows at a time
+#ifndef D3GA_SH_PASS_ROWS
+#define D3GA_SH_PASS_ROWS 32
+#endif
+constexpr int kShPassRows = D3GA_SH_PASS_ROWS;                  // 32: two passes (default), 16: four (measured, slower: below)
+constexpr int kShPasses = 64 / kShPassRows;
+constexpr int kShHalfSlab = kShPassRows * kShRow;
+constexpr size_t kShHalfLdsBytes = (size_t)(kBlock / 64) * kShHalfSlab * sizeof(float);      // 26,624 B per block (32 rows)
 
 // sum_k Y_k(dir_i) * coeff_k of this thread's Gaussian, with the (P,M,3) block read through wavefront-private LDS.
-// SH colour in two passes over HALF THE ROWS of the wavefront (rows 0..31, then 32..63; full 192-byte rows, so every
-// byte is fetched once): the slab of a wavefront is 32 x 52 floats = 6.5 KiB instead of 13 KiB, which lifts the kernels
-// from 12 to 20 resident wavefronts per CU.  Only wavefront-private LDS is touched: no workgroup barrier, program order
-// + wave_barrier suffice.  Every thread of the block must call it (s_sh: kShHalfLdsBytes of LDS).
+// SH colour in PASSES over a part of the wavefront's rows (full 192-byte rows, so every byte is fetched once): the slab of
+// a wavefront is kShPassRows x 52 floats -- 13 KiB for all 64 rows (12 resident wavefronts per CU), 6.5 KiB for 32 (20: the
+// default).  Round 4 measured 16 rows per pass (3.3 KiB: the tile window's 16 KiB is then the block's LDS, 28 wavefronts per
+// CU, the launch's 1954 workgroups in 1.09 instead of 1.53 rounds): with all four quarters in flight the registers hold the
+// kernel at 20 wavefronts anyway (88 VGPRs); with two in flight (68 VGPRs, 28 wavefronts) preprocess takes 61-65 us against
+// 55.6 (eager stage events, same box) -- the second memory round trip per wavefront and a quarter of the lanes per
+// accumulate pass cost more than the occupancy returns.  Only wavefront-private LDS is touched: no workgroup barrier,
+// program order + wave_barrier suffice.  Every thread of the block must call it.
 __device__ __forceinline__ void staged_sh_colour(const d3ga_raster_params &prm, const float *__restrict__ means3D,
                                                  const float *__restrict__ shs, const float *__restrict__ campos,
                                                  float *s_sh, float acc[3]) {
@@ -95,27 +104,42 @@ __device__ __forceinline__ void staged_sh_colour(const d3ga_raster_params &prm, 
     const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
     float B[16];
     if (M3 == 48 && rows == 64) {                              // wave-uniform: a full wavefront of full rows
-        // both halves' loads are issued up front (the second half waits in registers while the first is evaluated)
-        const ShRegs<32> h0 = sh_rows48_load<32>(shs + (size_t)48 * row0, lane);
-        const ShRegs<32> h1 = sh_rows48_load<32>(shs + (size_t)48 * (row0 + 32), lane);
-        sh_view_basis(prm, means3D, i, campos, B);
-        __builtin_amdgcn_wave_barrier();
-        sh_rows48_to_slab<32>(slab, h0, lane);
-        __builtin_amdgcn_wave_barrier();
-        if ((lane >> 5) == 0) sh_accumulate(B, slab + (lane & 31) * kShRow, 0, 16, nb, acc);
-        __builtin_amdgcn_wave_barrier();
-        sh_rows48_to_slab<32>(slab, h1, lane);
-        __builtin_amdgcn_wave_barrier();
-        if ((lane >> 5) == 1) sh_accumulate(B, slab + (lane & 31) * kShRow, 0, 16, nb, acc);
+        const float *src = shs + (size_t)48 * row0;
+        auto pass = [&](const ShRegs<kShPassRows> &h, int p) {
+            __builtin_amdgcn_wave_barrier();
+            sh_rows48_to_slab<kShPassRows>(slab, h, lane);
+            __builtin_amdgcn_wave_barrier();
+            if (lane / kShPassRows == p) sh_accumulate(B, slab + (lane % kShPassRows) * kShRow, 0, 16, nb, acc);
+        };
+        if constexpr (kShPasses == 2) {
+            // both halves' loads are issued up front (the second half waits in registers while the first is evaluated)
+            const ShRegs<kShPassRows> h0 = sh_rows48_load<kShPassRows>(src, lane);
+            const ShRegs<kShPassRows> h1 = sh_rows48_load<kShPassRows>(src + 48 * kShPassRows, lane);
+            sh_view_basis(prm, means3D, i, campos, B);
+            pass(h0, 0);
+            pass(h1, 1);
+        } else {
+            static_assert(kShPasses == 2 || kShPasses == 4, "two or four passes");
+            // two quarters' loads in flight at a time: quarter p + 2 is requested when quarter p has been evaluated
+            const ShRegs<kShPassRows> h0 = sh_rows48_load<kShPassRows>(src, lane);
+            const ShRegs<kShPassRows> h1 = sh_rows48_load<kShPassRows>(src + 48 * kShPassRows, lane);
+            sh_view_basis(prm, means3D, i, campos, B);
+            pass(h0, 0);
+            const ShRegs<kShPassRows> h2 = sh_rows48_load<kShPassRows>(src + 48 * kShPassRows * 2, lane);
+            pass(h1, 1);
+            const ShRegs<kShPassRows> h3 = sh_rows48_load<kShPassRows>(src + 48 * kShPassRows * 3, lane);
+            pass(h2, 2);
+            pass(h3, 3);
+        }
         return;
     }
     if (i < prm.P) sh_view_basis(prm, means3D, i, campos, B);
-    for (int h = 0; h < 2; ++h) {
-        const int r = min(32, rows - 32 * h);
+    for (int h = 0; h < kShPasses; ++h) {
+        const int r = min(kShPassRows, rows - kShPassRows * h);
         __builtin_amdgcn_wave_barrier();
-        if (r > 0) sh_slab_load(slab, shs + (size_t)M3 * (row0 + 32 * h), r, M3, lane);
+        if (r > 0) sh_slab_load(slab, shs + (size_t)M3 * (row0 + kShPassRows * h), r, M3, lane);
         __builtin_amdgcn_wave_barrier();
-        if (i < prm.P && (lane >> 5) == h) sh_accumulate(B, slab + (lane & 31) * kShRow, 0, 16, nb, acc);
+        if (i < prm.P && lane / kShPassRows == h) sh_accumulate(B, slab + (lane % kShPassRows) * kShRow, 0, 16, nb, acc);
     }
 }
 
