@@ -78,6 +78,9 @@ def parse():
                     help="sensitivity: multiply the Gaussians' world-space scales (D/P grows ~quadratically)")
     ap.add_argument("--fill", type=float, default=0.85,
                     help="sensitivity: fraction of the image height the 1.8 m body fills (0.85 = SURVEY sec. 8d recipe)")
+    ap.add_argument("--gaussian-order", choices=("tet", "random", "morton"), default="tet",
+                    help="sensitivity: 'random' = the scene's Gaussians in random index order (default: numbered by tetrahedron); "
+                         "'morton' = that random order numbered again by d3ga_amd.tetra.spatial_order")
     ap.add_argument("--views-per-rank", type=int, default=1,
                     help="N>1 (or --force-cut): every rank renders k views of the pose per step and the gradients of all of them leave "
                          "in ONE exchange (the deform runs once per rank and step); value counts N x k frames per step")
@@ -99,11 +102,16 @@ def parse():
 class Frame:
     """Avatar parameters + one camera, resident on the device."""
 
-    def __init__(self, wl_name, dev, view_index, n_views=8, scale_mult=1.0, fill=0.85):
+    def __init__(self, wl_name, dev, view_index, n_views=8, scale_mult=1.0, fill=0.85, order="tet"):
         from d3ga_amd import synthetic as syn
         from d3ga_amd.cage_deform import canonical_gradient
         self.syn = syn
         sc = syn.make_scene(wl_name)
+        if order in ("random", "morton"):
+            sc = syn.permute_gaussians(sc)
+        if order == "morton":                   # ... and numbered again along a Z-order curve (tetra.spatial_order): the remedy
+            from d3ga_amd.tetra import spatial_order
+            sc = syn.reorder_gaussians(sc, spatial_order(syn.canonical_centres(sc)))
         self.wl = sc["workload"]
         d = lambda t: t.to(dev)
         self.canon, self.tetras, self.tetra_id = d(sc["canon_points"]), d(sc["tetras"]), d(sc["tetra_id"])
@@ -881,7 +889,7 @@ def main():
 
     if args.pmc and world == 1:
         collect_pmc(args)
-    frame = Frame(args.workload, dev, view_index=rank % 8, scale_mult=args.scale_mult, fill=args.fill)
+    frame = Frame(args.workload, dev, view_index=rank % 8, scale_mult=args.scale_mult, fill=args.fill, order=args.gaussian_order)
     frame.fused_l1 = not args.no_fused_l1
     kv = max(int(args.views_per_rank), 1)
     if kv > 1:
@@ -1373,7 +1381,9 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.name + ("" if (args.scale_mult == 1.0 and args.fill == 0.85) else
-                                              f" [sensitivity: scales x{args.scale_mult:g}, body fills {args.fill:g} of the image height]"),
+                                              f" [sensitivity: scales x{args.scale_mult:g}, body fills {args.fill:g} of the image height]")
+                                   + {"tet": "", "random": " [sensitivity: Gaussians in random index order]",
+                                      "morton": " [sensitivity: Gaussians shuffled, then numbered by tetra.spatial_order]"}[args.gaussian_order],
                        "gaussians": P, "width": W, "height": H, "sh_degree": wl.sh_degree,
                        "duplicates_D": D, "max_tile_list": cnt_end["max_tile"], "visible": cnt_end["visible"],
                        "views_per_step": world * kv, "views_per_rank": kv, "parallelism": f"camera-sharded dp{world}",

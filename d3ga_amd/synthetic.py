@@ -144,6 +144,34 @@ def make_batch(width, height, azimuth=0.0, dist=3.0, fill=0.85, body_h=1.8, fram
     }
 
 
+PER_GAUSSIAN = ("tetra_id", "barys", "scaling", "rotation", "opacity_logit", "features_dc", "features_rest", "rgb")
+
+
+def permute_gaussians(sc, seed=5):
+    """The same scene with its Gaussians in RANDOM index order.  make_scene() numbers them by tetrahedron (spatially coherent
+    blocks of 256); the reference takes the order of its initial point cloud (`compute_bary(init_points, ...)`, lib/cage.py:325,
+    and appends on densification, utils/geometry.py:107) -- coherent along the template mesh, not sorted.  A random order is the
+    worst case for everything that works on blocks of consecutive Gaussians (bench.py --gaussian-order random)."""
+    perm = torch.from_numpy(np.random.default_rng(seed).permutation(sc["tetra_id"].shape[0]))
+    out = dict(sc)
+    for k in PER_GAUSSIAN:
+        out[k] = sc[k][perm].contiguous()
+    return out
+
+
+def reorder_gaussians(sc, order):
+    out = dict(sc)
+    for k in PER_GAUSSIAN:
+        out[k] = sc[k][order].contiguous()
+    return out
+
+
+def canonical_centres(sc):
+    """(P,3) canonical positions of the Gaussians: barycentric mean of their tetrahedron's canonical corners."""
+    corners = sc["canon_points"][sc["tetras"].long()[sc["tetra_id"].long()]]           # (P,4,3)
+    return (corners * sc["barys"][:, :, None]).sum(1)
+
+
 def make_scene(wl, seed=17):
     """Returns a dict of CPU tensors describing one avatar: cages, skinning, Gaussians."""
     if isinstance(wl, str):

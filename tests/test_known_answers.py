@@ -259,3 +259,25 @@ def test_hip_backward_matches_finite_differences_of_hip_forward():
             assert abs(float(fd - an)) <= tol, (k, trial, float(fd), float(an), tol)
             if trial < 2:
                 assert eps_loss / h < 0.1 * abs(float(an)), "the aligned trials must be dominated by the relative bar"
+
+
+def test_spatial_order_is_a_permutation_along_a_z_curve():
+    """tetra.spatial_order: a permutation; points of one octant of the bounding box are numbered consecutively (the top three
+    bits of the Morton code are the octant), ties keep their input order, degenerate inputs are accepted."""
+    import torch
+    from d3ga_amd.tetra import spatial_order
+    g = torch.Generator().manual_seed(3)
+    pts = torch.rand(5000, 3, generator=g) * torch.tensor([2.0, 0.5, 1.0]) - 0.3
+    order = spatial_order(pts)
+    assert sorted(order.tolist()) == list(range(5000))
+    lo, hi = pts.amin(0), pts.amax(0)
+    octant = (((pts - lo) / (hi - lo) * 1023).round().long() >> 9)          # top bit per axis
+    o = (octant[:, 0] + 2 * octant[:, 1] + 4 * octant[:, 2])[order]
+    assert bool((o[1:] >= o[:-1]).all())
+    # neighbours in the new numbering are close: mean distance between consecutive points far below the random order's
+    d_new = (pts[order][1:] - pts[order][:-1]).norm(dim=1).mean()
+    d_old = (pts[1:] - pts[:-1]).norm(dim=1).mean()
+    assert float(d_new) < 0.2 * float(d_old)
+    same = torch.zeros(7, 3)
+    assert spatial_order(same).tolist() == list(range(7))                  # all codes equal: stable
+    assert spatial_order(torch.zeros(0, 3)).numel() == 0

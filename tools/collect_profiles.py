@@ -26,7 +26,7 @@ if os.path.exists(b) and os.path.getsize(b) > 10:
 pj = os.path.join(ROOT, "gpurun_out", f"pmc_{wl}.json")          # written by `bench.py --pmc` on the GPU box (tools/gpu_evidence.sh)
 if os.path.exists(pj):       # ONE tracked copy per round (bench.py reads the newest rNN_pmc_<wl>.json; it carries the library's sha256)
     shutil.copy(pj, os.path.join(ROOT, "profiles", f"{tag}_pmc_{wl}.json"))
-for name in ("C3_s2", "C3_s4", "C3_fill"):                       # sensitivity lines
+for name in ("C3_s2", "C3_s4", "C3_fill", "C3_random", "C3_morton"):                       # sensitivity lines
     b = os.path.join(ROOT, "gpurun_out", f"bench_{name}.log")
     if os.path.exists(b) and os.path.getsize(b) > 10:
         shutil.copy(b, os.path.join(ROOT, "profiles", f"{tag}_bench_{name}.json"))

@@ -23,7 +23,11 @@ for sm in 2 4; do
   timeout 600 python bench.py --scale-mult $sm --steps 20 --warmup 8 --no-cpu-baseline --no-train-step > gpurun_out/bench_C3_s$sm.log 2> gpurun_out/bench_C3_s$sm.err
 done
 timeout 600 python bench.py --fill 1.7 --steps 20 --warmup 8 --no-cpu-baseline --no-train-step > gpurun_out/bench_C3_fill.log 2> gpurun_out/bench_C3_fill.err
-for f in gpurun_out/bench_C3_s2.log gpurun_out/bench_C3_s4.log gpurun_out/bench_C3_fill.log; do python - "$f" <<'PY'
+# round 4: the Gaussians' index order (random = worst case; morton = that order numbered again by tetra.spatial_order)
+for o in random morton; do
+  timeout 600 python bench.py --gaussian-order $o --steps 20 --warmup 8 --no-cpu-baseline --no-train-step 2> gpurun_out/bench_C3_$o.err | grep "^{" > gpurun_out/bench_C3_$o.log
+done
+for f in gpurun_out/bench_C3_s2.log gpurun_out/bench_C3_s4.log gpurun_out/bench_C3_fill.log gpurun_out/bench_C3_random.log gpurun_out/bench_C3_morton.log; do python - "$f" <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
