@@ -179,9 +179,14 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
 #endif
     if (i < prm.P) {
         // two call sites so that each inlined copy sees ONE address space (registers vs global_load, never flat)
+        PreLoaded pl;
+        pl.has_sh = staged; pl.has_c6 = pre;
+        pl.sh[0] = acc[0]; pl.sh[1] = acc[1]; pl.sh[2] = acc[2];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pl.c6[k] = pc6[k];
+        pl.op = pop;
         const PreOut o = staged ? preprocess_one(prm, i, means3D, nullptr, colors_precomp, opacities, scales, rotations,
-                                                 cov3D_precomp, viewmatrix, projmatrix, campos, acc, pre ? pc6 : nullptr,
-                                                 pre ? &pop : nullptr)
+                                                 cov3D_precomp, viewmatrix, projmatrix, campos, pl)
                                 : preprocess_one(prm, i, means3D, shs ? shs + (size_t)M3 * i : nullptr, colors_precomp,
                                                  opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                                                  campos);

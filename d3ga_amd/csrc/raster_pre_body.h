@@ -34,21 +34,28 @@ D3GA_HD void sh_accumulate(const float B[16], const float *part, int k0, int k1,
 }
 
 // R1 for Gaussian i.  Exactly one of (sh_row|sh_acc|colors_precomp), ((scales,rotations)|cov3D_precomp) is non-null.
-// sh_row points at THIS Gaussian's 3*M SH floats (in global memory or in an LDS staging row); alternatively sh_acc
-// holds the already evaluated sum_k Y_k(dir) * coeff_k (3 floats, see sh_view_basis / sh_accumulate).
-// pre_c6 / pre_op: this Gaussian's covariance row and raw opacity if the caller has loaded them already (the kernel issues
+// sh_row points at THIS Gaussian's 3*M SH floats (in global memory or in an LDS staging row); alternatively pl.sh
+// holds the already evaluated sum_k Y_k(dir) * coeff_k (see sh_view_basis / sh_accumulate).
+// pl.c6 / pl.op: this Gaussian's covariance row and raw opacity if the caller has loaded them already (the kernel issues
 // those loads before it stages the SH rows).  The opacity is read unconditionally: behind the visibility test it would be
 // one more dependent memory round trip per wavefront.
+// What the caller has in registers already, BY VALUE (round 4: as nullable pointers to locals these lived in scratch
+// memory -- 69 scratch instructions in the kernel and a dependent memory round trip in front of the colour).
+struct PreLoaded {
+    bool has_sh = false, has_c6 = false;   // uniform over the launch
+    float sh[3] = {0.f, 0.f, 0.f};         // sum_k Y_k(dir) * coeff_k, already evaluated (sh_view_basis / sh_accumulate)
+    float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float op = 0.f;                        // raw opacity (with has_c6)
+};
 D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float *means3D, const float *sh_row,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
-                              const float *projmatrix, const float *campos, const float *sh_acc = nullptr,
-                              const float *pre_c6 = nullptr, const float *pre_op = nullptr) {
+                              const float *projmatrix, const float *campos, const PreLoaded pl = PreLoaded()) {
     PreOut o;
     const V3 mean = ld3(means3D, i);
-    const float raw_opacity = pre_op ? *pre_op : opacities[i];
-    if (pre_c6) {
-        for (int k = 0; k < 6; ++k) o.c6[k] = pre_c6[k];
+    const float raw_opacity = pl.has_c6 ? pl.op : opacities[i];
+    if (pl.has_c6) {
+        for (int k = 0; k < 6; ++k) o.c6[k] = pl.c6[k];
     } else if (cov3D_precomp) {
         for (int k = 0; k < 6; ++k) o.c6[k] = cov3D_precomp[6 * (size_t)i + k];
     } else {
@@ -76,8 +83,8 @@ D3GA_HD PreOut preprocess_one(const d3ga_raster_params &prm, int i, const float 
         o.rgb[2] = colors_precomp[3 * (size_t)i + 2];
     } else {
         float acc[3] = {0.f, 0.f, 0.f};
-        if (sh_acc) {
-            acc[0] = sh_acc[0]; acc[1] = sh_acc[1]; acc[2] = sh_acc[2];
+        if (pl.has_sh) {
+            acc[0] = pl.sh[0]; acc[1] = pl.sh[1]; acc[2] = pl.sh[2];
         } else {
             float B[16];
             sh_view_basis(prm, means3D, i, campos, B);
