@@ -150,7 +150,7 @@ def _settings(inp, bg, sh_degree, mod=1.0):
         sh_degree=sh_degree, campos=inp["campos"].to(DEV), prefiltered=False, debug=False, antialiasing=False)
 
 
-def _oracle(inp, bg, gpix, sh_degree, use_sh=True, from_sr=False, mod=1.0, rots=None, mask=True):
+def _oracle(inp, bg, gpix, sh_degree, use_sh=True, from_sr=False, mod=1.0, rots=None, mask=True, antialiasing=False):
     cam = inp["cam"]
     kw = dict(shs=_np(inp["shs"]), sh_degree=sh_degree) if use_sh else dict(colors_precomp=_np(inp["rgb"]))
     if from_sr:
@@ -159,7 +159,7 @@ def _oracle(inp, bg, gpix, sh_degree, use_sh=True, from_sr=False, mod=1.0, rots=
         kw.update(cov3D_precomp=_np(inp["cov6"]))
     color, radii, invd, ctx = rc.forward(_np(inp["means3D"]), _np(inp["opacities"]), _np(bg), cam["world_view_transform"],
                                          cam["full_proj_transform"], cam["camera_center"], cam["tanfovx"],
-                                         cam["tanfovy"], inp["W"], inp["H"], **kw)
+                                         cam["tanfovy"], inp["W"], inp["H"], antialiasing=antialiasing, **kw)
     grads = None
     if gpix is not None:
         # Round 3: `gpix` (CPU tensor) is zeroed IN PLACE on the oracle's marginal pixels before EITHER backward sees it, so
@@ -1567,7 +1567,7 @@ def test_geometry_reuse_between_rgb_and_silhouette_pass():
 def test_fuzz_ragged_sizes_and_argument_paths(seed):
     """Seeded random configurations against the C oracle: image sizes that are not multiples of the 16-pixel tile (down
     to a single pixel row), off-centre principal points, every SH degree, both colour paths, both covariance paths, a
-    scale modifier, random background, few or many Gaussians per tile.  Integer results (radii, tile lists) bit-exact."""
+    scale modifier, random background, few or many Gaussians per tile, with and without the antialiasing factor.  Integer results (radii, tile lists) bit-exact."""
     from d3ga_amd import rasterizer as R
     rng = np.random.default_rng(1000 + seed)
     big = os.environ.get("D3GA_FUZZ_SCENE") == "C1"                  # campaign variant: 10k Gaussians, images up to 500 px
@@ -1593,9 +1593,10 @@ def test_fuzz_ragged_sizes_and_argument_paths(seed):
         args["scales"], args["rotations"] = _cu(inp["scales"], True), _cu(rots, True)
     else:
         args["cov3D_precomp"] = _cu(inp["cov6"], True)
-    rast = R.GaussianRasterizer(_settings(inp, bg, deg if use_sh else 0, mod))
+    aa = seed % 5 == 4                                     # branch dr_aa's antialiasing factor on every fifth seed (round 4)
+    rast = R.GaussianRasterizer(_settings(inp, bg, deg if use_sh else 0, mod)._replace(antialiasing=aa))
     color, radii, _ = rast(means2D=None, **args)
-    ocolor, oradii, _, ctx, og = _oracle(inp, bg, gpix, deg, use_sh=use_sh, from_sr=from_sr, mod=mod, rots=rots)
+    ocolor, oradii, _, ctx, og = _oracle(inp, bg, gpix, deg, use_sh=use_sh, from_sr=from_sr, mod=mod, rots=rots, antialiasing=aa)
     np.testing.assert_array_equal(_np(radii), oradii)
     start, plist, _ = R.last_tile_lists(W, H)
     ostart, olist = rc.tile_lists(ctx)
