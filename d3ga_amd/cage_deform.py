@@ -7,6 +7,8 @@ Host-side mirror of the reference's per-frame tensor program (SURVEY.md sec. 8a 
     lib/cage.py:349-361           -> fem_energy
 All three call hand-written gfx950 kernels through the C ABI (include/d3ga.h); GPU tensors only.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -62,6 +64,55 @@ def vertex_adjacency(tetras, tetra_id, n_vertices):
     return hit[0], hit[1]
 
 
+_plan_cache = {}
+_MERGE_BLOCK = 256        # = kBlock of csrc/deform.hip: the Gaussians of one workgroup
+# D3GA_DEFORM_MERGE=0: per-corner gradient records + a gather over all 4P items (rounds 1-3; kept for A/B runs)
+_merge_policy = {"enabled": os.environ.get("D3GA_DEFORM_MERGE", "1") != "0"}
+
+
+def merge_plan(tetras, tetra_id, n_vertices):
+    """Static plan of the block-merged backward (d3ga_cage_deform_bwd_merged), built once per binding and cached:
+    -> dict(item_pos (P,4) int16-as-uint16, seg_ptr (blocks+1) int32, seg_begin (segments) uint16 stored as int16,
+            vert_start (V+1) int32, vert_parts (segments) int32, n_segments).
+    Items are (Gaussian, corner) pairs, 1024 per workgroup of 256 consecutive Gaussians; inside a workgroup they are ordered
+    by cage vertex (stable), a SEGMENT is a run of equal vertex, and every segment's sum becomes one partial."""
+    key = (tetras.data_ptr(), tetra_id.data_ptr(), tetras._version, tetra_id._version, tetra_id.shape[0], n_vertices)
+    hit = _plan_cache.get(key)
+    if hit is None:
+        with torch.no_grad():
+            dev = tetra_id.device
+            P = tetra_id.shape[0]
+            per = 4 * _MERGE_BLOCK
+            vid = tetras.long()[tetra_id.long()].reshape(-1)                    # (4P,) vertex of item 4 i + corner
+            item = torch.arange(4 * P, device=dev)
+            blk = item // per
+            order = torch.sort(blk * n_vertices + vid, stable=True)[1]          # items by (workgroup, vertex), stable
+            inv = torch.empty_like(order)
+            inv[order] = item
+            item_pos = (inv - blk * per).to(torch.int16).reshape(P, 4).contiguous()      # < 1024: the bit pattern of a uint16
+            key_sorted = (blk * n_vertices + vid)[order]
+            first = torch.ones(4 * P, dtype=torch.bool, device=dev)
+            first[1:] = key_sorted[1:] != key_sorted[:-1]
+            seg_first = torch.nonzero(first).reshape(-1)                        # sorted index of every segment's first item
+            seg_key = key_sorted[seg_first]
+            seg_blk, seg_vid = seg_key // n_vertices, seg_key % n_vertices
+            nb = (P + _MERGE_BLOCK - 1) // _MERGE_BLOCK
+            seg_ptr = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+            seg_ptr[1:] = torch.cumsum(torch.bincount(seg_blk, minlength=nb), 0)
+            seg_begin = (seg_first - seg_blk * per).to(torch.int16).contiguous()
+            nseg = int(seg_first.numel())
+            order2 = torch.sort(seg_vid, stable=True)[1]
+            vstart = torch.zeros(n_vertices + 1, dtype=torch.int64, device=dev)
+            vstart[1:] = torch.cumsum(torch.bincount(seg_vid, minlength=n_vertices), 0)
+            hit = dict(item_pos=item_pos, seg_ptr=seg_ptr.to(torch.int32).contiguous(), seg_begin=seg_begin,
+                       vert_start=vstart.to(torch.int32).contiguous(), vert_parts=order2.to(torch.int32).contiguous(),
+                       n_segments=nseg, pins=(tetras, tetra_id))
+        if len(_plan_cache) > 64:
+            _plan_cache.clear()
+        _plan_cache[key] = hit               # holds tetras / tetra_id alive: their addresses cannot be recycled
+    return hit
+
+
 class _CageDeform(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations, delta_barys, flags):
@@ -97,6 +148,15 @@ class _CageDeform(torch.autograd.Function):
         g_s = torch.empty((P, 3), dtype=torch.float32, device=dev) if need[5] else None
         g_r = torch.empty((P, 4), dtype=torch.float32, device=dev) if need[6] else None
         vstart = vitems = corner = None
+        if need[0] and P > 0 and _merge_policy["enabled"]:
+            plan = merge_plan(tetras, tetra_id, V)
+            partials = torch.empty((plan["n_segments"], 3), dtype=torch.float32, device=dev)
+            check(_lib.lib().d3ga_cage_deform_bwd_merged(
+                P, V, dptr(tetpoints), dptr(tetras), dptr(tetra_id), dptr(barys), dptr(canon_grad), dptr(scales),
+                dptr(rotations), dptr(delta_barys), ctx.flags, dptr(g_means), dptr(g_cov6), dptr(g_tp), dptr(g_b), dptr(g_s),
+                dptr(g_r), dptr(plan["item_pos"]), dptr(plan["seg_ptr"]), dptr(plan["seg_begin"]), plan["n_segments"],
+                dptr(plan["vert_start"]), dptr(plan["vert_parts"]), dptr(partials), stream_handle()), "d3ga_cage_deform_bwd_merged")
+            return (g_tp, None, None, g_b if need[3] else None, None, g_s, g_r, g_b if need[7] else None, None)
         if need[0] and P > 0:
             vstart, vitems = vertex_adjacency(tetras, tetra_id, V)
             corner = torch.empty((P, 4, 3), dtype=torch.float32, device=dev)

@@ -122,33 +122,67 @@ __device__ __forceinline__ void atomic_add3(float *base, int v, V3 g) {
     atomicAdd(base + 3 * (size_t)v + 2, g.z);
 }
 
+// Block-level merge of the corner gradients (round 4; d3ga_cage_deform_bwd_merged).  The binding is static, so for every
+// workgroup of 256 consecutive Gaussians the positions of its 1024 (Gaussian, corner) items in vertex-sorted order
+// (item_pos), the segments of equal vertex (seg_ptr / seg_begin) and where each segment's sum goes (partial g = global
+// segment index) are built ONCE (cage_deform.py: merge_plan).  The kernel drops its corner gradients into LDS at those
+// positions, sums every segment in a fixed order (no atomics: bit-reproducible) and writes one partial per (workgroup,
+// vertex) -- with spatially coherent numbering a few hundred per workgroup instead of 1024 corner records; the vertex
+// gather then runs over the partials.
+struct DeformMerge {
+    const uint16_t *item_pos;      // (P,4)  position of item 4 i + c among its workgroup's items sorted by vertex
+    const int32_t *seg_ptr;        // (workgroups + 1)  first global segment of each workgroup
+    const uint16_t *seg_begin;     // (segments)  first position of the segment inside its workgroup
+    float *partials;               // (segments,3)
+};
+
 __global__ __launch_bounds__(kBlock) void cage_deform_bwd_kernel(
     int P, const float *__restrict__ tetpoints, const int32_t *__restrict__ tetras, const int32_t *__restrict__ tetra_id,
     const float *__restrict__ barys, const float *__restrict__ canon_grad, const float *__restrict__ scales,
     const float *__restrict__ rots, const float *__restrict__ delta_barys, int flags,
     const float *__restrict__ g_means, const float *__restrict__ g_cov6,
     float *__restrict__ g_tetpoints, float *__restrict__ g_barys, float *__restrict__ g_scales,
-    float *__restrict__ g_rots, float *__restrict__ corner_grads) {
+    float *__restrict__ g_rots, float *__restrict__ corner_grads, DeformMerge mg) {
+    __shared__ float s_val[3][4 * kBlock];                 // merged path: the workgroup's corner gradients in vertex order
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= P) return;
-    DeformIn in;
-    int4 vid;
-    load_deform_in(i, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rots, delta_barys, flags, in, vid);
-    float gm[3] = {g_means[3 * (size_t)i], g_means[3 * (size_t)i + 1], g_means[3 * (size_t)i + 2]};
-    float gc[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) gc[k] = g_cov6[6 * (size_t)i + k];
+    if (i >= P && !mg.item_pos) return;
     DeformGrad o;
-    deform_bwd(in, gm, gc, o);
-    if (g_barys) reinterpret_cast<float4 *>(g_barys)[i] = make_float4(o.gbary[0], o.gbary[1], o.gbary[2], o.gbary[3]);
-    if (g_scales) {
-        if (flags & D3GA_DEFORM_LOG_SCALES) {    // d/d(log s) = s * d/ds
-            o.gs[0] *= in.s[0]; o.gs[1] *= in.s[1]; o.gs[2] *= in.s[2];
+    int4 vid = make_int4(0, 0, 0, 0);
+    if (i < P) {
+        DeformIn in;
+        load_deform_in(i, tetpoints, tetras, tetra_id, barys, canon_grad, scales, rots, delta_barys, flags, in, vid);
+        float gm[3] = {g_means[3 * (size_t)i], g_means[3 * (size_t)i + 1], g_means[3 * (size_t)i + 2]};
+        float gc[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gc[k] = g_cov6[6 * (size_t)i + k];
+        deform_bwd(in, gm, gc, o);
+        if (g_barys) reinterpret_cast<float4 *>(g_barys)[i] = make_float4(o.gbary[0], o.gbary[1], o.gbary[2], o.gbary[3]);
+        if (g_scales) {
+            if (flags & D3GA_DEFORM_LOG_SCALES) {    // d/d(log s) = s * d/ds
+                o.gs[0] *= in.s[0]; o.gs[1] *= in.s[1]; o.gs[2] *= in.s[2];
+            }
+            g_scales[3 * (size_t)i] = o.gs[0]; g_scales[3 * (size_t)i + 1] = o.gs[1]; g_scales[3 * (size_t)i + 2] = o.gs[2];
         }
-        g_scales[3 * (size_t)i] = o.gs[0]; g_scales[3 * (size_t)i + 1] = o.gs[1]; g_scales[3 * (size_t)i + 2] = o.gs[2];
+        if (g_rots) reinterpret_cast<float4 *>(g_rots)[i] = make_float4(o.gq[0], o.gq[1], o.gq[2], o.gq[3]);
     }
-    if (g_rots) reinterpret_cast<float4 *>(g_rots)[i] = make_float4(o.gq[0], o.gq[1], o.gq[2], o.gq[3]);
-    if (corner_grads) {            // deterministic path: per-corner gradients, summed per vertex by vertex_gather_kernel
+    if (mg.item_pos) {
+        if (i < P) {
+            const ushort4 ps = reinterpret_cast<const ushort4 *>(mg.item_pos)[i];
+            s_val[0][ps.x] = o.gx0.x; s_val[1][ps.x] = o.gx0.y; s_val[2][ps.x] = o.gx0.z;
+            s_val[0][ps.y] = o.gx1.x; s_val[1][ps.y] = o.gx1.y; s_val[2][ps.y] = o.gx1.z;
+            s_val[0][ps.z] = o.gx2.x; s_val[1][ps.z] = o.gx2.y; s_val[2][ps.z] = o.gx2.z;
+            s_val[0][ps.w] = o.gx3.x; s_val[1][ps.w] = o.gx3.y; s_val[2][ps.w] = o.gx3.z;
+        }
+        __syncthreads();
+        const int g0 = mg.seg_ptr[blockIdx.x], g1 = mg.seg_ptr[blockIdx.x + 1];
+        const int nitems = 4 * min(kBlock, P - (int)blockIdx.x * kBlock);
+        for (int g = g0 + (int)threadIdx.x; g < g1; g += kBlock) {
+            const int b = mg.seg_begin[g], e = g + 1 < g1 ? (int)mg.seg_begin[g + 1] : nitems;
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (int k = b; k < e; ++k) { sx += s_val[0][k]; sy += s_val[1][k]; sz += s_val[2][k]; }
+            mg.partials[3 * (size_t)g] = sx; mg.partials[3 * (size_t)g + 1] = sy; mg.partials[3 * (size_t)g + 2] = sz;
+        }
+    } else if (corner_grads) {            // deterministic path: per-corner gradients, summed per vertex by vertex_gather_kernel
         float4 *c = reinterpret_cast<float4 *>(corner_grads + 12 * (size_t)i);
         c[0] = make_float4(o.gx0.x, o.gx0.y, o.gx0.z, o.gx1.x);
         c[1] = make_float4(o.gx1.y, o.gx1.z, o.gx2.x, o.gx2.y);
@@ -189,6 +223,30 @@ __global__ __launch_bounds__(kBlock) void vertex_gather_kernel(int V, const int3
     }
     sx = wave_sum_(sx); sy = wave_sum_(sy); sz = wave_sum_(sz);
     if (lane == 0) { g_tetpoints[3 * (size_t)v] = sx; g_tetpoints[3 * (size_t)v + 1] = sy; g_tetpoints[3 * (size_t)v + 2] = sz; }
+}
+
+// The same with ONE DPP ROW (16 lanes) per vertex, four vertices per wavefront: for short item lists -- the partials of the
+// block-merged backward, two to four per vertex with coherent numbering -- a whole wavefront per vertex leaves 60 lanes idle
+// and the launch is 4x the wavefronts (7.3 -> .. us at C3).
+__device__ __forceinline__ float row_sum_(float v) {          // every lane of the row ends with the row's total
+    v = dpp_add_<0xB1, 0xf>(v); v = dpp_add_<0x4E, 0xf>(v); v = dpp_add_<0x141, 0xf>(v); v = dpp_add_<0x140, 0xf>(v);
+    return v;
+}
+__global__ __launch_bounds__(kBlock) void vertex_gather_row_kernel(int V, const int32_t *__restrict__ vert_start,
+                                                                   const int32_t *__restrict__ vert_items,
+                                                                   const float *__restrict__ values,
+                                                                   float *__restrict__ g_tetpoints) {
+    const int v = blockIdx.x * (kBlock / 16) + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & 15;
+    const bool live = v < V;
+    const int b = live ? vert_start[v] : 0, e = live ? vert_start[v + 1] : 0;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int k = b + l16; k < e; k += 16) {
+        const float *c = values + 3 * (size_t)vert_items[k];
+        sx += c[0]; sy += c[1]; sz += c[2];
+    }
+    sx = row_sum_(sx); sy = row_sum_(sy); sz = row_sum_(sz);
+    if (live && l16 == 0) { g_tetpoints[3 * (size_t)v] = sx; g_tetpoints[3 * (size_t)v + 1] = sy; g_tetpoints[3 * (size_t)v + 2] = sz; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -287,11 +345,46 @@ extern "C" int d3ga_cage_deform_bwd_ex(int P, int V, const float *tetpoints, con
         return D3GA_E_NULL;
     hipLaunchKernelGGL(cage_deform_bwd_kernel, dim3(nblocks(P)), dim3(kBlock), 0, s, P, tetpoints, tetras, tetra_id,
                        barys, canon_grad, scales, rots, delta_barys, (int)flags, g_means, g_cov6, g_tetpoints, g_barys,
-                       g_scales, g_rots, csr ? corner_grads : nullptr);
+                       g_scales, g_rots, csr ? corner_grads : nullptr, DeformMerge{nullptr, nullptr, nullptr, nullptr});
     D3GA_TRY(check_launch(s, 0));
     if (csr && V > 0) {
         hipLaunchKernelGGL(vertex_gather_kernel, dim3((V + 3) / 4), dim3(kBlock), 0, s, V, vert_start, vert_items,
                            corner_grads, g_tetpoints);
+        return check_launch(s, 0);
+    }
+    return D3GA_OK;
+}
+
+extern "C" int d3ga_cage_deform_bwd_merged(int P, int V, const float *tetpoints, const int32_t *tetras,
+                                           const int32_t *tetra_id, const float *barys, const float *canon_grad,
+                                           const float *scales, const float *rots, const float *delta_barys, int32_t flags,
+                                           const float *g_means, const float *g_cov6, float *g_tetpoints, float *g_barys,
+                                           float *g_scales, float *g_rots, const uint16_t *item_pos, const int32_t *seg_ptr,
+                                           const uint16_t *seg_begin, int32_t n_segments, const int32_t *vert_start,
+                                           const int32_t *vert_parts, float *partials, d3ga_stream_t stream) {
+    if (P < 0 || V < 0 || n_segments < 0) return D3GA_E_SIZE;
+    if (flags & ~D3GA_DEFORM_LOG_SCALES) return D3GA_E_CONFIG;
+    if (!g_tetpoints) return D3GA_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) {
+        if (V > 0) D3GA_HIP(zero_async(g_tetpoints, sizeof(float) * 3 * (size_t)V, s));
+        return D3GA_OK;
+    }
+    if (!tetpoints || !tetras || !tetra_id || !barys || !canon_grad || !scales || !rots || !g_means || !g_cov6 || !item_pos ||
+        !seg_ptr || !seg_begin || !vert_start || !vert_parts || !partials)
+        return D3GA_E_NULL;
+    if ((uintptr_t)item_pos & 7) return D3GA_E_CONFIG;                       // read 8 bytes per Gaussian
+    hipLaunchKernelGGL(cage_deform_bwd_kernel, dim3(nblocks(P)), dim3(kBlock), 0, s, P, tetpoints, tetras, tetra_id,
+                       barys, canon_grad, scales, rots, delta_barys, (int)flags, g_means, g_cov6, g_tetpoints, g_barys,
+                       g_scales, g_rots, (float *)nullptr, DeformMerge{item_pos, seg_ptr, seg_begin, partials});
+    D3GA_TRY(check_launch(s, 0));
+    if (V > 0) {
+        if ((int64_t)n_segments <= 24 * (int64_t)V)          // short lists (the usual case): a DPP row per vertex
+            hipLaunchKernelGGL(vertex_gather_row_kernel, dim3((V + kBlock / 16 - 1) / (kBlock / 16)), dim3(kBlock), 0, s, V,
+                               vert_start, vert_parts, (const float *)partials, g_tetpoints);
+        else
+            hipLaunchKernelGGL(vertex_gather_kernel, dim3((V + 3) / 4), dim3(kBlock), 0, s, V, vert_start, vert_parts,
+                               (const float *)partials, g_tetpoints);
         return check_launch(s, 0);
     }
     return D3GA_OK;

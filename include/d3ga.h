@@ -90,6 +90,22 @@ int d3ga_cage_deform_bwd_ex(int P, int V, const float *tetpoints, const int32_t 
                             const int32_t *vert_start, const int32_t *vert_items, float *corner_grads,
                             d3ga_stream_t stream);
 
+/* The same backward with the corner gradients merged per WORKGROUP before they leave the CU (round 4).  The binding
+ * (tetras, tetra_id) is static, so a plan is built once (d3ga_amd/cage_deform.py: merge_plan): for every block of 256
+ * consecutive Gaussians, item_pos (P,4 u16; 8-byte aligned) = position of item 4 i + corner among the block's items sorted by
+ * cage vertex, seg_ptr (blocks + 1) / seg_begin (segments, u16) = the runs of equal vertex, and a second-level CSR
+ * vert_start (V + 1) / vert_parts (segments) from vertices to segments.  The kernel sums every run in a fixed order in LDS
+ * and writes one partial per run (partials: (segments,3) scratch); the vertex gather then adds a vertex's partials.
+ * No atomics, bit-reproducible; with spatially coherent numbering (tetra.spatial_order) a block has a few hundred runs
+ * instead of 1024 items.  g_tetpoints is required. */
+int d3ga_cage_deform_bwd_merged(int P, int V, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
+                                const float *barys, const float *canon_grad, const float *scales, const float *rots,
+                                const float *delta_barys, int32_t flags, const float *g_means, const float *g_cov6,
+                                float *g_tetpoints, float *g_barys, float *g_scales, float *g_rots,
+                                const uint16_t *item_pos, const int32_t *seg_ptr, const uint16_t *seg_begin,
+                                int32_t n_segments, const int32_t *vert_start, const int32_t *vert_parts, float *partials,
+                                d3ga_stream_t stream);
+
 /* D6  FEM regulariser (lib/cage.py:349-361): per-tet energy 0.5(det F-1)^2 + 0.5(|F|_F^2-3), F = Ds Dn^-1.
  *   fwd: energy (T).  bwd: g_energy (T) -> g_tetpoints (V,3) [zeroed by the call]. */
 int d3ga_fem_energy_fwd(int T, const float *tetpoints, const int32_t *tetras, const float *Dn_inv, float *energy,

@@ -281,3 +281,40 @@ def test_spatial_order_is_a_permutation_along_a_z_curve():
     same = torch.zeros(7, 3)
     assert spatial_order(same).tolist() == list(range(7))                  # all codes equal: stable
     assert spatial_order(torch.zeros(0, 3)).numel() == 0
+
+
+def test_merge_plan_of_the_deform_backward_reproduces_the_vertex_sums():
+    """cage_deform.merge_plan (host logic of d3ga_cage_deform_bwd_merged): emulating the kernel on the CPU -- items dropped at
+    item_pos inside their workgroup, every segment summed, a vertex's partials added -- gives index_add over the items, for a
+    sorted binding, a random one, a partial last workgroup and a single workgroup."""
+    import torch
+    from d3ga_amd import cage_deform as cd
+    g = torch.Generator().manual_seed(0)
+    for T, V, P, sort in ((200, 90, 1500, True), (300, 120, 1024, False), (50, 30, 77, True), (10, 8, 256, False)):
+        tetras = torch.randint(0, V, (T, 4), generator=g, dtype=torch.int32)
+        tid = torch.randint(0, T, (P,), generator=g)
+        tid = (torch.sort(tid)[0] if sort else tid).to(torch.int32)
+        pl = cd.merge_plan(tetras, tid, V)
+        vid = tetras.long()[tid.long()].reshape(-1)
+        vals = torch.randn(4 * P, 3, generator=g, dtype=torch.float64)
+        pos = pl["item_pos"].long().reshape(-1) & 0xffff
+        begin = pl["seg_begin"].long() & 0xffff
+        partials = torch.zeros(pl["n_segments"], 3, dtype=torch.float64)
+        for b in range((P + 255) // 256):
+            n = 4 * min(256, P - 256 * b)
+            buf = torch.zeros(1024, 3, dtype=torch.float64)
+            p_b = pos[1024 * b:1024 * b + n]
+            assert sorted(p_b.tolist()) == list(range(n))                      # a permutation of the workgroup's slots
+            buf[p_b] = vals[1024 * b:1024 * b + n]
+            g0, g1 = int(pl["seg_ptr"][b]), int(pl["seg_ptr"][b + 1])
+            for s_ in range(g0, g1):
+                e = int(begin[s_ + 1]) if s_ + 1 < g1 else n
+                partials[s_] = buf[int(begin[s_]):e].sum(0)
+        out = torch.zeros(V, 3, dtype=torch.float64)
+        vs, vp = pl["vert_start"].long(), pl["vert_parts"].long()
+        for v in range(V):
+            out[v] = partials[vp[vs[v]:vs[v + 1]]].sum(0)
+        ref = torch.zeros(V, 3, dtype=torch.float64).index_add_(0, vid, vals)
+        assert float((out - ref).abs().max()) < 1e-12
+        if sort:
+            assert pl["n_segments"] < 2 * P                                    # coherent numbering: runs are long
