@@ -191,8 +191,10 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
                                                  opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                                                  campos);
         const Splat &sp = o.sp;
+        if (!cov3D_precomp) {                   // (uniform) a precomputed covariance is read again from the caller's tensor
 #pragma unroll
-        for (int k = 0; k < 6; ++k) geom.cov3D[6 * (size_t)i + k] = o.c6[k];
+            for (int k = 0; k < 6; ++k) geom.cov3D[6 * (size_t)i + k] = o.c6[k];
+        }
         radii[i] = sp.radius;
         geom.depth[i] = sp.depth;
         geom.xy[i] = make_float2(sp.px, sp.py);
@@ -294,7 +296,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const float *__restrict__ projmatrix, const float *__restrict__ campos, GeomBuf geom,
     const float *__restrict__ acc, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
     float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors,
-    float *__restrict__ dL_dcov3D, float *__restrict__ dL_dscales, float *__restrict__ dL_drots) {
+    float *__restrict__ dL_dcov3D, float *__restrict__ dL_dscales, float *__restrict__ dL_drots,
+    const float *__restrict__ cov3D_precomp) {
     if (!(prm.tanfovx > 0.f)) { prm.tanfovx = campos[3]; prm.tanfovy = campos[4]; }     // camera slot: see d3ga.h
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_sh = reinterpret_cast<float *>(smem);
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
             }
         }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) c6[k] = geom.cov3D[6 * (size_t)i + k];
+        for (int k = 0; k < 6; ++k) c6[k] = (cov3D_precomp ? cov3D_precomp : geom.cov3D)[6 * (size_t)i + k];   // (the forward kept no copy of a precomputed one)
         clampmask = geom.clamped[i];
         act_opacity = geom.conic_o[i].w;
     }
@@ -496,7 +499,6 @@ extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const f
                                           float *dL_dopacity, float *dL_dsh, float *dL_dcolors, float *dL_dcov3D,
                                           float *dL_dscales, float *dL_drots, d3ga_stream_t stream) {
     D3GA_TRY(validate(prm));
-    (void)cov3D_precomp;
     if (prm->P == 0) return D3GA_OK;
     if (!means3D || !viewmatrix || !projmatrix || !campos || !geom || !acc || !dL_dmeans3D) return D3GA_E_NULL;
     if (dL_dsh && !shs) return D3GA_E_NULL;
@@ -508,7 +510,7 @@ extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const f
     const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? kShLdsBytes : 0;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D,
                        shs, scales, rotations, viewmatrix, projmatrix, campos, g, acc, dL_dmeans3D, dL_dmeans2D,
-                       dL_dopacity, dL_dsh, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots);
+                       dL_dopacity, dL_dsh, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots, cov3D_precomp);
     return check_launch(s, prm->debug);
 }
 

@@ -254,7 +254,9 @@ int d3ga_raster_recolor(const d3ga_raster_params *prm, const float *means3D, con
  * dL_dmeans3D (P,3), dL_dmeans2D (P,3), dL_dopacity (P,1), and dL_dsh (P,M,3) | dL_dcolors (P,3),
  * dL_dcov3D (P,6) | (dL_dscales (P,3), dL_drots (P,4)).
  * SH path with dL_dsh == NULL and dL_dcolors != NULL: FACTORED SH gradient -- dL_dcolors receives the clamp-masked
- * dL/dcolour (the (P,3) factor of the rank-1 SH gradient, see d3ga_sh_grad_from_views); dL/dmeans3D is complete. */
+ * dL/dcolour (the (P,3) factor of the rank-1 SH gradient, see d3ga_sh_grad_from_views); dL/dmeans3D is complete.
+ * cov3D_precomp: the SAME tensor, unchanged, that the forward was given (or NULL with scales / rotations): since round 4 the
+ * forward keeps no copy of a precomputed covariance in `geom` (24 B x P less written per frame), the backward reads it here. */
 int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const float *means3D, const float *shs,
                                const float *scales, const float *rotations, const float *cov3D_precomp,
                                const float *viewmatrix, const float *projmatrix, const float *campos,
