@@ -117,7 +117,13 @@ class Frame:
         self.canon, self.tetras, self.tetra_id = d(sc["canon_points"]), d(sc["tetras"]), d(sc["tetra_id"])
         self.barys0 = d(sc["barys"])
         self.joint_mats, self.skin_idx, self.skin_w = d(sc["joint_mats"]), d(sc["skin_idx"]), d(sc["skin_w"])
-        self.canon_grad = canonical_gradient(self.canon, self.tetras, self.tetra_id).contiguous()
+        # one inverse canonical gradient per TETRAHEDRON, read through tetra_id (cage_deform accepts the reference's per-Gaussian
+        # copy of the same matrices as well: --canon-grad per-gaussian; lib/cage.py:329 stores that form)
+        if os.environ.get("D3GA_BENCH_CANON_GRAD", "per-tet") == "per-tet":
+            from d3ga_amd.cage_deform import canonical_gradient_per_tet
+            self.canon_grad = canonical_gradient_per_tet(self.canon, self.tetras).contiguous()
+        else:
+            self.canon_grad = canonical_gradient(self.canon, self.tetras, self.tetra_id).contiguous()
         P = self.barys0.shape[0]
         par = lambda t: d(t).clone().requires_grad_(True)
         self.params = {
@@ -459,6 +465,8 @@ def deform_gpu_comparison(frame, reps=50):
     from oracle import deform as od
     p = frame.params
     tetras, tetra_id = frame.tetras.long(), frame.tetra_id.long()
+    # (the reference's form of the canonical gradient: gathered per Gaussian at init, lib/cage.py:329)
+    canon_grad_pg = frame.canon_grad if frame.canon_grad.shape[0] == frame.barys0.shape[0] else frame.canon_grad[tetra_id].contiguous()
 
     def fused():
         tp = lbs_cage(frame.canon, p["delta_node"], frame.joint_mats, frame.skin_idx, frame.skin_w)
@@ -468,7 +476,7 @@ def deform_gpu_comparison(frame, reps=50):
 
     def unfused():
         tp = od.lbs_cage(frame.canon, p["delta_node"], frame.joint_mats, frame.skin_idx.long(), frame.skin_w)
-        m, c = od.cage_deform(tp, tetras, tetra_id, frame.barys0 + p["delta_bary"], frame.canon_grad,
+        m, c = od.cage_deform(tp, tetras, tetra_id, frame.barys0 + p["delta_bary"], canon_grad_pg,
                               torch.exp(p["scaling"]), p["rotation"])
         (m.sum() + c.sum()).backward()
 

@@ -169,7 +169,7 @@ class _CageDeform(torch.autograd.Function):
 
 
 def cage_deform(tetpoints, tetras, tetra_id, barys, canonical_gradient, scales, rotations, delta_barys=None,
-                scale_activation=None):
+                scale_activation=None, gradient_per_tet=None):
     """(tetpoints (V,3), tetras (T,4), tetra_id (P), barys (P,4), canonical_gradient (P,3,3), scales (P,3),
     rotations (P,4) wxyz) -> (means3D (P,3), cov3D_precomp (P,6)); differentiable in tetpoints, barys, scales,
     rotations.  Drop-in for models/cage_net.py:218-230.  Index tensors may be int64
@@ -178,11 +178,22 @@ def cage_deform(tetpoints, tetras, tetra_id, barys, canonical_gradient, scales, 
 
     Optional fusion of the two activations in front of the op (models/cage_net.py:213-214):
     `delta_barys` (P,4) is added to `barys` inside the kernel (differentiable), and `scale_activation="exp"` makes
-    `scales` the raw log-scales (`scaling + delta`), with exp applied on load and the chain rule in the backward."""
+    `scales` the raw log-scales (`scaling + delta`), with exp applied on load and the chain rule in the backward.
+
+    `canonical_gradient` may also be ONE matrix per tetrahedron, (T,3,3) = `canonical_gradient_per_tet(...)` (round 4): the
+    reference gathers the same matrices per Gaussian at init (lib/cage.py:329), which makes the op stream 36 B x P per pass;
+    the per-tet table is read through `tetra_id` and stays in L2."""
     if scale_activation not in (None, "exp"):
         raise ValueError(f"scale_activation must be None or 'exp', got {scale_activation!r}")
+    P, T = barys.shape[0], tetras.shape[0]
+    if gradient_per_tet is None:             # (T,3,3) is recognised by its length unless T == P (then say which)
+        gradient_per_tet = canonical_gradient.shape[0] == T and T != P
+    if canonical_gradient.shape[0] != (T if gradient_per_tet else P):
+        raise ValueError(f"canonical_gradient has {canonical_gradient.shape[0]} matrices, expected "
+                         f"{T if gradient_per_tet else P} ({'one per tetrahedron' if gradient_per_tet else 'one per Gaussian'})")
+    flags = (1 if scale_activation == "exp" else 0) | (2 if gradient_per_tet else 0)
     return _CageDeform.apply(tetpoints, _i32c(tetras), _i32c(tetra_id), barys, canonical_gradient, scales, rotations,
-                             delta_barys, 1 if scale_activation == "exp" else 0)
+                             delta_barys, flags)
 
 
 class _LbsCage(torch.autograd.Function):
@@ -250,6 +261,13 @@ def fem_energy(tetpoints, tetras, Dn_inv):
 def canonical_gradient(canon_points, tetras, tetra_id):
     """inv(Dm) per Gaussian (lib/cage.py:329); init-time, plain torch on whatever device the inputs live."""
     c = canon_points[tetras.long()][tetra_id.long()]
+    Dm = torch.stack([c[:, 3] - c[:, 0], c[:, 2] - c[:, 0], c[:, 1] - c[:, 0]], dim=2)
+    return torch.linalg.inv(Dm)
+
+
+def canonical_gradient_per_tet(canon_points, tetras):
+    """inv(Dm) per TETRAHEDRON, (T,3,3): `canonical_gradient(...)` == this[tetra_id]; accepted by cage_deform directly."""
+    c = canon_points[tetras.long()]
     Dm = torch.stack([c[:, 3] - c[:, 0], c[:, 2] - c[:, 0], c[:, 1] - c[:, 0]], dim=2)
     return torch.linalg.inv(Dm)
 

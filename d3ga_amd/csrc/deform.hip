@@ -85,8 +85,11 @@ __device__ __forceinline__ void load_deform_in(int i, const float *__restrict__ 
         const float4 d = reinterpret_cast<const float4 *>(delta_barys)[i];
         in.bary[0] += d.x; in.bary[1] += d.y; in.bary[2] += d.z; in.bary[3] += d.w;
     }
+    // the canonical gradient is a property of the TETRAHEDRON: per Gaussian as the reference stores it (lib/cage.py:329,
+    // 36 B x P streamed per pass), or -- D3GA_DEFORM_GRAD_PER_TET -- one (T,3,3) table read through tetra_id (L2-resident)
+    const size_t gi = (flags & D3GA_DEFORM_GRAD_PER_TET) ? (size_t)t : (size_t)i;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) in.G.m[k] = canon_grad[9 * (size_t)i + k];
+    for (int k = 0; k < 9; ++k) in.G.m[k] = canon_grad[9 * gi + k];
     in.s[0] = scales[3 * (size_t)i]; in.s[1] = scales[3 * (size_t)i + 1]; in.s[2] = scales[3 * (size_t)i + 2];
     if (flags & D3GA_DEFORM_LOG_SCALES) {    // scales = exp(scaling) (models/cage_net.py:214), fused
         in.s[0] = expf(in.s[0]); in.s[1] = expf(in.s[1]); in.s[2] = expf(in.s[2]);
@@ -312,7 +315,7 @@ extern "C" int d3ga_cage_deform_fwd_ex(int P, const float *tetpoints, const int3
                                        const float *barys, const float *canon_grad, const float *scales,
                                        const float *rots, const float *delta_barys, int32_t flags, float *means3D,
                                        float *cov6, d3ga_stream_t stream) {
-    if (flags & ~D3GA_DEFORM_LOG_SCALES) return D3GA_E_CONFIG;
+    if (flags & ~(D3GA_DEFORM_LOG_SCALES | D3GA_DEFORM_GRAD_PER_TET)) return D3GA_E_CONFIG;
     if (P < 0) return D3GA_E_SIZE;
     if (P == 0) return D3GA_OK;
     if (!tetpoints || !tetras || !tetra_id || !barys || !canon_grad || !scales || !rots || !means3D || !cov6)
@@ -336,7 +339,7 @@ extern "C" int d3ga_cage_deform_bwd_ex(int P, int V, const float *tetpoints, con
                                        float *g_scales, float *g_rots, const int32_t *vert_start,
                                        const int32_t *vert_items, float *corner_grads, d3ga_stream_t stream) {
     if (P < 0 || V < 0) return D3GA_E_SIZE;
-    if (flags & ~D3GA_DEFORM_LOG_SCALES) return D3GA_E_CONFIG;
+    if (flags & ~(D3GA_DEFORM_LOG_SCALES | D3GA_DEFORM_GRAD_PER_TET)) return D3GA_E_CONFIG;
     hipStream_t s = (hipStream_t)stream;
     const bool csr = g_tetpoints && vert_start && vert_items && corner_grads;
     if (g_tetpoints && V > 0 && (!csr || P == 0)) D3GA_HIP(zero_async(g_tetpoints, sizeof(float) * 3 * (size_t)V, s));
@@ -363,7 +366,7 @@ extern "C" int d3ga_cage_deform_bwd_merged(int P, int V, const float *tetpoints,
                                            const uint16_t *seg_begin, int32_t n_segments, const int32_t *vert_start,
                                            const int32_t *vert_parts, float *partials, d3ga_stream_t stream) {
     if (P < 0 || V < 0 || n_segments < 0) return D3GA_E_SIZE;
-    if (flags & ~D3GA_DEFORM_LOG_SCALES) return D3GA_E_CONFIG;
+    if (flags & ~(D3GA_DEFORM_LOG_SCALES | D3GA_DEFORM_GRAD_PER_TET)) return D3GA_E_CONFIG;
     if (!g_tetpoints) return D3GA_E_NULL;
     hipStream_t s = (hipStream_t)stream;
     if (P == 0) {

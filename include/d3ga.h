@@ -70,6 +70,8 @@ int d3ga_lbs_cage_bwd(int V, int K, const float *joint_mats, const int32_t *skin
  *      - with those three NULL it falls back to float atomics into g_tetpoints (zeroed by the call).
  * ------------------------------------------------------------------------------------------------------- */
 #define D3GA_DEFORM_LOG_SCALES 1 /* `scales` holds log-scales: exp() applied inside, g_scales is d/d(log-scale) */
+#define D3GA_DEFORM_GRAD_PER_TET 2 /* `canon_grad` is (T,3,3), one matrix per tetrahedron, read through tetra_id (the reference
+                                    * stores the same matrices gathered per Gaussian, lib/cage.py:329: 36 B x P per pass) */
 int d3ga_cage_deform_fwd(int P, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
                          const float *barys, const float *canon_grad, const float *scales, const float *rots,
                          float *means3D, float *cov6, d3ga_stream_t stream);

@@ -1256,6 +1256,48 @@ def test_init_helpers_fuzz(seed):
     assert float(_np(active).mean()) > 0.99 and float(barys.min()) > -2e-3
 
 
+def test_cage_deform_per_tet_gradient_and_merged_backward_equal_the_reference_forms():
+    """Round 4: (i) `canonical_gradient` given per TETRAHEDRON ((T,3,3), read through tetra_id) is bit-identical to the
+    reference's per-Gaussian copy of the same matrices; (ii) the block-merged backward (one partial per workgroup and vertex,
+    a DPP row per vertex) equals the per-corner-record backward to float summation order, for a sorted and a random binding
+    and sizes around the workgroup boundary."""
+    from d3ga_amd import cage_deform as cd
+    from d3ga_amd import synthetic as syn
+    sc = syn.make_scene("C1")
+    canon, tetras = sc["canon_points"].to(DEV), sc["tetras"].to(DEV).int()
+    per_tet = cd.canonical_gradient_per_tet(canon, tetras)
+    g = torch.Generator().manual_seed(4)
+    for P, shuffle in ((10000, False), (10000, True), (257, False), (255, True), (1, False)):
+        idx = torch.randperm(10000, generator=g)[:P] if shuffle else torch.arange(P)
+        tid = sc["tetra_id"][idx].to(DEV).int().contiguous()
+        barys, rots = sc["barys"][idx].to(DEV).contiguous(), sc["rotation"][idx].to(DEV).contiguous()
+        scal = sc["scaling"][idx].to(DEV).contiguous()
+        per_g = per_tet[tid.long()].contiguous()
+        assert torch.equal(per_g, cd.canonical_gradient(canon, tetras, tid))
+        gm, gc = torch.randn(P, 3, generator=g).to(DEV), torch.randn(P, 6, generator=g).to(DEV)
+        tp0 = canon + 0.01 * torch.randn(canon.shape, generator=g).to(DEV)
+
+        def run(cg, merged):
+            cd._merge_policy["enabled"] = merged
+            try:
+                tp, b, s_, r = (_cu(t, True) for t in (tp0, barys, scal, rots))
+                m, c = cd.cage_deform(tp, tetras, tid, b, cg, s_, r, scale_activation="exp")
+                ((m * gm).sum() + (c * gc).sum()).backward()
+                return m, c, tp.grad, b.grad, s_.grad, r.grad
+            finally:
+                cd._merge_policy["enabled"] = True
+        ref = run(per_g, False)
+        for cg, merged in ((per_tet, False), (per_g, True), (per_tet, True)):
+            out = run(cg, merged)
+            for k, (a, b_) in enumerate(zip(out, ref)):
+                if k == 2 and merged:                      # vertex gradient: another (fixed) summation order
+                    assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max()) + 1e-12, (P, shuffle, merged)
+                else:
+                    assert torch.equal(a, b_), (P, shuffle, merged, k)
+        again = run(per_tet, True)                          # no atomics: bit-reproducible
+        assert torch.equal(again[2], out[2])
+
+
 def test_cage_deform_fused_activations_equal_the_unfused_composition():
     """delta_barys / scale_activation="exp" (cage_net.py:213-214 fused into the kernels) against the same op fed with
     barys + delta and exp(scaling) computed by ATen: values and all parameter gradients."""
