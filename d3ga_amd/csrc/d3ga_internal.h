@@ -15,7 +15,7 @@ static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 // Per-Gaussian state written by the preprocess kernel (structure of arrays, 256-byte aligned sections).
 struct GeomBuf {
     float *depth;       // P      view-space z
-    float2 *xy;         // P      pixel-space centre
+    float2 *xy;         // P      (unused since round 4: the kernels read the centre from the xyh record)
     float4 *conic_o;    // P      conic (a,b,c) + opacity
     float4 *rgb_invd;   // P      colour + 1/depth
     uint2 *rect;        // P      tile rectangle packed: x = minx | miny<<16, y = maxx | maxy<<16

@@ -47,8 +47,8 @@ __device__ unsigned long long g_diag_fwd_waves[32768 * 4];    // per active wave
 template <bool DUAL, bool DEPTH, bool L1V>
 __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
-    uint64_t dcap, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
-    const float4 *__restrict__ rgb_invd, const float4 *__restrict__ xyh, const float *__restrict__ bg,
+    uint64_t dcap, const float2 *xy /* = xyh viewed as float2: the centre is record[0..1], stride 2 (round 4: no separate xy array) */, const float4 *__restrict__ conic_o,
+    const float4 *__restrict__ rgb_invd, const float4 *xyh, const float *__restrict__ bg,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
     float *__restrict__ out_invdepth, const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2,
     const float *__restrict__ bg2, float *__restrict__ out_color2, uint2 *__restrict__ blk_list,
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
         bpg = make_uint2(0u, 0u);
         if ((uint32_t)lane < bn) {
             bpg = s_ring[(qhead + (uint32_t)lane) % kRing];
-            nxy = xy[bpg.y]; nco = conic_o[bpg.y]; nrgb = rgb_invd[bpg.y];
+            nxy = xy[2 * (size_t)bpg.y]; nco = conic_o[bpg.y]; nrgb = rgb_invd[bpg.y];
             if constexpr (DUAL) nrgb2 = make_float4(colors2[3 * (size_t)bpg.y], colors2[3 * (size_t)bpg.y + 1], colors2[3 * (size_t)bpg.y + 2], 0.f);
         }
         qhead = (qhead + bn) % kRing;
@@ -331,7 +331,7 @@ __global__ void alpha_selftest_kernel(int n, const float2 *__restrict__ xy, cons
                                       uint8_t *__restrict__ ok_out, float *__restrict__ alpha_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float2 c = xy[gid[i]];
+    const float2 c = xy[2 * (size_t)gid[i]];
     const float4 co = conic_o[gid[i]];
     const ConicQ q = conic_q(co.x, co.y, co.z);
     float al, G;
@@ -351,7 +351,7 @@ extern "C" int d3ga_selftest_alpha(int32_t P, const void *geom, int n, const int
     if (n == 0) return D3GA_OK;
     if (!geom || !gid || !px || !py || !ok) return D3GA_E_NULL;
     const GeomBuf g = carve_geom(const_cast<void *>(geom), P);
-    hipLaunchKernelGGL(d3ga::alpha_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, g.xy, g.conic_o, gid, px, py, ok, alpha);
+    hipLaunchKernelGGL(d3ga::alpha_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, reinterpret_cast<const float2 *>(g.xyh), g.conic_o, gid, px, py, ok, alpha);
     return check_launch((hipStream_t)stream, 0);
 }
 
@@ -388,7 +388,7 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
 #define D3GA_LAUNCH_FWD(DUALV, DEPTHV, L1VV)                                                                                    \
     hipLaunchKernelGGL((composite_fwd_q_kernel<DUALV, DEPTHV, L1VV>), grid, dim3(64),                                               \
                        lds_pad_bytes((const void *)composite_fwd_q_kernel<DUALV, DEPTHV, L1VV>, "D3GA_FWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
-                       bin.point_list, (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,     \
+                       bin.point_list, (uint64_t)d_capacity, reinterpret_cast<const float2 *>(g.xyh), g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,     \
                        out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact, l1v)
     if (colors2 && l1v.partials) return D3GA_E_CONFIG;
     if (colors2) { if (out_invdepth) D3GA_LAUNCH_FWD(true, true, false); else D3GA_LAUNCH_FWD(true, false, false); }

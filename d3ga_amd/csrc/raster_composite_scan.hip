@@ -77,7 +77,7 @@ __device__ __forceinline__ ScanEntry scan_gather(uint2 pg, const float2 *__restr
     e.rgb = make_float4(0.f, 0.f, 0.f, 0.f);
     e.c2r = e.c2g = e.c2b = 0.f;
     if (pg.x != 0u) {
-        e.xy = xy[pg.y]; e.co = conic_o[pg.y]; e.rgb = rgb_invd[pg.y];
+        e.xy = xy[2 * (size_t)pg.y]; e.co = conic_o[pg.y]; e.rgb = rgb_invd[pg.y];      // xy: the xyh records viewed as float2 (stride 2)
         if constexpr (DUAL) {
             e.c2r = colors2[3 * (size_t)pg.y]; e.c2g = colors2[3 * (size_t)pg.y + 1]; e.c2b = colors2[3 * (size_t)pg.y + 2];
         }
@@ -493,7 +493,7 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
 #define D3GA_LAUNCH_TILE(DUALV, SV, INVDV)                                                                                    \
     hipLaunchKernelGGL((composite_bwd_tile_kernel<DUALV, SV, INVDV>), tgrid, dim3(256),                                        \
                        lds_pad_bytes((const void *)composite_bwd_tile_kernel<DUALV, SV, INVDV>, "D3GA_BWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
-                       (uint64_t)d_capacity, g.xy, g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc, order,   \
+                       (uint64_t)d_capacity, reinterpret_cast<const float2 *>(g.xyh), g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc, order,   \
                        colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, composite_tile_assign(), l1, dL_dinvd)
     if (dL_dinvd) {                                          // inverse-depth gradient (branch dr_aa): single-image launches only
         if (colors2) return D3GA_E_CONFIG;

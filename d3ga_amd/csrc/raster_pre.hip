@@ -197,7 +197,6 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
         }
         radii[i] = sp.radius;
         geom.depth[i] = sp.depth;
-        geom.xy[i] = make_float2(sp.px, sp.py);
         // culled Gaussians keep an EMPTY rectangle: the scatter pass and the backward test visibility through it
         geom.rect[i] = sp.visible ? make_uint2((uint32_t)sp.rect[0] | ((uint32_t)sp.rect[1] << 16),
                                                (uint32_t)sp.rect[2] | ((uint32_t)sp.rect[3] << 16))
@@ -260,7 +259,6 @@ __global__ __launch_bounds__(kBlock) void recolor_kernel(d3ga_raster_params prm,
     const bool visible = ((rc.y & 0xffffu) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.x >> 16));
     const float depth = src.depth[i];
     dst.depth[i] = depth;
-    dst.xy[i] = src.xy[i];
     dst.conic_o[i] = src.conic_o[i];
     dst.xyh[i] = src.xyh[i];
     dst.rect[i] = rc;
