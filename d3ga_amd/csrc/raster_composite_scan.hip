@@ -131,7 +131,10 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     __shared__ __attribute__((aligned(16))) float s_pix_all[NW][4 * ROWF];
     __shared__ __attribute__((aligned(16))) float s_dump_all[NW][64 * 2 + 16 * PIXF];
     __shared__ __attribute__((aligned(16))) uint32_t s_cache[S * kSlot];
-    for (int i = threadIdx.x; i < S; i += 64 * NW) s_cache[i * kSlot + 10] = 0u;   // tags: every slot empty
+    // slot = (list position - 1) mod S: a list of n < S entries uses the first n slots only (init and publish stop there: a
+    // third of the publish at C4, where lists average 340 entries)
+    const int nslots = min(S, (int)(end - begin));
+    for (int i = threadIdx.x; i < nslots; i += 64 * NW) s_cache[i * kSlot + 10] = 0u;   // tags: every slot empty
     __shared__ uint32_t s_arrived;                          // wavefronts of this tile that are done (the last one publishes the cache)
     if (threadIdx.x == 0) s_arrived = 0u;
     __shared__ uint8_t s_perm[16];                          // assign 2: the tile's 16 blocks by descending list length
@@ -456,9 +459,9 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
     if (arrived != (uint32_t)(NW - 1) && !early_exit_off) return;
     if (early_exit_off) { __syncthreads(); if (wave != 0) return; }
-    for (int base = 0; base < S; base += kPerInst) {
+    for (int base = 0; base < nslots; base += kPerInst) {
         const int ent = base + min(fq, kPerInst - 1);
-        const bool mine = fq < kPerInst && ent < S;
+        const bool mine = fq < kPerInst && ent < nslots;
         const uint32_t *const sl = s_cache + min(ent, S - 1) * kSlot;
         const uint32_t tag = sl[10], gid = sl[9];
         const float val = __uint_as_float(sl[fk < 9 ? fk : 11]);
