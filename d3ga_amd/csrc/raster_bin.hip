@@ -26,28 +26,25 @@ __device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__rest
                                                uint32_t *__restrict__ big_tiles, uint32_t *__restrict__ huge_tiles,
                                                uint32_t *__restrict__ mid_tiles, uint32_t n_small, uint32_t n_mid,
                                                uint32_t n_large) {
-    // The histogram is staged through LDS in chunks of 8 tiles per thread: lane-contiguous global loads/stores with all of
-    // a thread's requests in flight at once (a thread-strided read of 8 values is 8 dependent L2 round trips), then each
-    // thread scans its 8 consecutive values from LDS (two 16-byte reads) and a wavefront scan + 16 LDS totals finish it.
+    // 8 CONSECUTIVE tiles per thread, moved with two 16-byte loads / stores per array (lane-contiguous: 2 KB per wavefront
+    // and instruction), a wavefront scan + 16 LDS totals: ONE barrier per chunk of 8192 tiles.  (Rounds 2-3 staged the
+    // counts and the results through LDS, three barriers per chunk: the scan workgroup was the 8-10 us of this launch.)
     constexpr int kPer = 8, kChunk = kPer * kScanBlock;
-    __shared__ __attribute__((aligned(16))) uint32_t s_c[kChunk];
-    __shared__ uint32_t s_wave[kScanBlock / 64];
+    __shared__ uint32_t s_wave[2][kScanBlock / 64];
     __shared__ uint32_t s_max;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_max = 0;
     uint32_t carry = 0, mx = 0;
-    for (int c0 = 0; c0 < tiles; c0 += kChunk) {
-        __syncthreads();                                   // previous chunk's LDS reads are done
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int t = c0 + k * kScanBlock + tid;
-            s_c[k * kScanBlock + tid] = t < tiles ? count[t] : 0u;
-        }
-        __syncthreads();
+    int par = 0;
+    for (int c0 = 0; c0 < tiles; c0 += kChunk, par ^= 1) {
+        const int t0 = c0 + kPer * tid;
         uint32_t c[kPer];
-        {
-            const uint4 lo = reinterpret_cast<const uint4 *>(s_c)[2 * tid], hi = reinterpret_cast<const uint4 *>(s_c)[2 * tid + 1];
+        if (t0 + kPer <= tiles) {
+            const uint4 lo = reinterpret_cast<const uint4 *>(count + t0)[0], hi = reinterpret_cast<const uint4 *>(count + t0)[1];
             c[0] = lo.x; c[1] = lo.y; c[2] = lo.z; c[3] = lo.w; c[4] = hi.x; c[5] = hi.y; c[6] = hi.z; c[7] = hi.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) c[k] = t0 + k < tiles ? count[t0 + k] : 0u;
         }
         uint32_t sum = 0;
 #pragma unroll
@@ -58,12 +55,12 @@ __device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__rest
             const uint32_t v = __shfl_up(incl, off);
             if (lane >= off) incl += v;
         }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
+        if (lane == 63) s_wave[par][wave] = incl;
+        __syncthreads();                                   // (two buffers: the next chunk's totals do not race this chunk's reads)
         uint32_t wbase = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < kScanBlock / 64; ++w) {
-            const uint32_t v = s_wave[w];
+            const uint32_t v = s_wave[par][w];
             wbase += w < wave ? v : 0u;
             total += v;
         }
@@ -76,7 +73,7 @@ __device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__rest
             // work lists for the long-list sort kernels (usually empty: those launches then cost one tiny grid).  Slots are
             // reserved per WAVEFRONT (ballot + one atomic): at 4K with 2M Gaussians thousands of tiles are in the mid class
             // and one same-address global atomic per tile made this kernel 79 us.
-            const int t = c0 + kPer * tid + k;
+            const int t = t0 + k;
             const int cls = c[k] > n_large ? 2 : (c[k] > n_mid ? 1 : (c[k] > n_small ? 0 : -1));
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -91,17 +88,14 @@ __device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__rest
                 }
             }
         }
-        reinterpret_cast<uint4 *>(s_c)[2 * tid] = make_uint4(e[0], e[1], e[2], e[3]);
-        reinterpret_cast<uint4 *>(s_c)[2 * tid + 1] = make_uint4(e[4], e[5], e[6], e[7]);
-        __syncthreads();
+        if (t0 + kPer <= tiles) {
+            const uint4 lo = make_uint4(e[0], e[1], e[2], e[3]), hi = make_uint4(e[4], e[5], e[6], e[7]);
+            reinterpret_cast<uint4 *>(start + t0)[0] = lo; reinterpret_cast<uint4 *>(start + t0)[1] = hi;
+            reinterpret_cast<uint4 *>(cursor + t0)[0] = lo; reinterpret_cast<uint4 *>(cursor + t0)[1] = hi;
+        } else {
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int t = c0 + k * kScanBlock + tid;
-            if (t < tiles) {
-                const uint32_t v = s_c[k * kScanBlock + tid];
-                start[t] = v;
-                cursor[t] = v;
-            }
+            for (int k = 0; k < kPer; ++k)
+                if (t0 + k < tiles) { start[t0 + k] = e[k]; cursor[t0 + k] = e[k]; }
         }
         carry += total;
     }
