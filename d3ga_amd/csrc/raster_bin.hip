@@ -471,18 +471,25 @@ __device__ __forceinline__ bool sort_huge_tile_bucket(uint64_t *s_key, uint32_t 
     return true;
 }
 
-// one workgroup per tile; tiles with longer lists are left to the list-driven kernels below
+// Resident workgroups walk the tiles in the order of tile_scan_order_kernel (descending list length: the empty tiles are
+// last) and stop at the first empty one; tiles with longer lists are left to the list-driven kernels below.  (Rounds 2-3
+// launched one workgroup per tile: at C3 6826 of the 8160 workgroups found an empty tile -- two dependent loads each while
+// holding a slot and 24 KB of LDS -- and took as long as the 1334 that sorted: 12.8 -> .. us.)
 template <int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void tile_sort_lds_kernel(const uint32_t *__restrict__ start,
                                                               const uint64_t *__restrict__ keys,
-                                                              uint32_t *__restrict__ point_list, uint64_t dcap) {
+                                                              uint32_t *__restrict__ point_list, uint64_t dcap,
+                                                              const uint32_t *__restrict__ order, int tiles) {
     __shared__ uint64_t s_key[CAP];
     __shared__ uint32_t s_bin[CAP + 1];
     __shared__ uint32_t s_red[2 * (BLOCK / 64)];
-    const int tile = blockIdx.x;
-    const uint32_t n = start[tile + 1] - start[tile];
-    if (n == 0 || n > (uint32_t)CAP) return;
-    sort_one_tile_bucket<BLOCK, CAP>(s_key, s_bin, s_red, tile, start, keys, point_list, dcap);
+    for (int rank = blockIdx.x; rank < tiles; rank += gridDim.x) {
+        const int tile = (int)order[rank];
+        const uint32_t n = start[tile + 1] - start[tile];
+        if (n == 0) return;                                  // (uniform) every later rank is empty as well
+        if (n <= (uint32_t)CAP) sort_one_tile_bucket<BLOCK, CAP>(s_key, s_bin, s_red, tile, start, keys, point_list, dcap);
+        __syncthreads();                                     // the LDS arrays are reused
+    }
 }
 
 // persistent grid over a work list written by the scan workgroup of tile_scan_order_kernel (tiles whose list does not fit the kernel above);
@@ -551,8 +558,21 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
     hipLaunchKernelGGL(tile_scatter_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, prm->P, gx, g.rect,
                        g.depth, bin.tile_cursor, bin.keys, (uint64_t)d_capacity);
     D3GA_TRY(check_launch(s, prm->debug));
-    hipLaunchKernelGGL((tile_sort_lds_kernel<256, kSortSmall>), dim3(tiles), dim3(256), 0, s, bin.tile_start, bin.keys,
-                       bin.point_list, (uint64_t)d_capacity);
+    {
+        static int resident[64] = {};                        // per device: workgroups of the per-tile sort the chip holds at once
+        int dev = 0;
+        D3GA_HIP(hipGetDevice(&dev));
+        int want = (dev >= 0 && dev < 64) ? resident[dev] : 0;
+        if (want == 0) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)tile_sort_lds_kernel<256, kSortSmall>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            want = per_cu * cus;
+            if (dev >= 0 && dev < 64) resident[dev] = want;
+        }
+        hipLaunchKernelGGL((tile_sort_lds_kernel<256, kSortSmall>), dim3(tiles < want ? tiles : want), dim3(256), 0, s, bin.tile_start,
+                           bin.keys, bin.point_list, (uint64_t)d_capacity, (const uint32_t *)bin.tile_order, tiles);
+    }
     D3GA_TRY(check_launch(s, prm->debug));
     // longer lists: persistent grids driven by the device-side work lists (empty for avatar-sized scenes), 256 workgroups each.
     // (Round 3 also tried sorting the 2049..4096 class inside the per-tile kernel, in segments: one launch less, but a single
