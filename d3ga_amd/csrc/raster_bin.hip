@@ -66,27 +66,37 @@ __device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__rest
         }
         uint32_t run = carry + wbase + incl - sum;
         uint32_t e[kPer];
+        int cls[kPer];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             e[k] = run;
             run += c[k];
-            // work lists for the long-list sort kernels (usually empty: those launches then cost one tiny grid).  Slots are
-            // reserved per WAVEFRONT (ballot + one atomic): at 4K with 2M Gaussians thousands of tiles are in the mid class
-            // and one same-address global atomic per tile made this kernel 79 us.
-            const int t = t0 + k;
-            const int cls = c[k] > n_large ? 2 : (c[k] > n_mid ? 1 : (c[k] > n_small ? 0 : -1));
+            cls[k] = c[k] > n_large ? 2 : (c[k] > n_mid ? 1 : (c[k] > n_small ? 0 : -1));
+        }
+        // work lists for the long-list sort kernels (usually empty: those launches then cost one tiny grid).  Slots are reserved
+        // per WAVEFRONT AND CLASS for all of a thread's 8 tiles at once: a wavefront scan of the per-lane counts and ONE returning
+        // atomic.  (One same-address global atomic per tile made this kernel 79 us at 4K with 2M Gaussians, where thousands of
+        // tiles are in the mid class; one per wavefront, class and k -- up to 24 dependent round trips per chunk -- 34 us.)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const unsigned long long m = __ballot(cls == q);
-                if (m == 0) continue;                                   // wave-uniform
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&counters[q == 0 ? D3GA_CNT_MID : (q == 1 ? D3GA_CNT_BIG : D3GA_CNT_HUGE)], (uint32_t)__popcll(m));
-                base = (uint32_t)__shfl((int)base, 0);
-                if (cls == q) {
-                    uint32_t *list = q == 0 ? mid_tiles : (q == 1 ? big_tiles : huge_tiles);
-                    list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)t;
-                }
+        for (int q = 0; q < 3; ++q) {
+            uint32_t nq = 0;
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) nq += cls[k] == q ? 1u : 0u;
+            if (__ballot(nq != 0u) == 0ull) continue;                    // wave-uniform
+            uint32_t inq = nq;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = __shfl_up(inq, off);
+                if (lane >= off) inq += v;
             }
+            const uint32_t tot = (uint32_t)__shfl((int)inq, 63);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&counters[q == 0 ? D3GA_CNT_MID : (q == 1 ? D3GA_CNT_BIG : D3GA_CNT_HUGE)], tot);
+            uint32_t pos = (uint32_t)__shfl((int)base, 0) + inq - nq;
+            uint32_t *list = q == 0 ? mid_tiles : (q == 1 ? big_tiles : huge_tiles);
+#pragma unroll
+            for (int k = 0; k < kPer; ++k)
+                if (cls[k] == q) list[pos++] = (uint32_t)(t0 + k);
         }
         if (t0 + kPer <= tiles) {
             const uint4 lo = make_uint4(e[0], e[1], e[2], e[3]), hi = make_uint4(e[4], e[5], e[6], e[7]);
