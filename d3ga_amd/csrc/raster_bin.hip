@@ -217,8 +217,10 @@ __global__ __launch_bounds__(kBlock) void tile_scatter_kernel(int P, int gx, con
                                                               uint32_t *__restrict__ cursor, uint64_t *__restrict__ keys,
                                                               uint64_t dcap) {
     __shared__ int s_box[4];
-    __shared__ uint32_t s_cnt[kWinTiles];     // pass A: per-tile count of this block; pass C: running slot counter
-    __shared__ uint32_t s_base[kWinTiles];    // pass B: first slot reserved for this block in each tile's list
+    // pass A: per-tile count of this block; pass B: the first slot reserved for the block in the tile's list; pass C: the running
+    // slot.  ONE array (round 4: a second one for the bases made it 32 KB -- four workgroups per CU, 1.9 rounds of the 1954
+    // workgroups at C3; with 16 KB the launch is one round)
+    __shared__ uint32_t s_cnt[kWinTiles];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kBlock + tid;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
@@ -242,15 +244,14 @@ __global__ __launch_bounds__(kBlock) void tile_scatter_kernel(int P, int gx, con
         const float inv_w = 1.0f / (float)win.w;
         for (int k = tid; k < area; k += kBlock) {           // ONE global (returning) atomic per touched tile
             const uint32_t c = s_cnt[k];
-            if (c) s_base[k] = atomicAdd(&cursor[win.tile_of(k, gx, inv_w)], c);
-            s_cnt[k] = 0;
+            if (c) s_cnt[k] = atomicAdd(&cursor[win.tile_of(k, gx, inv_w)], c);
         }
         __syncthreads();
         if (visible)
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx) {
                     const int l = (ty - win.y0) * win.w + (tx - win.x0);
-                    const uint32_t pos = s_base[l] + atomicAdd(&s_cnt[l], 1u);
+                    const uint32_t pos = atomicAdd(&s_cnt[l], 1u);
                     if (pos < dcap) keys[pos] = key;
                 }
     } else if (visible) {
