@@ -93,6 +93,10 @@ def parse():
     ap.add_argument("--init-timing", action="store_true",
                     help="also time the init-time helpers at the workload's size: compute_bary (point -> tet + barycentrics, "
                          "lib/cage.py:325-327) and the 3-NN scale seed (models/cage_net.py:66), uniform grid vs exhaustive")
+    ap.add_argument("--canon-grad", choices=("per-gaussian", "per-tet"), default=os.environ.get("D3GA_BENCH_CANON_GRAD", "per-gaussian"),
+                    help="layout of the inverse canonical gradient handed to cage_deform: 'per-gaussian' = (P,3,3), the form the reference "
+                         "stores (lib/cage.py:329) and therefore the drop-in path (default since round 5, ADVICE r4); 'per-tet' = one matrix per "
+                         "tetrahedron read through tetra_id (an extension: -3 us per frame at C3)")
     ap.add_argument("--pmc", action="store_true",
                     help="collect the HBM / SQ counters of the compositing kernels with rocprofv3 (separate --pmc passes of this "
                          "same command, MI355X_MICROARCH.md) into profiles/pmc_<workload>.json, then run normally")
@@ -102,7 +106,7 @@ def parse():
 class Frame:
     """Avatar parameters + one camera, resident on the device."""
 
-    def __init__(self, wl_name, dev, view_index, n_views=8, scale_mult=1.0, fill=0.85, order="tet"):
+    def __init__(self, wl_name, dev, view_index, n_views=8, scale_mult=1.0, fill=0.85, order="tet", canon_grad="per-gaussian"):
         from d3ga_amd import synthetic as syn
         from d3ga_amd.cage_deform import canonical_gradient
         self.syn = syn
@@ -117,9 +121,10 @@ class Frame:
         self.canon, self.tetras, self.tetra_id = d(sc["canon_points"]), d(sc["tetras"]), d(sc["tetra_id"])
         self.barys0 = d(sc["barys"])
         self.joint_mats, self.skin_idx, self.skin_w = d(sc["joint_mats"]), d(sc["skin_idx"]), d(sc["skin_w"])
-        # one inverse canonical gradient per TETRAHEDRON, read through tetra_id (cage_deform accepts the reference's per-Gaussian
-        # copy of the same matrices as well: --canon-grad per-gaussian; lib/cage.py:329 stores that form)
-        if os.environ.get("D3GA_BENCH_CANON_GRAD", "per-tet") == "per-tet":
+        # the inverse canonical gradient per GAUSSIAN, as the reference stores it (lib/cage.py:329): the drop-in layout is the one
+        # that is timed.  --canon-grad per-tet: one matrix per TETRAHEDRON read through tetra_id (extension, round 4)
+        self.canon_grad_mode = canon_grad
+        if canon_grad == "per-tet":
             from d3ga_amd.cage_deform import canonical_gradient_per_tet
             self.canon_grad = canonical_gradient_per_tet(self.canon, self.tetras).contiguous()
         else:
@@ -172,7 +177,7 @@ class Frame:
         tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
         # canon_barys = barys + delta_bary, scales = exp(scaling) (cage_net.py:213-214): fused into the deform kernels
         means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad, p["scaling"],
-                                  p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp")
+                                  p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp", gradient_per_tet=self.canon_grad_mode == "per-tet")
         # opacity = sigmoid(opacities) (cage_net.py:247): fused into the per-Gaussian kernels (pkg["opacity_logits"])
         return {"means3D": means, "cov3D_precomp": cov6, "opacity_logits": p["opacity"],
                 "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
@@ -239,12 +244,13 @@ class Frame:
             log_scales = p["scaling"] + d_scale
             means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad,
                                       log_scales, p["rotation"] + d_rot, delta_barys=d_bary,
-                                      scale_activation="exp")                                      # :213-230
+                                      scale_activation="exp", gradient_per_tet=self.canon_grad_mode == "per-tet")                                      # :213-230
         else:
             tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
             log_scales = p["scaling"]
             means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad, p["scaling"],
-                                      p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp")
+                                      p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp",
+                                      gradient_per_tet=self.canon_grad_mode == "per-tet")
         pkg = {"means3D": means, "cov3D_precomp": cov6, "opacity_logits": p["opacity"],
                "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
         if with_fields == "color":
@@ -471,7 +477,7 @@ def deform_gpu_comparison(frame, reps=50):
     def fused():
         tp = lbs_cage(frame.canon, p["delta_node"], frame.joint_mats, frame.skin_idx, frame.skin_w)
         m, c = cage_deform(tp, frame.tetras, frame.tetra_id, frame.barys0, frame.canon_grad, p["scaling"], p["rotation"],
-                           delta_barys=p["delta_bary"], scale_activation="exp")
+                           delta_barys=p["delta_bary"], scale_activation="exp", gradient_per_tet=frame.canon_grad_mode == "per-tet")
         (m.sum() + c.sum()).backward()
 
     def unfused():
@@ -705,7 +711,7 @@ def color_train_bench(args):
     d3ga_amd.lib()
     from d3ga_amd import rasterizer as R
     wl_name = args.workload if args.workload != "C3" or "--workload" in sys.argv else "C4"
-    frame = Frame(wl_name, dev, view_index=rank % 8)
+    frame = Frame(wl_name, dev, view_index=rank % 8, canon_grad=args.canon_grad)
     R.set_accumulator_policy("persistent")
     kw = dict(with_fields="color", pair=True, scale_weight=175.0)
     frame.train_step(**kw)                                 # creates the three networks (seeded: identical on every rank), sizes the scratch
@@ -897,7 +903,8 @@ def main():
 
     if args.pmc and world == 1:
         collect_pmc(args)
-    frame = Frame(args.workload, dev, view_index=rank % 8, scale_mult=args.scale_mult, fill=args.fill, order=args.gaussian_order)
+    frame = Frame(args.workload, dev, view_index=rank % 8, scale_mult=args.scale_mult, fill=args.fill, order=args.gaussian_order,
+                  canon_grad=args.canon_grad)
     frame.fused_l1 = not args.no_fused_l1
     kv = max(int(args.views_per_rank), 1)
     if kv > 1:
@@ -1393,7 +1400,7 @@ def main():
                                    + {"tet": "", "random": " [sensitivity: Gaussians in random index order]",
                                       "morton": " [sensitivity: Gaussians shuffled, then numbered by tetra.spatial_order]"}[args.gaussian_order],
                        "gaussians": P, "width": W, "height": H, "sh_degree": wl.sh_degree,
-                       "duplicates_D": D, "max_tile_list": cnt_end["max_tile"], "visible": cnt_end["visible"],
+                       "canon_grad": frame.canon_grad_mode, "duplicates_D": D, "max_tile_list": cnt_end["max_tile"], "visible": cnt_end["visible"],
                        "views_per_step": world * kv, "views_per_rank": kv, "parallelism": f"camera-sharded dp{world}",
                        "grad_exchange": ("none" if world == 1 else "cut: all-reduce of the rasterizer-input gradients + "
                                          "all-gather of the factored SH gradient" if cut else "per-parameter all-reduce"),

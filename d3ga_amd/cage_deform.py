@@ -187,6 +187,10 @@ def cage_deform(tetpoints, tetras, tetra_id, barys, canonical_gradient, scales, 
         raise ValueError(f"scale_activation must be None or 'exp', got {scale_activation!r}")
     P, T = barys.shape[0], tetras.shape[0]
     if gradient_per_tet is None:             # (T,3,3) is recognised by its length unless T == P (then say which)
+        if canonical_gradient.shape[0] == T and T == P:
+            import warnings
+            warnings.warn("cage_deform: as many tetrahedra as Gaussians -- canonical_gradient is read per GAUSSIAN (the reference's "
+                          "layout, lib/cage.py:329); pass gradient_per_tet=True if it is the per-tetrahedron table", stacklevel=2)
         gradient_per_tet = canonical_gradient.shape[0] == T and T != P
     if canonical_gradient.shape[0] != (T if gradient_per_tet else P):
         raise ValueError(f"canonical_gradient has {canonical_gradient.shape[0]} matrices, expected "

@@ -455,7 +455,11 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     // per record, seven records per instruction.
     if (D3GA_SCAN_ABL == 13 || D3GA_SCAN_ABL == 1) return;
     uint32_t arrived = 0u;
-    if (lane == 0) arrived = atomicAdd(&s_arrived, 1u);
+    // acq_rel at workgroup scope: this wavefront's cache stores are ordered BEFORE its arrival, and the publisher's reads of the
+    // cache AFTER it has seen the others' arrivals -- by the memory model, not only by in-order LDS issue
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // every lane's cache stores (not only lane 0's) before the arrival
+    if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
     if (arrived != (uint32_t)(NW - 1) && !early_exit_off) return;
     if (early_exit_off) { __syncthreads(); if (wave != 0) return; }

@@ -503,6 +503,9 @@ extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const f
     if (shs && !dL_dsh && !dL_dcolors) return D3GA_E_NULL;        // SH path: full block or factored (P,3) output
     if ((dL_dscales != nullptr) != (dL_drots != nullptr)) return D3GA_E_CONFIG;
     if (dL_dscales && (!scales || !rotations)) return D3GA_E_NULL;
+    // the covariance the forward worked with: built from (scales, rotations) -> the geometry record holds it; precomputed -> the
+    // forward kept NO copy (ABI 101), the caller's tensor is read again: a NULL here would mean uninitialised records
+    if (!cov3D_precomp && !(scales && rotations)) return D3GA_E_NULL;
     hipStream_t s = (hipStream_t)stream;
     GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
     const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? kShLdsBytes : 0;

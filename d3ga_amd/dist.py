@@ -362,7 +362,11 @@ class BucketedGradReducer:
         return 4 * sum(p.numel() for b in self.buckets for p in b)
 
     def _make_hook(self, i):
-        def hook(_param):
+        def hook(param):
+            # a non-contiguous .grad (autograd may hand one over for an expanded / transposed leaf) cannot be all-reduced in
+            # place, and reshape(-1) of it is a COPY -- the averaged values would land in a temporary
+            if param.grad is not None and not param.grad.is_contiguous():
+                param.grad = param.grad.contiguous()
             self._left[i] -= 1
             if self._left[i] == 0:
                 self._launch(i)
@@ -380,7 +384,7 @@ class BucketedGradReducer:
             t = b[0].grad
         else:
             t = self._flat[i]
-            torch._foreach_copy_(list(t.split([p.numel() for p in b])), [p.grad.reshape(-1) for p in b])
+            torch._foreach_copy_(list(t.split([p.numel() for p in b])), [p.grad.reshape(-1) for p in b])      # (contiguous: the hook saw to it)
         w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if dist.is_initialized() else None
         self._work.append((i, w, e0 if timed else None))
 
@@ -409,7 +413,7 @@ class BucketedGradReducer:
             else:
                 parts = list(self._flat[i].split([p.numel() for p in b]))
                 torch._foreach_mul_(parts, inv)
-                torch._foreach_copy_([p.grad.reshape(-1) for p in b], parts)
+                torch._foreach_copy_([p.grad for p in b], [q.view_as(p.grad) for p, q in zip(b, parts)])
             if e0 is not None:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()

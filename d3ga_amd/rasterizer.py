@@ -223,7 +223,7 @@ def _tkey(t):
 
 
 def _geometry_key(prm, cap_mode, tensors):
-    return (prm.P, prm.W, prm.H, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.opacity_activation, cap_mode) + tuple(
+    return (prm.P, prm.W, prm.H, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.opacity_activation, prm.antialiasing, cap_mode) + tuple(
         _tkey(t) for t in tensors)
 
 

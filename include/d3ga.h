@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define D3GA_VERSION 100 /* 0.1.0 */
+#define D3GA_VERSION 101 /* 0.1.1: d3ga_raster_preprocess_bwd / d3ga_raster_backward* read cov3D_precomp again (the forward keeps no copy); NULL without (scales, rotations) is D3GA_E_NULL */
 
 #define D3GA_OK 0
 #define D3GA_E_NULL (-1)     /* required pointer is NULL */
@@ -258,7 +258,8 @@ int d3ga_raster_recolor(const d3ga_raster_params *prm, const float *means3D, con
  * SH path with dL_dsh == NULL and dL_dcolors != NULL: FACTORED SH gradient -- dL_dcolors receives the clamp-masked
  * dL/dcolour (the (P,3) factor of the rank-1 SH gradient, see d3ga_sh_grad_from_views); dL/dmeans3D is complete.
  * cov3D_precomp: the SAME tensor, unchanged, that the forward was given (or NULL with scales / rotations): since round 4 the
- * forward keeps no copy of a precomputed covariance in `geom` (24 B x P less written per frame), the backward reads it here. */
+ * forward keeps no copy of a precomputed covariance in `geom` (24 B x P less written per frame), the backward reads it here;
+ * cov3D_precomp == NULL without (scales, rotations) returns D3GA_E_NULL (ABI 101). */
 int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const float *means3D, const float *shs,
                                const float *scales, const float *rotations, const float *cov3D_precomp,
                                const float *viewmatrix, const float *projmatrix, const float *campos,

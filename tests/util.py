@@ -133,3 +133,14 @@ def conditioning_noise(ctx, gpix, grads, gamma=SUM_NOISE_GAMMA, patterns=None):
                 d = 2.0 * np.abs(np.asarray(g2[k], np.float64) - np.asarray(v, np.float64))
                 out[k] = out[k] + d if exact else np.maximum(out[k], d)
     return out
+
+
+def sampled_allowance_excess(par, ctx, gpix, mine, ref, key, seeds=(1, 2, 3, 4, 5, 6)):
+    """NON-FATAL second opinion: the tighter allowance of rounds 2-3 -- the maximum over six random sign patterns of
+    the probe instead of the exact first-order worst case -- evaluated on a tensor that needed the allowance at all.  Returns the
+    excess ratio under that older bar and prints it, so that a kernel change which starts to lean on the wider bar shows up in
+    the test log (campaign logs: `grep "sampled allowance"`) instead of hiding inside it."""
+    noise = conditioning_noise(ctx, gpix, {key: ref}, patterns=list(seeds))[key]
+    _, excess, _, _ = par.grads(mine, ref, noise=noise)
+    print(f"[parity] {key}: x{excess:.2f} of the SAMPLED allowance (rounds 2-3 bar; informational, the exact worst case is the bar)")
+    return excess
