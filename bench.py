@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events")
+    ap.add_argument("--stage-burst", type=int, default=4,
+                    help="stage events: launches of each compositing kernel between its two HIP events (queue kept full: the "
+                         "quotient is the kernel's duration, not duration + dispatch latency; 1 = rounds 1-4 behaviour)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for tests)")
     ap.add_argument("--single-device", action="store_true", help="testing only: all ranks share cuda:0")
     ap.add_argument("--reduce", choices=("cut", "params"), default="cut",
@@ -1196,6 +1199,9 @@ def main():
     if not args.no_stage_events:
         R.stage_timer.enabled = True
         R.stage_timer.reset()
+        # the two compositing kernels (the roofline kernels) are launched 4x back to back between their event pair: the quotient
+        # is the kernel's duration without the dispatch latency of a lone launch on an idle queue (rasterizer.StageTimer)
+        R.stage_timer.burst = {"composite_fwd": args.stage_burst, "composite_bwd": args.stage_burst}
         for _ in range(args.steps):
             one_step()
         torch.cuda.synchronize()
@@ -1420,7 +1426,8 @@ def main():
                                                              else "one hipGraph incl. the collectives" if graph is not None else "eager"))}
                if dist_info else {}),
             **({"grad_exchange_note": exchange_note} if exchange_note else {}),
-            "stage_events": "separate eager pass, same K steps" if graph is not None else "none" if args.no_stage_events else "separate eager pass",
+            "stage_events": ("none" if args.no_stage_events else ("separate eager pass, same K steps" if graph is not None else "eager pass")
+                             + f"; compositing kernels launched {args.stage_burst}x back to back per event pair"),
         }
         if train is not None:
             out["training_step"] = train

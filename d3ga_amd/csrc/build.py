@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["deform.hip", "raster_pre.hip", "raster_bin.hip", "raster_composite.hip", "raster_composite_scan.hip", "raster_api.hip", "bary.hip", "loss.hip", "mlp.hip", "encoding.hip"]
+SOURCES = ["deform.hip", "raster_pre.hip", "raster_bin.hip", "raster_composite.hip", "raster_composite_lists.hip", "raster_composite_scan.hip", "raster_api.hip", "bary.hip", "loss.hip", "mlp.hip", "encoding.hip"]
 HEADERS = ["d3ga_math.h", "d3ga_internal.h", "raster_pre_body.h", "composite_common.h", os.path.join("..", "..", "include", "d3ga.h")]
 ABL = os.environ.get("D3GA_SCAN_ABL")       # timing ablation of the compositing backward (wrong results): own objects + .so
 VARIANT = os.environ.get("D3GA_VARIANT")    # A/B build of compile-time knobs: "tag:-DNAME=value,-DOTHER=value" -> tools/_build/libd3ga_hip_<tag>.so (correct results)
@@ -26,6 +26,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 # v_pk_* costs ~35 register shuffles per 4 pixels (ISA inspected) and a v_pk_fma_f32 issues in 4.2 cycles against 2.4 for a
 # v_fma_f32 (tools/micro/valu_issue.hip), so the vectoriser is off for the two compositing files.
 EXTRA = {"raster_composite_scan.hip": ["-fno-slp-vectorize"],
+         "raster_composite_lists.hip": ["-fno-slp-vectorize"],
          "raster_composite.hip": ["-fno-slp-vectorize"]}      # forward 117 -> 103 us at C3: packed f32 ops cost 2x, plus their shuffles
 if os.environ.get("D3GA_CHAIN_WAVES"):                        # A/B: wavefronts per workgroup of the fused field-network kernel
     FLAGS.append("-DD3GA_CHAIN_WAVES=" + os.environ["D3GA_CHAIN_WAVES"])

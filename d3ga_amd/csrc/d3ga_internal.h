@@ -23,10 +23,12 @@ struct GeomBuf {
     float *cov3D;       // P*6    3D covariance actually used (precomputed copy or from scale/rotation)
     float4 *xyh;        // P      pixel-space centre | half extents of the alpha >= 1/255 ellipse's bounding box (splat_cull):
                         //        the 16-byte record the compositing forward's first stage tests a list entry with
+    uint4 *span;        // P      round 5: the 4x4-pixel BLOCKS the alpha >= 1/255 ellipse can touch, as one column interval per
+                        //        block line (composite_common.h: splat_spans) -- what tile_cull_kernel builds the block lists from
 };
 static inline int64_t geom_bytes(int64_t P) {
     return align256(4 * P) + align256(8 * P) + align256(16 * P) + align256(16 * P) + align256(8 * P) + align256(P) +
-           align256(24 * P) + align256(16 * P);
+           align256(24 * P) + align256(16 * P) + align256(16 * P);
 }
 static inline GeomBuf carve_geom(void *base, int64_t P) {
     char *p = (char *)base;
@@ -38,7 +40,8 @@ static inline GeomBuf carve_geom(void *base, int64_t P) {
     g.rect = (uint2 *)p;      p += align256(8 * P);
     g.clamped = (uint8_t *)p; p += align256(P);
     g.cov3D = (float *)p;     p += align256(24 * P);
-    g.xyh = (float4 *)p;
+    g.xyh = (float4 *)p;      p += align256(16 * P);
+    g.span = (uint4 *)p;
     return g;
 }
 
@@ -82,11 +85,15 @@ struct ImgBuf {
     // a 16x16 tile has 16 blocks (quadrant q = 0..3, row r = 0..3 of that quadrant's wavefront -> block 4q + r); the
     // list of block b of a tile whose depth-sorted list is [begin, end) occupies blk_list[16*begin + b*(end-begin) ...],
     // blk_count[16*tile + b] entries {1-based position in the tile list, Gaussian index}, front to back.
+    // Round 5 (raster_composite_lists.hip): the lists are built by a pass of their own (tile_cull_kernel: every entry of a tile's
+    // sorted list against the tile's 16 blocks, blk_total entries per block) BEFORE the blend; the blend walks them and leaves in
+    // blk_count the length of the prefix that holds every entry some pixel of the block blended -- what the backward walks.
     uint32_t *blk_count;   // 16 * tiles
+    uint32_t *blk_total;   // 16 * tiles   entries the cull pass wrote per block (>= blk_count)
     uint2 *blk_list;       // 16 * d_capacity
 };
 static inline int64_t img_bytes(int64_t W, int64_t H, int64_t tiles, int64_t dcap) {
-    return 2 * align256(4 * W * H) + align256(64 * tiles) + align256(128 * dcap);
+    return 2 * align256(4 * W * H) + 2 * align256(64 * tiles) + align256(128 * dcap);
 }
 static inline ImgBuf carve_img(void *base, int64_t W, int64_t H, int64_t tiles) {
     ImgBuf i;
@@ -94,6 +101,7 @@ static inline ImgBuf carve_img(void *base, int64_t W, int64_t H, int64_t tiles) 
     i.final_T = (float *)p;        p += align256(4 * W * H);
     i.n_contrib = (uint32_t *)p;   p += align256(4 * W * H);
     i.blk_count = (uint32_t *)p;   p += align256(64 * tiles);
+    i.blk_total = (uint32_t *)p;   p += align256(64 * tiles);
     i.blk_list = (uint2 *)p;
     return i;
 }

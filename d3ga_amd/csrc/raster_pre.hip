@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     const float *__restrict__ colors_precomp, const float *__restrict__ opacities, const float *__restrict__ scales,
     const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, const float *__restrict__ viewmatrix,
     const float *__restrict__ projmatrix, const float *__restrict__ campos, GeomBuf geom,
-    uint32_t *__restrict__ tile_count, uint32_t *__restrict__ counters, int32_t *__restrict__ radii) {
+    uint32_t *__restrict__ tile_count, uint32_t *__restrict__ counters, int32_t *__restrict__ radii, int exact_cull) {
     if (!(prm.tanfovx > 0.f)) { prm.tanfovx = campos[3]; prm.tanfovy = campos[4]; }     // camera slot: see d3ga.h
     // one dynamic LDS region, used first as the SH staging slabs and then (after a barrier) as the tile window
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -205,6 +205,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
         {   // half extents of the splat's alpha >= 1/255 box, by the function the compositing stage culls with (bit-identical)
             const SplatCull sc = splat_cull(sp.conic[0], sp.conic[1], sp.conic[2], o.opacity);
             geom.xyh[i] = make_float4(sp.px, sp.py, sp.visible ? sc.hx : -1.0f, sc.hy);
+            // round 5: the blocks the splat can touch, one column interval per block line (tile_cull_kernel decodes it per tile)
+            geom.span[i] = sp.visible ? splat_spans(sp.px, sp.py, sp.conic[0], sp.conic[1], sp.conic[2], o.opacity, exact_cull != 0)
+                                      : make_uint4(0u, 0u, 0u, 0u);
         }
         geom.rgb_invd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], sp.visible ? 1.0f / sp.depth : 0.f);
         geom.clamped[i] = o.clampmask;
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(kBlock) void recolor_kernel(d3ga_raster_params prm,
     dst.depth[i] = depth;
     dst.conic_o[i] = src.conic_o[i];
     dst.xyh[i] = src.xyh[i];
+    dst.span[i] = src.span[i];
     dst.rect[i] = rc;
 #pragma unroll
     for (int k = 0; k < 6; ++k) dst.cov3D[6 * (size_t)i + k] = src.cov3D[6 * (size_t)i + k];
@@ -469,7 +473,7 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? (kShHalfLdsBytes > win ? kShHalfLdsBytes : win) : win;
     hipLaunchKernelGGL(preprocess_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
                        colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, g,
-                       bin.tile_count, bin.counters, radii);
+                       bin.tile_count, bin.counters, radii, (composite_variant() & kVariantExactCull) ? 1 : 0);
     return check_launch(s, prm->debug & 0xff);
 }
 

@@ -117,11 +117,20 @@ def last_counters(device=None):
 
 class StageTimer:
     """Optional per-stage HIP-event timing of the rasterizer (bench.py).  While enabled the forward/backward are
-    issued stage by stage through the C ABI (same kernels, same stream) with an event pair around each stage."""
+    issued stage by stage through the C ABI (same kernels, same stream) with an event pair around each stage.
+
+    `burst` (round 5): stage name -> R.  Such a stage is launched R times back to back between ITS two events and the
+    elapsed time divided by R.  A single eager launch between two events on an idle queue also measures the dispatch
+    latency of the kernel packet (BENCH_r04: compositing backward 121 us by the event pair against 107 us in the rocprofv3
+    kernel trace of the same command); with the queue kept full the quotient is the kernel's own duration, which is what
+    `roofline.achieved` is defined on.  Only for stages that may run twice on the same inputs (the compositing kernels:
+    the forward rewrites the same outputs, the backward adds into an accumulator whose gradients nobody reads in this
+    measuring pass)."""
 
     def __init__(self):
         self.enabled = False
-        self.records = []          # (stage, start_event, end_event)
+        self.records = []          # (stage, start_event, end_event, launches between them)
+        self.burst = {}
 
     def reset(self):
         self.records = []
@@ -129,25 +138,28 @@ class StageTimer:
     def stage(self, name, fn):
         if not self.enabled:
             return fn()
+        reps = int(self.burst.get(name, 1))
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()                  # on torch's current stream == the stream the kernels are launched on
         r = fn()
+        for _ in range(reps - 1):
+            fn()
         b.record()
-        self.records.append((name, a, b))
+        self.records.append((name, a, b, reps))
         return r
 
     def summary(self):
-        """stage -> (launches, mean ms); call after torch.cuda.synchronize().  An event pair also sees any gap in which the
-        GPU waited for the host between the two records (a Python GC pause inside one eager launch shows up as a
-        multi-millisecond "kernel"), so launches longer than 5x the stage's median are left out of the mean."""
+        """stage -> (launches, mean ms per launch); call after torch.cuda.synchronize().  An event pair also sees any gap in
+        which the GPU waited for the host between the two records (a Python GC pause inside one eager launch shows up as a
+        multi-millisecond "kernel"), so samples longer than 5x the stage's median are left out of the mean."""
         per = {}
-        for name, a, b in self.records:
-            per.setdefault(name, []).append(a.elapsed_time(b))
+        for name, a, b, reps in self.records:
+            per.setdefault(name, []).append((a.elapsed_time(b) / reps, reps))
         out = {}
         for name, ts in per.items():
-            med = sorted(ts)[len(ts) // 2]
-            kept = [t for t in ts if t <= 5.0 * med] or ts
-            out[name] = (len(kept), sum(kept) / len(kept))
+            med = sorted(t for t, _ in ts)[len(ts) // 2]
+            kept = [(t, r) for t, r in ts if t <= 5.0 * med] or ts
+            out[name] = (sum(r for _, r in kept), sum(t for t, _ in kept) / len(kept))
         return out
 
 

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+D3GA_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/libd3ga_hip_timeline.so timeout 300 python tools/diag_lists.py ${1:-C3} > gpurun_out/diag_lists.log 2>&1
+grep -v "Warning\|warn\|amdgpu.ids\|return Variable" gpurun_out/diag_lists.log | tail -40
