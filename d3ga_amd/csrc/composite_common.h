@@ -66,9 +66,10 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
 int launch_composite_fwd_lists(const d3ga_raster_params *prm, int gx, int gy, const BinBuf &bin, const GeomBuf &g, const ImgBuf &im,
                                int64_t d_capacity, const float *bg, float *out_color, float *out_invdepth, const float *colors2,
                                const float *bg2, float *out_color2, bool ordered, bool exact, const L1Value &l1v, hipStream_t s);
-// D3GA_FWD_IMPL (A/B knob, read once): 1 (default) the two-launch forward for renders that are followed by a backward,
-// 0 the one-launch quadrant forward everywhere (renders with forward_only always use the latter: no block lists are allocated)
-constexpr int kDefaultFwdImpl = 1;
+// D3GA_FWD_IMPL (A/B knob, read once): 0 (default) the one-launch quadrant forward (raster_composite.hip); 1 the two-launch forward
+// of raster_composite_lists.hip for renders that are followed by a backward (measured, not faster: its list pass is latency-bound --
+// DESIGN.md sec. 4; renders with forward_only always use the one-launch forward: no block lists are allocated)
+constexpr int kDefaultFwdImpl = 0;
 static inline int composite_fwd_impl_kind() {
     static const int v = [] {
         const char *e = getenv("D3GA_FWD_IMPL");
@@ -229,30 +230,36 @@ __device__ __forceinline__ BlockHits block_hits4_exact(float cx, float cy, float
 // by the slab of a block line spans [l(dyl), r(dyr)] with  r(dy) = (-B dy + sqrt(tau A - det dy^2)) / A  (concave, maximiser
 // dy* = -(B/C) hx: the rightmost point) taken at dy* clamped into the slab, and l likewise (convex, minimiser -dy*); a block is in
 // iff its pixel columns meet that interval.  tau and the box extents are the inflated ones of splat_cull() (0.1 % + 1e-4; 0.1 % +
-// 0.02 px), the interval is padded by 0.1 % of the extent + 0.02 px, everything is intersected with the bounding box: conservative.
-// exact == false: the bounding box on every line.  Written once per Gaussian by preprocess (GeomBuf::span), decoded per (tile,
-// entry) by tile_cull_kernel with integer arithmetic only.  Layout (16 bytes):
-//   x: block line R0 of the first line (i16) | block column C0 the intervals are relative to (i16) << 16
-//   y: number of lines K, 0..4 (0: touches nothing); kSpanBig: too tall / wide / far off for this record -- the reader falls back
-//      to the geometric test (block_mask16)
-//   z | w << 32: line k in bits 16 k .. 16 k + 15:  (lo + 1) | hi << 8, columns C0 + lo .. C0 + hi; low byte 0: empty line
-constexpr uint32_t kSpanBig = 255u;
+// 0.02 px), the interval is padded by 0.1 % of the extent + 0.02 px, everything is intersected with the bounding box: conservative
+// -- the same set as block_hits4() + block_hits4_exact() up to rounding.  exact == false: the bounding box on every line.
+// Written once per Gaussian by preprocess (GeomBuf::span) and decoded per (tile | quadrant, entry) with integer arithmetic by the
+// compositing forward, instead of the geometric test per (quadrant, entry).  Layout (16 bytes):
+//   x: block line R0 of the first line (i16; kSpanBigR0: see below) | block column C0 the intervals are relative to (i16) << 16
+//   y, z, w: up to twelve lines, line k in BYTE k:  (lo + 1) | hi << 4  = columns C0 + lo .. C0 + hi (lo <= 14, hi <= 15); low
+//      nibble 0: empty line (lines past the last one are stored empty)
+//   R0 == kSpanBigR0: too tall (> 12 block lines: half height > 22 px) / wide (> 16 columns) / far off for this record -- the reader
+//      falls back to the geometric test.  (At C3 2.4 % of the splats are taller than SIX block lines: a first version with 16-bit
+//      fields and six lines sent 79 % of the forward's 64-survivor batches through the fallback.)
+constexpr int kSpanBigR0 = 0x7fff, kSpanLines = 12;
+__device__ __forceinline__ uint4 span_big() { return make_uint4((uint32_t)kSpanBigR0, 0u, 0u, 0u); }
+__device__ __forceinline__ bool span_is_big(const uint4 &sp) { return (sp.x & 0xffffu) == (uint32_t)kSpanBigR0; }
 __device__ __forceinline__ uint4 splat_spans(float cx, float cy, float A, float B, float C, float o, bool exact) {
     const SplatCull sc = splat_cull(A, B, C, o);
     if (sc.hx < 0.0f) return make_uint4(0u, 0u, 0u, 0u);
-    if (!(sc.hx < 500.f) || !(sc.hy < 500.f) || !(fabsf(cx) < 100000.f) || !(fabsf(cy) < 100000.f)) return make_uint4(0u, kSpanBig, 0u, 0u);
+    if (!(sc.hx < 500.f) || !(sc.hy < 500.f) || !(fabsf(cx) < 100000.f) || !(fabsf(cy) < 100000.f)) return span_big();
     // block lines R with 4R <= cy + hy and 4R + 3 >= cy - hy; columns of the box likewise
     const int R0 = (int)ceilf((cy - sc.hy - 3.0f) * 0.25f), R1 = (int)floorf((cy + sc.hy) * 0.25f);
     const int C0 = (int)ceilf((cx - sc.hx - 3.0f) * 0.25f), C1 = (int)floorf((cx + sc.hx) * 0.25f);
     const int K = R1 - R0 + 1;
     if (K <= 0 || C1 < C0) return make_uint4(0u, 0u, 0u, 0u);
-    if (K > 4 || C1 - C0 > 250) return make_uint4(0u, kSpanBig, 0u, 0u);
+    if (K > kSpanLines || C1 - C0 > 15) return span_big();
     const float det = A * C - B * B, rA = __builtin_amdgcn_rcpf(A), tauA = sc.tau * A;
     const float dys = sc.nbc * sc.hx;
     const float pad = 1e-3f * sc.hx + 0.02f;
-    unsigned long long rows = 0ull;
+    uint32_t w[3] = {0u, 0u, 0u};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kSpanLines; ++k) {
+        if (k >= 4 && __builtin_amdgcn_ballot_w64(k < K) == 0ull) break;     // (uniform: no lane of the wavefront has a line k)
         int lo = C0, hi = C1;
         if (exact) {
             const float ya = (float)(4 * (R0 + k)) - cy, yb = ya + 3.0f;
@@ -260,35 +267,49 @@ __device__ __forceinline__ uint4 splat_spans(float cx, float cy, float A, float 
             const float sr = __builtin_amdgcn_sqrtf(fmaxf(0.0f, tauA - det * dyr * dyr));
             const float sl = __builtin_amdgcn_sqrtf(fmaxf(0.0f, tauA - det * dyl * dyl));
             const float rmax = (sr - B * dyr) * rA + pad, lmin = (-sl - B * dyl) * rA - pad;
-            // (NaN -> the box: the comparisons below are false)
             const int l2 = (int)ceilf((cx + lmin - 3.0f) * 0.25f), h2 = (int)floorf((cx + rmax) * 0.25f);
-            if (l2 > lo && lmin == lmin) lo = l2;
+            if (l2 > lo && lmin == lmin) lo = l2;                     // (NaN -> the box)
             if (h2 < hi && rmax == rmax) hi = h2;
         }
-        const unsigned long long e = (k < K && lo <= hi) ? (unsigned long long)((uint32_t)(lo - C0 + 1) | ((uint32_t)(hi - C0) << 8)) : 0ull;
-        rows |= e << (16 * k);
+        const uint32_t f = (k < K && lo <= hi) ? ((uint32_t)(lo - C0 + 1) | ((uint32_t)(hi - C0) << 4)) : 0u;
+        w[k >> 2] |= f << (8 * (k & 3));                              // (k is a constant here: no indexed access)
     }
-    return make_uint4(((uint32_t)R0 & 0xffffu) | ((uint32_t)C0 << 16), (uint32_t)K, (uint32_t)rows, (uint32_t)(rows >> 32));
+    return make_uint4(((uint32_t)R0 & 0xffffu) | ((uint32_t)C0 << 16), w[0], w[1], w[2]);
+}
+// the 8-bit field of span line idx (empty outside 0 .. kSpanLines - 1).  Shifts, not a select over the record's words: the
+// compiler turns `idx < 4 ? sp.y : ...` into an indexed load of the record, which puts the record into SCRATCH memory (measured:
+// the forward went from 79 to 106 us)
+__device__ __forceinline__ uint32_t span_line(const uint4 &sp, int idx) {
+    const unsigned long long lo8 = (unsigned long long)sp.y | ((unsigned long long)sp.z << 32);
+    const uint32_t a = (uint32_t)(lo8 >> (8 * (idx & 7))), b = sp.w >> (8 * (idx & 3));
+    const uint32_t e = ((idx & 8) ? b : a) & 0xffu;
+    return (unsigned)idx < (unsigned)kSpanLines ? e : 0u;
+}
+// column bits (bit i = block column Cq0 + i, i < ncols) of one span line field
+__device__ __forceinline__ uint32_t span_cols(uint32_t e, int cb, int ncols) {
+    const int lo = max(cb + (int)(e & 15u) - 1, 0), hi = min(cb + (int)(e >> 4), ncols - 1);
+    return ((e & 15u) != 0u && lo <= hi) ? ((2u << hi) - (1u << lo)) : 0u;
 }
 // the 16-bit block mask (bit 4 * quadrant + block within it, as the block lists are numbered) of a span record inside the tile whose
-// first block column / line are Ct0 / Rt0; the record must not be kSpanBig
+// first block column / line are Ct0 / Rt0; the record must not be big
 __device__ __forceinline__ uint32_t span_mask16(const uint4 &sp, int Ct0, int Rt0) {
     const int R0 = (int)(int16_t)(sp.x & 0xffffu), C0 = (int)sp.x >> 16;
-    const int k0 = Rt0 - R0;                                          // span line of the tile's first block line
-    const unsigned long long rows = (unsigned long long)sp.z | ((unsigned long long)sp.w << 32);
-    // the tile's four lines in bits 16 j ..: lines outside 0 .. K-1 read as empty (zero fill; lines >= K are stored empty)
-    const unsigned long long win = k0 >= 4 || k0 <= -4 ? 0ull : (k0 >= 0 ? rows >> (16 * k0) : rows << (16 * -k0));
-    const int cb = C0 - Ct0;
+    const int k0 = Rt0 - R0, cb = C0 - Ct0;
     uint32_t mask = 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const uint32_t e = (uint32_t)(win >> (16 * j)) & 0xffffu;
-        const int lo = max(cb + (int)(e & 0xffu) - 1, 0), hi = min(cb + (int)(e >> 8), 3);
-        const uint32_t cols = ((e & 0xffu) != 0u && lo <= hi) ? (((2u << hi) - (1u << lo)) & 15u) : 0u;
+        const uint32_t cols = span_cols(span_line(sp, k0 + j), cb, 4) & 15u;
         const int p0 = 8 * (j >> 1) + 2 * (j & 1);                    // block (i, j) -> bit 8 (j >> 1) + 2 (j & 1) + {0, 1, 4, 5}[i]
         mask |= ((cols & 3u) << p0) | (((cols >> 2) & 3u) << (p0 + 4));
     }
     return mask;
+}
+// the 4-bit mask of the 2x2 blocks of one quadrant (bit = block column + 2 x block line inside the quadrant: the forward's row
+// index) whose first block column / line are Cq0 / Rq0
+__device__ __forceinline__ uint32_t span_mask4(const uint4 &sp, int Cq0, int Rq0) {
+    const int R0 = (int)(int16_t)(sp.x & 0xffffu), C0 = (int)sp.x >> 16;
+    const int k0 = Rq0 - R0, cb = C0 - Cq0;
+    return (span_cols(span_line(sp, k0), cb, 2) & 3u) | ((span_cols(span_line(sp, k0 + 1), cb, 2) & 3u) << 2);
 }
 
 __device__ __forceinline__ int lanes_below(unsigned long long m) {   // popcount of m restricted to lower lanes

@@ -26,6 +26,10 @@
 #ifndef D3GA_FWD_WAVES
 #define D3GA_FWD_WAVES 5
 #endif
+// A/B (build.py D3GA_VARIANT): 0 = blk_count is the number of entries emitted (rounds 2-4), 1 = the prefix up to the last blended entry
+#ifndef D3GA_FWD_USED
+#define D3GA_FWD_USED 1
+#endif
 
 namespace d3ga {
 
@@ -79,6 +83,11 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     }
     uint2 *const blk_base = blk_list ? blk_list + 16 * (size_t)begin + (size_t)(4 * q.quad) * blk_cap : nullptr;
     uint32_t bc0 = 0, bc1 = 0, bc2 = 0, bc3 = 0;
+    // round 5: what the backward walks is the PREFIX of a block's list up to the last entry some pixel of the block blended (a
+    // row keeps emitting the hits of the batch in which its last pixel saturates, and of every batch to the end of the tile's list
+    // when it never saturates): used r = entries of block r's list up to that one.  Formed once per batch from the pixels' `last`
+    // (a row maximum), the batch's positions and the row's hit mask -- nothing per blended entry.
+    uint32_t used0 = 0, used1 = 0, used2 = 0, used3 = 0;
 
     __shared__ float4 s_co[65];
     __shared__ float4 s_rgb[65];
@@ -186,9 +195,13 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
 #ifdef D3GA_DIAG_COUNTERS
         df_pairs += __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
 #endif
+        const uint32_t bcb0 = bc0, bcb1 = bc1, bcb2 = bc2, bcb3 = bc3;      // the blocks' counts in front of this batch
+        bool em0 = false, em1 = false, em2 = false, em3 = false;            // the rows that emit this batch's hits
         if (blk_base) {
             const unsigned long long dm = __builtin_amdgcn_ballot_w64(done);
             const uint2 rec = cpg;                        // 1-based list position, id
+            em0 = (dm & 0xffffull) != 0xffffull; em1 = ((dm >> 16) & 0xffffull) != 0xffffull;
+            em2 = ((dm >> 32) & 0xffffull) != 0xffffull; em3 = (dm >> 48) != 0xffffull;
             if ((dm & 0xffffull) != 0xffffull) {
                 if (bh.r0) blk_base[bc0 + (uint32_t)lanes_below(m[0])] = rec;
                 bc0 += (uint32_t)__popcll(m[0]);
@@ -277,6 +290,18 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
 #ifdef D3GA_DIAG_TIMELINE
         df_blend_ticks += __builtin_amdgcn_s_memrealtime() - df_tb;
 #endif
+        if (D3GA_FWD_USED && blk_base) {
+            // the row's latest contributor so far (1-based position in the tile list, 0: none) against the positions of this batch
+            const uint32_t rowlast = row_max_u32(last);
+            const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 0), l1 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 16);
+            const uint32_t l2 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 32), l3 = (uint32_t)__builtin_amdgcn_readlane((int)rowlast, 48);
+            const uint32_t n0 = (uint32_t)__popcll(m[0] & __ballot(cpg.x <= l0)), n1 = (uint32_t)__popcll(m[1] & __ballot(cpg.x <= l1));
+            const uint32_t n2 = (uint32_t)__popcll(m[2] & __ballot(cpg.x <= l2)), n3 = (uint32_t)__popcll(m[3] & __ballot(cpg.x <= l3));
+            if (em0 && n0) used0 = bcb0 + n0;
+            if (em1 && n1) used1 = bcb1 + n1;
+            if (em2 && n2) used2 = bcb2 + n2;
+            if (em3 && n3) used3 = bcb3 + n3;
+        }
         if (all_done) break;
     }
     if constexpr (L1V) {
@@ -304,7 +329,8 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     }
     if (blk_count && (lane & 15) == 0) {
         const int r = lane >> 4;
-        blk_count[16 * (size_t)q.tile + 4 * q.quad + r] = r == 0 ? bc0 : (r == 1 ? bc1 : (r == 2 ? bc2 : bc3));
+        if (D3GA_FWD_USED) blk_count[16 * (size_t)q.tile + 4 * q.quad + r] = r == 0 ? used0 : (r == 1 ? used1 : (r == 2 ? used2 : used3));
+        else blk_count[16 * (size_t)q.tile + 4 * q.quad + r] = r == 0 ? bc0 : (r == 1 ? bc1 : (r == 2 ? bc2 : bc3));
     }
 #ifdef D3GA_DIAG_COUNTERS
     if (lane == 0 && end > begin) {
@@ -383,7 +409,7 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
     ImgBuf im = carve_img(img, prm->W, prm->H, (int64_t)gx * gy);
     if (prm->forward_only) { im.blk_list = nullptr; im.blk_count = nullptr; }     // the buffer ends behind n_contrib
     const bool ordered = (composite_variant() & kVariantOrdered) != 0, exact = (composite_variant() & kVariantExactCull) != 0;
-    if (!prm->forward_only && composite_fwd_impl_kind() == 1)          // round 5: lists first, then the blend (raster_composite_lists.hip)
+    if (!prm->forward_only && composite_fwd_impl_kind() == 1)          // opt-in (round 5): lists first, then the blend (raster_composite_lists.hip)
         return launch_composite_fwd_lists(prm, gx, gy, bin, g, im, d_capacity, bg, out_color, out_invdepth, colors2, bg2, out_color2,
                                           ordered, exact, l1v, s);
     const dim3 grid(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy));

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kCullThreads) void tile_cull_kernel(
 #pragma unroll
         for (int j = 0; j < kCullSub; ++j)
             if (j < J) {
-                if (D3GA_CULL_ABL & 2) sp[j] = make_uint4(id[j] * 2654435761u, 1u, (id[j] >> 3) & 0x0303u, 0u);
+                if (D3GA_CULL_ABL & 2) sp[j] = make_uint4((id[j] * 2654435761u) & 0x00070007u, 0x21u | ((id[j] & 3u) << 4), 0u, 0u);
                 else sp[j] = span[id[j]];                   // (id 0 is always readable)
             }
 #pragma unroll
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kCullThreads) void tile_cull_kernel(
             if (j < J) {
                 const uint32_t i = sbase + (uint32_t)(j * kCullThreads) + threadIdx.x;
                 const bool have = i < end;
-                const bool big = have && sp[j].y == kSpanBig;
+                const bool big = have && span_is_big(sp[j]);
                 mask[j] = (have && !big) ? span_mask16(sp[j], 4 * tcx, 4 * tcy) : 0u;
                 if (__builtin_amdgcn_ballot_w64(big) != 0ull) {     // rare: a splat too large for a span record -- the geometric test
                     if (big) mask[j] = block_mask16_slow(id[j], xyh, conic_o, tx0, ty0, exact_cull);

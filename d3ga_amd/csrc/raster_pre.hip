@@ -206,8 +206,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
             const SplatCull sc = splat_cull(sp.conic[0], sp.conic[1], sp.conic[2], o.opacity);
             geom.xyh[i] = make_float4(sp.px, sp.py, sp.visible ? sc.hx : -1.0f, sc.hy);
             // round 5: the blocks the splat can touch, one column interval per block line (tile_cull_kernel decodes it per tile)
-            geom.span[i] = sp.visible ? splat_spans(sp.px, sp.py, sp.conic[0], sp.conic[1], sp.conic[2], o.opacity, exact_cull != 0)
-                                      : make_uint4(0u, 0u, 0u, 0u);
+            if (exact_cull >= 0)                  // (uniform; < 0: nobody reads span records -- the one-launch forward, the default)
+                geom.span[i] = sp.visible ? splat_spans(sp.px, sp.py, sp.conic[0], sp.conic[1], sp.conic[2], o.opacity, exact_cull != 0)
+                                          : make_uint4(0u, 0u, 0u, 0u);
         }
         geom.rgb_invd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], sp.visible ? 1.0f / sp.depth : 0.f);
         geom.clamped[i] = o.clampmask;
@@ -473,7 +474,8 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? (kShHalfLdsBytes > win ? kShHalfLdsBytes : win) : win;
     hipLaunchKernelGGL(preprocess_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
                        colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, g,
-                       bin.tile_count, bin.counters, radii, (composite_variant() & kVariantExactCull) ? 1 : 0);
+                       bin.tile_count, bin.counters, radii,
+                       composite_fwd_impl_kind() == 1 ? ((composite_variant() & kVariantExactCull) ? 1 : 0) : -1);
     return check_launch(s, prm->debug & 0xff);
 }
 
