@@ -14,6 +14,8 @@
 //   tile_sort_lds_kernel       one workgroup per tile: LDS bitonic sort, 8 keys per thread (lists up to 2048 entries)
 //   tile_sort_lds_list_kernel  longer lists (up to 8192): 64 KB LDS, persistent grid over a device-side work list
 //                              (+ in the same launch: even longer lists, same network on global memory)
+#include <stdlib.h>
+
 #include "d3ga_internal.h"
 
 namespace d3ga {
@@ -513,7 +515,9 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_
                                                                    const uint32_t *__restrict__ list_count,
                                                                    uint64_t *__restrict__ keys_rw,
                                                                    const uint32_t *__restrict__ huge_list,
-                                                                   const uint32_t *__restrict__ huge_count) {
+                                                                   const uint32_t *__restrict__ huge_count,
+                                                                   const uint32_t *__restrict__ list2 = nullptr,
+                                                                   const uint32_t *__restrict__ list2_count = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_key_dyn[];
     uint32_t *s_bin = reinterpret_cast<uint32_t *>(s_key_dyn + CAP);
     uint32_t *s_red = s_bin + CAP + 1;
@@ -522,6 +526,15 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
         __syncthreads();
         sort_one_tile_bucket<BLOCK, CAP>(s_key_dyn, s_bin, s_red, (int)list[k], start, keys, point_list, dcap);
+    }
+    // a second work list of a smaller class in the same launch (round 5: frames of up to 16384 tiles send the 2049..4096 class
+    // through the 8192-key kernel instead of a launch of its own -- at C3 that launch sorted ONE list and the other found none)
+    if (list2) {
+        const uint32_t count2 = *list2_count;
+        for (uint32_t k = gridDim.x - 1u - blockIdx.x; k < count2; k += gridDim.x) {      // (from the other end of the grid)
+            __syncthreads();
+            sort_one_tile_bucket<BLOCK, CAP>(s_key_dyn, s_bin, s_red, (int)list2[k], start, keys, point_list, dcap);
+        }
     }
     // lists that do not fit any LDS class (huge_list != null: same launch, saves a near-empty grid per frame): segmented
     // bucket sort; the bitonic network on global memory only if one bucket alone exceeds the LDS class
@@ -603,14 +616,24 @@ extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, v
     // (48 KB of LDS: three workgroups of the 2049..4096 class fit a CU -- at 4K with 2M Gaussians thousands of tiles are in it;
     //  96 KB: one workgroup of the larger class per CU)
     const int lgrid = tiles < 256 ? tiles : 256, mgrid = tiles < 768 ? tiles : 768;
-    hipLaunchKernelGGL((tile_sort_lds_list_kernel<512, kSortMid>), dim3(mgrid), dim3(512), sort_lds_bytes(kSortMid, 512), s,
-                       bin.tile_start, bin.keys, bin.point_list, (uint64_t)d_capacity, bin.mid_tiles,
-                       bin.counters + D3GA_CNT_MID, (uint64_t *)nullptr, (const uint32_t *)nullptr,
-                       (const uint32_t *)nullptr);
-    D3GA_TRY(check_launch(s, prm->debug));
+    // Round 5: ONE list launch for frames of up to 16384 tiles (1080p: 8160): the 2049..4096 class rides in the 8192-key kernel (one
+    // workgroup of 1024 threads per CU instead of three of 512 -- for a handful of such lists that is no loss, and a launch that
+    // finds an empty work list still costs 4-5 us of a frame).  Larger frames (4K with millions of Gaussians: thousands of tiles
+    // in the mid class) keep the launch of their own.  D3GA_SORT_MERGE=0/1 overrides.
+    static const int merge_env = [] { const char *e = getenv("D3GA_SORT_MERGE"); return e ? atoi(e) : -1; }();
+    const bool merged = merge_env >= 0 ? merge_env != 0 : tiles <= 16384;
+    if (!merged) {
+        hipLaunchKernelGGL((tile_sort_lds_list_kernel<512, kSortMid>), dim3(mgrid), dim3(512), sort_lds_bytes(kSortMid, 512), s,
+                           bin.tile_start, bin.keys, bin.point_list, (uint64_t)d_capacity, bin.mid_tiles,
+                           bin.counters + D3GA_CNT_MID, (uint64_t *)nullptr, (const uint32_t *)nullptr,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+        D3GA_TRY(check_launch(s, prm->debug));
+    }
     hipLaunchKernelGGL((tile_sort_lds_list_kernel<1024, kSortLarge>), dim3(lgrid), dim3(1024),
                        sort_lds_bytes(kSortLarge, 1024, true), s, bin.tile_start, bin.keys, bin.point_list,
                        (uint64_t)d_capacity, bin.big_tiles, bin.counters + D3GA_CNT_BIG, bin.keys,
-                       (const uint32_t *)bin.huge_tiles, (const uint32_t *)(bin.counters + D3GA_CNT_HUGE));
+                       (const uint32_t *)bin.huge_tiles, (const uint32_t *)(bin.counters + D3GA_CNT_HUGE),
+                       merged ? (const uint32_t *)bin.mid_tiles : (const uint32_t *)nullptr,
+                       merged ? (const uint32_t *)(bin.counters + D3GA_CNT_MID) : (const uint32_t *)nullptr);
     return check_launch(s, prm->debug);
 }
