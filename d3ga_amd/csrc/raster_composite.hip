@@ -120,11 +120,15 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     uint32_t qhead = 0, qcount = 0;                       // ring: entries (qhead + i) % kRing, i < qcount (wave-uniform)
     uint32_t g0 = 0, g1 = 0;                              // ids of the chunk in flight
     float4 h0 = make_float4(0.f, 0.f, -1.f, 0.f), h1 = h0; // its xyh records
-    auto chunk_ids = [&](uint32_t base) {                 // 1st level: the ids (coalesced)
-        g0 = base + lane < end ? point_list[base + lane] : 0u;
-        g1 = base + 64 + lane < end ? point_list[base + 64 + lane] : 0u;
+    // round 5: the ids are fetched TWO chunks ahead (gn0 / gn1), the records one chunk ahead: at the top of a chunk its records'
+    // gathers find their ids in registers instead of waiting for them (the gathers used to be issued right behind the id loads
+    // they depend on: one exposed L2 round trip per chunk, ~7 chunks per wavefront)
+    uint32_t gn0 = 0, gn1 = 0;
+    auto chunk_ids = [&](uint32_t base) {                 // 1st level: the ids (coalesced) of the chunk at `base` -> gn
+        gn0 = base + lane < end ? point_list[base + lane] : 0u;
+        gn1 = base + 64 + lane < end ? point_list[base + 64 + lane] : 0u;
     };
-    auto chunk_recs = [&]() { h0 = xyh[g0]; h1 = xyh[g1]; };       // 2nd level: the gathers (id 0 is always readable)
+    auto chunk_recs = [&]() { g0 = gn0; g1 = gn1; h0 = xyh[g0]; h1 = xyh[g1]; };       // 2nd level: the gathers of gn's chunk (id 0 is always readable)
     auto quad_hit = [&](const float4 &r) {                // NaN extents answer "relevant", like block_hits4
         return !(r.z < 0.0f) && !(r.x + r.z < bx0) && !(r.x - r.z > bx0 + 7.0f) && !(r.y + r.w < by0) && !(r.y - r.w > by0 + 7.0f);
     };
@@ -160,11 +164,11 @@ __global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
     auto fill = [&]() {                                   // stage one until a full batch is queued or the list is exhausted
         while (qcount < 64u && sbase < end) {
             consume_chunk();                              // (the ring holds < 64 + 128 entries)
-            if (sbase < end) { chunk_ids(sbase); chunk_recs(); }      // rarely taken twice in a row: dependent loads, not prefetched
+            if (sbase < end) { chunk_recs(); chunk_ids(min(sbase + 128u, end)); }      // records of the chunk at sbase (ids arrived a chunk ago), ids of the next
         }
     };
 
-    if (begin < end) { chunk_ids(begin); chunk_recs(); }
+    if (begin < end) { chunk_ids(begin); chunk_recs(); chunk_ids(min(begin + 128u, end)); }
     __builtin_amdgcn_wave_barrier();
     fill();
     __builtin_amdgcn_wave_barrier();
