@@ -52,6 +52,7 @@ _SIGNATURES = {
     "d3ga_raster_scratch_bytes": ([ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, ctypes.POINTER(_i64)], _i),
     "d3ga_raster_binning_layout": ([ctypes.c_int32, ctypes.c_int32, _i64, ctypes.POINTER(_i64)], _i),
     "d3ga_raster_img_layout": ([ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_i64)], _i),
+    "d3ga_raster_img_layout_blocks": ([ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_i64)], _i),
     "d3ga_raster_img_bytes": ([ctypes.c_int32, ctypes.c_int32, _i64, ctypes.c_int32], _i64),
     "d3ga_raster_preprocess": ([_prm] + [_vp] * 12 + [_i64, _vp, _vp], _i),
     "d3ga_raster_bin_sort": ([_prm, _vp, _vp, _i64, _vp], _i),

@@ -55,6 +55,18 @@ extern "C" int d3ga_raster_img_layout(int32_t W, int32_t H, int64_t offsets[2]) 
     return D3GA_OK;
 }
 
+extern "C" int d3ga_raster_img_layout_blocks(int32_t W, int32_t H, int64_t offsets[3]) {
+    if (!offsets) return D3GA_E_NULL;
+    if (W <= 0 || H <= 0) return D3GA_E_SIZE;
+    const int64_t tiles = (int64_t)tiles_x(W) * tiles_y(H);
+    char *base = (char *)nullptr + 256;
+    const ImgBuf im = carve_img(base, W, H, tiles);
+    offsets[0] = (char *)im.blk_count - base;
+    offsets[1] = (char *)im.blk_total - base;
+    offsets[2] = (char *)im.blk_list - base;
+    return D3GA_OK;
+}
+
 extern "C" int d3ga_raster_forward(const d3ga_raster_params *prm, const float *means3D, const float *shs,
                                    const float *colors_precomp, const float *opacities, const float *scales,
                                    const float *rotations, const float *cov3D_precomp, const float *viewmatrix,

@@ -591,6 +591,25 @@ def last_termination(device=None):
     return (img[off[0]:off[0] + n].view(torch.float32).view(H, W), img[off[1]:off[1] + n].view(torch.int32).view(H, W))
 
 
+def last_block_lists(device=None):
+    """(blk_count (tiles,16) int64, blk_total (tiles,16) int64, blk_list (16 x capacity, 2) int64 {1-based tile-list position,
+    Gaussian index}) of the most recent forward that was followed by (or may be followed by) a backward on `device` -- views
+    decoded from its image scratch (d3ga_raster_img_layout_blocks; inspection / tests).  Block b of a tile whose list is
+    [begin, end) starts at row 16 begin + b (end - begin) of blk_list; blk_count is the prefix the backward walks."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    img, W, H = _last_img[dev][:3]
+    off = (ctypes.c_int64 * 3)()
+    check(_lib.lib().d3ga_raster_img_layout_blocks(W, H, off), "d3ga_raster_img_layout_blocks")
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    if img.numel() <= off[2]:
+        raise RuntimeError("the last forward was a forward_only render: it has no block lists")
+    cnt = img[off[0]:off[0] + 64 * tiles].view(torch.int32).view(tiles, 16).long()
+    tot = img[off[1]:off[1] + 64 * tiles].view(torch.int32).view(tiles, 16).long()
+    n = (img.numel() - off[2]) // 8
+    lst = img[off[2]:off[2] + 8 * n].view(torch.int32).view(n, 2).long()
+    return cnt, tot, lst
+
+
 def last_alpha_decisions(gid, px, py, device=None):
     """(ok (n,) bool, alpha (n,) float32): the compositing forward's own alpha and "touches the pixel" decision for the listed
     (Gaussian, pixel) pairs over the geometry records of the most recent forward (d3ga_selftest_alpha; tests)."""

@@ -163,6 +163,12 @@ int64_t d3ga_raster_img_bytes(int32_t W, int32_t H, int64_t d_capacity, int32_t 
 int d3ga_raster_binning_layout(int32_t W, int32_t H, int64_t d_capacity, int64_t offsets[6]);
 /* Same for the image buffer: offsets[0] final_T (H*W f32), [1] n_contrib (H*W u32). */
 int d3ga_raster_img_layout(int32_t W, int32_t H, int64_t offsets[2]);
+/* ... and its per-block lists (absent from a forward_only buffer), for inspection/tests: offsets[0] blk_count (16 x tiles u32: the
+ * length of the prefix of a block's list the backward walks = up to the last entry some pixel of the block blended, round 5),
+ * [1] blk_total (16 x tiles u32: entries the list pass of the two-launch forward wrote; unused by the one-launch forward),
+ * [2] blk_list (16 x d_capacity {u32 1-based position in the tile's list, u32 Gaussian index}; block b of a tile whose list is
+ * [begin, end) starts at element 16 begin + b (end - begin); b = 4 x quadrant + block within the quadrant). */
+int d3ga_raster_img_layout_blocks(int32_t W, int32_t H, int64_t offsets[3]);
 
 /* The binning buffer starts with 8 uint32 counters the host may read back after the forward:
  *   [0] D = duplicates required (sum of tiles touched)      [1] 1 if D > d_capacity (lists truncated: re-run)

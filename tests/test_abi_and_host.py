@@ -329,3 +329,40 @@ def test_replay_watchdog_fires_on_a_stuck_event_only():
         assert wd.fired is not None
     finally:
         wd.close()
+
+
+def test_bucketed_reducer_averages_a_non_contiguous_gradient():
+    """a non-contiguous .grad went into the flat bucket through reshape(-1) (a copy) and the averaged values came back
+    into that temporary -- the parameter kept its local gradient.  The hook now makes the gradient contiguous and finish() copies
+    through a view of the gradient itself."""
+    from d3ga_amd.dist import BucketedGradReducer
+    p, q = torch.zeros(4, 3, requires_grad=True), torch.zeros(5, requires_grad=True)
+    red = BucketedGradReducer([[p, q]], always=True)
+    red.world = lambda: 2                                   # (no process group here: finish() then halves what the bucket holds)
+    red.begin_step()
+    gp = torch.arange(12.0).reshape(3, 4).t()               # (4,3), strides (1,4): not contiguous
+    p.grad, q.grad = gp, torch.ones(5)
+    assert not p.grad.is_contiguous()
+    hook = red._make_hook(0)
+    hook(p); hook(q)                                        # the bucket is complete: staged (and, with a group, reduced)
+    assert p.grad.is_contiguous()
+    assert red.finish() == 1
+    assert torch.equal(p.grad, 0.5 * gp) and torch.equal(q.grad, torch.full((5,), 0.5))
+
+
+def test_cage_deform_warns_when_tets_and_gaussians_are_equally_many():
+    """a (T,3,3) canonical gradient is recognised by its length -- ambiguous when T == P; the reference's per-Gaussian
+    layout is assumed and said so (gradient_per_tet=True states the other)."""
+    import warnings
+    from d3ga_amd import _lib
+    from d3ga_amd.cage_deform import cage_deform
+    P = T = 4
+    args = (torch.zeros(8, 3), torch.zeros(T, 4, dtype=torch.int32), torch.zeros(P, dtype=torch.int32), torch.full((P, 4), 0.25),
+            torch.eye(3).repeat(P, 1, 1), torch.ones(P, 3), torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1))
+    with pytest.warns(UserWarning, match="as many tetrahedra as Gaussians"):
+        with pytest.raises(_lib.D3GAError):                 # (CPU tensors: no fallback -- the warning comes first)
+            cage_deform(*args)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with pytest.raises(_lib.D3GAError):
+            cage_deform(*args, gradient_per_tet=False)      # said explicitly: no warning

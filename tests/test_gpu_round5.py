@@ -1,0 +1,120 @@
+"""Round 5: the backward's block-list prefix, the opt-in two-launch forward, ABI 101 refusals (GPU)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import scene_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _render(name, scale_mult, seed=3):
+    from d3ga_amd import rasterizer as R
+    from test_gpu_parity import _settings
+    inp = scene_inputs(name, scale_mult=scale_mult)
+    bg = torch.tensor([0.3, 0.6, 0.1])
+    rast = R.GaussianRasterizer(_settings(inp, bg, 3))
+    leaves = {k: inp[k].to(DEV).clone().requires_grad_(True) for k in ("means3D", "cov6", "opacities", "shs")}
+    img, radii, _ = rast(means3D=leaves["means3D"], means2D=None, opacities=leaves["opacities"], shs=leaves["shs"],
+                         cov3D_precomp=leaves["cov6"])
+    gpix = torch.randn(img.shape, generator=torch.Generator().manual_seed(seed)).to(DEV)
+    return inp, R, img, radii, leaves, gpix
+
+
+@pytest.mark.parametrize("name,scale_mult", [("T1", 3.0), ("C1", 1.0), ("T1", 8.0)])
+def test_block_count_is_the_prefix_up_to_the_last_blended_entry(name, scale_mult):
+    """blk_count of a block = number of entries of its list up to (and including) the last one some pixel of the block blended:
+    the entry in front of that cut carries the largest n_contrib of the block's 16 pixels, nothing behind it is needed by the
+    backward.  A block none of whose pixels blended anything has count 0.  (Rounds 2-4 handed the backward every emitted entry.)"""
+    inp, R, img, _, _, _ = _render(name, scale_mult)
+    W, H = inp["W"], inp["H"]
+    torch.cuda.synchronize()
+    cnt, _, lst = R.last_block_lists()
+    _, ncontrib = R.last_termination()
+    start, _, _ = R.last_tile_lists(W, H)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    cnt, lst, ncontrib, start = cnt.cpu().numpy(), lst.cpu().numpy(), ncontrib.cpu().numpy().astype(np.int64), start.cpu().numpy()
+    pad = np.zeros((gy * 16, gx * 16), np.int64)
+    pad[:H, :W] = ncontrib
+    checked = 0
+    for t in range(gx * gy):
+        b0, e0 = int(start[t]), int(start[t + 1])
+        if e0 == b0:
+            continue
+        ty, tx = divmod(t, gx)
+        for b in range(16):
+            q, r = b >> 2, b & 3
+            bx, by = 2 * (q & 1) + (r & 1), 2 * (q >> 1) + (r >> 1)
+            if tx * 16 + 8 * (q & 1) >= W or ty * 16 + 8 * (q >> 1) >= H:
+                continue                                   # (the forward writes the counts of quadrants that start inside the image)
+            last = int(pad[ty * 16 + 4 * by: ty * 16 + 4 * by + 4, tx * 16 + 4 * bx: tx * 16 + 4 * bx + 4].max())
+            c = int(cnt[t, b])
+            if last == 0:
+                assert c == 0
+                continue
+            entries = lst[16 * b0 + b * (e0 - b0): 16 * b0 + b * (e0 - b0) + c]
+            assert c > 0 and int(entries[-1, 0]) == last, (t, b, c, last, entries[-3:])
+            assert (np.diff(entries[:, 0]) > 0).all()        # list order = position order
+            checked += 1
+    assert checked > 0
+
+
+_CHILD = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from test_gpu_round5 import _render
+out = {{}}
+for name, sm in (("T1", 3.0), ("C1", 1.0), ("T1", 8.0)):
+    inp, R, img, radii, leaves, gpix = _render(name, sm)
+    (img * gpix).sum().backward()
+    torch.cuda.synchronize()
+    T, n = R.last_termination()
+    out[f"{{name}}_{{sm}}_img"] = img.detach().cpu().numpy(); out[f"{{name}}_{{sm}}_n"] = n.cpu().numpy()
+    for k, v in leaves.items():
+        out[f"{{name}}_{{sm}}_{{k}}"] = v.grad.cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_two_launch_forward_equals_the_one_launch_forward(tmp_path):
+    """D3GA_FWD_IMPL=1 (opt-in: block lists built by tile_cull_kernel from the per-Gaussian span records, then the lists blend)
+    renders the same frames as the default forward: identical termination, images to float rounding, gradients to 2e-5 of the
+    largest element.  T1 x 8 holds splats too large for a span record (the geometric fallback of the list pass)."""
+    files = {}
+    for impl in ("0", "1"):
+        f = str(tmp_path / f"impl{impl}.npz")
+        env = dict(os.environ, D3GA_FWD_IMPL=impl)
+        r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT), f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        files[impl] = np.load(f)
+    a, b = files["0"], files["1"]
+    for k in a.files:
+        if k.endswith("_n"):
+            assert (a[k] != b[k]).mean() < 1e-4, k           # (a T < 1e-4 decision may fall the other way: sums in another order)
+        elif k.endswith("_img"):
+            np.testing.assert_allclose(b[k], a[k], atol=2e-6, err_msg=k)
+        else:
+            scale = np.abs(a[k]).max() + 1e-30
+            assert np.abs(a[k] - b[k]).max() <= 2e-5 * scale, (k, np.abs(a[k] - b[k]).max() / scale)
+
+
+def test_backward_without_the_precomputed_covariance_is_refused():
+    """ABI 101: the forward keeps no copy of a precomputed covariance, so a per-Gaussian backward that is handed
+    neither cov3D_precomp nor (scales, rotations) returns D3GA_E_NULL instead of reading uninitialised records."""
+    from d3ga_amd import _lib
+    L = _lib.lib()
+    assert L.d3ga_version() == 101
+    prm = _lib.RasterParams(P=16, M=0, sh_degree=0, W=64, H=64, tanfovx=1.0, tanfovy=1.0, scale_modifier=1.0, antialiasing=0,
+                            prefiltered=0, debug=0, opacity_activation=0, forward_only=0, acc_self_clearing=0)
+    buf = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
+    p = ctypes.c_void_p(buf.data_ptr())
+    st = L.d3ga_raster_preprocess_bwd(ctypes.byref(prm), p, None, None, None, None, p, p, p, p, p, p, None, None, None, p, None, None,
+                                      None, None)
+    assert st == -1, st                                      # D3GA_E_NULL
