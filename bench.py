@@ -93,6 +93,9 @@ def parse():
     ap.add_argument("--no-fused-l1", action="store_true",
                     help="render() and l1_loss() as two operators instead of d3ga_amd.renderer.render_l1 (same loss and gradients; "
                          "the gradient image then makes a round trip through HBM)")
+    ap.add_argument("--no-fused-lbs", action="store_true",
+                    help="lbs_cage() and cage_deform() as two operators instead of d3ga_amd.cage_deform.lbs_cage_deform (same outputs and "
+                         "gradients; the LBS backward then takes a launch of its own)")
     ap.add_argument("--init-timing", action="store_true",
                     help="also time the init-time helpers at the workload's size: compute_bary (point -> tet + barycentrics, "
                          "lib/cage.py:325-327) and the 3-NN scale seed (models/cage_net.py:66), uniform grid vs exhaustive")
@@ -175,16 +178,24 @@ class Frame:
 
     def upstream(self):
         """Parameters -> what enters the rasterizer (view-independent: the same on every rank of a camera-sharded run)."""
-        from d3ga_amd.cage_deform import cage_deform, lbs_cage
+        from d3ga_amd.cage_deform import cage_deform, lbs_cage, lbs_cage_deform
         p = self.params
-        tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
         # canon_barys = barys + delta_bary, scales = exp(scaling) (cage_net.py:213-214): fused into the deform kernels
-        means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad, p["scaling"],
-                                  p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp", gradient_per_tet=self.canon_grad_mode == "per-tet")
+        if self.fused_lbs:      # LBS + cage deform as one autograd node: dL/d(delta_node) formed in the vertex-gather launch (round 5)
+            means, cov6, _ = lbs_cage_deform(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w, self.tetras,
+                                             self.tetra_id, self.barys0, self.canon_grad, p["scaling"], p["rotation"],
+                                             delta_barys=p["delta_bary"], scale_activation="exp",
+                                             gradient_per_tet=self.canon_grad_mode == "per-tet")
+        else:
+            tetpoints = lbs_cage(self.canon, p["delta_node"], self.joint_mats, self.skin_idx, self.skin_w)
+            means, cov6 = cage_deform(tetpoints, self.tetras, self.tetra_id, self.barys0, self.canon_grad, p["scaling"],
+                                      p["rotation"], delta_barys=p["delta_bary"], scale_activation="exp",
+                                      gradient_per_tet=self.canon_grad_mode == "per-tet")
         # opacity = sigmoid(opacities) (cage_net.py:247): fused into the per-Gaussian kernels (pkg["opacity_logits"])
         return {"means3D": means, "cov3D_precomp": cov6, "opacity_logits": p["opacity"],
                 "shs": p["features"], "rgb": None, "sh_degree": self.sh_degree}
 
+    fused_lbs = True                # --no-fused-lbs: lbs_cage() and cage_deform() as two operators (one more launch in the backward)
     fused_l1 = True                 # --no-fused-l1: render() + l1_loss() as two operators (a (3,H,W) gradient image in between)
 
     def loss_from(self, pkg):
@@ -909,6 +920,7 @@ def main():
     frame = Frame(args.workload, dev, view_index=rank % 8, scale_mult=args.scale_mult, fill=args.fill, order=args.gaussian_order,
                   canon_grad=args.canon_grad)
     frame.fused_l1 = not args.no_fused_l1
+    frame.fused_lbs = not args.no_fused_lbs
     kv = max(int(args.views_per_rank), 1)
     if kv > 1:
         if world == 1 and not args.force_cut:

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "d3ga_cage_deform_fwd_ex": ([_i] + [_vp] * 8 + [ctypes.c_int32] + [_vp] * 2 + [_vp], _i),
     "d3ga_cage_deform_bwd_ex": ([_i, _i] + [_vp] * 8 + [ctypes.c_int32] + [_vp] * 9 + [_vp], _i),
     "d3ga_cage_deform_bwd_merged": ([_i, _i] + [_vp] * 8 + [ctypes.c_int32] + [_vp] * 9 + [ctypes.c_int32] + [_vp] * 3 + [_vp], _i),
+    "d3ga_cage_deform_bwd_merged_lbs": ([_i, _i] + [_vp] * 8 + [ctypes.c_int32] + [_vp] * 9 + [ctypes.c_int32] + [_vp] * 3 + [_i] + [_vp] * 6 + [_vp], _i),
     "d3ga_fem_energy_fwd": ([_i] + [_vp] * 4 + [_vp], _i),
     "d3ga_fem_energy_bwd": ([_i, _i] + [_vp] * 5 + [_vp], _i),
     "d3ga_raster_scratch_bytes": ([ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, ctypes.POINTER(_i64)], _i),

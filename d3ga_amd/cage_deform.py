@@ -235,6 +235,83 @@ def lbs_cage(template, delta, joint_mats, skin_idx, skin_w, Rh=None, Th=None):
     return _LbsCage.apply(template, delta, joint_mats, _i32c(skin_idx), skin_w, Rh, Th)
 
 
+class _LbsCageDeform(torch.autograd.Function):
+    """lbs_cage + cage_deform as ONE autograd node (round 5): the forward is the two launches of the separate operators; the
+    backward merges the corner gradients per workgroup (merge_plan) and forms dL/d(delta) in the vertex-gather launch
+    (d3ga_cage_deform_bwd_merged_lbs) -- one launch instead of the gather + d3ga_lbs_cage_bwd."""
+
+    @staticmethod
+    def forward(ctx, template, delta, joint_mats, skin_idx, skin_w, Rh, Th, tetras, tetra_id, barys, canon_grad, scales, rotations,
+                delta_barys, flags):
+        require_cuda(template, delta, joint_mats, skin_idx, skin_w, Rh, Th, tetras, tetra_id, barys, canon_grad, scales, rotations)
+        template, delta, joint_mats, skin_w, Rh, Th = map(_f32c, (template, delta, joint_mats, skin_w, Rh, Th))
+        barys, canon_grad, scales, rotations, delta_barys = map(_f32c, (barys, canon_grad, scales, rotations, delta_barys))
+        V, K = skin_w.shape
+        P, dev = barys.shape[0], barys.device
+        L = _lib.lib()
+        tetpoints = torch.empty((V, 3), dtype=torch.float32, device=dev)
+        check(L.d3ga_lbs_cage_fwd(V, K, dptr(template), dptr(delta), dptr(joint_mats), dptr(skin_idx), dptr(skin_w), dptr(Rh),
+                                  dptr(Th), dptr(tetpoints), stream_handle()), "d3ga_lbs_cage_fwd")
+        means = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        cov6 = torch.empty((P, 6), dtype=torch.float32, device=dev)
+        check(L.d3ga_cage_deform_fwd_ex(P, dptr(tetpoints), dptr(tetras), dptr(tetra_id), dptr(barys), dptr(canon_grad),
+                                        dptr(scales), dptr(rotations), dptr(delta_barys), flags, dptr(means), dptr(cov6),
+                                        stream_handle()), "d3ga_cage_deform_fwd_ex")
+        ctx.flags, ctx.has_dbary, ctx.has_Rh, ctx.has_delta = flags, delta_barys is not None, Rh is not None, delta is not None
+        ctx.set_materialize_grads(False)
+        none = torch.empty(0, device=dev)
+        ctx.save_for_backward(tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations,
+                              delta_barys if delta_barys is not None else none, joint_mats, skin_idx, skin_w,
+                              Rh if Rh is not None else none)
+        return means, cov6, tetpoints
+
+    @staticmethod
+    def backward(ctx, g_means, g_cov6, g_tp_extra):
+        (tetpoints, tetras, tetra_id, barys, canon_grad, scales, rotations, delta_barys, joint_mats, skin_idx, skin_w,
+         Rh) = ctx.saved_tensors
+        P, V, K, dev = barys.shape[0], tetpoints.shape[0], skin_w.shape[1], barys.device
+        g_means = torch.zeros((P, 3), device=dev) if g_means is None else _f32c(g_means)
+        g_cov6 = torch.zeros((P, 6), device=dev) if g_cov6 is None else _f32c(g_cov6)
+        need = ctx.needs_input_grad
+        g_b = torch.empty((P, 4), dtype=torch.float32, device=dev) if (need[9] or need[13]) else None
+        g_s = torch.empty((P, 3), dtype=torch.float32, device=dev) if need[11] else None
+        g_r = torch.empty((P, 4), dtype=torch.float32, device=dev) if need[12] else None
+        g_d = torch.empty((V, 3), dtype=torch.float32, device=dev)
+        plan = merge_plan(tetras, tetra_id, V)
+        partials = torch.empty((max(plan["n_segments"], 1), 3), dtype=torch.float32, device=dev)
+        check(_lib.lib().d3ga_cage_deform_bwd_merged_lbs(
+            P, V, dptr(tetpoints), dptr(tetras), dptr(tetra_id), dptr(barys), dptr(canon_grad), dptr(scales), dptr(rotations),
+            dptr(delta_barys if ctx.has_dbary else None), ctx.flags, dptr(g_means), dptr(g_cov6), None, dptr(g_b), dptr(g_s),
+            dptr(g_r), dptr(plan["item_pos"]), dptr(plan["seg_ptr"]), dptr(plan["seg_begin"]), plan["n_segments"],
+            dptr(plan["vert_start"]), dptr(plan["vert_parts"]), dptr(partials), K, dptr(joint_mats), dptr(skin_idx), dptr(skin_w),
+            dptr(Rh if ctx.has_Rh else None), dptr(None if g_tp_extra is None else _f32c(g_tp_extra)), dptr(g_d),
+            stream_handle()), "d3ga_cage_deform_bwd_merged_lbs")
+        return (g_d if need[0] else None, g_d if (ctx.has_delta and need[1]) else None, None, None, None, None, None, None, None,
+                g_b if need[9] else None, None, g_s, g_r, g_b if need[13] else None, None)
+
+
+def lbs_cage_deform(template, delta, joint_mats, skin_idx, skin_w, tetras, tetra_id, barys, canonical_gradient, scales, rotations,
+                    delta_barys=None, scale_activation=None, gradient_per_tet=None, Rh=None, Th=None):
+    """`cage_deform(lbs_cage(template, delta, joint_mats, skin_idx, skin_w, Rh, Th), tetras, ...)` as one operator (an extension
+    like `renderer.render_l1`; lib/smplman.py:155-171 feeding models/cage_net.py:218-230): same outputs, same gradients, one
+    launch less in the backward.  -> (means3D (P,3), cov3D_precomp (P,6), tetpoints (V,3)); the posed cage vertices are returned
+    for the terms that read them directly (the FEM regulariser, lib/cage.py:349-361) -- their gradient joins the skinning backward."""
+    if scale_activation not in (None, "exp"):
+        raise ValueError(f"scale_activation must be None or 'exp', got {scale_activation!r}")
+    P, T = barys.shape[0], tetras.shape[0]
+    if gradient_per_tet is None:
+        if canonical_gradient.shape[0] == T and T == P:
+            import warnings
+            warnings.warn("lbs_cage_deform: as many tetrahedra as Gaussians -- canonical_gradient is read per GAUSSIAN (the reference's "
+                          "layout, lib/cage.py:329); pass gradient_per_tet=True if it is the per-tetrahedron table", stacklevel=2)
+        gradient_per_tet = canonical_gradient.shape[0] == T and T != P
+    if canonical_gradient.shape[0] != (T if gradient_per_tet else P):
+        raise ValueError(f"canonical_gradient has {canonical_gradient.shape[0]} matrices, expected {T if gradient_per_tet else P}")
+    flags = (1 if scale_activation == "exp" else 0) | (2 if gradient_per_tet else 0)
+    return _LbsCageDeform.apply(template, delta, joint_mats, _i32c(skin_idx), skin_w, Rh, Th, _i32c(tetras), _i32c(tetra_id), barys,
+                                canonical_gradient, scales, rotations, delta_barys, flags)
+
+
 class _FemEnergy(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tetpoints, tetras, Dn_inv):

@@ -251,6 +251,46 @@ __global__ __launch_bounds__(kBlock) void vertex_gather_row_kernel(int V, const 
     sx = row_sum_(sx); sy = row_sum_(sy); sz = row_sum_(sz);
     if (live && l16 == 0) { g_tetpoints[3 * (size_t)v] = sx; g_tetpoints[3 * (size_t)v + 1] = sy; g_tetpoints[3 * (size_t)v + 2] = sz; }
 }
+// The same gather with the LBS backward of D0 behind it (round 5: d3ga_cage_deform_bwd_merged_lbs -- the posed cage vertices came
+// from d3ga_lbs_cage_fwd, so dL/d(delta) = (sum_k w_k A_k[:3,:3])^T Rh^T dL/d(tetpoint) can be formed while the vertex gradient sits
+// in the row's registers: one launch instead of two for ~24 k vertices).  Lane k of the row takes joint k of the vertex.
+// g_extra: a gradient that reaches the vertices by another route (the FEM regulariser), added before the skinning; g_tetpoints
+// (optional): the vertex gradient itself.
+__global__ __launch_bounds__(kBlock) void vertex_gather_lbs_row_kernel(int V, int K, const int32_t *__restrict__ vert_start,
+                                                                       const int32_t *__restrict__ vert_items,
+                                                                       const float *__restrict__ values,
+                                                                       const float *__restrict__ g_extra,
+                                                                       const float *__restrict__ A, const int32_t *__restrict__ idx,
+                                                                       const float *__restrict__ w, const float *__restrict__ Rh,
+                                                                       float *__restrict__ g_tetpoints, float *__restrict__ gdelta) {
+    const int v = blockIdx.x * (kBlock / 16) + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & 15;
+    const bool live = v < V;
+    const int b = live ? vert_start[v] : 0, e = live ? vert_start[v + 1] : 0;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int k = b + l16; k < e; k += 16) {
+        const float *c = values + 3 * (size_t)vert_items[k];
+        sx += c[0]; sy += c[1]; sz += c[2];
+    }
+    if (g_extra && live && l16 == 0) { sx += g_extra[3 * (size_t)v]; sy += g_extra[3 * (size_t)v + 1]; sz += g_extra[3 * (size_t)v + 2]; }
+    sx = row_sum_(sx); sy = row_sum_(sy); sz = row_sum_(sz);
+    if (g_tetpoints && live && l16 == 0) { g_tetpoints[3 * (size_t)v] = sx; g_tetpoints[3 * (size_t)v + 1] = sy; g_tetpoints[3 * (size_t)v + 2] = sz; }
+    V3 go = v3(sx, sy, sz);
+    if (Rh) go = v3(Rh[0] * go.x + Rh[3] * go.y + Rh[6] * go.z, Rh[1] * go.x + Rh[4] * go.y + Rh[7] * go.z,
+                    Rh[2] * go.x + Rh[5] * go.y + Rh[8] * go.z);
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (live) {
+        for (int k = l16; k < K; k += 16) {
+            const float wk = w[(size_t)v * K + k];
+            const float *a = A + 16 * (size_t)idx[(size_t)v * K + k];
+            dx += wk * (a[0] * go.x + a[4] * go.y + a[8] * go.z);
+            dy += wk * (a[1] * go.x + a[5] * go.y + a[9] * go.z);
+            dz += wk * (a[2] * go.x + a[6] * go.y + a[10] * go.z);
+        }
+    }
+    dx = row_sum_(dx); dy = row_sum_(dy); dz = row_sum_(dz);
+    if (live && l16 == 0) { gdelta[3 * (size_t)v] = dx; gdelta[3 * (size_t)v + 1] = dy; gdelta[3 * (size_t)v + 2] = dz; }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // D6
@@ -391,6 +431,39 @@ extern "C" int d3ga_cage_deform_bwd_merged(int P, int V, const float *tetpoints,
         return check_launch(s, 0);
     }
     return D3GA_OK;
+}
+
+extern "C" int d3ga_cage_deform_bwd_merged_lbs(int P, int V, const float *tetpoints, const int32_t *tetras,
+                                               const int32_t *tetra_id, const float *barys, const float *canon_grad,
+                                               const float *scales, const float *rots, const float *delta_barys, int32_t flags,
+                                               const float *g_means, const float *g_cov6, float *g_tetpoints, float *g_barys,
+                                               float *g_scales, float *g_rots, const uint16_t *item_pos, const int32_t *seg_ptr,
+                                               const uint16_t *seg_begin, int32_t n_segments, const int32_t *vert_start,
+                                               const int32_t *vert_parts, float *partials, int K, const float *joint_mats,
+                                               const int32_t *skin_idx, const float *skin_w, const float *Rh,
+                                               const float *g_tetpoints_extra, float *g_delta, d3ga_stream_t stream) {
+    if (P < 0 || V < 0 || n_segments < 0 || K <= 0) return D3GA_E_SIZE;
+    if (flags & ~(D3GA_DEFORM_LOG_SCALES | D3GA_DEFORM_GRAD_PER_TET)) return D3GA_E_CONFIG;
+    if (!g_delta || !joint_mats || !skin_idx || !skin_w) return D3GA_E_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    if (V == 0) return D3GA_OK;
+    if (P > 0) {
+        if (!tetpoints || !tetras || !tetra_id || !barys || !canon_grad || !scales || !rots || !g_means || !g_cov6 || !item_pos ||
+            !seg_ptr || !seg_begin || !vert_start || !vert_parts || !partials)
+            return D3GA_E_NULL;
+        if ((uintptr_t)item_pos & 7) return D3GA_E_CONFIG;                   // read 8 bytes per Gaussian
+        // (g_tetpoints of the corner kernel is unused on the merged path: the partials carry the corner gradients)
+        hipLaunchKernelGGL(cage_deform_bwd_kernel, dim3(nblocks(P)), dim3(kBlock), 0, s, P, tetpoints, tetras, tetra_id,
+                           barys, canon_grad, scales, rots, delta_barys, (int)flags, g_means, g_cov6, g_tetpoints, g_barys,
+                           g_scales, g_rots, (float *)nullptr, DeformMerge{item_pos, seg_ptr, seg_begin, partials});
+        D3GA_TRY(check_launch(s, 0));
+    } else if (!vert_start || !vert_parts) {
+        return D3GA_E_NULL;                                                  // (P == 0: an all-empty CSR is still read)
+    }
+    hipLaunchKernelGGL(vertex_gather_lbs_row_kernel, dim3((V + kBlock / 16 - 1) / (kBlock / 16)), dim3(kBlock), 0, s, V, K,
+                       vert_start, vert_parts, (const float *)partials, g_tetpoints_extra, joint_mats, skin_idx, skin_w, Rh,
+                       g_tetpoints, g_delta);
+    return check_launch(s, 0);
 }
 
 extern "C" int d3ga_cage_deform_bwd(int P, int V, const float *tetpoints, const int32_t *tetras,

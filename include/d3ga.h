@@ -108,6 +108,21 @@ int d3ga_cage_deform_bwd_merged(int P, int V, const float *tetpoints, const int3
                                 int32_t n_segments, const int32_t *vert_start, const int32_t *vert_parts, float *partials,
                                 d3ga_stream_t stream);
 
+/* ... with the LBS backward of D0 in the vertex-gather launch (round 5): when the posed cage vertices came from d3ga_lbs_cage_fwd
+ * (lib/smplman.py:155-171 feeding models/cage_net.py:218), dL/d(delta) = (sum_k w_k A_k[:3,:3])^T Rh^T dL/d(tetpoint) is formed while
+ * the gathered vertex gradient sits in registers: one launch instead of d3ga_cage_deform_bwd_merged's gather + d3ga_lbs_cage_bwd.
+ * K, joint_mats, skin_idx, skin_w, Rh: as d3ga_lbs_cage_bwd.  g_tetpoints_extra (V,3) | NULL: a gradient that reaches the posed
+ * vertices by another route (the FEM regulariser), added before the skinning.  g_tetpoints (V,3) | NULL: also write the vertex
+ * gradient itself.  g_delta (V,3): required. */
+int d3ga_cage_deform_bwd_merged_lbs(int P, int V, const float *tetpoints, const int32_t *tetras, const int32_t *tetra_id,
+                                    const float *barys, const float *canon_grad, const float *scales, const float *rots,
+                                    const float *delta_barys, int32_t flags, const float *g_means, const float *g_cov6,
+                                    float *g_tetpoints, float *g_barys, float *g_scales, float *g_rots,
+                                    const uint16_t *item_pos, const int32_t *seg_ptr, const uint16_t *seg_begin,
+                                    int32_t n_segments, const int32_t *vert_start, const int32_t *vert_parts, float *partials,
+                                    int K, const float *joint_mats, const int32_t *skin_idx, const float *skin_w, const float *Rh,
+                                    const float *g_tetpoints_extra, float *g_delta, d3ga_stream_t stream);
+
 /* D6  FEM regulariser (lib/cage.py:349-361): per-tet energy 0.5(det F-1)^2 + 0.5(|F|_F^2-3), F = Ds Dn^-1.
  *   fwd: energy (T).  bwd: g_energy (T) -> g_tetpoints (V,3) [zeroed by the call]. */
 int d3ga_fem_energy_fwd(int T, const float *tetpoints, const int32_t *tetras, const float *Dn_inv, float *energy,

@@ -118,3 +118,42 @@ def test_backward_without_the_precomputed_covariance_is_refused():
     st = L.d3ga_raster_preprocess_bwd(ctypes.byref(prm), p, None, None, None, None, p, p, p, p, p, p, None, None, None, p, None, None,
                                       None, None)
     assert st == -1, st                                      # D3GA_E_NULL
+
+
+def test_lbs_cage_deform_equals_the_two_operators():
+    """d3ga_amd.cage_deform.lbs_cage_deform (LBS + cage deform as one autograd node; the LBS backward formed in the vertex-gather
+    launch: d3ga_cage_deform_bwd_merged_lbs) against lbs_cage() followed by cage_deform(): identical outputs, the same gradients
+    (the sums are formed in the same order: bit for bit but for the skinning's own reduction), also with a second route into
+    the posed vertices (an extra term on tetpoints, as the FEM regulariser adds one)."""
+    from d3ga_amd.cage_deform import cage_deform, lbs_cage, lbs_cage_deform, canonical_gradient
+    from d3ga_amd import synthetic as syn
+    sc = syn.make_scene("T1", seed=5)
+    d = lambda t: t.to(DEV)
+    canon, tetras, tid, barys = d(sc["canon_points"]), d(sc["tetras"]), d(sc["tetra_id"]), d(sc["barys"])
+    jm, si, sw = d(sc["joint_mats"]), d(sc["skin_idx"]), d(sc["skin_w"])
+    cg = canonical_gradient(canon, tetras, tid).contiguous()
+    g = torch.Generator().manual_seed(11)
+    Rh = torch.linalg.qr(torch.randn(3, 3, generator=g))[0].to(DEV)
+    Th = torch.randn(3, generator=g).to(DEV)
+    P, V = barys.shape[0], canon.shape[0]
+    wm, wc, wt = torch.randn(P, 3, generator=g).to(DEV), torch.randn(P, 6, generator=g).to(DEV), torch.randn(V, 3, generator=g).to(DEV)
+    res = {}
+    for fused in (False, True):
+        leaves = dict(delta=d(sc["delta_node"]).clone().requires_grad_(True), scaling=d(sc["scaling"]).clone().requires_grad_(True),
+                      rot=d(sc["rotation"]).clone().requires_grad_(True), dbary=torch.zeros(P, 4, device=DEV, requires_grad=True))
+        if fused:
+            m, c, tp = lbs_cage_deform(canon, leaves["delta"], jm, si, sw, tetras, tid, barys, cg, leaves["scaling"], leaves["rot"],
+                                       delta_barys=leaves["dbary"], scale_activation="exp", Rh=Rh, Th=Th)
+        else:
+            tp = lbs_cage(canon, leaves["delta"], jm, si, sw, Rh, Th)
+            m, c = cage_deform(tp, tetras, tid, barys, cg, leaves["scaling"], leaves["rot"], delta_barys=leaves["dbary"],
+                               scale_activation="exp")
+        ((m * wm).sum() + (c * wc).sum() + (tp * wt).sum()).backward()
+        torch.cuda.synchronize()
+        res[fused] = dict(m=m.detach(), c=c.detach(), tp=tp.detach(), **{k: v.grad for k, v in leaves.items()})
+    a, b = res[False], res[True]
+    for k in ("m", "c", "tp", "scaling", "rot", "dbary"):
+        assert torch.equal(a[k], b[k]), k
+    scale = float(a["delta"].abs().max())
+    assert float((a["delta"] - b["delta"]).abs().max()) <= 2e-6 * scale
+    assert float(b["delta"].abs().max()) > 0
