@@ -140,11 +140,10 @@ __global__ __launch_bounds__(kCullThreads) void tile_cull_kernel(
     int gx, int tiles, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list, uint64_t dcap,
     const float4 *__restrict__ conic_o, const float4 *__restrict__ xyh, const uint4 *__restrict__ span,
     const uint32_t *__restrict__ tile_order, uint2 *__restrict__ blk_list, uint32_t *__restrict__ blk_total, bool exact_cull) {
-    // workgroup b runs on XCD b % 8 (observed; speed only): XCD x takes the tiles [x T/8, (x+1) T/8) in row-major order -- a
-    // horizontal band of the image -- so that the span record of a Gaussian (it sits in ~3 neighbouring tiles) is fetched into ONE
-    // L2.  (Dealt heaviest tile first over the XCDs like the compositing launches, every XCD pulled nearly all 8 MB of records
-    // through its 4 MB L2 and the gathers alone took 30 of the kernel's 48 us: D3GA_CULL_ABL.)  The work is uniform enough:
-    // all workgroups are resident at once.
+    // tile_order == null (D3GA_CULL_ORDERED=0, an A/B): workgroup b runs on XCD b % 8 (observed; speed only) and XCD x takes the tiles
+    // [x T/8, (x+1) T/8) in row-major order -- a horizontal band of the image -- so that the span record of a Gaussian (it sits in ~3
+    // neighbouring tiles) is fetched into ONE L2.  Measured: 57-63 us against 37-42 us for the work-ordered deal of the compositing
+    // launches (the bands are unevenly loaded); the default is the work order.
     const int per = (tiles + 7) / 8;
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if ((int)blockIdx.x >= 8 * per || tile >= tiles) return;
@@ -482,7 +481,7 @@ int launch_composite_fwd_lists(const d3ga_raster_params *prm, int gx, int gy, co
                                const float *bg2, float *out_color2, bool ordered, bool exact, const L1Value &l1v, hipStream_t s) {
     const int tiles = gx * gy;
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
-    static const bool cull_ordered = [] { const char *e = getenv("D3GA_CULL_ORDERED"); return e && atoi(e) != 0; }();      // A/B
+    static const bool cull_ordered = [] { const char *e = getenv("D3GA_CULL_ORDERED"); return e ? atoi(e) != 0 : true; }();      // A/B: 0 = the band mapping
     static const int cull_grid = [] { const char *e = getenv("D3GA_CULL_GRID"); return e ? atoi(e) : 0; }();      // experiment: launch only the first n ranks
     hipLaunchKernelGGL(tile_cull_kernel, dim3(cull_grid > 0 ? cull_grid : 8 * ((tiles + 7) / 8)), dim3(kCullThreads), 0, s, gx, tiles, (const uint32_t *)bin.tile_start,
                        (const uint32_t *)bin.point_list, (uint64_t)d_capacity, (const float4 *)g.conic_o, (const float4 *)g.xyh,

@@ -50,4 +50,11 @@ for src, dst in (("bench_color_train.log", f"{tag}_bench_color_train_C4.json"), 
     f = os.path.join(ROOT, "gpurun_out", src)
     if os.path.exists(f) and os.path.getsize(f) > 10:
         shutil.copy(f, os.path.join(ROOT, "profiles", dst))
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", "fwd_impl_*.log")):                  # round 5: the opt-in two-launch forward beside the default
+    if os.path.getsize(f) > 10:
+        shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_" + os.path.basename(f).replace(".log", ".json")))
+for src, dst in (("kstats_lists.txt", f"{tag}_two_launch_forward_kernel_stats.txt"), ("diag_lists_summary.txt", f"{tag}_two_launch_forward_timeline.txt")):
+    f = os.path.join(ROOT, "gpurun_out", src)
+    if os.path.exists(f) and os.path.getsize(f) > 10:
+        shutil.copy(f, os.path.join(ROOT, "profiles", dst))
 print(sorted(os.listdir(os.path.join(ROOT, "profiles"))))

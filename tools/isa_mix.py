@@ -5,7 +5,7 @@ Cross-compiles d3ga_amd/csrc/raster_composite_scan.hip to gfx950 assembly (no GP
 composite_bwd_scan_kernel<false> -- the depth-2 loop (four pixels of one block line) counted four times, the rest of the
 depth-1 loop once -- and classes every VALU instruction by the issue-cost classes tools/micro/valu_issue.hip measures:
 plain (2-operand / fma), dpp, transcendental, packed, and other VOP3 (cndmask / cmp with an SGPR pair, med3, bfi ...).
-Writes profiles/r04_composite_bwd_mix.json (one per round; bench.py reads the newest).
+Writes profiles/r05_composite_bwd_mix.json (one per round; bench.py reads the newest).
 """
 import json
 import os
@@ -74,7 +74,7 @@ def main():
     out = {"kernel": kname, "unit": "instructions per 16-entry group (pixel-line loop x 4, one insert attempt)", "counts": counts,
            "non_valu": other, "note": "vop3_other is priced at the v_cndmask_b32_e64 / v_cmp_*_e64 / v_med3 / v_bfi rate measured by "
            "tools/micro/valu_issue.hip (1.9 ns vs 1.2 ns for v_fma_f32 at 8 waves/SIMD)", "vop3_other_cycles": 3.8}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r04_composite_bwd_mix.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "r05_composite_bwd_mix.json"), "w"), indent=1)
     print(json.dumps(out))
 
 
