@@ -145,8 +145,9 @@ __global__ __launch_bounds__(kCullThreads) void tile_cull_kernel(
     // neighbouring tiles) is fetched into ONE L2.  Measured: 57-63 us against 37-42 us for the work-ordered deal of the compositing
     // launches (the bands are unevenly loaded); the default is the work order.
     const int per = (tiles + 7) / 8;
+    if (tile_order ? (int)blockIdx.x >= tiles : (int)blockIdx.x >= 8 * per) return;      // (the grid is rounded up to a multiple of 8)
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if ((int)blockIdx.x >= 8 * per || tile >= tiles) return;
+    if ((unsigned)tile >= (unsigned)tiles) return;
     const uint32_t begin = (uint32_t)min((uint64_t)tile_start[tile], dcap);
     const uint32_t end = (uint32_t)min((uint64_t)tile_start[tile + 1], dcap);
     if (begin >= end) {                                     // uniform: empty tile
