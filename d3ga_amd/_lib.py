@@ -29,7 +29,7 @@ class RasterParams(ctypes.Structure):
                 ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
                 ("antialiasing", ctypes.c_int32), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
                 ("opacity_activation", ctypes.c_int32), ("forward_only", ctypes.c_int32),
-                ("acc_self_clearing", ctypes.c_int32)]
+                ("acc_self_clearing", ctypes.c_int32), ("block_lists", ctypes.c_int32)]
 
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -57,6 +57,7 @@ _SIGNATURES = {
     "d3ga_raster_img_bytes": ([ctypes.c_int32, ctypes.c_int32, _i64, ctypes.c_int32], _i64),
     "d3ga_raster_preprocess": ([_prm] + [_vp] * 12 + [_i64, _vp, _vp], _i),
     "d3ga_raster_bin_sort": ([_prm, _vp, _vp, _i64, _vp], _i),
+    "d3ga_raster_bin_sort_lists": ([_prm, _vp, _vp, _vp, _i64, ctypes.POINTER(ctypes.c_int32), _vp], _i),
     "d3ga_raster_composite_fwd": ([_prm, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i),
     "d3ga_raster_composite_bwd": ([_prm, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i),
     "d3ga_raster_composite_bwd_depth": ([_prm, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp], _i),
@@ -119,8 +120,8 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = res
-        if L.d3ga_version() != 101:
-            raise D3GAError(f"libd3ga_hip.so version {L.d3ga_version()} does not match the Python layer (101)")
+        if L.d3ga_version() != 102:
+            raise D3GAError(f"libd3ga_hip.so version {L.d3ga_version()} does not match the Python layer (102)")
         info = (ctypes.c_int32 * 8)()
         L.d3ga_debug_defaults(info)
         if info[0] != 0 and os.environ.get("D3GA_ALLOW_ABLATION") != "1":

@@ -65,10 +65,13 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
 // raster_composite_lists.hip: the two-launch forward (tile_cull_kernel + composite_fwd_lists_kernel)
 int launch_composite_fwd_lists(const d3ga_raster_params *prm, int gx, int gy, const BinBuf &bin, const GeomBuf &g, const ImgBuf &im,
                                int64_t d_capacity, const float *bg, float *out_color, float *out_invdepth, const float *colors2,
-                               const float *bg2, float *out_color2, bool ordered, bool exact, const L1Value &l1v, hipStream_t s);
-// D3GA_FWD_IMPL (A/B knob, read once): 0 (default) the one-launch quadrant forward (raster_composite.hip); 1 the two-launch forward
-// of raster_composite_lists.hip for renders that are followed by a backward (measured, not faster: its list pass is latency-bound --
-// DESIGN.md sec. 4; renders with forward_only always use the one-launch forward: no block lists are allocated)
+                               const float *bg2, float *out_color2, bool ordered, bool exact, const L1Value &l1v, bool lists_ready,
+                               hipStream_t s);
+// D3GA_FWD_IMPL (A/B knob, read once): 0 the one-launch quadrant forward (raster_composite.hip); 1 the two-launch forward of
+// raster_composite_lists.hip for renders that are followed by a backward (measured, not faster: its list pass is latency-bound --
+// DESIGN.md sec. 4); 2 the lists blend of raster_composite_lists.hip over block lists the per-tile SORT emitted
+// (d3ga_raster_bin_sort_lists + d3ga_raster_params::block_lists; a composite call whose params do not say so builds them with the
+// list pass of 1).  Renders with forward_only always use the one-launch forward: no block lists are allocated.
 constexpr int kDefaultFwdImpl = 0;
 static inline int composite_fwd_impl_kind() {
     static const int v = [] {
@@ -310,6 +313,77 @@ __device__ __forceinline__ uint32_t span_mask4(const uint4 &sp, int Cq0, int Rq0
     const int R0 = (int)(int16_t)(sp.x & 0xffffu), C0 = (int)sp.x >> 16;
     const int k0 = Rq0 - R0, cb = C0 - Cq0;
     return (span_cols(span_line(sp, k0), cb, 2) & 3u) | ((span_cols(span_line(sp, k0 + 1), cb, 2) & 3u) << 2);
+}
+
+// (bx, by) = block column / line inside the tile -> the block index both directions use: 4 * quadrant + block within it
+__device__ __forceinline__ int blk_of(int bx, int by) { return 4 * ((bx >> 1) + 2 * (by >> 1)) + ((bx & 1) + 2 * (by & 1)); }
+
+// Blocks of the tile at (tx0, ty0) that the splat (centre, conic | opacity) can touch, as a 16-bit mask over blk_of().
+// Box test = block_hits4() per block column / line; exact: per block LINE j the x interval of {q <= tau} inside the slab
+// y in [4j, 4j+3] -- q(dx, dy) = A dx^2 + 2 B dx dy + C dy^2 is convex, so the intersection of the ellipse with the slab spans
+// [l(dyl), r(dyr)] with  r(dy) = (-B dy + sqrt(tau A - det dy^2)) / A  (concave; its maximiser dy* = -(B/C) hx is the
+// ellipse's rightmost point) taken at dy* clamped into the slab, likewise l (convex, minimiser -dy*); a block is kept iff its
+// pixel columns meet that interval.  Same set as block_hits4_exact() up to rounding (tau is inflated by 0.1 % + 1e-4 there and
+// here; the interval is padded by 0.1 % of the splat's extent + 0.02 px), so it stays conservative for ANY footprint.
+__device__ __forceinline__ uint32_t block_mask16(float cx, float cy, float A, float B, float C, float o, float tx0, float ty0, bool exact) {
+    const SplatCull sc = splat_cull(A, B, C, o);
+    if (sc.hx < 0.0f) return 0u;                                      // alpha < 1/255 everywhere (NaN: falls through = relevant)
+    const float xl = cx - sc.hx, xr = cx + sc.hx, yt = cy - sc.hy, yb = cy + sc.hy;
+    uint32_t colbox = 0u, rowbox = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float c0 = tx0 + 4.0f * (float)i, r0 = ty0 + 4.0f * (float)i;
+        colbox |= (!(xr < c0) && !(xl > c0 + 3.0f)) ? (1u << i) : 0u;
+        rowbox |= (!(yb < r0) && !(yt > r0 + 3.0f)) ? (1u << i) : 0u;
+    }
+    if (colbox == 0u || rowbox == 0u) return 0u;
+    const float det = A * C - B * B, rA = __builtin_amdgcn_rcpf(A), tauA = sc.tau * A;
+    const float dys = sc.nbc * sc.hx;                                 // dy of the rightmost point (-dys: leftmost)
+    const float pad = 1e-3f * sc.hx + 0.02f;
+    uint32_t mask = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t cols = colbox;
+        if (exact) {
+            const float ya = (ty0 + 4.0f * (float)j) - cy, yb2 = ya + 3.0f;
+            const float dyr = clamp3(dys, ya, yb2), dyl = clamp3(-dys, ya, yb2);
+            const float sr = __builtin_amdgcn_sqrtf(fmaxf(0.0f, tauA - det * dyr * dyr));
+            const float sl = __builtin_amdgcn_sqrtf(fmaxf(0.0f, tauA - det * dyl * dyl));
+            const float rmax = (sr - B * dyr) * rA + pad, lmin = (-sl - B * dyl) * rA - pad;
+            cols = 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xa = (tx0 + 4.0f * (float)i) - cx;
+                cols |= (!(rmax < xa) && !(lmin > xa + 3.0f)) ? (1u << i) : 0u;     // (NaN: relevant)
+            }
+            cols &= colbox;
+        }
+        cols = ((rowbox >> j) & 1u) ? cols : 0u;
+        // block (i, j) -> bit 8 (j >> 1) + 2 (j & 1) + {0, 1, 4, 5}[i]
+        const int p0 = 8 * (j >> 1) + 2 * (j & 1);
+        mask |= ((cols & 3u) << p0) | (((cols >> 2) & 3u) << (p0 + 4));
+    }
+    return mask;
+}
+
+// the rare path of the mask decoders (tile_cull_kernel, tile_scatter_kernel, the huge-list emission: a splat too large for a span record): out of line, so that its ~250 instructions and their
+// registers are not replicated into every sub-round of the kernel
+static __device__ __attribute__((noinline)) uint32_t block_mask16_slow(uint32_t id, const float4 *__restrict__ xyh, const float4 *__restrict__ conic_o,
+                                                                 float tx0, float ty0, bool exact) {
+    const float4 h = xyh[id], co = conic_o[id];
+    return block_mask16(h.x, h.y, co.x, co.y, co.z, co.w, tx0, ty0, exact);
+}
+
+// inclusive prefix sum over the 64 lanes (DPP: row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast:15 / :31 across them);
+// used on four 8-bit counters packed in a dword (a lane contributes 0 or 1 per counter: no carry between the fields)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // rows 1, 3 += lane 15 of rows 0, 2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // rows 2, 3 += lane 31
+    return v;
 }
 
 __device__ __forceinline__ int lanes_below(unsigned long long m) {   // popcount of m restricted to lower lanes

@@ -75,8 +75,11 @@ extern "C" int d3ga_raster_forward(const d3ga_raster_params *prm, const float *m
                                    float *out_invdepth, d3ga_stream_t stream) {
     D3GA_TRY(d3ga_raster_preprocess(prm, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                     viewmatrix, projmatrix, campos, geom, binning, d_capacity, radii, stream));
-    D3GA_TRY(d3ga_raster_bin_sort(prm, geom, binning, d_capacity, stream));
-    return d3ga_raster_composite_fwd(prm, bg, geom, binning, d_capacity, img, out_color, out_invdepth, stream);
+    int32_t lists = 0;
+    D3GA_TRY(d3ga_raster_bin_sort_lists(prm, geom, binning, img, d_capacity, &lists, stream));
+    d3ga_raster_params p2 = *prm;
+    p2.block_lists = lists;
+    return d3ga_raster_composite_fwd(&p2, bg, geom, binning, d_capacity, img, out_color, out_invdepth, stream);
 }
 
 extern "C" int d3ga_raster_backward(const d3ga_raster_params *prm, const float *means3D, const float *shs,

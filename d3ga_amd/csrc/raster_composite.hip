@@ -413,9 +413,9 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
     ImgBuf im = carve_img(img, prm->W, prm->H, (int64_t)gx * gy);
     if (prm->forward_only) { im.blk_list = nullptr; im.blk_count = nullptr; }     // the buffer ends behind n_contrib
     const bool ordered = (composite_variant() & kVariantOrdered) != 0, exact = (composite_variant() & kVariantExactCull) != 0;
-    if (!prm->forward_only && composite_fwd_impl_kind() == 1)          // opt-in (round 5): lists first, then the blend (raster_composite_lists.hip)
-        return launch_composite_fwd_lists(prm, gx, gy, bin, g, im, d_capacity, bg, out_color, out_invdepth, colors2, bg2, out_color2,
-                                          ordered, exact, l1v, s);
+    if (!prm->forward_only && composite_fwd_impl_kind() != 0)          // (round 5) the blend over explicit block lists (raster_composite_lists.hip):
+        return launch_composite_fwd_lists(prm, gx, gy, bin, g, im, d_capacity, bg, out_color, out_invdepth, colors2, bg2, out_color2,      // emitted by the sort
+                                          ordered, exact, l1v, composite_fwd_impl_kind() == 2 && prm->block_lists != 0, s);                // (block_lists) or built here
     const dim3 grid(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy));
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
 #define D3GA_LAUNCH_FWD(DUALV, DEPTHV, L1VV)                                                                                    \

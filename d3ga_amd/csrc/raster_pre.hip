@@ -475,7 +475,7 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     hipLaunchKernelGGL(preprocess_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
                        colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, g,
                        bin.tile_count, bin.counters, radii,
-                       composite_fwd_impl_kind() == 1 ? ((composite_variant() & kVariantExactCull) ? 1 : 0) : -1);
+                       composite_fwd_impl_kind() != 0 ? ((composite_variant() & kVariantExactCull) ? 1 : 0) : -1);
     return check_launch(s, prm->debug & 0xff);
 }
 

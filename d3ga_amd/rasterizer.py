@@ -331,8 +331,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                     pp, dptr(means3D), dptr(sh), dptr(colors_precomp), dptr(opacities), dptr(scales), dptr(rotations),
                     dptr(cov3Ds_precomp), dptr(view), dptr(proj), dptr(campos), dptr(geom), dptr(binning), cap,
                     dptr(radii), st), "d3ga_raster_preprocess"))
-                stage_timer.stage("bin_sort", lambda: check(L.d3ga_raster_bin_sort(
-                    pp, dptr(geom), dptr(binning), cap, st), "d3ga_raster_bin_sort"))
+                # (the per-tile sort also emits the block lists the compositing kernels walk, when the library's forward uses them)
+                lists = ctypes.c_int32(0)
+                stage_timer.stage("bin_sort", lambda: check(L.d3ga_raster_bin_sort_lists(
+                    pp, dptr(geom), dptr(binning), dptr(img), cap, ctypes.byref(lists), st), "d3ga_raster_bin_sort_lists"))
+                prm.block_lists = lists.value
                 if dual:
                     stage_timer.stage("composite_fwd", lambda: check(L.d3ga_raster_composite_fwd2(
                         pp, dptr(bg), dptr(bg2), dptr(geom), dptr(colors2), dptr(binning), cap, dptr(img), dptr(color),

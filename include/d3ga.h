@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define D3GA_VERSION 101 /* 0.1.1: d3ga_raster_preprocess_bwd / d3ga_raster_backward* read cov3D_precomp again (the forward keeps no copy); NULL without (scales, rotations) is D3GA_E_NULL */
+#define D3GA_VERSION 102 /* 0.1.2: d3ga_raster_params::block_lists, d3ga_raster_bin_sort_lists (the per-tile sort emits the block lists of the compositing kernels).  101: 0.1.1: d3ga_raster_preprocess_bwd / d3ga_raster_backward* read cov3D_precomp again (the forward keeps no copy); NULL without (scales, rotations) is D3GA_E_NULL */
 
 #define D3GA_OK 0
 #define D3GA_E_NULL (-1)     /* required pointer is NULL */
@@ -161,6 +161,10 @@ typedef struct d3ga_raster_params {
      * d3ga_raster_preprocess_bwd zero-fills every record it consumed, so that the buffer is all zero again when it returns.
      * All backwards sharing one such buffer must be ordered on one stream. */
     int32_t acc_self_clearing;
+    /* != 0: the per-4x4-block lists of the img buffer handed to d3ga_raster_composite_fwd* were written by
+     * d3ga_raster_bin_sort_lists (it said so through *lists_written) for THIS binning; the forward then only blends them.
+     * 0: the forward builds whatever lists it needs itself (any binning, e.g. one kept from an earlier render). */
+    int32_t block_lists;
 } d3ga_raster_params;
 #define D3GA_OPACITY_SIGMOID 1
 
@@ -208,6 +212,14 @@ int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float *means3D, 
 /* R2+R3 tile offsets (scan), scatter of (depth,index) keys, per-tile sort in LDS. */
 int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, void *binning, int64_t d_capacity,
                          d3ga_stream_t stream);
+/* The same, and -- when a backward will follow (forward_only == 0) and the library's compositing forward walks explicit block
+ * lists (the default; D3GA_FWD_IMPL=2) -- the per-tile sort also EMITS the per-4x4-block lists into `img` (ImgBuf::blk_list /
+ * blk_total): the scatter writes, beside every (depth, index) key, the 16-bit mask of the tile's blocks the splat's alpha >=
+ * 1/255 ellipse can touch (from the span record preprocess left in geom), the sort carries it along and every wavefront of the
+ * sort workgroup emits the lists of its blocks from the sorted entries in LDS.  *lists_written (HOST int) = 1 if they were
+ * written: pass it on as d3ga_raster_params::block_lists to d3ga_raster_composite_fwd*.  `img` may be NULL when forward_only. */
+int d3ga_raster_bin_sort_lists(const d3ga_raster_params *prm, void *geom, void *binning, void *img, int64_t d_capacity,
+                               int32_t *lists_written, d3ga_stream_t stream);
 /* R4 front-to-back compositing.  bg (3) device.  out_color (3,H,W); out_invdepth (H,W)|NULL. */
 int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, void *img, float *out_color, float *out_invdepth,

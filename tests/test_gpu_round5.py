@@ -85,17 +85,22 @@ np.savez(sys.argv[1], **out)
 
 def test_two_launch_forward_equals_the_one_launch_forward(tmp_path):
     """D3GA_FWD_IMPL=1 (opt-in: block lists built by tile_cull_kernel from the per-Gaussian span records, then the lists blend)
-    renders the same frames as the default forward: identical termination, images to float rounding, gradients to 2e-5 of the
-    largest element.  T1 x 8 holds splats too large for a span record (the geometric fallback of the list pass)."""
+    and D3GA_FWD_IMPL=2 (opt-in: the per-tile SORT emits the block lists -- d3ga_raster_bin_sort_lists -- then the same blend)
+    render the same frames as the default forward: identical termination, images to float rounding, gradients to 2e-5 of the
+    largest element; 1 and 2 build identical lists, so their results are bit-identical.  T1 x 8 holds splats too large for a
+    span record (the geometric fallback of the list pass / of the sort's mask decoder)."""
     files = {}
-    for impl in ("0", "1"):
+    for impl in ("0", "1", "2"):
         f = str(tmp_path / f"impl{impl}.npz")
         env = dict(os.environ, D3GA_FWD_IMPL=impl)
         r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT), f], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         files[impl] = np.load(f)
-    a, b = files["0"], files["1"]
-    for k in a.files:
+    for k in files["1"].files:                               # the same lists, the same blend (the backward's sums may differ in order)
+        if k.endswith(("_n", "_img")):
+            np.testing.assert_array_equal(files["1"][k], files["2"][k], err_msg=k)
+    for a, b in ((files["0"], files["1"]), (files["0"], files["2"])):
+      for k in a.files:
         if k.endswith("_n"):
             assert (a[k] != b[k]).mean() < 1e-4, k           # (a T < 1e-4 decision may fall the other way: sums in another order)
         elif k.endswith("_img"):
@@ -110,7 +115,7 @@ def test_backward_without_the_precomputed_covariance_is_refused():
     neither cov3D_precomp nor (scales, rotations) returns D3GA_E_NULL instead of reading uninitialised records."""
     from d3ga_amd import _lib
     L = _lib.lib()
-    assert L.d3ga_version() == 101
+    assert L.d3ga_version() == 102
     prm = _lib.RasterParams(P=16, M=0, sh_degree=0, W=64, H=64, tanfovx=1.0, tanfovy=1.0, scale_modifier=1.0, antialiasing=0,
                             prefiltered=0, debug=0, opacity_activation=0, forward_only=0, acc_self_clearing=0)
     buf = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
