@@ -84,11 +84,21 @@ __global__ __launch_bounds__(1024) void sum_partials_wide_kernel(int np, const f
     __shared__ float s_part[16];
     float acc = 0.f;
     const int np4 = np >> 2;
-    for (int i = threadIdx.x; i < np4; i += 1024) {
+    // eight independent 16-byte loads in flight per thread (a 4K frame has 130 k partials: 32 DEPENDENT load -> add trips per
+    // thread made this launch 14.8 us at C5; 1080p: 8 trips, 4.7 us = the floor of any launch)
+    int i = threadIdx.x;
+    for (; i + 7 * 1024 < np4; i += 8 * 1024) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4 *>(partials)[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+    }
+    for (; i < np4; i += 1024) {
         const float4 v = reinterpret_cast<const float4 *>(partials)[i];
         acc += (v.x + v.y) + (v.z + v.w);
     }
-    for (int i = 4 * np4 + threadIdx.x; i < np; i += 1024) acc += partials[i];
+    for (int j = 4 * np4 + threadIdx.x; j < np; j += 1024) acc += partials[j];
     acc = wave_sum_loss(acc);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
     __syncthreads();

@@ -785,9 +785,13 @@ static int bin_sort_impl(const d3ga_raster_params *prm, void *geom, void *binnin
         const ImgBuf im = carve_img(img, prm->W, prm->H, tiles);
         lo = ListOut{im.blk_list, im.blk_total, g.span, g.xyh, g.conic_o, gx, (composite_variant() & kVariantExactCull) != 0};
     }
+    // A/B (D3GA_SORT_SMALL=4096): the per-tile kernel with 512 threads and 4096 keys -- no 2049..4096 class (at C3 the list launch
+    // then finds nothing to do)
+    static const int small_env = [] { const char *e = getenv("D3GA_SORT_SMALL"); return e ? atoi(e) : 0; }();
+    const bool small4k = small_env == 4096 && !lists;
     hipLaunchKernelGGL(tile_scan_order_kernel, dim3(2), dim3(kScanBlock), 0, s, tiles, bin.tile_count, bin.tile_start,
                        bin.tile_cursor, bin.counters, (uint64_t)d_capacity, bin.big_tiles, bin.huge_tiles, bin.mid_tiles,
-                       (uint32_t)kSortSmall, (uint32_t)kSortMid, (uint32_t)kSortLarge, bin.tile_order);
+                       (uint32_t)(small4k ? kSortMid : kSortSmall), (uint32_t)kSortMid, (uint32_t)kSortLarge, bin.tile_order);
     D3GA_TRY(check_launch(s, prm->debug));
     if (prm->P == 0 || d_capacity == 0) return D3GA_OK;
     hipLaunchKernelGGL(tile_scatter_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, prm->P, gx, g.rect,
@@ -806,7 +810,16 @@ static int bin_sort_impl(const d3ga_raster_params *prm, void *geom, void *binnin
             want = per_cu * cus;
             if (dev >= 0 && dev < 64) resident[dev][lists ? 1 : 0] = want;
         }
-        if (lists)
+        if (small4k) {
+            static int want4k = 0;
+            if (want4k == 0) {
+                int per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)tile_sort_lds_kernel<512, kSortMid, false>, 512, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+                want4k = per_cu * 256;
+            }
+            hipLaunchKernelGGL((tile_sort_lds_kernel<512, kSortMid, false>), dim3(tiles < want4k ? tiles : want4k), dim3(512), 0, s, bin.tile_start,
+                               bin.keys, bin.point_list, (uint64_t)d_capacity, (const uint32_t *)bin.tile_order, tiles, lo);
+        } else if (lists)
             hipLaunchKernelGGL((tile_sort_lds_kernel<256, kSortSmall, true>), dim3(tiles < want ? tiles : want), dim3(256), 0, s, bin.tile_start,
                                bin.keys, bin.point_list, (uint64_t)d_capacity, (const uint32_t *)bin.tile_order, tiles, lo);
         else

@@ -46,10 +46,10 @@ for k in 1 2 4; do
   timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train-step --force-cut --views-per-rank $k 2>> gpurun_out/force_cut.err | grep "^{" > gpurun_out/force_cut_C3_k$k.log
 done
 timeout 600 python bench.py --workload C4 --steps 100 --warmup 10 --no-cpu-baseline --no-train-step --force-cut 2>> gpurun_out/force_cut.err | grep "^{" > gpurun_out/force_cut_C4_k1.log
-# round 5: the opt-in two-launch forward (D3GA_FWD_IMPL=1) beside the default, same box: headline, larger splats, 4K
+# round 5: the opt-in forwards over explicit block lists (D3GA_FWD_IMPL=1: a list pass; 2: lists emitted by the per-tile sort) beside the default, same box: headline, larger splats, 4K
 for wl in "C3:" "C3s2:--scale-mult 2" "C5:--workload C5"; do
   name=${wl%%:*}; extra=${wl#*:}
-  for impl in 0 1; do
+  for impl in 0 1 2; do
     D3GA_FWD_IMPL=$impl timeout 600 python bench.py --steps 20 --warmup 8 --no-cpu-baseline --no-train-step $extra 2> gpurun_out/fwd_impl_${name}_$impl.err | grep "^{" > gpurun_out/fwd_impl_${name}_$impl.log
   done
 done
@@ -63,6 +63,6 @@ for f in sorted(glob.glob("gpurun_out/fwd_impl_*.log")):
         print(f, "FAILED", e)
 PY
 # the two-launch forward's kernels by rocprofv3 + its per-wave timeline (tools/diag_lists.py)
-bash tools/gpu_kstats.sh "lists:D3GA_FWD_IMPL=1,D3GA_CULL_ORDERED=1" 2>&1 | grep -E "^==|composite|cull|preprocess_kernel" > gpurun_out/kstats_lists.txt
+bash tools/gpu_kstats.sh "lists:D3GA_FWD_IMPL=1,D3GA_CULL_ORDERED=1 sortlists:D3GA_FWD_IMPL=2" 2>&1 | grep -E "^==|composite|cull|preprocess_kernel|sort|scatter" > gpurun_out/kstats_lists.txt
 D3GA_FWD_IMPL=1 D3GA_CULL_ORDERED=1 bash tools/gpu_diag_lists.sh > gpurun_out/diag_lists_summary.txt 2>&1
 bash tools/gpu_diag_json.sh C3 > gpurun_out/diag_json.log 2>&1
