@@ -31,6 +31,17 @@ def test_library_exports_every_declared_symbol():
     assert L.d3ga_status_string(-3) == b"unsupported argument combination"
 
 
+def test_driver_build_entry_accepts_the_shipped_abi():
+    """Found at the start of a session of round 5: __graft_entry__.build() still asserted the previous ABI number after the
+    header moved on, so the driver's "does it build" check would have failed on a library that was fine.  build() now reads
+    the number from include/d3ga.h; this runs the same checks it runs behind the compile step."""
+    import d3ga_amd
+    ver = int(re.search(r"#define\s+D3GA_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "d3ga.h")).read()).group(1))
+    assert d3ga_amd.lib().d3ga_version() == ver
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "D3GA_VERSION" in src and not re.search(r"d3ga_version\(\)\s*==\s*\d", src)
+
+
 def test_library_defaults_are_the_ones_design_md_states():
     """docs and binary disagreed about the backward's block -> wavefront assignment.  DESIGN.md carries a
     machine-readable table of the library's knob defaults; the shipped .so must report exactly those (and must not be a
