@@ -38,6 +38,16 @@ static inline int composite_tile_assign() {        // A/B knob (D3GA_TILE_ASSIGN
     }();
     return v;
 }
+// rows per block of the backward's tile kernel (D3GA_BWD_ROWS: 1 | 2 | 4 -- 4 / 8 / 16 wavefronts per tile; raster_composite_scan.hip)
+constexpr int kDefaultBwdRows = 1;
+static inline int composite_bwd_rows() {
+    static const int v = [] {
+        const char *e = getenv("D3GA_BWD_ROWS");
+        const int r = e ? atoi(e) : kDefaultBwdRows;
+        return (r == 2 || r == 4) ? r : 1;
+    }();
+    return v;
+}
 // A/B knob (D3GA_FWD_LDS_TOTAL / D3GA_BWD_LDS_TOTAL, bytes): pad a kernel's LDS allocation up to this total with dynamic shared
 // memory -- limits the workgroups resident per CU (160 KB / total) without touching the code: fewer, faster waves per SIMD
 // and more dispatch rounds (the hardware dispatcher hands out workgroups in launch order as slots free up).  0 / unset: no pad.

@@ -48,15 +48,29 @@ namespace d3ga {
     OP " %1, %1, %1 row_shr:" #N " row_mask:0xf bank_mask:0xf" BC "\n" \
     OP " %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf" BC "\n" \
     OP " %3, %3, %3 row_shr:" #N " row_mask:0xf bank_mask:0xf" BC "\n"
+// R rows per block (R = 2, 4: a block's list runs over 32 / 64 lanes): the row scans are continued across the rows with
+// row_bcast:15 (lane 15 of a row -> every lane of the next row; row_mask 0xa: rows 1 and 3 take it) and, for R = 4,
+// row_bcast:31 (lane 31 -> rows 2 and 3) -- the wave-wide scan idiom of this ISA family, two more steps per chain.
+#define D3GA_SCANX(OP, CTRL, MASK) \
+    OP " %0, %0, %0 " CTRL " row_mask:" MASK " bank_mask:0xf\n" \
+    OP " %1, %1, %1 " CTRL " row_mask:" MASK " bank_mask:0xf\n" \
+    OP " %2, %2, %2 " CTRL " row_mask:" MASK " bank_mask:0xf\n" \
+    OP " %3, %3, %3 " CTRL " row_mask:" MASK " bank_mask:0xf\n"
+template <int R = 1>
 __device__ __forceinline__ void row_scan_mul4(float &a, float &b, float &c, float &d) {
     asm("s_nop 1\n" D3GA_SCAN4("v_mul_f32_dpp", "", 1) D3GA_SCAN4("v_mul_f32_dpp", "", 2) D3GA_SCAN4("v_mul_f32_dpp", "", 4)
         D3GA_SCAN4("v_mul_f32_dpp", "", 8)
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (R >= 2) asm("s_nop 1\n" D3GA_SCANX("v_mul_f32_dpp", "row_bcast:15", "0xa") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (R >= 4) asm("s_nop 1\n" D3GA_SCANX("v_mul_f32_dpp", "row_bcast:31", "0xc") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+template <int R = 1>
 __device__ __forceinline__ void row_scan_add4(float &a, float &b, float &c, float &d) {
     asm("s_nop 1\n" D3GA_SCAN4("v_add_f32_dpp", " bound_ctrl:1", 1) D3GA_SCAN4("v_add_f32_dpp", " bound_ctrl:1", 2)
         D3GA_SCAN4("v_add_f32_dpp", " bound_ctrl:1", 4) D3GA_SCAN4("v_add_f32_dpp", " bound_ctrl:1", 8)
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (R >= 2) asm("s_nop 1\n" D3GA_SCANX("v_add_f32_dpp", "row_bcast:15", "0xa") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    if constexpr (R >= 4) asm("s_nop 1\n" D3GA_SCANX("v_add_f32_dpp", "row_bcast:31", "0xc") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
 struct ScanEntry {          // one list entry as the lane that owns it holds it
@@ -105,8 +119,12 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 // INVD: the inverse-depth image of branch dr_aa takes part as a fourth channel (its "colour" is the entry's 1 / depth): the
 // incoming dL/dinvdepth joins c . g, and the entry's dL/d(1/depth) = sum alpha T dL/dinvdepth is a tenth accumulated value
 // (the pad word of the cache slot, float 10 of the accumulator record).
-template <bool DUAL, int S, bool INVD = false>
-__global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kernel(
+// R: rows per block (D3GA_BWD_ROWS).  1: a wavefront's four rows walk four blocks, 16 entries per group and block, four
+// wavefronts per tile.  2 / 4: 8 / 16 wavefronts per tile, a block's list runs over 2 / 4 rows (32 / 64 entries per group), a
+// wavefront takes 2 / 1 blocks -- the same pixel steps in total, but the tile's longest list is walked in half / a quarter of
+// the groups: the critical path of a heavy tile (18 groups of one wavefront at C3) shrinks with it.
+template <bool DUAL, int S, bool INVD = false, int R = 1>
+__global__ __launch_bounds__(256 * R, D3GA_TILE_WAVES) void composite_bwd_tile_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, uint64_t dcap, const float2 *__restrict__ xy,
     const float4 *__restrict__ conic_o, const float4 *__restrict__ rgb_invd, const float *__restrict__ bg,
     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
@@ -114,7 +132,8 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     const float *__restrict__ bg2, const float *__restrict__ dL_dpix2, const uint2 *__restrict__ blk_list,
     const uint32_t *__restrict__ blk_count, int assign, L1Source l1, const float *__restrict__ dL_dinvd) {
     static_assert((S & (S - 1)) == 0, "power of two");
-    constexpr int NW = 4;                            // wavefronts per tile (three, the third walking two sets of blocks: measured, slower -- DESIGN.md sec. 4)
+    constexpr int NW = 4 * R;                        // wavefronts per tile (three, the third walking two sets of blocks: measured, slower -- DESIGN.md sec. 4)
+    constexpr int SEG = 4 / R, LW = 16 * R;          // blocks per wavefront, lanes per block
     constexpr int PIXF = DUAL ? 12 : 8;
     constexpr int ROWF = 16 * PIXF + 4;
     constexpr int kSlot = 12;                        // dwords per cache slot
@@ -128,7 +147,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     const uint32_t end = (uint32_t)min((uint64_t)tile_start[tile + 1], dcap);
     if (begin >= end) return;                              // uniform: empty tile
 
-    __shared__ __attribute__((aligned(16))) float s_pix_all[NW][4 * ROWF];
+    __shared__ __attribute__((aligned(16))) float s_pix_all[NW][SEG * ROWF];
     __shared__ __attribute__((aligned(16))) float s_dump_all[NW][64 * 2 + 16 * PIXF];
     __shared__ __attribute__((aligned(16))) uint32_t s_cache[S * kSlot];
     // slot = (list position - 1) mod S: a list of n < S entries uses the first n slots only (init and publish stop there: a
@@ -138,6 +157,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     __shared__ uint32_t s_arrived;                          // wavefronts of this tile that are done (the last one publishes the cache)
     if (threadIdx.x == 0) s_arrived = 0u;
     __shared__ uint8_t s_perm[16];                          // assign 2: the tile's 16 blocks by descending list length
+    if (R > 1) assign = 2;                                  // (the quadrant / interleaved assignments exist for R = 1 only)
     if (assign == 2 && threadIdx.x < 16) {
         const int b = threadIdx.x, tx0 = (tile % gx) * kTile, ty0 = (tile / gx) * kTile;
         auto count_of = [&](int j) -> uint32_t {            // (the forward writes the counts of quadrants that start inside the image)
@@ -164,7 +184,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     // g = (wave + workgroup) mod 4.  A wavefront runs as many groups as its longest row needs, so rows of unequal length pad
     // (quadrants: 57.5 k wave-groups at C3, interleaved 59.3 k, against 49 k row-groups / 4); and rotating g with the workgroup
     // index gives every SIMD of a CU (wave w of a workgroup runs on SIMD w) one wavefront of each weight class.
-    const int row = lane >> 4, l16 = lane & 15;
+    const int row = lane / LW, l16 = lane & 15, lseg = lane & (LW - 1);      // row: which of the wavefront's blocks; lseg: lane within the block's group
     constexpr int kVals = INVD ? 10 : 9, kPerInst = 64 / kVals;           // publish: values per record, records per instruction
     const int fq = lane / kVals, fk = lane - kVals * fq;   // lane -> (record within a group of 7 (6), value)
     const int fk_off = fk < 2 ? fk : fk + 1;               // acc layout 0,1 | 3,4,5 | 6 | 7,8,9 | 10 (dL/d(1/depth), INVD)
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
         int bx = assign ? 2 * (row & 1) + (wave & 1) : 2 * (wave & 1) + (row & 1);
         int by = assign ? 2 * (row >> 1) + (wave >> 1) : 2 * (wave >> 1) + (row >> 1);
         if (assign == 2) {
-            const int b = s_perm[4 * ((wave + (int)blockIdx.x) & 3) + row], q = b >> 2, r = b & 3;
+            const int b = s_perm[SEG * ((wave + (int)blockIdx.x) & (NW - 1)) + row], q = b >> 2, r = b & 3;
             bx = 2 * (q & 1) + (r & 1); by = 2 * (q >> 1) + (r >> 1);
         }
         const int blk = 4 * ((bx >> 1) + 2 * (by >> 1)) + ((bx & 1) + 2 * (by & 1));
@@ -216,7 +236,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
         if (maxlast == 0) break;
 
         float *const pixrow = s_pix + row * ROWF;
-        float *const wr_base = l16 == 15 ? pixrow : s_dump + 2 * lane;
+        float *const wr_base = lseg == LW - 1 ? pixrow : s_dump + 2 * lane;
         {
             float *rec = pixrow + l16 * PIXF;
             *reinterpret_cast<float4 *>(rec) = make_float4(T_final, 0.f, g0, g1);
@@ -230,14 +250,14 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
         const bool quad_in = bx0 - 4 * (bx & 1) < W && by0 - 4 * (by & 1) < H;
         const uint32_t cnt = quad_in ? blk_count[16 * (size_t)tile + blk] : 0u;
         const uint2 *const list = blk_list + 16 * (size_t)begin + (size_t)blk * blk_cap;
-        const int ngroups = (int)((wave_max_u32(cnt) + 15u) >> 4);
+        const int ngroups = (int)((wave_max_u32(cnt) + (uint32_t)(LW - 1)) / (uint32_t)LW);
         const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
         const float bxr = (float)bx0, byr = (float)by0;
-        const int per = D3GA_SCAN_ABL == 12 ? 16 : (ngroups > 0 ? ((int)cnt + ngroups - 1) / ngroups : 0);      // rows paced to finish together (see above)
+        const int per = D3GA_SCAN_ABL == 12 ? LW : (ngroups > 0 ? ((int)cnt + ngroups - 1) / ngroups : 0);      // rows paced to finish together (see above)
         auto list_entry = [&](int g) -> uint2 {
-            const int idx = (int)cnt - 1 - per * g - l16;
+            const int idx = (int)cnt - 1 - per * g - lseg;
             uint2 v = list[max(idx, 0)];
-            v.x = (idx >= 0 && l16 < per) ? v.x : 0u;
+            v.x = (idx >= 0 && lseg < per) ? v.x : 0u;
             return v;
         };
         ScanEntry e = scan_gather<DUAL>(list_entry(0), xy, conic_o, rgb_invd, colors2);
@@ -299,13 +319,13 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
                     if constexpr (INVD) cgv[k] = fmaf(e.rgb.w, pb[k].w, cgv[k]);
                 }
                 float p0 = r[0], p1 = r[1], p2 = r[2], p3 = r[3];
-                row_scan_mul4(p0, p1, p2, p3);
+                row_scan_mul4<R>(p0, p1, p2, p3);
                 const float Ti[4] = {pa[0].x * p0, pa[1].x * p1, pa[2].x * p2, pa[3].x * p3};
                 float dch[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { dch[k] = al[k] * Ti[k]; u[k] = cgv[k] * dch[k]; }
                 float s0 = u[0], s1 = u[1], s2 = u[2], s3 = u[3];
-                row_scan_add4(s0, s1, s2, s3);
+                row_scan_add4<R>(s0, s1, s2, s3);
                 const float Sin[4] = {s0 + pa[0].y, s1 + pa[1].y, s2 + pa[2].y, s3 + pa[3].y};
                 float *const wq = wr_base + ky * 4 * PIXF;
                 float gop[4];
@@ -345,7 +365,7 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
 #endif
 #ifdef D3GA_DIAG_COUNTERS
             dg_entries += act ? 1 : 0;
-            dg_rowgroups += (act && l16 == 0) ? 1 : 0;
+            dg_rowgroups += (act && lseg == 0) ? 1 : 0;
 #endif
             while (__builtin_amdgcn_ballot_w64(pending) != 0ull) {
 #ifdef D3GA_DIAG_TIMELINE
@@ -438,9 +458,9 @@ __global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_tile_kerne
     atomicAdd(&g_diag_scan[8], dg_valid); atomicAdd(&g_diag_scan[9], dg_entries); atomicAdd(&g_diag_scan[10], dg_rowgroups);
 #endif
 #ifdef D3GA_DIAG_TIMELINE
-    if (lane == 0 && dg_groups && blockIdx.x < 8192) {      // no atomics here: returning same-address atomics serialise at the memory side and would BE the timeline
+    if (lane == 0 && dg_groups && blockIdx.x < 32768 / NW) {      // no atomics here: returning same-address atomics serialise at the memory side and would BE the timeline
         const unsigned long long diag_w1 = __builtin_amdgcn_s_memrealtime();
-        const size_t slot = 4 * (size_t)blockIdx.x + wave;
+        const size_t slot = NW * (size_t)blockIdx.x + wave;
         g_diag_waves[4 * slot] = diag_w0 | ((__builtin_readcyclecounter() - diag_t0) << 40);
         g_diag_waves[4 * slot + 1] = diag_w1;
         g_diag_waves[4 * slot + 2] = dg_groups | (dg_trips << 16) | ((unsigned long long)(end - begin) << 32);
@@ -497,11 +517,15 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
     const dim3 tgrid(gx * gy);
     const int S = composite_merge_slots();
-#define D3GA_LAUNCH_TILE(DUALV, SV, INVDV)                                                                                    \
-    hipLaunchKernelGGL((composite_bwd_tile_kernel<DUALV, SV, INVDV>), tgrid, dim3(256),                                        \
-                       lds_pad_bytes((const void *)composite_bwd_tile_kernel<DUALV, SV, INVDV>, "D3GA_BWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
+    const int R = composite_bwd_rows();
+#define D3GA_LAUNCH_TILE_R(DUALV, SV, INVDV, RV)                                                                              \
+    hipLaunchKernelGGL((composite_bwd_tile_kernel<DUALV, SV, INVDV, RV>), tgrid, dim3(256 * RV),                                \
+                       lds_pad_bytes((const void *)composite_bwd_tile_kernel<DUALV, SV, INVDV, RV>, "D3GA_BWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
                        (uint64_t)d_capacity, reinterpret_cast<const float2 *>(g.xyh), g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc, order,   \
                        colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, composite_tile_assign(), l1, dL_dinvd)
+#define D3GA_LAUNCH_TILE(DUALV, SV, INVDV)                                                                                    \
+    do { if (R == 2) D3GA_LAUNCH_TILE_R(DUALV, SV, INVDV, 2); else if (R == 4) D3GA_LAUNCH_TILE_R(DUALV, SV, INVDV, 4);        \
+         else D3GA_LAUNCH_TILE_R(DUALV, SV, INVDV, 1); } while (0)
     if (dL_dinvd) {                                          // inverse-depth gradient (branch dr_aa): single-image launches only
         if (colors2) return D3GA_E_CONFIG;
         if (S >= 512) D3GA_LAUNCH_TILE(false, 512, true); else D3GA_LAUNCH_TILE(false, 256, true);
@@ -510,6 +534,7 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
     else if (S >= 512) D3GA_LAUNCH_TILE(false, 512, false);
     else D3GA_LAUNCH_TILE(false, 256, false);
 #undef D3GA_LAUNCH_TILE
+#undef D3GA_LAUNCH_TILE_R
     return check_launch(s, prm->debug);
 }
 
