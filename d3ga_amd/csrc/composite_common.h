@@ -48,6 +48,23 @@ static inline int composite_bwd_rows() {
     }();
     return v;
 }
+// the D3GA_BWD_SPLIT heaviest tiles (in work order) get two workgroups each in the backward (raster_composite_scan.hip)
+constexpr int kDefaultBwdSplit = 0;
+static inline int composite_bwd_split() {
+    static const int v = [] { const char *e = getenv("D3GA_BWD_SPLIT"); const int r = e ? atoi(e) : kDefaultBwdSplit; return r < 0 ? 0 : r; }();
+    return v;
+}
+// persistent variant of the backward's tile kernel (D3GA_BWD_PERSIST = resident workgroups per CU, 0: off) and the slots of each of
+// its two merge caches (D3GA_PERSIST_SLOTS: 128 | 256 | 512)
+constexpr int kDefaultBwdPersist = 0;
+static inline int composite_bwd_persist() {
+    static const int v = [] { const char *e = getenv("D3GA_BWD_PERSIST"); const int r = e ? atoi(e) : kDefaultBwdPersist; return r < 0 ? 0 : (r > 8 ? 8 : r); }();
+    return v;
+}
+static inline int composite_persist_slots() {
+    static const int v = [] { const char *e = getenv("D3GA_PERSIST_SLOTS"); return e ? atoi(e) : 256; }();
+    return v;
+}
 // A/B knob (D3GA_FWD_LDS_TOTAL / D3GA_BWD_LDS_TOTAL, bytes): pad a kernel's LDS allocation up to this total with dynamic shared
 // memory -- limits the workgroups resident per CU (160 KB / total) without touching the code: fewer, faster waves per SIMD
 // and more dispatch rounds (the hardware dispatcher hands out workgroups in launch order as slots free up).  0 / unset: no pad.
