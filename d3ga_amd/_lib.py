@@ -120,8 +120,8 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = res
-        if L.d3ga_version() != 102:
-            raise D3GAError(f"libd3ga_hip.so version {L.d3ga_version()} does not match the Python layer (102)")
+        if L.d3ga_version() != 103:
+            raise D3GAError(f"libd3ga_hip.so version {L.d3ga_version()} does not match the Python layer (103)")
         info = (ctypes.c_int32 * 8)()
         L.d3ga_debug_defaults(info)
         if info[0] != 0 and os.environ.get("D3GA_ALLOW_ABLATION") != "1":

@@ -38,31 +38,11 @@ static inline int composite_tile_assign() {        // A/B knob (D3GA_TILE_ASSIGN
     }();
     return v;
 }
-// rows per block of the backward's tile kernel (D3GA_BWD_ROWS: 1 | 2 | 4 -- 4 / 8 / 16 wavefronts per tile; raster_composite_scan.hip)
-constexpr int kDefaultBwdRows = 1;
-static inline int composite_bwd_rows() {
-    static const int v = [] {
-        const char *e = getenv("D3GA_BWD_ROWS");
-        const int r = e ? atoi(e) : kDefaultBwdRows;
-        return (r == 2 || r == 4) ? r : 1;
-    }();
-    return v;
-}
-// the D3GA_BWD_SPLIT heaviest tiles (in work order) get two workgroups each in the backward (raster_composite_scan.hip)
-constexpr int kDefaultBwdSplit = 0;
+// Backward: the heaviest tiles (in work order) get two workgroups each (raster_composite_scan.hip).  D3GA_BWD_SPLIT: -1 (default) = as many
+// as the order kernel counts (a tenth of the non-empty tiles: D3GA_CNT_HEAVY), 0 = none, n > 0 = the n heaviest
+constexpr int kDefaultBwdSplit = -1;
 static inline int composite_bwd_split() {
-    static const int v = [] { const char *e = getenv("D3GA_BWD_SPLIT"); const int r = e ? atoi(e) : kDefaultBwdSplit; return r < 0 ? 0 : r; }();
-    return v;
-}
-// persistent variant of the backward's tile kernel (D3GA_BWD_PERSIST = resident workgroups per CU, 0: off) and the slots of each of
-// its two merge caches (D3GA_PERSIST_SLOTS: 128 | 256 | 512)
-constexpr int kDefaultBwdPersist = 0;
-static inline int composite_bwd_persist() {
-    static const int v = [] { const char *e = getenv("D3GA_BWD_PERSIST"); const int r = e ? atoi(e) : kDefaultBwdPersist; return r < 0 ? 0 : (r > 8 ? 8 : r); }();
-    return v;
-}
-static inline int composite_persist_slots() {
-    static const int v = [] { const char *e = getenv("D3GA_PERSIST_SLOTS"); return e ? atoi(e) : 256; }();
+    static const int v = [] { const char *e = getenv("D3GA_BWD_SPLIT"); return e ? atoi(e) : kDefaultBwdSplit; }();
     return v;
 }
 // A/B knob (D3GA_FWD_LDS_TOTAL / D3GA_BWD_LDS_TOTAL, bytes): pad a kernel's LDS allocation up to this total with dynamic shared

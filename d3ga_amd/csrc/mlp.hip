@@ -587,126 +587,6 @@ __global__ __launch_bounds__(kWgThreads) void wgrad_ws_kernel(int P, int N, int 
 }
 
 
-// Round 5: the same pipeline with the two roles as separate top-level branches (the accumulators are live in the multipliers'
-// branch only, so the loaders have the whole 128-register budget) and THREE chunks of loads in flight per loader instead of
-// two: 96 KB instead of 64 KB outstanding per CU (the two-set kernel above sits at 3.8 TB/s at 500k rows; a third set
-// inside it spilled).  Barriers are executed the same number of times in both branches (the branch is wave-uniform, made
-// scalar with readfirstlane); the LDS buffers stay two (chunk c lives in buffer c & 1: it is committed in step c and
-// multiplied in step c + 1).
-template <bool VECA, bool VECB, int NS>
-__global__ __launch_bounds__(kWgThreads) void wgrad_ws3_kernel(int P, int N, int K, int NBk, int NBn, int rows_per_block,
-                                                               const float *__restrict__ dpre, const float *__restrict__ X,
-                                                               float *__restrict__ dW, float *__restrict__ db) {
-    extern __shared__ __attribute__((aligned(16))) char smem_ws[];     // two buffers x (dPre planes | X planes)
-    uint4 *s_buf = reinterpret_cast<uint4 *>(smem_ws);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r_begin = blockIdx.x * rows_per_block;
-    const int r_end = min(P, r_begin + rows_per_block);
-    if (r_begin >= r_end) return;
-    const int n_chunks = (r_end - r_begin + kWsRows - 1) / kWsRows;
-    float *s_sum = reinterpret_cast<float *>(smem_ws);
-    if (wave < 8) {                                                    // ---- loaders ----
-        const bool is_a = wave < 4;
-        WgJob job = {is_a ? dpre : X, nullptr, is_a ? N : K, wave & 3, 2 * lane, 2, is_a};
-        float2 v[NS][8];
-        float cs[2] = {0.f, 0.f};
-        auto fetch = [&](float2 (&v)[8], int c) __attribute__((always_inline)) {
-            const int r0 = min(r_begin + c * kWsRows, r_end - 1);      // past the range: clamped rows, never committed
-            if (is_a) wg_issue<VECA>(v, job, r0, r_end); else wg_issue<VECB>(v, job, r0, r_end);
-        };
-        auto commit = [&](const float2 (&v)[8], int c) __attribute__((always_inline)) {
-            WgJob j = job;
-            j.s_op = s_buf + (c & 1) * kWsBufferUnits + (is_a ? 0 : kWsOperandUnits);
-            wg_commit_ws(v, j, r_begin + c * kWsRows, r_end, cs);
-        };
-#pragma unroll
-        for (int j = 0; j < NS; ++j) { fetch(v[j], j); __builtin_amdgcn_sched_barrier(0); }
-        for (int c = 0; c <= n_chunks; c += NS) {
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                if (c + j <= n_chunks) {                               // (uniform; the multipliers count the same barriers)
-                    if (c + j < n_chunks) { commit(v[j], c + j); fetch(v[j], c + j + NS); }
-                    __syncthreads();
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (db) {                                                      // bias gradient: column sums held by the dPre loaders
-            __syncthreads();
-            if (tid < 128) s_sum[tid] = 0.f;
-            __syncthreads();
-            if (is_a) { if (job.c < N) atomicAdd(s_sum + job.c, cs[0]); if (job.c + 1 < N) atomicAdd(s_sum + job.c + 1, cs[1]); }
-            __syncthreads();
-            if (tid < N) atomicAdd(db + tid, s_sum[tid]);
-        }
-        return;
-    }
-    // ---- multipliers ----
-    const int half = lane >> 5, l32 = lane & 31;
-    const int m = wave - 8, NBk2 = (NBk + 1) / 2;
-    const bool worker = m < NBn * NBk2;
-    const int nb = worker ? m / NBk2 : 0, kb0 = worker ? 2 * (m - nb * NBk2) : 0;
-    const bool two = kb0 + 1 < NBk;
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    auto multiply = [&](int c) __attribute__((always_inline)) {
-        const uint4 *pa = s_buf + (c & 1) * kWsBufferUnits + half * 128 + 32 * nb + l32;
-        const uint4 *pb = s_buf + (c & 1) * kWsBufferUnits + kWsOperandUnits + half * 128 + 32 * kb0 + l32;
-#pragma unroll
-        for (int ks = 0; ks < kWsRows / 16; ++ks) {
-            bf16x8_t a[3], b[3], d[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                a[pl] = __builtin_bit_cast(bf16x8_t, pa[pl * kWsPlaneUnits + 2 * ks * 128]);
-                b[pl] = __builtin_bit_cast(bf16x8_t, pb[pl * kWsPlaneUnits + 2 * ks * 128]);
-                d[pl] = __builtin_bit_cast(bf16x8_t, pb[pl * kWsPlaneUnits + 2 * ks * 128 + (two ? 32 : 0)]);
-            }
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], d[0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], d[1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], d[2], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], d[0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], d[1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], d[0], acc1, 0, 0, 0);
-        }
-    };
-    for (int c = 0; c <= n_chunks; c += NS) {
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            if (c + j <= n_chunks) {
-                if (worker && c + j >= 1) multiply(c + j - 1);
-                __syncthreads();
-            }
-        }
-    }
-    if (db) {
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
-        if (tid < N) atomicAdd(db + tid, s_sum[tid]);                  // (tid >= 512 here: only N > 512 would reach it -- never)
-    }
-    if (!worker) return;
-    // C/D layout: col = lane & 31 -> k, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> n
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        if (blk == 1 && !two) break;
-        const int k = 32 * (kb0 + blk) + l32;
-        if (k < K) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int nn = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (nn < N) atomicAdd(dW + (uint32_t)nn * (uint32_t)K + (uint32_t)k, blk ? acc1[r] : acc0[r]);
-            }
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 3: ONE kernel per field network (forward) -- the activations never leave the registers.
@@ -1249,8 +1129,7 @@ static int mlp_wgrad_launch(int32_t P, int32_t N, int32_t K, const float *dpre, 
     const size_t lds = 2 * (size_t)kWgOperandBytes;
     const bool va = N % 2 == 0 && ((uintptr_t)dpre & 7) == 0, vb = K % 2 == 0 && ((uintptr_t)X & 7) == 0;   // float2 loads
     const bool mixed = N <= 16 || K <= 16;
-    static const int ws_mode = [] { const char *e = getenv("D3GA_WGRAD_WS"); return e ? atoi(e) : 1; }();   // A/B knob: 0 wgrad_kernel, 1 two load sets in flight, 3 three (wgrad_ws3_kernel)
-    const bool use_ws = ws_mode != 0;
+    static const bool use_ws = [] { const char *e = getenv("D3GA_WGRAD_WS"); return !e || atoi(e) != 0; }();   // A/B knob
 #define D3GA_WG(VA, VB, MX)                                                                                           \
     do {                                                                                                              \
         static bool attr[64] = {};                                                                                    \
@@ -1275,21 +1154,6 @@ static int mlp_wgrad_launch(int32_t P, int32_t N, int32_t K, const float *dpre, 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));                   \
             attr[dev] = true;                                                                                         \
         }                                                                                                             \
-        if (ws_mode >= 3) {                                                                                           \
-            static bool attr3[64] = {};                                                                               \
-            if (dev >= 0 && dev < 64 && !attr3[dev]) {                                                                \
-                D3GA_HIP(hipFuncSetAttribute((const void *)wgrad_ws3_kernel<VA, VB, 3>,                               \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));               \
-                D3GA_HIP(hipFuncSetAttribute((const void *)wgrad_ws3_kernel<VA, VB, 4>,                               \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));               \
-                D3GA_HIP(hipFuncSetAttribute((const void *)wgrad_ws3_kernel<VA, VB, 5>,                               \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws));               \
-                attr3[dev] = true;                                                                                    \
-            }                                                                                                         \
-            if (ws_mode == 3) hipLaunchKernelGGL((wgrad_ws3_kernel<VA, VB, 3>), dim3(grid), dim3(kWgThreads), lds_ws, s, P, N, K, NBk, NBn, rows, dpre, X, dW, db); \
-            else if (ws_mode == 4) hipLaunchKernelGGL((wgrad_ws3_kernel<VA, VB, 4>), dim3(grid), dim3(kWgThreads), lds_ws, s, P, N, K, NBk, NBn, rows, dpre, X, dW, db); \
-            else hipLaunchKernelGGL((wgrad_ws3_kernel<VA, VB, 5>), dim3(grid), dim3(kWgThreads), lds_ws, s, P, N, K, NBk, NBn, rows, dpre, X, dW, db); \
-        } else                                                                                                        \
         hipLaunchKernelGGL((wgrad_ws_kernel<VA, VB>), dim3(grid), dim3(kWgThreads), lds_ws, s, P, N, K, NBk, NBn, rows, \
                            dpre, X, dW, db);                                                                          \
     } while (0)

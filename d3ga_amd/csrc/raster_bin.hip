@@ -141,7 +141,7 @@ __device__ __forceinline__ void tile_scan_body(int tiles, const uint32_t *__rest
 // and the dispatcher deals workgroups round-robin, so dealing them in descending order of work gives every SIMD one
 // wavefront from each work quantile instead of a random handful.
 __device__ __forceinline__ void tile_order_body(int tiles, const uint32_t *__restrict__ count,
-                                                uint32_t *__restrict__ order) {
+                                                uint32_t *__restrict__ order, uint32_t *__restrict__ counters) {
     // Round 3: ONE pass over the counts.  The bucket of a tile is its list length in units of 16 entries (the group size of
     // the compositing backward), clipped at 254 -- a fixed map, so the maximum need not be known first (round 2 took the
     // maximum, then built the histogram, then scattered: three dependent rounds of global loads on one workgroup, 10 us);
@@ -187,7 +187,11 @@ __device__ __forceinline__ void tile_order_body(int tiles, const uint32_t *__res
             for (int k = 0; k < 4; ++k) { s_hist[4 * tid + k] = run; run += v[k]; }   // [255] = number of non-empty tiles
         }
         __syncthreads();
-        if (tid == 0) s_zero = s_hist[255];               // empty tiles follow the non-empty ones
+        if (tid == 0) {
+            s_zero = s_hist[255];                         // empty tiles follow the non-empty ones
+            // the compositing backward gives the heaviest tenth of the non-empty tiles two workgroups each (raster_composite_scan.hip)
+            counters[D3GA_CNT_HEAVY] = (s_hist[255] + 9u) / 10u;
+        }
         __syncthreads();
         for (int c1 = 0; c1 < tiles; c1 += kPer * kScanBlock) {
             if (c0 != 0) {                                // more than one chunk (> 8192 tiles): the registers hold one chunk only
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(kScanBlock) void tile_scan_order_kernel(int tiles, 
                                                                      uint32_t n_mid, uint32_t n_large,
                                                                      uint32_t *__restrict__ order) {
     if (blockIdx.x == 0) tile_scan_body(tiles, count, start, cursor, counters, dcap, big_tiles, huge_tiles, mid_tiles, n_small, n_mid, n_large);
-    else tile_order_body(tiles, count, order);
+    else tile_order_body(tiles, count, order, counters);
 }
 
 __global__ __launch_bounds__(kBlock) void tile_scatter_kernel(int P, int gx, const uint2 *__restrict__ rect,

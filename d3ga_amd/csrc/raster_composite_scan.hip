@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256 * R, D3GA_TILE_WAVES) void composite_bwd_tile_k
     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
     float *__restrict__ acc, const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2,
     const float *__restrict__ bg2, const float *__restrict__ dL_dpix2, const uint2 *__restrict__ blk_list,
-    const uint32_t *__restrict__ blk_count, int assign, L1Source l1, const float *__restrict__ dL_dinvd, int split_h) {
+    const uint32_t *__restrict__ blk_count, int assign, L1Source l1, const float *__restrict__ dL_dinvd, int split_cap, const uint32_t *__restrict__ split_cnt) {
     static_assert((S & (S - 1)) == 0, "power of two");
     constexpr int NW = 4 * R;                        // wavefronts per tile (three, the third walking two sets of blocks: measured, slower -- DESIGN.md sec. 4)
     constexpr int SEG = 4 / R, LW = 16 * R;          // blocks per wavefront, lanes per block
@@ -417,8 +417,10 @@ __global__ __launch_bounds__(256 * R, D3GA_TILE_WAVES) void composite_bwd_tile_k
     // split_h (D3GA_BWD_SPLIT, R = 1 only, needs the work order): each of the split_h heaviest tiles gets TWO workgroups -- the
     // even / odd ranks of its 16 blocks by length -- whose wavefronts take two blocks each over two rows (the R = 2 walk: 32
     // entries per group): the tile's longest list is walked in half the groups, at the price of a merge cache per half
+    // The grid has room for split_cap of them; how many there are this frame is the order kernel's count (split_cnt; null: split_cap).
     int rank = (int)blockIdx.x, half = -1;
-    if (R == 1 && split_h > 0) {
+    if (R == 1 && split_cap > 0) {
+        const int split_h = split_cnt ? min((int)*split_cnt, split_cap) : split_cap;
         if (rank < 2 * split_h) { half = rank & 1; rank >>= 1; } else rank -= split_h;
     }
     const int tile = tile_order ? (rank < tiles ? (int)tile_order[rank] : -1) : (rank < tiles ? rank : -1);
@@ -532,95 +534,6 @@ __global__ __launch_bounds__(256 * R, D3GA_TILE_WAVES) void composite_bwd_tile_k
     }
 }
 
-// Persistent variant (D3GA_BWD_PERSIST = workgroups per CU, opt-in).  The kernel above gives every tile a workgroup: 1334
-// workgroups for 1024 resident slots at C3, every first-round tile shares its SIMDs four ways and finishes late, and the 310
-// tiles of the second round start at half of the span.  Here the grid is the RESIDENT workgroups
-// and a workgroup walks a fixed, strictly increasing sequence of ranks of the work-ordered tile list (w, 2G-1-w, 2G+w, ...:
-// heavy tiles first, each partnered with a light one) -- and, unlike the folded launch measured in round 4, its wavefronts
-// advance ONE BY ONE: a wavefront that is done with its blocks of tile i starts tile i+1 at once, in the other of the
-// workgroup's TWO merge caches; the last wavefront to arrive at tile i publishes cache i & 1, clears its tags and bumps the
-// buffer's generation, which is what a wavefront about to enter tile i+2 waits for (an LDS spin that almost never spins:
-// the four wavefronts of a tile carry blocks of similar length).  No workgroup-wide barrier after the start.
-template <bool DUAL, int S, bool INVD>
-__global__ __launch_bounds__(256, D3GA_TILE_WAVES) void composite_bwd_persist_kernel(
-    BwdArgs A, int gy, const uint32_t *__restrict__ tile_start, uint64_t dcap, const uint32_t *__restrict__ tile_order) {
-    constexpr int NW = 4, R = 1;
-    constexpr int PIXF = DUAL ? 12 : 8;
-    constexpr int ROWF = 16 * PIXF + 4;
-    constexpr int kSlot = 12;
-    __shared__ __attribute__((aligned(16))) float s_pix_all[NW][4 * ROWF];
-    __shared__ __attribute__((aligned(16))) float s_dump_all[NW][64 * 2 + 16 * PIXF];
-    __shared__ __attribute__((aligned(16))) uint32_t s_cache_all[2][S * kSlot];
-    __shared__ uint32_t s_arrived[2], s_gen[2];
-    for (int i = threadIdx.x; i < 2 * S; i += 64 * NW) s_cache_all[i / S][(i % S) * kSlot + 10] = 0u;   // tags: every slot empty
-    if (threadIdx.x < 2) { s_arrived[threadIdx.x] = 0u; s_gen[threadIdx.x] = 0u; }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tiles = A.gx * gy, G = (int)gridDim.x, w = (int)blockIdx.x;
-    constexpr int kVals = INVD ? 10 : 9, kPerInst = 64 / kVals;
-    const int fq = lane / kVals, fk = lane - kVals * fq;
-    const int fk_off = fk < 2 ? fk : fk + 1;
-    constexpr int kAccStride = D3GA_ACC_STRIDE;
-    BwdDiag dg;
-    for (int i = 0;; ++i) {
-        const int rank = (i & 1) ? (i + 1) * G - 1 - w : i * G + w;          // strictly increasing in i
-        if (rank >= tiles) break;
-        const int tile = (int)tile_order[rank];
-        const uint32_t begin = (uint32_t)min((uint64_t)tile_start[tile], dcap);
-        const uint32_t end = (uint32_t)min((uint64_t)tile_start[tile + 1], dcap);
-        if (begin >= end) break;                                             // work order: every later rank is empty too
-        const int buf = i & 1;
-        uint32_t *const s_cache = s_cache_all[buf];
-        // the buffer's previous tenant (tile i - 2 of this workgroup) must be published and its tags cleared
-        if (i >= 2) {
-            while (__hip_atomic_load(&s_gen[buf], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)(i >> 1)) __builtin_amdgcn_s_sleep(2);
-        }
-        // this wavefront's four blocks: ranks 4 g .. 4 g + 3 of the tile's blocks by descending list length (ties by index),
-        // g rotating with the wavefront, the workgroup and the tile -- the ranking of the kernel above, formed per wavefront
-        int blk;
-        {
-            const int j = lane & 15, q = j >> 2;
-            const int tx0 = (tile % A.gx) * kTile, ty0 = (tile / A.gx) * kTile;
-            const uint32_t mine = (tx0 + ((q & 1) << 3) < A.W && ty0 + ((q >> 1) << 3) < A.H) ? A.blk_count[16 * (size_t)tile + j] : 0u;
-            int rk = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
-                rk += (c > mine || (c == mine && k < j)) ? 1 : 0;
-            }
-            const int want = 4 * ((wave + w + i) & 3) + (lane >> 4);
-            blk = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) blk = __builtin_amdgcn_readlane(rk, k) == want ? k : blk;
-        }
-        bwd_tile_wave<DUAL, S, INVD, R>(A, tile, begin, end, blk, s_cache, s_pix_all[wave], s_dump_all[wave], lane, dg);
-        // arrival (acq_rel at workgroup scope, as in the kernel above); the last wavefront of the tile publishes the cache
-        uint32_t arrived = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrived[buf], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
-        if (arrived != (uint32_t)(NW - 1)) continue;
-        const int nslots = min(S, (int)(end - begin));
-        for (int base = 0; base < nslots; base += kPerInst) {
-            const int ent = base + min(fq, kPerInst - 1);
-            const bool mine = fq < kPerInst && ent < nslots;
-            const uint32_t *const sl = s_cache + min(ent, S - 1) * kSlot;
-            const uint32_t tag = sl[10], gid = sl[9];
-            const float val = __uint_as_float(sl[fk < 9 ? fk : 11]);
-            if (mine && tag != 0u && val != 0.f) atomicAdd(A.acc + kAccStride * (size_t)gid + fk_off, val);
-        }
-        for (int k = lane; k < nslots; k += 64) s_cache[k * kSlot + 10] = 0u;
-        if (lane == 0) __hip_atomic_store(&s_arrived[buf], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&s_gen[buf], (uint32_t)(i >> 1) + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-#ifdef D3GA_DIAG_COUNTERS
-    atomicAdd(&g_diag_scan[3], dg.install); atomicAdd(&g_diag_scan[4], dg.hit); atomicAdd(&g_diag_scan[5], dg.evict);
-    atomicAdd(&g_diag_scan[8], dg.valid); atomicAdd(&g_diag_scan[9], dg.entries); atomicAdd(&g_diag_scan[10], dg.rowgroups);
-#endif
-}
-
 #ifdef D3GA_DIAG
 extern "C" int d3ga_diag_scan_read(unsigned long long *out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag_scan), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
@@ -643,34 +556,20 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
                               hipStream_t s, const float *dL_dinvd) {
     // workgroup per tile, heaviest tiles first (tile_order of the bin stage); S = slots of the tile's merge cache
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
-    const int R = composite_bwd_rows();
-    const int split_h = (ordered && R == 1) ? min(composite_bwd_split(), gx * gy) : 0;
-    const dim3 tgrid(gx * gy + split_h);
+    // split of the heaviest tiles (see the kernel): D3GA_BWD_SPLIT < 0 (default): the order kernel's count (a tenth of the non-empty
+    // tiles, D3GA_CNT_HEAVY), read by every workgroup and capped by the grid's room for it; >= 0: that many (0: none)
+    const int split_knob = composite_bwd_split();
+    const int split_cap = !ordered ? 0 : (split_knob < 0 ? (gx * gy + 9) / 10 : min(split_knob, gx * gy));
+    const uint32_t *split_cnt = (ordered && split_knob < 0) ? (const uint32_t *)(bin.counters + D3GA_CNT_HEAVY) : (const uint32_t *)nullptr;
+    const dim3 tgrid(gx * gy + split_cap);
     const int S = composite_merge_slots();
-    const int persist = composite_bwd_persist();               // workgroups per CU of the persistent variant (0: a workgroup per tile)
-    if (persist > 0 && ordered) {
-        const BwdArgs A = {prm->W, prm->H, gx, reinterpret_cast<const float2 *>(g.xyh), g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc,
-                           colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, l1, dL_dinvd};
-        const dim3 pgrid(min(gx * gy, persist * 256));
-#define D3GA_LAUNCH_PERSIST(DUALV, SV, INVDV) \
-    hipLaunchKernelGGL((composite_bwd_persist_kernel<DUALV, SV, INVDV>), pgrid, dim3(256), 0, s, A, gy, bin.tile_start, (uint64_t)d_capacity, order)
-        const int SP = composite_persist_slots();
-        if (dL_dinvd) { if (colors2) return D3GA_E_CONFIG; D3GA_LAUNCH_PERSIST(false, 256, true); }
-        else if (colors2) D3GA_LAUNCH_PERSIST(true, 256, false);
-        else if (SP <= 128) D3GA_LAUNCH_PERSIST(false, 128, false);
-        else if (SP >= 512) D3GA_LAUNCH_PERSIST(false, 512, false);
-        else D3GA_LAUNCH_PERSIST(false, 256, false);
-#undef D3GA_LAUNCH_PERSIST
-        return check_launch(s, prm->debug);
-    }
 #define D3GA_LAUNCH_TILE_R(DUALV, SV, INVDV, RV)                                                                              \
     hipLaunchKernelGGL((composite_bwd_tile_kernel<DUALV, SV, INVDV, RV>), tgrid, dim3(256 * RV),                                \
                        lds_pad_bytes((const void *)composite_bwd_tile_kernel<DUALV, SV, INVDV, RV>, "D3GA_BWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
                        (uint64_t)d_capacity, reinterpret_cast<const float2 *>(g.xyh), g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc, order,   \
-                       colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, composite_tile_assign(), l1, dL_dinvd, split_h)
+                       colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, composite_tile_assign(), l1, dL_dinvd, split_cap, split_cnt)
 #define D3GA_LAUNCH_TILE(DUALV, SV, INVDV)                                                                                    \
-    do { if (R == 2) D3GA_LAUNCH_TILE_R(DUALV, SV, INVDV, 2); else if (R == 4) D3GA_LAUNCH_TILE_R(DUALV, SV, INVDV, 4);        \
-         else D3GA_LAUNCH_TILE_R(DUALV, SV, INVDV, 1); } while (0)
+    D3GA_LAUNCH_TILE_R(DUALV, SV, INVDV, 1)
     if (dL_dinvd) {                                          // inverse-depth gradient (branch dr_aa): single-image launches only
         if (colors2) return D3GA_E_CONFIG;
         if (S >= 512) D3GA_LAUNCH_TILE(false, 512, true); else D3GA_LAUNCH_TILE(false, 256, true);

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define D3GA_VERSION 102 /* 0.1.2: d3ga_raster_params::block_lists, d3ga_raster_bin_sort_lists (the per-tile sort emits the block lists of the compositing kernels).  101: 0.1.1: d3ga_raster_preprocess_bwd / d3ga_raster_backward* read cov3D_precomp again (the forward keeps no copy); NULL without (scales, rotations) is D3GA_E_NULL */
+#define D3GA_VERSION 103 /* 0.1.3: D3GA_CNT_HEAVY (counter 7 of the binning buffer: how many tiles at the head of the work order the compositing backward splits over two workgroups).  102: 0.1.2: d3ga_raster_params::block_lists, d3ga_raster_bin_sort_lists (the per-tile sort emits the block lists of the compositing kernels).  101: 0.1.1: d3ga_raster_preprocess_bwd / d3ga_raster_backward* read cov3D_precomp again (the forward keeps no copy); NULL without (scales, rotations) is D3GA_E_NULL */
 
 #define D3GA_OK 0
 #define D3GA_E_NULL (-1)     /* required pointer is NULL */
@@ -200,6 +200,7 @@ int d3ga_raster_img_layout_blocks(int32_t W, int32_t H, int64_t offsets[3]);
 #define D3GA_CNT_BIG 4  /* tiles with 4097..8192 entries (72 KB-LDS sort kernel) */
 #define D3GA_CNT_HUGE 5 /* tiles with more than 8192 entries (sorted in global memory) */
 #define D3GA_CNT_MID 6  /* tiles with 2049..4096 entries (36 KB-LDS sort kernel) */
+#define D3GA_CNT_HEAVY 7 /* (non-empty tiles + 9) / 10: the head of the work order whose tiles get two workgroups each in the compositing backward */
 
 /* R1 per-Gaussian stage + tile histogram.  Exactly one of (shs | colors_precomp) and of
  * ((scales,rotations) | cov3D_precomp) is non-NULL.  viewmatrix/projmatrix are the reference's transposed
