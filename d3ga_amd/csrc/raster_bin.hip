@@ -189,8 +189,10 @@ __device__ __forceinline__ void tile_order_body(int tiles, const uint32_t *__res
         __syncthreads();
         if (tid == 0) {
             s_zero = s_hist[255];                         // empty tiles follow the non-empty ones
-            // the compositing backward gives the heaviest tenth of the non-empty tiles two workgroups each (raster_composite_scan.hip)
-            counters[D3GA_CNT_HEAVY] = (s_hist[255] + 9u) / 10u;
+            // the compositing backward gives the heaviest tenth of the non-empty tiles two workgroups each (raster_composite_scan.hip:
+            // -5 % at C3 / C4, where the launch is 1.3 rounds of resident workgroups and ends when its longest lists do) -- unless
+            // the launch is many rounds anyway (more than 4 x 1024 resident workgroups: measured +3 % at C5, whose tail is light tiles)
+            counters[D3GA_CNT_HEAVY] = s_hist[255] <= 4096u ? (s_hist[255] + 9u) / 10u : 0u;
         }
         __syncthreads();
         for (int c1 = 0; c1 < tiles; c1 += kPer * kScanBlock) {

@@ -200,7 +200,7 @@ int d3ga_raster_img_layout_blocks(int32_t W, int32_t H, int64_t offsets[3]);
 #define D3GA_CNT_BIG 4  /* tiles with 4097..8192 entries (72 KB-LDS sort kernel) */
 #define D3GA_CNT_HUGE 5 /* tiles with more than 8192 entries (sorted in global memory) */
 #define D3GA_CNT_MID 6  /* tiles with 2049..4096 entries (36 KB-LDS sort kernel) */
-#define D3GA_CNT_HEAVY 7 /* (non-empty tiles + 9) / 10: the head of the work order whose tiles get two workgroups each in the compositing backward */
+#define D3GA_CNT_HEAVY 7 /* (non-empty tiles + 9) / 10, or 0 beyond 4096 non-empty tiles: the head of the work order whose tiles get two workgroups each in the compositing backward */
 
 /* R1 per-Gaussian stage + tile histogram.  Exactly one of (shs | colors_precomp) and of
  * ((scales,rotations) | cov3D_precomp) is non-NULL.  viewmatrix/projmatrix are the reference's transposed

@@ -162,3 +162,39 @@ def test_lbs_cage_deform_equals_the_two_operators():
     scale = float(a["delta"].abs().max())
     assert float((a["delta"] - b["delta"]).abs().max()) <= 2e-6 * scale
     assert float(b["delta"].abs().max()) > 0
+
+
+def test_backward_with_split_heavy_tiles_equals_the_unsplit_one(tmp_path):
+    """Round 5 (last session): the heaviest tiles of the work order get TWO workgroups each in the compositing backward (their blocks
+    dealt by rank parity, two blocks per wavefront walked over two DPP rows with wave-wide scans: the R = 2 walk), by default as
+    many as the order kernel counts (D3GA_CNT_HEAVY).  The forward is untouched, so images and termination are bit-identical;
+    gradients are the same sums in another order (2e-5 of the largest element).  D3GA_BWD_SPLIT=7 splits seven tiles whatever
+    their length (a split tile with short or empty halves), 100000 every tile the grid has (capped by the tile count)."""
+    files = {}
+    for split in ("0", "-1", "7", "100000"):
+        f = str(tmp_path / f"split{split}.npz")
+        env = dict(os.environ, D3GA_BWD_SPLIT=split, D3GA_FWD_IMPL="0")
+        r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT), f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        files[split] = np.load(f)
+    a = files["0"]
+    for split in ("-1", "7", "100000"):
+        b = files[split]
+        for k in a.files:
+            if k.endswith(("_n", "_img")):
+                np.testing.assert_array_equal(a[k], b[k], err_msg=f"{split} {k}")
+            else:
+                scale = np.abs(a[k]).max() + 1e-30
+                assert np.abs(a[k] - b[k]).max() <= 2e-5 * scale, (split, k, np.abs(a[k] - b[k]).max() / scale)
+
+
+def test_order_kernel_counts_the_tiles_the_backward_splits():
+    """D3GA_CNT_HEAVY (ABI 103) = (non-empty tiles + 9) // 10 while the frame has at most 4096 non-empty tiles."""
+    from d3ga_amd import rasterizer as rz
+    inp, R, img, radii, leaves, gpix = _render("C1", 1.0)
+    torch.cuda.synchronize()
+    start = rz.last_tile_lists(inp["W"], inp["H"])[0].cpu().numpy().astype(np.int64)
+    nonempty = int((np.diff(start) > 0).sum())
+    assert 0 < nonempty <= 4096
+    counters = rz._last[torch.cuda.current_device()][0][:32].view(torch.int32).cpu().numpy()
+    assert int(counters[7]) == (nonempty + 9) // 10, (counters, nonempty)
