@@ -26,6 +26,11 @@
 #ifndef D3GA_FWD_WAVES
 #define D3GA_FWD_WAVES 5
 #endif
+// (round 5) the register budget of the DUAL instantiations (render_pair) separately: at 5 wavefronts per SIMD they spill
+// (7-10 VGPRs, 32-44 bytes of scratch per lane)
+#ifndef D3GA_FWD_DUAL_WAVES
+#define D3GA_FWD_DUAL_WAVES 5
+#endif
 // A/B (build.py D3GA_VARIANT): 0 = blk_count is the number of entries emitted (rounds 2-4), 1 = the prefix up to the last blended entry
 #ifndef D3GA_FWD_USED
 #define D3GA_FWD_USED 1
@@ -49,7 +54,7 @@ __device__ unsigned long long g_diag_fwd_waves[32768 * 4];    // per active wave
 // renderer.py:141 takes [0]; without it the blend loop is one FMA per entry shorter and 4 B per pixel are not written)
 // L1V: the L1 loss value against a target image is formed here as well (d3ga_raster_composite_fwd_l1; never with DUAL)
 template <bool DUAL, bool DEPTH, bool L1V>
-__global__ __launch_bounds__(64, D3GA_FWD_WAVES) void composite_fwd_q_kernel(
+__global__ __launch_bounds__(64, (DUAL ? D3GA_FWD_DUAL_WAVES : D3GA_FWD_WAVES)) void composite_fwd_q_kernel(
     int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
     uint64_t dcap, const float2 *xy /* = xyh viewed as float2: the centre is record[0..1], stride 2 (round 4: no separate xy array) */, const float4 *__restrict__ conic_o,
     const float4 *__restrict__ rgb_invd, const float4 *xyh, const float *__restrict__ bg,
