@@ -23,12 +23,14 @@ struct GeomBuf {
     float *cov3D;       // P*6    3D covariance actually used (precomputed copy or from scale/rotation)
     float4 *xyh;        // P      pixel-space centre | half extents of the alpha >= 1/255 ellipse's bounding box (splat_cull):
                         //        the 16-byte record the compositing forward's first stage tests a list entry with
+    float *dcol;        // P*9    round 5: d(SH colour)/d(unit view direction), [direction x, y, z][channel] -- left by the forward's staged SH
+                        //        evaluation so that preprocess_bwd need not read the coefficients again (96 MB at C3) for dL/dmean
     uint4 *span;        // P      round 5: the 4x4-pixel BLOCKS the alpha >= 1/255 ellipse can touch, as one column interval per
                         //        block line (composite_common.h: splat_spans) -- what tile_cull_kernel builds the block lists from
 };
 static inline int64_t geom_bytes(int64_t P) {
     return align256(4 * P) + align256(8 * P) + align256(16 * P) + align256(16 * P) + align256(8 * P) + align256(P) +
-           align256(24 * P) + align256(16 * P) + align256(16 * P);
+           align256(24 * P) + align256(16 * P) + align256(16 * P) + align256(36 * P);
 }
 static inline GeomBuf carve_geom(void *base, int64_t P) {
     char *p = (char *)base;
@@ -41,7 +43,8 @@ static inline GeomBuf carve_geom(void *base, int64_t P) {
     g.clamped = (uint8_t *)p; p += align256(P);
     g.cov3D = (float *)p;     p += align256(24 * P);
     g.xyh = (float4 *)p;      p += align256(16 * P);
-    g.span = (uint4 *)p;
+    g.span = (uint4 *)p;      p += align256(16 * P);
+    g.dcol = (float *)p;
     return g;
 }
 

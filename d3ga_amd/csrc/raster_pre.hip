@@ -92,9 +92,12 @@ constexpr size_t kShHalfLdsBytes = (size_t)(kBlock / 64) * kShHalfSlab * sizeof(
 // 55.6 (eager stage events, same box) -- the second memory round trip per wavefront and a quarter of the lanes per
 // accumulate pass cost more than the occupancy returns.  Only wavefront-private LDS is touched: no workgroup barrier,
 // program order + wave_barrier suffice.  Every thread of the block must call it.
+template <bool WANT_J>
 __device__ __forceinline__ void staged_sh_colour(const d3ga_raster_params &prm, const float *__restrict__ means3D,
                                                  const float *__restrict__ shs, const float *__restrict__ campos,
-                                                 float *s_sh, float acc[3]) {
+                                                 float *s_sh, float acc[3], ShColJ &cj) {
+    constexpr bool want_j = WANT_J;
+    // WANT_J: also J = d(colour)/d(unit direction) of this Gaussian (sh_colour_dir_jacobian), from the same staged row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * kBlock + tid;
     const int M3 = 3 * prm.M;
@@ -103,13 +106,18 @@ __device__ __forceinline__ void staged_sh_colour(const d3ga_raster_params &prm, 
     const int rows = min(64, prm.P - row0);
     const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
     float B[16];
+    float dx = 0.f, dy = 0.f, dz = 1.f;
+    if (want_j && i < prm.P) sh_view_dir(means3D, i, campos, dx, dy, dz);
     if (M3 == 48 && rows == 64) {                              // wave-uniform: a full wavefront of full rows
         const float *src = shs + (size_t)48 * row0;
         auto pass = [&](const ShRegs<kShPassRows> &h, int p) {
             __builtin_amdgcn_wave_barrier();
             sh_rows48_to_slab<kShPassRows>(slab, h, lane);
             __builtin_amdgcn_wave_barrier();
-            if (lane / kShPassRows == p) sh_accumulate(B, slab + (lane % kShPassRows) * kShRow, 0, 16, nb, acc);
+            if (lane / kShPassRows == p) {
+                if (want_j) cj = sh_accumulate_jacobian(B, dx, dy, dz, slab + (lane % kShPassRows) * kShRow, nb, cj);
+                else sh_accumulate(B, slab + (lane % kShPassRows) * kShRow, 0, 16, nb, acc);
+            }
         };
         if constexpr (kShPasses == 2) {
             // both halves' loads are issued up front (the second half waits in registers while the first is evaluated)
@@ -139,10 +147,14 @@ __device__ __forceinline__ void staged_sh_colour(const d3ga_raster_params &prm, 
         __builtin_amdgcn_wave_barrier();
         if (r > 0) sh_slab_load(slab, shs + (size_t)M3 * (row0 + kShPassRows * h), r, M3, lane);
         __builtin_amdgcn_wave_barrier();
-        if (i < prm.P && lane / kShPassRows == h) sh_accumulate(B, slab + (lane % kShPassRows) * kShRow, 0, 16, nb, acc);
+        if (i < prm.P && lane / kShPassRows == h) {
+            if (want_j) cj = sh_accumulate_jacobian(B, dx, dy, dz, slab + (lane % kShPassRows) * kShRow, nb, cj);
+            else sh_accumulate(B, slab + (lane % kShPassRows) * kShRow, 0, 16, nb, acc);
+        }
     }
 }
 
+template <bool WANT_J>      // WANT_J: a backward will follow (forward_only == 0) and the SH coefficients are staged: leave d(colour)/d(direction) for it
 __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     d3ga_raster_params prm, const float *__restrict__ means3D, const float *__restrict__ shs,
     const float *__restrict__ colors_precomp, const float *__restrict__ opacities, const float *__restrict__ scales,
@@ -168,8 +180,11 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
         for (int k = 0; k < 6; ++k) pc6[k] = cov3D_precomp[6 * (size_t)i + k];
         pop = opacities[i];
     }
+    ShColJ cj = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr bool want_j = WANT_J;                                 // (the launcher: staged && !forward_only)
     if (staged) {
-        staged_sh_colour(prm, means3D, shs, campos, s_sh, acc);
+        staged_sh_colour<WANT_J>(prm, means3D, shs, campos, s_sh, acc, cj);
+        if (want_j) { acc[0] = cj.a0; acc[1] = cj.a1; acc[2] = cj.a2; }
         __syncthreads();                                            // the region becomes the tile window below
     }
     bool visible = false;
@@ -212,6 +227,10 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
         }
         geom.rgb_invd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], sp.visible ? 1.0f / sp.depth : 0.f);
         geom.clamped[i] = o.clampmask;
+        if (want_j) {
+            float *d = geom.dcol + 9 * (size_t)i;
+            d[0] = cj.j0; d[1] = cj.j1; d[2] = cj.j2; d[3] = cj.j3; d[4] = cj.j4; d[5] = cj.j5; d[6] = cj.j6; d[7] = cj.j7; d[8] = cj.j8;
+        }
         visible = sp.visible;
         r0 = sp.rect[0]; r1 = sp.rect[1]; r2 = sp.rect[2]; r3 = sp.rect[3];
     }
@@ -247,6 +266,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
 // pass from one garment_pkg, models/trainer.py:102-110): copies the geometry records of `src` to `dst` and evaluates
 // only the colour (SH of this camera or colors_precomp) -- the projection, the tile histogram and the whole binning
 // stage of the second pass disappear; `dst` then shares the first pass's binning buffer.
+template <bool WANT_J>
 __global__ __launch_bounds__(kBlock) void recolor_kernel(d3ga_raster_params prm, const float *__restrict__ means3D,
                                                          const float *__restrict__ shs,
                                                          const float *__restrict__ colors_precomp,
@@ -257,8 +277,15 @@ __global__ __launch_bounds__(kBlock) void recolor_kernel(d3ga_raster_params prm,
     const int M3 = 3 * prm.M;
     const bool staged = shs != nullptr && sh_staged(prm.M);
     float acc[3] = {0.f, 0.f, 0.f};
-    if (staged) staged_sh_colour(prm, means3D, shs, campos, s_sh, acc);
+    ShColJ cj = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr bool want_j = WANT_J;
+    if (staged) staged_sh_colour<WANT_J>(prm, means3D, shs, campos, s_sh, acc, cj);
     if (i >= prm.P) return;
+    if (want_j) {
+        acc[0] = cj.a0; acc[1] = cj.a1; acc[2] = cj.a2;
+        float *d = dst.dcol + 9 * (size_t)i;
+        d[0] = cj.j0; d[1] = cj.j1; d[2] = cj.j2; d[3] = cj.j3; d[4] = cj.j4; d[5] = cj.j5; d[6] = cj.j6; d[7] = cj.j7; d[8] = cj.j8;
+    }
     const uint2 rc = src.rect[i];
     const bool visible = ((rc.y & 0xffffu) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.x >> 16));
     const float depth = src.depth[i];
@@ -340,7 +367,16 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
         clampmask = geom.clamped[i];
         act_opacity = geom.conic_o[i].w;
     }
-    if (staged) {
+    // Round 5: the forward left d(colour)/d(direction) of every Gaussian (geom.dcol, 36 bytes) when it staged the coefficients and
+    // a backward was to follow: the coefficients themselves (192 bytes per Gaussian) are then not read here at all -- the slab
+    // only collects the gradient rows for the coalesced store.
+    const bool have_j = staged && !prm.forward_only;
+    ShColJ jd = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (have_j && i < prm.P) {
+        const float *d = geom.dcol + 9 * (size_t)i;
+        jd.j0 = d[0]; jd.j1 = d[1]; jd.j2 = d[2]; jd.j3 = d[3]; jd.j4 = d[4]; jd.j5 = d[5]; jd.j6 = d[6]; jd.j7 = d[7]; jd.j8 = d[8];
+    }
+    if (staged && !have_j) {
         if (full48) sh_rows48_to_slab<64>(slab, sh_rows48_load<64>(shs + (size_t)48 * row0, lane), lane);
         else if (rows > 0) sh_slab_load(slab, shs + (size_t)M3 * row0, rows, M3, lane);
         __builtin_amdgcn_wave_barrier();          // the slab is private to the wavefront: program order suffices
@@ -362,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
             preprocess_bwd_one(prm, i, visible, means3D, slab + lane * kShRow, scales, rotations, viewmatrix, projmatrix,
                                campos, c6, clampmask, a, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
                                dL_dsh ? slab + lane * kShRow : nullptr, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots,
-                               act_opacity);
+                               act_opacity, have_j, jd);
         else
             preprocess_bwd_one(prm, i, visible, means3D, shs ? shs + (size_t)M3 * i : nullptr, scales, rotations,
                                viewmatrix, projmatrix, campos, c6, clampmask, a, dL_dmeans3D, dL_dmeans2D,
@@ -472,10 +508,17 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     GeomBuf g = carve_geom(geom, prm->P);
     const size_t win = (size_t)kWinTiles * 4;
     const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? (kShHalfLdsBytes > win ? kShHalfLdsBytes : win) : win;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
-                       colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, g,
-                       bin.tile_count, bin.counters, radii,
-                       composite_fwd_impl_kind() != 0 ? ((composite_variant() & kVariantExactCull) ? 1 : 0) : -1);
+    // (the kernels' `staged` condition, on the host: with it and a backward to follow the forward leaves GeomBuf::dcol)
+    const bool want_j = shs && prm->M > 0 && (3 * prm->M) % 4 == 0 && 3 * prm->M <= 48 && !prm->forward_only;
+    const int cull_arg = composite_fwd_impl_kind() != 0 ? ((composite_variant() & kVariantExactCull) ? 1 : 0) : -1;
+    if (want_j)
+        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, g,
+                           bin.tile_count, bin.counters, radii, cull_arg);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<false>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, g,
+                           bin.tile_count, bin.counters, radii, cull_arg);
     return check_launch(s, prm->debug & 0xff);
 }
 
@@ -491,8 +534,13 @@ extern "C" int d3ga_raster_recolor(const d3ga_raster_params *prm, const float *m
     hipStream_t s = (hipStream_t)stream;
     const GeomBuf src = carve_geom(const_cast<void *>(geom_src), prm->P), dst = carve_geom(geom_dst, prm->P);
     const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? kShHalfLdsBytes : 0;
-    hipLaunchKernelGGL(recolor_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
-                       colors_precomp, campos, src, dst);
+    const bool want_j = shs && prm->M > 0 && (3 * prm->M) % 4 == 0 && 3 * prm->M <= 48 && !prm->forward_only;
+    if (want_j)
+        hipLaunchKernelGGL(recolor_kernel<true>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
+                           colors_precomp, campos, src, dst);
+    else
+        hipLaunchKernelGGL(recolor_kernel<false>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
+                           colors_precomp, campos, src, dst);
     return check_launch(s, prm->debug & 0xff);
 }
 

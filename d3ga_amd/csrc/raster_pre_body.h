@@ -22,6 +22,48 @@ D3GA_HD void sh_view_basis(const d3ga_raster_params &prm, const float *means3D, 
     const float inv = 1.0f / sqrtf(dot(d, d));
     sh_basis(prm.sh_degree, d.x * inv, d.y * inv, d.z * inv, B);
 }
+// The unit view direction of Gaussian i (what sh_view_basis evaluates the basis at)
+D3GA_HD void sh_view_dir(const float *means3D, int i, const float *campos, float &x, float &y, float &z) {
+    const V3 d = ld3(means3D, i) - v3(campos[0], campos[1], campos[2]);
+    const float inv = 1.0f / sqrtf(dot(d, d));
+    x = d.x * inv; y = d.y * inv; z = d.z * inv;
+}
+// acc[c] += sum_k B[k] * coeff[k][c]  AND  J[3 dir + c] = sum_k dY_k/d(dir)(x, y, z) * coeff[k][c] -- the derivative of the
+// (unclamped, un-offset) SH colour w.r.t. the unit direction -- in ONE walk over the row: every coefficient is read once and
+// the three derivative values of a basis function are formed where they are used (no 3 x 16 gradient arrays: the forward's
+// staging kernel has no registers for them).  Same polynomials as sh_basis_grad.
+struct ShColJ { float a0, a1, a2, j0, j1, j2, j3, j4, j5, j6, j7, j8; };      // by value: as arrays behind pointers these landed in scratch memory
+D3GA_HD ShColJ sh_accumulate_jacobian(const float B[16], float x, float y, float z, const float *row, int nb, ShColJ o) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    o.j0 = o.j1 = o.j2 = o.j3 = o.j4 = o.j5 = o.j6 = o.j7 = o.j8 = 0.f;
+#define D3GA_SHJ(K, GX, GY, GZ)                                                                             \
+    if (K < nb) {                                                                                           \
+        const float r0 = row[3 * K], r1 = row[3 * K + 1], r2 = row[3 * K + 2];                              \
+        o.a0 += B[K] * r0; o.a1 += B[K] * r1; o.a2 += B[K] * r2;                                            \
+        const float gx_ = (GX), gy_ = (GY), gz_ = (GZ);                                                     \
+        o.j0 += gx_ * r0; o.j1 += gx_ * r1; o.j2 += gx_ * r2;                                               \
+        o.j3 += gy_ * r0; o.j4 += gy_ * r1; o.j5 += gy_ * r2;                                               \
+        o.j6 += gz_ * r0; o.j7 += gz_ * r1; o.j8 += gz_ * r2;                                               \
+    }
+    if (0 < nb) { o.a0 += B[0] * row[0]; o.a1 += B[0] * row[1]; o.a2 += B[0] * row[2]; }
+    D3GA_SHJ(1, 0.f, -kC1, 0.f)
+    D3GA_SHJ(2, 0.f, 0.f, kC1)
+    D3GA_SHJ(3, -kC1, 0.f, 0.f)
+    D3GA_SHJ(4, kC2_0 * y, kC2_0 * x, 0.f)
+    D3GA_SHJ(5, 0.f, kC2_1 * z, kC2_1 * y)
+    D3GA_SHJ(6, -2.f * kC2_2 * x, -2.f * kC2_2 * y, 4.f * kC2_2 * z)
+    D3GA_SHJ(7, kC2_3 * z, 0.f, kC2_3 * x)
+    D3GA_SHJ(8, 2.f * kC2_4 * x, -2.f * kC2_4 * y, 0.f)
+    D3GA_SHJ(9, kC3_0 * 6.f * xy, kC3_0 * 3.f * (xx - yy), 0.f)
+    D3GA_SHJ(10, kC3_1 * yz, kC3_1 * xz, kC3_1 * xy)
+    D3GA_SHJ(11, kC3_2 * -2.f * xy, kC3_2 * (4.f * zz - xx - 3.f * yy), kC3_2 * 8.f * yz)
+    D3GA_SHJ(12, kC3_3 * -6.f * xz, kC3_3 * -6.f * yz, kC3_3 * 3.f * (2.f * zz - xx - yy))
+    D3GA_SHJ(13, kC3_4 * (4.f * zz - 3.f * xx - yy), kC3_4 * -2.f * xy, kC3_4 * 8.f * xz)
+    D3GA_SHJ(14, kC3_5 * 2.f * xz, kC3_5 * -2.f * yz, kC3_5 * (xx - yy))
+    D3GA_SHJ(15, kC3_6 * 3.f * (xx - yy), kC3_6 * -6.f * xy, 0.f)
+#undef D3GA_SHJ
+    return o;
+}
 // acc[c] += sum_{k in [k0, k1)} B[k] * coeff[k][c];  `part` points at coefficient k0 of the row (3 floats per coefficient)
 D3GA_HD void sh_accumulate(const float B[16], const float *part, int k0, int k1, int nb, float acc[3]) {
 #pragma unroll
@@ -107,7 +149,8 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
                                 const float *viewmatrix, const float *projmatrix, const float *campos,
                                 const float *c6, uint8_t clampmask, const float *a, float *dL_dmeans3D,
                                 float *dL_dmeans2D, float *dL_dopacity, float *dsh_row, float *dL_dcolors,
-                                float *dL_dcov3D, float *dL_dscales, float *dL_drots, float act_opacity = 0.f) {
+                                float *dL_dcov3D, float *dL_dscales, float *dL_drots, float act_opacity = 0.f,
+                                bool have_j = false, ShColJ jd = ShColJ()) {      // have_j: jd.j0..j8 = the forward's d(colour)/d(direction) of this Gaussian (then sh_row is not read)
     float gmean[3] = {0.f, 0.f, 0.f};
     float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const V3 mean = ld3(means3D, i);
@@ -133,21 +176,32 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
             const V3 d0 = mean - v3(campos[0], campos[1], campos[2]);
             const float inv = 1.0f / sqrtf(dot(d0, d0));
             const float x = d0.x * inv, y = d0.y * inv, z = d0.z * inv;
-            float B[16], Bx[16], By[16], Bz[16];
+            float B[16];
             sh_basis(prm.sh_degree, x, y, z, B);
-            sh_basis_grad(prm.sh_degree, x, y, z, Bx, By, Bz);
             const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
-            const float *sh = sh_row;
             V3 gd = v3(0.f, 0.f, 0.f);
+            if (have_j) {                    // dL/d(dir) = J . (clamp-masked dL/dcolour): the coefficients are not read
+                gd = v3(jd.j0 * gr[0] + jd.j1 * gr[1] + jd.j2 * gr[2], jd.j3 * gr[0] + jd.j4 * gr[1] + jd.j5 * gr[2],
+                        jd.j6 * gr[0] + jd.j7 * gr[1] + jd.j8 * gr[2]);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {   // fixed trip count: keeps the basis arrays in registers
-                if (k < nb) {
-                    const float s0 = sh[3 * k], s1 = sh[3 * k + 1], s2 = sh[3 * k + 2];
-                    if (out) { out[3 * k] = B[k] * gr[0]; out[3 * k + 1] = B[k] * gr[1]; out[3 * k + 2] = B[k] * gr[2]; }
-                    const float w = s0 * gr[0] + s1 * gr[1] + s2 * gr[2];
-                    gd.x += Bx[k] * w; gd.y += By[k] * w; gd.z += Bz[k] * w;
-                } else if (k < nbM && out) {
-                    out[3 * k] = 0.f; out[3 * k + 1] = 0.f; out[3 * k + 2] = 0.f;
+                for (int k = 0; k < 16; ++k) {
+                    if (k < nb) { if (out) { out[3 * k] = B[k] * gr[0]; out[3 * k + 1] = B[k] * gr[1]; out[3 * k + 2] = B[k] * gr[2]; } }
+                    else if (k < nbM && out) { out[3 * k] = 0.f; out[3 * k + 1] = 0.f; out[3 * k + 2] = 0.f; }
+                }
+            } else {
+                float Bx[16], By[16], Bz[16];
+                sh_basis_grad(prm.sh_degree, x, y, z, Bx, By, Bz);
+                const float *sh = sh_row;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {   // fixed trip count: keeps the basis arrays in registers
+                    if (k < nb) {
+                        const float s0 = sh[3 * k], s1 = sh[3 * k + 1], s2 = sh[3 * k + 2];
+                        if (out) { out[3 * k] = B[k] * gr[0]; out[3 * k + 1] = B[k] * gr[1]; out[3 * k + 2] = B[k] * gr[2]; }
+                        const float w = s0 * gr[0] + s1 * gr[1] + s2 * gr[2];
+                        gd.x += Bx[k] * w; gd.y += By[k] * w; gd.z += Bz[k] * w;
+                    } else if (k < nbM && out) {
+                        out[3 * k] = 0.f; out[3 * k + 1] = 0.f; out[3 * k + 2] = 0.f;
+                    }
                 }
             }
             const V3 gm = normalize_bwd(d0, gd);
