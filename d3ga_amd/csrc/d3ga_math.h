@@ -363,6 +363,10 @@ constexpr float kC3_0 = -0.5900435899266435f, kC3_1 = 2.890611442640554f, kC3_2 
 
 // basis[k], k < (deg+1)^2, for unit direction (x,y,z)
 D3GA_HD void sh_basis(int deg, float x, float y, float z, float B[16]) {
+    // no contraction: the basis values must not depend on what the surrounding code shares with them (round 5: the forward that
+    // also leaves d(colour)/d(direction) reuses xx, yy, ... -- with contraction its colours differed from the inference
+    // forward's in the last ulp; an inference render and a training render of the same inputs give the same image bit for bit)
+    D3GA_NO_CONTRACT
     B[0] = kC0;
     if (deg > 0) {
         B[1] = -kC1 * y; B[2] = kC1 * z; B[3] = -kC1 * x;

@@ -26,6 +26,9 @@ constexpr int kShSlab = 64 * kShRow;            // floats per wavefront
 constexpr size_t kShLdsBytes = (size_t)(kBlock / 64) * kShSlab * sizeof(float);   // 53,248 B per block
 
 __device__ __forceinline__ bool sh_staged(int M) { return M > 0 && (3 * M) % 4 == 0 && 3 * M <= 48; }
+#ifndef D3GA_PRE_DCOL        // 1: the forward leaves GeomBuf::dcol for the backward (round 5); 0: the backward reads the coefficients again (A/B build)
+#define D3GA_PRE_DCOL 1
+#endif
 
 // global (rows x 3M floats, contiguous) -> LDS slab; `rows` valid rows of this wavefront (<= 64)
 __device__ __forceinline__ void sh_slab_load(float *slab, const float *__restrict__ src, int rows, int M3, int lane) {
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     // Round 5: the forward left d(colour)/d(direction) of every Gaussian (geom.dcol, 36 bytes) when it staged the coefficients and
     // a backward was to follow: the coefficients themselves (192 bytes per Gaussian) are then not read here at all -- the slab
     // only collects the gradient rows for the coalesced store.
-    const bool have_j = staged && !prm.forward_only;
+    const bool have_j = D3GA_PRE_DCOL && staged && !prm.forward_only;
     ShColJ jd = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (have_j && i < prm.P) {
         const float *d = geom.dcol + 9 * (size_t)i;
@@ -509,7 +512,7 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     const size_t win = (size_t)kWinTiles * 4;
     const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? (kShHalfLdsBytes > win ? kShHalfLdsBytes : win) : win;
     // (the kernels' `staged` condition, on the host: with it and a backward to follow the forward leaves GeomBuf::dcol)
-    const bool want_j = shs && prm->M > 0 && (3 * prm->M) % 4 == 0 && 3 * prm->M <= 48 && !prm->forward_only;
+    const bool want_j = D3GA_PRE_DCOL && shs && prm->M > 0 && (3 * prm->M) % 4 == 0 && 3 * prm->M <= 48 && !prm->forward_only;
     const int cull_arg = composite_fwd_impl_kind() != 0 ? ((composite_variant() & kVariantExactCull) ? 1 : 0) : -1;
     if (want_j)
         hipLaunchKernelGGL(preprocess_kernel<true>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
@@ -534,7 +537,7 @@ extern "C" int d3ga_raster_recolor(const d3ga_raster_params *prm, const float *m
     hipStream_t s = (hipStream_t)stream;
     const GeomBuf src = carve_geom(const_cast<void *>(geom_src), prm->P), dst = carve_geom(geom_dst, prm->P);
     const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? kShHalfLdsBytes : 0;
-    const bool want_j = shs && prm->M > 0 && (3 * prm->M) % 4 == 0 && 3 * prm->M <= 48 && !prm->forward_only;
+    const bool want_j = D3GA_PRE_DCOL && shs && prm->M > 0 && (3 * prm->M) % 4 == 0 && 3 * prm->M <= 48 && !prm->forward_only;
     if (want_j)
         hipLaunchKernelGGL(recolor_kernel<true>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
                            colors_precomp, campos, src, dst);

@@ -16,17 +16,20 @@ struct PreOut {
     uint8_t clampmask;
 };
 
-// SH basis of Gaussian i's view direction (the direction is normalize(mean - campos), as in R1)
-D3GA_HD void sh_view_basis(const d3ga_raster_params &prm, const float *means3D, int i, const float *campos, float B[16]) {
-    const V3 d = ld3(means3D, i) - v3(campos[0], campos[1], campos[2]);
-    const float inv = 1.0f / sqrtf(dot(d, d));
-    sh_basis(prm.sh_degree, d.x * inv, d.y * inv, d.z * inv, B);
-}
-// The unit view direction of Gaussian i (what sh_view_basis evaluates the basis at)
+// The unit view direction of Gaussian i: normalize(mean - campos), as in R1.  Without contraction, like sh_basis: the
+// inference forward and the forward that also leaves d(colour)/d(direction) must evaluate the same basis values.
 D3GA_HD void sh_view_dir(const float *means3D, int i, const float *campos, float &x, float &y, float &z) {
-    const V3 d = ld3(means3D, i) - v3(campos[0], campos[1], campos[2]);
-    const float inv = 1.0f / sqrtf(dot(d, d));
-    x = d.x * inv; y = d.y * inv; z = d.z * inv;
+    D3GA_NO_CONTRACT
+    const V3 m = ld3(means3D, i);
+    const float dx = m.x - campos[0], dy = m.y - campos[1], dz = m.z - campos[2];
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    x = dx * inv; y = dy * inv; z = dz * inv;
+}
+// SH basis of Gaussian i's view direction
+D3GA_HD void sh_view_basis(const d3ga_raster_params &prm, const float *means3D, int i, const float *campos, float B[16]) {
+    float x, y, z;
+    sh_view_dir(means3D, i, campos, x, y, z);
+    sh_basis(prm.sh_degree, x, y, z, B);
 }
 // acc[c] += sum_k B[k] * coeff[k][c]  AND  J[3 dir + c] = sum_k dY_k/d(dir)(x, y, z) * coeff[k][c] -- the derivative of the
 // (unclamped, un-offset) SH colour w.r.t. the unit direction -- in ONE walk over the row: every coefficient is read once and
@@ -39,13 +42,13 @@ D3GA_HD ShColJ sh_accumulate_jacobian(const float B[16], float x, float y, float
 #define D3GA_SHJ(K, GX, GY, GZ)                                                                             \
     if (K < nb) {                                                                                           \
         const float r0 = row[3 * K], r1 = row[3 * K + 1], r2 = row[3 * K + 2];                              \
-        o.a0 += B[K] * r0; o.a1 += B[K] * r1; o.a2 += B[K] * r2;                                            \
+        o.a0 = fmaf(B[K], r0, o.a0); o.a1 = fmaf(B[K], r1, o.a1); o.a2 = fmaf(B[K], r2, o.a2);   /* as sh_accumulate, bit for bit */                                            \
         const float gx_ = (GX), gy_ = (GY), gz_ = (GZ);                                                     \
         o.j0 += gx_ * r0; o.j1 += gx_ * r1; o.j2 += gx_ * r2;                                               \
         o.j3 += gy_ * r0; o.j4 += gy_ * r1; o.j5 += gy_ * r2;                                               \
         o.j6 += gz_ * r0; o.j7 += gz_ * r1; o.j8 += gz_ * r2;                                               \
     }
-    if (0 < nb) { o.a0 += B[0] * row[0]; o.a1 += B[0] * row[1]; o.a2 += B[0] * row[2]; }
+    if (0 < nb) { o.a0 = fmaf(B[0], row[0], o.a0); o.a1 = fmaf(B[0], row[1], o.a1); o.a2 = fmaf(B[0], row[2], o.a2); }
     D3GA_SHJ(1, 0.f, -kC1, 0.f)
     D3GA_SHJ(2, 0.f, 0.f, kC1)
     D3GA_SHJ(3, -kC1, 0.f, 0.f)
@@ -70,7 +73,7 @@ D3GA_HD void sh_accumulate(const float B[16], const float *part, int k0, int k1,
     for (int k = 0; k < 16; ++k) {           // fixed trip count: keeps B[] in registers
         if (k >= k0 && k < k1 && k < nb) {
             const float *c = part + 3 * (k - k0);
-            acc[0] += B[k] * c[0]; acc[1] += B[k] * c[1]; acc[2] += B[k] * c[2];
+            acc[0] = fmaf(B[k], c[0], acc[0]); acc[1] = fmaf(B[k], c[1], acc[1]); acc[2] = fmaf(B[k], c[2], acc[2]);   // explicit: the same in every caller
         }
     }
 }

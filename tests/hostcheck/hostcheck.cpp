@@ -99,10 +99,30 @@ void hc_preprocess_bwd(const d3ga_raster_params *prm, const float *means3D, cons
                        const float *rots, const float *view, const float *proj, const float *campos,
                        const int32_t *radii, const float *cov3D, const uint8_t *clamped, const float *acc,
                        float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dopacity, float *dL_dsh, float *dL_dcolors,
-                       float *dL_dcov3D, float *dL_dscales, float *dL_drots, const float *act_opacity) {
+                       float *dL_dcov3D, float *dL_dscales, float *dL_drots, const float *act_opacity, int use_dcol) {
+    // use_dcol: the round-5 split -- d(colour)/d(direction) as the FORWARD forms it (sh_accumulate_jacobian), handed to the
+    // backward in place of the coefficients (preprocess_bwd_one must then not read them: it is given a row of NaNs)
     const float zeros[12] = {0};
     for (int i = 0; i < prm->P; ++i) {
         const bool vis = radii[i] > 0;
+        if (use_dcol && shs) {
+            float B[16], x, y, z;
+            sh_view_dir(means3D, i, campos, x, y, z);
+            sh_basis(prm->sh_degree, x, y, z, B);
+            ShColJ cj = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const int nb = (prm->sh_degree + 1) * (prm->sh_degree + 1);
+            cj = sh_accumulate_jacobian(B, x, y, z, shs + (size_t)3 * prm->M * i, nb, cj);
+            float acc3[3] = {0.f, 0.f, 0.f};
+            sh_accumulate(B, shs + (size_t)3 * prm->M * i, 0, 16, nb, acc3);
+            if (acc3[0] != cj.a0 || acc3[1] != cj.a1 || acc3[2] != cj.a2) { dL_dmeans3D[0] = NAN; return; }   // same colour, bit for bit
+            float poison[48];
+            for (int k = 0; k < 48; ++k) poison[k] = NAN;
+            preprocess_bwd_one(*prm, i, vis, means3D, poison, scales, rots, view, proj, campos, cov3D + 6 * (size_t)i, clamped[i],
+                               vis ? acc + D3GA_ACC_STRIDE * (size_t)i : zeros, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
+                               dL_dsh ? dL_dsh + (size_t)3 * prm->M * i : nullptr, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots,
+                               act_opacity ? act_opacity[i] : 0.f, true, cj);
+            continue;
+        }
         preprocess_bwd_one(*prm, i, vis, means3D, shs ? shs + (size_t)3 * prm->M * i : nullptr, scales, rots, view, proj,
                            campos, cov3D + 6 * (size_t)i, clamped[i], vis ? acc + D3GA_ACC_STRIDE * (size_t)i : zeros, dL_dmeans3D,
                            dL_dmeans2D, dL_dopacity, dL_dsh ? dL_dsh + (size_t)3 * prm->M * i : nullptr, dL_dcolors,

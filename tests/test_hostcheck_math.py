@@ -111,7 +111,7 @@ def test_preprocess_forward_vs_oracles(hostcheck):
     np.testing.assert_array_equal(o["rect"][vis], rect[vis])
 
 
-def _bwd_case(hostcheck, inp, prm, use_sh, from_sr, seed, invdepth=False):
+def _bwd_case(hostcheck, inp, prm, use_sh, from_sr, seed, invdepth=False, use_dcol=False):
     """Feed the same accumulated screen-space gradients to the product's per-Gaussian backward and to an
     autograd evaluation of the oracle's preprocess stage."""
     P = prm.P
@@ -137,7 +137,9 @@ def _bwd_case(hostcheck, inp, prm, use_sh, from_sr, seed, invdepth=False):
                                 ptr(_np(inp["view"])), ptr(_np(inp["proj"])), ptr(_np(inp["campos"])), ptr(o["radii"]),
                                 ptr(o["cov3D"]), ptr(o["clamped"]), ptr(acc), ptr(outs["m3"]), ptr(outs["m2"]),
                                 ptr(outs["op"]), ptr(outs["sh"]), ptr(outs["col"]), ptr(outs["cov"]), ptr(outs["sc"]),
-                                ptr(outs["ro"]), ptr(np.ascontiguousarray(o["conic_o"][:, 3])))
+                                ptr(outs["ro"]), ptr(np.ascontiguousarray(o["conic_o"][:, 3])), int(use_dcol))
+    if use_sh and not use_dcol:       # round 5: the same case with d(colour)/d(direction) from the forward instead of the coefficients
+        _bwd_case(hostcheck, inp, prm, use_sh, from_sr, seed, invdepth, use_dcol=True)
     # oracle: autograd through preprocess with a linear functional reproducing `acc`
     dd = torch.float64
     m = inp["means3D"].to(dd).requires_grad_(True)
