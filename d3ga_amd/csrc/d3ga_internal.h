@@ -23,7 +23,7 @@ struct GeomBuf {
     float *cov3D;       // P*6    3D covariance actually used (precomputed copy or from scale/rotation)
     float4 *xyh;        // P      pixel-space centre | half extents of the alpha >= 1/255 ellipse's bounding box (splat_cull):
                         //        the 16-byte record the compositing forward's first stage tests a list entry with
-    float *dcol;        // P*9    round 5: d(SH colour)/d(unit view direction), [direction x, y, z][channel] -- left by the forward's staged SH
+    float *dcol;        // 9 planes of P floats, round 5: d(SH colour)/d(unit view direction), plane 3 * (direction x, y, z) + channel -- left by the forward's staged SH
                         //        evaluation so that preprocess_bwd need not read the coefficients again (96 MB at C3) for dL/dmean
     uint4 *span;        // P      round 5: the 4x4-pixel BLOCKS the alpha >= 1/255 ellipse can touch, as one column interval per
                         //        block line (composite_common.h: splat_spans) -- what tile_cull_kernel builds the block lists from

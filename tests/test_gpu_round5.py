@@ -198,3 +198,57 @@ def test_order_kernel_counts_the_tiles_the_backward_splits():
     assert 0 < nonempty <= 4096
     counters = rz._last[torch.cuda.current_device()][0][:32].view(torch.int32).cpu().numpy()
     assert int(counters[7]) == (nonempty + 9) // 10, (counters, nonempty)
+
+
+@pytest.mark.parametrize("deg", [3, 1])
+def test_view_direction_term_of_the_mean_gradient_comes_from_the_forwards_jacobian(deg):
+    """Round 5: preprocess leaves d(SH colour)/d(unit view direction) per Gaussian (GeomBuf::dcol) and preprocess_bwd forms the
+    direction term of dL/dmean from it without reading the coefficients.  Isolated here: the same scene rendered once with the SH
+    coefficients and once with colors_precomp = the colours those coefficients give -- same alphas, same pixel gradient, so the two
+    dL/dmeans3D differ by exactly  sum_c dL/dcolour_c . d colour_c / d mean  (clamped channels excluded), which torch forms in
+    float64 from the oracle's eval_sh.  Also: the SH gradient itself and dL/dcolour agree between the two renders."""
+    from d3ga_amd import rasterizer as R
+    from oracle import raster_torch as rt
+    from test_gpu_parity import _settings
+    inp = scene_inputs("T1", scale_mult=3.0)
+    shs = inp["shs"].clone()
+    shs[::3, 0, :] = -2.5                                   # some channels clamp at 0 (no gradient through them)
+    shs[:, 1:] *= 4.0                                       # a strong view dependence: the term under test is not a rounding-level share
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    rast = R.GaussianRasterizer(_settings(inp, bg, deg))
+    m64 = inp["means3D"].double()
+    d = m64 - inp["campos"].double()[None]
+    col_raw = rt.eval_sh(deg, shs.double(), d / d.norm(dim=1, keepdim=True)) + 0.5
+    col = col_raw.clamp_min(0.0).float()
+    gpix = torch.randn(3, inp["H"], inp["W"], generator=torch.Generator().manual_seed(9)).to(DEV)
+
+    def run(**colour):
+        leaves = {k: v.to(DEV).clone().requires_grad_(True) for k, v in dict(means3D=inp["means3D"], **colour).items()}
+        img, radii, _ = rast(means2D=None, opacities=inp["opacities"].to(DEV), cov3D_precomp=inp["cov6"].to(DEV), **leaves)
+        (img * gpix).sum().backward()
+        torch.cuda.synchronize()
+        return {k: v.grad.cpu() for k, v in leaves.items()}, radii.cpu()
+    g_sh, radii = run(shs=shs)
+    g_pre, _ = run(colors_precomp=col)
+    gcol = g_pre["colors_precomp"].double()
+    assert float(gcol.abs().max()) > 0 and int((radii > 0).sum()) > 100
+    # expected direction term, float64: clamped channels pass no gradient (upstream's clamped[] flags)
+    mm = m64.clone().requires_grad_(True)
+    dd = mm - inp["campos"].double()[None]
+    c = rt.eval_sh(deg, shs.double(), dd / dd.norm(dim=1, keepdim=True)) + 0.5
+    live = (col_raw > 0).double()
+    (c * gcol * live).sum().backward()
+    want = mm.grad
+    got = (g_sh["means3D"].double() - g_pre["means3D"].double())
+    scale_term, scale_all = float(want.abs().max()), float(g_pre["means3D"].abs().max())
+    assert scale_term > 1e-3 * scale_all                     # the term is visible beside the geometry term it rides on
+    err = float((got - want).abs().max())
+    assert err <= 2e-3 * scale_term + 4e-6 * scale_all, (err, scale_term, scale_all)
+    # the SH gradient is basis x (clamp-masked dL/dcolour), the colour gradient of the precomputed render is the unmasked one
+    B = torch.zeros(shs.shape[0], shs.shape[1], dtype=torch.float64)
+    for k in range((deg + 1) ** 2):
+        e = torch.zeros(shs.shape[0], shs.shape[1], 3, dtype=torch.float64)
+        e[:, k, :] = 1.0
+        B[:, k] = rt.eval_sh(deg, e, (d / d.norm(dim=1, keepdim=True)))[:, 0]
+    want_sh = B[:, :, None] * (gcol * live)[:, None, :]
+    assert float((g_sh["shs"].double() - want_sh).abs().max()) <= 1e-4 * float(want_sh.abs().max())
