@@ -1,4 +1,4 @@
-"""Loop statistics of composite_bwd_scan_kernel on a workload (needs a library built with D3GA_DIAG=counters)."""
+"""Loop statistics of composite_bwd_tile_kernel on a workload (needs a library built with D3GA_DIAG=counters)."""
 import ctypes
 import os
 import sys

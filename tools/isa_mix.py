@@ -2,7 +2,7 @@
 """Static VALU instruction mix of the compositing backward's hot loop (for bench.py's calibrated `roofline.valu_frac`).
 
 Cross-compiles d3ga_amd/csrc/raster_composite_scan.hip to gfx950 assembly (no GPU needed), takes the group loop of
-composite_bwd_scan_kernel<false> -- the depth-2 loop (four pixels of one block line) counted four times, the rest of the
+composite_bwd_tile_kernel<false, 512> -- the depth-2 loop (four pixels of one block line) counted four times, the rest of the
 depth-1 loop once -- and classes every VALU instruction by the issue-cost classes tools/micro/valu_issue.hip measures:
 plain (2-operand / fma), dpp, transcendental, packed, and other VOP3 (cndmask / cmp with an SGPR pair, med3, bfi ...).
 Writes profiles/r05_composite_bwd_mix.json (one per round; bench.py reads the newest).
