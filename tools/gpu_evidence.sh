@@ -46,6 +46,7 @@ for k in 1 2 4; do
   timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train-step --force-cut --views-per-rank $k 2>> gpurun_out/force_cut.err | grep "^{" > gpurun_out/force_cut_C3_k$k.log
 done
 timeout 600 python bench.py --workload C4 --steps 100 --warmup 10 --no-cpu-baseline --no-train-step --force-cut 2>> gpurun_out/force_cut.err | grep "^{" > gpurun_out/force_cut_C4_k1.log
+if [ -n "$EVIDENCE_SKIP_OPTIN" ]; then bash tools/gpu_diag_json.sh C3 > gpurun_out/diag_json.log 2>&1; exit 0; fi     # (the opt-in forwards' own evidence is unchanged by a change elsewhere)
 # round 5: the opt-in forwards over explicit block lists (D3GA_FWD_IMPL=1: a list pass; 2: lists emitted by the per-tile sort) beside the default, same box: headline, larger splats, 4K
 for wl in "C3:" "C3s2:--scale-mult 2" "C5:--workload C5"; do
   name=${wl%%:*}; extra=${wl#*:}
