@@ -249,6 +249,7 @@ class Frame:
                 dev = self.bg.device
                 self.canon_field, self.deform_field = CanonicalField().to(dev), DeformationField(scaling=0.07).to(dev)
                 self.pose = 0.3 * torch.randn(98, device=dev)
+                self.deform_field.set_constant_input(self.canon)      # the canonical cage vertices are a buffer of the model (cage_net.py:197)
                 self.field_params = list(self.canon_field.parameters()) + list(self.deform_field.parameters())
             for q in self.field_params:
                 q.grad = None

@@ -132,36 +132,100 @@ def _linear(x, panel, bias, slope, n_out, want_sign=False, mask_bits=None, mask_
     return y, sign
 
 
+def _chain_fwd_impl(x, slopes, weights, biases, track):
+    """The forward of a trunk (no autograd): -> (h_L, [h_0 .. h_L], sign words per layer or None).  One launch when the shapes
+    allow (d3ga_mlp_chain_fwd), else one per layer."""
+    require_cuda(x, *weights)
+    h = f32c16(x)
+    acts, signs = [h], []
+    fused = (_chain_shapes_ok(h.shape[0], h.shape[1], [w.shape[0] for w in weights])
+             and all(weights[i].shape[1] == (h.shape[1] if i == 0 else weights[i - 1].shape[0]) for i in range(len(weights))))
+    if fused:                                              # the whole trunk in one launch: activations stay in registers
+        outs, signs = _chain_forward(h, weights, biases, slopes, track)
+        acts += outs
+        h = outs[-1]
+        weights_loop = ()
+    else:
+        weights_loop = zip(weights, biases, slopes)
+    for w, b, slope in weights_loop:
+        N, K = w.shape
+        if h.shape[1] != K or K > 128 or N > 128:
+            raise ValueError(f"linear_act: x (P,{h.shape[1]}) weight {tuple(w.shape)}: need matching K <= 128 and N <= 128")
+        h, sign = _linear(h, _panel(w, True), None if b is None else b.float().contiguous(), slope, N,
+                          want_sign=track and slope != 1.0)
+        acts.append(h)
+        signs.append(sign)
+    return h, acts, signs
+
+
+def _chain_bwd_impl(dy, acts, weights, signs, slopes, need, want_dx):
+    """The backward of a trunk: need[i] = (weight gradient wanted, bias gradient wanted) -> (dx or None, [dW_0, db_0, dW_1, ...]).
+    The chain is walked once: the input-gradient GEMM of layer i multiplies by the leaky_relu derivative of layer i-1 in its
+    epilogue, so each layer's pre-activation gradient is written exactly once and feeds both its weight gradient and the next GEMM."""
+    L = len(weights)
+    dpre = f32c16(dy)
+    if slopes[-1] != 1.0:                                 # a chain that ENDS in an activation (not the fields' case)
+        dpre = dpre * torch.where(acts[L] > 0, 1.0, slopes[-1])
+    grads = [None] * (2 * L)
+    dx = None
+    # all weight / bias gradients of the chain live in ONE zero-filled buffer (one fill instead of two memsets a layer)
+    sizes = [(w.numel() if nw or nbias else 0, w.shape[0] if nbias else 0) for w, (nw, nbias) in zip(weights, need)]
+    flat = torch.zeros(sum(a + b for a, b in sizes), dtype=torch.float32, device=dpre.device)
+    offs, o = [], 0
+    for a, b in sizes:
+        offs.append((o, o + a))
+        o += a + b
+    # the input-gradient chain dPre_{L-1} = dy -> dPre_{L-2} -> ... -> dPre_0 [-> dx]: one launch when the shapes allow
+    # (the same kernel as the forward: transposed weights, the sign words of the forward as masks, no bias)
+    dpres = [None] * L
+    dpres[L - 1] = dpre
+    chain_layers = list(range(L - 1, 0, -1)) + ([0] if want_dx else [])       # layer i maps dPre_i -> dPre_{i-1} (or dx)
+    widths = [weights[i].shape[1] for i in chain_layers]
+    if L >= 2 and _chain_shapes_ok(dpre.shape[0], dpre.shape[1], widths):
+        masks = [signs[i - 1] if (i > 0 and slopes[i - 1] != 1.0) else None for i in chain_layers]
+        mslopes = [slopes[i - 1] if i > 0 else 1.0 for i in chain_layers]
+        outs, _ = _chain_run(dpre, [_chain_panel(weights[i], True) for i in chain_layers],
+                             [(weights[i].shape[0], weights[i].shape[1]) for i in chain_layers], [None] * len(chain_layers),
+                             [1.0] * len(chain_layers), [False] * len(chain_layers), masks, mslopes)
+        for i, o in zip(chain_layers, outs):
+            if i > 0:
+                dpres[i - 1] = o
+            else:
+                dx = o
+        fused_bwd = True
+    else:
+        fused_bwd = False
+    for i in range(L - 1, -1, -1):
+        w, x_in = weights[i], acts[i]
+        N, K = w.shape
+        need_w, need_b = need[i]
+        dpre = dpres[i]
+        if need_w or need_b:                              # dW += dPre^T X (a reduction over all rows), db += column sums
+            dw = flat[offs[i][0]:offs[i][1]].view(N, K)
+            db = flat[offs[i][1]:offs[i][1] + N] if need_b else None
+            check(_lib.lib().d3ga_mlp_wgrad_acc(dpre.shape[0], N, K, dptr(dpre), dptr(x_in), dptr(dw), dptr(db),
+                                                stream_handle()), "d3ga_mlp_wgrad_acc")
+            grads[2 * i], grads[2 * i + 1] = (dw if need_w else None), db
+        if fused_bwd:
+            continue
+        if i > 0:                                         # dPre of the layer below: (dPre W) (.) act'_{i-1}(h_i)
+            below = slopes[i - 1]
+            dpres[i - 1] = _linear(dpre, _panel(w, False), None, 1.0, K, mask_bits=signs[i - 1] if below != 1.0 else None,
+                                   mask_slope=below)[0]
+        elif want_dx:
+            dx = _linear(dpre, _panel(w, False), None, 1.0, K)[0]
+    return dx, grads
+
+
 class _Chain(torch.autograd.Function):
     """h_{i+1} = act_i(h_i @ W_i.T + b_i), act(y) = y if y > 0 else slope_i * y (slope 1: none), i = 0..L-1, h_0 = x.
-    apply(x, slopes, W_0, b_0, W_1, b_1, ...) -> h_L.  The backward walks the chain once: the input-gradient GEMM of layer
-    i multiplies by the leaky_relu derivative of layer i-1 in its epilogue, so each layer's pre-activation gradient is
-    written exactly once and feeds both its weight gradient and the next GEMM."""
+    apply(x, slopes, W_0, b_0, W_1, b_1, ...) -> h_L.  ONE autograd node for the whole trunk (_chain_fwd_impl / _chain_bwd_impl)."""
 
     @staticmethod
     def forward(ctx, x, slopes, *wb):
         weights, biases = wb[0::2], wb[1::2]
-        require_cuda(x, *weights)
-        h = f32c16(x)
-        acts, signs = [h], []
         track = any(ctx.needs_input_grad)                      # (grad mode is off inside forward: ask the node instead)
-        fused = (_chain_shapes_ok(h.shape[0], h.shape[1], [w.shape[0] for w in weights])
-                 and all(weights[i].shape[1] == (h.shape[1] if i == 0 else weights[i - 1].shape[0]) for i in range(len(weights))))
-        if fused:                                              # the whole trunk in one launch: activations stay in registers
-            outs, signs = _chain_forward(h, weights, biases, slopes, track)
-            acts += outs
-            h = outs[-1]
-            weights_loop = ()
-        else:
-            weights_loop = zip(weights, biases, slopes)
-        for w, b, slope in weights_loop:
-            N, K = w.shape
-            if h.shape[1] != K or K > 128 or N > 128:
-                raise ValueError(f"linear_act: x (P,{h.shape[1]}) weight {tuple(w.shape)}: need matching K <= 128 and N <= 128")
-            h, sign = _linear(h, _panel(w, True), None if b is None else b.float().contiguous(), slope, N,
-                              want_sign=track and slope != 1.0)
-            acts.append(h)
-            signs.append(sign)
+        h, acts, signs = _chain_fwd_impl(x, slopes, weights, biases, track)
         ctx.slopes = tuple(float(v) for v in slopes)
         ctx.n_layers = len(weights)
         ctx.has_bias = tuple(b is not None for b in biases)
@@ -173,60 +237,94 @@ class _Chain(torch.autograd.Function):
     def backward(ctx, dy):
         L = ctx.n_layers
         acts, weights = ctx.saved_tensors[:L + 1], ctx.saved_tensors[L + 1:]
-        dpre = f32c16(dy)
-        if ctx.slopes[-1] != 1.0:                             # a chain that ENDS in an activation (not the fields' case)
-            dpre = dpre * torch.where(acts[L] > 0, 1.0, ctx.slopes[-1])
-        grads = [None] * (2 * L)
-        dx = None
-        # all weight / bias gradients of the chain live in ONE zero-filled buffer (one fill instead of two memsets a layer)
         need = [(ctx.needs_input_grad[2 + 2 * i], ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]) for i in range(L)]
-        sizes = [(w.numel() if nw or nbias else 0, w.shape[0] if nbias else 0) for w, (nw, nbias) in zip(weights, need)]
-        flat = torch.zeros(sum(a + b for a, b in sizes), dtype=torch.float32, device=dpre.device)
-        offs, o = [], 0
-        for a, b in sizes:
-            offs.append((o, o + a))
-            o += a + b
-        # the input-gradient chain dPre_{L-1} = dy -> dPre_{L-2} -> ... -> dPre_0 [-> dx]: one launch when the shapes allow
-        # (the same kernel as the forward: transposed weights, the sign words of the forward as masks, no bias)
-        dpres = [None] * L
-        dpres[L - 1] = dpre
-        want_dx = bool(ctx.needs_input_grad[0])
-        chain_layers = list(range(L - 1, 0, -1)) + ([0] if want_dx else [])       # layer i maps dPre_i -> dPre_{i-1} (or dx)
-        widths = [weights[i].shape[1] for i in chain_layers]
-        if L >= 2 and _chain_shapes_ok(dpre.shape[0], dpre.shape[1], widths):
-            masks = [ctx.signs[i - 1] if (i > 0 and ctx.slopes[i - 1] != 1.0) else None for i in chain_layers]
-            mslopes = [ctx.slopes[i - 1] if i > 0 else 1.0 for i in chain_layers]
-            outs, _ = _chain_run(dpre, [_chain_panel(weights[i], True) for i in chain_layers],
-                                 [(weights[i].shape[0], weights[i].shape[1]) for i in chain_layers], [None] * len(chain_layers),
-                                 [1.0] * len(chain_layers), [False] * len(chain_layers), masks, mslopes)
-            for i, o in zip(chain_layers, outs):
-                if i > 0:
-                    dpres[i - 1] = o
-                else:
-                    dx = o
-            fused_bwd = True
-        else:
-            fused_bwd = False
-        for i in range(L - 1, -1, -1):
-            w, x_in = weights[i], acts[i]
-            N, K = w.shape
-            need_w, need_b = need[i]
-            dpre = dpres[i]
-            if need_w or need_b:                              # dW += dPre^T X (a reduction over all rows), db += column sums
-                dw = flat[offs[i][0]:offs[i][1]].view(N, K)
-                db = flat[offs[i][1]:offs[i][1] + N] if need_b else None
-                check(_lib.lib().d3ga_mlp_wgrad_acc(dpre.shape[0], N, K, dptr(dpre), dptr(x_in), dptr(dw), dptr(db),
-                                                    stream_handle()), "d3ga_mlp_wgrad_acc")
-                grads[2 * i], grads[2 * i + 1] = (dw if need_w else None), db
-            if fused_bwd:
-                continue
-            if i > 0:                                         # dPre of the layer below: (dPre W) (.) act'_{i-1}(h_i)
-                below = ctx.slopes[i - 1]
-                dpres[i - 1] = _linear(dpre, _panel(w, False), None, 1.0, K, mask_bits=ctx.signs[i - 1] if below != 1.0 else None,
-                                       mask_slope=below)[0]
-            elif want_dx:
-                dx = _linear(dpre, _panel(w, False), None, 1.0, K)[0]
+        dx, grads = _chain_bwd_impl(dy, acts, weights, ctx.signs, ctx.slopes, need, bool(ctx.needs_input_grad[0]))
         return (dx, None, *grads)
+
+
+def _merge_ranges(ranges):
+    out = []
+    for a, b in ranges:
+        if out and out[-1][1] == a:
+            out[-1] = (out[-1][0], b)
+        else:
+            out.append((a, b))
+    return tuple(out)
+
+
+def _take_columns(w, ranges):
+    """Columns of w in `ranges` as one (N, sum of widths) tensor: a view for one range (the packed-panel cache then follows the
+    parameter's version), one small cat otherwise."""
+    return w[:, ranges[0][0]:ranges[0][1]] if len(ranges) == 1 else torch.cat([w[:, a:b] for a, b in ranges], dim=1)
+
+
+class _FieldTrunk(torch.autograd.Function):
+    """A field's trunk with the reference's input layout z = [column groups, some per row, some broadcast] as ONE autograd node.
+    apply(x_rows (P, per-row columns), bc (broadcast columns, 1-D, or None), layout, slopes, W_0, b_0, W_1, b_1, ...) with
+    layout = (row_ranges, bc_ranges): the column ranges of W_0 that meet x_rows / bc, each in z's order.
+    The broadcast columns are folded into the first bias (b_0 + W_0[:, bc] . bc: one addmv) and the first layer's weight gradient
+    is assembled in ONE buffer here -- its per-row columns from the trunk's weight gradient, its broadcast columns as the outer
+    product of the bias gradient and bc.  (Round 5: as separate autograd ops -- two column slices of W_0, F.linear, the trunk -- the
+    same arithmetic cost two zero fills, two strided copies, an add and three hipBLASLt launches of 8-14 us on a 128 x 98
+    matrix per field and step: ~150 us of ~30 tiny launches in the colour step.)"""
+
+    @staticmethod
+    def forward(ctx, x_rows, bc, layout, slopes, *wb):
+        row_ranges, bc_ranges = layout
+        first_w, first_b = wb[0], wb[1]
+        w_row = _take_columns(first_w, row_ranges)
+        w_bc = _take_columns(first_w, bc_ranges) if bc_ranges else None
+        if w_bc is not None:
+            bcv = bc.detach().reshape(-1).float()
+            bias0 = torch.addmv(first_b, w_bc, bcv) if first_b is not None else torch.mv(w_bc, bcv)
+        else:
+            bcv, bias0 = None, first_b
+        weights, biases = (w_row,) + tuple(wb[2::2]), (bias0,) + tuple(wb[3::2])
+        track = any(ctx.needs_input_grad)
+        h, acts, signs = _chain_fwd_impl(x_rows, slopes, weights, biases, track)
+        ctx.slopes = tuple(float(v) for v in slopes)
+        ctx.layout = layout
+        ctx.n_layers = len(weights)
+        ctx.has_bias = tuple(b is not None for b in wb[1::2])
+        ctx.signs = signs                                      # int32 bit words: not differentiable, kept on the ctx
+        ctx.has_bc = w_bc is not None
+        # everything else through save_for_backward -- the output h among the activations: kept as a plain attribute it would close
+        # a reference cycle (ctx -> h -> grad_fn -> ctx) that keeps a capture's tensors alive past capture_end()
+        extras = (w_row, w_bc, bcv) if ctx.has_bc else (w_row,)
+        ctx.save_for_backward(*acts, *wb[0::2], *extras)
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = ctx.n_layers
+        saved = ctx.saved_tensors
+        acts, params, extras = saved[:L + 1], saved[L + 1:2 * L + 1], saved[2 * L + 1:]
+        first_w, w_row = params[0], extras[0]
+        w_bc, bcv = (extras[1], extras[2]) if ctx.has_bc else (None, None)
+        weights = (w_row,) + tuple(params[1:])
+        nig = ctx.needs_input_grad
+        need_x, need_bc = bool(nig[0]), bool(nig[1]) and ctx.has_bc
+        need_w0, need_b0 = bool(nig[4]), ctx.has_bias[0] and bool(nig[5])
+        # the folded bias' gradient also feeds W_0's broadcast columns and d(bc)
+        want_db0 = need_b0 or need_bc or (need_w0 and ctx.has_bc)
+        need = [(need_w0, want_db0)] + [(bool(nig[4 + 2 * i]), ctx.has_bias[i] and bool(nig[5 + 2 * i])) for i in range(1, L)]
+        dx, grads = _chain_bwd_impl(dy, acts, weights, ctx.signs, ctx.slopes, need, need_x)
+        dw_row, db0 = grads[0], grads[1]
+        g_w0 = None
+        if need_w0:
+            row_ranges, bc_ranges = ctx.layout
+            g_w0 = torch.empty_like(first_w, dtype=torch.float32, memory_format=torch.contiguous_format)
+            o = 0
+            for a, b in row_ranges:
+                g_w0[:, a:b].copy_(dw_row[:, o:o + b - a])
+                o += b - a
+            o = 0
+            for a, b in bc_ranges:
+                torch.mul(db0[:, None], bcv[None, o:o + b - a], out=g_w0[:, a:b])
+                o += b - a
+        g_bc = torch.mv(w_bc.t(), db0) if need_bc else None
+        grads[0], grads[1] = g_w0, (db0 if need_b0 else None)
+        return (dx, g_bc, None, None, *grads)
 
 
 def linear_act(x, weight, bias=None, negative_slope=1.0):
@@ -298,42 +396,40 @@ class FieldMLP(nn.Module):
     def forward_parts(self, parts):
         """General column layout: `parts` lists z's column groups in the reference's order, each a (P, w) per-row tensor or a
         1-D broadcast vector (ColorField mixes both kinds: models/mlp.py:208-226).  Broadcast groups are folded into the
-        first layer's bias, per-row groups are concatenated and meet the matching columns of the first weight."""
+        first layer's bias, per-row groups are concatenated and meet the matching columns of the first weight (_FieldTrunk)."""
         first = self.network[0]
         rows = [t for t in parts if t.dim() != 1]
         bcs = [t for t in parts if t.dim() == 1]
         sig = tuple((t.dim() == 1, t.shape[-1]) for t in parts)
-        idx = self._col_index.get((sig, first.weight.device))
-        if idx is None:                  # column indices of the two kinds, built once per layout (no H2D copy per call)
-            row_cols, bc_cols, c = [], [], 0
+        layout = self._col_index.get(sig)
+        if layout is None:               # column ranges of the two kinds, adjacent ranges merged, built once per layout
+            row_r, bc_r, c = [], [], 0
             for is_bc, w in sig:
-                (bc_cols if is_bc else row_cols).extend(range(c, c + w))
+                if w:
+                    (bc_r if is_bc else row_r).append((c, c + w))
                 c += w
             if c != first.weight.shape[1]:
                 raise ValueError(f"field input has {c} columns, the first layer expects {first.weight.shape[1]}")
-            dev = first.weight.device
-            idx = (torch.tensor(row_cols, device=dev), torch.tensor(bc_cols, device=dev) if bc_cols else None)
-            self._col_index[(sig, dev)] = idx
-        w_row = first.weight.index_select(1, idx[0])
-        bias0 = first.bias
-        if bcs:
-            bias0 = F.linear(torch.cat(bcs).reshape(1, -1), first.weight.index_select(1, idx[1]), first.bias)[0]
-        return self._trunk(torch.cat(rows, dim=1) if len(rows) > 1 else rows[0], w_row, bias0)
+            if not row_r:
+                raise ValueError("a field needs at least one per-row column group")
+            layout = (_merge_ranges(row_r), _merge_ranges(bc_r))
+            self._col_index[sig] = layout
+        x = torch.cat(rows, dim=1) if len(rows) > 1 else rows[0]
+        bcs = [t for t in bcs if t.numel()]
+        bc = (torch.cat(bcs) if len(bcs) > 1 else bcs[0]) if bcs else None
+        return self._trunk(x, bc, layout)
 
-    def _trunk(self, x, w_first, b_first):
-        hidden = list(self.network)[1:]
-        layers = [(w_first, b_first)] + [(l.weight, l.bias) for l in hidden] + [(self.output.weight, self.output.bias)]
-        return mlp_chain(x, layers, [0.1] * (1 + len(hidden)) + [1.0])
+    def _trunk(self, x, bc, layout):
+        layers = [(l.weight, l.bias) for l in self.network] + [(self.output.weight, self.output.bias)]
+        flat = [t for wb in layers for t in wb]
+        return _FieldTrunk.apply(x, bc, layout, tuple([0.1] * len(self.network) + [1.0]), *flat)
 
     def forward(self, row_feats, broadcast):
         """z = [broadcast.expand(P, -1) | row_feats] (the reference's column order) -> (P, n_output)."""
-        first = self.network[0]
-        nb = broadcast.numel()
-        if nb:
-            bias0 = F.linear(broadcast.reshape(1, nb), first.weight[:, :nb], first.bias)[0]  # folded pose columns
-        else:
-            bias0 = first.bias
-        return self._trunk(row_feats, first.weight[:, nb:], bias0)
+        nb, K = broadcast.numel(), self.network[0].weight.shape[1]
+        if nb + row_feats.shape[1] != K:
+            raise ValueError(f"field input has {nb + row_feats.shape[1]} columns, the first layer expects {K}")
+        return self._trunk(row_feats, broadcast if nb else None, (((nb, K),), (((0, nb),) if nb else ())))
 
 
 class CanonicalField(FieldMLP):
@@ -358,6 +454,25 @@ def embed(x, multires=7):
     return torch.cat(out, -1)
 
 
+_embed_cache = {}
+
+
+def embed_const(x, multires=7):
+    """embed() of an input that does not require a gradient (the canonical cage vertices, models/cage_net.py:197: the same tensor
+    every step): evaluated once per (storage, version) -- 22 element-wise launches per step otherwise, each at the ~2.6 us floor
+    of a launch.  Not used under stream capture (a cached result would be baked into the graph)."""
+    if x.requires_grad or (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+        return embed(x, multires)
+    key = (_lib.replay_epoch[0], x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), x.dtype, x.device, multires)
+    hit = _embed_cache.get(key)
+    if hit is None:
+        if len(_embed_cache) > 16:
+            _embed_cache.clear()
+        hit = (embed(x, multires), x)              # (x kept alive: its address cannot be recycled under the same key)
+        _embed_cache[key] = hit
+    return hit[0]
+
+
 class DeformationField(FieldMLP):
     """models/mlp.py:39-71.  forward(canonical (V,3), pose) -> tanh(.) * scaling with z = [pose | embed_7(canonical)]."""
 
@@ -365,8 +480,20 @@ class DeformationField(FieldMLP):
         super().__init__(n_cond + 45, 3, n_nodes, n_layers)
         self.scaling = scaling
 
+    def set_constant_input(self, canonical):
+        """The caller's promise that `canonical` (the canonical cage vertices: a buffer of the model, models/cage_net.py:197) never
+        changes: its embedding is evaluated once, here, and a forward that is handed this very tensor uses it -- also under stream
+        capture, where embed_const() must not answer from its cache (the reference's ShadowDecoder keeps its embedded template the
+        same way).  None: forget it."""
+        self._const_src = canonical
+        self._const_emb = None if canonical is None else embed(canonical.detach())
+
     def forward(self, canonical, pose):
-        return field_heads(super().forward(embed(canonical), pose), ((3, "tanh", self.scaling),))[0]
+        if canonical is getattr(self, "_const_src", None) and not canonical.requires_grad:
+            z = self._const_emb
+        else:
+            z = embed_const(canonical)
+        return field_heads(super().forward(z, pose), ((3, "tanh", self.scaling),))[0]
 
 
 class ShadowDecoder(FieldMLP):

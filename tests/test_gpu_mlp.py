@@ -482,3 +482,51 @@ def test_linear_act_against_torch(P, K, N, slope):
     assert rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) < 2e-6
     for a, r in zip(mine_in, ref_in):
         assert rel_err(a.grad.cpu().numpy(), r.grad.numpy()) < 5e-6
+
+
+def test_field_trunk_node_and_embed_cache():
+    """Round 5: (a) a field's first layer -- broadcast columns folded into the bias, the weight gradient assembled from the trunk's
+    per-row block and the outer product (bias gradient x broadcast vector) -- is ONE autograd node (_FieldTrunk) instead of two
+    column slices + F.linear + the trunk: against plain torch in float64, a layout with two per-row and two broadcast ranges and
+    a broadcast vector that requires a gradient; (b) embed() of a constant input is cached per (storage, version): same values,
+    and an in-place change of the input is seen."""
+    from d3ga_amd.mlp import DeformationField, FieldMLP, embed, embed_const
+    torch.manual_seed(3)
+    P = 1000
+    net = FieldMLP(5 + 7 + 16 + 9, 6, n_nodes=128, n_layers=2).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    mk = lambda *shape: torch.randn(*shape, generator=g)
+    r1, b1, r2, b2, up = mk(P, 5), mk(7), mk(P, 16), mk(9), mk(P, 6)
+    leaves = [t.to(DEV).requires_grad_(True) for t in (r1, b1, r2, b2)]
+    out = net.forward_parts(leaves)
+    out.backward(up.to(DEV))
+    l64 = [t.double().requires_grad_(True) for t in (r1, b1, r2, b2)]
+    W = [(l.weight.detach().double().cpu().requires_grad_(True), l.bias.detach().double().cpu().requires_grad_(True)) for l in net.network]
+    Wo, bo = net.output.weight.detach().double().cpu().requires_grad_(True), net.output.bias.detach().double().cpu().requires_grad_(True)
+    z = torch.cat([l64[0], l64[1].expand(P, -1), l64[2], l64[3].expand(P, -1)], dim=1)
+    for w, b in W:
+        z = torch.nn.functional.leaky_relu(torch.nn.functional.linear(z, w, b), 0.1)
+    ref = torch.nn.functional.linear(z, Wo, bo)
+    ref.backward(up.double())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=2e-6)
+    for a, b, name in zip(leaves, l64, ("rows1", "bc1", "rows2", "bc2")):
+        assert rel_err(a.grad.cpu().numpy(), b.grad.numpy()) < 2e-5, name
+    for (w, b), layer in zip(W, net.network):
+        assert rel_err(layer.weight.grad.cpu().numpy(), w.grad.numpy()) < 2e-5
+        assert rel_err(layer.bias.grad.cpu().numpy(), b.grad.numpy()) < 2e-5
+    assert rel_err(net.output.weight.grad.cpu().numpy(), Wo.grad.numpy()) < 2e-5
+    # (b)
+    x = torch.randn(300, 3, generator=g).to(DEV)
+    e0 = embed_const(x)
+    assert torch.equal(e0, embed(x)) and embed_const(x) is e0
+    x.mul_(2.0)                                              # version bump: the cache must not answer with the old values
+    assert torch.equal(embed_const(x), embed(x)) and embed_const(x) is not e0
+    df = DeformationField().to(DEV)
+    pose = torch.randn(98, generator=g).to(DEV)
+    a = df(x, pose)
+    b = df(x.clone().requires_grad_(True), pose)
+    assert torch.equal(a, b.detach())
+    df.set_constant_input(x)                                 # the explicit form (valid under stream capture as well)
+    assert torch.equal(df(x, pose), a)
+    df.set_constant_input(None)
+    assert torch.equal(df(x, pose), a)
