@@ -293,7 +293,11 @@ int d3ga_raster_recolor(const d3ga_raster_params *prm, const float *means3D, con
  * dL/dcolour (the (P,3) factor of the rank-1 SH gradient, see d3ga_sh_grad_from_views); dL/dmeans3D is complete.
  * cov3D_precomp: the SAME tensor, unchanged, that the forward was given (or NULL with scales / rotations): since round 4 the
  * forward keeps no copy of a precomputed covariance in `geom` (24 B x P less written per frame), the backward reads it here;
- * cov3D_precomp == NULL without (scales, rotations) returns D3GA_E_NULL (ABI 101). */
+ * cov3D_precomp == NULL without (scales, rotations) returns D3GA_E_NULL (ABI 101).
+ * `geom` must be what d3ga_raster_preprocess / d3ga_raster_recolor of THIS library left for THIS prm (forward_only == 0): since
+ * round 5 it carries, for SH colours with M <= 16 and 3 M a multiple of 4, d(colour)/d(view direction) of every Gaussian (36 B,
+ * nine planes of P floats) from which the direction term of dL/dmeans3D is formed -- `shs` is then not read here at all
+ * (it must still be non-NULL: it selects the SH path). */
 int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const float *means3D, const float *shs,
                                const float *scales, const float *rotations, const float *cov3D_precomp,
                                const float *viewmatrix, const float *projmatrix, const float *campos,
