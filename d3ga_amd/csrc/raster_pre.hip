@@ -109,7 +109,7 @@ __device__ __forceinline__ void staged_sh_colour(const d3ga_raster_params &prm, 
                                                  const float *__restrict__ shs, const float *__restrict__ campos,
                                                  float *s_sh, float acc[3], ShColJ &cj) {
     constexpr bool want_j = WANT_J;
-    // WANT_J: also J = d(colour)/d(unit direction) of this Gaussian (sh_colour_dir_jacobian), from the same staged row
+    // WANT_J: also J = d(colour)/d(unit direction) of this Gaussian (sh_accumulate_jacobian), from the same staged row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * kBlock + tid;
     const int M3 = 3 * prm.M;
