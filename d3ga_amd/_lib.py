@@ -97,6 +97,8 @@ _SIGNATURES = {
     "d3ga_view_dirs_bwd": ([ctypes.c_int32, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_sh4_encoding_fwd": ([ctypes.c_int32, _vp, _vp, _vp], _i),
     "d3ga_sh4_encoding_bwd": ([ctypes.c_int32, _vp, _vp, _vp, _vp], _i),
+    "d3ga_color_rows_fwd": ([ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp], _i),
+    "d3ga_color_rows_bwd": ([ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp], _i),
     "d3ga_ssim_fwd": ([ctypes.c_int32] * 3 + [_vp] * 6 + [_vp], _i),
     "d3ga_ssim_bwd": ([ctypes.c_int32] * 3 + [_vp] * 7 + [_vp], _i),
     "d3ga_ssim_l1_fwd": ([ctypes.c_int32] * 3 + [_vp] * 7 + [_vp], _i),
@@ -120,8 +122,8 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = res
-        if L.d3ga_version() != 103:
-            raise D3GAError(f"libd3ga_hip.so version {L.d3ga_version()} does not match the Python layer (103)")
+        if L.d3ga_version() != 104:
+            raise D3GAError(f"libd3ga_hip.so version {L.d3ga_version()} does not match the Python layer (104)")
         info = (ctypes.c_int32 * 8)()
         L.d3ga_debug_defaults(info)
         if info[0] != 0 and os.environ.get("D3GA_ALLOW_ABLATION") != "1":

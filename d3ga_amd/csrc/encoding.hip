@@ -73,6 +73,49 @@ __global__ __launch_bounds__(kBlock) void sh4_encoding_bwd_kernel(int P, const f
     d_dirs[3 * i] = 2.0f * gx, d_dirs[3 * i + 1] = 2.0f * gy, d_dirs[3 * i + 2] = 2.0f * gz;     // x = 2 d - 1
 }
 
+// ColorField's per-row input columns in one pass (round 5): x (P, 16 + F) = [ sh4 encoding of the view direction | features ]
+// -- what models/mlp.py:208-226 forms with an encoding call and a torch.cat (ATen: the 64-byte encoding rows written, then
+// 2 x 320 B per Gaussian moved again by the cat; backward: the (P, 16 + F) input gradient split by two strided copies) --
+// and its backward (input gradient -> d(direction), d(features)).  One thread per 16-byte group of x: consecutive threads
+// touch consecutive groups of the row-major output, the features move as whole float4.
+__global__ __launch_bounds__(kBlock) void color_rows_fwd_kernel(int P, int G /* 4 + F / 4 groups per row */, const float *__restrict__ dirs,
+                                                                const float4 *__restrict__ feats, float4 *__restrict__ x) {
+    using namespace sh4;
+    const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= (size_t)P * G) return;
+    const int row = (int)(idx / (unsigned)G), g = (int)(idx - (size_t)row * G);
+    if (g >= 4) { x[idx] = feats[(size_t)row * (G - 4) + (g - 4)]; return; }
+    const float vx = 2.0f * dirs[3 * (size_t)row] - 1.0f, vy = 2.0f * dirs[3 * (size_t)row + 1] - 1.0f, vz = 2.0f * dirs[3 * (size_t)row + 2] - 1.0f;
+    const float xx = vx * vx, yy = vy * vy, zz = vz * vz, xy = vx * vy, yz = vy * vz, xz = vx * vz;
+    float4 o;                                                // the same expressions as sh4_encoding_fwd_kernel, group by group
+    if (g == 0) o = make_float4(c0, -c1 * vy, c1 * vz, -c1 * vx);
+    else if (g == 1) o = make_float4(c2a * xy, -c2a * yz, c2b * zz - c2c, -c2a * xz);
+    else if (g == 2) o = make_float4(c2d * xx - c2d * yy, c3a * vy * (-3.0f * xx + yy), c3b * xy * vz, c3c * vy * (1.0f - 5.0f * zz));
+    else o = make_float4(c3d * vz * (5.0f * zz - 3.0f), c3c * vx * (1.0f - 5.0f * zz), c3e * vz * (xx - yy), c3a * vx * (-xx + 3.0f * yy));
+    x[idx] = o;
+}
+
+__global__ __launch_bounds__(kBlock) void color_rows_bwd_kernel(int P, int G, const float *__restrict__ dirs, const float4 *__restrict__ gx4,
+                                                                float *__restrict__ d_dirs, float4 *__restrict__ d_feats) {
+    using namespace sh4;
+    const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= (size_t)P * G) return;
+    const int row = (int)(idx / (unsigned)G), g = (int)(idx - (size_t)row * G);
+    if (g >= 4) { if (d_feats) d_feats[(size_t)row * (G - 4) + (g - 4)] = gx4[idx]; return; }
+    if (g != 0 || !d_dirs) return;                           // the row's first thread takes the four encoding groups (64 bytes)
+    const float x = 2.0f * dirs[3 * (size_t)row] - 1.0f, y = 2.0f * dirs[3 * (size_t)row + 1] - 1.0f, z = 2.0f * dirs[3 * (size_t)row + 2] - 1.0f;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    const float4 g0 = gx4[idx], g1 = gx4[idx + 1], g2 = gx4[idx + 2], g3 = gx4[idx + 3];
+    const float q = 1.0f - 5.0f * zz, r = 3.0f * (yy - xx);          // (as sh4_encoding_bwd_kernel)
+    const float gxv = -c1 * g0.w + c2a * (y * g1.x - z * g1.w) + 2.0f * c2d * x * g2.x - 6.0f * c3a * xy * g2.y + c3b * yz * g2.z +
+                      c3c * q * g3.y + 2.0f * c3e * xz * g3.z + c3a * r * g3.w;
+    const float gyv = -c1 * g0.y + c2a * (x * g1.x - z * g1.y) - 2.0f * c2d * y * g2.x + c3a * r * g2.y + c3b * xz * g2.z +
+                      c3c * q * g2.w - 2.0f * c3e * yz * g3.z + 6.0f * c3a * xy * g3.w;
+    const float gzv = c1 * g0.z - c2a * (y * g1.y + x * g1.w) + 2.0f * c2b * z * g1.z + c3b * xy * g2.z - 10.0f * c3c * yz * g2.w +
+                      c3d * (15.0f * zz - 3.0f) * g3.x - 10.0f * c3c * xz * g3.y + c3e * (xx - yy) * g3.z;
+    d_dirs[3 * (size_t)row] = 2.0f * gxv, d_dirs[3 * (size_t)row + 1] = 2.0f * gyv, d_dirs[3 * (size_t)row + 2] = 2.0f * gzv;
+}
+
 // Output heads of a field network: pred (P,N) -> up to four column groups, each written as its own contiguous (P, w_h)
 // block of one planar buffer (block h starts at P * start_h floats) through its activation:
 //   0: y = x        1: y = a * tanh(x)        2: y = sigmoid(x + a)
@@ -188,6 +231,31 @@ extern "C" int d3ga_sh4_encoding_fwd(int32_t P, const float *dirs, float *enc, d
     if ((uintptr_t)enc & 15) return D3GA_E_CONFIG;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(sh4_encoding_fwd_kernel, dim3(ew_grid(P)), dim3(kBlock), 0, s, P, dirs, enc);
+    return check_launch(s, 0);
+}
+
+extern "C" int d3ga_color_rows_fwd(int32_t P, int32_t F, const float *dirs, const float *feats, float *x, d3ga_stream_t stream) {
+    if (P <= 0 || F < 0 || (F & 3)) return D3GA_E_SIZE;
+    if (!dirs || !x || (F > 0 && !feats)) return D3GA_E_NULL;
+    if (((uintptr_t)x | (uintptr_t)feats) & 15) return D3GA_E_CONFIG;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = 4 + F / 4;
+    const size_t n = (size_t)P * G;
+    hipLaunchKernelGGL(color_rows_fwd_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, P, G, dirs,
+                       reinterpret_cast<const float4 *>(feats), reinterpret_cast<float4 *>(x));
+    return check_launch(s, 0);
+}
+
+extern "C" int d3ga_color_rows_bwd(int32_t P, int32_t F, const float *dirs, const float *d_x, float *d_dirs, float *d_feats,
+                                   d3ga_stream_t stream) {
+    if (P <= 0 || F < 0 || (F & 3)) return D3GA_E_SIZE;
+    if (!dirs || !d_x) return D3GA_E_NULL;
+    if (((uintptr_t)d_x | (uintptr_t)d_feats) & 15) return D3GA_E_CONFIG;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = 4 + F / 4;
+    const size_t n = (size_t)P * G;
+    hipLaunchKernelGGL(color_rows_bwd_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, P, G, dirs,
+                       reinterpret_cast<const float4 *>(d_x), d_dirs, reinterpret_cast<float4 *>(d_feats));
     return check_launch(s, 0);
 }
 

@@ -397,10 +397,15 @@ class FieldMLP(nn.Module):
         """General column layout: `parts` lists z's column groups in the reference's order, each a (P, w) per-row tensor or a
         1-D broadcast vector (ColorField mixes both kinds: models/mlp.py:208-226).  Broadcast groups are folded into the
         first layer's bias, per-row groups are concatenated and meet the matching columns of the first weight (_FieldTrunk)."""
-        first = self.network[0]
         rows = [t for t in parts if t.dim() != 1]
         bcs = [t for t in parts if t.dim() == 1]
         sig = tuple((t.dim() == 1, t.shape[-1]) for t in parts)
+        return self.forward_layout(torch.cat(rows, dim=1) if len(rows) > 1 else rows[0], bcs, sig)
+
+    def forward_layout(self, x, bcs, sig):
+        """x = the per-row column groups already side by side (P, sum of their widths), bcs = the broadcast vectors, sig = z's
+        column groups in order as (is_broadcast, width)."""
+        first = self.network[0]
         layout = self._col_index.get(sig)
         if layout is None:               # column ranges of the two kinds, adjacent ranges merged, built once per layout
             row_r, bc_r, c = [], [], 0
@@ -414,7 +419,6 @@ class FieldMLP(nn.Module):
                 raise ValueError("a field needs at least one per-row column group")
             layout = (_merge_ranges(row_r), _merge_ranges(bc_r))
             self._col_index[sig] = layout
-        x = torch.cat(rows, dim=1) if len(rows) > 1 else rows[0]
         bcs = [t for t in bcs if t.numel()]
         bc = (torch.cat(bcs) if len(bcs) > 1 else bcs[0]) if bcs else None
         return self._trunk(x, bc, layout)
@@ -539,6 +543,32 @@ class _Sh4Encoding(torch.autograd.Function):
         return gd
 
 
+class _ColorRows(torch.autograd.Function):
+    """x (P, 16 + F) = [sh4_direction_encoding(view_dir) | feats]: ColorField's per-row input columns written in ONE pass
+    (d3ga_color_rows_fwd) instead of the encoding call + torch.cat (the 64-byte encoding rows and 2 x 320 B per Gaussian moved
+    again), and its input gradient split in one pass (d3ga_color_rows_bwd) instead of two strided copies."""
+
+    @staticmethod
+    def forward(ctx, d, feats):
+        require_cuda(d, feats)
+        d, feats = f32c16(d), f32c16(feats)
+        P, F_ = feats.shape
+        x = torch.empty((P, 16 + F_), dtype=torch.float32, device=d.device)
+        check(_lib.lib().d3ga_color_rows_fwd(P, F_, dptr(d), dptr(feats), dptr(x), stream_handle()), "d3ga_color_rows_fwd")
+        ctx.save_for_backward(d)
+        ctx.n_feat = F_
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        P, F_ = d.shape[0], ctx.n_feat
+        gd = torch.empty_like(d) if ctx.needs_input_grad[0] else None
+        gf = torch.empty((P, F_), dtype=torch.float32, device=d.device) if ctx.needs_input_grad[1] else None
+        check(_lib.lib().d3ga_color_rows_bwd(P, F_, dptr(d), dptr(f32c16(g)), dptr(gd), dptr(gf), stream_handle()), "d3ga_color_rows_bwd")
+        return gd, gf
+
+
 def sh4_direction_encoding(d):
     """Stand-in for tiny-cuda-nn's degree-4 `SphericalHarmonics` direction encoding (16 outputs, models/mlp.py:166-179):
     x = 2 d - 1, then the real SH polynomials of degree < 4 (constants of utils/sh_utils.py:7-24); one HIP kernel each way
@@ -588,6 +618,13 @@ class ColorField(FieldMLP):
         self.direction_encoding = direction_encoding
 
     def forward(self, shs, pose, view_dir, frame_encoding=None, camera_encoding=None, shadow=None):
+        if (shadow is None and self.direction_encoding is sh4_direction_encoding and shs.dim() == 2 and shs.shape[1] % 4 == 0
+                and shs.shape[0] > 0 and view_dir.dim() == 2 and view_dir.shape[1] == 3):
+            # the two per-row groups (first and last columns of z) as one buffer, written in one pass; same layout as below
+            bcs = [t.reshape(-1) for t in (pose, camera_encoding, frame_encoding) if t is not None]
+            sig = [(False, 16)] + [(True, t.numel()) for t in bcs] + [(False, shs.shape[1])]
+            x = _ColorRows.apply(view_dir, shs)
+            return field_heads(self.forward_layout(x, bcs, tuple(sig)), ((3, "sigmoid", 0.0), (1, "sigmoid", 0.1)))
         parts = [self.direction_encoding(view_dir), pose.reshape(-1)]
         if shadow is not None:
             parts.append(shadow)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define D3GA_VERSION 103 /* 0.1.3: D3GA_CNT_HEAVY (counter 7 of the binning buffer: how many tiles at the head of the work order the compositing backward splits over two workgroups).  102: 0.1.2: d3ga_raster_params::block_lists, d3ga_raster_bin_sort_lists (the per-tile sort emits the block lists of the compositing kernels).  101: 0.1.1: d3ga_raster_preprocess_bwd / d3ga_raster_backward* read cov3D_precomp again (the forward keeps no copy); NULL without (scales, rotations) is D3GA_E_NULL */
+#define D3GA_VERSION 104 /* 0.1.4: d3ga_color_rows_fwd / _bwd (ColorField's per-row input columns in one pass).  103: 0.1.3: D3GA_CNT_HEAVY (counter 7 of the binning buffer: how many tiles at the head of the work order the compositing backward splits over two workgroups).  102: 0.1.2: d3ga_raster_params::block_lists, d3ga_raster_bin_sort_lists (the per-tile sort emits the block lists of the compositing kernels).  101: 0.1.1: d3ga_raster_preprocess_bwd / d3ga_raster_backward* read cov3D_precomp again (the forward keeps no copy); NULL without (scales, rotations) is D3GA_E_NULL */
 
 #define D3GA_OK 0
 #define D3GA_E_NULL (-1)     /* required pointer is NULL */
@@ -485,6 +485,12 @@ int d3ga_view_dirs_bwd(int32_t P, const float *means3D, const float *campos, con
                        d3ga_stream_t stream);
 int d3ga_sh4_encoding_fwd(int32_t P, const float *dirs, float *enc, d3ga_stream_t stream);
 int d3ga_sh4_encoding_bwd(int32_t P, const float *dirs, const float *d_enc, float *d_dirs, d3ga_stream_t stream);
+/* ColorField's per-row input columns in one pass (models/mlp.py:208-226: z's per-row groups when no shadow column is present):
+ * x (P, 16 + F) = [ sh4_encoding(dirs) | feats (P,F) ], F a multiple of 4, x / feats 16-byte aligned -- instead of the encoding
+ * call and a torch.cat; backward: d_x (P, 16 + F) -> d_dirs (P,3) and d_feats (P,F), either may be NULL (ABI 104). */
+int d3ga_color_rows_fwd(int32_t P, int32_t F, const float *dirs, const float *feats, float *x, d3ga_stream_t stream);
+int d3ga_color_rows_bwd(int32_t P, int32_t F, const float *dirs, const float *d_x, float *d_dirs, float *d_feats,
+                        d3ga_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/d3ga.h but not exported"
     assert set(EXPORTS) == set(names), set(EXPORTS) ^ set(names)
-    assert L.d3ga_version() == 103
+    assert L.d3ga_version() == 104
     assert L.d3ga_status_string(-3) == b"unsupported argument combination"
 
 

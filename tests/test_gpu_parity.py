@@ -26,7 +26,7 @@ def test_library_loaded_and_row_scans():
     import d3ga_amd
     from d3ga_amd._lib import check, dptr, stream_handle
     L = d3ga_amd.lib()
-    assert L.d3ga_version() == 103
+    assert L.d3ga_version() == 104
     x = torch.randn(256 * 8, device=DEV)
     out = torch.full((256 * 8, 8), float("nan"), device=DEV)
     check(L.d3ga_selftest_row_scan(x.numel(), dptr(x), dptr(out), stream_handle()), "selftest")

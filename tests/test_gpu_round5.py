@@ -115,7 +115,7 @@ def test_backward_without_the_precomputed_covariance_is_refused():
     neither cov3D_precomp nor (scales, rotations) returns D3GA_E_NULL instead of reading uninitialised records."""
     from d3ga_amd import _lib
     L = _lib.lib()
-    assert L.d3ga_version() == 103
+    assert L.d3ga_version() == 104
     prm = _lib.RasterParams(P=16, M=0, sh_degree=0, W=64, H=64, tanfovx=1.0, tanfovy=1.0, scale_modifier=1.0, antialiasing=0,
                             prefiltered=0, debug=0, opacity_activation=0, forward_only=0, acc_self_clearing=0)
     buf = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
