@@ -1246,13 +1246,15 @@ extern "C" int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t
         for (const void *k : ks) D3GA_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr[dev] = true;
     }
-    hipLaunchKernelGGL(chain_bias_kernel, dim3(L), dim3(128), 0, s, ba);          // this call's biases into the panels' tails
-    const int nblocks = (P + kChainRows - 1) / kChainRows;
-    static const int grid_cap = getenv("D3GA_CHAIN_GRID") ? atoi(getenv("D3GA_CHAIN_GRID")) : 2048 / kChainWaves;
-    const dim3 grid(nblocks < grid_cap ? nblocks : grid_cap), block(kChainThreads);
     // the backward's chain: no bias, no activation, no sign output anywhere -- its own instantiation without that arithmetic
     bool bwd = masks != nullptr;
     for (int l = 0; l < L && bwd; ++l) bwd = !signs[l] && slopes[l] == 1.f && !(biases && biases[l]);
+    // this call's biases into the panels' tails.  (The BWD instantiation never reads a bias -- the tail still rides along with the
+    // panel's DMA, whatever it holds: no launch for it, 5.7 us x 3 chains per colour step.)
+    if (!bwd) hipLaunchKernelGGL(chain_bias_kernel, dim3(L), dim3(128), 0, s, ba);
+    const int nblocks = (P + kChainRows - 1) / kChainRows;
+    static const int grid_cap = getenv("D3GA_CHAIN_GRID") ? atoi(getenv("D3GA_CHAIN_GRID")) : 2048 / kChainWaves;
+    const dim3 grid(nblocks < grid_cap ? nblocks : grid_cap), block(kChainThreads);
     if (masks && !bwd)                                     // masks together with bias / activation / sign output: not built
         for (int l = 0; l < L; ++l) if (masks[l]) return D3GA_E_CONFIG;
     if (bwd) {
