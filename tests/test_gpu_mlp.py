@@ -530,3 +530,31 @@ def test_field_trunk_node_and_embed_cache():
     assert torch.equal(df(x, pose), a)
     df.set_constant_input(None)
     assert torch.equal(df(x, pose), a)
+
+
+@pytest.mark.parametrize("P,F", [(1, 4), (777, 64), (5000, 24), (300, 0)])
+def test_color_rows_equal_encoding_and_cat(P, F):
+    """d3ga_color_rows_fwd / _bwd (ABI 104): ColorField's per-row input columns [sh4 encoding | features] in one pass each way,
+    against sh4_direction_encoding + torch.cat and autograd's split of the gradient; either gradient may be left out."""
+    from d3ga_amd.mlp import _ColorRows, sh4_direction_encoding
+    g = torch.Generator().manual_seed(P + F)
+    d = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(DEV)
+    f = torch.randn(P, F, generator=g).to(DEV)
+    up = torch.randn(P, 16 + F, generator=g).to(DEV)
+    d1, f1 = d.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    x = _ColorRows.apply(d1, f1)
+    x.backward(up)
+    d2, f2 = d.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    ref = torch.cat([sh4_direction_encoding(d2), f2], dim=1)
+    ref.backward(up)
+    torch.testing.assert_close(x, ref, rtol=1e-6, atol=1e-6)
+    assert torch.equal(x[:, 16:], f)
+    # (sums of cancelling terms, contracted differently by the two kernels: compared on the scale of the largest gradient)
+    torch.testing.assert_close(d1.grad, d2.grad, rtol=1e-4, atol=1e-5 * float(d2.grad.abs().max()))
+    assert torch.equal(f1.grad, f2.grad)
+    d3 = d.clone().requires_grad_(True)                      # features without a gradient: d_feats == NULL
+    _ColorRows.apply(d3, f).backward(up)
+    assert torch.equal(d3.grad, d1.grad)
+    f3 = f.clone().requires_grad_(True)                      # ... and the other way round
+    _ColorRows.apply(d, f3).backward(up)
+    assert torch.equal(f3.grad, f1.grad)
