@@ -377,3 +377,36 @@ def test_cage_deform_warns_when_tets_and_gaussians_are_equally_many():
         warnings.simplefilter("error")
         with pytest.raises(_lib.D3GAError):
             cage_deform(*args, gradient_per_tet=False)      # said explicitly: no warning
+
+
+def test_field_column_layout_is_resolved_into_merged_ranges():
+    """Host logic of round 5 (no GPU): a field's input layout -- z's column groups, per row or broadcast, in the reference's order
+    (models/mlp.py:208-226) -- becomes column ranges of the first weight, adjacent groups of one kind merged; a wrong total is
+    refused; ColorField's fast path uses the same layout as the general one."""
+    import torch
+    from d3ga_amd import mlp
+    assert mlp._merge_ranges([(0, 16), (16, 20), (30, 40), (40, 41)]) == ((0, 20), (30, 41))
+    assert mlp._merge_ranges([]) == ()
+    col = mlp.ColorField(n_features=24, n_cond=30, frame_dims=8, camera_dims=6, n_nodes=64, n_layers=2, shadow_dims=1)
+    seen = []
+    col._trunk = lambda x, bc, layout: seen.append((tuple(x.shape), None if bc is None else tuple(bc.shape), layout)) or torch.zeros(x.shape[0], 4)
+    P = 5
+    enc, shadow, feats = torch.zeros(P, 16), torch.zeros(P, 1), torch.zeros(P, 24)
+    pose, cam, frame = torch.zeros(30), torch.zeros(6), torch.zeros(8)
+    col.forward_parts([enc, pose, shadow, cam, frame, feats])
+    # z = [enc 0:16 | pose 16:46 | shadow 46:47 | camera 47:53 | frame 53:61 | feats 61:85]
+    assert seen[-1] == ((P, 41), (44,), (((0, 16), (46, 47), (61, 85)), ((16, 46), (47, 61))))
+    col2 = mlp.ColorField(n_features=24, n_cond=30, frame_dims=8, camera_dims=0, n_nodes=64, n_layers=2)
+    col2._trunk = col._trunk
+    col2.forward_layout(torch.zeros(P, 40), [pose, frame], ((False, 16), (True, 30), (True, 8), (False, 24)))
+    assert seen[-1] == ((P, 40), (38,), (((0, 16), (54, 78)), ((16, 54),)))
+    with pytest.raises(ValueError):
+        col2.forward_layout(torch.zeros(P, 40), [pose], ((False, 16), (True, 30), (False, 24)))
+    f = mlp.FieldMLP(12, 3, n_nodes=32, n_layers=1)
+    f._trunk = col._trunk
+    f.forward(torch.zeros(P, 5), torch.zeros(7))
+    assert seen[-1] == ((P, 5), (7,), (((7, 12),), ((0, 7),)))
+    f.forward(torch.zeros(P, 12), torch.zeros(0))
+    assert seen[-1] == ((P, 12), None, (((0, 12),), ()))
+    with pytest.raises(ValueError):
+        f.forward(torch.zeros(P, 4), torch.zeros(7))
