@@ -200,18 +200,21 @@ def test_order_kernel_counts_the_tiles_the_backward_splits():
     assert int(counters[7]) == (nonempty + 9) // 10, (counters, nonempty)
 
 
-@pytest.mark.parametrize("deg", [3, 1])
-def test_view_direction_term_of_the_mean_gradient_comes_from_the_forwards_jacobian(deg):
+@pytest.mark.parametrize("deg,M", [(3, 16), (1, 16), (1, 4), (2, 9), (2, 12), (0, 1)])
+def test_view_direction_term_of_the_mean_gradient_comes_from_the_forwards_jacobian(deg, M):
     """Round 5: preprocess leaves d(SH colour)/d(unit view direction) per Gaussian (GeomBuf::dcol) and preprocess_bwd forms the
     direction term of dL/dmean from it without reading the coefficients.  Isolated here: the same scene rendered once with the SH
     coefficients and once with colors_precomp = the colours those coefficients give -- same alphas, same pixel gradient, so the two
     dL/dmeans3D differ by exactly  sum_c dL/dcolour_c . d colour_c / d mean  (clamped channels excluded), which torch forms in
-    float64 from the oracle's eval_sh.  Also: the SH gradient itself and dL/dcolour agree between the two renders."""
+    float64 from the oracle's eval_sh.  Also: the SH gradient itself and dL/dcolour agree between the two renders.
+    (deg, M): M = 16 and 12 take the staged path with full / partial rows and the Jacobian record, M = 4 the staged path with short
+    rows, M = 9 and 1 (3 M not a multiple of 4) the direct path, where the backward still reads the coefficients; degree 0 has no
+    view dependence at all.)"""
     from d3ga_amd import rasterizer as R
     from oracle import raster_torch as rt
     from test_gpu_parity import _settings
     inp = scene_inputs("T1", scale_mult=3.0)
-    shs = inp["shs"].clone()
+    shs = inp["shs"][:, :M].clone()
     shs[::3, 0, :] = -2.5                                   # some channels clamp at 0 (no gradient through them)
     shs[:, 1:] *= 4.0                                       # a strong view dependence: the term under test is not a rounding-level share
     bg = torch.tensor([0.1, 0.2, 0.3])
@@ -237,11 +240,13 @@ def test_view_direction_term_of_the_mean_gradient_comes_from_the_forwards_jacobi
     dd = mm - inp["campos"].double()[None]
     c = rt.eval_sh(deg, shs.double(), dd / dd.norm(dim=1, keepdim=True)) + 0.5
     live = (col_raw > 0).double()
-    (c * gcol * live).sum().backward()
-    want = mm.grad
+    if deg > 0:
+        (c * gcol * live).sum().backward()
+    want = mm.grad if mm.grad is not None else torch.zeros_like(m64)      # (degree 0: the colour does not see the direction)
     got = (g_sh["means3D"].double() - g_pre["means3D"].double())
     scale_term, scale_all = float(want.abs().max()), float(g_pre["means3D"].abs().max())
-    assert scale_term > 1e-3 * scale_all                     # the term is visible beside the geometry term it rides on
+    if deg > 0:
+        assert scale_term > 1e-3 * scale_all                 # the term is visible beside the geometry term it rides on
     err = float((got - want).abs().max())
     assert err <= 2e-3 * scale_term + 4e-6 * scale_all, (err, scale_term, scale_all)
     # the SH gradient is basis x (clamp-masked dL/dcolour), the colour gradient of the precomputed render is the unmasked one
