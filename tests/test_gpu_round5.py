@@ -257,3 +257,21 @@ def test_view_direction_term_of_the_mean_gradient_comes_from_the_forwards_jacobi
         B[:, k] = rt.eval_sh(deg, e, (d / d.norm(dim=1, keepdim=True)))[:, 0]
     want_sh = B[:, :, None] * (gcol * live)[:, None, :]
     assert float((g_sh["shs"].double() - want_sh).abs().max()) <= 1e-4 * float(want_sh.abs().max())
+
+
+@pytest.mark.parametrize("deg,M", [(3, 16), (2, 12), (1, 4), (2, 9)])
+def test_inference_and_training_forward_give_the_same_image_bit_for_bit(deg, M):
+    """The forward a backward follows also leaves d(colour)/d(direction) (another instantiation of preprocess_kernel, other
+    registers live around the SH sum): basis, direction and the SH sum are contraction-free / explicit fmaf chains so that its
+    colours -- and the image -- are bit-identical to the inference forward's, for every staging path."""
+    from d3ga_amd import rasterizer as R
+    from test_gpu_parity import _settings
+    inp = scene_inputs("T1", scale_mult=3.0)
+    rast = R.GaussianRasterizer(_settings(inp, torch.tensor([0.2, 0.4, 0.6]), deg))
+    args = dict(means3D=inp["means3D"].to(DEV), means2D=None, opacities=inp["opacities"].to(DEV),
+                shs=inp["shs"][:, :M].contiguous().to(DEV), cov3D_precomp=inp["cov6"].to(DEV))
+    with torch.no_grad():
+        img_inf, radii_inf, _ = rast(**args)
+    img_g, radii_g, _ = rast(**dict(args, means3D=args["means3D"].clone().requires_grad_(True)))
+    assert torch.equal(img_inf, img_g.detach()) and torch.equal(radii_inf, radii_g)
+    assert float(img_inf.std()) > 0
