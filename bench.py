@@ -87,6 +87,9 @@ def parse():
     ap.add_argument("--views-per-rank", type=int, default=1,
                     help="N>1 (or --force-cut): every rank renders k views of the pose per step and the gradients of all of them leave "
                          "in ONE exchange (the deform runs once per rank and step); value counts N x k frames per step")
+    ap.add_argument("--batch-views", type=int, default=4,
+                    help="N = 1: also time the VIEW-BATCHED step (k cameras of the pose in one grid per rasterizer stage: d3ga_amd/raster_views.py) "
+                         "and report it as `batched_views` beside the single-view headline; 0 = off")
     ap.add_argument("--fresh-scratch", action="store_true",
                     help="allocate and clear the backward's gradient accumulator per call instead of keeping a self-clearing one "
                          "(rasterizer.set_accumulator_policy)")
@@ -870,6 +873,80 @@ def color_train_bench(args):
             sys.exit(4)
 
 
+def batched_views_bench(frame, k, steps, burst):
+    """The frame step with k cameras of the pose rasterised as ONE batch (include/d3ga.h: d3ga_raster_params::n_views): upstream
+    (LBS + cage deform) once, k views through one grid per rasterizer stage, loss = mean L1 over the k images (train.py:218-221
+    averages the losses of a batch of frames), the whole backward.  One captured hipGraph, K replays; then an eager pass with
+    HIP events per stage.  Returns the `batched_views` object of the bench line: frames/s counts VIEWS (k per step)."""
+    from d3ga_amd import rasterizer as R
+    from d3ga_amd.graph import CapturedStep
+    from d3ga_amd.raster_views import CameraBatch, rasterize_gaussians_views
+    dev, wl = frame.dev, frame.wl
+    W, H = wl.width, wl.height
+    nv = max(8, k)
+    batches = [frame.syn.make_batch(W, H, azimuth=2 * math.pi * v / nv, camera_id=v, fill=frame.fill) for v in range(k)]
+    cams = CameraBatch(k, W, H, device=dev).set(batches)
+    targets = torch.stack([torch.rand(3, H, W, generator=torch.Generator().manual_seed(100 + v)) for v in range(k)]).to(dev)
+    one = torch.ones((), device=dev)
+    params = list(frame.params.values())
+
+    def step():
+        pkg = frame.upstream()
+        _, _, loss = rasterize_gaussians_views(pkg["means3D"], pkg["shs"], None, pkg["opacity_logits"], None, None, pkg["cov3D_precomp"],
+                                               cams, frame.bg, sh_degree=frame.sh_degree, opacity_activation="sigmoid", l1_targets=targets)
+        loss.backward(one)
+        return loss
+
+    def zero():
+        for p in params:
+            p.grad = None
+    R.set_capacity_policy("auto")
+    for _ in range(3):
+        zero(); step()
+    cnt = R.last_counters()
+    R.set_capacity_policy("static", int(cnt["D"] * 1.25) + 4096)
+    zero(); step()
+    torch.cuda.synchronize()
+    graph = CapturedStep(step, params=params)
+    for _ in range(30):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    end = graph.check_overflow()
+    del graph
+    R.stage_timer.enabled = True
+    R.stage_timer.reset()
+    R.stage_timer.burst = {"composite_fwd": burst, "composite_bwd": burst}
+    for _ in range(steps):
+        zero(); step()
+    torch.cuda.synchronize()
+    R.stage_timer.enabled = False
+    stages = R.stage_timer.summary()
+    R.stage_timer.reset()
+    P, M, D = wl.n_gaussians, frame.params["features"].shape[1], cnt["D"]
+    tiles = math.ceil(W / 16) * math.ceil(H / 16)
+    alg = {"preprocess": k * P * (88 + 12 * M), "bin_sort": 36 * D + 8 * tiles * k, "composite_fwd": 40 * D + 20 * W * H * k,
+           "composite_bwd": 80 * D + 20 * W * H * k, "preprocess_bwd": k * P * (140 + 40) + P * 12 * M}
+    kernels = {n: {"ms": round(ms, 4), "ms_per_view": round(ms / k, 4), "launches": c, "alg_bytes": alg[n],
+                   "achieved_GBs": round(alg[n] / (ms * 1e-3) / 1e9, 1), "frac_hbm_peak": round(alg[n] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+               for n, (c, ms) in stages.items() if n in alg}
+    worst = max((n for n in ("composite_bwd", "composite_fwd") if n in kernels), key=lambda n: kernels[n]["ms"], default=None)
+    return {"views": k, "value": round(k * steps / dt, 3), "unit": "frames/s (views)", "ms_per_step": round(1e3 * dt / steps, 4),
+            "ms_per_view": round(1e3 * dt / steps / k, 4), "steps": steps, "duplicates_D": D, "max_tile_list": cnt["max_tile"],
+            "capacity_check": None if end is None else {"D": end["D"], "capacity": end["capacity"]},
+            "step": "LBS + cage deform once, k views in one grid per rasterizer stage, mean L1 over the k images, the whole backward; "
+                    "one hipGraph replay per step",
+            "roofline": None if worst is None else {"kernel": worst, "bound": "hbm", "achieved": kernels[worst]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                                                    "unit": "GB/s", "frac": kernels[worst]["frac_hbm_peak"], "traffic": None,
+                                                    "alg_bytes_per_launch": alg[worst], "avg_ms": kernels[worst]["ms"]},
+            "kernels": kernels,
+            "stage_events": f"separate eager pass, same K steps; compositing kernels launched {burst}x back to back per event pair"}
+
+
 def _self_launch(n):
     """`python bench.py --gpus N` WITHOUT a launcher (WORLD_SIZE unset): re-exec this command line under
     `python -m torch.distributed.run`, one rank per GPU, exactly as the driver launches N > 1 -- a plain invocation must
@@ -1444,6 +1521,11 @@ def main():
         }
         if train is not None:
             out["training_step"] = train
+        if world == 1 and args.batch_views > 1 and not args.force_cut:
+            try:
+                out["batched_views"] = batched_views_bench(frame, int(args.batch_views), args.steps, args.stage_burst)
+            except Exception as e:  # noqa: BLE001  (an extra regime must never take the headline down)
+                out["batched_views"] = {"error": repr(e)}
         if args.init_timing:
             try:
                 out["init"] = init_timing(frame)

@@ -11,6 +11,9 @@ ACC_STRIDE = 16          # D3GA_ACC_STRIDE (include/d3ga.h): floats per Gaussian
 # touching their `_version`, so host-side caches keyed by (data_ptr, _version) -- the packed weight panels of mlp.py --
 # carry this epoch in their key as well (eager forward -> replays with in-graph Adam -> eager forward used stale panels).
 replay_epoch = [0]
+ABI_VERSION = 110       # D3GA_VERSION (include/d3ga.h)
+# D3GA_KNOB_* (include/d3ga.h), in key order
+KNOBS = ("composite_variant", "merge_slots", "tile_assign", "bwd_split", "sort_merge", "ssim_impl", "wgrad_ws", "chain_abl", "chain_grid")
 LOSS_PARTIALS = 2048     # D3GA_LOSS_PARTIALS (include/d3ga.h): floats of scratch behind a two-stage loss reduction
 
 
@@ -29,7 +32,7 @@ class RasterParams(ctypes.Structure):
                 ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
                 ("antialiasing", ctypes.c_int32), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
                 ("opacity_activation", ctypes.c_int32), ("forward_only", ctypes.c_int32),
-                ("acc_self_clearing", ctypes.c_int32), ("block_lists", ctypes.c_int32)]
+                ("acc_self_clearing", ctypes.c_int32), ("n_views", ctypes.c_int32)]
 
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -39,7 +42,8 @@ _prm = ctypes.POINTER(RasterParams)
 _SIGNATURES = {
     "d3ga_version": ([], _i),
     "d3ga_status_string": ([_i], ctypes.c_char_p),
-    "d3ga_debug_defaults": ([ctypes.POINTER(ctypes.c_int32)], _i),
+    "d3ga_debug_set": ([ctypes.c_int32, ctypes.c_int32], _i),
+    "d3ga_debug_defaults": ([ctypes.POINTER(ctypes.c_int32), ctypes.c_int32], _i),
     "d3ga_lbs_cage_fwd": ([_i, _i] + [_vp] * 8 + [_vp], _i),
     "d3ga_lbs_cage_bwd": ([_i, _i] + [_vp] * 6 + [_vp], _i),
     "d3ga_cage_deform_fwd": ([_i] + [_vp] * 9 + [_vp], _i),
@@ -51,13 +55,13 @@ _SIGNATURES = {
     "d3ga_fem_energy_fwd": ([_i] + [_vp] * 4 + [_vp], _i),
     "d3ga_fem_energy_bwd": ([_i, _i] + [_vp] * 5 + [_vp], _i),
     "d3ga_raster_scratch_bytes": ([ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i64, ctypes.POINTER(_i64)], _i),
+    "d3ga_raster_scratch_bytes_views": ([ctypes.c_int32] * 4 + [_i64, ctypes.c_int32, ctypes.POINTER(_i64)], _i),
     "d3ga_raster_binning_layout": ([ctypes.c_int32, ctypes.c_int32, _i64, ctypes.POINTER(_i64)], _i),
     "d3ga_raster_img_layout": ([ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_i64)], _i),
     "d3ga_raster_img_layout_blocks": ([ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_i64)], _i),
     "d3ga_raster_img_bytes": ([ctypes.c_int32, ctypes.c_int32, _i64, ctypes.c_int32], _i64),
     "d3ga_raster_preprocess": ([_prm] + [_vp] * 12 + [_i64, _vp, _vp], _i),
     "d3ga_raster_bin_sort": ([_prm, _vp, _vp, _i64, _vp], _i),
-    "d3ga_raster_bin_sort_lists": ([_prm, _vp, _vp, _vp, _i64, ctypes.POINTER(ctypes.c_int32), _vp], _i),
     "d3ga_raster_composite_fwd": ([_prm, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i),
     "d3ga_raster_composite_bwd": ([_prm, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i),
     "d3ga_raster_composite_bwd_depth": ([_prm, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp], _i),
@@ -122,23 +126,40 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = res
-        if L.d3ga_version() != 104:
-            raise D3GAError(f"libd3ga_hip.so version {L.d3ga_version()} does not match the Python layer (104)")
-        info = (ctypes.c_int32 * 8)()
-        L.d3ga_debug_defaults(info)
+        if L.d3ga_version() != ABI_VERSION:
+            raise D3GAError(f"libd3ga_hip.so version {L.d3ga_version()} does not match the Python layer ({ABI_VERSION})")
+        info = (ctypes.c_int32 * (2 + 2 * len(KNOBS)))()
+        L.d3ga_debug_defaults(info, len(info))
         if info[0] != 0 and os.environ.get("D3GA_ALLOW_ABLATION") != "1":
             raise D3GAError(f"{_PATH} is a timing-ablation build (D3GA_SCAN_ABL={info[0]}): its results are wrong by design. "
                             "Set D3GA_ALLOW_ABLATION=1 to load it for a timing run.")
+        # The library reads no environment.  Tests and A/B runs set its debug knobs through THIS layer:
+        # D3GA_KNOBS="merge_slots=256,tile_assign=1" (names: KNOBS) -> d3ga_debug_set at load.  Product runs leave it unset.
+        spec = os.environ.get("D3GA_KNOBS", "")
+        for item in filter(None, (x.strip() for x in spec.split(","))):
+            name, _, val = item.partition("=")
+            if name not in KNOBS:
+                raise D3GAError(f"D3GA_KNOBS: unknown knob {name!r} (known: {', '.join(KNOBS)})")
+            st = L.d3ga_debug_set(KNOBS.index(name), int(val))
+            if st != 0:
+                raise D3GAError(f"d3ga_debug_set({name}, {val}) failed with status {st}")
         _lib = L
     return _lib
 
 
 def debug_defaults():
-    """d3ga_debug_defaults() as a dict: what the loaded library runs by default and with the current environment."""
-    info = (ctypes.c_int32 * 8)()
-    check(lib().d3ga_debug_defaults(info), "d3ga_debug_defaults")
-    return {"scan_abl": info[0], "diag": info[1], "composite_variant": (info[2], info[3]),
-            "merge_slots": (info[4], info[5]), "tile_assign": (info[6], info[7])}
+    """d3ga_debug_defaults() as a dict: scan_abl, diag, then knob name -> (compiled default, value in effect)."""
+    info = (ctypes.c_int32 * (2 + 2 * len(KNOBS)))()
+    check(lib().d3ga_debug_defaults(info, len(info)), "d3ga_debug_defaults")
+    out = {"scan_abl": info[0], "diag": info[1]}
+    for k, name in enumerate(KNOBS):
+        out[name] = (info[2 + 2 * k], info[3 + 2 * k])
+    return out
+
+
+def debug_set(name, value=None):
+    """Set a debug knob of the library (tests / A/B runs only); value None restores the compiled default."""
+    check(lib().d3ga_debug_set(KNOBS.index(name), -2**31 if value is None else int(value)), "d3ga_debug_set")
 
 
 def check(status, what):

@@ -4,7 +4,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["deform.hip", "raster_pre.hip", "raster_bin.hip", "raster_composite.hip", "raster_composite_lists.hip", "raster_composite_scan.hip", "raster_api.hip", "bary.hip", "loss.hip", "mlp.hip", "encoding.hip"]
+SOURCES = ["deform.hip", "raster_pre.hip", "raster_bin.hip", "raster_composite.hip", "raster_composite_scan.hip", "raster_api.hip", "bary.hip", "loss.hip", "mlp.hip", "encoding.hip"]
+LINK_MAP = os.path.join(HERE, "d3ga.map")
 HEADERS = ["d3ga_math.h", "d3ga_internal.h", "raster_pre_body.h", "composite_common.h", os.path.join("..", "..", "include", "d3ga.h")]
 ABL = os.environ.get("D3GA_SCAN_ABL")       # timing ablation of the compositing backward (wrong results): own objects + .so
 VARIANT = os.environ.get("D3GA_VARIANT")    # A/B build of compile-time knobs: "tag:-DNAME=value,-DOTHER=value" -> tools/_build/libd3ga_hip_<tag>.so (correct results)
@@ -20,13 +21,12 @@ else:
     FLAGS_VARIANT = []
 OUT = (os.path.join(DIAG_DIR, f"libd3ga_hip_abl{ABL}.so" if ABL else f"libd3ga_hip_{_DIAG_TAG}.so") if DIAG
        else os.path.join(HERE, "..", "libd3ga_hip.so"))
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-munsafe-fp-atomics", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"] + FLAGS_VARIANT
 # per-source extras.  The entry-per-lane compositing backward is VALU-issue bound; SLP-packing its scalar f32 chains into
 # v_pk_* costs ~35 register shuffles per 4 pixels (ISA inspected) and a v_pk_fma_f32 issues in 4.2 cycles against 2.4 for a
 # v_fma_f32 (tools/micro/valu_issue.hip), so the vectoriser is off for the two compositing files.
 EXTRA = {"raster_composite_scan.hip": ["-fno-slp-vectorize"],
-         "raster_composite_lists.hip": ["-fno-slp-vectorize"],
          "raster_composite.hip": ["-fno-slp-vectorize"]}      # forward 117 -> 103 us at C3: packed f32 ops cost 2x, plus their shuffles
 if os.environ.get("D3GA_CHAIN_WAVES"):                        # A/B: wavefronts per workgroup of the fused field-network kernel
     FLAGS.append("-DD3GA_CHAIN_WAVES=" + os.environ["D3GA_CHAIN_WAVES"])
@@ -70,14 +70,14 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
         objs.append(o)
-    if force or _newer(OUT, objs):
+    if force or _newer(OUT, objs + [LINK_MAP]):
         # Link against the HIP runtime that PyTorch-ROCm itself loads (torch/lib/libamdhip64.so, SONAME without a
         # version) so that the process holds ONE runtime: torch's streams, events and allocations are then valid
         # in our launches.  /opt/rocm/lib stays on the runpath for hosts that load the library without torch.
         import torch
         tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
         cmd = ["g++", "-shared", "-fPIC"] + objs + ["-L" + tlib, "-lamdhip64", "-Wl,-rpath," + tlib,
-                                                    "-Wl,-rpath,/opt/rocm/lib", "-o", OUT]
+                                                    "-Wl,-rpath,/opt/rocm/lib", "-Wl,--version-script=" + LINK_MAP, "-o", OUT]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

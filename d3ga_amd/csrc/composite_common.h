@@ -4,58 +4,21 @@
 #pragma once
 #include "d3ga_internal.h"
 
-#include <stdlib.h>
-
 namespace d3ga {
 
-// D3GA_COMPOSITE_VARIANT (A/B knob, read once; the other bits selected kernels that no longer exist):
-//   bit 5 (32)  work-ordered dispatch: quadrants are handed out heaviest tile first (tile_order of the bin stage);
-//   bit 7 (128) exact ellipse / block-rectangle test behind the bounding-box test of the forward's culling.
+// Debug knobs of the compositing kernels (d3ga_debug_set; include/d3ga.h D3GA_KNOB_*; defaults in raster_api.hip):
+//   composite variant: bit 5 (32) work-ordered dispatch -- quadrants / tiles are handed out heaviest tile first (tile_order of
+//     the bin stage); bit 7 (128) exact ellipse / block-rectangle test behind the bounding-box test of the forward's culling;
+//   merge slots: slots of the backward's tile-level merge cache (256 | 512 | 1024);
+//   tile assign: block -> wavefront assignment of the backward's tile kernel: 0 quadrants, 1 interleaved (blocks 8 px apart),
+//     2 by list length (the default: DESIGN.md sec. 4);
+//   bwd split: the heaviest tiles (in work order) get two workgroups each (raster_composite_scan.hip): -1 (default) = as many as
+//     the order kernel counts (a tenth of the non-empty tiles: D3GA_CNT_HEAVY), 0 = none, n > 0 = the n heaviest.
 constexpr int kVariantOrdered = 32, kVariantExactCull = 128;
-constexpr int kDefaultCompositeVariant = kVariantOrdered | kVariantExactCull;
-static inline int composite_variant() {
-    static const int v = [] {
-        const char *e = getenv("D3GA_COMPOSITE_VARIANT");
-        return e ? atoi(e) : kDefaultCompositeVariant;
-    }();
-    return v;
-}
-constexpr int kDefaultMergeSlots = 512;
-static inline int composite_merge_slots() {        // A/B knob: slots of the tile-level merge cache (256 | 512 | 1024)
-    static const int v = [] {
-        const char *e = getenv("D3GA_MERGE_SLOTS");
-        return e ? atoi(e) : kDefaultMergeSlots;
-    }();
-    return v;
-}
-// block -> wavefront assignment of the backward's tile kernel: 0 quadrants, 1 interleaved (blocks 8 px apart), 2 by list
-// length (the default: DESIGN.md sec. 4; d3ga_debug_defaults() reports what THIS library runs and a test pins it)
-constexpr int kDefaultTileAssign = 2;
-static inline int composite_tile_assign() {        // A/B knob (D3GA_TILE_ASSIGN)
-    static const int v = [] {
-        const char *e = getenv("D3GA_TILE_ASSIGN");
-        return e ? atoi(e) : kDefaultTileAssign;
-    }();
-    return v;
-}
-// Backward: the heaviest tiles (in work order) get two workgroups each (raster_composite_scan.hip).  D3GA_BWD_SPLIT: -1 (default) = as many
-// as the order kernel counts (a tenth of the non-empty tiles: D3GA_CNT_HEAVY), 0 = none, n > 0 = the n heaviest
-constexpr int kDefaultBwdSplit = -1;
-static inline int composite_bwd_split() {
-    static const int v = [] { const char *e = getenv("D3GA_BWD_SPLIT"); return e ? atoi(e) : kDefaultBwdSplit; }();
-    return v;
-}
-// A/B knob (D3GA_FWD_LDS_TOTAL / D3GA_BWD_LDS_TOTAL, bytes): pad a kernel's LDS allocation up to this total with dynamic shared
-// memory -- limits the workgroups resident per CU (160 KB / total) without touching the code: fewer, faster waves per SIMD
-// and more dispatch rounds (the hardware dispatcher hands out workgroups in launch order as slots free up).  0 / unset: no pad.
-static inline unsigned lds_pad_bytes(const void *kernel, const char *env_name) {
-    const char *e = getenv(env_name);
-    const long total = e ? atol(e) : 0;
-    if (total <= 0) return 0u;
-    hipFuncAttributes a;
-    if (hipFuncGetAttributes(&a, kernel) != hipSuccess) return 0u;
-    return total > (long)a.sharedSizeBytes ? (unsigned)(total - (long)a.sharedSizeBytes) : 0u;
-}
+static inline int composite_variant() { return debug_knob(D3GA_KNOB_COMPOSITE_VARIANT); }
+static inline int composite_merge_slots() { return debug_knob(D3GA_KNOB_MERGE_SLOTS); }
+static inline int composite_tile_assign() { return debug_knob(D3GA_KNOB_TILE_ASSIGN); }
+static inline int composite_bwd_split() { return debug_knob(D3GA_KNOB_BWD_SPLIT); }
 // L1 image loss fused into the compositing backward: image (3,H,W) = the forward's colour output, target (or the device
 // cell that holds its address: graph.TensorSlot), g_loss = dL/dloss (device scalar), inv_n = 1 / (3 H W); image == null: off
 struct L1Source { const float *image, *target; const float *const *target_cell; const float *g_loss; float inv_n; };
@@ -69,25 +32,6 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
                               bool ordered, const float *colors2, const float *bg2, const float *dL_dpix2, const L1Source &l1,
                               hipStream_t s, const float *dL_dinvd = nullptr);
 
-// raster_composite_lists.hip: the two-launch forward (tile_cull_kernel + composite_fwd_lists_kernel)
-int launch_composite_fwd_lists(const d3ga_raster_params *prm, int gx, int gy, const BinBuf &bin, const GeomBuf &g, const ImgBuf &im,
-                               int64_t d_capacity, const float *bg, float *out_color, float *out_invdepth, const float *colors2,
-                               const float *bg2, float *out_color2, bool ordered, bool exact, const L1Value &l1v, bool lists_ready,
-                               hipStream_t s);
-// D3GA_FWD_IMPL (A/B knob, read once): 0 the one-launch quadrant forward (raster_composite.hip); 1 the two-launch forward of
-// raster_composite_lists.hip for renders that are followed by a backward (measured, not faster: its list pass is latency-bound --
-// DESIGN.md sec. 4); 2 the lists blend of raster_composite_lists.hip over block lists the per-tile SORT emitted
-// (d3ga_raster_bin_sort_lists + d3ga_raster_params::block_lists; a composite call whose params do not say so builds them with the
-// list pass of 1).  Renders with forward_only always use the one-launch forward: no block lists are allocated.
-constexpr int kDefaultFwdImpl = 0;
-static inline int composite_fwd_impl_kind() {
-    static const int v = [] {
-        const char *e = getenv("D3GA_FWD_IMPL");
-        return e ? atoi(e) : kDefaultFwdImpl;
-    }();
-    return v;
-}
-
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
@@ -95,13 +39,27 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 // ---- work item -> (tile, quadrant) with tile rows interleaved over the 8 XCDs ----
+// View-batched launches (d3ga_raster_params::n_views = k > 1): the grid spans gx x (k gyv) tiles, tile row v gyv + ty is row ty of
+// view v; pixel coordinates (and the splat centres they are compared with) stay LOCAL to the view -- every view computes exactly
+// what a single-view launch computes -- and `view` selects the image planes.  One view: gyv = gy, view = 0.
 struct Quad {
     bool valid;
-    int tile, px, py;            // tile index, this lane's pixel
-    int qx0, qy0;                // quadrant origin in pixels
+    int tile, px, py;            // tile index (of the whole batch), this lane's pixel (local to its view)
+    int qx0, qy0;                // quadrant origin in pixels (local)
     int quad;                    // quadrant index inside the tile (0..3)
+    int view;
 };
-__device__ __forceinline__ Quad quad_of_block(int gx, int gy) {
+__device__ __forceinline__ void quad_place(Quad &q, int tx, int ty, int quad, int gyv) {
+    q.view = ty / gyv;
+    const int tyl = ty - q.view * gyv;
+    q.quad = quad;
+    q.qx0 = tx * kTile + ((quad & 1) << 3);
+    q.qy0 = tyl * kTile + ((quad >> 1) << 3);
+    const int lane = threadIdx.x & 63;
+    q.px = q.qx0 + (lane & 7);
+    q.py = q.qy0 + (lane >> 3);
+}
+__device__ __forceinline__ Quad quad_of_block(int gx, int gy, int gyv) {
     Quad q;
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
@@ -110,30 +68,20 @@ __device__ __forceinline__ Quad quad_of_block(int gx, int gy) {
     const int ty = xcd + 8 * k, tx = rem >> 2, quad = rem & 3;
     q.valid = ty < gy;
     q.tile = ty * gx + tx;
-    q.quad = quad;
-    q.qx0 = tx * kTile + ((quad & 1) << 3);
-    q.qy0 = ty * kTile + ((quad >> 1) << 3);
-    const int lane = threadIdx.x & 63;
-    q.px = q.qx0 + (lane & 7);
-    q.py = q.qy0 + (lane >> 3);
+    quad_place(q, tx, q.valid ? ty : 0, quad, gyv);
     return q;
 }
 static inline int quad_grid(int gx, int gy) { return 8 * ((gy + 7) / 8) * gx * 4; }
 // Work-ordered mapping: tile rank k (tile_order: descending list length) -> blocks b, b+8, b+16, b+24 of one XCD (the four
 // quadrants of a tile keep sharing an L2), ranks dealt round-robin over the XCDs.
-__device__ __forceinline__ Quad quad_of_block_ordered(int gx, int tiles, const uint32_t *__restrict__ order) {
+__device__ __forceinline__ Quad quad_of_block_ordered(int gx, int tiles, int gyv, const uint32_t *__restrict__ order) {
     Quad q;
     const int b = blockIdx.x;
     const int k = (b & 7) + 8 * (b >> 5), quad = (b >> 3) & 3;
     q.valid = k < tiles;
     q.tile = q.valid ? (int)order[k] : 0;
     const int ty = q.tile / gx, tx = q.tile - ty * gx;
-    q.quad = quad;
-    q.qx0 = tx * kTile + ((quad & 1) << 3);
-    q.qy0 = ty * kTile + ((quad >> 1) << 3);
-    const int lane = threadIdx.x & 63;
-    q.px = q.qx0 + (lane & 7);
-    q.py = q.qy0 + (lane >> 3);
+    quad_place(q, tx, ty, quad, gyv);
     return q;
 }
 static inline int quad_grid_ordered(int tiles) { return 32 * ((tiles + 7) / 8); }
@@ -234,165 +182,6 @@ __device__ __forceinline__ BlockHits block_hits4_exact(float cx, float cy, float
     h.r3 = box.r3 && !(fminf(qx(fx1, ya1, yb1), qy(fy1, xa1, xb1)) > c.tau);
     return h;
 }
-// ---- block spans of a splat (round 5) ----
-// The 4x4-pixel blocks (global block grid: block column C covers pixel columns 4C .. 4C+3, block line R pixel lines 4R .. 4R+3)
-// that the alpha >= 1/255 ellipse {q <= tau} can touch, as ONE column interval per block line.  q is convex, so the ellipse cut
-// by the slab of a block line spans [l(dyl), r(dyr)] with  r(dy) = (-B dy + sqrt(tau A - det dy^2)) / A  (concave, maximiser
-// dy* = -(B/C) hx: the rightmost point) taken at dy* clamped into the slab, and l likewise (convex, minimiser -dy*); a block is in
-// iff its pixel columns meet that interval.  tau and the box extents are the inflated ones of splat_cull() (0.1 % + 1e-4; 0.1 % +
-// 0.02 px), the interval is padded by 0.1 % of the extent + 0.02 px, everything is intersected with the bounding box: conservative
-// -- the same set as block_hits4() + block_hits4_exact() up to rounding.  exact == false: the bounding box on every line.
-// Written once per Gaussian by preprocess (GeomBuf::span) and decoded per (tile | quadrant, entry) with integer arithmetic by the
-// compositing forward, instead of the geometric test per (quadrant, entry).  Layout (16 bytes):
-//   x: block line R0 of the first line (i16; kSpanBigR0: see below) | block column C0 the intervals are relative to (i16) << 16
-//   y, z, w: up to twelve lines, line k in BYTE k:  (lo + 1) | hi << 4  = columns C0 + lo .. C0 + hi (lo <= 14, hi <= 15); low
-//      nibble 0: empty line (lines past the last one are stored empty)
-//   R0 == kSpanBigR0: too tall (> 12 block lines: half height > 22 px) / wide (> 16 columns) / far off for this record -- the reader
-//      falls back to the geometric test.  (At C3 2.4 % of the splats are taller than SIX block lines: a first version with 16-bit
-//      fields and six lines sent 79 % of the forward's 64-survivor batches through the fallback.)
-constexpr int kSpanBigR0 = 0x7fff, kSpanLines = 12;
-__device__ __forceinline__ uint4 span_big() { return make_uint4((uint32_t)kSpanBigR0, 0u, 0u, 0u); }
-__device__ __forceinline__ bool span_is_big(const uint4 &sp) { return (sp.x & 0xffffu) == (uint32_t)kSpanBigR0; }
-__device__ __forceinline__ uint4 splat_spans(float cx, float cy, float A, float B, float C, float o, bool exact) {
-    const SplatCull sc = splat_cull(A, B, C, o);
-    if (sc.hx < 0.0f) return make_uint4(0u, 0u, 0u, 0u);
-    if (!(sc.hx < 500.f) || !(sc.hy < 500.f) || !(fabsf(cx) < 100000.f) || !(fabsf(cy) < 100000.f)) return span_big();
-    // block lines R with 4R <= cy + hy and 4R + 3 >= cy - hy; columns of the box likewise
-    const int R0 = (int)ceilf((cy - sc.hy - 3.0f) * 0.25f), R1 = (int)floorf((cy + sc.hy) * 0.25f);
-    const int C0 = (int)ceilf((cx - sc.hx - 3.0f) * 0.25f), C1 = (int)floorf((cx + sc.hx) * 0.25f);
-    const int K = R1 - R0 + 1;
-    if (K <= 0 || C1 < C0) return make_uint4(0u, 0u, 0u, 0u);
-    if (K > kSpanLines || C1 - C0 > 15) return span_big();
-    const float det = A * C - B * B, rA = __builtin_amdgcn_rcpf(A), tauA = sc.tau * A;
-    const float dys = sc.nbc * sc.hx;
-    const float pad = 1e-3f * sc.hx + 0.02f;
-    uint32_t w[3] = {0u, 0u, 0u};
-#pragma unroll
-    for (int k = 0; k < kSpanLines; ++k) {
-        if (k >= 4 && __builtin_amdgcn_ballot_w64(k < K) == 0ull) break;     // (uniform: no lane of the wavefront has a line k)
-        int lo = C0, hi = C1;
-        if (exact) {
-            const float ya = (float)(4 * (R0 + k)) - cy, yb = ya + 3.0f;
-            const float dyr = clamp3(dys, ya, yb), dyl = clamp3(-dys, ya, yb);
-            const float sr = __builtin_amdgcn_sqrtf(fmaxf(0.0f, tauA - det * dyr * dyr));
-            const float sl = __builtin_amdgcn_sqrtf(fmaxf(0.0f, tauA - det * dyl * dyl));
-            const float rmax = (sr - B * dyr) * rA + pad, lmin = (-sl - B * dyl) * rA - pad;
-            const int l2 = (int)ceilf((cx + lmin - 3.0f) * 0.25f), h2 = (int)floorf((cx + rmax) * 0.25f);
-            if (l2 > lo && lmin == lmin) lo = l2;                     // (NaN -> the box)
-            if (h2 < hi && rmax == rmax) hi = h2;
-        }
-        const uint32_t f = (k < K && lo <= hi) ? ((uint32_t)(lo - C0 + 1) | ((uint32_t)(hi - C0) << 4)) : 0u;
-        w[k >> 2] |= f << (8 * (k & 3));                              // (k is a constant here: no indexed access)
-    }
-    return make_uint4(((uint32_t)R0 & 0xffffu) | ((uint32_t)C0 << 16), w[0], w[1], w[2]);
-}
-// the 8-bit field of span line idx (empty outside 0 .. kSpanLines - 1).  Shifts, not a select over the record's words: the
-// compiler turns `idx < 4 ? sp.y : ...` into an indexed load of the record, which puts the record into SCRATCH memory (measured:
-// the forward went from 79 to 106 us)
-__device__ __forceinline__ uint32_t span_line(const uint4 &sp, int idx) {
-    const unsigned long long lo8 = (unsigned long long)sp.y | ((unsigned long long)sp.z << 32);
-    const uint32_t a = (uint32_t)(lo8 >> (8 * (idx & 7))), b = sp.w >> (8 * (idx & 3));
-    const uint32_t e = ((idx & 8) ? b : a) & 0xffu;
-    return (unsigned)idx < (unsigned)kSpanLines ? e : 0u;
-}
-// column bits (bit i = block column Cq0 + i, i < ncols) of one span line field
-__device__ __forceinline__ uint32_t span_cols(uint32_t e, int cb, int ncols) {
-    const int lo = max(cb + (int)(e & 15u) - 1, 0), hi = min(cb + (int)(e >> 4), ncols - 1);
-    return ((e & 15u) != 0u && lo <= hi) ? ((2u << hi) - (1u << lo)) : 0u;
-}
-// the 16-bit block mask (bit 4 * quadrant + block within it, as the block lists are numbered) of a span record inside the tile whose
-// first block column / line are Ct0 / Rt0; the record must not be big
-__device__ __forceinline__ uint32_t span_mask16(const uint4 &sp, int Ct0, int Rt0) {
-    const int R0 = (int)(int16_t)(sp.x & 0xffffu), C0 = (int)sp.x >> 16;
-    const int k0 = Rt0 - R0, cb = C0 - Ct0;
-    uint32_t mask = 0u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t cols = span_cols(span_line(sp, k0 + j), cb, 4) & 15u;
-        const int p0 = 8 * (j >> 1) + 2 * (j & 1);                    // block (i, j) -> bit 8 (j >> 1) + 2 (j & 1) + {0, 1, 4, 5}[i]
-        mask |= ((cols & 3u) << p0) | (((cols >> 2) & 3u) << (p0 + 4));
-    }
-    return mask;
-}
-// the 4-bit mask of the 2x2 blocks of one quadrant (bit = block column + 2 x block line inside the quadrant: the forward's row
-// index) whose first block column / line are Cq0 / Rq0
-__device__ __forceinline__ uint32_t span_mask4(const uint4 &sp, int Cq0, int Rq0) {
-    const int R0 = (int)(int16_t)(sp.x & 0xffffu), C0 = (int)sp.x >> 16;
-    const int k0 = Rq0 - R0, cb = C0 - Cq0;
-    return (span_cols(span_line(sp, k0), cb, 2) & 3u) | ((span_cols(span_line(sp, k0 + 1), cb, 2) & 3u) << 2);
-}
-
-// (bx, by) = block column / line inside the tile -> the block index both directions use: 4 * quadrant + block within it
-__device__ __forceinline__ int blk_of(int bx, int by) { return 4 * ((bx >> 1) + 2 * (by >> 1)) + ((bx & 1) + 2 * (by & 1)); }
-
-// Blocks of the tile at (tx0, ty0) that the splat (centre, conic | opacity) can touch, as a 16-bit mask over blk_of().
-// Box test = block_hits4() per block column / line; exact: per block LINE j the x interval of {q <= tau} inside the slab
-// y in [4j, 4j+3] -- q(dx, dy) = A dx^2 + 2 B dx dy + C dy^2 is convex, so the intersection of the ellipse with the slab spans
-// [l(dyl), r(dyr)] with  r(dy) = (-B dy + sqrt(tau A - det dy^2)) / A  (concave; its maximiser dy* = -(B/C) hx is the
-// ellipse's rightmost point) taken at dy* clamped into the slab, likewise l (convex, minimiser -dy*); a block is kept iff its
-// pixel columns meet that interval.  Same set as block_hits4_exact() up to rounding (tau is inflated by 0.1 % + 1e-4 there and
-// here; the interval is padded by 0.1 % of the splat's extent + 0.02 px), so it stays conservative for ANY footprint.
-__device__ __forceinline__ uint32_t block_mask16(float cx, float cy, float A, float B, float C, float o, float tx0, float ty0, bool exact) {
-    const SplatCull sc = splat_cull(A, B, C, o);
-    if (sc.hx < 0.0f) return 0u;                                      // alpha < 1/255 everywhere (NaN: falls through = relevant)
-    const float xl = cx - sc.hx, xr = cx + sc.hx, yt = cy - sc.hy, yb = cy + sc.hy;
-    uint32_t colbox = 0u, rowbox = 0u;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float c0 = tx0 + 4.0f * (float)i, r0 = ty0 + 4.0f * (float)i;
-        colbox |= (!(xr < c0) && !(xl > c0 + 3.0f)) ? (1u << i) : 0u;
-        rowbox |= (!(yb < r0) && !(yt > r0 + 3.0f)) ? (1u << i) : 0u;
-    }
-    if (colbox == 0u || rowbox == 0u) return 0u;
-    const float det = A * C - B * B, rA = __builtin_amdgcn_rcpf(A), tauA = sc.tau * A;
-    const float dys = sc.nbc * sc.hx;                                 // dy of the rightmost point (-dys: leftmost)
-    const float pad = 1e-3f * sc.hx + 0.02f;
-    uint32_t mask = 0u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t cols = colbox;
-        if (exact) {
-            const float ya = (ty0 + 4.0f * (float)j) - cy, yb2 = ya + 3.0f;
-            const float dyr = clamp3(dys, ya, yb2), dyl = clamp3(-dys, ya, yb2);
-            const float sr = __builtin_amdgcn_sqrtf(fmaxf(0.0f, tauA - det * dyr * dyr));
-            const float sl = __builtin_amdgcn_sqrtf(fmaxf(0.0f, tauA - det * dyl * dyl));
-            const float rmax = (sr - B * dyr) * rA + pad, lmin = (-sl - B * dyl) * rA - pad;
-            cols = 0u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float xa = (tx0 + 4.0f * (float)i) - cx;
-                cols |= (!(rmax < xa) && !(lmin > xa + 3.0f)) ? (1u << i) : 0u;     // (NaN: relevant)
-            }
-            cols &= colbox;
-        }
-        cols = ((rowbox >> j) & 1u) ? cols : 0u;
-        // block (i, j) -> bit 8 (j >> 1) + 2 (j & 1) + {0, 1, 4, 5}[i]
-        const int p0 = 8 * (j >> 1) + 2 * (j & 1);
-        mask |= ((cols & 3u) << p0) | (((cols >> 2) & 3u) << (p0 + 4));
-    }
-    return mask;
-}
-
-// the rare path of the mask decoders (tile_cull_kernel, tile_scatter_kernel, the huge-list emission: a splat too large for a span record): out of line, so that its ~250 instructions and their
-// registers are not replicated into every sub-round of the kernel
-static __device__ __attribute__((noinline)) uint32_t block_mask16_slow(uint32_t id, const float4 *__restrict__ xyh, const float4 *__restrict__ conic_o,
-                                                                 float tx0, float ty0, bool exact) {
-    const float4 h = xyh[id], co = conic_o[id];
-    return block_mask16(h.x, h.y, co.x, co.y, co.z, co.w, tx0, ty0, exact);
-}
-
-// inclusive prefix sum over the 64 lanes (DPP: row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast:15 / :31 across them);
-// used on four 8-bit counters packed in a dword (a lane contributes 0 or 1 per counter: no carry between the fields)
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // rows 1, 3 += lane 15 of rows 0, 2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // rows 2, 3 += lane 31
-    return v;
-}
-
 __device__ __forceinline__ int lanes_below(unsigned long long m) {   // popcount of m restricted to lower lanes
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }

@@ -10,42 +10,50 @@ namespace d3ga {
 
 constexpr int kBlock = 256;
 
+// the library's debug knobs (include/d3ga.h: D3GA_KNOB_*, d3ga_debug_set): value in effect.  No environment is read anywhere.
+int debug_knob(int key);
+
 static inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 // Per-Gaussian state written by the preprocess kernel (structure of arrays, 256-byte aligned sections).
+// View-batched renders (d3ga_raster_*_views): the arrays hold n_views * P records, view v's Gaussian i at v * P + i.
 struct GeomBuf {
     float *depth;       // P      view-space z
-    float2 *xy;         // P      (unused since round 4: the kernels read the centre from the xyh record)
     float4 *conic_o;    // P      conic (a,b,c) + opacity
     float4 *rgb_invd;   // P      colour + 1/depth
     uint2 *rect;        // P      tile rectangle packed: x = minx | miny<<16, y = maxx | maxy<<16
     uint8_t *clamped;   // P      bit c set: SH colour channel c was clamped at 0
-    float *cov3D;       // P*6    3D covariance actually used (precomputed copy or from scale/rotation)
+    float *cov3D;       // P*6    3D covariance built from (scale, rotation); unused with a precomputed one (read from the caller's tensor)
     float4 *xyh;        // P      pixel-space centre | half extents of the alpha >= 1/255 ellipse's bounding box (splat_cull):
                         //        the 16-byte record the compositing forward's first stage tests a list entry with
-    float *dcol;        // 9 planes of P floats, round 5: d(SH colour)/d(unit view direction), plane 3 * (direction x, y, z) + channel -- left by the forward's staged SH
-                        //        evaluation so that preprocess_bwd need not read the coefficients again (96 MB at C3) for dL/dmean
-    uint4 *span;        // P      round 5: the 4x4-pixel BLOCKS the alpha >= 1/255 ellipse can touch, as one column interval per
-                        //        block line (composite_common.h: splat_spans) -- what tile_cull_kernel builds the block lists from
+    float *dcol;        // 9 planes of `dcol_stride` floats: d(SH colour)/d(unit view direction), plane 3 * (direction x, y, z) + channel -- left by
+                        //        the forward's staged SH evaluation so that preprocess_bwd need not read the coefficients again (96 MB at C3) for dL/dmean
+    int64_t dcol_stride;
 };
 static inline int64_t geom_bytes(int64_t P) {
-    return align256(4 * P) + align256(8 * P) + align256(16 * P) + align256(16 * P) + align256(8 * P) + align256(P) +
-           align256(24 * P) + align256(16 * P) + align256(16 * P) + align256(36 * P);
+    return align256(4 * P) + align256(16 * P) + align256(16 * P) + align256(8 * P) + align256(P) +
+           align256(24 * P) + align256(16 * P) + align256(36 * P);
 }
 static inline GeomBuf carve_geom(void *base, int64_t P) {
     char *p = (char *)base;
     GeomBuf g;
     g.depth = (float *)p;     p += align256(4 * P);
-    g.xy = (float2 *)p;       p += align256(8 * P);
     g.conic_o = (float4 *)p;  p += align256(16 * P);
     g.rgb_invd = (float4 *)p; p += align256(16 * P);
     g.rect = (uint2 *)p;      p += align256(8 * P);
     g.clamped = (uint8_t *)p; p += align256(P);
     g.cov3D = (float *)p;     p += align256(24 * P);
     g.xyh = (float4 *)p;      p += align256(16 * P);
-    g.span = (uint4 *)p;      p += align256(16 * P);
     g.dcol = (float *)p;
+    g.dcol_stride = P;
     return g;
+}
+// the records of view v of a batch (every array advanced by v * P records; the dcol planes keep the batch's stride)
+static inline GeomBuf geom_view(const GeomBuf &g, int64_t P, int64_t v) {
+    GeomBuf o = g;
+    const int64_t d = v * P;
+    o.depth += d; o.conic_o += d; o.rgb_invd += d; o.rect += d; o.clamped += d; o.cov3D += 6 * d; o.xyh += d; o.dcol += d;
+    return o;
 }
 
 // Binning state.
@@ -82,29 +90,26 @@ static inline BinBuf carve_bin(void *base, int64_t tiles, int64_t dcap) {
 }
 
 struct ImgBuf {
-    float *final_T;        // H*W
+    float *final_T;        // H*W  (view-batched: n_views images back to back)
     uint32_t *n_contrib;   // H*W   1-based tile-list position of the last contributing Gaussian
     // Per-4x4-block culled lists, written by the compositing forward for its backward (raster_composite_scan.hip):
     // a 16x16 tile has 16 blocks (quadrant q = 0..3, row r = 0..3 of that quadrant's wavefront -> block 4q + r); the
     // list of block b of a tile whose depth-sorted list is [begin, end) occupies blk_list[16*begin + b*(end-begin) ...],
-    // blk_count[16*tile + b] entries {1-based position in the tile list, Gaussian index}, front to back.
-    // Round 5 (raster_composite_lists.hip): the lists are built by a pass of their own (tile_cull_kernel: every entry of a tile's
-    // sorted list against the tile's 16 blocks, blk_total entries per block) BEFORE the blend; the blend walks them and leaves in
-    // blk_count the length of the prefix that holds every entry some pixel of the block blended -- what the backward walks.
+    // entries {1-based position in the tile list, Gaussian index}, front to back; blk_count[16*tile + b] = the length of the
+    // prefix that holds every entry some pixel of the block blended -- what the backward walks.
     uint32_t *blk_count;   // 16 * tiles
-    uint32_t *blk_total;   // 16 * tiles   entries the cull pass wrote per block (>= blk_count)
     uint2 *blk_list;       // 16 * d_capacity
 };
-static inline int64_t img_bytes(int64_t W, int64_t H, int64_t tiles, int64_t dcap) {
-    return 2 * align256(4 * W * H) + 2 * align256(64 * tiles) + align256(128 * dcap);
+// W x H: one view; tiles: of the whole batch; views: images in the batch
+static inline int64_t img_bytes(int64_t W, int64_t H, int64_t tiles, int64_t dcap, int64_t views = 1) {
+    return 2 * align256(4 * W * H * views) + align256(64 * tiles) + align256(128 * dcap);
 }
-static inline ImgBuf carve_img(void *base, int64_t W, int64_t H, int64_t tiles) {
+static inline ImgBuf carve_img(void *base, int64_t W, int64_t H, int64_t tiles, int64_t views = 1) {
     ImgBuf i;
     char *p = (char *)base;
-    i.final_T = (float *)p;        p += align256(4 * W * H);
-    i.n_contrib = (uint32_t *)p;   p += align256(4 * W * H);
+    i.final_T = (float *)p;        p += align256(4 * W * H * views);
+    i.n_contrib = (uint32_t *)p;   p += align256(4 * W * H * views);
     i.blk_count = (uint32_t *)p;   p += align256(64 * tiles);
-    i.blk_total = (uint32_t *)p;   p += align256(64 * tiles);
     i.blk_list = (uint2 *)p;
     return i;
 }
@@ -158,6 +163,8 @@ __device__ __forceinline__ TileWindow block_tile_window(int *s_box, bool visible
 
 static inline int tiles_x(int W) { return (W + kTile - 1) / kTile; }
 static inline int tiles_y(int H) { return (H + kTile - 1) / kTile; }
+// cameras in the batch (d3ga_raster_params::n_views: 0 and 1 both mean one)
+static inline int n_views_of(const d3ga_raster_params *prm) { return prm->n_views > 1 ? prm->n_views : 1; }
 
 // launch check: returns hipError (>0) or 0; in debug mode also synchronises
 static inline int check_launch(hipStream_t s, int debug) {

@@ -699,13 +699,7 @@ static int ssim_march_rows(const void *kernel, int C, int H, int strips) {
     }
     return best;
 }
-static inline int ssim_impl() {          // A/B knob D3GA_SSIM_IMPL: 0 the LDS-tiled kernels, 1 (default) the marching kernels
-    static const int v = [] {
-        const char *e = getenv("D3GA_SSIM_IMPL");
-        return e ? atoi(e) : 1;
-    }();
-    return v;
-}
+static inline int ssim_impl() { return debug_knob(D3GA_KNOB_SSIM_IMPL); }      // 1 (default) the marching kernels, 0 the LDS-tiled ones of round 3
 
 extern "C" int d3ga_ssim_l1_fwd(int32_t C, int32_t H, int32_t W, const float *img1, const float *img2, float *out,
                                 float *Dm, float *Dq1, float *Dq12, float *out_l1, d3ga_stream_t stream) {

@@ -1129,7 +1129,7 @@ static int mlp_wgrad_launch(int32_t P, int32_t N, int32_t K, const float *dpre, 
     const size_t lds = 2 * (size_t)kWgOperandBytes;
     const bool va = N % 2 == 0 && ((uintptr_t)dpre & 7) == 0, vb = K % 2 == 0 && ((uintptr_t)X & 7) == 0;   // float2 loads
     const bool mixed = N <= 16 || K <= 16;
-    static const bool use_ws = [] { const char *e = getenv("D3GA_WGRAD_WS"); return !e || atoi(e) != 0; }();   // A/B knob
+    const bool use_ws = debug_knob(D3GA_KNOB_WGRAD_WS) != 0;
 #define D3GA_WG(VA, VB, MX)                                                                                           \
     do {                                                                                                              \
         static bool attr[64] = {};                                                                                    \
@@ -1232,7 +1232,7 @@ extern "C" int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t
     if (L < 2) return D3GA_E_CONFIG;
     for (int l = 0; l + 1 < L; ++l) if (Ns[l] != 128) return D3GA_E_CONFIG;
     const int ntl = (Ns[L - 1] + 31) / 32;
-    static const int abl = getenv("D3GA_CHAIN_ABL") ? atoi(getenv("D3GA_CHAIN_ABL")) : 0;      // timing ablations (wrong results)
+    const int abl = debug_knob(D3GA_KNOB_CHAIN_ABL);      // timing ablations (wrong results)
     a.abl = abl;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)kChainSlots * kChainSlotUnits * 16 + (3 * 128 + (kChainThreads / 64) * 32 * kChainStageLd) * sizeof(float);
@@ -1253,7 +1253,7 @@ extern "C" int d3ga_mlp_chain_fwd(int32_t P, int32_t K0, const float *X, int32_t
     // panel's DMA, whatever it holds: no launch for it, 5.7 us x 3 chains per colour step.)
     if (!bwd) hipLaunchKernelGGL(chain_bias_kernel, dim3(L), dim3(128), 0, s, ba);
     const int nblocks = (P + kChainRows - 1) / kChainRows;
-    static const int grid_cap = getenv("D3GA_CHAIN_GRID") ? atoi(getenv("D3GA_CHAIN_GRID")) : 2048 / kChainWaves;
+    const int grid_cap = debug_knob(D3GA_KNOB_CHAIN_GRID) > 0 ? debug_knob(D3GA_KNOB_CHAIN_GRID) : 2048 / kChainWaves;
     const dim3 grid(nblocks < grid_cap ? nblocks : grid_cap), block(kChainThreads);
     if (masks && !bwd)                                     // masks together with bias / activation / sign output: not built
         for (int l = 0; l < L; ++l) if (masks[l]) return D3GA_E_CONFIG;

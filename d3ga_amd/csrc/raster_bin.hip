@@ -14,22 +14,9 @@
 //   tile_sort_lds_kernel       one workgroup per tile: LDS bitonic sort, 8 keys per thread (lists up to 2048 entries)
 //   tile_sort_lds_list_kernel  longer lists (up to 8192): 64 KB LDS, persistent grid over a device-side work list
 //                              (+ in the same launch: even longer lists, same network on global memory)
-#include <stdlib.h>
+#include <atomic>
 
 #include "composite_common.h"
-
-// timing ablations of the list emission (tools/_build variants, WRONG results): 1 no list stores, 2 no span gather (mask from the
-// index's bits), 4 no emission loop at all
-#ifndef D3GA_SORT_ABL
-#define D3GA_SORT_ABL 0
-#endif
-// A/B (build.py D3GA_VARIANT): records staged through LDS rings and written 64 at a time | nontemporal list stores
-#ifndef D3GA_EMIT_STAGED
-#define D3GA_EMIT_STAGED 0
-#endif
-#ifndef D3GA_EMIT_NT
-#define D3GA_EMIT_NT 0
-#endif
 
 namespace d3ga {
 
@@ -317,140 +304,6 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr k, int n, int tid, int nthre
     }
 }
 
-// ---- block lists as a by-product of the sort (round 5; d3ga_raster_bin_sort_lists) ----
-// What the compositing kernels walk is, per 4x4-pixel block of a tile, the sub-list of the tile's depth-sorted list whose splats
-// can touch the block: {1-based position in the tile list, Gaussian index}, front to back (ImgBuf::blk_list / blk_total).  The
-// one-launch forward builds them while it blends (culling = 40 % of its instructions, on the critical path of its heaviest
-// wavefronts); the two-launch forward of raster_composite_lists.hip builds them in a pass of its own (latency-bound: a span
-// gather per (tile, entry) behind the list load with nothing to overlap, 32-48 us at C3 for a blend that takes 54 instead of 80).
-// Here the sort workgroup, which holds the tile's entries anyway, emits them: a thread requests the span records of its keys as
-// soon as it has the keys -- the gathers are in flight while the workgroup buckets, scans and orders (four barriers) -- decodes the
-// 16-bit block mask of (tile, Gaussian) from them, and writes {index, mask} to the entry's SORTED position in LDS (in place of the
-// bucket-ordered keys).  Then wavefront w emits the lists of ITS blocks: it walks the sorted entries 64 at a time, one ballot and
-// one mbcnt pair per block rank its lanes -- no barrier, no cross-wavefront table; the next 64 entries are read ahead.
-// (First version: the scatter wrote the mask beside every key -- its divergent per-lane tile loop paid 75 instructions per (tile,
-// Gaussian) pair at 40 % lane occupancy: 14.6 -> 22 us -- and the emission ranked its lanes with a packed DPP prefix scan, 60
-// instructions per wavefront and 64 entries: 11 -> 25 us for the per-tile sort; the pair lost what the lists blend gained.)
-struct ListOut {
-    uint2 *blk_list;            // null: no lists (d3ga_raster_bin_sort, forward-only renders)
-    uint32_t *blk_total;
-    const uint4 *span;
-    const float4 *xyh, *conic_o;        // the rare splat too large for a span record: the geometric test
-    int gx;
-    bool exact;
-};
-// block mask of Gaussian `id` in the tile (tcx, tcy) from its span record
-__device__ __forceinline__ uint32_t tile_block_mask(const ListOut &lo, uint32_t id, const uint4 &sp, int tcx, int tcy) {
-    uint32_t m = span_is_big(sp) ? 0u : span_mask16(sp, 4 * tcx, 4 * tcy);
-    if (__builtin_amdgcn_ballot_w64(span_is_big(sp)) != 0ull) {        // rare
-        if (span_is_big(sp)) m = block_mask16_slow(id, lo.xyh, lo.conic_o, (float)(tcx * kTile), (float)(tcy * kTile), lo.exact);
-    }
-    return m;
-}
-// NWAVES wavefronts of the workgroup (the first NWAVES) emit the lists of blocks [first, first + NWAVES * KB): wavefront w those of
-// blocks first + KB * w .. + KB - 1.  entry(i) -> {Gaussian index, 16-bit block mask} of sorted position i.
-template <int KB, bool WIDE, typename Entry>
-__device__ __forceinline__ void emit_block_lists(Entry entry, int n, uint32_t cap, uint2 *__restrict__ base, uint32_t *__restrict__ total16,
-                                                 int first, int nwaves) {
-    const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6);
-    if (wave >= nwaves) return;
-    const int b0 = first + KB * wave;
-    uint32_t run[KB];                                        // (uniform: entries of the block's list so far)
-#pragma unroll
-    for (int k = 0; k < KB; ++k) run[k] = (uint32_t)(b0 + k) * cap;
-    uint2 e = make_uint2(0u, 0u);
-    if (lane < n) e = entry(lane);
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int i = i0 + lane;
-        const uint2 cur = e;
-        e = make_uint2(0u, 0u);
-        if (i + 64 < n) e = entry(i + 64);                   // read ahead
-        const uint32_t bits = i < n ? (cur.y >> b0) : 0u;
-        const uint2 rec = make_uint2((uint32_t)i + 1u, cur.x);
-#pragma unroll
-        for (int k = 0; k < KB; ++k) {
-            const bool h = ((bits >> k) & 1u) != 0u;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(h);
-            if (h && !(D3GA_SORT_ABL & 1)) {
-                if (WIDE) base[(size_t)run[k] + (size_t)lanes_below(m)] = rec;
-                else {
-                    uint32_t off = (run[k] + (uint32_t)lanes_below(m)) << 3;
-                    if (D3GA_SORT_ABL & 8) off &= 0x3fffu;                    // (timing: every list store of a tile into one 16 KB window)
-                    if (D3GA_SORT_ABL & 16) off = (off & 0x3ffu) + 1024u * (uint32_t)lane;     // (timing: a private KB per lane: 64 lines per store)
-                    uint2 *dst = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(base) + off);   // (SGPR base + 32-bit offset)
-                    if (D3GA_EMIT_NT) __builtin_nontemporal_store(((unsigned long long)rec.y << 32) | rec.x, reinterpret_cast<unsigned long long *>(dst));
-                    else *dst = rec;
-                }
-            }
-            run[k] += (uint32_t)__popcll(m);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < KB; ++k)
-        if (lane == k) total16[b0 + k] = (D3GA_SORT_ABL & 25) ? 0u : run[k] - (uint32_t)(b0 + k) * cap;
-}
-// The same with the records STAGED through LDS: a wavefront's scattered appends (a store instruction per (64 entries, block) with
-// ~7 of 64 lanes active: 415 k store instructions per frame at C3 -- they, not the ranking, were the cost of the first version:
-// per-tile sort 19 us without the stores, 30 with them) go to a 128-record ring per list in LDS, and a list is written to HBM 64
-// records at a time, one full 512-byte store instruction.  LDS operations of one wavefront execute in order: no barrier.
-// ring: KB x 128 records of this wavefront.
-template <int KB, typename Entry>
-__device__ __forceinline__ void emit_block_lists_staged(Entry entry, int n, uint32_t cap, uint2 *__restrict__ base,
-                                                        uint32_t *__restrict__ total16, int first, int nwaves, uint2 *ring) {
-    const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6);
-    if (wave >= nwaves) return;
-    const int b0 = first + KB * wave;
-    uint32_t wr[KB], fl[KB];                                 // (uniform) records appended / written out so far
-#pragma unroll
-    for (int k = 0; k < KB; ++k) { wr[k] = 0u; fl[k] = 0u; }
-    auto flush = [&](int k, uint32_t cnt) {                  // records fl[k] .. fl[k] + cnt - 1 of list k -> HBM
-        if ((uint32_t)lane < cnt) {
-            const uint2 v = ring[128 * k + ((fl[k] + (uint32_t)lane) & 127u)];
-            *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(base) + (((uint32_t)(b0 + k) * cap + fl[k] + (uint32_t)lane) << 3)) = v;
-        }
-    };
-    uint2 e = make_uint2(0u, 0u);
-    if (lane < n) e = entry(lane);
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int i = i0 + lane;
-        const uint2 cur = e;
-        e = make_uint2(0u, 0u);
-        if (i + 64 < n) e = entry(i + 64);                   // read ahead
-        const uint32_t bits = i < n ? (cur.y >> b0) : 0u;
-        const uint2 rec = make_uint2((uint32_t)i + 1u, cur.x);
-#pragma unroll
-        for (int k = 0; k < KB; ++k) {
-            const bool h = ((bits >> k) & 1u) != 0u;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(h);
-            if (h) ring[128 * k + ((wr[k] + (uint32_t)lanes_below(m)) & 127u)] = rec;
-            wr[k] += (uint32_t)__popcll(m);
-            if (wr[k] - fl[k] >= 64u) {                      // (uniform)
-                if (!(D3GA_SORT_ABL & 1)) flush(k, 64u);
-                fl[k] += 64u;
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < KB; ++k) {
-        if (!(D3GA_SORT_ABL & 1)) flush(k, wr[k] - fl[k]);
-        if (lane == k) total16[b0 + k] = (D3GA_SORT_ABL & 1) ? 0u : wr[k];
-    }
-}
-// the same from the sorted list in HBM (lists no LDS class holds): the mask is decoded from the span record, gathered here
-template <int NW>
-__device__ __forceinline__ void emit_block_lists_global(const ListOut &lo, int tile, uint64_t b64, int n, uint32_t cap,
-                                                        const uint32_t *__restrict__ point_list) {
-    const int tcx = tile % lo.gx, tcy = tile / lo.gx;
-    auto entry = [&](int i) {
-        const uint32_t id = __hip_atomic_load(point_list + b64 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written by this workgroup
-        const uint4 sp = lo.span[id];
-        const uint32_t m = span_is_big(sp) ? block_mask16_slow(id, lo.xyh, lo.conic_o, (float)(tcx * kTile), (float)(tcy * kTile), lo.exact)
-                                           : span_mask16(sp, 4 * tcx, 4 * tcy);
-        return make_uint2(id, m);
-    };
-    emit_block_lists<16 / NW, true>(entry, n, cap, lo.blk_list + 16 * b64, lo.blk_total + 16 * (size_t)tile, 0, NW);
-}
-
 // Depth sort of ONE tile list in LDS by BUCKETING (counting sort on a power-of-two quantisation of the depth bits, then an exact
 // fix-up inside every bucket).  The bitonic network above moves every 8-byte key through LDS 36 times (2048 keys: 1.5 MB of
 // LDS traffic per tile -- the sort was LDS-bandwidth bound, 52 us of the 82 us bin+sort at C3); here a key is written to LDS
@@ -465,31 +318,21 @@ __device__ __forceinline__ void emit_block_lists_global(const ListOut &lo, int t
 //      total order of DESIGN.md sec. 2).  A bucket holds ~0.6 keys on average (n = 1200, CAP = 2048); the loop is O(bucket^2)
 //      only for coplanar splats of IDENTICAL quantised depth, bounded by CAP.
 // The result is the sorted list, independent of the atomic arrival order.
-template <int BLOCK, int CAP, bool LISTS>
+template <int BLOCK, int CAP>
 __device__ __forceinline__ void sort_one_tile_bucket(uint64_t *s_key, uint32_t *s_bin, uint32_t *s_red, int tile,
                                                      const uint32_t *__restrict__ start, const uint64_t *__restrict__ keys,
-                                                     uint32_t *__restrict__ point_list, uint64_t dcap, const ListOut &lo_,
-                                                     uint2 *s_ring_hi = nullptr, int emit_first = 0, int emit_waves = BLOCK / 64) {
+                                                     uint32_t *__restrict__ point_list, uint64_t dcap) {
     static_assert(CAP == 8 * BLOCK, "eight keys / eight counters per thread");
     constexpr int NW = BLOCK / 64;
     const uint64_t b64 = min((uint64_t)start[tile], dcap), e64 = min((uint64_t)start[tile + 1], dcap);
     const int n = min((int)(e64 - b64), CAP);             // (lists are clamped only if the capacity overflowed)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint64_t r[8];
-    uint4 sp[LISTS ? 8 : 1];                               // LISTS: the keys' span records (in flight while the list is ordered)
-    uint32_t km[LISTS ? 8 : 1];                            //        their block masks in this tile, later | sorted position << 16
     uint32_t lo = 0xffffffffu, hi = 0u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int i = tid + k * BLOCK;
         r[k] = i < n ? keys[b64 + i] : ~0ull;
-    }
-    if (LISTS) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (D3GA_SORT_ABL & 2) sp[k] = make_uint4(((uint32_t)r[k] * 2654435761u) & 0x00070007u, 0x21u | (((uint32_t)r[k] & 3u) << 4), 0u, 0u);
-            else sp[k] = lo_.span[tid + k * BLOCK < n ? (uint32_t)r[k] : 0u];     // (index 0 is always readable)
-        }
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -540,11 +383,6 @@ __device__ __forceinline__ void sort_one_tile_bucket(uint64_t *s_key, uint32_t *
         if (tid == BLOCK - 1) s_bin[CAP] = run;
     }
     __syncthreads();
-    if (LISTS) {                                           // the span records have had three phases to arrive
-        const int tcx = tile % lo_.gx, tcy = tile / lo_.gx;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) km[k] = tid + k * BLOCK < n ? tile_block_mask(lo_, (uint32_t)r[k], sp[k], tcx, tcy) : 0u;
-    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int i = tid + k * BLOCK;
@@ -559,32 +397,6 @@ __device__ __forceinline__ void sort_one_tile_bucket(uint64_t *s_key, uint32_t *
             uint32_t less = 0;
             for (uint32_t p = b0; p < b1; ++p) less += s_key[p] < r[k] ? 1u : 0u;
             point_list[b64 + b0 + less] = (uint32_t)r[k];
-            if (LISTS) km[k] |= (b0 + less) << 16;           // (CAP <= 8192: 13 bits)
-        }
-    }
-    if (LISTS) {
-        // the sorted (index, mask) pairs take the place of the bucket-ordered keys, then every wavefront emits its blocks' lists
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = tid + k * BLOCK;
-            if (i < n) s_key[km[k] >> 16] = (uint64_t)(uint32_t)r[k] | ((uint64_t)(km[k] & 0xffffu) << 32);
-        }
-        __syncthreads();
-        const uint2 *s_ent = reinterpret_cast<const uint2 *>(s_key);
-        if (D3GA_SORT_ABL & 4) { if (tid < 16) lo_.blk_total[16 * (size_t)tile + tid] = 0u; }
-        else if (!D3GA_EMIT_STAGED)
-            emit_block_lists<16 / (BLOCK / 64), false>([&](int i) { return s_ent[i]; }, n, (uint32_t)(e64 - b64), lo_.blk_list + 16 * b64,
-                                                       lo_.blk_total + 16 * (size_t)tile, emit_first, emit_waves);
-        else {
-            // rings: 1 KB per list, 16 KB per workgroup -- the bucket counters' array is free now (CAP >= 4096: all of it fits there;
-            // CAP == 2048: the upper half of the wavefronts uses s_ring_hi)
-            constexpr int KB = 16 / (BLOCK / 64);
-            const int wave = tid >> 6;
-            uint2 *ring = reinterpret_cast<uint2 *>(s_bin) + 128 * KB * wave;
-            if (CAP < 4096 && wave >= BLOCK / 128) ring = s_ring_hi + 128 * KB * (wave - BLOCK / 128);
-            emit_block_lists_staged<KB>([&](int i) { return s_ent[i]; }, n, (uint32_t)(e64 - b64), lo_.blk_list + 16 * b64,
-                                        lo_.blk_total + 16 * (size_t)tile, emit_first, emit_waves, ring);
         }
     }
 }
@@ -686,27 +498,26 @@ __device__ __forceinline__ bool sort_huge_tile_bucket(uint64_t *s_key, uint32_t 
 // last) and stop at the first empty one; tiles with longer lists are left to the list-driven kernels below.  (Rounds 2-3
 // launched one workgroup per tile: at C3 6826 of the 8160 workgroups found an empty tile -- two dependent loads each while
 // holding a slot and 24 KB of LDS -- and took as long as the 1334 that sorted: 12.8 -> .. us.)
-template <int BLOCK, int CAP, bool LISTS>
+template <int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void tile_sort_lds_kernel(const uint32_t *__restrict__ start,
                                                               const uint64_t *__restrict__ keys,
                                                               uint32_t *__restrict__ point_list, uint64_t dcap,
-                                                              const uint32_t *__restrict__ order, int tiles, ListOut lo) {
+                                                              const uint32_t *__restrict__ order, int tiles) {
     __shared__ uint64_t s_key[CAP];
     __shared__ __attribute__((aligned(8))) uint32_t s_bin[CAP + 1];
-    __shared__ uint2 s_ring_hi[(LISTS && D3GA_EMIT_STAGED) ? 128 * 4 * (BLOCK / 128) : 1];     // (the list emission's rings of the upper wavefronts)
     __shared__ uint32_t s_red[2 * (BLOCK / 64)];
     for (int rank = blockIdx.x; rank < tiles; rank += gridDim.x) {
         const int tile = (int)order[rank];
         const uint32_t n = start[tile + 1] - start[tile];
         if (n == 0) return;                                  // (uniform) every later rank is empty as well
-        if (n <= (uint32_t)CAP) sort_one_tile_bucket<BLOCK, CAP, LISTS>(s_key, s_bin, s_red, tile, start, keys, point_list, dcap, lo, s_ring_hi);
+        if (n <= (uint32_t)CAP) sort_one_tile_bucket<BLOCK, CAP>(s_key, s_bin, s_red, tile, start, keys, point_list, dcap);
         __syncthreads();                                     // the LDS arrays are reused
     }
 }
 
 // persistent grid over a work list written by the scan workgroup of tile_scan_order_kernel (tiles whose list does not fit the kernel above);
 // dynamic LDS: CAP keys + CAP + 1 bucket counters (+ reduction scratch): 48 KB for 4096, 96 KB for 8192
-template <int BLOCK, int CAP, bool LISTS>
+template <int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_t *__restrict__ start,
                                                                    const uint64_t *__restrict__ keys,
                                                                    uint32_t *__restrict__ point_list, uint64_t dcap,
@@ -716,29 +527,23 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_
                                                                    const uint32_t *__restrict__ huge_list,
                                                                    const uint32_t *__restrict__ huge_count,
                                                                    const uint32_t *__restrict__ list2,
-                                                                   const uint32_t *__restrict__ list2_count, ListOut lo) {
+                                                                   const uint32_t *__restrict__ list2_count) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_key_dyn[];
     uint32_t *s_bin = reinterpret_cast<uint32_t *>(s_key_dyn + CAP);
     uint32_t *s_red = s_bin + CAP + 1;
     uint32_t *s_cur = s_red + 2 * (BLOCK / 64) + 2;              // huge lists only (the launch sizes the LDS accordingly)
-    // LISTS: a work list much shorter than the grid (1080p: a handful of tiles, 256 workgroups) is dealt R = 2 or 4 times -- R
-    // workgroups sort the SAME tile (identical stores) and each emits 16 / R of its block lists with 1 / R of its wavefronts, which
-    // then have their SIMD to themselves: one workgroup emitting all 16 lists of a 2345-entry tile added 10 us to this launch at C3
-    auto redundancy = [&](uint32_t c) { return !LISTS ? 1u : (4u * c <= gridDim.x ? 4u : (2u * c <= gridDim.x ? 2u : 1u)); };
-    const uint32_t count = *list_count, R1 = redundancy(count);
-    for (uint32_t v = blockIdx.x; v < count * R1; v += gridDim.x) {
+    const uint32_t count = *list_count;
+    for (uint32_t v = blockIdx.x; v < count; v += gridDim.x) {
         __syncthreads();
-        sort_one_tile_bucket<BLOCK, CAP, LISTS>(s_key_dyn, s_bin, s_red, (int)list[v / R1], start, keys, point_list, dcap, lo,
-                                                nullptr, (int)((v % R1) * (16u / R1)), (int)((BLOCK / 64) / R1));
+        sort_one_tile_bucket<BLOCK, CAP>(s_key_dyn, s_bin, s_red, (int)list[v], start, keys, point_list, dcap);
     }
-    // a second work list of a smaller class in the same launch (round 5: frames of up to 16384 tiles send the 2049..4096 class
+    // a second work list of a smaller class in the same launch (round 5: frames with few lists of the 2049..4096 class send them
     // through the 8192-key kernel instead of a launch of its own -- at C3 that launch sorted ONE list and the other found none)
     if (list2) {
-        const uint32_t count2 = *list2_count, R2 = redundancy(count2);
-        for (uint32_t v = gridDim.x - 1u - blockIdx.x; v < count2 * R2; v += gridDim.x) {      // (from the other end of the grid)
+        const uint32_t count2 = *list2_count;
+        for (uint32_t v = gridDim.x - 1u - blockIdx.x; v < count2; v += gridDim.x) {      // (from the other end of the grid)
             __syncthreads();
-            sort_one_tile_bucket<BLOCK, CAP, LISTS>(s_key_dyn, s_bin, s_red, (int)list2[v / R2], start, keys, point_list, dcap, lo,
-                                                    nullptr, (int)((v % R2) * (16u / R2)), (int)((BLOCK / 64) / R2));
+            sort_one_tile_bucket<BLOCK, CAP>(s_key_dyn, s_bin, s_red, (int)list2[v], start, keys, point_list, dcap);
         }
     }
     // lists that do not fit any LDS class (huge_list != null: same launch, saves a near-empty grid per frame): segmented
@@ -754,10 +559,6 @@ __global__ __launch_bounds__(BLOCK) void tile_sort_lds_list_kernel(const uint32_
             if (!sort_huge_tile_bucket<BLOCK, CAP>(s_key_dyn, s_bin, s_cur, s_red, tile, start, keys, point_list, dcap)) {
                 bitonic_sort(keys_rw + b64, n, tid, BLOCK);
                 for (int i = tid; i < n; i += BLOCK) point_list[b64 + i] = (uint32_t)keys_rw[b64 + i];
-            }
-            if (LISTS) {                                     // from the sorted list in HBM (this workgroup wrote it: barrier = its stores are done)
-                __syncthreads();
-                emit_block_lists_global<BLOCK / 64>(lo, tile, b64, n, (uint32_t)n, point_list);
             }
         }
     }
@@ -775,62 +576,40 @@ static inline size_t sort_lds_bytes(int cap, int block, bool huge = false) {    
 }
 
 
-// lists != null: the scatter writes block masks and the sort kernels emit the per-block lists into the img buffer
-static int bin_sort_impl(const d3ga_raster_params *prm, void *geom, void *binning, void *img, int64_t d_capacity, bool lists,
-                         d3ga_stream_t stream) {
+extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, void *binning, int64_t d_capacity,
+                                    d3ga_stream_t stream) {
     if (!prm || !geom || !binning) return D3GA_E_NULL;
     if (prm->P < 0 || prm->W <= 0 || prm->H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
-    if (lists && !img) return D3GA_E_NULL;
     hipStream_t s = (hipStream_t)stream;
+    // a batch of views is one tall frame for this stage: views x P records, views x tiles lists (d3ga.h: n_views)
+    const int views = n_views_of(prm);
     const int gx = tiles_x(prm->W);
-    const int tiles = gx * tiles_y(prm->H);
+    const int tiles = gx * tiles_y(prm->H) * views;
+    const int64_t P = (int64_t)prm->P * views;
     BinBuf bin = carve_bin(binning, tiles, d_capacity);
-    GeomBuf g = carve_geom(geom, prm->P);
-    ListOut lo = {nullptr, nullptr, nullptr, nullptr, nullptr, gx, false};
-    if (lists) {
-        const ImgBuf im = carve_img(img, prm->W, prm->H, tiles);
-        lo = ListOut{im.blk_list, im.blk_total, g.span, g.xyh, g.conic_o, gx, (composite_variant() & kVariantExactCull) != 0};
-    }
-    // A/B (D3GA_SORT_SMALL=4096): the per-tile kernel with 512 threads and 4096 keys -- no 2049..4096 class (at C3 the list launch
-    // then finds nothing to do)
-    static const int small_env = [] { const char *e = getenv("D3GA_SORT_SMALL"); return e ? atoi(e) : 0; }();
-    const bool small4k = small_env == 4096 && !lists;
+    GeomBuf g = carve_geom(geom, P);
     hipLaunchKernelGGL(tile_scan_order_kernel, dim3(2), dim3(kScanBlock), 0, s, tiles, bin.tile_count, bin.tile_start,
                        bin.tile_cursor, bin.counters, (uint64_t)d_capacity, bin.big_tiles, bin.huge_tiles, bin.mid_tiles,
-                       (uint32_t)(small4k ? kSortMid : kSortSmall), (uint32_t)kSortMid, (uint32_t)kSortLarge, bin.tile_order);
+                       (uint32_t)kSortSmall, (uint32_t)kSortMid, (uint32_t)kSortLarge, bin.tile_order);
     D3GA_TRY(check_launch(s, prm->debug));
-    if (prm->P == 0 || d_capacity == 0) return D3GA_OK;
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, prm->P, gx, g.rect,
+    if (P == 0 || d_capacity == 0) return D3GA_OK;
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3((unsigned)((P + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, (int)P, gx, g.rect,
                        g.depth, bin.tile_cursor, bin.keys, (uint64_t)d_capacity);
     D3GA_TRY(check_launch(s, prm->debug));
     {
-        static int resident[64][2] = {};                     // per device: workgroups of the per-tile sort the chip holds at once
+        static std::atomic<int> resident[64] = {};           // per device: workgroups of the per-tile sort the chip holds at once (a cache of two queries)
         int dev = 0;
         D3GA_HIP(hipGetDevice(&dev));
-        int want = (dev >= 0 && dev < 64) ? resident[dev][lists ? 1 : 0] : 0;
+        int want = (dev >= 0 && dev < 64) ? resident[dev].load(std::memory_order_relaxed) : 0;
         if (want == 0) {
             int per_cu = 0, cus = 0;
-            const void *fn = lists ? (const void *)tile_sort_lds_kernel<256, kSortSmall, true> : (const void *)tile_sort_lds_kernel<256, kSortSmall, false>;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)tile_sort_lds_kernel<256, kSortSmall>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
             want = per_cu * cus;
-            if (dev >= 0 && dev < 64) resident[dev][lists ? 1 : 0] = want;
+            if (dev >= 0 && dev < 64) resident[dev].store(want, std::memory_order_relaxed);
         }
-        if (small4k) {
-            static int want4k = 0;
-            if (want4k == 0) {
-                int per_cu = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)tile_sort_lds_kernel<512, kSortMid, false>, 512, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-                want4k = per_cu * 256;
-            }
-            hipLaunchKernelGGL((tile_sort_lds_kernel<512, kSortMid, false>), dim3(tiles < want4k ? tiles : want4k), dim3(512), 0, s, bin.tile_start,
-                               bin.keys, bin.point_list, (uint64_t)d_capacity, (const uint32_t *)bin.tile_order, tiles, lo);
-        } else if (lists)
-            hipLaunchKernelGGL((tile_sort_lds_kernel<256, kSortSmall, true>), dim3(tiles < want ? tiles : want), dim3(256), 0, s, bin.tile_start,
-                               bin.keys, bin.point_list, (uint64_t)d_capacity, (const uint32_t *)bin.tile_order, tiles, lo);
-        else
-            hipLaunchKernelGGL((tile_sort_lds_kernel<256, kSortSmall, false>), dim3(tiles < want ? tiles : want), dim3(256), 0, s, bin.tile_start,
-                               bin.keys, bin.point_list, (uint64_t)d_capacity, (const uint32_t *)bin.tile_order, tiles, lo);
+        hipLaunchKernelGGL((tile_sort_lds_kernel<256, kSortSmall>), dim3(tiles < want ? tiles : want), dim3(256), 0, s, bin.tile_start,
+                           bin.keys, bin.point_list, (uint64_t)d_capacity, (const uint32_t *)bin.tile_order, tiles);
     }
     D3GA_TRY(check_launch(s, prm->debug));
     // longer lists: persistent grids driven by the device-side work lists (empty for avatar-sized scenes), 256 workgroups each.
@@ -839,54 +618,38 @@ static int bin_sort_impl(const d3ga_raster_params *prm, void *geom, void *binnin
     // (... and running the two list kernels on a side stream beside the per-tile kernel -- fork / join events, parallel graph
     // branches under capture: the events cost more than the overlap saves, bin+sort 49 -> 64 us eager, step 0.409 -> 0.422 ms.)
     {   // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (function attributes are per device)
-        static bool attr_set[64] = {};
+        static std::atomic<bool> attr_set[64] = {};
         int dev = 0;
         D3GA_HIP(hipGetDevice(&dev));
-        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            D3GA_HIP(hipFuncSetAttribute((const void *)tile_sort_lds_list_kernel<1024, kSortLarge, false>,
+        if (dev >= 0 && dev < 64 && !attr_set[dev].load(std::memory_order_relaxed)) {
+            D3GA_HIP(hipFuncSetAttribute((const void *)tile_sort_lds_list_kernel<1024, kSortLarge>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(kSortLarge, 1024, true)));
-            D3GA_HIP(hipFuncSetAttribute((const void *)tile_sort_lds_list_kernel<1024, kSortLarge, true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(kSortLarge, 1024, true)));
-            attr_set[dev] = true;
+            attr_set[dev].store(true, std::memory_order_relaxed);
         }
     }
     // (48 KB of LDS: three workgroups of the 2049..4096 class fit a CU -- at 4K with 2M Gaussians thousands of tiles are in it;
     //  96 KB: one workgroup of the larger class per CU)
     const int lgrid = tiles < 256 ? tiles : 256, mgrid = tiles < 768 ? tiles : 768;
-    // Round 5: ONE list launch for frames of up to 16384 tiles (1080p: 8160): the 2049..4096 class rides in the 8192-key kernel (one
-    // workgroup of 1024 threads per CU instead of three of 512 -- for a handful of such lists that is no loss, and a launch that
-    // finds an empty work list still costs 4-5 us of a frame).  Larger frames (4K with millions of Gaussians: thousands of tiles
-    // in the mid class) keep the launch of their own.  D3GA_SORT_MERGE=0/1 overrides.
-    static const int merge_env = [] { const char *e = getenv("D3GA_SORT_MERGE"); return e ? atoi(e) : -1; }();
-    const bool merged = merge_env >= 0 ? merge_env != 0 : tiles <= 16384;
-#define D3GA_LAUNCH_LIST_SORT(BLOCKV, CAPV, LISTSV, GRID, HUGE, LIST, CNT, KEYS_RW, HLIST, HCNT, LIST2, CNT2)                              \
-    hipLaunchKernelGGL((tile_sort_lds_list_kernel<BLOCKV, CAPV, LISTSV>), dim3(GRID), dim3(BLOCKV), sort_lds_bytes(CAPV, BLOCKV, HUGE), s, \
-                       bin.tile_start, bin.keys, bin.point_list, (uint64_t)d_capacity, LIST, CNT, KEYS_RW, HLIST, HCNT, LIST2, CNT2, lo)
+    // ONE list launch when few lists of the 2049..4096 class are expected: they ride in the 8192-key kernel (one workgroup of 1024
+    // threads per CU instead of three of 512 -- for a handful of such lists that is no loss, and a launch that finds an empty work
+    // list still costs 4-5 us of a frame).  "Few" is decided from what the host knows without a read-back: the mean list length over
+    // ALL tiles of the frame, d_capacity / tiles (the capacity tracks the duplicate count: its high-water mark + 25 %).  An avatar
+    // frame at 1080p (C3: 2.1 M / 8160 = 255) has a handful of mid-class lists; a dense scene -- millions of Gaussians at 1080p, or
+    // C5's 4K frame (13 M / 32 400 = 400, thousands of tiles in the class) -- keeps the launch of its own, three workgroups per CU
+    // (the tile count alone sent a dense 1080p scene through the one-workgroup-per-CU kernel).  D3GA_KNOB_SORT_MERGE overrides.
+    const int merge_knob = debug_knob(D3GA_KNOB_SORT_MERGE);
+    const bool merged = merge_knob >= 0 ? merge_knob != 0 : d_capacity / (tiles > 0 ? tiles : 1) < 320;
+#define D3GA_LAUNCH_LIST_SORT(BLOCKV, CAPV, GRID, HUGE, LIST, CNT, KEYS_RW, HLIST, HCNT, LIST2, CNT2)                              \
+    hipLaunchKernelGGL((tile_sort_lds_list_kernel<BLOCKV, CAPV>), dim3(GRID), dim3(BLOCKV), sort_lds_bytes(CAPV, BLOCKV, HUGE), s, \
+                       bin.tile_start, bin.keys, bin.point_list, (uint64_t)d_capacity, LIST, CNT, KEYS_RW, HLIST, HCNT, LIST2, CNT2)
     const uint32_t *const nil = nullptr;
     if (!merged) {
-        if (lists) D3GA_LAUNCH_LIST_SORT(512, kSortMid, true, mgrid, false, bin.mid_tiles, bin.counters + D3GA_CNT_MID, (uint64_t *)nullptr, nil, nil, nil, nil);
-        else D3GA_LAUNCH_LIST_SORT(512, kSortMid, false, mgrid, false, bin.mid_tiles, bin.counters + D3GA_CNT_MID, (uint64_t *)nullptr, nil, nil, nil, nil);
+        D3GA_LAUNCH_LIST_SORT(512, kSortMid, mgrid, false, bin.mid_tiles, bin.counters + D3GA_CNT_MID, (uint64_t *)nullptr, nil, nil, nil, nil);
         D3GA_TRY(check_launch(s, prm->debug));
     }
     const uint32_t *l2 = merged ? (const uint32_t *)bin.mid_tiles : nil, *c2 = merged ? (const uint32_t *)(bin.counters + D3GA_CNT_MID) : nil;
-    if (lists) D3GA_LAUNCH_LIST_SORT(1024, kSortLarge, true, lgrid, true, bin.big_tiles, bin.counters + D3GA_CNT_BIG, bin.keys,
-                                     (const uint32_t *)bin.huge_tiles, (const uint32_t *)(bin.counters + D3GA_CNT_HUGE), l2, c2);
-    else D3GA_LAUNCH_LIST_SORT(1024, kSortLarge, false, lgrid, true, bin.big_tiles, bin.counters + D3GA_CNT_BIG, bin.keys,
-                               (const uint32_t *)bin.huge_tiles, (const uint32_t *)(bin.counters + D3GA_CNT_HUGE), l2, c2);
+    D3GA_LAUNCH_LIST_SORT(1024, kSortLarge, lgrid, true, bin.big_tiles, bin.counters + D3GA_CNT_BIG, bin.keys,
+                          (const uint32_t *)bin.huge_tiles, (const uint32_t *)(bin.counters + D3GA_CNT_HUGE), l2, c2);
 #undef D3GA_LAUNCH_LIST_SORT
     return check_launch(s, prm->debug);
-}
-
-extern "C" int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, void *binning, int64_t d_capacity,
-                                    d3ga_stream_t stream) {
-    return bin_sort_impl(prm, geom, binning, nullptr, d_capacity, false, stream);
-}
-
-extern "C" int d3ga_raster_bin_sort_lists(const d3ga_raster_params *prm, void *geom, void *binning, void *img, int64_t d_capacity,
-                                          int32_t *lists_written, d3ga_stream_t stream) {
-    if (!prm || !lists_written) return D3GA_E_NULL;
-    // the lists are emitted for renders a backward will follow, when the library's forward is the one that walks them (D3GA_FWD_IMPL=2)
-    const bool lists = !prm->forward_only && composite_fwd_impl_kind() == 2;
-    *lists_written = lists ? 1 : 0;
-    return bin_sort_impl(prm, geom, binning, img, d_capacity, lists, stream);
 }

@@ -18,8 +18,6 @@
 // Dispatch: quad_of_block_ordered() hands the quadrants out heaviest tile first (tile_order of the bin stage), the four
 // quadrants of a tile on one XCD (workgroup b lands on XCD b % 8: observed, speed only).
 // Numbers, history and the negative results (persistent workers, dispatch orders, occupancy): DESIGN.md sec. 4.
-#include <stdlib.h>
-
 #include "composite_common.h"
 
 // wavefronts per SIMD the register budget of the two-stage forward targets (A/B: build.py D3GA_SCAN_ABL=0f6)
@@ -55,14 +53,14 @@ __device__ unsigned long long g_diag_fwd_waves[32768 * 4];    // per active wave
 // L1V: the L1 loss value against a target image is formed here as well (d3ga_raster_composite_fwd_l1; never with DUAL)
 template <bool DUAL, bool DEPTH, bool L1V>
 __global__ __launch_bounds__(64, (DUAL ? D3GA_FWD_DUAL_WAVES : D3GA_FWD_WAVES)) void composite_fwd_q_kernel(
-    int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+    int W, int H, int gx, int gy, int gyv /* tile rows per view (= gy for one view) */, const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
     uint64_t dcap, const float2 *xy /* = xyh viewed as float2: the centre is record[0..1], stride 2 (round 4: no separate xy array) */, const float4 *__restrict__ conic_o,
     const float4 *__restrict__ rgb_invd, const float4 *xyh, const float *__restrict__ bg,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
     float *__restrict__ out_invdepth, const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2,
     const float *__restrict__ bg2, float *__restrict__ out_color2, uint2 *__restrict__ blk_list,
     uint32_t *__restrict__ blk_count, bool exact_cull, L1Value l1v) {
-    const Quad q = tile_order ? quad_of_block_ordered(gx, gx * gy, tile_order) : quad_of_block(gx, gy);
+    const Quad q = tile_order ? quad_of_block_ordered(gx, gx * gy, gyv, tile_order) : quad_of_block(gx, gy, gyv);
     if (!q.valid) return;                                 // wave-uniform
     if (q.qx0 >= W || q.qy0 >= H) {                       // a quadrant without pixels: its L1 partial is zero
         if (L1V && threadIdx.x == 0) l1v.partials[4 * (size_t)q.tile + q.quad] = 0.f;
@@ -83,7 +81,7 @@ __global__ __launch_bounds__(64, (DUAL ? D3GA_FWD_DUAL_WAVES : D3GA_FWD_WAVES)) 
     float tg0 = 0.f, tg1 = 0.f, tg2 = 0.f;
     if (L1V && inside) {
         const float *tg = l1v.target_cell ? *l1v.target_cell : l1v.target;
-        const size_t pid = (size_t)rg.py * W + rg.px, hw = (size_t)H * W;
+        const size_t hw = (size_t)H * W, pid = 3 * hw * q.view + (size_t)rg.py * W + rg.px;
         tg0 = tg[pid]; tg1 = tg[hw + pid]; tg2 = tg[2 * hw + pid];
     }
     uint2 *const blk_base = blk_list ? blk_list + 16 * (size_t)begin + (size_t)(4 * q.quad) * blk_cap : nullptr;
@@ -322,14 +320,14 @@ __global__ __launch_bounds__(64, (DUAL ? D3GA_FWD_DUAL_WAVES : D3GA_FWD_WAVES)) 
         if (lane == 0) l1v.partials[4 * (size_t)q.tile + q.quad] = d * l1v.inv_n;
     }
     if (inside) {
-        const size_t pid = (size_t)rg.py * W + rg.px;
         const size_t hw = (size_t)H * W;
-        final_T[pid] = T;
-        n_contrib[pid] = last;
+        const size_t pid1 = hw * q.view + (size_t)rg.py * W + rg.px, pid = pid1 + 2 * hw * q.view;      // one-plane / three-plane images of the view
+        final_T[pid1] = T;
+        n_contrib[pid1] = last;
         out_color[pid] = C0 + T * bg[0];
         out_color[hw + pid] = C1 + T * bg[1];
         out_color[2 * hw + pid] = C2 + T * bg[2];
-        if constexpr (DEPTH) out_invdepth[pid] = Dp;
+        if constexpr (DEPTH) out_invdepth[pid1] = Dp;
         if constexpr (DUAL) {
             out_color2[pid] = E0 + T * bg2[0];
             out_color2[hw + pid] = E1 + T * bg2[1];
@@ -411,21 +409,19 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
     if (!prm || !bg || !geom || !binning || !img || !out_color) return D3GA_E_NULL;
     if (prm->P < 0 || prm->W <= 0 || prm->H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
     if (colors2 && (!bg2 || !out_color2)) return D3GA_E_NULL;
+    const int views = n_views_of(prm);
+    if (colors2 && views > 1) return D3GA_E_CONFIG;        // the second colour set is indexed by Gaussian, not by (view, Gaussian)
     hipStream_t s = (hipStream_t)stream;
-    const int gx = tiles_x(prm->W), gy = tiles_y(prm->H);
+    const int gx = tiles_x(prm->W), gyv = tiles_y(prm->H), gy = gyv * views;
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
-    const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
-    ImgBuf im = carve_img(img, prm->W, prm->H, (int64_t)gx * gy);
+    const GeomBuf g = carve_geom(const_cast<void *>(geom), (int64_t)prm->P * views);
+    ImgBuf im = carve_img(img, prm->W, prm->H, (int64_t)gx * gy, views);
     if (prm->forward_only) { im.blk_list = nullptr; im.blk_count = nullptr; }     // the buffer ends behind n_contrib
     const bool ordered = (composite_variant() & kVariantOrdered) != 0, exact = (composite_variant() & kVariantExactCull) != 0;
-    if (!prm->forward_only && composite_fwd_impl_kind() != 0)          // (round 5) the blend over explicit block lists (raster_composite_lists.hip):
-        return launch_composite_fwd_lists(prm, gx, gy, bin, g, im, d_capacity, bg, out_color, out_invdepth, colors2, bg2, out_color2,      // emitted by the sort
-                                          ordered, exact, l1v, composite_fwd_impl_kind() == 2 && prm->block_lists != 0, s);                // (block_lists) or built here
     const dim3 grid(ordered ? quad_grid_ordered(gx * gy) : quad_grid(gx, gy));
     const uint32_t *order = ordered ? (const uint32_t *)bin.tile_order : (const uint32_t *)nullptr;
 #define D3GA_LAUNCH_FWD(DUALV, DEPTHV, L1VV)                                                                                    \
-    hipLaunchKernelGGL((composite_fwd_q_kernel<DUALV, DEPTHV, L1VV>), grid, dim3(64),                                               \
-                       lds_pad_bytes((const void *)composite_fwd_q_kernel<DUALV, DEPTHV, L1VV>, "D3GA_FWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
+    hipLaunchKernelGGL((composite_fwd_q_kernel<DUALV, DEPTHV, L1VV>), grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, gyv, bin.tile_start, \
                        bin.point_list, (uint64_t)d_capacity, reinterpret_cast<const float2 *>(g.xyh), g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,     \
                        out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact, l1v)
     if (colors2 && l1v.partials) return D3GA_E_CONFIG;
@@ -448,10 +444,11 @@ extern "C" int d3ga_raster_composite_fwd_l1(const d3ga_raster_params *prm, const
                                             float *loss, float *partials, d3ga_stream_t stream) {
     if (!prm || !loss || !partials || (!target && !target_cell)) return D3GA_E_NULL;
     if (prm->W <= 0 || prm->H <= 0) return D3GA_E_SIZE;
-    const L1Value l1v = {target, (const float *const *)target_cell, partials, 1.0f / (3.0f * (float)prm->W * (float)prm->H)};
+    const int views = n_views_of(prm);
+    const L1Value l1v = {target, (const float *const *)target_cell, partials, 1.0f / (3.0f * (float)prm->W * (float)prm->H * (float)views)};
     D3GA_TRY(composite_fwd_impl(prm, bg, geom, binning, d_capacity, img, out_color, out_invdepth, nullptr, nullptr, nullptr,
                                 stream, l1v));
-    launch_sum_partials(4 * tiles_x(prm->W) * tiles_y(prm->H), partials, loss, (hipStream_t)stream);
+    launch_sum_partials(4 * tiles_x(prm->W) * tiles_y(prm->H) * views, partials, loss, (hipStream_t)stream);
     return check_launch((hipStream_t)stream, prm->debug);
 }
 
@@ -474,10 +471,12 @@ static int composite_bwd_impl(const d3ga_raster_params *prm, const float *bg, co
     if (!dL_dpix && !l1.image && !dL_dinvd) return D3GA_E_NULL;        // some incoming gradient: an image, the fused L1 term, the inverse depth
     if (l1.image && (!(l1.target || l1.target_cell) || !l1.g_loss)) return D3GA_E_NULL;
     if (colors2 && (!bg2 || !dL_dpix2)) return D3GA_E_NULL;
-    const int gx = tiles_x(prm->W), gy = tiles_y(prm->H);
+    const int views = n_views_of(prm);
+    if (colors2 && views > 1) return D3GA_E_CONFIG;
+    const int gx = tiles_x(prm->W), gy = tiles_y(prm->H) * views;
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
-    const GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
-    const ImgBuf im = carve_img(const_cast<void *>(img), prm->W, prm->H, (int64_t)gx * gy);
+    const GeomBuf g = carve_geom(const_cast<void *>(geom), (int64_t)prm->P * views);
+    const ImgBuf im = carve_img(const_cast<void *>(img), prm->W, prm->H, (int64_t)gx * gy, views);
     return launch_composite_bwd_scan(prm, gx, gy, bin, g, im, d_capacity, bg, dL_dpix, acc,
                                      (composite_variant() & kVariantOrdered) != 0, colors2, bg2, dL_dpix2, l1, (hipStream_t)stream, dL_dinvd);
 }
@@ -512,6 +511,6 @@ extern "C" int d3ga_raster_composite_bwd_l1(const d3ga_raster_params *prm, const
                                             const float *dL_dpix, float *acc, d3ga_stream_t stream) {
     if (!prm) return D3GA_E_NULL;
     if (!image) return D3GA_E_NULL;
-    const L1Source l1 = {image, target, (const float *const *)target_cell, g_loss, 1.0f / (3.0f * (float)prm->W * (float)prm->H)};
+    const L1Source l1 = {image, target, (const float *const *)target_cell, g_loss, 1.0f / (3.0f * (float)prm->W * (float)prm->H * (float)n_views_of(prm))};
     return composite_bwd_impl(prm, bg, geom, binning, d_capacity, img, dL_dpix, acc, nullptr, nullptr, nullptr, l1, stream);
 }

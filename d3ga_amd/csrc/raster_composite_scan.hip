@@ -117,7 +117,7 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 // Everything the per-tile work of one wavefront reads (the kernels' pointer arguments, by value).
 struct BwdArgs {
-    int W, H, gx;
+    int W, H, gx, gyv;       // gyv: tile rows per view (view-batched launches: composite_common.h, Quad)
     const float2 *xy; const float4 *conic_o; const float4 *rgb_invd; const float *bg; const float *final_T; const uint32_t *n_contrib;
     const float *dL_dpix; float *acc; const float *colors2; const float *bg2; const float *dL_dpix2; const uint2 *blk_list;
     const uint32_t *blk_count; L1Source l1; const float *dL_dinvd;
@@ -142,13 +142,15 @@ __device__ __forceinline__ void bwd_tile_wave(const BwdArgs &A, const int tile, 
     const int fk_off = fk < 2 ? fk : fk + 1;               // acc layout 0,1 | 3,4,5 | 6 | 7,8,9 | 10 (dL/d(1/depth), INVD)
     constexpr int kAccStride = D3GA_ACC_STRIDE;
     const int bx = 2 * ((blk >> 2) & 1) + (blk & 1), by = 2 * (blk >> 3) + ((blk >> 1) & 1);      // the forward numbers a tile's blocks 4 * quadrant + (block within the quadrant)
-    const int bx0 = (tile % A.gx) * kTile + 4 * bx, by0 = (tile / A.gx) * kTile + 4 * by;      // block origin in pixels
+    const int tyb = tile / A.gx, view = tyb / A.gyv;                                          // tile row of the batch -> (view, row of the view)
+    const int bx0 = (tile - tyb * A.gx) * kTile + 4 * bx, by0 = (tyb - view * A.gyv) * kTile + 4 * by;      // block origin in pixels (local to the view)
     const int px = bx0 + (l16 & 3), py = by0 + (l16 >> 2);
     const bool inside = px < A.W && py < A.H;
-    const size_t pid = (size_t)py * A.W + px;
     const size_t hw = (size_t)A.H * A.W;
-    const float T_final = inside ? A.final_T[pid] : 0.f;
-    const uint32_t last = inside ? A.n_contrib[pid] : 0u;
+    const size_t pid1 = hw * view + (size_t)py * A.W + px;       // one-plane images (final_T, n_contrib, inverse depth) of the view
+    const size_t pid = pid1 + 2 * hw * view;                     // three-plane images
+    const float T_final = inside ? A.final_T[pid1] : 0.f;
+    const uint32_t last = inside ? A.n_contrib[pid1] : 0u;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (inside && A.dL_dpix) { g0 = A.dL_dpix[pid]; g1 = A.dL_dpix[hw + pid]; g2 = A.dL_dpix[2 * hw + pid]; }
     if (inside && A.l1.image) {
@@ -176,7 +178,7 @@ __device__ __forceinline__ void bwd_tile_wave(const BwdArgs &A, const int tile, 
         float *rec = pixrow + l16 * PIXF;
         *reinterpret_cast<float4 *>(rec) = make_float4(T_final, 0.f, g0, g1);
         float gd = 0.f;
-        if constexpr (INVD) gd = inside ? A.dL_dinvd[pid] : 0.f;
+        if constexpr (INVD) gd = inside ? A.dL_dinvd[pid1] : 0.f;
         *reinterpret_cast<float4 *>(rec + 4) = make_float4(g2, T_final * bg_dot, __uint_as_float(last), gd);
         if constexpr (DUAL) *reinterpret_cast<float4 *>(rec + 8) = make_float4(h0, h1, h2, 0.f);
     }
@@ -398,7 +400,7 @@ __device__ __forceinline__ void bwd_tile_wave(const BwdArgs &A, const int tile, 
 // the groups: the critical path of a heavy tile (18 groups of one wavefront at C3) shrinks with it.
 template <bool DUAL, int S, bool INVD = false, int R = 1>
 __global__ __launch_bounds__(256 * R, D3GA_TILE_WAVES) void composite_bwd_tile_kernel(
-    int W, int H, int gx, int gy, const uint32_t *__restrict__ tile_start, uint64_t dcap, const float2 *__restrict__ xy,
+    int W, int H, int gx, int gy, int gyv, const uint32_t *__restrict__ tile_start, uint64_t dcap, const float2 *__restrict__ xy,
     const float4 *__restrict__ conic_o, const float4 *__restrict__ rgb_invd, const float *__restrict__ bg,
     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
     float *__restrict__ acc, const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2,
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(256 * R, D3GA_TILE_WAVES) void composite_bwd_tile_k
     __shared__ uint8_t s_perm[16];                          // assign 2: the tile's 16 blocks by descending list length
     if (R > 1 || half >= 0) assign = 2;                     // (the quadrant / interleaved assignments exist for R = 1 only)
     if (assign == 2 && threadIdx.x < 16) {
-        const int b = threadIdx.x, tx0 = (tile % gx) * kTile, ty0 = (tile / gx) * kTile;
+        const int b = threadIdx.x, tx0 = (tile % gx) * kTile, ty0 = ((tile / gx) % gyv) * kTile;
         auto count_of = [&](int j) -> uint32_t {            // (the forward writes the counts of quadrants that start inside the image)
             const int q = j >> 2;
             return (tx0 + ((q & 1) << 3) < W && ty0 + ((q >> 1) << 3) < H) ? blk_count[16 * (size_t)tile + j] : 0u;
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256 * R, D3GA_TILE_WAVES) void composite_bwd_tile_k
             const int by = assign ? 2 * (row >> 1) + (wave >> 1) : 2 * (wave >> 1) + (row >> 1);
             blk = 4 * ((bx >> 1) + 2 * (by >> 1)) + ((bx & 1) + 2 * (by & 1));
         }
-        const BwdArgs A = {W, H, gx, xy, conic_o, rgb_invd, bg, final_T, n_contrib, dL_dpix, acc, colors2, bg2, dL_dpix2, blk_list, blk_count, l1, dL_dinvd};
+        const BwdArgs A = {W, H, gx, gyv, xy, conic_o, rgb_invd, bg, final_T, n_contrib, dL_dpix, acc, colors2, bg2, dL_dpix2, blk_list, blk_count, l1, dL_dinvd};
         if (R == 1 && half >= 0) {
             blk = s_perm[2 * (2 * ((wave + (int)blockIdx.x) & 3) + (lane >> 5)) + half];
             bwd_tile_wave<DUAL, S, INVD, (R == 1 ? 2 : R)>(A, tile, begin, end, blk, s_cache, s_pix, s_dump, lane, dg);
@@ -565,7 +567,7 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
     const int S = composite_merge_slots();
 #define D3GA_LAUNCH_TILE_R(DUALV, SV, INVDV, RV)                                                                              \
     hipLaunchKernelGGL((composite_bwd_tile_kernel<DUALV, SV, INVDV, RV>), tgrid, dim3(256 * RV),                                \
-                       lds_pad_bytes((const void *)composite_bwd_tile_kernel<DUALV, SV, INVDV, RV>, "D3GA_BWD_LDS_TOTAL"), s, prm->W, prm->H, gx, gy, bin.tile_start, \
+                       0, s, prm->W, prm->H, gx, gy, gy / n_views_of(prm), bin.tile_start, \
                        (uint64_t)d_capacity, reinterpret_cast<const float2 *>(g.xyh), g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc, order,   \
                        colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, composite_tile_assign(), l1, dL_dinvd, split_cap, split_cnt)
 #define D3GA_LAUNCH_TILE(DUALV, SV, INVDV)                                                                                    \
@@ -596,21 +598,6 @@ __global__ void row_scan_selftest_kernel(const float *__restrict__ in, float *__
 }
 
 }  // namespace d3ga
-
-// What this build of the library runs by default (and with the current environment): see include/d3ga.h.
-extern "C" int d3ga_debug_defaults(int32_t out[8]) {
-    if (!out) return D3GA_E_NULL;
-    out[0] = D3GA_SCAN_ABL;                     // != 0: a timing ablation -- results are WRONG by design (_lib.py refuses it)
-#ifdef D3GA_DIAG
-    out[1] = 1;
-#else
-    out[1] = 0;
-#endif
-    out[2] = d3ga::kDefaultCompositeVariant; out[3] = d3ga::composite_variant();
-    out[4] = d3ga::kDefaultMergeSlots;       out[5] = d3ga::composite_merge_slots();
-    out[6] = d3ga::kDefaultTileAssign;       out[7] = d3ga::composite_tile_assign();
-    return D3GA_OK;
-}
 
 extern "C" int d3ga_selftest_row_scan(int n, const float *in, float *out, d3ga_stream_t stream) {
     if (n <= 0 || (n % 256) != 0) return D3GA_E_SIZE;

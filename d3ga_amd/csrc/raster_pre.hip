@@ -34,7 +34,7 @@ __device__ __forceinline__ bool sh_staged(int M) { return M > 0 && (3 * M) % 4 =
 #define D3GA_DCOL_PLANAR 1
 #endif
 #if D3GA_DCOL_PLANAR
-#define D3GA_DCOL_AT(base, i, k, P) ((base)[(size_t)(k) * (size_t)(P) + (size_t)(i)])
+#define D3GA_DCOL_AT(base, i, k, P) ((base)[(size_t)(k) * (size_t)(P) + (size_t)(i)])       /* P: the planes' stride (GeomBuf::dcol_stride) */
 #else
 #define D3GA_DCOL_AT(base, i, k, P) ((base)[9 * (size_t)(i) + (k)])
 #endif
@@ -172,7 +172,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     const float *__restrict__ colors_precomp, const float *__restrict__ opacities, const float *__restrict__ scales,
     const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, const float *__restrict__ viewmatrix,
     const float *__restrict__ projmatrix, const float *__restrict__ campos, GeomBuf geom,
-    uint32_t *__restrict__ tile_count, uint32_t *__restrict__ counters, int32_t *__restrict__ radii, int exact_cull) {
+    uint32_t *__restrict__ tile_count, uint32_t *__restrict__ counters, int32_t *__restrict__ radii,
+    int tile_row0 /* view-batched renders: this view's first tile row in the batch's grid (d3ga.h: n_views); else 0 */) {
     if (!(prm.tanfovx > 0.f)) { prm.tanfovx = campos[3]; prm.tanfovy = campos[4]; }     // camera slot: see d3ga.h
     // one dynamic LDS region, used first as the SH staging slabs and then (after a barrier) as the tile window
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -225,27 +226,23 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
         radii[i] = sp.radius;
         geom.depth[i] = sp.depth;
         // culled Gaussians keep an EMPTY rectangle: the scatter pass and the backward test visibility through it
-        geom.rect[i] = sp.visible ? make_uint2((uint32_t)sp.rect[0] | ((uint32_t)sp.rect[1] << 16),
-                                               (uint32_t)sp.rect[2] | ((uint32_t)sp.rect[3] << 16))
+        geom.rect[i] = sp.visible ? make_uint2((uint32_t)sp.rect[0] | ((uint32_t)(sp.rect[1] + tile_row0) << 16),
+                                               (uint32_t)sp.rect[2] | ((uint32_t)(sp.rect[3] + tile_row0) << 16))
                                   : make_uint2(0u, 0u);
         geom.conic_o[i] = make_float4(sp.conic[0], sp.conic[1], sp.conic[2], o.opacity);
         {   // half extents of the splat's alpha >= 1/255 box, by the function the compositing stage culls with (bit-identical)
             const SplatCull sc = splat_cull(sp.conic[0], sp.conic[1], sp.conic[2], o.opacity);
             geom.xyh[i] = make_float4(sp.px, sp.py, sp.visible ? sc.hx : -1.0f, sc.hy);
-            // round 5: the blocks the splat can touch, one column interval per block line (tile_cull_kernel decodes it per tile)
-            if (exact_cull >= 0)                  // (uniform; < 0: nobody reads span records -- the one-launch forward, the default)
-                geom.span[i] = sp.visible ? splat_spans(sp.px, sp.py, sp.conic[0], sp.conic[1], sp.conic[2], o.opacity, exact_cull != 0)
-                                          : make_uint4(0u, 0u, 0u, 0u);
         }
         geom.rgb_invd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], sp.visible ? 1.0f / sp.depth : 0.f);
         geom.clamped[i] = o.clampmask;
         if (want_j) {
             const float jv[9] = {cj.j0, cj.j1, cj.j2, cj.j3, cj.j4, cj.j5, cj.j6, cj.j7, cj.j8};
 #pragma unroll
-            for (int k = 0; k < 9; ++k) D3GA_DCOL_AT(geom.dcol, i, k, prm.P) = jv[k];
+            for (int k = 0; k < 9; ++k) D3GA_DCOL_AT(geom.dcol, i, k, geom.dcol_stride) = jv[k];
         }
         visible = sp.visible;
-        r0 = sp.rect[0]; r1 = sp.rect[1]; r2 = sp.rect[2]; r3 = sp.rect[3];
+        r0 = sp.rect[0]; r1 = sp.rect[1] + tile_row0; r2 = sp.rect[2]; r3 = sp.rect[3] + tile_row0;
     }
 #ifdef D3GA_DIAG
     if (prm.debug & 0x100) return;                                              // diag: no histogram
@@ -298,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void recolor_kernel(d3ga_raster_params prm,
         acc[0] = cj.a0; acc[1] = cj.a1; acc[2] = cj.a2;
         const float jv[9] = {cj.j0, cj.j1, cj.j2, cj.j3, cj.j4, cj.j5, cj.j6, cj.j7, cj.j8};
 #pragma unroll
-        for (int k = 0; k < 9; ++k) D3GA_DCOL_AT(dst.dcol, i, k, prm.P) = jv[k];
+        for (int k = 0; k < 9; ++k) D3GA_DCOL_AT(dst.dcol, i, k, dst.dcol_stride) = jv[k];
     }
     const uint2 rc = src.rect[i];
     const bool visible = ((rc.y & 0xffffu) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.x >> 16));
@@ -306,7 +303,6 @@ __global__ __launch_bounds__(kBlock) void recolor_kernel(d3ga_raster_params prm,
     dst.depth[i] = depth;
     dst.conic_o[i] = src.conic_o[i];
     dst.xyh[i] = src.xyh[i];
-    dst.span[i] = src.span[i];
     dst.rect[i] = rc;
 #pragma unroll
     for (int k = 0; k < 6; ++k) dst.cov3D[6 * (size_t)i + k] = src.cov3D[6 * (size_t)i + k];
@@ -341,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const float *__restrict__ acc, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
     float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors,
     float *__restrict__ dL_dcov3D, float *__restrict__ dL_dscales, float *__restrict__ dL_drots,
-    const float *__restrict__ cov3D_precomp) {
+    const float *__restrict__ cov3D_precomp, bool accum /* views > 0 of a batch: add to the view-independent inputs' gradients */) {
     if (!(prm.tanfovx > 0.f)) { prm.tanfovx = campos[3]; prm.tanfovy = campos[4]; }     // camera slot: see d3ga.h
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_sh = reinterpret_cast<float *>(smem);
@@ -388,9 +384,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     ShColJ jd = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (have_j && i < prm.P) {
         const float *d = geom.dcol;
-        jd.j0 = D3GA_DCOL_AT(d, i, 0, prm.P); jd.j1 = D3GA_DCOL_AT(d, i, 1, prm.P); jd.j2 = D3GA_DCOL_AT(d, i, 2, prm.P);
-        jd.j3 = D3GA_DCOL_AT(d, i, 3, prm.P); jd.j4 = D3GA_DCOL_AT(d, i, 4, prm.P); jd.j5 = D3GA_DCOL_AT(d, i, 5, prm.P);
-        jd.j6 = D3GA_DCOL_AT(d, i, 6, prm.P); jd.j7 = D3GA_DCOL_AT(d, i, 7, prm.P); jd.j8 = D3GA_DCOL_AT(d, i, 8, prm.P);
+        jd.j0 = D3GA_DCOL_AT(d, i, 0, geom.dcol_stride); jd.j1 = D3GA_DCOL_AT(d, i, 1, geom.dcol_stride); jd.j2 = D3GA_DCOL_AT(d, i, 2, geom.dcol_stride);
+        jd.j3 = D3GA_DCOL_AT(d, i, 3, geom.dcol_stride); jd.j4 = D3GA_DCOL_AT(d, i, 4, geom.dcol_stride); jd.j5 = D3GA_DCOL_AT(d, i, 5, geom.dcol_stride);
+        jd.j6 = D3GA_DCOL_AT(d, i, 6, geom.dcol_stride); jd.j7 = D3GA_DCOL_AT(d, i, 7, geom.dcol_stride); jd.j8 = D3GA_DCOL_AT(d, i, 8, geom.dcol_stride);
     }
     if (staged && !have_j) {
         if (full48) sh_rows48_to_slab<64>(slab, sh_rows48_load<64>(shs + (size_t)48 * row0, lane), lane);
@@ -414,13 +410,13 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
             preprocess_bwd_one(prm, i, visible, means3D, slab + lane * kShRow, scales, rotations, viewmatrix, projmatrix,
                                campos, c6, clampmask, a, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
                                dL_dsh ? slab + lane * kShRow : nullptr, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots,
-                               act_opacity, have_j, jd);
+                               act_opacity, have_j, jd, accum);
         else
             preprocess_bwd_one(prm, i, visible, means3D, shs ? shs + (size_t)M3 * i : nullptr, scales, rotations,
                                viewmatrix, projmatrix, campos, c6, clampmask, a, dL_dmeans3D, dL_dmeans2D,
                                dL_dopacity, dL_dsh ? dL_dsh + (size_t)M3 * i : nullptr, dL_dcolors, dL_dcov3D,
                                dL_dscales, dL_drots,
-                               act_opacity);
+                               act_opacity, false, ShColJ(), accum);
     }
     if (staged && dL_dsh) {
         __builtin_amdgcn_wave_barrier();          // the slab is private to the wavefront: program order suffices
@@ -498,7 +494,9 @@ static int validate(const d3ga_raster_params *prm) {
     if (!prm) return D3GA_E_NULL;
     if (prm->P < 0 || prm->W <= 0 || prm->H <= 0 || prm->M < 0 || prm->M > 16) return D3GA_E_SIZE;
     if (prm->sh_degree < 0 || prm->sh_degree > 3) return D3GA_E_CONFIG;
-    if (((prm->W + kTile - 1) / kTile) > 65535 || ((prm->H + kTile - 1) / kTile) > 65535) return D3GA_E_SIZE;
+    if (prm->n_views < 0) return D3GA_E_SIZE;
+    if (((prm->W + kTile - 1) / kTile) > 65535 || (int64_t)((prm->H + kTile - 1) / kTile) * n_views_of(prm) > 65535) return D3GA_E_SIZE;
+    if ((int64_t)prm->P * n_views_of(prm) >= (1ll << 31)) return D3GA_E_SIZE;
     return D3GA_OK;
 }
 
@@ -511,7 +509,8 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     if (!geom || !binning || !viewmatrix || !projmatrix || !campos) return D3GA_E_NULL;
     if (d_capacity < 0) return D3GA_E_SIZE;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t tiles = (int64_t)tiles_x(prm->W) * tiles_y(prm->H);
+    const int views = n_views_of(prm), gyv = tiles_y(prm->H);
+    const int64_t tiles = (int64_t)tiles_x(prm->W) * gyv * views;
     BinBuf bin = carve_bin(binning, tiles, d_capacity);
     // counters + tile_count are adjacent: one memset
     D3GA_HIP(zero_async(bin.counters, 256 + align256(4 * tiles), s));
@@ -521,20 +520,25 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     if (sr == (cov3D_precomp != nullptr)) return D3GA_E_CONFIG;
     if (shs && (prm->sh_degree + 1) * (prm->sh_degree + 1) > prm->M) return D3GA_E_CONFIG;
     if (!means3D || !opacities || !radii) return D3GA_E_NULL;
-    GeomBuf g = carve_geom(geom, prm->P);
+    const GeomBuf g = carve_geom(geom, (int64_t)prm->P * views);
     const size_t win = (size_t)kWinTiles * 4;
     const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? (kShHalfLdsBytes > win ? kShHalfLdsBytes : win) : win;
     // (the kernels' `staged` condition, on the host: with it and a backward to follow the forward leaves GeomBuf::dcol)
     const bool want_j = D3GA_PRE_DCOL && shs && prm->M > 0 && (3 * prm->M) % 4 == 0 && 3 * prm->M <= 48 && !prm->forward_only;
-    const int cull_arg = composite_fwd_impl_kind() != 0 ? ((composite_variant() & kVariantExactCull) ? 1 : 0) : -1;
-    if (want_j)
-        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
-                           colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, g,
-                           bin.tile_count, bin.counters, radii, cull_arg);
-    else
-        hipLaunchKernelGGL(preprocess_kernel<false>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
-                           colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, g,
-                           bin.tile_count, bin.counters, radii, cull_arg);
+    const int cam_stride = prm->tanfovx > 0.f ? 3 : 5;       // camera slots carry the two tangents behind the position
+    // a batch of views: one launch per view into ITS records of the batch's buffers (the per-Gaussian stage is a streaming kernel
+    // at the copy rate with nothing to gain from a taller grid; what the batch shares is everything downstream)
+    for (int v = 0; v < views; ++v) {
+        const GeomBuf gv = geom_view(g, prm->P, v);
+        const float *vm = viewmatrix + 16 * (size_t)v, *pm = projmatrix + 16 * (size_t)v, *cp = campos + (size_t)cam_stride * v;
+        int32_t *rv = radii + (size_t)prm->P * v;
+        if (want_j)
+            hipLaunchKernelGGL(preprocess_kernel<true>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
+                               colors_precomp, opacities, scales, rotations, cov3D_precomp, vm, pm, cp, gv, bin.tile_count, bin.counters, rv, v * gyv);
+        else
+            hipLaunchKernelGGL(preprocess_kernel<false>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
+                               colors_precomp, opacities, scales, rotations, cov3D_precomp, vm, pm, cp, gv, bin.tile_count, bin.counters, rv, v * gyv);
+    }
     return check_launch(s, prm->debug & 0xff);
 }
 
@@ -542,6 +546,7 @@ extern "C" int d3ga_raster_recolor(const d3ga_raster_params *prm, const float *m
                                    const float *colors_precomp, const float *campos, const void *geom_src,
                                    void *geom_dst, d3ga_stream_t stream) {
     D3GA_TRY(validate(prm));
+    if (n_views_of(prm) > 1) return D3GA_E_CONFIG;
     if (prm->P == 0) return D3GA_OK;
     if (!geom_src || !geom_dst || geom_src == geom_dst) return D3GA_E_NULL;
     if ((shs != nullptr) == (colors_precomp != nullptr)) return D3GA_E_CONFIG;
@@ -577,12 +582,33 @@ extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const f
     // forward kept NO copy (ABI 101), the caller's tensor is read again: a NULL here would mean uninitialised records
     if (!cov3D_precomp && !(scales && rotations)) return D3GA_E_NULL;
     hipStream_t s = (hipStream_t)stream;
-    GeomBuf g = carve_geom(const_cast<void *>(geom), prm->P);
+    const int views = n_views_of(prm);
+    const GeomBuf g = carve_geom(const_cast<void *>(geom), (int64_t)prm->P * views);
     const size_t lds = (shs && prm->M > 0 && (3 * prm->M) % 4 == 0) ? kShLdsBytes : 0;
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D,
-                       shs, scales, rotations, viewmatrix, projmatrix, campos, g, acc, dL_dmeans3D, dL_dmeans2D,
-                       dL_dopacity, dL_dsh, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots, cov3D_precomp);
-    return check_launch(s, prm->debug);
+    if (views == 1) {
+        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D,
+                           shs, scales, rotations, viewmatrix, projmatrix, campos, g, acc, dL_dmeans3D, dL_dmeans2D,
+                           dL_dopacity, dL_dsh, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots, cov3D_precomp, false);
+        return check_launch(s, prm->debug);
+    }
+    // a batch of views (d3ga.h: n_views): one launch per view on ITS records; view 0 writes the gradients of the view-independent
+    // inputs, the later ones add to them (launches of one stream: ordered); the SH gradient leaves as per-view (P,3) factors and
+    // the (P,M,3) block is rebuilt ONCE from all of them -- 12 M bytes per Gaussian and batch instead of per view
+    if (shs && !dL_dcolors) return D3GA_E_NULL;
+    const int cam_stride = prm->tanfovx > 0.f ? 3 : 5;
+    for (int v = 0; v < views; ++v) {
+        const size_t o = (size_t)prm->P * v;
+        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D,
+                           shs, scales, rotations, viewmatrix + 16 * (size_t)v, projmatrix + 16 * (size_t)v, campos + (size_t)cam_stride * v,
+                           geom_view(g, prm->P, v), acc + D3GA_ACC_STRIDE * o, dL_dmeans3D, dL_dmeans2D ? dL_dmeans2D + 3 * o : nullptr,
+                           dL_dopacity, (float *)nullptr, shs ? dL_dcolors + 3 * o : dL_dcolors, dL_dcov3D, dL_dscales, dL_drots,
+                           cov3D_precomp, v > 0);
+    }
+    D3GA_TRY(check_launch(s, prm->debug));
+    if (shs && dL_dsh)
+        return d3ga_sh_grad_from_views(prm->P, prm->M, prm->sh_degree, views, means3D, dL_dcolors, 3 * (int64_t)prm->P, campos, cam_stride,
+                                       1.0f, dL_dsh, stream);
+    return D3GA_OK;
 }
 
 extern "C" int d3ga_sh_grad_from_views(int32_t P, int32_t M, int32_t sh_degree, int32_t n_views, const float *means3D,

@@ -1,0 +1,190 @@
+"""View-batched rasterization: k cameras of ONE set of Gaussians in one grid per stage (include/d3ga.h: d3ga_raster_params::n_views).
+
+No counterpart upstream -- the reference renders one camera per call (renderer.py:69) and averages the losses of a batch of
+frames (train.py:218-221).  A single avatar view leaves two thirds of the chip idle in the binning and compositing launches
+(DESIGN.md sec. 4); k views of the same pose are one tall frame for those stages.  Per view the arithmetic is that of the
+single-view operator, so every image equals `rasterize_gaussians` from that camera and the gradients equal the sum over the k
+single-view backwards.
+
+    CameraBatch(k, width, height)            k cameras in one static device buffer (graph-replayable: `set(batches)`)
+    rasterize_gaussians_views(...)           -> (colors (k,3,H,W), radii (k,P), loss | None)
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import RasterParams, check, dptr, require_cuda, stream_handle
+from .cameras import Camera
+from . import rasterizer as _R
+
+
+class CameraBatch:
+    """k cameras of one raster size in ONE device buffer: view matrices (k,16) | full projections (k,16) | centres + tangents
+    (k,5).  The kernels read tan(FoV/2) per view from the buffer (the camera-slot convention of include/d3ga.h: the settings
+    carry tanfovx = 0), so the cameras of a batch may differ in everything but the raster size, and a captured step is replayed
+    with other cameras after `set()` -- one asynchronous H2D copy."""
+
+    def __init__(self, n_views, width, height, device="cuda"):
+        self.n_views, self.image_width, self.image_height = int(n_views), int(width), int(height)
+        k = self.n_views
+        self.buffer = torch.zeros(37 * k, dtype=torch.float32, device=torch.device(device))
+        self.viewmatrices = self.buffer[:16 * k].view(k, 16)
+        self.projmatrices = self.buffer[16 * k:32 * k].view(k, 16)
+        self.campos = self.buffer[32 * k:].view(k, 5)
+        self._host = torch.zeros(37 * k, dtype=torch.float32)
+        if self.buffer.is_cuda:
+            self._host = self._host.pin_memory()
+        self._event = None
+
+    def set(self, batches):
+        """batches: k dicts with the reference's camera keys (R, T, FoVx, FoVy, width, height: lib/cameras.py:14-26)."""
+        k = self.n_views
+        if len(batches) != k:
+            raise ValueError(f"CameraBatch holds {k} cameras, got {len(batches)}")
+        if self._event is not None:
+            self._event.synchronize()                 # the copy that last read the staging buffer has run
+        h = self._host
+        for v, b in enumerate(batches):
+            if int(b["width"]) != self.image_width or int(b["height"]) != self.image_height:
+                raise ValueError(f"CameraBatch is {self.image_width}x{self.image_height}; view {v} is {b['width']}x{b['height']}")
+            m = Camera.pack_host(b["R"], b["T"], b["FoVx"], b["FoVy"])        # view (16) | projection (16) | full (16) | centre (3)
+            h[16 * v:16 * v + 16] = torch.from_numpy(m[0:16])
+            h[16 * k + 16 * v:16 * k + 16 * v + 16] = torch.from_numpy(m[32:48])
+            o = 32 * k + 5 * v
+            h[o:o + 3] = torch.from_numpy(m[48:51])
+            h[o + 3] = math.tan(float(b["FoVx"]) * 0.5)
+            h[o + 4] = math.tan(float(b["FoVy"]) * 0.5)
+        self.buffer.copy_(h, non_blocking=True)
+        if self.buffer.is_cuda:
+            self._event = torch.cuda.Event()
+            self._event.record()
+        return self
+
+
+def _scratch_views(P, W, H, k, cap, dev, fwd_only):
+    sizes = (ctypes.c_int64 * 3)()
+    check(_lib.lib().d3ga_raster_scratch_bytes_views(P, W, H, k, cap, int(fwd_only), sizes), "d3ga_raster_scratch_bytes_views")
+    return [torch.empty(int(n), dtype=torch.uint8, device=dev) for n in sizes]
+
+
+class _RasterizeViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cams, bg, sh_degree,
+                scale_modifier, antialiasing, opacity_activation, l1_targets):
+        require_cuda(means3D)
+        dev = means3D.device
+        f32 = lambda t: _R._f32(t, dev)
+        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, bg = map(
+            f32, (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, bg))
+        if (sh is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3Ds_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3Ds_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        k, W, H = cams.n_views, cams.image_width, cams.image_height
+        P = means3D.shape[0]
+        M = sh.shape[1] if sh is not None else 0
+        fwd_only = not any(ctx.needs_input_grad[:7])
+        prm = RasterParams(P=P, M=M, sh_degree=int(sh_degree), W=W, H=H, tanfovx=0.0, tanfovy=0.0,
+                           scale_modifier=float(scale_modifier), antialiasing=int(bool(antialiasing)), prefiltered=0, debug=0,
+                           opacity_activation=_R._ACTIVATIONS[opacity_activation], forward_only=int(fwd_only), n_views=k)
+        colors = torch.empty((k, 3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((k, P), dtype=torch.int32, device=dev)
+        loss = tgt = None
+        if l1_targets is not None:
+            tgt = f32(l1_targets)
+            if tuple(tgt.shape) != (k, 3, H, W):
+                raise ValueError(f"rasterize_gaussians_views: the targets must be ({k}, 3, {H}, {W}), got {tuple(tgt.shape)}")
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        st, pp = stream_handle(), ctypes.byref(prm)
+        static = _R._policy["mode"] == "static"
+        cap = _R._policy["static"] if static else max(k * _R._hwm.get(dev.index, 0), k * (4 * P + 1024))
+        while True:
+            geom, binning, img = _scratch_views(P, W, H, k, cap, dev, fwd_only)
+            tm = _R.stage_timer
+            tm.stage("preprocess", lambda: check(L.d3ga_raster_preprocess(
+                pp, dptr(means3D), dptr(sh), dptr(colors_precomp), dptr(opacities), dptr(scales), dptr(rotations),
+                dptr(cov3Ds_precomp), dptr(cams.viewmatrices), dptr(cams.projmatrices), dptr(cams.campos), dptr(geom), dptr(binning),
+                cap, dptr(radii), st), "d3ga_raster_preprocess"))
+            tm.stage("bin_sort", lambda: check(L.d3ga_raster_bin_sort(pp, dptr(geom), dptr(binning), cap, st), "d3ga_raster_bin_sort"))
+            if tgt is not None and P > 0:
+                ws = torch.empty(4 * k * ((W + 15) // 16) * ((H + 15) // 16), dtype=torch.float32, device=dev)
+                tm.stage("composite_fwd", lambda: check(L.d3ga_raster_composite_fwd_l1(
+                    pp, dptr(bg), dptr(geom), dptr(binning), cap, dptr(img), dptr(colors), None, dptr(tgt), None, dptr(loss), dptr(ws), st),
+                    "d3ga_raster_composite_fwd_l1"))
+            else:
+                tm.stage("composite_fwd", lambda: check(L.d3ga_raster_composite_fwd(
+                    pp, dptr(bg), dptr(geom), dptr(binning), cap, dptr(img), dptr(colors), None, st), "d3ga_raster_composite_fwd"))
+                if tgt is not None:
+                    _R.l1_mean_forward(colors, tgt, None, loss, dev)
+            _R._last[dev.index] = (binning, cap)
+            if _R._capture_log is not None:
+                _R._capture_log.append((binning, cap))
+            if static:
+                break
+            cnt = binning[:32].view(torch.int32)[:2].cpu().tolist()           # host sync (upstream: num_rendered)
+            D = cnt[0] & 0xFFFFFFFF
+            _R._hwm[dev.index] = max(_R._hwm.get(dev.index, 0), int(D * 1.25 / k) + 1024)      # the mark is per view
+            if not cnt[1]:
+                break
+            cap = k * _R._hwm[dev.index]
+        ctx.prm, ctx.cap, ctx.cams = prm, cap, cams
+        ctx.l1 = tgt is not None and P > 0
+        ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, bg, geom, binning, img,
+                              colors if ctx.l1 else None, tgt if ctx.l1 else None)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
+        return (colors, radii, loss) if tgt is not None else (colors, radii)
+
+    @staticmethod
+    def backward(ctx, grad_colors, _grad_radii, grad_loss=None):
+        means3D, sh, scales, rotations, cov3Ds_precomp, bg, geom, binning, img, image, tgt = ctx.saved_tensors
+        prm, cams, dev, P, k = ctx.prm, ctx.cams, means3D.device, means3D.shape[0], ctx.prm.n_views
+        if P == 0:
+            return (None,) * 14
+        g_loss = None
+        if ctx.l1 and grad_loss is not None:
+            g_loss = _R._f32(grad_loss, dev).reshape(1)
+        if grad_colors is None and g_loss is None:
+            grad_colors = torch.zeros((k, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
+        grad_colors = _R._f32(grad_colors, dev)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        acc = torch.empty((k * P, _lib.ACC_STRIDE), dtype=torch.float32, device=dev)
+        from_sr = cov3Ds_precomp is None
+        g_means3D, g_opac = new(P, 3), new(P, 1)
+        g_sh = new(P, prm.M, 3) if sh is not None else None
+        g_col = new(k, P, 3) if sh is not None else new(P, 3)      # SH: the per-view factors of the rank-1 SH gradient (scratch)
+        g_cov = None if from_sr else new(P, 6)
+        g_scales = new(P, 3) if from_sr else None
+        g_rots = new(P, 4) if from_sr else None
+        L = _lib.lib()
+        st, pp = stream_handle(), ctypes.byref(prm)
+        tm = _R.stage_timer
+        acc.zero_()
+        if g_loss is not None:
+            tm.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd_l1(
+                pp, dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img), dptr(image), dptr(tgt), None, dptr(g_loss),
+                dptr(grad_colors), dptr(acc), st), "d3ga_raster_composite_bwd_l1"))
+        else:
+            tm.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd(
+                pp, dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img), dptr(grad_colors), dptr(acc), st),
+                "d3ga_raster_composite_bwd"))
+        tm.stage("preprocess_bwd", lambda: check(L.d3ga_raster_preprocess_bwd(
+            pp, dptr(means3D), dptr(sh), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp), dptr(cams.viewmatrices),
+            dptr(cams.projmatrices), dptr(cams.campos), dptr(geom), dptr(acc), dptr(g_means3D), None, dptr(g_opac), dptr(g_sh),
+            dptr(g_col), dptr(g_cov), dptr(g_scales), dptr(g_rots), st), "d3ga_raster_preprocess_bwd"))
+        return (g_means3D, g_sh, g_col if sh is None else None, g_opac, g_scales, g_rots, g_cov,
+                None, None, None, None, None, None, None)
+
+
+def rasterize_gaussians_views(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cameras, bg, sh_degree=0,
+                              scale_modifier=1.0, antialiasing=False, opacity_activation=None, l1_targets=None):
+    """k views of the same Gaussians in one grid per stage.  cameras: a CameraBatch; bg (3,) shared by the views.
+    -> (colors (k,3,H,W), radii (k,P)) or, with l1_targets (k,3,H,W), (colors, radii, loss) where loss = mean |colors - targets|
+    over all k images (= the mean over the views of the reference's per-frame l1_loss, train.py:218-221: equal sizes) whose
+    gradient is formed inside the compositing backward.  Inputs and gradients as `rasterize_gaussians`."""
+    return _RasterizeViews.apply(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cameras, bg,
+                                 sh_degree, scale_modifier, antialiasing, opacity_activation, l1_targets)

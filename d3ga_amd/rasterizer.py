@@ -331,11 +331,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                     pp, dptr(means3D), dptr(sh), dptr(colors_precomp), dptr(opacities), dptr(scales), dptr(rotations),
                     dptr(cov3Ds_precomp), dptr(view), dptr(proj), dptr(campos), dptr(geom), dptr(binning), cap,
                     dptr(radii), st), "d3ga_raster_preprocess"))
-                # (the per-tile sort also emits the block lists the compositing kernels walk, when the library's forward uses them)
-                lists = ctypes.c_int32(0)
-                stage_timer.stage("bin_sort", lambda: check(L.d3ga_raster_bin_sort_lists(
-                    pp, dptr(geom), dptr(binning), dptr(img), cap, ctypes.byref(lists), st), "d3ga_raster_bin_sort_lists"))
-                prm.block_lists = lists.value
+                stage_timer.stage("bin_sort", lambda: check(L.d3ga_raster_bin_sort(
+                    pp, dptr(geom), dptr(binning), cap, st), "d3ga_raster_bin_sort"))
                 if dual:
                     stage_timer.stage("composite_fwd", lambda: check(L.d3ga_raster_composite_fwd2(
                         pp, dptr(bg), dptr(bg2), dptr(geom), dptr(colors2), dptr(binning), cap, dptr(img), dptr(color),
@@ -595,22 +592,21 @@ def last_termination(device=None):
 
 
 def last_block_lists(device=None):
-    """(blk_count (tiles,16) int64, blk_total (tiles,16) int64, blk_list (16 x capacity, 2) int64 {1-based tile-list position,
-    Gaussian index}) of the most recent forward that was followed by (or may be followed by) a backward on `device` -- views
-    decoded from its image scratch (d3ga_raster_img_layout_blocks; inspection / tests).  Block b of a tile whose list is
-    [begin, end) starts at row 16 begin + b (end - begin) of blk_list; blk_count is the prefix the backward walks."""
+    """(blk_count (tiles,16) int64, blk_list (16 x capacity, 2) int64 {1-based tile-list position, Gaussian index}) of the most
+    recent forward that was followed by (or may be followed by) a backward on `device` -- views decoded from its image scratch
+    (d3ga_raster_img_layout_blocks; inspection / tests).  Block b of a tile whose list is [begin, end) starts at row
+    16 begin + b (end - begin) of blk_list; blk_count is the prefix the backward walks."""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     img, W, H = _last_img[dev][:3]
-    off = (ctypes.c_int64 * 3)()
+    off = (ctypes.c_int64 * 2)()
     check(_lib.lib().d3ga_raster_img_layout_blocks(W, H, off), "d3ga_raster_img_layout_blocks")
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    if img.numel() <= off[2]:
+    if img.numel() <= off[1]:
         raise RuntimeError("the last forward was a forward_only render: it has no block lists")
     cnt = img[off[0]:off[0] + 64 * tiles].view(torch.int32).view(tiles, 16).long()
-    tot = img[off[1]:off[1] + 64 * tiles].view(torch.int32).view(tiles, 16).long()
-    n = (img.numel() - off[2]) // 8
-    lst = img[off[2]:off[2] + 8 * n].view(torch.int32).view(n, 2).long()
-    return cnt, tot, lst
+    n = (img.numel() - off[1]) // 8
+    lst = img[off[1]:off[1] + 8 * n].view(torch.int32).view(n, 2).long()
+    return cnt, lst
 
 
 def last_alpha_decisions(gid, px, py, device=None):

@@ -22,7 +22,12 @@
 extern "C" {
 #endif
 
-#define D3GA_VERSION 104 /* 0.1.4: d3ga_color_rows_fwd / _bwd (ColorField's per-row input columns in one pass).  103: 0.1.3: D3GA_CNT_HEAVY (counter 7 of the binning buffer: how many tiles at the head of the work order the compositing backward splits over two workgroups).  102: 0.1.2: d3ga_raster_params::block_lists, d3ga_raster_bin_sort_lists (the per-tile sort emits the block lists of the compositing kernels).  101: 0.1.1: d3ga_raster_preprocess_bwd / d3ga_raster_backward* read cov3D_precomp again (the forward keeps no copy); NULL without (scales, rotations) is D3GA_E_NULL */
+/* The library is built with -fvisibility=hidden: exactly the functions declared in this header are exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+#define D3GA_VERSION 110 /* round 6 (frozen for the round): view-batched rendering (d3ga_raster_params::n_views, d3ga_raster_scratch_bytes_views), d3ga_debug_set / D3GA_KNOB_* replace every environment knob, the opt-in list forwards of round 5 are gone (d3ga_raster_bin_sort_lists, d3ga_raster_params::block_lists), only the functions declared here are exported */
 
 #define D3GA_OK 0
 #define D3GA_E_NULL (-1)     /* required pointer is NULL */
@@ -34,12 +39,27 @@ typedef void *d3ga_stream_t; /* hipStream_t */
 
 int d3ga_version(void);
 const char *d3ga_status_string(int status);
-/* What this build runs (host only, no device work).  out[0] = D3GA_SCAN_ABL the library was compiled with (0 = product;
- * anything else is a TIMING ABLATION whose results are wrong by design -- the Python layer refuses such a library unless
- * D3GA_ALLOW_ABLATION=1), out[1] = 1 for a diagnostic (counter) build, then (compiled default, value in effect with the
- * current environment) pairs: out[2..3] D3GA_COMPOSITE_VARIANT, out[4..5] D3GA_MERGE_SLOTS, out[6..7] D3GA_TILE_ASSIGN
- * (block -> wavefront assignment of the compositing backward: 0 quadrants, 1 interleaved, 2 by list length). */
-int d3ga_debug_defaults(int32_t out[8]);
+/* Debug knobs (host only, no device work).  The library reads NO environment variable; the one piece of mutable process state it
+ * keeps is this table of integers, for tests and A/B timing runs (d3ga_amd/_lib.py applies D3GA_KNOBS="name=value,..." at load).
+ * Product code never calls d3ga_debug_set; with every knob at its default the entry points are re-entrant across devices and streams.
+ *   d3ga_debug_set(key, value): set knob `key` (D3GA_KNOB_*); value == D3GA_KNOB_DEFAULT restores the compiled default.
+ *   d3ga_debug_defaults(out, n): out[0] = D3GA_SCAN_ABL the library was compiled with (0 = product; anything else is a TIMING
+ *   ABLATION whose results are wrong by design -- the Python layer refuses such a library unless D3GA_ALLOW_ABLATION=1), out[1] = 1
+ *   for a diagnostic (counter) build, then for knob k < D3GA_KNOB_COUNT: out[2 + 2k] = compiled default, out[3 + 2k] = value in
+ *   effect; n = capacity of out in int32 (>= 2 + 2 * D3GA_KNOB_COUNT, else D3GA_E_SIZE). */
+#define D3GA_KNOB_COMPOSITE_VARIANT 0 /* bit 5 (32) work-ordered dispatch of the compositing kernels, bit 7 (128) exact block culling; default 160 */
+#define D3GA_KNOB_MERGE_SLOTS 1       /* slots of the compositing backward's per-tile merge cache: 256 | 512 (default) | 1024 */
+#define D3GA_KNOB_TILE_ASSIGN 2       /* block -> wavefront assignment of the compositing backward: 0 quadrants, 1 interleaved, 2 by list length (default); +8: no early exit */
+#define D3GA_KNOB_BWD_SPLIT 3         /* compositing backward: -1 (default) the D3GA_CNT_HEAVY heaviest tiles get two workgroups, 0 none, n > 0 the n heaviest */
+#define D3GA_KNOB_SORT_MERGE 4        /* -1 (default) by size: the 2049..4096 list class rides in the 8192-key sort launch when few such lists are expected; 0 never; 1 always */
+#define D3GA_KNOB_SSIM_IMPL 5         /* 1 (default) the marching register-window SSIM kernels, 0 the LDS-tiled ones of round 3 */
+#define D3GA_KNOB_WGRAD_WS 6          /* 1 (default) the wavefront-specialised weight-gradient kernel for two wide operands, 0 the barrier-phased one */
+#define D3GA_KNOB_CHAIN_ABL 7         /* 0 (default); != 0: TIMING ablations of the fused field-network kernel (wrong results) */
+#define D3GA_KNOB_CHAIN_GRID 8        /* 0 (default) = 2048 / wavefronts per workgroup; > 0: workgroups of the fused field-network kernel */
+#define D3GA_KNOB_COUNT 9
+#define D3GA_KNOB_DEFAULT (-2147483647 - 1)
+int d3ga_debug_set(int32_t key, int32_t value);
+int d3ga_debug_defaults(int32_t *out, int32_t n);
 
 /* ---------------------------------------------------------------------------------------------------------
  * D0  Linear blend skinning of cage vertices (K-sparse weights).
@@ -161,10 +181,20 @@ typedef struct d3ga_raster_params {
      * d3ga_raster_preprocess_bwd zero-fills every record it consumed, so that the buffer is all zero again when it returns.
      * All backwards sharing one such buffer must be ordered on one stream. */
     int32_t acc_self_clearing;
-    /* != 0: the per-4x4-block lists of the img buffer handed to d3ga_raster_composite_fwd* were written by
-     * d3ga_raster_bin_sort_lists (it said so through *lists_written) for THIS binning; the forward then only blends them.
-     * 0: the forward builds whatever lists it needs itself (any binning, e.g. one kept from an earlier render). */
-    int32_t block_lists;
+    /* View-batched rendering (round 6; no counterpart upstream: the reference renders one camera per call, renderer.py:69).
+     * 0 or 1: one camera (everything below reads as before).  k > 1: the SAME Gaussians seen from k cameras are rasterised in ONE
+     * grid per stage -- the launches of a single avatar view fill a third of the chip, k views fill it.  Then
+     *   viewmatrix / projmatrix are (k,16), campos (k,3) -- (k,5) for camera slots -- radii (k,P);
+     *   geom / binning / img are sized by d3ga_raster_scratch_bytes_views and hold k x P records / k x tiles lists: view v's Gaussian
+     *   i is record v P + i, its tile (tx, ty) is tile (v gy + ty) gx + tx; W, H, tanfov*, bg are shared by the views;
+     *   out_color (k,3,H,W), out_invdepth (k,H,W), dL_dpix (k,3,H,W), the L1 target (k,3,H,W) and its loss = mean over all k images;
+     *   acc (k P, D3GA_ACC_STRIDE);  d3ga_raster_preprocess_bwd SUMS dL/dmeans3D, dL/dopacity, dL/dcov3D | (dL/dscales, dL/drots) and a
+     *   precomputed colour's gradient over the views, writes dL_dmeans2D per view (k,P,3), and for SH colours needs dL_dcolors
+     *   (k,P,3) = the per-view factors of the rank-1 SH gradient, from which dL_dsh (P,M,3), when given, is rebuilt in one pass
+     *   (d3ga_sh_grad_from_views) -- one 12 M-byte row per Gaussian and BATCH instead of per view.
+     * Every view's image and the summed gradients equal k single-view calls (same kernels, same arithmetic per view).
+     * Not available batched (D3GA_E_CONFIG): d3ga_raster_composite_fwd2 / _bwd2, d3ga_raster_recolor. */
+    int32_t n_views;
 } d3ga_raster_params;
 #define D3GA_OPACITY_SIGMOID 1
 
@@ -174,6 +204,10 @@ typedef struct d3ga_raster_params {
 int d3ga_raster_scratch_bytes(int32_t P, int32_t W, int32_t H, int64_t d_capacity, int64_t sizes[3]);
 /* Bytes of the img buffer alone; forward_only != 0: without the per-block lists (d3ga_raster_params.forward_only). */
 int64_t d3ga_raster_img_bytes(int32_t W, int32_t H, int64_t d_capacity, int32_t forward_only);
+/* The same for a batch of n_views cameras (d3ga_raster_params::n_views): d_capacity counts the duplicates of ALL views;
+ * sizes[2] is the img buffer with (forward_only == 0) or without the per-block lists. */
+int d3ga_raster_scratch_bytes_views(int32_t P, int32_t W, int32_t H, int32_t n_views, int64_t d_capacity, int32_t forward_only,
+                                    int64_t sizes[3]);
 
 /* Byte offsets of the sections of the binning buffer, for inspection/tests:
  * offsets[0] counters (8 x u32), [1] tile_count (tiles x u32), [2] tile_start (tiles+1 x u32, exclusive prefix),
@@ -183,11 +217,10 @@ int d3ga_raster_binning_layout(int32_t W, int32_t H, int64_t d_capacity, int64_t
 /* Same for the image buffer: offsets[0] final_T (H*W f32), [1] n_contrib (H*W u32). */
 int d3ga_raster_img_layout(int32_t W, int32_t H, int64_t offsets[2]);
 /* ... and its per-block lists (absent from a forward_only buffer), for inspection/tests: offsets[0] blk_count (16 x tiles u32: the
- * length of the prefix of a block's list the backward walks = up to the last entry some pixel of the block blended, round 5),
- * [1] blk_total (16 x tiles u32: entries the list pass of the two-launch forward wrote; unused by the one-launch forward),
- * [2] blk_list (16 x d_capacity {u32 1-based position in the tile's list, u32 Gaussian index}; block b of a tile whose list is
+ * length of the prefix of a block's list the backward walks = up to the last entry some pixel of the block blended),
+ * [1] blk_list (16 x d_capacity {u32 1-based position in the tile's list, u32 Gaussian index}; block b of a tile whose list is
  * [begin, end) starts at element 16 begin + b (end - begin); b = 4 x quadrant + block within the quadrant). */
-int d3ga_raster_img_layout_blocks(int32_t W, int32_t H, int64_t offsets[3]);
+int d3ga_raster_img_layout_blocks(int32_t W, int32_t H, int64_t offsets[2]);
 
 /* The binning buffer starts with 8 uint32 counters the host may read back after the forward:
  *   [0] D = duplicates required (sum of tiles touched)      [1] 1 if D > d_capacity (lists truncated: re-run)
@@ -213,14 +246,6 @@ int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float *means3D, 
 /* R2+R3 tile offsets (scan), scatter of (depth,index) keys, per-tile sort in LDS. */
 int d3ga_raster_bin_sort(const d3ga_raster_params *prm, void *geom, void *binning, int64_t d_capacity,
                          d3ga_stream_t stream);
-/* The same, and -- when a backward will follow (forward_only == 0) and the library's compositing forward walks explicit block
- * lists (the default; D3GA_FWD_IMPL=2) -- the per-tile sort also EMITS the per-4x4-block lists into `img` (ImgBuf::blk_list /
- * blk_total): the scatter writes, beside every (depth, index) key, the 16-bit mask of the tile's blocks the splat's alpha >=
- * 1/255 ellipse can touch (from the span record preprocess left in geom), the sort carries it along and every wavefront of the
- * sort workgroup emits the lists of its blocks from the sorted entries in LDS.  *lists_written (HOST int) = 1 if they were
- * written: pass it on as d3ga_raster_params::block_lists to d3ga_raster_composite_fwd*.  `img` may be NULL when forward_only. */
-int d3ga_raster_bin_sort_lists(const d3ga_raster_params *prm, void *geom, void *binning, void *img, int64_t d_capacity,
-                               int32_t *lists_written, d3ga_stream_t stream);
 /* R4 front-to-back compositing.  bg (3) device.  out_color (3,H,W); out_invdepth (H,W)|NULL. */
 int d3ga_raster_composite_fwd(const d3ga_raster_params *prm, const float *bg, const void *geom, const void *binning,
                               int64_t d_capacity, void *img, float *out_color, float *out_invdepth,
@@ -492,6 +517,9 @@ int d3ga_color_rows_fwd(int32_t P, int32_t F, const float *dirs, const float *fe
 int d3ga_color_rows_bwd(int32_t P, int32_t F, const float *dirs, const float *d_x, float *d_dirs, float *d_feats,
                         d3ga_stream_t stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -36,7 +36,7 @@ def test_block_count_is_the_prefix_up_to_the_last_blended_entry(name, scale_mult
     inp, R, img, _, _, _ = _render(name, scale_mult)
     W, H = inp["W"], inp["H"]
     torch.cuda.synchronize()
-    cnt, _, lst = R.last_block_lists()
+    cnt, lst = R.last_block_lists()
     _, ncontrib = R.last_termination()
     start, _, _ = R.last_tile_lists(W, H)
     gx, gy = (W + 15) // 16, (H + 15) // 16
@@ -83,39 +83,12 @@ np.savez(sys.argv[1], **out)
 """
 
 
-def test_two_launch_forward_equals_the_one_launch_forward(tmp_path):
-    """D3GA_FWD_IMPL=1 (opt-in: block lists built by tile_cull_kernel from the per-Gaussian span records, then the lists blend)
-    and D3GA_FWD_IMPL=2 (opt-in: the per-tile SORT emits the block lists -- d3ga_raster_bin_sort_lists -- then the same blend)
-    render the same frames as the default forward: identical termination, images to float rounding, gradients to 2e-5 of the
-    largest element; 1 and 2 build identical lists, so their results are bit-identical.  T1 x 8 holds splats too large for a
-    span record (the geometric fallback of the list pass / of the sort's mask decoder)."""
-    files = {}
-    for impl in ("0", "1", "2"):
-        f = str(tmp_path / f"impl{impl}.npz")
-        env = dict(os.environ, D3GA_FWD_IMPL=impl)
-        r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT), f], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        files[impl] = np.load(f)
-    for k in files["1"].files:                               # the same lists, the same blend (the backward's sums may differ in order)
-        if k.endswith(("_n", "_img")):
-            np.testing.assert_array_equal(files["1"][k], files["2"][k], err_msg=k)
-    for a, b in ((files["0"], files["1"]), (files["0"], files["2"])):
-      for k in a.files:
-        if k.endswith("_n"):
-            assert (a[k] != b[k]).mean() < 1e-4, k           # (a T < 1e-4 decision may fall the other way: sums in another order)
-        elif k.endswith("_img"):
-            np.testing.assert_allclose(b[k], a[k], atol=2e-6, err_msg=k)
-        else:
-            scale = np.abs(a[k]).max() + 1e-30
-            assert np.abs(a[k] - b[k]).max() <= 2e-5 * scale, (k, np.abs(a[k] - b[k]).max() / scale)
-
-
 def test_backward_without_the_precomputed_covariance_is_refused():
     """ABI 101: the forward keeps no copy of a precomputed covariance, so a per-Gaussian backward that is handed
     neither cov3D_precomp nor (scales, rotations) returns D3GA_E_NULL instead of reading uninitialised records."""
     from d3ga_amd import _lib
     L = _lib.lib()
-    assert L.d3ga_version() == 104
+    assert L.d3ga_version() == _lib.ABI_VERSION
     prm = _lib.RasterParams(P=16, M=0, sh_degree=0, W=64, H=64, tanfovx=1.0, tanfovy=1.0, scale_modifier=1.0, antialiasing=0,
                             prefiltered=0, debug=0, opacity_activation=0, forward_only=0, acc_self_clearing=0)
     buf = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
@@ -168,12 +141,13 @@ def test_backward_with_split_heavy_tiles_equals_the_unsplit_one(tmp_path):
     """Round 5 (last session): the heaviest tiles of the work order get TWO workgroups each in the compositing backward (their blocks
     dealt by rank parity, two blocks per wavefront walked over two DPP rows with wave-wide scans: the R = 2 walk), by default as
     many as the order kernel counts (D3GA_CNT_HEAVY).  The forward is untouched, so images and termination are bit-identical;
-    gradients are the same sums in another order (2e-5 of the largest element).  D3GA_BWD_SPLIT=7 splits seven tiles whatever
-    their length (a split tile with short or empty halves), 100000 every tile the grid has (capped by the tile count)."""
+    gradients are the same sums in another order (2e-5 of the largest element).  The knob `bwd_split` (d3ga_debug_set, applied by
+    d3ga_amd/_lib.py from D3GA_KNOBS) = 7 splits seven tiles whatever their length (a split tile with short or empty halves), 100000
+    every tile the grid has (capped by the tile count)."""
     files = {}
     for split in ("0", "-1", "7", "100000"):
         f = str(tmp_path / f"split{split}.npz")
-        env = dict(os.environ, D3GA_BWD_SPLIT=split, D3GA_FWD_IMPL="0")
+        env = dict(os.environ, D3GA_KNOBS=f"bwd_split={split}")
         r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT), f], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         files[split] = np.load(f)

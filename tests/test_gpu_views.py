@@ -1,0 +1,172 @@
+"""View-batched rasterization (d3ga_amd/raster_views.py; include/d3ga.h: d3ga_raster_params::n_views): k cameras of one set of
+Gaussians in one grid per stage.  Claim under test: every view's image IS the single-view render of that camera and the gradients
+are the sum over the k single-view backwards -- the single-view operator is the one the oracle tests pin (tests/test_gpu_parity.py),
+and one case here goes to the C oracle directly."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from util import Parity, scene_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _batches(inp, k, fov_jitter=False):
+    from d3ga_amd import synthetic as syn
+    out = []
+    for v in range(k):
+        b = syn.make_batch(inp["W"], inp["H"], azimuth=0.4 + 2 * math.pi * v / max(k, 3), camera_id=v,
+                           fill=0.85 * (1.0 + (0.1 * v if fov_jitter else 0.0)))
+        out.append(b)
+    return out
+
+
+def _single_view(inp, batch, leaves, bg, use_sh, from_sr, target=None, gpix=None):
+    """One view through the single-view operator -> (image, loss | None); gradients accumulate into the leaves."""
+    from d3ga_amd import rasterizer as R
+    from d3ga_amd.cameras import batch_to_camera
+    cam = batch_to_camera(batch, device=DEV)
+    s = R.GaussianRasterizationSettings(
+        image_height=inp["H"], image_width=inp["W"], tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, scale_modifier=1.0,
+        viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=3 if use_sh else 0,
+        campos=cam.camera_center, prefiltered=False, debug=False, antialiasing=False)
+    args = (leaves["means3D"], None, leaves["shs"] if use_sh else None, None if use_sh else leaves["rgb"], leaves["opacities"],
+            leaves["scales"] if from_sr else None, leaves["rots"] if from_sr else None, None if from_sr else leaves["cov6"], s)
+    if target is not None:
+        img, _, _, loss = R.rasterize_gaussians_l1(*args, target, want_invdepth=False)
+        return img, loss
+    img = R.rasterize_gaussians(*args, want_invdepth=False)[0]
+    return img, None
+
+
+def _leaves(inp, use_sh, from_sr):
+    d = {"means3D": inp["means3D"], "opacities": inp["opacities"]}
+    d.update({"shs": inp["shs"]} if use_sh else {"rgb": inp["rgb"]})
+    d.update({"scales": inp["scales"], "rots": inp["scene"]["rotation"]} if from_sr else {"cov6": inp["cov6"]})
+    return {k: v.to(DEV).clone().contiguous().requires_grad_(True) for k, v in d.items()}
+
+
+def _views(inp, batches, leaves, bg, use_sh, from_sr, targets=None):
+    from d3ga_amd.raster_views import CameraBatch, rasterize_gaussians_views
+    cams = CameraBatch(len(batches), inp["W"], inp["H"], device=DEV).set(batches)
+    return rasterize_gaussians_views(
+        leaves["means3D"], leaves["shs"] if use_sh else None, None if use_sh else leaves["rgb"], leaves["opacities"],
+        leaves["scales"] if from_sr else None, leaves["rots"] if from_sr else None, None if from_sr else leaves["cov6"], cams, bg,
+        sh_degree=3 if use_sh else 0, l1_targets=targets)
+
+
+@pytest.mark.parametrize("name,scale_mult,k,use_sh,from_sr", [("T1", 3.0, 3, True, False), ("C1", 1.0, 4, True, False),
+                                                               ("T1", 3.0, 2, False, True), ("T1", 8.0, 5, False, False)])
+def test_batched_views_equal_the_single_view_renders(name, scale_mult, k, use_sh, from_sr):
+    """Images: bit-identical per view (the same kernels on the same per-view records; only the tile numbering differs).
+    Gradients: the sum over the views, formed in another order (float atomics across tiles; the SH block rebuilt from the k
+    per-view factors in one pass) -- 2e-5 of the largest element, the bar of the other same-arithmetic comparisons."""
+    inp = scene_inputs(name, scale_mult=scale_mult)
+    batches = _batches(inp, k, fov_jitter=True)
+    bg = torch.tensor([0.3, 0.6, 0.1], device=DEV)
+    g = torch.Generator().manual_seed(3)
+    gpix = torch.randn(k, 3, inp["H"], inp["W"], generator=g).to(DEV)
+    ref = _leaves(inp, use_sh, from_sr)
+    imgs = []
+    for v, b in enumerate(batches):
+        img, _ = _single_view(inp, b, ref, bg, use_sh, from_sr)
+        (img * gpix[v]).sum().backward()
+        imgs.append(img.detach())
+    mine = _leaves(inp, use_sh, from_sr)
+    colors, radii = _views(inp, batches, mine, bg, use_sh, from_sr)
+    (colors * gpix).sum().backward()
+    torch.cuda.synchronize()
+    assert colors.shape == (k, 3, inp["H"], inp["W"]) and radii.shape == (k, inp["means3D"].shape[0])
+    for v in range(k):
+        assert torch.equal(colors[v], imgs[v]), (v, float((colors[v] - imgs[v]).abs().max()))
+        assert float((colors[v] - bg.view(3, 1, 1)).abs().max()) > 0.05        # something was rendered in every view
+    for key in ref:
+        a, b = ref[key].grad, mine[key].grad
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (key, float((a - b).abs().max()) / scale)
+
+
+def test_batched_views_with_the_fused_l1_loss():
+    """loss = mean |colors - targets| over all k images = the mean over the views of the single-view fused L1 losses; its gradient
+    is formed inside the batched compositing backward."""
+    inp = scene_inputs("C1")
+    k = 3
+    batches = _batches(inp, k)
+    bg = torch.ones(3, device=DEV)
+    g = torch.Generator().manual_seed(5)
+    targets = torch.rand(k, 3, inp["H"], inp["W"], generator=g).to(DEV)
+    ref = _leaves(inp, True, False)
+    tot = 0.0
+    for v, b in enumerate(batches):
+        _, loss = _single_view(inp, b, ref, bg, True, False, target=targets[v].contiguous())
+        (loss / k).backward()
+        tot += float(loss) / k
+    mine = _leaves(inp, True, False)
+    colors, _, loss = _views(inp, batches, mine, bg, True, False, targets=targets)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - tot) <= 2e-6 * abs(tot), (float(loss), tot)
+    for key in ref:
+        a, b = ref[key].grad, mine[key].grad
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (key, float((a - b).abs().max()) / scale)
+
+
+def test_batched_views_against_the_oracle():
+    """Two views of T1 against the C oracle directly, under the bars of the single-view parity tests (strict image bar on the
+    non-marginal pixels; element-wise gradient bar on the SUM of the two views' oracle gradients, the incoming gradient zeroed
+    on the oracle's marginal pixels on both sides)."""
+    from oracle import raster_c as rc
+    from oracle import camera as oc
+    inp = scene_inputs("T1", scale_mult=3.0)
+    k = 2
+    batches = _batches(inp, k)
+    bgc = torch.tensor([0.2, 0.5, 0.9])
+    npy = lambda t: np.ascontiguousarray(t.detach().cpu().numpy())
+    g = torch.Generator().manual_seed(9)
+    gpix = torch.randn(k, 3, inp["H"], inp["W"], generator=g)
+    octx, oimg = [], []
+    for v, b in enumerate(batches):
+        cam = oc.camera(b["R"], b["T"], b["FoVx"], b["FoVy"])
+        img, _, _, ctx = rc.forward(npy(inp["means3D"]), npy(inp["opacities"]), npy(bgc), cam["world_view_transform"],
+                                    cam["full_proj_transform"], cam["camera_center"], cam["tanfovx"], cam["tanfovy"], inp["W"], inp["H"],
+                                    cov3D_precomp=npy(inp["cov6"]), shs=npy(inp["shs"]), sh_degree=3)
+        octx.append(ctx); oimg.append(img)
+    pars = [Parity(c) for c in octx]
+    for v in range(k):
+        pars[v].mask(gpix[v])
+    og = None
+    for v in range(k):
+        gv = rc.backward(octx[v], npy(gpix[v]))
+        og = gv if og is None else {key: (None if og[key] is None else og[key] + gv[key]) for key in og}
+    mine = _leaves(inp, True, False)
+    colors, _ = _views(inp, batches, mine, bgc.to(DEV), True, False)
+    (colors * gpix.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    for v in range(k):
+        ok, mx, mxm, nm = pars[v].image(npy(colors[v]), oimg[v])
+        assert ok, (v, mx, mxm, nm)
+    par = pars[0]                                            # (both views were masked: every Gaussian is held to the strict bar)
+    for key, okey in (("means3D", "means3D"), ("cov6", "cov3D"), ("opacities", "opacities"), ("shs", "shs")):
+        ok, excess, _, _ = par.grads(npy(mine[key].grad), og[okey])
+        assert ok, (key, excess)
+
+
+def test_batched_views_refusals_and_sizes():
+    import ctypes
+    from d3ga_amd import _lib
+    L = _lib.lib()
+    s1, s4 = (ctypes.c_int64 * 3)(), (ctypes.c_int64 * 3)()
+    assert L.d3ga_raster_scratch_bytes_views(1000, 640, 360, 1, 5000, 0, s1) == 0
+    assert L.d3ga_raster_scratch_bytes_views(1000, 640, 360, 4, 20000, 0, s4) == 0
+    assert s4[0] > 3 * s1[0] and s4[2] > 3 * s1[2]
+    assert L.d3ga_raster_scratch_bytes_views(1000, 640, 16 * 70000, 1, 5000, 0, s1) == -2        # tile rows are 16-bit fields
+    assert L.d3ga_raster_scratch_bytes_views(1000, 640, 360, -1, 5000, 0, s1) == -2
+    prm = _lib.RasterParams(P=16, M=0, sh_degree=0, W=64, H=64, tanfovx=1.0, tanfovy=1.0, scale_modifier=1.0, n_views=2)
+    buf = torch.zeros(1 << 22, dtype=torch.uint8, device=DEV)
+    p = ctypes.c_void_p(buf.data_ptr())
+    assert L.d3ga_raster_recolor(ctypes.byref(prm), p, None, p, p, p, ctypes.c_void_p(buf.data_ptr() + (1 << 21)), None) == -3      # D3GA_E_CONFIG
+    assert L.d3ga_raster_composite_fwd2(ctypes.byref(prm), p, p, p, p, p, 1024, p, p, p, None, None) == -3
