@@ -880,7 +880,8 @@ def batched_views_bench(frame, k, steps, burst):
     HIP events per stage.  Returns the `batched_views` object of the bench line: frames/s counts VIEWS (k per step)."""
     from d3ga_amd import rasterizer as R
     from d3ga_amd.graph import CapturedStep
-    from d3ga_amd.raster_views import CameraBatch, rasterize_gaussians_views
+    from d3ga_amd.raster_views import CameraBatch
+    from d3ga_amd.renderer import render_views
     dev, wl = frame.dev, frame.wl
     W, H = wl.width, wl.height
     nv = max(8, k)
@@ -891,9 +892,7 @@ def batched_views_bench(frame, k, steps, burst):
     params = list(frame.params.values())
 
     def step():
-        pkg = frame.upstream()
-        _, _, loss = rasterize_gaussians_views(pkg["means3D"], pkg["shs"], None, pkg["opacity_logits"], None, None, pkg["cov3D_precomp"],
-                                               cams, frame.bg, sh_degree=frame.sh_degree, opacity_activation="sigmoid", l1_targets=targets)
+        loss = render_views(None, frame.upstream(), frame.bg, targets=targets, cameras=cams)["l1"]
         loss.backward(one)
         return loss
 
@@ -1295,7 +1294,19 @@ def main():
         for _ in range(args.steps):
             one_step()
         torch.cuda.synchronize()
+        stages_burst = R.stage_timer.summary()
+        # ... and the same pass with ONE launch per event pair (launches 2..R of a burst find the lists warm in L2 / the
+        # Infinity Cache, so the burst figure is the kernel's duration on warm caches; the lone launch also carries the dispatch
+        # latency of a packet on an idle queue -- the truth for the captured step lies between them, rocprofv3's trace of the
+        # same command is the third opinion under profiles/)
+        R.stage_timer.reset()
+        R.stage_timer.burst = {}
+        for _ in range(args.steps):
+            one_step()
+        torch.cuda.synchronize()
+        stages_single = R.stage_timer.summary()
         R.stage_timer.enabled = False
+        R.stage_timer.reset()
 
     # the reference-faithful training step (RGB + silhouette render), reported beside the headline frame
     train = None
@@ -1424,7 +1435,7 @@ def main():
         wl = frame.wl
         P, W, H, D = wl.n_gaussians, frame.batch["width"], frame.batch["height"], cnt_end["D"]
         M = frame.params["features"].shape[1]
-        stages = R.stage_timer.summary()
+        stages = stages_burst if not args.no_stage_events else {}
         alg = {   # algorithmic bytes per launch
             "preprocess": P * (88 + 12 * M),
             "bin_sort": 36 * D + 8 * (math.ceil(W / 16) * math.ceil(H / 16)),
@@ -1436,6 +1447,10 @@ def main():
                        "achieved_GBs": round(alg[k] / (ms * 1e-3) / 1e9, 1),
                        "frac_hbm_peak": round(alg[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                    for k, (n, ms) in stages.items() if k in alg}
+        if not args.no_stage_events:
+            for k in kernels:
+                if k in stages_single:
+                    kernels[k]["ms_single_launch"] = round(stages_single[k][1], 4)
         # HBM traffic of the compositing kernels from the committed rocprofv3 --pmc passes of this same command
         # (bench.py --pmc -> profiles/pmc_<workload>.json): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH doubled per the gfx950
         # correction of MI355X_MICROARCH.md.  None when no PMC summary for this workload is present.

@@ -228,6 +228,39 @@ class _LbsCage(torch.autograd.Function):
         return g_t, g_d, None, None, None, None, None
 
 
+def skeleton_matrices(bind_state, target_states):
+    """(B,J,4,4) joint matrices for `lbs_cage` from Goliath-style skeleton states (translation 3 | quaternion xyzw 4 | scale 1):
+    M_j = T_target,j . T_bind,j^-1 -- what lbsmodel/body_model.py:350-387 (states_to_matrix) hands to LinearBlendSkinning.skinning
+    (:208-234), whose (V,8) skin_indices / skin_weights buffers are `lbs_cage`'s skin_idx / skin_w as they are.  A few dozen joints
+    per pose: plain torch on whatever device the states live on.  bind_state (1,J,8) | (J,8), target_states (B,J,8) | (J,8)."""
+    def split(s):
+        return s[..., 0:3], s[..., 3:7] / s[..., 3:7].norm(dim=-1, keepdim=True), s[..., 7:8]
+
+    def qmul(a, b):                                        # Hamilton product, xyzw
+        av, aw, bv, bw = a[..., :3], a[..., 3:], b[..., :3], b[..., 3:]
+        return torch.cat([aw * bv + bw * av + torch.cross(av, bv, dim=-1), aw * bw - (av * bv).sum(-1, keepdim=True)], -1)
+
+    def qrot(q, v):
+        qv, qw = q[..., :3], q[..., 3:]
+        c = torch.cross(qv, v, dim=-1)
+        return v + 2.0 * (qw * c + torch.cross(qv, c, dim=-1))
+    bt, bq, bs = split(bind_state)
+    tt, tq, ts = split(target_states)
+    bq_inv = bq * bq.new_tensor([-1.0, -1.0, -1.0, 1.0])
+    q = qmul(tq, bq_inv)                                   # rotation of the composed map
+    sc = ts / bs                                           # its scale
+    t = tt - sc * qrot(q, bt.expand_as(tt) if bt.dim() == tt.dim() else bt)      # x -> sc R(q) (x - t_bind) + t_target
+    x, y, z, w = q.unbind(-1)
+    R = torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                     torch.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                     torch.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], -2)
+    M = torch.zeros(q.shape[:-1] + (4, 4), dtype=q.dtype, device=q.device)
+    M[..., :3, :3] = R * sc[..., None]
+    M[..., :3, 3] = t
+    M[..., 3, 3] = 1.0
+    return M
+
+
 def lbs_cage(template, delta, joint_mats, skin_idx, skin_w, Rh=None, Th=None):
     """K-sparse linear blend skinning of cage vertices: (sum_k w_k A[idx_k]) [v+delta;1], then .Rh^T + Th
     (lib/smplman.py:155-171).  Differentiable in template and delta (the deformation_field output when

@@ -490,10 +490,16 @@ class DeformationField(FieldMLP):
         capture, where embed_const() must not answer from its cache (the reference's ShadowDecoder keeps its embedded template the
         same way).  None: forget it."""
         self._const_src = canonical
+        self._const_ver = None if canonical is None else canonical._version
         self._const_emb = None if canonical is None else embed(canonical.detach())
 
     def forward(self, canonical, pose):
         if canonical is getattr(self, "_const_src", None) and not canonical.requires_grad:
+            if canonical._version != self._const_ver:      # written in place since (load_state_dict, buffer.copy_): same object, new values
+                if canonical.is_cuda and torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("DeformationField: the tensor given to set_constant_input() was modified in place; call "
+                                       "set_constant_input() again before capturing")
+                self.set_constant_input(canonical)
             z = self._const_emb
         else:
             z = embed_const(canonical)

@@ -57,6 +57,31 @@ def render_l1(batch, pkg, bg_color, target, grad_sync=None):
     return render(batch, pkg, bg_color, grad_sync=grad_sync, _l1=target)
 
 
+def render_views(batches, pkg, bg_color, targets=None, cameras=None):
+    """k cameras of ONE package in one pass (extension; the reference renders one camera per call and averages the losses of a
+    batch of frames, train.py:218-221): -> {"render": (k,3,H,W)} and, with targets (k,3,H,W), "l1" = the mean over the views of
+    `l1_loss(render, target)`, its gradient formed inside the compositing backward.  Every image equals `render(batch_v, pkg,
+    bg_color)["render"]`, the gradients equal the sum over the k calls (d3ga_amd/raster_views.py).  The views share the raster
+    size and must not be cropped (lib/batch.py:186-198: centred principal point).  cameras: a `raster_views.CameraBatch` to
+    reuse (a captured step keeps one and calls `cameras.set(batches)` before every replay); batches may then be None."""
+    from .raster_views import CameraBatch, rasterize_gaussians_views
+    means3D = pkg["means3D"]
+    if cameras is None:
+        for b in batches:
+            c = b["crop"]
+            if int(c[4]) != int(b["width"]) or int(c[5]) != int(b["height"]):
+                raise ValueError("render_views: a view with an off-centre crop -- use render() per view")
+        cameras = CameraBatch(len(batches), int(batches[0]["width"]), int(batches[0]["height"]), device=means3D.device).set(batches)
+    opacities, act = pkg.get("opacities"), None
+    if opacities is None and pkg.get("opacity_logits") is not None:
+        opacities, act = pkg["opacity_logits"], "sigmoid"
+    shs = pkg["shs"]
+    out = rasterize_gaussians_views(means3D, shs, None if shs is not None else pkg["rgb"], opacities, pkg.get("scales"),
+                                    pkg.get("rotations"), pkg.get("cov3D_precomp"), cameras, bg_color,
+                                    sh_degree=pkg["sh_degree"] if "sh_degree" in pkg else 0, opacity_activation=act, l1_targets=targets)
+    return {"render": out[0], "l1": out[2]} if targets is not None else {"render": out[0]}
+
+
 def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_bg=True, fast=False, detach=[],
            grad_sync=None, _pair=None, _l1=None):
     means3D = pkg["means3D"]
@@ -81,31 +106,24 @@ def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_
         antialiasing=False,
     )
 
-    cov3D_precomp = pkg.get("cov3D_precomp")
-    scales = pkg.get("scales")
-    rotations = pkg.get("rotations")
-    opacities = pkg.get("opacities")
+    # what the rasterizer is handed (renderer.py:95-120): geometry as packaged; `detach` names inputs whose gradient is cut
+    # ("position", "covariance", "opacity": the silhouette pass of models/trainer.py:104-110); the colour is the explicit
+    # `colors_precomp` if given, else the package's SH coefficients, else its RGB
+    geo = {k: pkg.get(k) for k in ("cov3D_precomp", "scales", "rotations", "opacities")}
     # extension: a package may carry the raw `opacity_logits` instead of activated `opacities` (models/cage_net.py:247
     # applies sigmoid in Python): the activation then runs inside the per-Gaussian kernels, forward and backward
     act = None
-    if opacities is None and pkg.get("opacity_logits") is not None:
-        opacities, act = pkg["opacity_logits"], "sigmoid"
-    shs = pkg["shs"]
-
-    if len(detach) > 0:
-        if "position" in detach:
-            means3D = means3D.detach()
-        if "covariance" in detach:
-            cov3D_precomp = cov3D_precomp.detach()
-        if "opacity" in detach:
-            opacities = opacities.detach()
-
-    if colors_precomp is None:
+    if geo["opacities"] is None and pkg.get("opacity_logits") is not None:
+        geo["opacities"], act = pkg["opacity_logits"], "sigmoid"
+    cut = {"position": "means3D", "covariance": "cov3D_precomp", "opacity": "opacities"}
+    geo["means3D"] = means3D
+    for name in detach:
+        if name in cut:
+            geo[cut[name]] = geo[cut[name]].detach()
+    means3D, cov3D_precomp, scales, rotations, opacities = (geo[k] for k in ("means3D", "cov3D_precomp", "scales", "rotations", "opacities"))
+    shs = pkg["shs"] if colors_precomp is None else None
+    if colors_precomp is None and shs is None:
         colors_precomp = pkg["rgb"]
-        if shs is not None:
-            colors_precomp = None
-    else:
-        shs = None
 
     # screen-space points: a zero tensor whose .grad receives dL/d(mean2D) (renderer.py:122-128).  A fresh leaf over a
     # cached block of zeros: no fill kernel per render (the rasterizer never reads or writes its values)

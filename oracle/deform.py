@@ -96,3 +96,28 @@ def lbs_cage(template, delta, joint_mats, skin_idx, skin_w, Rh=None, Th=None):
     if Th is not None:
         out = out + Th
     return out
+
+
+def skeleton_matrices(bind_state, target_states):
+    """Per-joint skinning matrices of Goliath's body model: target transform composed with the inverse bind transform.
+
+    Follows lbsmodel/body_model.py:350-387 (states_to_matrix).  A skeleton state is (translation 3 | unit quaternion xyzw 4 |
+    scale 1) per joint, i.e. x -> s R(q) x + t.  bind_state (1,J,8), target_states (B,J,8) -> (B,J,4,4) homogeneous matrices
+    M = T_target . T_bind^-1 (the reference returns the top 3x4 block).  Written with rotation matrices instead of the
+    reference's quaternion algebra -- the same map."""
+    def rot(q):                                            # xyzw unit quaternion -> (..., 3, 3)
+        x, y, z, w = q.unbind(-1)
+        return torch.stack([
+            torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+            torch.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+            torch.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], -2)
+
+    def homo(state):
+        t, q, sc = state[..., 0:3], state[..., 3:7], state[..., 7:8]
+        q = q / q.norm(dim=-1, keepdim=True)
+        M = torch.zeros(state.shape[:-1] + (4, 4), dtype=state.dtype)
+        M[..., :3, :3] = rot(q) * sc[..., None]
+        M[..., :3, 3] = t
+        M[..., 3, 3] = 1.0
+        return M
+    return homo(target_states) @ torch.linalg.inv(homo(bind_state))

@@ -190,3 +190,73 @@ def test_shard_views_covers_everything():
     for n, w in ((8, 8), (8, 2), (5, 2), (3, 4)):
         got = sorted(v for r in range(w) for v in shard_views(n, r, w))
         assert got == list(range(n))
+
+
+def _eight_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from d3ga_amd import dist as dd
+    r, _, w = dd.init_process_group(backend="gloo")
+    ok = (r, w) == (rank, world)
+    ok = ok and dd.shard_views(world, rank, world) == [rank]
+    # per-tensor reducer: the mean over the ranks' views = the mean of `world` sequential views
+    torch.manual_seed(0)
+    params = [torch.randn(5, 3, requires_grad=True), torch.randn(7, requires_grad=True)]
+    red = dd.GradReducer(params)
+    red.zero()
+    sum(((rank + 1.0) * p).sum() for p in params).backward()
+    red.all_reduce_mean()
+    expect = sum(v + 1.0 for v in range(world)) / world
+    ok = ok and all(torch.allclose(p.grad, torch.full_like(p, expect)) for p in params)
+    # the cut exchange of the SH path: a planar buffer summed (x 1 / world), and the (P + 1, 3) colour factor of EVERY rank
+    # gathered in rank order (row P carries the rank's camera position) -- what d3ga_sh_grad_from_views rebuilds dL/dsh from
+    sync = dd.ViewShardedGrads()
+    ok = ok and sync.world == world and abs(sync.scale - 1.0 / world) < 1e-12
+    P = 6
+    flat = torch.full((P * 4,), float(rank + 1))
+    factor = torch.full((P + 1, 3), float(100 * (rank + 1)))
+    factor[P] = torch.tensor([float(rank), 0.5, -1.0])
+    gathered = sync.exchange(flat, factor)
+    ok = ok and tuple(gathered.shape) == (world, P + 1, 3)
+    ok = ok and torch.allclose(flat, torch.full((P * 4,), expect))
+    ok = ok and torch.allclose(gathered[:, 0, 0], 100.0 * torch.arange(1, world + 1, dtype=torch.float32))
+    ok = ok and torch.allclose(gathered[:, P, 0], torch.arange(world, dtype=torch.float32))
+    # bucketed reducer (the ColorField configuration): equals the sequential mean over `world` views
+    torch.manual_seed(0)
+    net = torch.nn.Linear(6, 4)
+    feat = torch.randn(10, 6, requires_grad=True)
+    bred = dd.BucketedGradReducer([net.parameters(), [feat]])
+    loss_of = lambda view: (net(feat * (view + 1.0)) ** 2).mean()
+    bred.begin_step()
+    loss_of(rank).backward()
+    ok = ok and bred.finish() == 2
+    mine = [p.grad.clone() for p in list(net.parameters()) + [feat]]
+    bred.close()
+    for p in list(net.parameters()) + [feat]:
+        p.grad = None
+    (sum(loss_of(v) for v in range(world)) / world).backward()
+    ref = [p.grad.clone() for p in list(net.parameters()) + [feat]]
+    ok = ok and all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(mine, ref))
+    out[rank] = bool(ok)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_reducers_and_the_cut_exchange_at_eight_ranks():
+    """nothing rank-count dependent had run above N = 2.  The reducers, the cut exchange (all-reduce + the
+    all-gather of eight colour factors in rank order) and the bucketed reducer at world_size 8 over gloo on CPU: the
+    reduced gradients equal the mean of eight sequential views."""
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        out = m.dict()
+        procs = [ctx.Process(target=_eight_worker, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(240)
+            assert p.exitcode == 0
+        assert dict(out) == {r: True for r in range(world)}

@@ -530,6 +530,12 @@ def test_field_trunk_node_and_embed_cache():
     assert torch.equal(df(x, pose), a)
     df.set_constant_input(None)
     assert torch.equal(df(x, pose), a)
+    # an in-place update of the promised tensor (load_state_dict, buffer.copy_) keeps the object: the cached embedding
+    # must not survive it
+    df.set_constant_input(x)
+    x.mul_(1.5)
+    fresh = df(x.clone(), pose)
+    assert torch.equal(df(x, pose), fresh) and not torch.equal(fresh, a)
 
 
 @pytest.mark.parametrize("P,F", [(1, 4), (777, 64), (5000, 24), (300, 0)])
@@ -558,3 +564,28 @@ def test_color_rows_equal_encoding_and_cat(P, F):
     f3 = f.clone().requires_grad_(True)                      # ... and the other way round
     _ColorRows.apply(d, f3).backward(up)
     assert torch.equal(f3.grad, f1.grad)
+
+
+@pytest.mark.parametrize("P,F", [(777, 64), (5000, 24)])
+def test_color_rows_against_the_oracle_in_f64(P, F):
+    """d3ga_color_rows_fwd / _bwd against the ORACLE (oracle/mlp.py: sh4_direction_encoding, the restatement the ColorField
+    golden was generated with) evaluated in float64 with autograd -- not against another HIP kernel.
+    Values to float32 rounding; the direction gradient element-wise under the 1e-3 relative bar, with the float32 noise of its
+    16-term sums of cancelling products as the absolute floor (1e-5 of the largest element)."""
+    from oracle import mlp as om
+    from d3ga_amd.mlp import _ColorRows
+    from util import elementwise_excess
+    g = torch.Generator().manual_seed(7 * P + F)
+    d = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    d = 0.5 * (d + 1.0)                                      # the encoding's input lives in [0, 1] (models/cage_net.py:233-235 + tcnn's 2x - 1)
+    f = torch.randn(P, F, generator=g)
+    up = torch.randn(P, 16 + F, generator=g)
+    d1, f1 = d.to(DEV).requires_grad_(True), f.to(DEV).requires_grad_(True)
+    x = _ColorRows.apply(d1, f1)
+    x.backward(up.to(DEV))
+    d64, f64 = d.double().requires_grad_(True), f.double().requires_grad_(True)
+    ref = torch.cat([om.sh4_direction_encoding(d64), f64], dim=1)
+    ref.backward(up.double())
+    np.testing.assert_allclose(x.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-6)
+    assert elementwise_excess(d1.grad.cpu().numpy(), d64.grad.numpy(), atol_rel=1e-5) <= 1.0
+    np.testing.assert_array_equal(f1.grad.cpu().numpy(), up[:, 16:].numpy())

@@ -8,7 +8,7 @@ import torch
 from oracle import bary as ob
 from oracle import deform as od
 from oracle import raster_c as rc
-from util import Parity, conditioning_noise, rel_err, sampled_allowance_excess, scene_inputs
+from util import Parity, conditioning_noise, elementwise_excess, rel_err, sampled_allowance_excess, scene_inputs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -26,7 +26,8 @@ def test_library_loaded_and_row_scans():
     import d3ga_amd
     from d3ga_amd._lib import check, dptr, stream_handle
     L = d3ga_amd.lib()
-    assert L.d3ga_version() == 104
+    from d3ga_amd._lib import ABI_VERSION
+    assert L.d3ga_version() == ABI_VERSION
     x = torch.randn(256 * 8, device=DEV)
     out = torch.full((256 * 8, 8), float("nan"), device=DEV)
     check(L.d3ga_selftest_row_scan(x.numel(), dptr(x), dptr(out), stream_handle()), "selftest")
@@ -51,16 +52,19 @@ def test_cage_deform_matches_reference_golden(golden):
         np.testing.assert_allclose(_np(means), g["means3D"], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(_np(cov6), g["cov3D_precomp"], rtol=5e-4, atol=1e-10)
         ((means * t("up_grad_means").to(DEV)).sum() + (cov6 * t("up_grad_cov").to(DEV)).sum()).backward()
-        assert rel_err(_np(tp.grad), g["grad_tetpoints"]) < 1e-3
-        assert rel_err(_np(b.grad), g["grad_barys"]) < 1e-3
+        # element-wise (the north star's gradient tolerance is RELATIVE).  The vertex gradient is a sum over every
+        # Gaussian of the adjacent tets, formed in float32 by the reference as well (its golden carries that noise): its absolute
+        # floor is 1e-5 of the largest element instead of the 1e-6 of the per-Gaussian outputs
+        assert elementwise_excess(_np(tp.grad), g["grad_tetpoints"], atol_rel=1e-5) <= 1.0, (name, elementwise_excess(_np(tp.grad), g["grad_tetpoints"], atol_rel=1e-5))
+        assert elementwise_excess(_np(b.grad), g["grad_barys"]) <= 1.0, (name, elementwise_excess(_np(b.grad), g["grad_barys"]))
         # scales / rotations: oracle autograd in float64
         d = lambda k: torch.from_numpy(g[k]).double().requires_grad_(True)
         s64, r64 = d("scales"), d("rotations")
         m, c = od.cage_deform(t("tetpoints").double(), t("tetras"), t("tetra_id"), t("canon_barys").double(),
                               t("canonical_gradient").double(), s64, r64)
         ((m * t("up_grad_means").double()).sum() + (c * t("up_grad_cov").double()).sum()).backward()
-        assert rel_err(_np(s.grad), _np(s64.grad)) < 1e-3
-        assert rel_err(_np(r.grad), _np(r64.grad)) < 1e-3
+        assert elementwise_excess(_np(s.grad), _np(s64.grad)) <= 1.0, (name, elementwise_excess(_np(s.grad), _np(s64.grad)))
+        assert elementwise_excess(_np(r.grad), _np(r64.grad)) <= 1.0, (name, elementwise_excess(_np(r.grad), _np(r64.grad)))
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_DEFORM_FUZZ_N", "5"))))
@@ -102,7 +106,8 @@ def test_cage_deform_fuzz(seed):
     assert rel_err(_np(c), c64.detach().numpy()) < 1e-4, tag
     for mine, ref, name in ((tp.grad, tp64.grad, "tetpoints"), (b.grad, b64.grad, "barys"), (sr.grad, s64.grad, "scales"),
                             (r.grad, r64.grad, "rot")) + (((db.grad, d64.grad, "dbary"),) if fused else ()):
-        assert rel_err(_np(mine), ref.numpy()) < 1e-3, (tag, name)
+        ex = elementwise_excess(_np(mine), ref.numpy(), atol_rel=1e-5 if name == "tetpoints" else 1e-6)      # (the vertex gradient is a long float32 sum)
+        assert ex <= 1.0, (tag, name, ex)
 
 
 def test_lbs_and_fem_match_oracle(golden):
@@ -121,7 +126,7 @@ def test_lbs_and_fem_match_oracle(golden):
     w = torch.randn(out.shape, generator=torch.Generator().manual_seed(3))
     (out * w.to(DEV)).sum().backward()
     (ref * w.double()).sum().backward()
-    assert rel_err(_np(delta.grad), _np(d64.grad)) < 1e-5
+    assert elementwise_excess(_np(delta.grad), _np(d64.grad)) <= 1.0
     # golden LBS case from the reference's Smplman.deform (dense weights as K = J table)
     g = golden("lbs_case.npz")
     V, J = g["weights"].shape
@@ -130,6 +135,22 @@ def test_lbs_and_fem_match_oracle(golden):
                   torch.from_numpy(g["A"]).to(DEV), idx.to(DEV), torch.from_numpy(g["weights"]).to(DEV),
                   torch.from_numpy(g["Rh"]).to(DEV), torch.from_numpy(g["Th"]).to(DEV))
     np.testing.assert_allclose(_np(o2), g["out"], rtol=1e-5, atol=1e-5)
+    # golden from the reference's SECOND skinning form, Goliath's 8-sparse LinearBlendSkinning.skinning on states_to_matrix
+    # (lbsmodel/body_model.py:208-234, 350-387): the (V,8) index / weight buffers are lbs_cage's arguments as they are; the
+    # joint matrices come from d3ga_amd.cage_deform.skeleton_matrices; values and the gradient w.r.t. the vertices, element-wise
+    from d3ga_amd.cage_deform import skeleton_matrices
+    gg = golden("lbs_goliath_case.npz")
+    tg = lambda k: torch.from_numpy(gg[k]).to(DEV)
+    mats = skeleton_matrices(tg("bind_state"), tg("target_states"))
+    np.testing.assert_allclose(_np(mats[:, :, :3, :]), gg["mat"], rtol=1e-5, atol=2e-6)
+    verts = _cu(torch.from_numpy(gg["vertices"]), True)
+    tot = 0.0
+    for bi in range(gg["target_states"].shape[0]):
+        o3 = lbs_cage(verts, None, mats[bi].contiguous(), tg("skin_indices"), tg("skin_weights"))
+        np.testing.assert_allclose(_np(o3), gg["out"][bi], rtol=1e-5, atol=1e-5)
+        tot = tot + (o3 * tg("grad_out")[bi]).sum()
+    tot.backward()
+    assert elementwise_excess(_np(verts.grad), gg["grad_vertices"]) <= 1.0, elementwise_excess(_np(verts.grad), gg["grad_vertices"])
     # FEM
     gd = golden("deform_case0.npz")
     tp = _cu(torch.from_numpy(gd["tetpoints"]), True)
@@ -139,7 +160,7 @@ def test_lbs_and_fem_match_oracle(golden):
     e64 = od.fem_energy(tp64, torch.from_numpy(gd["tetras"]), torch.from_numpy(gd["Dn_inv"]).double())
     e.mean().backward()
     e64.mean().backward()
-    assert rel_err(_np(tp.grad), _np(tp64.grad)) < 1e-4
+    assert elementwise_excess(_np(tp.grad), _np(tp64.grad), atol_rel=1e-5) <= 1.0, elementwise_excess(_np(tp.grad), _np(tp64.grad), atol_rel=1e-5)
 
 
 def _settings(inp, bg, sh_degree, mod=1.0):

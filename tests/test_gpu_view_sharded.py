@@ -175,7 +175,7 @@ def _worker(rank, world, port, out):
     digest = torch.stack([p.grad.double().sum() for p in mine.params.values()]).cpu()
     both = [torch.zeros_like(digest) for _ in range(world)]
     torch.distributed.all_gather(both, digest)
-    same = bool(torch.allclose(both[0], both[1], rtol=1e-6, atol=0))
+    same = all(bool(torch.allclose(both[0], b, rtol=1e-6, atol=0)) for b in both[1:])
     # the same step as two hipGraphs with the exchange issued eagerly between them (d3ga_amd.graph.CapturedCutStep)
     from d3ga_amd import rasterizer as R
     from d3ga_amd.graph import CapturedCutStep
@@ -193,9 +193,13 @@ def _worker(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_gloo_full_chain():
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_on_one_gpu_gloo_full_chain(world):
+    """world = 8: SURVEY sec. 8e's determinism row as written -- "8 views on 1 GPU sequentially vs 8 ranks" -- with the
+    eight ranks sharing the test box's GPU over gloo: every rank's reduced gradients equal the mean of the eight per-view
+    gradients, on every rank alike, eagerly and through the two-graph cut step."""
     import torch.multiprocessing as mp
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as m:
         out = m.dict()
@@ -203,13 +207,13 @@ def test_two_ranks_one_gpu_gloo_full_chain():
         for p in procs:
             p.start()
         for p in procs:
-            p.join(300)
+            p.join(600)
             assert p.exitcode == 0
         res = dict(out)
-    assert set(res) == {0, 1}
+    assert set(res) == set(range(world))
     for r in range(world):
         err, same, nbytes = res[r]
-        assert err < 1e-5, res
+        assert err < (1e-5 if world == 2 else 1e-4), res      # (eight float32 summands in another order)
         assert same, res
         assert nbytes > 0
 

@@ -175,3 +175,25 @@ def test_field_oracle_matches_reference_fields(golden):
     grads = torch.autograd.grad([rgb, opa], [feat, pose, vd, frame], [torch.from_numpy(g["col_up0"]), torch.from_numpy(g["col_up1"])])
     for gr, k in zip(grads, ("col_g_feat", "col_g_pose", "col_g_viewdir", "col_g_frame")):
         np.testing.assert_allclose(gr.numpy(), g[k], rtol=1e-4, atol=1e-6)
+
+
+def test_goliath_skinning_golden(golden):
+    """D0's second cited source (lbsmodel/body_model.py:208-234 LinearBlendSkinning.skinning on :350-387 states_to_matrix, the
+    8-sparse form): the oracle's skeleton_matrices + lbs_cage and the product's host-side skeleton_matrices against the fixture
+    tools/gen_golden.py (G8) generated by calling the reference's own functions."""
+    from d3ga_amd.cage_deform import skeleton_matrices
+    g = golden("lbs_goliath_case.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    M = od.skeleton_matrices(t("bind_state").double(), t("target_states").double())
+    np.testing.assert_allclose(M[:, :, :3, :].numpy(), g["mat"], rtol=1e-5, atol=3e-6)
+    assert float((M[:, :, 3, :] - torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=torch.float64)).abs().max()) < 1e-12
+    Mh = skeleton_matrices(t("bind_state"), t("target_states"))
+    np.testing.assert_allclose(Mh[:, :, :3, :].numpy(), g["mat"], rtol=1e-5, atol=3e-6)
+    v = t("vertices").double().requires_grad_(True)
+    tot = 0.0
+    for b in range(g["target_states"].shape[0]):
+        out = od.lbs_cage(v, None, M[b], t("skin_indices"), t("skin_weights").double())
+        np.testing.assert_allclose(out.detach().numpy(), g["out"][b], rtol=1e-5, atol=3e-6)
+        tot = tot + (out * t("grad_out")[b].double()).sum()
+    tot.backward()
+    np.testing.assert_allclose(v.grad.numpy(), g["grad_vertices"], rtol=1e-4, atol=2e-6)

@@ -13,6 +13,16 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def elementwise_excess(a, b, rtol=1e-3, atol_rel=1e-6):
+    """The element-wise gradient bar of the rasterizer tests (Parity.grads) for any pair of tensors: the worst ratio
+    |a - b| / (rtol |b| + atol_rel max|b|) -- <= 1 passes.  BASELINE.md states the gradient tolerance as 1e-3 RELATIVE; the
+    absolute term only keeps elements that are zero up to rounding (1e-6 of the largest element) from dividing by nothing."""
+    b = np.asarray(b, np.float64)
+    a = np.asarray(a, np.float64).reshape(b.shape)
+    allow = rtol * np.abs(b) + atol_rel * (np.abs(b).max() + 1e-300)
+    return float((np.abs(a - b) / allow).max()) if b.size else 0.0
+
+
 def scene_inputs(name="T0", seed=17, azimuth=0.4, scale_mult=1.0, cx=None, cy=None, width=None, height=None):
     """CPU tensors for one frame: oracle-deformed Gaussians + camera of a synthetic workload."""
     sc = syn.make_scene(name, seed=seed)

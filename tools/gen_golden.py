@@ -15,6 +15,8 @@ called as they are:
   G5 SH       utils.sh_utils constants                                     -> sh_consts.npz
   G6 lbs      lib.smplman.Smplman.deform (unbound)                         -> lbs_case.npz
   G7 ply      models.cage_net.CageNet.describe_ply / get_ply (unbound)     -> ply_case.npz
+  G8 lbs (Goliath)  lbsmodel.body_model.states_to_matrix + LinearBlendSkinning.skinning (unbound; 8-sparse
+              indices / weights) + autograd gradient w.r.t. the vertices          -> lbs_goliath_case.npz
 The only stand-in with numerical content is ``Tetra.gradient`` (un-vendored tetra_sampler): it is
 written here as the column-edge matrix of lib/tet_mesh.py:88-94 (the reference's in-tree analogue).
 """
@@ -340,6 +342,36 @@ def gen_lbs(smplman_mod):
              delta=delta.numpy(), Rh=Rh_mat.numpy(), Th=Th[0].numpy(), out=out[0].numpy())
 
 
+def gen_lbs_goliath(bm):
+    """lbsmodel/body_model.py:208-234 (LinearBlendSkinning.skinning, called unbound on a namespace that holds the 8-sparse
+    skin_indices / skin_weights buffers) on top of :350-387 (states_to_matrix): seeded bind / target skeleton states
+    (translation 3 | quaternion xyzw 4 | scale 1), J = 30 joints, two poses; the skinned vertices, the (J,3,4) matrices and the
+    reference's autograd gradient w.r.t. the vertices for a fixed upstream gradient."""
+    g = torch.Generator().manual_seed(29)
+    V, J, K, B = 600, 30, 8, 2
+
+    def states(n):
+        q = torch.randn(n, J, 4, generator=g)
+        q = q / q.norm(dim=2, keepdim=True)
+        t = torch.randn(n, J, 3, generator=g) * 0.5
+        sc = torch.exp(0.2 * torch.randn(n, J, 1, generator=g))
+        return torch.cat([t, q, sc], dim=2)
+    bind, target = states(1), states(B)
+    idx = torch.randint(0, J, (V, K), generator=g)
+    w = torch.rand(V, K, generator=g)
+    w[:, 5:] = 0.0                                   # rows with fewer than 8 influences carry zero weights (the file format pads)
+    w = w / w.sum(1, keepdim=True)
+    verts = torch.randn(1, V, 3, generator=g).requires_grad_(True)
+    ns = SimpleNamespace(skin_indices=idx, skin_weights=w)
+    mat = bm.states_to_matrix(bind, target)
+    out = bm.LinearBlendSkinning.skinning(ns, bind, verts, target)
+    gout = torch.randn(out.shape, generator=g)
+    (out * gout).sum().backward()
+    np.savez(os.path.join(OUT, "lbs_goliath_case.npz"), bind_state=bind.numpy(), target_states=target.numpy(),
+             skin_indices=idx.numpy().astype(np.int32), skin_weights=w.numpy(), vertices=verts.detach()[0].numpy(),
+             mat=mat.detach().numpy(), out=out.detach().numpy(), grad_out=gout.numpy(), grad_vertices=verts.grad[0].numpy())
+
+
 def gen_losses(loss_utils):
     """utils/loss_utils.py: l1_loss (:29) and ssim (:59-86) of the reference on seeded images, values and autograd
     gradients w.r.t. the first image (sizes chosen to cross tile borders of the HIP kernel: not multiples of 16)."""
@@ -503,6 +535,10 @@ def main():
     if sys.argv[1:] == ["ply"]:                 # one section only (the other fixtures are left untouched)
         gen_ply(cn)
         return
+    if sys.argv[1:] == ["lbs_goliath"]:
+        import lbsmodel.body_model as bm
+        gen_lbs_goliath(bm)
+        return
     gen_ply(cn)
     gen_camera(cameras_mod)
     gen_cov(gu)
@@ -515,6 +551,8 @@ def main():
     import models.mlp as mlp_mod
     gen_fields(mlp_mod)
     gen_lbs(smplman_mod)
+    import lbsmodel.body_model as bm
+    gen_lbs_goliath(bm)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
