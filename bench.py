@@ -709,6 +709,53 @@ def field_mlp_bench(args):
     print(json.dumps(out))
 
 
+def field_mlp_summary(P, dev, steps=20, warmup=5):
+    """The `field_mlp` object of the default bench line: CanonicalField (models/mlp.py:74-110: 109 -> 128 x 4 -> 11 with the 98 pose
+    columns folded into the first bias) forward + backward to inputs AND weights over the workload's P Gaussians -- the unit that is
+    85 % of the reference-faithful training step.  Here the matrix cores are the right roofline: every f32
+    product is six bf16 MFMA products (exact 3-way split), so the MFMA work is 6 x the f32-equivalent FLOPs; peak = the dense bf16
+    rate of MI355X_MICROARCH.md (2.5 PFLOP/s).  The HBM side of the same launches is reported beside it (the weight gradients and
+    the per-layer outputs are HBM-bound)."""
+    from d3ga_amd.mlp import CanonicalField
+    torch.manual_seed(17)
+    cf = CanonicalField().to(dev)
+    g = torch.Generator().manual_seed(17)
+    barys = torch.rand(P, 4, generator=g).to(dev).requires_grad_(True)
+    rots = torch.randn(P, 4, generator=g).to(dev).requires_grad_(True)
+    scales = (0.1 * torch.randn(P, 3, generator=g)).to(dev).requires_grad_(True)
+    pose = (0.3 * torch.randn(98, generator=g)).to(dev)
+    leaves = list(cf.parameters()) + [barys, rots, scales]
+
+    def step():
+        for t in leaves:
+            t.grad = None
+        o = cf(rots, scales, barys, pose)
+        (o[0].sum() + o[1].sum() + o[2].sum()).backward()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    flops = 3 * 2.0 * P * (11 * 128 + 3 * 128 * 128 + 128 * 11)         # forward + input-gradient + weight-gradient GEMMs, f32-equivalent
+    widths = [11, 128, 128, 128, 128, 11]
+    fwd_b = 4 * widths[0] + sum(4 * b for b in widths[1:]) + 16 * 4      # fused forward: input once, every layer's output once, sign bits
+    dx_b = sum(4 * (a + b) for a, b in zip(widths[:-1], widths[1:])) + 16 * 4
+    wg_b = sum(4 * (a + b) for a, b in zip(widths[:-1], widths[1:]))
+    hbm = float(P) * (fwd_b + dx_b + wg_b)
+    mfma_tf = 6.0 * flops / (ms * 1e-3) / 1e12
+    return {"unit_of_work": f"CanonicalField forward + backward (inputs and weights), {P} rows, 109 -> 128 x 4 -> 11, f32-equivalent",
+            "ms": round(ms, 4), "rows_per_s": round(P / (ms * 1e-3), 1), "f32_equivalent_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+            "roofline": {"bound": "mfma", "achieved": round(mfma_tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(mfma_tf / 2500.0, 4),
+                         "traffic": None, "note": "6 bf16 MFMA products per f32 product (exact 3-way split, v_mfma_f32_32x32x16_bf16); "
+                                                  "peak = dense bf16, MI355X_MICROARCH.md"},
+            "hbm": {"alg_bytes": int(hbm), "achieved_GBs": round(hbm / (ms * 1e-3) / 1e9, 1), "frac_hbm_peak": round(hbm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+
 def color_train_bench(args):
     """`--train-step color`: BASELINE configs[3] -- the actor02-shaped training step on N ranks (camera sharding, parameter-level
     gradient exchange: the rasterizer's inputs are view-dependent there, so the cut exchange of the SH frame is invalid)."""
@@ -1316,7 +1363,7 @@ def main():
             frame.train_step()
         assert not R.last_counters()["overflow"]
         torch.cuda.synchronize()
-        n_ts = max(5, args.steps // 2)
+        n_ts = max(20, args.steps)      # (eager steps are host-bound: a 10-step window is mostly pipeline start-up)
 
         def timed_train(captured=False, **kw):
             """ms per training step (a new camera + target every step): median of three runs of n_ts steps (an occasional host
@@ -1536,6 +1583,11 @@ def main():
         }
         if train is not None:
             out["training_step"] = train
+        if world == 1 and not args.no_train_step:
+            try:
+                out["field_mlp"] = field_mlp_summary(P, dev, steps=args.steps)
+            except Exception as e:  # noqa: BLE001
+                out["field_mlp"] = {"error": repr(e)}
         if world == 1 and args.batch_views > 1 and not args.force_cut:
             try:
                 out["batched_views"] = batched_views_bench(frame, int(args.batch_views), args.steps, args.stage_burst)

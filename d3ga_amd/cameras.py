@@ -57,6 +57,27 @@ class Camera:
         self.tanfovy = math.tan(self.FoVy * 0.5)
 
     @staticmethod
+    def pack_host_cached(batch):
+        """pack_host of a batch's camera (+ the two tangents: 53 floats), cached on the numbers that define it: a capture rig has a
+        few hundred cameras and a trainer draws them again and again (datasets/actorshq_dataset.py:229) -- three 4x4 inversions in
+        numpy cost ~60 us of host time per step otherwise (tools/prof_host.py, round 6)."""
+        R = np.ascontiguousarray(np.asarray(batch["R"], dtype=np.float64))
+        T = np.ascontiguousarray(np.asarray(batch["T"], dtype=np.float64))
+        key = (R.tobytes(), T.tobytes(), float(batch["FoVx"]), float(batch["FoVy"]))
+        hit = _host_cache.get(key)
+        if hit is None:
+            hit = np.empty(53, dtype=np.float32)
+            hit[:51] = Camera.pack_host(R, T, batch["FoVx"], batch["FoVy"])
+            hit[51] = math.tan(float(batch["FoVx"]) * 0.5)
+            hit[52] = math.tan(float(batch["FoVy"]) * 0.5)
+            _host_cache[key] = hit
+            if len(_host_cache) > _CACHE_MAX:
+                _host_cache.popitem(last=False)
+        else:
+            _host_cache.move_to_end(key)
+        return hit
+
+    @staticmethod
     def pack_host(R, T, FoVx, FoVy):
         """The 51 float32 numbers of a camera on the HOST: view (16) | projection (16) | full projection (16) | centre (3)."""
         wv = _view_matrix(R, T).T.copy()
@@ -101,7 +122,10 @@ class CameraSlot:
         if dev.type == "cuda":
             self._ring = [t.pin_memory() for t in self._ring]
         self._host_cam = torch.zeros(53, dtype=torch.float32)   # what the device holds / will hold: re-sent with every copy
+        self._host_cam_np = self._host_cam.numpy()              # (numpy views of the host tensors: an element write through torch costs ~2 us)
+        self._ring_np = [t.numpy() for t in self._ring]
         self._host_cells = torch.zeros(max(self.n_cells, 1), dtype=torch.int64)
+        self._host_cells_np = self._host_cells.numpy()
         self._cells_dirty = False
         self.world_view_transform = self.matrices[0:16].view(4, 4)
         self.projection_matrix = self.matrices[16:32].view(4, 4)
@@ -118,7 +142,7 @@ class CameraSlot:
 
     def stage_cell(self, i, address):
         """Host side of a TensorSlot living in this slot: the address goes out with the next `set()` / `flush()`."""
-        self._host_cells[i] = int(address)
+        self._host_cells_np[i] = int(address)
         self._cells_dirty = True
 
     def flush(self):
@@ -128,9 +152,10 @@ class CameraSlot:
         if self._events[i] is not None:
             self._events[i].synchronize()                      # the copy that last read this staging buffer has run
         stage = self._ring[i]
-        stage[:212].view(torch.float32).copy_(self._host_cam)
+        snp = self._ring_np[i]
+        snp[:212].view(np.float32)[:] = self._host_cam_np
         if self.n_cells:
-            stage[self._CAM_BYTES:].view(torch.int64).copy_(self._host_cells[:self.n_cells])
+            snp[self._CAM_BYTES:].view(np.int64)[:] = self._host_cells_np[:self.n_cells]
         self.buffer.copy_(stage, non_blocking=True)
         self._cells_dirty = False
         if self.buffer.is_cuda:
@@ -143,14 +168,12 @@ class CameraSlot:
         if int(batch["width"]) != self.image_width or int(batch["height"]) != self.image_height:
             raise ValueError(f"CameraSlot is {self.image_width}x{self.image_height}; the batch is "
                              f"{batch['width']}x{batch['height']} (one slot / captured step per raster size)")
-        host = Camera.pack_host(batch["R"], batch["T"], batch["FoVx"], batch["FoVy"])
-        self._host_cam[:51] = torch.from_numpy(host)
-        self._host_cam[51] = math.tan(float(batch["FoVx"]) * 0.5)
-        self._host_cam[52] = math.tan(float(batch["FoVy"]) * 0.5)
+        self._host_cam_np[:] = Camera.pack_host_cached(batch)
         return self.flush()
 
 
 _cache = OrderedDict()
+_host_cache = OrderedDict()
 _CACHE_MAX = 512
 
 

@@ -10,7 +10,6 @@ single-view backwards.
     rasterize_gaussians_views(...)           -> (colors (k,3,H,W), radii (k,P), loss | None)
 """
 import ctypes
-import math
 
 import torch
 
@@ -36,6 +35,7 @@ class CameraBatch:
         self._host = torch.zeros(37 * k, dtype=torch.float32)
         if self.buffer.is_cuda:
             self._host = self._host.pin_memory()
+        self._host_np = self._host.numpy()
         self._event = None
 
     def set(self, batches):
@@ -45,18 +45,17 @@ class CameraBatch:
             raise ValueError(f"CameraBatch holds {k} cameras, got {len(batches)}")
         if self._event is not None:
             self._event.synchronize()                 # the copy that last read the staging buffer has run
-        h = self._host
+        h = self._host_np
         for v, b in enumerate(batches):
             if int(b["width"]) != self.image_width or int(b["height"]) != self.image_height:
                 raise ValueError(f"CameraBatch is {self.image_width}x{self.image_height}; view {v} is {b['width']}x{b['height']}")
-            m = Camera.pack_host(b["R"], b["T"], b["FoVx"], b["FoVy"])        # view (16) | projection (16) | full (16) | centre (3)
-            h[16 * v:16 * v + 16] = torch.from_numpy(m[0:16])
-            h[16 * k + 16 * v:16 * k + 16 * v + 16] = torch.from_numpy(m[32:48])
+            m = Camera.pack_host_cached(b)        # view (16) | projection (16) | full (16) | centre (3) | tan(FoVx/2), tan(FoVy/2)
+            h[16 * v:16 * v + 16] = m[0:16]
+            h[16 * k + 16 * v:16 * k + 16 * v + 16] = m[32:48]
             o = 32 * k + 5 * v
-            h[o:o + 3] = torch.from_numpy(m[48:51])
-            h[o + 3] = math.tan(float(b["FoVx"]) * 0.5)
-            h[o + 4] = math.tan(float(b["FoVy"]) * 0.5)
-        self.buffer.copy_(h, non_blocking=True)
+            h[o:o + 3] = m[48:51]
+            h[o + 3:o + 5] = m[51:53]
+        self.buffer.copy_(self._host, non_blocking=True)
         if self.buffer.is_cuda:
             self._event = torch.cuda.Event()
             self._event.record()

@@ -166,16 +166,25 @@ class StageTimer:
 stage_timer = StageTimer()
 
 
+_scratch_sizes = {}
+
+
 def _scratch(P, W, H, cap, device, forward_only=False, binning=True):
     """(geom, binning, img) byte tensors.  forward_only: the img buffer without the per-block lists of the backward
     (128 B per duplicate of capacity -- several hundred MB per render at a few million duplicates); binning=False: None
     for the binning buffer (a geometry-cache hit shares the first pass's)."""
-    sizes = (ctypes.c_int64 * 3)()
-    L = _lib.lib()
-    check(L.d3ga_raster_scratch_bytes(P, W, H, cap, sizes), "d3ga_raster_scratch_bytes")
-    img_bytes = int(L.d3ga_raster_img_bytes(W, H, cap, 1)) if forward_only else int(sizes[2])
-    new = lambda n: torch.empty(int(n), dtype=torch.uint8, device=device)
-    return [new(sizes[0]), new(sizes[1]) if binning else None, new(img_bytes)]
+    key = (P, W, H, cap, bool(forward_only))
+    sz = _scratch_sizes.get(key)
+    if sz is None:                                   # (two ctypes calls per render otherwise: the sizes of a training loop never change)
+        sizes = (ctypes.c_int64 * 3)()
+        L = _lib.lib()
+        check(L.d3ga_raster_scratch_bytes(P, W, H, cap, sizes), "d3ga_raster_scratch_bytes")
+        img_bytes = int(L.d3ga_raster_img_bytes(W, H, cap, 1)) if forward_only else int(sizes[2])
+        if len(_scratch_sizes) > 64:
+            _scratch_sizes.clear()
+        sz = _scratch_sizes[key] = (int(sizes[0]), int(sizes[1]), img_bytes)
+    new = lambda n: torch.empty(n, dtype=torch.uint8, device=device)
+    return [new(sz[0]), new(sz[1]) if binning else None, new(sz[2])]
 
 
 def _f32(t, device):

@@ -4,7 +4,7 @@ solid_bg=True, fast=False, detach=[]) -> {"render": (3,H',W')}` (renderer.py:69-
 import torch
 
 from .cameras import batch_to_camera
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_l1, rasterize_gaussians_pair
+from .rasterizer import GaussianRasterizationSettings, rasterize_gaussians, rasterize_gaussians_l1, rasterize_gaussians_pair
 
 bg_colors = {"white": (1.0, 1.0, 1.0), "black": (0.0, 0.0, 0.0)}
 
@@ -142,15 +142,13 @@ def render(batch, pkg, bg_color, colors_precomp=None, measure_time=False, solid_
         img, _radii, _invd, loss = rasterize_gaussians_l1(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                                           cov3D_precomp, settings, _l1, grad_sync, act, want_invdepth=False)
         return {"render": img, "l1": loss}
-    rasterizer = GaussianRasterizer(raster_settings=settings)
-    rasterizer.opacity_activation = act
-    rasterizer.want_invdepth = False                # only [0] of the rasterizer's outputs is used here (renderer.py:141)
-    if grad_sync is not None:                       # extension over upstream's constructor: set only when asked for
-        rasterizer.grad_sync = grad_sync
+    # the operator behind upstream's `GaussianRasterizer(raster_settings)(...)` module call (renderer.py:130-141), without
+    # building an nn.Module per render: its constructor and attribute writes cost ~25 us of host time per call, a sixth of an
+    # eager render's enqueue time (tools/prof_host.py); the module class stays available for callers that use it themselves
     if measure_time:
         torch.cuda.synchronize()
-    rendered = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
-                          opacities=opacities, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)[0]
+    rendered = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings,
+                                   grad_sync, act, want_invdepth=False)[0]     # only [0] of the rasterizer's outputs is used here (renderer.py:141)
     if measure_time:
         torch.cuda.synchronize()
     return {"render": paste(rendered, crop)}

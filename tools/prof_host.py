@@ -9,9 +9,16 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
 mode = sys.argv[2] if len(sys.argv) > 2 else "frame"
 f = bench.Frame(wl, torch.device("cuda", 0), 0)
 R.set_accumulator_policy("persistent")
+cycle = mode.endswith("_cycle")       # a new camera and target every step, as bench.py's eager training step does it
+mode = mode.replace("_cycle", "")
 step = {"frame": f.step, "train": f.train_step, "pair": lambda: f.train_step(pair=True)}[mode]
+views = f.camera_cycle() if cycle else None
+it = [0]
 def run(n):
     for _ in range(n):
+        if cycle:
+            b, t = views[it[0] % len(views)]; it[0] += 1
+            f.target.copy_(t, non_blocking=True); f.target_slot.set(t); f.slot.set(b)
         for p in f.params.values(): p.grad = None
         step()
 run(3)
