@@ -345,7 +345,7 @@ def collect_pmc(args):
         d = tempfile.mkdtemp(prefix=f"d3ga_pmc_{name}_", dir="/tmp")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--kernel-include-regex", "d3ga", "--output-format", "csv",
                "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "5",
-               "--warmup", "3", "--no-cpu-baseline", "--no-train-step", "--no-stage-events", "--no-graph", "--fixed-camera",
+               "--warmup", "3", "--no-cpu-baseline", "--no-train-step", "--no-stage-events", "--no-graph", "--fixed-camera", "--batch-views", "0",
                "--scale-mult", str(args.scale_mult), "--fill", str(args.fill)]
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
         files = glob.glob(os.path.join(d, "**", "pmc_counter_collection.csv"), recursive=True)
@@ -930,9 +930,9 @@ def batched_views_bench(frame, k, steps, burst):
     from d3ga_amd.raster_views import CameraBatch
     from d3ga_amd.renderer import render_views
     dev, wl = frame.dev, frame.wl
-    W, H = wl.width, wl.height
     nv = max(8, k)
-    batches = [frame.syn.make_batch(W, H, azimuth=2 * math.pi * v / nv, camera_id=v, fill=frame.fill) for v in range(k)]
+    batches = [frame.syn.make_batch(wl.width, wl.height, azimuth=2 * math.pi * v / nv, camera_id=v, fill=frame.fill) for v in range(k)]
+    W, H = int(batches[0]["width"]), int(batches[0]["height"])      # (the raster: an odd image width is padded to the symmetric frustum, lib/batch.py:186-198)
     cams = CameraBatch(k, W, H, device=dev).set(batches)
     targets = torch.stack([torch.rand(3, H, W, generator=torch.Generator().manual_seed(100 + v)) for v in range(k)]).to(dev)
     one = torch.ones((), device=dev)

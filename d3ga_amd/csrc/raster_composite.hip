@@ -389,7 +389,7 @@ extern "C" int d3ga_selftest_alpha(int32_t P, const void *geom, int n, const int
 }
 
 #ifdef D3GA_DIAG
-extern "C" int d3ga_diag_fwd_read(unsigned long long *out8, unsigned long long *waves, int n, int reset) {
+extern "C" __attribute__((visibility("default"))) int d3ga_diag_fwd_read(unsigned long long *out8, unsigned long long *waves, int n, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_diag_fwd), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
     if (waves && n > 0 && hipMemcpyFromSymbol(waves, HIP_SYMBOL(g_diag_fwd_waves), sizeof(unsigned long long) * 4 * (size_t)n) != hipSuccess) return 1;
     if (reset) {

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256 * R, D3GA_TILE_WAVES) void composite_bwd_tile_k
 }
 
 #ifdef D3GA_DIAG
-extern "C" int d3ga_diag_scan_read(unsigned long long *out16, int reset) {
+extern "C" __attribute__((visibility("default"))) int d3ga_diag_scan_read(unsigned long long *out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag_scan), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
     if (reset) {
         unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -547,7 +547,7 @@ extern "C" int d3ga_diag_scan_read(unsigned long long *out16, int reset) {
     }
     return 0;
 }
-extern "C" int d3ga_diag_scan_waves(unsigned long long *out, int n) {      // n <= 32768 records of 4 words
+extern "C" __attribute__((visibility("default"))) int d3ga_diag_scan_waves(unsigned long long *out, int n) {      // n <= 32768 records of 4 words
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_waves), sizeof(unsigned long long) * 4 * (size_t)n) != hipSuccess;
 }
 #endif

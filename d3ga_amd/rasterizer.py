@@ -167,6 +167,7 @@ stage_timer = StageTimer()
 
 
 _scratch_sizes = {}
+_prm_cache = {}          # parameter blocks by value (never mutated: the backward copies one when it needs another acc_self_clearing)
 
 
 def _scratch(P, W, H, cap, device, forward_only=False, binning=True):
@@ -192,7 +193,7 @@ def _f32(t, device):
         return None
     if t.dtype != torch.float32 or t.device != device:
         t = t.to(device=device, dtype=torch.float32)
-    return t.contiguous()
+    return t if t.is_contiguous() else t.contiguous()
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -282,11 +283,18 @@ class _RasterizeGaussians(torch.autograd.Function):
                                  "camera slot (tanfovx = tanfovy = 0 with a 5-float campos: cameras.CameraSlot) reads them from the device")
         # no input requires a gradient (inference, torch.no_grad): the forward skips the per-block lists of the backward
         fwd_only = not any(ctx.needs_input_grad[:8])
-        prm = RasterParams(P=P, M=M, sh_degree=int(s.sh_degree), W=W, H=H, tanfovx=tfx,
-                           tanfovy=tfy, scale_modifier=float(s.scale_modifier),
-                           antialiasing=int(bool(s.antialiasing)), prefiltered=int(bool(s.prefiltered)),
-                           debug=int(bool(s.debug)), opacity_activation=_ACTIVATIONS[opacity_activation],
-                           forward_only=int(fwd_only))
+        # (the parameter block of a training loop repeats: building the ctypes structure costs ~6 us of an ~80 us host-bound render)
+        pkey = (P, M, int(s.sh_degree), W, H, tfx, tfy, float(s.scale_modifier), bool(s.antialiasing), bool(s.prefiltered), bool(s.debug),
+                opacity_activation, fwd_only)
+        prm = _prm_cache.get(pkey)
+        if prm is None:
+            if len(_prm_cache) > 64:
+                _prm_cache.clear()
+            prm = _prm_cache[pkey] = RasterParams(P=P, M=M, sh_degree=int(s.sh_degree), W=W, H=H, tanfovx=tfx,
+                                                  tanfovy=tfy, scale_modifier=float(s.scale_modifier),
+                                                  antialiasing=int(bool(s.antialiasing)), prefiltered=int(bool(s.prefiltered)),
+                                                  debug=int(bool(s.debug)), opacity_activation=_ACTIVATIONS[opacity_activation],
+                                                  forward_only=int(fwd_only))
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         # fused L1 image loss (rasterize_gaussians_l1): the loss VALUE is formed by the compositing forward while the colours
         # are in registers (d3ga_raster_composite_fwd_l1: one partial per quadrant, then one small sum), its gradient inside
@@ -370,6 +378,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                       # detached aliases: they pin the storage without keeping an autograd graph alive
                                       "pins": tuple(None if t is None else t.detach() for t in geo_inputs)}
         ctx.prm = prm
+        ctx.pkey = pkey
         ctx.cap = cap
         ctx.has_means2D = means2D is not None
         ctx.grad_sync = grad_sync if (grad_sync is not None and (grad_sync.world > 1 or getattr(grad_sync, "always", False)) and P > 0) else None
@@ -420,8 +429,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         acc, self_clearing = _accumulator(P, dev)
         if self_clearing != bool(prm.acc_self_clearing):
-            prm = RasterParams(**{f: getattr(prm, f) for f, _ in RasterParams._fields_})       # (ctx.prm is shared with a retained graph)
-            prm.acc_self_clearing = int(self_clearing)
+            # (ctx.prm is shared -- a retained graph, the cache of parameter blocks: the variant is a block of its own, cached too)
+            key2 = (ctx.pkey, self_clearing)
+            p2 = _prm_cache.get(key2)
+            if p2 is None:
+                p2 = RasterParams(**{f: getattr(prm, f) for f, _ in RasterParams._fields_})
+                p2.acc_self_clearing = int(self_clearing)
+                _prm_cache[key2] = p2
+            prm = p2
         from_sr = cov3Ds_precomp is None
         sync = ctx.grad_sync
         if sync is None:

@@ -50,11 +50,16 @@ for src, dst in (("bench_color_train.log", f"{tag}_bench_color_train_C4.json"), 
     f = os.path.join(ROOT, "gpurun_out", src)
     if os.path.exists(f) and os.path.getsize(f) > 10:
         shutil.copy(f, os.path.join(ROOT, "profiles", dst))
-for f in glob.glob(os.path.join(ROOT, "gpurun_out", "fwd_impl_*.log")):                  # round 5: the opt-in two-launch forward beside the default
-    if os.path.getsize(f) > 10:
-        shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_" + os.path.basename(f).replace(".log", ".json")))
-for src, dst in (("kstats_lists.txt", f"{tag}_two_launch_forward_kernel_stats.txt"), ("diag_lists_summary.txt", f"{tag}_two_launch_forward_timeline.txt")):
+for src, dst in (("bench_C3_views2.log", f"{tag}_bench_C3_views2.json"), ("bench_C3_views8.log", f"{tag}_bench_C3_views8.json"),
+                 ("pmc_C3_views4.json", f"{tag}_pmc_C3_views4.json"), ("prof_mlp_summary.txt", f"{tag}_field_mlp_summary.txt"),
+                 ("pytest_gpu.log", f"{tag}_pytest_gpu_tail.txt"), ("driver_like.log", f"{tag}_driver_like.log")):
     f = os.path.join(ROOT, "gpurun_out", src)
     if os.path.exists(f) and os.path.getsize(f) > 10:
         shutil.copy(f, os.path.join(ROOT, "profiles", dst))
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", "prof_views", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_views4_{wl}_kernel_stats.csv"))
+for m in ("frame_cycle", "train_cycle", "pair_cycle"):
+    f = os.path.join(ROOT, "gpurun_out", f"prof_host_{m}.txt")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_host_profile_{m}.txt"))
 print(sorted(os.listdir(os.path.join(ROOT, "profiles"))))

@@ -21,4 +21,4 @@ e0.record()
 for _ in range(30): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 30
-print(f"D3GA_WGRAD_WS={os.environ.get('D3GA_WGRAD_WS','(default)')} P={P}: {ms*1e3:.1f} us  {2*P*512/ms/1e6:.0f} GB/s  rel err dW {err:.2e} db {errb:.2e}")
+print(f"D3GA_KNOBS={os.environ.get('D3GA_KNOBS','(defaults)')} P={P}: {ms*1e3:.1f} us  {2*P*512/ms/1e6:.0f} GB/s  rel err dW {err:.2e} db {errb:.2e}")
