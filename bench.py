@@ -130,6 +130,7 @@ class Frame:
         self.canon, self.tetras, self.tetra_id = d(sc["canon_points"]), d(sc["tetras"]), d(sc["tetra_id"])
         self.barys0 = d(sc["barys"])
         self.joint_mats, self.skin_idx, self.skin_w = d(sc["joint_mats"]), d(sc["skin_idx"]), d(sc["skin_w"])
+        self.joint_pos = sc["joint_pos"].numpy()
         # the inverse canonical gradient per GAUSSIAN, as the reference stores it (lib/cage.py:329): the drop-in layout is the one
         # that is timed.  --canon-grad per-tet: one matrix per TETRAHEDRON read through tetra_id (extension, round 4)
         self.canon_grad_mode = canon_grad
@@ -993,6 +994,94 @@ def batched_views_bench(frame, k, steps, burst):
             "stage_events": f"separate eager pass, same K steps; compositing kernels launched {burst}x back to back per event pair"}
 
 
+def batched_frames_bench(frame, k, steps):
+    """The reference-faithful training step over a BATCH of k frames -- k poses, k cameras, RGB + silhouette render per frame, losses as
+    train.py:190-193 averaged over the batch (train.py:218-221) -- as ONE view-batched rasterizer pass with per-frame geometry
+    (d3ga_raster_params::per_view_geometry; LBS + cage deform per frame, one grid per rasterizer stage, the SSIM / L1 kernels over the
+    3k channels) against the same k frames stepped one after the other (`Frame.train_step(pair=True)`, gradients accumulated).  One
+    captured hipGraph each; ms per FRAME."""
+    import numpy as np
+    from d3ga_amd import rasterizer as R
+    from d3ga_amd.cage_deform import lbs_cage_deform
+    from d3ga_amd.graph import CapturedStep
+    from d3ga_amd.losses import l1_loss, l1_ssim
+    from d3ga_amd.raster_views import CameraBatch
+    from d3ga_amd.renderer import render_pair, render_views
+    dev, wl, p = frame.dev, frame.wl, frame.params
+    joint_pos = frame.joint_pos
+    poses = [torch.from_numpy(frame.syn.pose_matrices(joint_pos, np.random.default_rng(1000 + v))).to(dev) for v in range(k)]
+    batches = [frame.syn.make_batch(wl.width, wl.height, azimuth=2 * math.pi * v / max(8, k), camera_id=v, fill=frame.fill) for v in range(k)]
+    W, H = int(batches[0]["width"]), int(batches[0]["height"])
+    cams = CameraBatch(k, W, H, device=dev).set(batches)
+    targets = torch.stack([torch.rand(3, H, W, generator=torch.Generator().manual_seed(100 + v)) for v in range(k)]).to(dev)
+    sil_t = (targets.mean(1, keepdim=True) > 0.5).float().expand(-1, 3, -1, -1).contiguous()
+    P = frame.barys0.shape[0]
+    sil_rgb, bg0, lam = torch.ones(P, 3, device=dev), torch.zeros(3, device=dev), 0.2
+    params = list(p.values())
+
+    def package(A):
+        means, cov6, _ = lbs_cage_deform(frame.canon, p["delta_node"], A, frame.skin_idx, frame.skin_w, frame.tetras, frame.tetra_id,
+                                         frame.barys0, frame.canon_grad, p["scaling"], p["rotation"], delta_barys=p["delta_bary"],
+                                         scale_activation="exp", gradient_per_tet=frame.canon_grad_mode == "per-tet")
+        return {"means3D": means, "cov3D_precomp": cov6, "opacity_logits": p["opacity"], "shs": p["features"], "rgb": None,
+                "sh_degree": frame.sh_degree}
+
+    def losses(img, sil, tgt, sil_tgt):
+        rgb_l1, rgb_ssim = l1_ssim(img, tgt)
+        return (1.0 - lam) * rgb_l1 + lam * (1.0 - rgb_ssim) + l1_loss(sil, sil_tgt)
+
+    def step_batched():
+        out = render_views(None, [package(A) for A in poses], frame.bg, cameras=cams, colors2=sil_rgb, bg_color2=bg0)
+        loss = losses(out["render"].view(3 * k, H, W), out["render2"].view(3 * k, H, W), targets.view(3 * k, H, W), sil_t.view(3 * k, H, W))
+        loss.backward()
+        return loss
+
+    def step_sequential():
+        tot = None
+        for v in range(k):
+            both = render_pair(batches[v], package(poses[v]), frame.bg, sil_rgb, bg0)
+            loss = losses(both["render"], both["render2"], targets[v], sil_t[v]) / k
+            loss.backward()
+            tot = loss.detach() if tot is None else tot + loss.detach()
+        return tot
+
+    def zero():
+        for q in params:
+            q.grad = None
+    res = {}
+    for name, fn in (("batched", step_batched), ("sequential", step_sequential)):
+        R.set_capacity_policy("auto")
+        for _ in range(3):
+            zero(); fn()
+        torch.cuda.synchronize()
+        cap = int(R.last_counters()["D"] * 1.3) + 4096
+        R.set_capacity_policy("static", cap)
+        zero(); fn()
+        torch.cuda.synchronize()
+        graph = CapturedStep(fn, params=params)
+        for _ in range(10):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        res[name] = (1e3 * (time.perf_counter() - t0) / steps, float(graph.result.detach()), graph.check_overflow())
+        grads = {n: q.grad.detach().clone() for n, q in p.items() if q.grad is not None}
+        res[name + "_grads"] = grads
+        del graph
+    ga, gb = res["batched_grads"], res["sequential_grads"]
+    agree = max(float((ga[n] - gb[n]).abs().max() / (gb[n].abs().max() + 1e-30)) for n in gb)
+    mb, ms_ = res["batched"][0], res["sequential"][0]
+    return {"frames": k, "step": "k poses x k cameras: LBS + cage deform per frame, RGB + silhouette of all frames in one view-batched pass "
+                                 "(per-frame geometry), 0.8 L1 + 0.2 (1 - SSIM) on RGB + L1 on the silhouette averaged over the batch, the whole "
+                                 "backward; one hipGraph replay per step",
+            "ms_per_step": round(mb, 4), "ms_per_frame": round(mb / k, 4), "frames_per_s": round(k * 1e3 / mb, 1),
+            "sequential_ms_per_step": round(ms_, 4), "sequential_ms_per_frame": round(ms_ / k, 4),
+            "speedup_over_sequential": round(ms_ / mb, 3), "loss_batched": round(res["batched"][1], 6),
+            "loss_sequential": round(res["sequential"][1], 6), "max_rel_gradient_difference": float(f"{agree:.2e}"), "steps": steps}
+
+
 def _self_launch(n):
     """`python bench.py --gpus N` WITHOUT a launcher (WORLD_SIZE unset): re-exec this command line under
     `python -m torch.distributed.run`, one rank per GPU, exactly as the driver launches N > 1 -- a plain invocation must
@@ -1593,6 +1682,11 @@ def main():
                 out["batched_views"] = batched_views_bench(frame, int(args.batch_views), args.steps, args.stage_burst)
             except Exception as e:  # noqa: BLE001  (an extra regime must never take the headline down)
                 out["batched_views"] = {"error": repr(e)}
+            if not args.no_train_step:
+                try:
+                    out["batched_frames"] = batched_frames_bench(frame, int(args.batch_views), max(10, args.steps // 2))
+                except Exception as e:  # noqa: BLE001
+                    out["batched_frames"] = {"error": repr(e)}
         if args.init_timing:
             try:
                 out["init"] = init_timing(frame)

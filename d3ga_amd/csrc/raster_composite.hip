@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64, (DUAL ? D3GA_FWD_DUAL_WAVES : D3GA_FWD_WAVES)) 
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ out_color,
     float *__restrict__ out_invdepth, const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2,
     const float *__restrict__ bg2, float *__restrict__ out_color2, uint2 *__restrict__ blk_list,
-    uint32_t *__restrict__ blk_count, bool exact_cull, L1Value l1v) {
+    uint32_t *__restrict__ blk_count, bool exact_cull, L1Value l1v, int P /* Gaussians per view: colors2 is indexed by Gaussian, the lists by (view, Gaussian) */) {
     const Quad q = tile_order ? quad_of_block_ordered(gx, gx * gy, gyv, tile_order) : quad_of_block(gx, gy, gyv);
     if (!q.valid) return;                                 // wave-uniform
     if (q.qx0 >= W || q.qy0 >= H) {                       // a quadrant without pixels: its L1 partial is zero
@@ -159,7 +159,10 @@ __global__ __launch_bounds__(64, (DUAL ? D3GA_FWD_DUAL_WAVES : D3GA_FWD_WAVES)) 
         if ((uint32_t)lane < bn) {
             bpg = s_ring[(qhead + (uint32_t)lane) % kRing];
             nxy = xy[2 * (size_t)bpg.y]; nco = conic_o[bpg.y]; nrgb = rgb_invd[bpg.y];
-            if constexpr (DUAL) nrgb2 = make_float4(colors2[3 * (size_t)bpg.y], colors2[3 * (size_t)bpg.y + 1], colors2[3 * (size_t)bpg.y + 2], 0.f);
+            if constexpr (DUAL) {
+                const size_t g2 = 3 * ((size_t)bpg.y - (size_t)q.view * (size_t)P);
+                nrgb2 = make_float4(colors2[g2], colors2[g2 + 1], colors2[g2 + 2], 0.f);
+            }
         }
         qhead = (qhead + bn) % kRing;
         qcount -= bn;
@@ -410,7 +413,6 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
     if (prm->P < 0 || prm->W <= 0 || prm->H <= 0 || d_capacity < 0) return D3GA_E_SIZE;
     if (colors2 && (!bg2 || !out_color2)) return D3GA_E_NULL;
     const int views = n_views_of(prm);
-    if (colors2 && views > 1) return D3GA_E_CONFIG;        // the second colour set is indexed by Gaussian, not by (view, Gaussian)
     hipStream_t s = (hipStream_t)stream;
     const int gx = tiles_x(prm->W), gyv = tiles_y(prm->H), gy = gyv * views;
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
@@ -423,7 +425,7 @@ static int composite_fwd_impl(const d3ga_raster_params *prm, const float *bg, co
 #define D3GA_LAUNCH_FWD(DUALV, DEPTHV, L1VV)                                                                                    \
     hipLaunchKernelGGL((composite_fwd_q_kernel<DUALV, DEPTHV, L1VV>), grid, dim3(64), 0, s, prm->W, prm->H, gx, gy, gyv, bin.tile_start, \
                        bin.point_list, (uint64_t)d_capacity, reinterpret_cast<const float2 *>(g.xyh), g.conic_o, g.rgb_invd, g.xyh, bg, im.final_T, im.n_contrib,     \
-                       out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact, l1v)
+                       out_color, out_invdepth, order, colors2, bg2, out_color2, im.blk_list, im.blk_count, exact, l1v, prm->P)
     if (colors2 && l1v.partials) return D3GA_E_CONFIG;
     if (colors2) { if (out_invdepth) D3GA_LAUNCH_FWD(true, true, false); else D3GA_LAUNCH_FWD(true, false, false); }
     else if (l1v.partials) { if (out_invdepth) D3GA_LAUNCH_FWD(false, true, true); else D3GA_LAUNCH_FWD(false, false, true); }
@@ -472,7 +474,6 @@ static int composite_bwd_impl(const d3ga_raster_params *prm, const float *bg, co
     if (l1.image && (!(l1.target || l1.target_cell) || !l1.g_loss)) return D3GA_E_NULL;
     if (colors2 && (!bg2 || !dL_dpix2)) return D3GA_E_NULL;
     const int views = n_views_of(prm);
-    if (colors2 && views > 1) return D3GA_E_CONFIG;
     const int gx = tiles_x(prm->W), gy = tiles_y(prm->H) * views;
     const BinBuf bin = carve_bin(const_cast<void *>(binning), (int64_t)gx * gy, d_capacity);
     const GeomBuf g = carve_geom(const_cast<void *>(geom), (int64_t)prm->P * views);

@@ -83,7 +83,7 @@ struct ScanEntry {          // one list entry as the lane that owns it holds it
 
 template <bool DUAL>
 __device__ __forceinline__ ScanEntry scan_gather(uint2 pg, const float2 *__restrict__ xy, const float4 *__restrict__ conic_o,
-                                                 const float4 *__restrict__ rgb_invd, const float *__restrict__ colors2) {
+                                                 const float4 *__restrict__ rgb_invd, const float *__restrict__ colors2 /* DUAL: already moved back by 3 x view x P (the lists hold (view, Gaussian) indices, colors2 is per Gaussian) */) {
     ScanEntry e;
     e.pos = pg.x; e.gid = pg.y;
     e.xy = make_float2(0.f, 0.f);
@@ -117,7 +117,7 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 // Everything the per-tile work of one wavefront reads (the kernels' pointer arguments, by value).
 struct BwdArgs {
-    int W, H, gx, gyv;       // gyv: tile rows per view (view-batched launches: composite_common.h, Quad)
+    int W, H, gx, gyv, P;    // gyv: tile rows per view (view-batched launches: composite_common.h, Quad); P: Gaussians per view
     const float2 *xy; const float4 *conic_o; const float4 *rgb_invd; const float *bg; const float *final_T; const uint32_t *n_contrib;
     const float *dL_dpix; float *acc; const float *colors2; const float *bg2; const float *dL_dpix2; const uint2 *blk_list;
     const uint32_t *blk_count; L1Source l1; const float *dL_dinvd;
@@ -197,12 +197,13 @@ __device__ __forceinline__ void bwd_tile_wave(const BwdArgs &A, const int tile, 
         v.x = (idx >= 0 && lseg < per) ? v.x : 0u;
         return v;
     };
-    ScanEntry e = scan_gather<DUAL>(list_entry(0), A.xy, A.conic_o, A.rgb_invd, A.colors2);
+    const float *const colors2v = DUAL ? A.colors2 - 3 * (size_t)view * (size_t)A.P : nullptr;
+    ScanEntry e = scan_gather<DUAL>(list_entry(0), A.xy, A.conic_o, A.rgb_invd, colors2v);
     uint2 pg1 = list_entry(1);
     __builtin_amdgcn_wave_barrier();
 
     for (int g = 0; g < ngroups; ++g) {
-        ScanEntry nxt = scan_gather<DUAL>(pg1, A.xy, A.conic_o, A.rgb_invd, A.colors2);
+        ScanEntry nxt = scan_gather<DUAL>(pg1, A.xy, A.conic_o, A.rgb_invd, colors2v);
         uint2 pg2 = list_entry(g + 2);
         const bool act = e.pos != 0u;
         const float exr = e.xy.x - bxr, eyr = e.xy.y - byr;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(256 * R, D3GA_TILE_WAVES) void composite_bwd_tile_k
     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
     float *__restrict__ acc, const uint32_t *__restrict__ tile_order, const float *__restrict__ colors2,
     const float *__restrict__ bg2, const float *__restrict__ dL_dpix2, const uint2 *__restrict__ blk_list,
-    const uint32_t *__restrict__ blk_count, int assign, L1Source l1, const float *__restrict__ dL_dinvd, int split_cap, const uint32_t *__restrict__ split_cnt) {
+    const uint32_t *__restrict__ blk_count, int assign, L1Source l1, const float *__restrict__ dL_dinvd, int split_cap, const uint32_t *__restrict__ split_cnt, int P) {
     static_assert((S & (S - 1)) == 0, "power of two");
     constexpr int NW = 4 * R;                        // wavefronts per tile (three, the third walking two sets of blocks: measured, slower -- DESIGN.md sec. 4)
     constexpr int SEG = 4 / R, LW = 16 * R;          // blocks per wavefront, lanes per block
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256 * R, D3GA_TILE_WAVES) void composite_bwd_tile_k
             const int by = assign ? 2 * (row >> 1) + (wave >> 1) : 2 * (wave >> 1) + (row >> 1);
             blk = 4 * ((bx >> 1) + 2 * (by >> 1)) + ((bx & 1) + 2 * (by & 1));
         }
-        const BwdArgs A = {W, H, gx, gyv, xy, conic_o, rgb_invd, bg, final_T, n_contrib, dL_dpix, acc, colors2, bg2, dL_dpix2, blk_list, blk_count, l1, dL_dinvd};
+        const BwdArgs A = {W, H, gx, gyv, P, xy, conic_o, rgb_invd, bg, final_T, n_contrib, dL_dpix, acc, colors2, bg2, dL_dpix2, blk_list, blk_count, l1, dL_dinvd};
         if (R == 1 && half >= 0) {
             blk = s_perm[2 * (2 * ((wave + (int)blockIdx.x) & 3) + (lane >> 5)) + half];
             bwd_tile_wave<DUAL, S, INVD, (R == 1 ? 2 : R)>(A, tile, begin, end, blk, s_cache, s_pix, s_dump, lane, dg);
@@ -569,7 +570,7 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
     hipLaunchKernelGGL((composite_bwd_tile_kernel<DUALV, SV, INVDV, RV>), tgrid, dim3(256 * RV),                                \
                        0, s, prm->W, prm->H, gx, gy, gy / n_views_of(prm), bin.tile_start, \
                        (uint64_t)d_capacity, reinterpret_cast<const float2 *>(g.xyh), g.conic_o, g.rgb_invd, bg, im.final_T, im.n_contrib, dL_dpix, acc, order,   \
-                       colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, composite_tile_assign(), l1, dL_dinvd, split_cap, split_cnt)
+                       colors2, bg2, dL_dpix2, (const uint2 *)im.blk_list, (const uint32_t *)im.blk_count, composite_tile_assign(), l1, dL_dinvd, split_cap, split_cnt, prm->P)
 #define D3GA_LAUNCH_TILE(DUALV, SV, INVDV)                                                                                    \
     D3GA_LAUNCH_TILE_R(DUALV, SV, INVDV, 1)
     if (dL_dinvd) {                                          // inverse-depth gradient (branch dr_aa): single-image launches only

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     const float *__restrict__ acc, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
     float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors,
     float *__restrict__ dL_dcov3D, float *__restrict__ dL_dscales, float *__restrict__ dL_drots,
-    const float *__restrict__ cov3D_precomp, bool accum /* views > 0 of a batch: add to the view-independent inputs' gradients */) {
+    const float *__restrict__ cov3D_precomp, int accum /* views > 0 of a batch: add to the gradients of inputs the views share (raster_pre_body.h) */) {
     if (!(prm.tanfovx > 0.f)) { prm.tanfovx = campos[3]; prm.tanfovy = campos[4]; }     // camera slot: see d3ga.h
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_sh = reinterpret_cast<float *>(smem);
@@ -431,8 +431,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
 // rebuilds   dL_dsh = scale * sum_v basis(dir_v) (x) g_v   here.  One thread per Gaussian, 48 accumulators in
 // registers, rows leave through the per-wavefront LDS slab (16 B/lane contiguous stores).
 __global__ __launch_bounds__(kBlock) void sh_grad_from_views_kernel(
-    int P, int M, int sh_degree, int n_views, const float *__restrict__ means3D, const float *__restrict__ g_views,
-    int64_t g_stride, const float *__restrict__ campos_views, int64_t campos_stride, float scale,
+    int P, int M, int sh_degree, int n_views, const float *__restrict__ means3D, int64_t means_stride /* floats between the views' means (0: shared) */,
+    const float *__restrict__ g_views, int64_t g_stride, const float *__restrict__ campos_views, int64_t campos_stride, float scale,
     float *__restrict__ dL_dsh) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_sh = reinterpret_cast<float *>(smem);
@@ -447,12 +447,12 @@ __global__ __launch_bounds__(kBlock) void sh_grad_from_views_kernel(
         float out[48];
 #pragma unroll
         for (int k = 0; k < 48; ++k) out[k] = 0.f;
-        const V3 mean = ld3(means3D, i);
         const int nb = (sh_degree + 1) * (sh_degree + 1);
         for (int v = 0; v < n_views; ++v) {
             const float *g = g_views + v * g_stride + 3 * (size_t)i;
             const float g0 = g[0], g1 = g[1], g2 = g[2];
             if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;        // culled / invisible / clamped in this view
+            const V3 mean = ld3(means3D + v * means_stride, i);
             const float *cp = campos_views + v * campos_stride;
             const V3 d0 = mean - v3(cp[0], cp[1], cp[2]);
             const float inv = 1.0f / sqrtf(dot(d0, d0));
@@ -528,16 +528,19 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     const int cam_stride = prm->tanfovx > 0.f ? 3 : 5;       // camera slots carry the two tangents behind the position
     // a batch of views: one launch per view into ITS records of the batch's buffers (the per-Gaussian stage is a streaming kernel
     // at the copy rate with nothing to gain from a taller grid; what the batch shares is everything downstream)
+    const size_t pv = (views > 1 && prm->per_view_geometry) ? (size_t)prm->P : 0;      // records between the views' geometry (0: shared)
     for (int v = 0; v < views; ++v) {
         const GeomBuf gv = geom_view(g, prm->P, v);
         const float *vm = viewmatrix + 16 * (size_t)v, *pm = projmatrix + 16 * (size_t)v, *cp = campos + (size_t)cam_stride * v;
+        const float *mv = means3D + 3 * pv * v, *sv = scales ? scales + 3 * pv * v : nullptr, *rq = rotations ? rotations + 4 * pv * v : nullptr;
+        const float *cv = cov3D_precomp ? cov3D_precomp + 6 * pv * v : nullptr;
         int32_t *rv = radii + (size_t)prm->P * v;
         if (want_j)
-            hipLaunchKernelGGL(preprocess_kernel<true>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
-                               colors_precomp, opacities, scales, rotations, cov3D_precomp, vm, pm, cp, gv, bin.tile_count, bin.counters, rv, v * gyv);
+            hipLaunchKernelGGL(preprocess_kernel<true>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, mv, shs,
+                               colors_precomp, opacities, sv, rq, cv, vm, pm, cp, gv, bin.tile_count, bin.counters, rv, v * gyv);
         else
-            hipLaunchKernelGGL(preprocess_kernel<false>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D, shs,
-                               colors_precomp, opacities, scales, rotations, cov3D_precomp, vm, pm, cp, gv, bin.tile_count, bin.counters, rv, v * gyv);
+            hipLaunchKernelGGL(preprocess_kernel<false>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, mv, shs,
+                               colors_precomp, opacities, sv, rq, cv, vm, pm, cp, gv, bin.tile_count, bin.counters, rv, v * gyv);
     }
     return check_launch(s, prm->debug & 0xff);
 }
@@ -588,7 +591,7 @@ extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const f
     if (views == 1) {
         hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D,
                            shs, scales, rotations, viewmatrix, projmatrix, campos, g, acc, dL_dmeans3D, dL_dmeans2D,
-                           dL_dopacity, dL_dsh, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots, cov3D_precomp, false);
+                           dL_dopacity, dL_dsh, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots, cov3D_precomp, 0);
         return check_launch(s, prm->debug);
     }
     // a batch of views (d3ga.h: n_views): one launch per view on ITS records; view 0 writes the gradients of the view-independent
@@ -596,18 +599,24 @@ extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const f
     // the (P,M,3) block is rebuilt ONCE from all of them -- 12 M bytes per Gaussian and batch instead of per view
     if (shs && !dL_dcolors) return D3GA_E_NULL;
     const int cam_stride = prm->tanfovx > 0.f ? 3 : 5;
+    const size_t pv = prm->per_view_geometry ? (size_t)prm->P : 0;      // a batch of frames: every view has its own geometry and geometry gradients
     for (int v = 0; v < views; ++v) {
-        const size_t o = (size_t)prm->P * v;
-        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D,
-                           shs, scales, rotations, viewmatrix + 16 * (size_t)v, projmatrix + 16 * (size_t)v, campos + (size_t)cam_stride * v,
-                           geom_view(g, prm->P, v), acc + D3GA_ACC_STRIDE * o, dL_dmeans3D, dL_dmeans2D ? dL_dmeans2D + 3 * o : nullptr,
-                           dL_dopacity, (float *)nullptr, shs ? dL_dcolors + 3 * o : dL_dcolors, dL_dcov3D, dL_dscales, dL_drots,
-                           cov3D_precomp, v > 0);
+        const size_t o = (size_t)prm->P * v, og = pv * v;
+        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D + 3 * og,
+                           shs, scales ? scales + 3 * og : nullptr, rotations ? rotations + 4 * og : nullptr, viewmatrix + 16 * (size_t)v,
+                           projmatrix + 16 * (size_t)v, campos + (size_t)cam_stride * v, geom_view(g, prm->P, v), acc + D3GA_ACC_STRIDE * o,
+                           dL_dmeans3D + 3 * og, dL_dmeans2D ? dL_dmeans2D + 3 * o : nullptr, dL_dopacity, (float *)nullptr,
+                           shs ? dL_dcolors + 3 * o : dL_dcolors, dL_dcov3D ? dL_dcov3D + 6 * og : nullptr,
+                           dL_dscales ? dL_dscales + 3 * og : nullptr, dL_drots ? dL_drots + 4 * og : nullptr,
+                           cov3D_precomp ? cov3D_precomp + 6 * og : nullptr, v > 0 ? (pv ? 1 : 3) : 0);
     }
     D3GA_TRY(check_launch(s, prm->debug));
-    if (shs && dL_dsh)
-        return d3ga_sh_grad_from_views(prm->P, prm->M, prm->sh_degree, views, means3D, dL_dcolors, 3 * (int64_t)prm->P, campos, cam_stride,
-                                       1.0f, dL_dsh, stream);
+    if (shs && dL_dsh) {
+        const size_t lds2 = ((3 * prm->M) % 4 == 0) ? kShLdsBytes : 0;
+        hipLaunchKernelGGL(sh_grad_from_views_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds2, s, prm->P, prm->M, prm->sh_degree,
+                           views, means3D, (int64_t)(3 * pv), dL_dcolors, 3 * (int64_t)prm->P, campos, (int64_t)cam_stride, 1.0f, dL_dsh);
+        return check_launch(s, prm->debug);
+    }
     return D3GA_OK;
 }
 
@@ -621,7 +630,7 @@ extern "C" int d3ga_sh_grad_from_views(int32_t P, int32_t M, int32_t sh_degree, 
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = ((3 * M) % 4 == 0) ? kShLdsBytes : 0;
     hipLaunchKernelGGL(sh_grad_from_views_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, P, M, sh_degree,
-                       n_views, means3D, g_views, g_stride, campos_views, campos_stride, scale, dL_dsh);
+                       n_views, means3D, (int64_t)0, g_views, g_stride, campos_views, campos_stride, scale, dL_dsh);
     return check_launch(s, 0);
 }
 

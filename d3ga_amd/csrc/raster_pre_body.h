@@ -154,7 +154,7 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
                                 float *dL_dmeans2D, float *dL_dopacity, float *dsh_row, float *dL_dcolors,
                                 float *dL_dcov3D, float *dL_dscales, float *dL_drots, float act_opacity = 0.f,
                                 bool have_j = false, ShColJ jd = ShColJ(),      // have_j: jd.j0..j8 = the forward's d(colour)/d(direction) of this Gaussian (then sh_row is not read)
-                                bool accum = false) {      // accum (views > 0 of a batch, d3ga.h n_views): the view-independent inputs' gradients are ADDED to what the outputs hold
+                                int accum = 0) {      // views > 0 of a batch (d3ga.h n_views): gradients of inputs the views SHARE are added to what the outputs hold -- bit 0: opacity and a precomputed colour, bit 1: the geometry (mean, covariance | scale, rotation)
     float gmean[3] = {0.f, 0.f, 0.f};
     float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const V3 mean = ld3(means3D, i);
@@ -221,11 +221,11 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
         }
     } else if (dL_dcolors) {                 // a precomputed colour is view-independent: summed over a batch's views
         float *o = dL_dcolors + 3 * (size_t)i;
-        o[0] = accum ? o[0] + (a[7]) : (a[7]); o[1] = accum ? o[1] + (a[8]) : (a[8]); o[2] = accum ? o[2] + (a[9]) : (a[9]);
+        o[0] = (accum & 1) ? o[0] + (a[7]) : (a[7]); o[1] = (accum & 1) ? o[1] + (a[8]) : (a[8]); o[2] = (accum & 1) ? o[2] + (a[9]) : (a[9]);
     }
     {
         float *o = dL_dmeans3D + 3 * (size_t)i;
-        o[0] = accum ? o[0] + (gmean[0]) : (gmean[0]); o[1] = accum ? o[1] + (gmean[1]) : (gmean[1]); o[2] = accum ? o[2] + (gmean[2]) : (gmean[2]);
+        o[0] = (accum & 2) ? o[0] + (gmean[0]) : (gmean[0]); o[1] = (accum & 2) ? o[1] + (gmean[1]) : (gmean[1]); o[2] = (accum & 2) ? o[2] + (gmean[2]) : (gmean[2]);
     }
     if (dL_dmeans2D) {                       // screen-space: per view
         dL_dmeans2D[3 * (size_t)i] = a[0]; dL_dmeans2D[3 * (size_t)i + 1] = a[1]; dL_dmeans2D[3 * (size_t)i + 2] = 0.f;
@@ -235,10 +235,10 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
     if (dL_dopacity) {
         const float op = act_opacity / aa, g_op = a[6] * aa;
         const float g = prm.opacity_activation == D3GA_OPACITY_SIGMOID ? g_op * op * (1.0f - op) : g_op;
-        dL_dopacity[i] = accum ? dL_dopacity[i] + g : g;
+        dL_dopacity[i] = (accum & 1) ? dL_dopacity[i] + g : g;
     }
     if (dL_dcov3D) {
-        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = accum ? dL_dcov3D[6 * (size_t)i + k] + (g6[k]) : (g6[k]);
+        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * (size_t)i + k] = (accum & 2) ? dL_dcov3D[6 * (size_t)i + k] + (g6[k]) : (g6[k]);
     }
     if (dL_dscales && dL_drots) {
         float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -248,8 +248,8 @@ D3GA_HD void preprocess_bwd_one(const d3ga_raster_params &prm, int i, bool visib
                                 rotations[4 * (size_t)i + 3]};
             cov3d_from_scale_rot_bwd(s, prm.scale_modifier, q, g6, gs, gq);
         }
-        for (int k = 0; k < 3; ++k) dL_dscales[3 * (size_t)i + k] = accum ? dL_dscales[3 * (size_t)i + k] + (gs[k]) : (gs[k]);
-        for (int k = 0; k < 4; ++k) dL_drots[4 * (size_t)i + k] = accum ? dL_drots[4 * (size_t)i + k] + (gq[k]) : (gq[k]);
+        for (int k = 0; k < 3; ++k) dL_dscales[3 * (size_t)i + k] = (accum & 2) ? dL_dscales[3 * (size_t)i + k] + (gs[k]) : (gs[k]);
+        for (int k = 0; k < 4; ++k) dL_drots[4 * (size_t)i + k] = (accum & 2) ? dL_drots[4 * (size_t)i + k] + (gq[k]) : (gq[k]);
     }
 }
 

@@ -71,7 +71,7 @@ def _scratch_views(P, W, H, k, cap, dev, fwd_only):
 class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cams, bg, sh_degree,
-                scale_modifier, antialiasing, opacity_activation, l1_targets):
+                scale_modifier, antialiasing, opacity_activation, l1_targets, colors2=None, bg2=None):
         require_cuda(means3D)
         dev = means3D.device
         f32 = lambda t: _R._f32(t, dev)
@@ -83,12 +83,26 @@ class _RasterizeViews(torch.autograd.Function):
                 (scales is not None or rotations is not None) and cov3Ds_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         k, W, H = cams.n_views, cams.image_width, cams.image_height
-        P = means3D.shape[0]
+        # a batch of FRAMES: every view brings its own geometry (k,P,.) -- the avatar deformed per pose -- and shares the appearance
+        per_view = means3D.dim() == 3
+        P = means3D.shape[-2]
+        geo = [t for t in (means3D, scales, rotations, cov3Ds_precomp) if t is not None]
+        if any((t.dim() == 3) != per_view for t in geo) or (per_view and any(t.shape[0] != k for t in geo)):
+            raise ValueError("rasterize_gaussians_views: means3D and the covariance inputs must all be (P,.) or all be (k,P,.)")
+        if opacities.shape[0] != P:
+            raise ValueError("rasterize_gaussians_views: opacities (and the colours) are shared by the views: (P,.)")
         M = sh.shape[1] if sh is not None else 0
         fwd_only = not any(ctx.needs_input_grad[:7])
+        dual = colors2 is not None
+        if dual and l1_targets is not None:
+            raise ValueError("rasterize_gaussians_views: the fused L1 loss and a second colour set cannot be combined")
+        if dual:
+            colors2, bg2 = f32(colors2.detach()), f32(bg2)
         prm = RasterParams(P=P, M=M, sh_degree=int(sh_degree), W=W, H=H, tanfovx=0.0, tanfovy=0.0,
                            scale_modifier=float(scale_modifier), antialiasing=int(bool(antialiasing)), prefiltered=0, debug=0,
-                           opacity_activation=_R._ACTIVATIONS[opacity_activation], forward_only=int(fwd_only), n_views=k)
+                           opacity_activation=_R._ACTIVATIONS[opacity_activation], forward_only=int(fwd_only), n_views=k,
+                           per_view_geometry=int(per_view))
+        colors2_img = torch.empty((k, 3, H, W), dtype=torch.float32, device=dev) if dual else None
         colors = torch.empty((k, 3, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((k, P), dtype=torch.int32, device=dev)
         loss = tgt = None
@@ -114,11 +128,17 @@ class _RasterizeViews(torch.autograd.Function):
                 tm.stage("composite_fwd", lambda: check(L.d3ga_raster_composite_fwd_l1(
                     pp, dptr(bg), dptr(geom), dptr(binning), cap, dptr(img), dptr(colors), None, dptr(tgt), None, dptr(loss), dptr(ws), st),
                     "d3ga_raster_composite_fwd_l1"))
+            elif dual and P > 0:
+                tm.stage("composite_fwd", lambda: check(L.d3ga_raster_composite_fwd2(
+                    pp, dptr(bg), dptr(bg2), dptr(geom), dptr(colors2), dptr(binning), cap, dptr(img), dptr(colors), dptr(colors2_img),
+                    None, st), "d3ga_raster_composite_fwd2"))
             else:
                 tm.stage("composite_fwd", lambda: check(L.d3ga_raster_composite_fwd(
                     pp, dptr(bg), dptr(geom), dptr(binning), cap, dptr(img), dptr(colors), None, st), "d3ga_raster_composite_fwd"))
                 if tgt is not None:
                     _R.l1_mean_forward(colors, tgt, None, loss, dev)
+                if dual:
+                    colors2_img.copy_(bg2.view(1, 3, 1, 1).expand_as(colors2_img))
             _R._last[dev.index] = (binning, cap)
             if _R._capture_log is not None:
                 _R._capture_log.append((binning, cap))
@@ -132,38 +152,48 @@ class _RasterizeViews(torch.autograd.Function):
             cap = k * _R._hwm[dev.index]
         ctx.prm, ctx.cap, ctx.cams = prm, cap, cams
         ctx.l1 = tgt is not None and P > 0
+        ctx.dual, ctx.per_view = dual, per_view
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, bg, geom, binning, img,
-                              colors if ctx.l1 else None, tgt if ctx.l1 else None)
+                              colors if ctx.l1 else None, tgt if ctx.l1 else None, colors2, bg2)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)
+        if dual:
+            return colors, radii, colors2_img
         return (colors, radii, loss) if tgt is not None else (colors, radii)
 
     @staticmethod
-    def backward(ctx, grad_colors, _grad_radii, grad_loss=None):
-        means3D, sh, scales, rotations, cov3Ds_precomp, bg, geom, binning, img, image, tgt = ctx.saved_tensors
-        prm, cams, dev, P, k = ctx.prm, ctx.cams, means3D.device, means3D.shape[0], ctx.prm.n_views
+    def backward(ctx, grad_colors, _grad_radii, grad_third=None):
+        means3D, sh, scales, rotations, cov3Ds_precomp, bg, geom, binning, img, image, tgt, colors2, bg2 = ctx.saved_tensors
+        prm, cams, dev, P, k = ctx.prm, ctx.cams, means3D.device, ctx.prm.P, ctx.prm.n_views
         if P == 0:
-            return (None,) * 14
-        g_loss = None
-        if ctx.l1 and grad_loss is not None:
-            g_loss = _R._f32(grad_loss, dev).reshape(1)
+            return (None,) * 16
+        g_loss = grad_colors2 = None
+        if ctx.l1 and grad_third is not None:
+            g_loss = _R._f32(grad_third, dev).reshape(1)
+        if ctx.dual:
+            grad_colors2 = torch.zeros((k, 3, prm.H, prm.W), dtype=torch.float32, device=dev) if grad_third is None else _R._f32(grad_third, dev)
         if grad_colors is None and g_loss is None:
             grad_colors = torch.zeros((k, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
         grad_colors = _R._f32(grad_colors, dev)
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         acc = torch.empty((k * P, _lib.ACC_STRIDE), dtype=torch.float32, device=dev)
         from_sr = cov3Ds_precomp is None
-        g_means3D, g_opac = new(P, 3), new(P, 1)
+        gshape = (k, P) if ctx.per_view else (P,)                 # a batch of frames: geometry gradients per view
+        g_means3D, g_opac = new(*gshape, 3), new(P, 1)
         g_sh = new(P, prm.M, 3) if sh is not None else None
         g_col = new(k, P, 3) if sh is not None else new(P, 3)      # SH: the per-view factors of the rank-1 SH gradient (scratch)
-        g_cov = None if from_sr else new(P, 6)
-        g_scales = new(P, 3) if from_sr else None
-        g_rots = new(P, 4) if from_sr else None
+        g_cov = None if from_sr else new(*gshape, 6)
+        g_scales = new(*gshape, 3) if from_sr else None
+        g_rots = new(*gshape, 4) if from_sr else None
         L = _lib.lib()
         st, pp = stream_handle(), ctypes.byref(prm)
         tm = _R.stage_timer
         acc.zero_()
-        if g_loss is not None:
+        if ctx.dual:
+            tm.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd2(
+                pp, dptr(bg), dptr(bg2), dptr(geom), dptr(colors2), dptr(binning), ctx.cap, dptr(img), dptr(grad_colors),
+                dptr(grad_colors2), dptr(acc), st), "d3ga_raster_composite_bwd2"))
+        elif g_loss is not None:
             tm.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd_l1(
                 pp, dptr(bg), dptr(geom), dptr(binning), ctx.cap, dptr(img), dptr(image), dptr(tgt), None, dptr(g_loss),
                 dptr(grad_colors), dptr(acc), st), "d3ga_raster_composite_bwd_l1"))
@@ -176,14 +206,18 @@ class _RasterizeViews(torch.autograd.Function):
             dptr(cams.projmatrices), dptr(cams.campos), dptr(geom), dptr(acc), dptr(g_means3D), None, dptr(g_opac), dptr(g_sh),
             dptr(g_col), dptr(g_cov), dptr(g_scales), dptr(g_rots), st), "d3ga_raster_preprocess_bwd"))
         return (g_means3D, g_sh, g_col if sh is None else None, g_opac, g_scales, g_rots, g_cov,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 def rasterize_gaussians_views(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cameras, bg, sh_degree=0,
-                              scale_modifier=1.0, antialiasing=False, opacity_activation=None, l1_targets=None):
-    """k views of the same Gaussians in one grid per stage.  cameras: a CameraBatch; bg (3,) shared by the views.
-    -> (colors (k,3,H,W), radii (k,P)) or, with l1_targets (k,3,H,W), (colors, radii, loss) where loss = mean |colors - targets|
-    over all k images (= the mean over the views of the reference's per-frame l1_loss, train.py:218-221: equal sizes) whose
-    gradient is formed inside the compositing backward.  Inputs and gradients as `rasterize_gaussians`."""
+                              scale_modifier=1.0, antialiasing=False, opacity_activation=None, l1_targets=None, colors2=None, bg2=None):
+    """k views in one grid per stage.  cameras: a CameraBatch; bg (3,) shared by the views.
+    Geometry: means3D (P,3) with cov3Ds_precomp (P,6) | scales + rotations -- k CAMERAS of one set of Gaussians -- or all of them
+    (k,P,.) -- k FRAMES, the avatar deformed per pose (the reference's batch, train.py:218-221); opacities and the colours are shared.
+    -> (colors (k,3,H,W), radii (k,P)); with l1_targets (k,3,H,W): (colors, radii, loss), loss = mean |colors - targets| over all k
+    images (= the mean over the frames of the reference's per-frame l1_loss: equal sizes), its gradient formed inside the compositing
+    backward; with colors2 (P,3) + bg2: (colors, radii, colors2_image (k,3,H,W)) -- the reference's RGB + silhouette pair
+    (models/trainer.py:102-110) from one pass, colors2 constant.  Gradients as `rasterize_gaussians`: summed over the views for
+    shared inputs, per view for (k,P,.) geometry."""
     return _RasterizeViews.apply(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cameras, bg,
-                                 sh_degree, scale_modifier, antialiasing, opacity_activation, l1_targets)
+                                 sh_degree, scale_modifier, antialiasing, opacity_activation, l1_targets, colors2, bg2)

@@ -57,14 +57,27 @@ def render_l1(batch, pkg, bg_color, target, grad_sync=None):
     return render(batch, pkg, bg_color, grad_sync=grad_sync, _l1=target)
 
 
-def render_views(batches, pkg, bg_color, targets=None, cameras=None):
-    """k cameras of ONE package in one pass (extension; the reference renders one camera per call and averages the losses of a
-    batch of frames, train.py:218-221): -> {"render": (k,3,H,W)} and, with targets (k,3,H,W), "l1" = the mean over the views of
-    `l1_loss(render, target)`, its gradient formed inside the compositing backward.  Every image equals `render(batch_v, pkg,
-    bg_color)["render"]`, the gradients equal the sum over the k calls (d3ga_amd/raster_views.py).  The views share the raster
-    size and must not be cropped (lib/batch.py:186-198: centred principal point).  cameras: a `raster_views.CameraBatch` to
-    reuse (a captured step keeps one and calls `cameras.set(batches)` before every replay); batches may then be None."""
+def render_views(batches, pkg, bg_color, targets=None, cameras=None, colors2=None, bg_color2=None):
+    """k views in one pass (extension; the reference renders one camera per call and averages the losses of a batch of frames,
+    train.py:218-221): -> {"render": (k,3,H,W)}; with targets (k,3,H,W) also "l1" = the mean over the views of `l1_loss(render,
+    target)` (its gradient formed inside the compositing backward); with colors2 (P,3) + bg_color2 also "render2" (k,3,H,W), the
+    reference's silhouette pass (models/trainer.py:102-110) from the same pass.
+    pkg: one package seen from k CAMERAS -- or a LIST of k packages, one per FRAME of the batch (the avatar deformed per pose:
+    their means3D and covariances are stacked to (k,P,.)); appearance (opacities, shs | rgb) is taken from the first package and
+    must be the same tensors in all of them.  Every image equals `render(batch_v, pkg_v, bg_color)["render"]`, the gradients equal
+    the sum over the k calls (d3ga_amd/raster_views.py).  The views share the raster size and must not be cropped
+    (lib/batch.py:186-198: centred principal point).  cameras: a `raster_views.CameraBatch` to reuse (a captured step keeps one and
+    calls `cameras.set(batches)` before every replay); batches may then be None."""
     from .raster_views import CameraBatch, rasterize_gaussians_views
+    frames = pkg if isinstance(pkg, (list, tuple)) else None
+    if frames is not None:
+        first = frames[0]
+        for f in frames[1:]:
+            for key in ("opacities", "opacity_logits", "shs", "rgb"):
+                if f.get(key) is not first.get(key):
+                    raise ValueError(f"render_views: the frames of a batch share their appearance; `{key}` differs between the packages")
+        stack = lambda key: None if first.get(key) is None else torch.stack([f[key] for f in frames])
+        pkg = dict(first, means3D=stack("means3D"), cov3D_precomp=stack("cov3D_precomp"), scales=stack("scales"), rotations=stack("rotations"))
     means3D = pkg["means3D"]
     if cameras is None:
         for b in batches:
@@ -78,7 +91,10 @@ def render_views(batches, pkg, bg_color, targets=None, cameras=None):
     shs = pkg["shs"]
     out = rasterize_gaussians_views(means3D, shs, None if shs is not None else pkg["rgb"], opacities, pkg.get("scales"),
                                     pkg.get("rotations"), pkg.get("cov3D_precomp"), cameras, bg_color,
-                                    sh_degree=pkg["sh_degree"] if "sh_degree" in pkg else 0, opacity_activation=act, l1_targets=targets)
+                                    sh_degree=pkg["sh_degree"] if "sh_degree" in pkg else 0, opacity_activation=act, l1_targets=targets,
+                                    colors2=colors2, bg2=bg_color2)
+    if colors2 is not None:
+        return {"render": out[0], "render2": out[2]}
     return {"render": out[0], "l1": out[2]} if targets is not None else {"render": out[0]}
 
 

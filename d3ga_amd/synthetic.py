@@ -103,6 +103,21 @@ def make_skeleton(n_joints, rng, max_angle=0.5):
     return pos.astype(np.float32), A
 
 
+def pose_matrices(joint_pos, rng, max_angle=0.5):
+    """Another pose of the skeleton `make_skeleton` placed (the same joints, new rotations about them): (J,4,4) float32 -- the
+    frames of a batch differ in exactly this (lib/smplman.py:155-171 takes the joint transforms of the frame)."""
+    pos = np.asarray(joint_pos, np.float64)
+    A = np.zeros((pos.shape[0], 4, 4), np.float32)
+    for j in range(pos.shape[0]):
+        rv = rng.normal(size=3)
+        rv = rv / np.linalg.norm(rv) * rng.uniform(0, max_angle) * 0.3
+        R = rodrigues(rv)
+        A[j, :3, :3] = R
+        A[j, :3, 3] = pos[j] - R @ pos[j] + rng.normal(size=3) * 0.01
+        A[j, 3, 3] = 1
+    return A
+
+
 def skin_weights(verts, joint_pos, k):
     d = ((verts[:, None, :] - joint_pos[None]) ** 2).sum(-1)               # (V,J)
     idx = np.argsort(d, axis=1)[:, :k]
@@ -212,6 +227,6 @@ def make_scene(wl, seed=17):
         "canon_points": t(canon), "tetras": t(tetras), "tetra_id": t(tetra_id), "barys": t(barys),
         "scaling": t(scaling), "rotation": t(rotation), "opacity_logit": t(opacity_logit),
         "features_dc": t(features_dc), "features_rest": t(features_rest), "rgb": t(rgb),
-        "joint_mats": t(A), "skin_idx": t(skin_idx), "skin_w": t(skin_w),
+        "joint_mats": t(A), "joint_pos": t(joint_pos), "skin_idx": t(skin_idx), "skin_w": t(skin_w),
         "delta_node": t((rng.normal(size=canon.shape) * 0.002).astype(np.float32)),
     }

@@ -188,13 +188,19 @@ typedef struct d3ga_raster_params {
      *   geom / binning / img are sized by d3ga_raster_scratch_bytes_views and hold k x P records / k x tiles lists: view v's Gaussian
      *   i is record v P + i, its tile (tx, ty) is tile (v gy + ty) gx + tx; W, H, tanfov*, bg are shared by the views;
      *   out_color (k,3,H,W), out_invdepth (k,H,W), dL_dpix (k,3,H,W), the L1 target (k,3,H,W) and its loss = mean over all k images;
+     *   d3ga_raster_composite_fwd2 / _bwd2: colors2 stays (P,3) (shared by the views), out_color2 / dL_dpix2 are (k,3,H,W);
      *   acc (k P, D3GA_ACC_STRIDE);  d3ga_raster_preprocess_bwd SUMS dL/dmeans3D, dL/dopacity, dL/dcov3D | (dL/dscales, dL/drots) and a
      *   precomputed colour's gradient over the views, writes dL_dmeans2D per view (k,P,3), and for SH colours needs dL_dcolors
      *   (k,P,3) = the per-view factors of the rank-1 SH gradient, from which dL_dsh (P,M,3), when given, is rebuilt in one pass
      *   (d3ga_sh_grad_from_views) -- one 12 M-byte row per Gaussian and BATCH instead of per view.
      * Every view's image and the summed gradients equal k single-view calls (same kernels, same arithmetic per view).
-     * Not available batched (D3GA_E_CONFIG): d3ga_raster_composite_fwd2 / _bwd2, d3ga_raster_recolor. */
+     * Not available batched (D3GA_E_CONFIG): d3ga_raster_recolor. */
     int32_t n_views;
+    /* n_views > 1 only.  != 0: a batch of FRAMES, not only of cameras -- every view has its own geometry (the reference's batch
+     * holds frames of different poses, train.py:218-221: the avatar is deformed per frame, its appearance parameters are shared):
+     * means3D is (k,P,3) and cov3D_precomp (k,P,6) | scales (k,P,3) + rotations (k,P,4); their gradients are written PER VIEW,
+     * (k,P,.), not summed; opacities, shs | colors_precomp stay (P,.) with gradients summed over the views. */
+    int32_t per_view_geometry;
 } d3ga_raster_params;
 #define D3GA_OPACITY_SIGMOID 1
 

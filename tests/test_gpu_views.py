@@ -169,4 +169,124 @@ def test_batched_views_refusals_and_sizes():
     buf = torch.zeros(1 << 22, dtype=torch.uint8, device=DEV)
     p = ctypes.c_void_p(buf.data_ptr())
     assert L.d3ga_raster_recolor(ctypes.byref(prm), p, None, p, p, p, ctypes.c_void_p(buf.data_ptr() + (1 << 21)), None) == -3      # D3GA_E_CONFIG
-    assert L.d3ga_raster_composite_fwd2(ctypes.byref(prm), p, p, p, p, p, 1024, p, p, p, None, None) == -3
+
+
+@pytest.mark.parametrize("use_sh,from_sr", [(True, False), (False, True)])
+def test_batch_of_frames_with_per_view_geometry(use_sh, from_sr):
+    """per_view_geometry: the reference's batch holds FRAMES (train.py:218-221) -- the avatar deformed per pose, (k,P,.) geometry, shared
+    appearance.  Every image equals the single-view render of (frame v's Gaussians, camera v); the geometry gradients come back per
+    frame, the appearance gradients summed over the frames."""
+    inp = scene_inputs("T1", scale_mult=3.0)
+    k = 3
+    batches = _batches(inp, k)
+    bg = torch.tensor([0.9, 0.8, 0.7], device=DEV)
+    g = torch.Generator().manual_seed(13)
+    gpix = torch.randn(k, 3, inp["H"], inp["W"], generator=g).to(DEV)
+    P = inp["means3D"].shape[0]
+    shift = 0.02 * torch.randn(k, P, 3, generator=g)
+    base = _leaves(inp, use_sh, from_sr)
+    geo = ("means3D",) + (("scales", "rots") if from_sr else ("cov6",))
+    per = {n: torch.stack([base[n].detach().cpu() * (1.0 + (0.05 * v if n != "means3D" else 0.0)) + (shift[v] if n == "means3D" else 0.0)
+                           for v in range(k)]).to(DEV) for n in geo}
+    # reference: k single-view renders, each with its own geometry leaves, the appearance leaves shared
+    shared = {n: t for n, t in _leaves(inp, use_sh, from_sr).items() if n not in geo}
+    ref_geo, imgs = [], []
+    for v, b in enumerate(batches):
+        lv = dict(shared, **{n: per[n][v].clone().requires_grad_(True) for n in geo})
+        img, _ = _single_view(inp, b, lv, bg, use_sh, from_sr)
+        (img * gpix[v]).sum().backward()
+        imgs.append(img.detach())
+        ref_geo.append({n: lv[n].grad for n in geo})
+    mine_shared = {n: t for n, t in _leaves(inp, use_sh, from_sr).items() if n not in geo}
+    mine_geo = {n: per[n].clone().requires_grad_(True) for n in geo}
+    colors, _ = _views(inp, batches, dict(mine_shared, **mine_geo), bg, use_sh, from_sr)
+    (colors * gpix).sum().backward()
+    torch.cuda.synchronize()
+    for v in range(k):
+        assert torch.equal(colors[v], imgs[v]), v
+        for n in geo:
+            a, b = ref_geo[v][n], mine_geo[n].grad[v]
+            scale = float(a.abs().max())
+            assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (v, n, float((a - b).abs().max()) / scale)
+    for n in shared:
+        a, b = shared[n].grad, mine_shared[n].grad
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (n, float((a - b).abs().max()) / scale)
+
+
+def test_batched_pair_render_equals_the_single_view_pairs():
+    """The reference's RGB + silhouette pair (models/trainer.py:102-110) for a batch: colors2 (P,3) shared by the views, blended with the
+    same alphas into a second (k,3,H,W) image; both images' gradients reach the geometry and the opacities."""
+    from d3ga_amd import rasterizer as R
+    from d3ga_amd.cameras import batch_to_camera
+    from d3ga_amd.raster_views import CameraBatch, rasterize_gaussians_views
+    inp = scene_inputs("C1")
+    k = 3
+    batches = _batches(inp, k)
+    bg, bg2 = torch.ones(3, device=DEV), torch.zeros(3, device=DEV)
+    g = torch.Generator().manual_seed(21)
+    P = inp["means3D"].shape[0]
+    sil = torch.rand(P, 3, generator=g).to(DEV)
+    gp, gp2 = torch.randn(k, 3, inp["H"], inp["W"], generator=g).to(DEV), torch.randn(k, 3, inp["H"], inp["W"], generator=g).to(DEV)
+    ref = _leaves(inp, True, False)
+    imgs, imgs2 = [], []
+    for v, b in enumerate(batches):
+        cam = batch_to_camera(b, device=DEV)
+        s = R.GaussianRasterizationSettings(
+            image_height=inp["H"], image_width=inp["W"], tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, scale_modifier=1.0,
+            viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center,
+            prefiltered=False, debug=False, antialiasing=False)
+        img, _, _, img2 = R.rasterize_gaussians_pair(ref["means3D"], None, ref["shs"], None, ref["opacities"], None, None, ref["cov6"], s,
+                                                     sil, bg2, want_invdepth=False)
+        ((img * gp[v]).sum() + (img2 * gp2[v]).sum()).backward()
+        imgs.append(img.detach()); imgs2.append(img2.detach())
+    mine = _leaves(inp, True, False)
+    cams = CameraBatch(k, inp["W"], inp["H"], device=DEV).set(batches)
+    colors, _, colors2 = rasterize_gaussians_views(mine["means3D"], mine["shs"], None, mine["opacities"], None, None, mine["cov6"], cams, bg,
+                                                   sh_degree=3, colors2=sil, bg2=bg2)
+    ((colors * gp).sum() + (colors2 * gp2).sum()).backward()
+    torch.cuda.synchronize()
+    for v in range(k):
+        assert torch.equal(colors[v], imgs[v]) and torch.equal(colors2[v], imgs2[v]), v
+    for n in ref:
+        a, b = ref[n].grad, mine[n].grad
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (n, float((a - b).abs().max()) / scale)
+
+
+def test_render_views_over_a_batch_of_frames_equals_render_per_frame():
+    """renderer.render_views with a LIST of packages (one per frame of the batch: own means / covariances, shared appearance tensors)
+    and the silhouette pair against renderer.render_pair per frame: identical images, the same summed gradients on the shared leaves."""
+    from d3ga_amd.renderer import render_pair, render_views
+    inp = scene_inputs("T1", scale_mult=3.0)
+    k = 3
+    batches = _batches(inp, k)
+    bg, bg0 = torch.ones(3, device=DEV), torch.zeros(3, device=DEV)
+    P = inp["means3D"].shape[0]
+    g = torch.Generator().manual_seed(31)
+    sil = torch.ones(P, 3, device=DEV)
+    gp, gp2 = torch.randn(k, 3, inp["H"], inp["W"], generator=g).to(DEV), torch.randn(k, 3, inp["H"], inp["W"], generator=g).to(DEV)
+    shift = (0.02 * torch.randn(k, P, 3, generator=g)).to(DEV)
+
+    def leaves():
+        return {n: inp[n].to(DEV).clone().requires_grad_(True) for n in ("means3D", "cov6", "opacities", "shs")}
+
+    def packages(L):          # "poses": the shared means moved per frame (a differentiable function of the shared leaf, like the deform)
+        return [{"means3D": L["means3D"] + shift[v], "cov3D_precomp": L["cov6"] * (1.0 + 0.1 * v), "opacities": L["opacities"], "shs": L["shs"],
+                 "rgb": None, "sh_degree": 3} for v in range(k)]
+    ref = leaves()
+    imgs = []
+    for v, pk in enumerate(packages(ref)):
+        both = render_pair(batches[v], pk, bg, sil, bg0)
+        ((both["render"] * gp[v]).sum() + (both["render2"] * gp2[v]).sum()).backward()
+        imgs.append((both["render"].detach(), both["render2"].detach()))
+    mine = leaves()
+    out = render_views(batches, packages(mine), bg, colors2=sil, bg_color2=bg0)
+    ((out["render"] * gp).sum() + (out["render2"] * gp2).sum()).backward()
+    torch.cuda.synchronize()
+    for v in range(k):
+        assert torch.equal(out["render"][v], imgs[v][0]) and torch.equal(out["render2"][v], imgs[v][1]), v
+    for n in ref:
+        a, b = ref[n].grad, mine[n].grad
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (n, float((a - b).abs().max()) / scale)
