@@ -1129,7 +1129,14 @@ static int mlp_wgrad_launch(int32_t P, int32_t N, int32_t K, const float *dpre, 
     const size_t lds = 2 * (size_t)kWgOperandBytes;
     const bool va = N % 2 == 0 && ((uintptr_t)dpre & 7) == 0, vb = K % 2 == 0 && ((uintptr_t)X & 7) == 0;   // float2 loads
     const bool mixed = N <= 16 || K <= 16;
-    const bool use_ws = debug_knob(D3GA_KNOB_WGRAD_WS) != 0;
+    // D3GA_KNOB_WGRAD_WS: 0 the barrier-phased kernel everywhere; 1 (default) the wavefront-specialised kernel for two wide operands
+    // AND for a narrow dPre against a wide activation (the fields' output layers, N <= 16: its idle lanes load a clamped column,
+    // its spare multipliers leave at once -- 98 -> 84 us at N = 11, 92 -> 81 at N = 4, 500k rows, tools/time_wgrad.py; the other
+    // way round, a wide dPre against a narrow input, the second loader layout of the barrier-phased kernel stays ahead: 109 vs 117);
+    // 2: the wavefront-specialised kernel for every shape
+    const int ws_knob = debug_knob(D3GA_KNOB_WGRAD_WS);
+    const bool use_ws = ws_knob != 0;
+    const bool ws_for_mixed = ws_knob == 2 || (ws_knob == 1 && N <= 16 && K > 16);
 #define D3GA_WG(VA, VB, MX)                                                                                           \
     do {                                                                                                              \
         static bool attr[64] = {};                                                                                    \
@@ -1159,7 +1166,7 @@ static int mlp_wgrad_launch(int32_t P, int32_t N, int32_t K, const float *dpre, 
     } while (0)
 #define D3GA_WG2(VA, VB)                                                                                              \
     do {                                                                                                              \
-        if (mixed) D3GA_WG(VA, VB, true);                                                                             \
+        if (mixed && !ws_for_mixed) D3GA_WG(VA, VB, true);                                                            \
         else if (use_ws) D3GA_WS(VA, VB);                                                                             \
         else D3GA_WG(VA, VB, false);                                                                                  \
     } while (0)

@@ -53,7 +53,7 @@ const char *d3ga_status_string(int status);
 #define D3GA_KNOB_BWD_SPLIT 3         /* compositing backward: -1 (default) the D3GA_CNT_HEAVY heaviest tiles get two workgroups, 0 none, n > 0 the n heaviest */
 #define D3GA_KNOB_SORT_MERGE 4        /* -1 (default) by size: the 2049..4096 list class rides in the 8192-key sort launch when few such lists are expected; 0 never; 1 always */
 #define D3GA_KNOB_SSIM_IMPL 5         /* 1 (default) the marching register-window SSIM kernels, 0 the LDS-tiled ones of round 3 */
-#define D3GA_KNOB_WGRAD_WS 6          /* 1 (default) the wavefront-specialised weight-gradient kernel for two wide operands, 0 the barrier-phased one */
+#define D3GA_KNOB_WGRAD_WS 6          /* 1 (default) the wavefront-specialised weight-gradient kernel for two wide operands and for a narrow dPre, 0 the barrier-phased one, 2 wavefront-specialised for every shape */
 #define D3GA_KNOB_CHAIN_ABL 7         /* 0 (default); != 0: TIMING ablations of the fused field-network kernel (wrong results) */
 #define D3GA_KNOB_CHAIN_GRID 8        /* 0 (default) = 2048 / wavefronts per workgroup; > 0: workgroups of the fused field-network kernel */
 #define D3GA_KNOB_COUNT 9
