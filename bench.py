@@ -713,7 +713,7 @@ def field_mlp_bench(args):
 def field_mlp_summary(P, dev, steps=20, warmup=5):
     """The `field_mlp` object of the default bench line: CanonicalField (models/mlp.py:74-110: 109 -> 128 x 4 -> 11 with the 98 pose
     columns folded into the first bias) forward + backward to inputs AND weights over the workload's P Gaussians -- the unit that is
-    85 % of the reference-faithful training step (DESIGN.md sec. 4b).  Here the matrix cores are the right roofline: every f32
+    85 % of the reference-faithful training step (DESIGN.md sec. 4.5).  Here the matrix cores are the right roofline: every f32
     product is six bf16 MFMA products (exact 3-way split), so the MFMA work is 6 x the f32-equivalent FLOPs; peak = the dense bf16
     rate of MI355X_MICROARCH.md (2.5 PFLOP/s).  The HBM side of the same launches is reported beside it (the weight gradients and
     the per-layer outputs are HBM-bound)."""

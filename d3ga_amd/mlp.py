@@ -5,7 +5,7 @@ with ``z = [pose.expand(P, -1) | per-row features]`` (models/mlp.py:58-69, 94-10
   * the broadcast part of the first layer is folded into its bias once per call (``W0[:, :n_pose] @ pose + b0``: a
     128-vector instead of 98 of the 109 input columns for every one of the P rows),
   * every dense layer is one launch of ``d3ga_mlp_linear`` (f32-equivalent arithmetic on the bf16 matrix cores -- an exact
-    3-way split of every operand, six products, f32 accumulate: DESIGN.md sec. 4b -- with bias + leaky_relu fused),
+    3-way split of every operand, six products, f32 accumulate: DESIGN.md sec. 4.5 -- with bias + leaky_relu fused),
   * the whole trunk is ONE autograd node (``_Chain``): the forward keeps one sign bit per activation, the input-gradient
     GEMM of a layer applies the leaky_relu derivative of the layer below from those bits in its epilogue, so every
     pre-activation gradient is written once and no activation is re-read for masking,
@@ -578,7 +578,7 @@ class _ColorRows(torch.autograd.Function):
 def sh4_direction_encoding(d):
     """Stand-in for tiny-cuda-nn's degree-4 `SphericalHarmonics` direction encoding (16 outputs, models/mlp.py:166-179):
     x = 2 d - 1, then the real SH polynomials of degree < 4 (constants of utils/sh_utils.py:7-24); one HIP kernel each way
-    (csrc/encoding.hip).  tiny-cuda-nn is un-vendored: parity of THIS function is unpinned (DESIGN.md sec. 4b); everything
+    (csrc/encoding.hip).  tiny-cuda-nn is un-vendored: parity of THIS function is unpinned (DESIGN.md sec. 4.5); everything
     around it is pinned."""
     if d.dim() != 2 or d.shape[1] != 3:
         raise ValueError("sh4_direction_encoding: (P,3) directions")

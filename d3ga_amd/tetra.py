@@ -189,7 +189,7 @@ distCUDA2 = knn_mean_dist2
 def spatial_order(points, bits=10):
     """(P,3) -> (P,) int64 permutation that numbers the points along a Morton (Z-order) curve of their bounding box.
 
-    Why (DESIGN sec. 4 *Index order*): every stage of the frame works on blocks of CONSECUTIVE Gaussians -- 256 per workgroup
+    Why (docs/LOG.md sec. 4 *Index order*): every stage of the frame works on blocks of CONSECUTIVE Gaussians -- 256 per workgroup
     in the per-Gaussian kernels, whose tile-histogram / scatter windows in LDS cover the union of the block's rectangles --
     and the compositing stages gather 16-byte geometry records by Gaussian id in list order.  With spatially coherent
     numbering a block's window is a few dozen tiles and a tile list's records share cache lines; with a random numbering

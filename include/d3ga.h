@@ -466,7 +466,7 @@ int d3ga_mlp_linear(int32_t P, int32_t K, int32_t n_out, const float *X, const v
                     d3ga_stream_t stream);
 
 /* One launch for a whole trunk (forward): h_{l+1} = act_l(h_l W_l^T + b_l), l = 0..L-1, with the activations kept in the
- * registers of the wavefront that owns the rows -- no activation is read back between the layers (DESIGN.md sec. 4b).  Same
+ * registers of the wavefront that owns the rows -- no activation is read back between the layers (DESIGN.md sec. 4.5).  Same
  * arithmetic as d3ga_mlp_linear (exact 3-way bf16 split, six products, f32 accumulate).  Layer l: Ks[l] inputs (= Ns[l-1];
  * Ks[0] = K0 <= 128), Ns[l] <= 128 outputs, panels[l] = its weights packed by d3ga_mlp_pack_chain (d3ga_mlp_chain_panel_bytes;
  * the call writes biases[l] -- or zeros: biases / biases[l] may be NULL -- into the 512-byte tail of panels[l], which is why

@@ -419,7 +419,7 @@ def test_captured_trunk_follows_in_place_weight_updates(fused):
 @pytest.mark.parametrize("spread", [0.0, 4.0])
 def test_split_bf16_products_have_f32_accuracy(spread):
     """The dense layer splits every f32 operand exactly into three bf16 pieces and keeps six of the nine cross products
-    (DESIGN.md sec. 4b).  Claim under test: the result is as accurate as f32 arithmetic -- the error against f64, in units
+    (DESIGN.md sec. 4.5).  Claim under test: the result is as accurate as f32 arithmetic -- the error against f64, in units
     of 2^-24 sum_k |x_k||w_k| per output, is no larger than that of ATen's f32 GEMM on the same data (measured: 10-35 %
     smaller) -- also when the magnitudes of the operands spread over many binades (spread = decades)."""
     from d3ga_amd.mlp import linear_act

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The fuzz campaigns of DESIGN.md sec. 5 (each is a committed test with a larger seed range); results in gpurun_out/campaigns.log
+# The fuzz campaigns of docs/LOG.md sec. 5 (each is a committed test with a larger seed range); results in gpurun_out/campaigns.log
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
 : > gpurun_out/campaigns.log
