@@ -406,9 +406,12 @@ __global__ __launch_bounds__(kMarchW, 4) void ssim_march_fwd_kernel(int C, int H
     for (int k = 0; k < 11; ++k) w[k] = c_ssim_w[k];
     float local = 0.f, local_l1 = 0.f;
     const int nitems = C * strips * segs;
-    if (tid < 5 * 8 * (kMarchLd - kMarchW)) {              // the pad columns behind the 256 written ones: zero once
-        const int r = tid / (5 * (kMarchLd - kMarchW)), q = tid % (5 * (kMarchLd - kMarchW));
-        s_v[r][q / (kMarchLd - kMarchW)][kMarchW + q % (kMarchLd - kMarchW)] = 0.f;
+    if constexpr (kMarchLd > kMarchW) {                    // pad columns behind the kMarchW written ones (none since kMarchLd == kMarchW): zero once
+        constexpr int pad = kMarchLd > kMarchW ? kMarchLd - kMarchW : 1;
+        if (tid < 5 * 8 * pad) {
+            const int r = tid / (5 * pad), q = tid % (5 * pad);
+            s_v[r][q / pad][kMarchW + q % pad] = 0.f;
+        }
     }
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int c = item / (strips * segs), r = item - c * strips * segs;
@@ -526,9 +529,12 @@ __global__ __launch_bounds__(kMarchW) void ssim_march_bwd_kernel(int C, int H, i
     const float scale = g[0] * inv_n;
     const float scale_l1 = g_l1 ? g_l1[0] * inv_n : 0.f;
     const int nitems = C * strips * segs;
-    if (tid < 3 * 8 * (kMarchLd - kMarchW)) {
-        const int r = tid / (3 * (kMarchLd - kMarchW)), q = tid % (3 * (kMarchLd - kMarchW));
-        s_v[r][q / (kMarchLd - kMarchW)][kMarchW + q % (kMarchLd - kMarchW)] = 0.f;
+    if constexpr (kMarchLd > kMarchW) {
+        constexpr int pad = kMarchLd > kMarchW ? kMarchLd - kMarchW : 1;
+        if (tid < 3 * 8 * pad) {
+            const int r = tid / (3 * pad), q = tid % (3 * pad);
+            s_v[r][q / pad][kMarchW + q % pad] = 0.f;
+        }
     }
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int c = item / (strips * segs), r = item - c * strips * segs;

@@ -413,7 +413,6 @@ __global__ __launch_bounds__(256 * R, D3GA_TILE_WAVES) void composite_bwd_tile_k
     constexpr int PIXF = DUAL ? 12 : 8;
     constexpr int ROWF = 16 * PIXF + 4;
     constexpr int kSlot = 12;                        // dwords per cache slot
-    constexpr uint32_t kLocked = 0xffffffffu;
     const bool early_exit_off = (assign & 8) != 0;         // A/B: bit 3 of D3GA_TILE_ASSIGN keeps every wavefront until the tile is done
     assign &= 7;
     const int tiles = gx * gy;
@@ -469,7 +468,7 @@ __global__ __launch_bounds__(256 * R, D3GA_TILE_WAVES) void composite_bwd_tile_k
     // g = (wave + workgroup) mod 4.  A wavefront runs as many groups as its longest row needs, so rows of unequal length pad
     // (quadrants: 57.5 k wave-groups at C3, interleaved 59.3 k, against 49 k row-groups / 4); and rotating g with the workgroup
     // index gives every SIMD of a CU (wave w of a workgroup runs on SIMD w) one wavefront of each weight class.
-    const int row = lane / LW, l16 = lane & 15, lseg = lane & (LW - 1);      // row: which of the wavefront's blocks; lseg: lane within the block's group
+    const int row = lane / LW;                             // which of the wavefront's blocks
     constexpr int kVals = INVD ? 10 : 9, kPerInst = 64 / kVals;           // publish: values per record, records per instruction
     const int fq = lane / kVals, fk = lane - kVals * fq;   // lane -> (record within a group of 7 (6), value)
     const int fk_off = fk < 2 ? fk : fk + 1;               // acc layout 0,1 | 3,4,5 | 6 | 7,8,9 | 10 (dL/d(1/depth), INVD)
