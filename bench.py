@@ -90,6 +90,8 @@ def parse():
     ap.add_argument("--batch-views", type=int, default=4,
                     help="N = 1: also time the VIEW-BATCHED step (k cameras of the pose in one grid per rasterizer stage: d3ga_amd/raster_views.py) "
                          "and report it as `batched_views` beside the single-view headline; 0 = off")
+    ap.add_argument("--sequential-views", action="store_true",
+                    help="--views-per-rank k as k sequential renders (rounds 4-5) instead of one view-batched pass")
     ap.add_argument("--fresh-scratch", action="store_true",
                     help="allocate and clear the backward's gradient accumulator per call instead of keeping a self-clearing one "
                          "(rasterizer.set_accumulator_policy)")
@@ -206,7 +208,16 @@ class Frame:
         from d3ga_amd.losses import l1_loss
         from d3ga_amd.renderer import render, render_l1
         # mean |img - target| (utils/loss_utils.py:29); with camera_cycle() the target is whatever the slot names
-        if getattr(self, "my_views", None):     # --views-per-rank k: k cameras of the pose, one package, the mean of their losses
+        if getattr(self, "my_views", None) and getattr(self, "batch_my_views", True):
+            # --views-per-rank k: this rank's k cameras of the pose in ONE view-batched pass (round 6; --sequential-views: k renders)
+            from d3ga_amd.renderer import render_views
+            if getattr(self, "_my_cams", None) is None:
+                from d3ga_amd.raster_views import CameraBatch
+                b0 = self.my_views[0][0]
+                self._my_cams = CameraBatch(len(self.my_views), int(b0["width"]), int(b0["height"]), device=self.dev).set([b for b, _ in self.my_views])
+                self._my_targets = torch.stack([t for _, t in self.my_views]).contiguous()
+            return render_views(None, pkg, self.bg, targets=self._my_targets, cameras=self._my_cams, grad_sync=self.grad_sync)["l1"]
+        if getattr(self, "my_views", None):     # k cameras of the pose, one package, the mean of their losses, k sequential renders
             tot = None
             for b, t in self.my_views:
                 l = render_l1(b, pkg, self.bg, t, grad_sync=self.grad_sync)["l1"]
@@ -1139,11 +1150,13 @@ def main():
         if world == 1 and not args.force_cut:
             raise SystemExit("--views-per-rank applies to the camera-sharded step (N > 1, or --force-cut on one GPU)")
         nv = max(8, world * kv)
+        frame.batch_my_views = not args.sequential_views
         frame.my_views = []
         for j in range(kv):
             v = (rank * kv + j) % nv
             b = frame.syn.make_batch(frame.wl.width, frame.wl.height, azimuth=2 * math.pi * v / nv, camera_id=v, fill=args.fill)
-            frame.my_views.append((b, torch.rand(3, frame.wl.height, frame.wl.width, generator=torch.Generator().manual_seed(100 + v)).to(dev)))
+            th, tw = (int(b["height"]), int(b["width"])) if frame.batch_my_views else (frame.wl.height, frame.wl.width)      # (batched: the raster; an odd width is padded, lib/batch.py:186-198)
+            frame.my_views.append((b, torch.rand(3, th, tw, generator=torch.Generator().manual_seed(100 + v)).to(dev)))
     if not args.fresh_scratch:
         R.set_accumulator_policy("persistent")         # one training stream: the accumulator cleans itself
     flat = ddist.GradReducer(list(frame.params.values()))

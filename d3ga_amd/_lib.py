@@ -32,7 +32,8 @@ class RasterParams(ctypes.Structure):
                 ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
                 ("antialiasing", ctypes.c_int32), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
                 ("opacity_activation", ctypes.c_int32), ("forward_only", ctypes.c_int32),
-                ("acc_self_clearing", ctypes.c_int32), ("n_views", ctypes.c_int32), ("per_view_geometry", ctypes.c_int32)]
+                ("acc_self_clearing", ctypes.c_int32), ("n_views", ctypes.c_int32), ("per_view_geometry", ctypes.c_int32),
+                ("factor_rows", ctypes.c_int32)]
 
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float

@@ -400,7 +400,8 @@ __device__ __forceinline__ void bwd_tile_wave(const BwdArgs &A, const int tile, 
 // wavefront takes 2 / 1 blocks -- the same pixel steps in total, but the tile's longest list is walked in half / a quarter of
 // the groups: the critical path of a heavy tile (18 groups of one wavefront at C3) shrinks with it.
 template <bool DUAL, int S, bool INVD = false, int R = 1>
-__global__ __launch_bounds__(256 * R, D3GA_TILE_WAVES) void composite_bwd_tile_kernel(
+__global__ __launch_bounds__(256 * R, (DUAL ? (D3GA_TILE_WAVES < 3 ? D3GA_TILE_WAVES : 3) : D3GA_TILE_WAVES)) void composite_bwd_tile_kernel(   // (DUAL: 12-float pixel records -- the LDS of three workgroups per CU)
+   
     int W, int H, int gx, int gy, int gyv, const uint32_t *__restrict__ tile_start, uint64_t dcap, const float2 *__restrict__ xy,
     const float4 *__restrict__ conic_o, const float4 *__restrict__ rgb_invd, const float *__restrict__ bg,
     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
@@ -576,7 +577,6 @@ int launch_composite_bwd_scan(const d3ga_raster_params *prm, int gx, int gy, con
         if (colors2) return D3GA_E_CONFIG;
         if (S >= 512) D3GA_LAUNCH_TILE(false, 512, true); else D3GA_LAUNCH_TILE(false, 256, true);
     } else if (colors2) { if (S >= 512) D3GA_LAUNCH_TILE(true, 512, false); else D3GA_LAUNCH_TILE(true, 256, false); }
-    else if (S >= 1024) D3GA_LAUNCH_TILE(false, 1024, false);
     else if (S >= 512) D3GA_LAUNCH_TILE(false, 512, false);
     else D3GA_LAUNCH_TILE(false, 256, false);
 #undef D3GA_LAUNCH_TILE

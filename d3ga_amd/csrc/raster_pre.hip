@@ -600,13 +600,15 @@ extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const f
     if (shs && !dL_dcolors) return D3GA_E_NULL;
     const int cam_stride = prm->tanfovx > 0.f ? 3 : 5;
     const size_t pv = prm->per_view_geometry ? (size_t)prm->P : 0;      // a batch of frames: every view has its own geometry and geometry gradients
+    if (prm->factor_rows != 0 && prm->factor_rows < prm->P) return D3GA_E_SIZE;
+    const size_t fr = prm->factor_rows > 0 ? (size_t)prm->factor_rows : (size_t)prm->P;      // rows between the views' SH factors
     for (int v = 0; v < views; ++v) {
         const size_t o = (size_t)prm->P * v, og = pv * v;
         hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, means3D + 3 * og,
                            shs, scales ? scales + 3 * og : nullptr, rotations ? rotations + 4 * og : nullptr, viewmatrix + 16 * (size_t)v,
                            projmatrix + 16 * (size_t)v, campos + (size_t)cam_stride * v, geom_view(g, prm->P, v), acc + D3GA_ACC_STRIDE * o,
                            dL_dmeans3D + 3 * og, dL_dmeans2D ? dL_dmeans2D + 3 * o : nullptr, dL_dopacity, (float *)nullptr,
-                           shs ? dL_dcolors + 3 * o : dL_dcolors, dL_dcov3D ? dL_dcov3D + 6 * og : nullptr,
+                           shs ? dL_dcolors + 3 * fr * v : dL_dcolors, dL_dcov3D ? dL_dcov3D + 6 * og : nullptr,
                            dL_dscales ? dL_dscales + 3 * og : nullptr, dL_drots ? dL_drots + 4 * og : nullptr,
                            cov3D_precomp ? cov3D_precomp + 6 * og : nullptr, v > 0 ? (pv ? 1 : 3) : 0);
     }
@@ -614,7 +616,7 @@ extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const f
     if (shs && dL_dsh) {
         const size_t lds2 = ((3 * prm->M) % 4 == 0) ? kShLdsBytes : 0;
         hipLaunchKernelGGL(sh_grad_from_views_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds2, s, prm->P, prm->M, prm->sh_degree,
-                           views, means3D, (int64_t)(3 * pv), dL_dcolors, 3 * (int64_t)prm->P, campos, (int64_t)cam_stride, 1.0f, dL_dsh);
+                           views, means3D, (int64_t)(3 * pv), dL_dcolors, (int64_t)(3 * fr), campos, (int64_t)cam_stride, 1.0f, dL_dsh);
         return check_launch(s, prm->debug);
     }
     return D3GA_OK;

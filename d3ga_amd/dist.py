@@ -294,8 +294,8 @@ class ViewShardedGrads:
             if sh is not None:
                 P, M, deg, means3D = sh["P"], sh["M"], sh["sh_degree"], sh["means3D"]
                 g_sh = torch.empty((P, M, 3), dtype=torch.float32, device=means3D.device)
-                g = e["gathered"]
-                check(_lib.lib().d3ga_sh_grad_from_views(P, M, deg, self.world, dptr(means3D), dptr(g), 3 * (P + 1),
+                g = e["gathered"].view(-1, P + 1, 3)       # (world, P+1, 3), or (world, k, P+1, 3) from a view-batched render: world x k views
+                check(_lib.lib().d3ga_sh_grad_from_views(P, M, deg, g.shape[0], dptr(means3D), dptr(g), 3 * (P + 1),
                                                          dptr(g[0, P]), 3 * (P + 1), self.scale, dptr(g_sh), stream_handle()),
                       "d3ga_sh_grad_from_views")
                 mine["shs"] = g_sh

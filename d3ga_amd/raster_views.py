@@ -71,7 +71,7 @@ def _scratch_views(P, W, H, k, cap, dev, fwd_only):
 class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cams, bg, sh_degree,
-                scale_modifier, antialiasing, opacity_activation, l1_targets, colors2=None, bg2=None):
+                scale_modifier, antialiasing, opacity_activation, l1_targets, colors2=None, bg2=None, grad_sync=None):
         require_cuda(means3D)
         dev = means3D.device
         f32 = lambda t: _R._f32(t, dev)
@@ -153,6 +153,16 @@ class _RasterizeViews(torch.autograd.Function):
         ctx.prm, ctx.cap, ctx.cams = prm, cap, cams
         ctx.l1 = tgt is not None and P > 0
         ctx.dual, ctx.per_view = dual, per_view
+        # camera-sharded training (d3ga_amd/dist.py: ViewShardedGrads): every gradient that leaves this op is summed over the ranks
+        # at this cut -- this rank's k views arrive already summed, their k SH factors travel in one all-gather
+        ctx.grad_sync = grad_sync if (grad_sync is not None and (grad_sync.world > 1 or getattr(grad_sync, "always", False)) and P > 0) else None
+        if ctx.grad_sync is not None:
+            if per_view:
+                raise ValueError("rasterize_gaussians_views: grad_sync needs view-independent geometry (k cameras of one pose); a batch of "
+                                 "frames is reduced at the parameters (dist.GradReducer)")
+            if hasattr(grad_sync, "verify_inputs"):
+                grad_sync.verify_inputs({"means3D": means3D, "opacities": opacities, "colors_precomp": colors_precomp, "shs": sh,
+                                         "cov3D_precomp": cov3Ds_precomp, "scales": scales, "rotations": rotations})
         ctx.save_for_backward(means3D, sh, scales, rotations, cov3Ds_precomp, bg, geom, binning, img,
                               colors if ctx.l1 else None, tgt if ctx.l1 else None, colors2, bg2)
         ctx.mark_non_differentiable(radii)
@@ -166,7 +176,7 @@ class _RasterizeViews(torch.autograd.Function):
         means3D, sh, scales, rotations, cov3Ds_precomp, bg, geom, binning, img, image, tgt, colors2, bg2 = ctx.saved_tensors
         prm, cams, dev, P, k = ctx.prm, ctx.cams, means3D.device, ctx.prm.P, ctx.prm.n_views
         if P == 0:
-            return (None,) * 16
+            return (None,) * 17
         g_loss = grad_colors2 = None
         if ctx.l1 and grad_third is not None:
             g_loss = _R._f32(grad_third, dev).reshape(1)
@@ -178,15 +188,38 @@ class _RasterizeViews(torch.autograd.Function):
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         acc = torch.empty((k * P, _lib.ACC_STRIDE), dtype=torch.float32, device=dev)
         from_sr = cov3Ds_precomp is None
-        gshape = (k, P) if ctx.per_view else (P,)                 # a batch of frames: geometry gradients per view
-        g_means3D, g_opac = new(*gshape, 3), new(P, 1)
-        g_sh = new(P, prm.M, 3) if sh is not None else None
-        g_col = new(k, P, 3) if sh is not None else new(P, 3)      # SH: the per-view factors of the rank-1 SH gradient (scratch)
-        g_cov = None if from_sr else new(*gshape, 6)
-        g_scales = new(*gshape, 3) if from_sr else None
-        g_rots = new(*gshape, 4) if from_sr else None
+        sync, flat, factor = ctx.grad_sync, None, None
+        if sync is None:
+            gshape = (k, P) if ctx.per_view else (P,)                 # a batch of frames: geometry gradients per view
+            g_means3D, g_opac = new(*gshape, 3), new(P, 1)
+            g_sh = new(P, prm.M, 3) if sh is not None else None
+            g_col = new(k, P, 3) if sh is not None else new(P, 3)      # SH: the per-view factors of the rank-1 SH gradient (scratch)
+            g_cov = None if from_sr else new(*gshape, 6)
+            g_scales = new(*gshape, 3) if from_sr else None
+            g_rots = new(*gshape, 4) if from_sr else None
+        else:
+            # one planar buffer for the all-reduce (as rasterizer._RasterizeGaussians.backward lays it out); the SH gradient leaves
+            # as k factors of (P + 1, 3) -- row P carries the view's camera position -- for ONE all-gather of (k, P + 1, 3) per rank
+            widths = [3, 1] + ([3, 4] if from_sr else [6]) + ([3] if sh is None else [])
+            flat = new(P * sum(widths))
+            parts, off = [], 0
+            for w in widths:
+                parts.append(flat[off:off + P * w].view(P, w))
+                off += P * w
+            g_means3D, g_opac = parts[0], parts[1]
+            g_scales, g_rots = (parts[2], parts[3]) if from_sr else (None, None)
+            g_cov = None if from_sr else parts[2]
+            g_sh = None
+            if sh is None:
+                g_col = parts[-1]
+            else:
+                factor = new(k, P + 1, 3)
+                g_col = factor
+                p2 = RasterParams(**{f: getattr(prm, f) for f, _ in RasterParams._fields_})
+                p2.factor_rows = P + 1
+                prm = p2
         L = _lib.lib()
-        st, pp = stream_handle(), ctypes.byref(prm)
+        st, pp = stream_handle(), ctypes.byref(prm)          # (prm: the block with factor_rows when the gradients are exchanged)
         tm = _R.stage_timer
         acc.zero_()
         if ctx.dual:
@@ -203,14 +236,32 @@ class _RasterizeViews(torch.autograd.Function):
                 "d3ga_raster_composite_bwd"))
         tm.stage("preprocess_bwd", lambda: check(L.d3ga_raster_preprocess_bwd(
             pp, dptr(means3D), dptr(sh), dptr(scales), dptr(rotations), dptr(cov3Ds_precomp), dptr(cams.viewmatrices),
-            dptr(cams.projmatrices), dptr(cams.campos), dptr(geom), dptr(acc), dptr(g_means3D), None, dptr(g_opac), dptr(g_sh),
-            dptr(g_col), dptr(g_cov), dptr(g_scales), dptr(g_rots), st), "d3ga_raster_preprocess_bwd"))
+            dptr(cams.projmatrices), dptr(cams.campos), dptr(geom), dptr(acc), dptr(g_means3D), None, dptr(g_opac),
+            dptr(g_sh if sync is None else None), dptr(g_col), dptr(g_cov), dptr(g_scales), dptr(g_rots), st), "d3ga_raster_preprocess_bwd"))
+        if sync is not None:
+            if factor is not None:
+                factor[:, P].copy_(cams.campos[:, :3])
+            if getattr(sync, "deferred", False):          # two-graph step (graph.CapturedCutStep): the collectives run between the graphs
+                by_name = {"means3D": g_means3D, "opacities": g_opac}
+                by_name.update({"scales": g_scales, "rotations": g_rots} if from_sr else {"cov3D_precomp": g_cov})
+                if sh is None:
+                    by_name["colors_precomp"] = g_col
+                sync.park(flat, factor, by_name, None if factor is None else {"P": P, "M": prm.M, "sh_degree": prm.sh_degree, "means3D": means3D})
+                return (None,) * 17
+            gathered = sync.exchange(flat, factor)        # flat: averaged over the ranks in place; gathered: (world, k, P + 1, 3)
+            if factor is not None:
+                g_sh = new(P, prm.M, 3)
+                g = gathered.view(-1, P + 1, 3)
+                check(L.d3ga_sh_grad_from_views(P, prm.M, prm.sh_degree, g.shape[0], dptr(means3D), dptr(g), 3 * (P + 1), dptr(g[0, P]),
+                                                3 * (P + 1), sync.scale, dptr(g_sh), stream_handle()), "d3ga_sh_grad_from_views")
+                g_col = None
         return (g_means3D, g_sh, g_col if sh is None else None, g_opac, g_scales, g_rots, g_cov,
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
 def rasterize_gaussians_views(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cameras, bg, sh_degree=0,
-                              scale_modifier=1.0, antialiasing=False, opacity_activation=None, l1_targets=None, colors2=None, bg2=None):
+                              scale_modifier=1.0, antialiasing=False, opacity_activation=None, l1_targets=None, colors2=None, bg2=None,
+                              grad_sync=None):
     """k views in one grid per stage.  cameras: a CameraBatch; bg (3,) shared by the views.
     Geometry: means3D (P,3) with cov3Ds_precomp (P,6) | scales + rotations -- k CAMERAS of one set of Gaussians -- or all of them
     (k,P,.) -- k FRAMES, the avatar deformed per pose (the reference's batch, train.py:218-221); opacities and the colours are shared.
@@ -218,6 +269,7 @@ def rasterize_gaussians_views(means3D, sh, colors_precomp, opacities, scales, ro
     images (= the mean over the frames of the reference's per-frame l1_loss: equal sizes), its gradient formed inside the compositing
     backward; with colors2 (P,3) + bg2: (colors, radii, colors2_image (k,3,H,W)) -- the reference's RGB + silhouette pair
     (models/trainer.py:102-110) from one pass, colors2 constant.  Gradients as `rasterize_gaussians`: summed over the views for
-    shared inputs, per view for (k,P,.) geometry."""
+    shared inputs, per view for (k,P,.) geometry.  grad_sync: a dist.ViewShardedGrads -- the returned gradients are then already
+    averaged over the ranks of a camera-sharded run (every rank renders its own k cameras of the pose)."""
     return _RasterizeViews.apply(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, cameras, bg,
-                                 sh_degree, scale_modifier, antialiasing, opacity_activation, l1_targets, colors2, bg2)
+                                 sh_degree, scale_modifier, antialiasing, opacity_activation, l1_targets, colors2, bg2, grad_sync)

@@ -57,7 +57,7 @@ def render_l1(batch, pkg, bg_color, target, grad_sync=None):
     return render(batch, pkg, bg_color, grad_sync=grad_sync, _l1=target)
 
 
-def render_views(batches, pkg, bg_color, targets=None, cameras=None, colors2=None, bg_color2=None):
+def render_views(batches, pkg, bg_color, targets=None, cameras=None, colors2=None, bg_color2=None, grad_sync=None):
     """k views in one pass (extension; the reference renders one camera per call and averages the losses of a batch of frames,
     train.py:218-221): -> {"render": (k,3,H,W)}; with targets (k,3,H,W) also "l1" = the mean over the views of `l1_loss(render,
     target)` (its gradient formed inside the compositing backward); with colors2 (P,3) + bg_color2 also "render2" (k,3,H,W), the
@@ -92,7 +92,7 @@ def render_views(batches, pkg, bg_color, targets=None, cameras=None, colors2=Non
     out = rasterize_gaussians_views(means3D, shs, None if shs is not None else pkg["rgb"], opacities, pkg.get("scales"),
                                     pkg.get("rotations"), pkg.get("cov3D_precomp"), cameras, bg_color,
                                     sh_degree=pkg["sh_degree"] if "sh_degree" in pkg else 0, opacity_activation=act, l1_targets=targets,
-                                    colors2=colors2, bg2=bg_color2)
+                                    colors2=colors2, bg2=bg_color2, grad_sync=grad_sync)
     if colors2 is not None:
         return {"render": out[0], "render2": out[2]}
     return {"render": out[0], "l1": out[2]} if targets is not None else {"render": out[0]}

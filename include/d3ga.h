@@ -48,7 +48,7 @@ const char *d3ga_status_string(int status);
  *   for a diagnostic (counter) build, then for knob k < D3GA_KNOB_COUNT: out[2 + 2k] = compiled default, out[3 + 2k] = value in
  *   effect; n = capacity of out in int32 (>= 2 + 2 * D3GA_KNOB_COUNT, else D3GA_E_SIZE). */
 #define D3GA_KNOB_COMPOSITE_VARIANT 0 /* bit 5 (32) work-ordered dispatch of the compositing kernels, bit 7 (128) exact block culling; default 160 */
-#define D3GA_KNOB_MERGE_SLOTS 1       /* slots of the compositing backward's per-tile merge cache: 256 | 512 (default) | 1024 */
+#define D3GA_KNOB_MERGE_SLOTS 1       /* slots of the compositing backward's per-tile merge cache: 256 | 512 (default) */
 #define D3GA_KNOB_TILE_ASSIGN 2       /* block -> wavefront assignment of the compositing backward: 0 quadrants, 1 interleaved, 2 by list length (default); +8: no early exit */
 #define D3GA_KNOB_BWD_SPLIT 3         /* compositing backward: -1 (default) the D3GA_CNT_HEAVY heaviest tiles get two workgroups, 0 none, n > 0 the n heaviest */
 #define D3GA_KNOB_SORT_MERGE 4        /* -1 (default) by size: the 2049..4096 list class rides in the 8192-key sort launch when few such lists are expected; 0 never; 1 always */
@@ -201,6 +201,10 @@ typedef struct d3ga_raster_params {
      * means3D is (k,P,3) and cov3D_precomp (k,P,6) | scales (k,P,3) + rotations (k,P,4); their gradients are written PER VIEW,
      * (k,P,.), not summed; opacities, shs | colors_precomp stay (P,.) with gradients summed over the views. */
     int32_t per_view_geometry;
+    /* n_views > 1, SH colours: rows between consecutive views' factors in the dL_dcolors handed to d3ga_raster_preprocess_bwd (0 = P).
+     * The camera-sharded exchange keeps one extra row per view (the view's camera position) so that factors and positions travel in
+     * ONE all-gather (d3ga_amd/dist.py): P + 1. */
+    int32_t factor_rows;
 } d3ga_raster_params;
 #define D3GA_OPACITY_SIGMOID 1
 

@@ -440,3 +440,73 @@ def test_two_ranks_view_dependent_colour_needs_the_parameter_reducer():
         refused, err, worst = res[r]
         assert refused, "ViewShardedGrads must refuse view-dependent rasterizer inputs"
         assert err < 1e-4, (r, err, worst)
+
+
+def _worker_batched(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import math
+    import bench
+    from d3ga_amd import dist as dd
+    from d3ga_amd import rasterizer as R
+    dd.init_process_group(backend="gloo")
+    dev = torch.device("cuda", 0)
+    k = 2
+    nv = world * k
+    frame = bench.Frame("T1", dev, view_index=0)
+    views = []
+    for v in range(nv):
+        b = frame.syn.make_batch(frame.wl.width, frame.wl.height, azimuth=2 * math.pi * v / nv, camera_id=v)
+        views.append((b, torch.rand(3, int(b["height"]), int(b["width"]), generator=torch.Generator().manual_seed(100 + v)).to(dev)))
+    # expected: the mean over ALL world x k views of the per-view parameter gradients, sequential single-view renders, no exchange
+    want = {}
+    for b, t in views:
+        frame.batch, frame.target = b, t
+        for p in frame.params.values():
+            p.grad = None
+        frame.step()
+        for n, p in frame.params.items():
+            want[n] = want.get(n, 0) + p.grad / nv
+    # this rank: its k views in ONE view-batched pass, gradients exchanged at the cut
+    frame.my_views, frame.batch_my_views = views[rank * k:(rank + 1) * k], True
+    frame.grad_sync = dd.ViewShardedGrads()
+    for p in frame.params.values():
+        p.grad = None
+    frame.step()
+    torch.cuda.synchronize()
+    err = max(rel_err(p.grad.cpu().numpy(), want[n].cpu().numpy()) for n, p in frame.params.items())
+    # ... and as two hipGraphs around the eager exchange (the parked buffers carry k factors per rank)
+    from d3ga_amd.graph import CapturedCutStep
+    R.set_capacity_policy("static", int(R.last_counters()["D"] * 1.5) + 4096)
+    cut = CapturedCutStep(frame.upstream, frame.loss_from, frame.grad_sync, params=list(frame.params.values()))
+    for _ in range(2):
+        for p in frame.params.values():
+            if p.grad is not None:
+                p.grad.zero_()
+        cut.replay()
+    torch.cuda.synchronize()
+    err_cut = max(rel_err(p.grad.cpu().numpy(), want[n].cpu().numpy()) for n, p in frame.params.items())
+    out[rank] = (err, err_cut)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_camera_sharded_ranks_with_view_batched_renders():
+    """Two ranks x two cameras each, every rank's cameras in ONE view-batched pass (round 6) with the gradients exchanged at the cut
+    (the k SH factors of a rank travel in one all-gather): every parameter gradient equals the mean over the four sequential
+    single-view renders, eagerly and through the two-graph cut step."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        out = m.dict()
+        procs = [ctx.Process(target=_worker_batched, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0
+        res = dict(out)
+    assert set(res) == {0, 1}
+    for r in range(world):
+        assert res[r][0] < 2e-5 and res[r][1] < 2e-5, res

@@ -290,3 +290,28 @@ def test_render_views_over_a_batch_of_frames_equals_render_per_frame():
         a, b = ref[n].grad, mine[n].grad
         scale = float(a.abs().max())
         assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (n, float((a - b).abs().max()) / scale)
+
+
+def test_batched_views_inference_single_view_batch_and_empty_scene():
+    """The corners of the batched operator: (1) under torch.no_grad the forward_only path (an image scratch without block lists)
+    renders the same images; (2) a batch of ONE view is the single-view render; (3) an empty scene gives k background images and
+    no gradients to compute."""
+    from d3ga_amd.raster_views import CameraBatch, rasterize_gaussians_views
+    inp = scene_inputs("T1", scale_mult=3.0)
+    k = 3
+    batches = _batches(inp, k)
+    bg = torch.tensor([0.25, 0.5, 0.75], device=DEV)
+    L = _leaves(inp, True, False)
+    colors, radii = _views(inp, batches, L, bg, True, False)
+    with torch.no_grad():
+        c2, r2 = _views(inp, batches, L, bg, True, False)
+    assert torch.equal(colors, c2) and torch.equal(radii, r2) and not c2.requires_grad
+    one, _ = _views(inp, batches[:1], L, bg, True, False)
+    img, _ = _single_view(inp, batches[0], L, bg, True, False)
+    assert torch.equal(one[0], img)
+    cams = CameraBatch(k, inp["W"], inp["H"], device=DEV).set(batches)
+    z = lambda *s: torch.zeros(*s, device=DEV, requires_grad=True)
+    e_col, e_rad = rasterize_gaussians_views(z(0, 3), z(0, 16, 3), None, z(0, 1), None, None, z(0, 6), cams, bg, sh_degree=3)
+    assert e_col.shape == (k, 3, inp["H"], inp["W"]) and e_rad.shape == (k, 0)
+    assert torch.equal(e_col, bg.view(1, 3, 1, 1).expand_as(e_col))
+    e_col.sum().backward()                                  # (nothing to differentiate: must not raise)

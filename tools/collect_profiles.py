@@ -46,7 +46,7 @@ for src, dst in (("prof_mlp/mlp_kernel_stats.csv", f"{tag}_field_mlp_kernel_stat
         shutil.copy(f, os.path.join(ROOT, "profiles", dst))
 for src, dst in (("bench_color_train.log", f"{tag}_bench_color_train_C4.json"), ("force_cut_C3_k1.log", f"{tag}_force_cut_C3_k1.json"),
                  ("force_cut_C3_k2.log", f"{tag}_force_cut_C3_k2.json"), ("force_cut_C3_k4.log", f"{tag}_force_cut_C3_k4.json"),
-                 ("force_cut_C4_k1.log", f"{tag}_force_cut_C4_k1.json"), (f"composite_diag_{wl}.json", f"{tag}_composite_diag_{wl}.json")):
+                 ("force_cut_C4_k1.log", f"{tag}_force_cut_C4_k1.json"), ("force_cut_C3_k4_sequential.log", f"{tag}_force_cut_C3_k4_sequential.json"), (f"composite_diag_{wl}.json", f"{tag}_composite_diag_{wl}.json")):
     f = os.path.join(ROOT, "gpurun_out", src)
     if os.path.exists(f) and os.path.getsize(f) > 10:
         shutil.copy(f, os.path.join(ROOT, "profiles", dst))

@@ -51,6 +51,7 @@ timeout 900 python bench.py --train-step color --steps 100 --warmup 10 2> gpurun
 for k in 1 2 4; do
   timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train-step --force-cut --views-per-rank $k 2>> gpurun_out/force_cut.err | grep "^{" > gpurun_out/force_cut_C3_k$k.log
 done
+timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train-step --force-cut --views-per-rank 4 --sequential-views 2>> gpurun_out/force_cut.err | grep "^{" > gpurun_out/force_cut_C3_k4_sequential.log
 timeout 600 python bench.py --workload C4 --steps 100 --warmup 10 --no-cpu-baseline --no-train-step --force-cut 2>> gpurun_out/force_cut.err | grep "^{" > gpurun_out/force_cut_C4_k1.log
 # the batched compositing kernels by rocprofv3: per-kernel durations (k = 4) and their counters (separate --pmc passes)
 rm -rf gpurun_out/prof_views && mkdir -p gpurun_out/prof_views
