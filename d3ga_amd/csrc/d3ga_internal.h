@@ -49,7 +49,7 @@ static inline GeomBuf carve_geom(void *base, int64_t P) {
     return g;
 }
 // the records of view v of a batch (every array advanced by v * P records; the dcol planes keep the batch's stride)
-static inline GeomBuf geom_view(const GeomBuf &g, int64_t P, int64_t v) {
+__host__ __device__ static inline GeomBuf geom_view(const GeomBuf &g, int64_t P, int64_t v) {
     GeomBuf o = g;
     const int64_t d = v * P;
     o.depth += d; o.conic_o += d; o.rgb_invd += d; o.rect += d; o.clamped += d; o.cov3D += 6 * d; o.xyh += d; o.dcol += d;

@@ -166,6 +166,64 @@ __device__ __forceinline__ void staged_sh_colour(const d3ga_raster_params &prm, 
     }
 }
 
+// what preprocess leaves per Gaussian (GeomBuf records of ITS view, radius); returns the tile rectangle in the batch's grid
+struct TileRect { bool visible; int r0, r1, r2, r3; };
+__device__ __forceinline__ TileRect write_geom_records(const GeomBuf &geom, int i, const PreOut &o, bool keep_cov, int tile_row0,
+                                                       int32_t *__restrict__ radii, bool want_j, const ShColJ &cj) {
+    const Splat &sp = o.sp;
+    if (keep_cov) {                         // (uniform) a precomputed covariance is read again from the caller's tensor
+#pragma unroll
+        for (int k = 0; k < 6; ++k) geom.cov3D[6 * (size_t)i + k] = o.c6[k];
+    }
+    radii[i] = sp.radius;
+    geom.depth[i] = sp.depth;
+    // culled Gaussians keep an EMPTY rectangle: the scatter pass and the backward test visibility through it
+    geom.rect[i] = sp.visible ? make_uint2((uint32_t)sp.rect[0] | ((uint32_t)(sp.rect[1] + tile_row0) << 16),
+                                           (uint32_t)sp.rect[2] | ((uint32_t)(sp.rect[3] + tile_row0) << 16))
+                              : make_uint2(0u, 0u);
+    geom.conic_o[i] = make_float4(sp.conic[0], sp.conic[1], sp.conic[2], o.opacity);
+    {   // half extents of the splat's alpha >= 1/255 box, by the function the compositing stage culls with (bit-identical)
+        const SplatCull sc = splat_cull(sp.conic[0], sp.conic[1], sp.conic[2], o.opacity);
+        geom.xyh[i] = make_float4(sp.px, sp.py, sp.visible ? sc.hx : -1.0f, sc.hy);
+    }
+    geom.rgb_invd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], sp.visible ? 1.0f / sp.depth : 0.f);
+    geom.clamped[i] = o.clampmask;
+    if (want_j) {
+        const float jv[9] = {cj.j0, cj.j1, cj.j2, cj.j3, cj.j4, cj.j5, cj.j6, cj.j7, cj.j8};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) D3GA_DCOL_AT(geom.dcol, i, k, geom.dcol_stride) = jv[k];
+    }
+    return TileRect{sp.visible, sp.rect[0], sp.rect[1] + tile_row0, sp.rect[2], sp.rect[3] + tile_row0};
+}
+
+// tile histogram (counting-sort pass 1) of this block's Gaussians through its LDS window.  Every thread of the block must call it
+// (barriers inside); s_cnt: kWinTiles words that nobody else uses between the call's first and last barrier.
+__device__ __forceinline__ void tile_histogram(int *s_box, uint32_t *s_cnt, const TileRect &t, int gx, uint32_t *__restrict__ tile_count,
+                                               uint32_t *__restrict__ counters) {
+    const int tid = threadIdx.x;
+    const TileWindow win = block_tile_window(s_box, t.visible, t.r0, t.r1, t.r2, t.r3);   // barriers inside
+    const int nvis = __syncthreads_count(t.visible);
+    if (tid == 0 && nvis) atomicAdd(&counters[D3GA_CNT_VISIBLE], (uint32_t)nvis);
+    const int area = win.area();
+    if (area == 0) return;                                   // uniform
+    if (win.fits()) {
+        for (int k = tid; k < area; k += kBlock) s_cnt[k] = 0;
+        __syncthreads();
+        if (t.visible)
+            for (int ty = t.r1; ty < t.r3; ++ty)
+                for (int tx = t.r0; tx < t.r2; ++tx) atomicAdd(&s_cnt[(ty - win.y0) * win.w + (tx - win.x0)], 1u);
+        __syncthreads();
+        const float inv_w = 1.0f / (float)win.w;
+        for (int k = tid; k < area; k += kBlock) {
+            const uint32_t c = s_cnt[k];
+            if (c) atomicAdd(&tile_count[win.tile_of(k, gx, inv_w)], c);
+        }
+    } else if (t.visible) {                                  // huge footprints: straight to global memory
+        for (int ty = t.r1; ty < t.r3; ++ty)
+            for (int tx = t.r0; tx < t.r2; ++tx) atomicAdd(&tile_count[ty * gx + tx], 1u);
+    }
+}
+
 template <bool WANT_J>      // WANT_J: a backward will follow (forward_only == 0) and the SH coefficients are staged: leave d(colour)/d(direction) for it
 __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     d3ga_raster_params prm, const float *__restrict__ means3D, const float *__restrict__ shs,
@@ -200,8 +258,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
         if (want_j) { acc[0] = cj.a0; acc[1] = cj.a1; acc[2] = cj.a2; }
         __syncthreads();                                            // the region becomes the tile window below
     }
-    bool visible = false;
-    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    TileRect tr = {false, 0, 0, 0, 0};
 #ifdef D3GA_DIAG
     if (prm.debug & 0x200) { if (acc[0] == 12345.f) radii[0] = 1; return; }     // diag: SH staging only
 #endif
@@ -218,57 +275,118 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
                                 : preprocess_one(prm, i, means3D, shs ? shs + (size_t)M3 * i : nullptr, colors_precomp,
                                                  opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
                                                  campos);
-        const Splat &sp = o.sp;
-        if (!cov3D_precomp) {                   // (uniform) a precomputed covariance is read again from the caller's tensor
-#pragma unroll
-            for (int k = 0; k < 6; ++k) geom.cov3D[6 * (size_t)i + k] = o.c6[k];
-        }
-        radii[i] = sp.radius;
-        geom.depth[i] = sp.depth;
-        // culled Gaussians keep an EMPTY rectangle: the scatter pass and the backward test visibility through it
-        geom.rect[i] = sp.visible ? make_uint2((uint32_t)sp.rect[0] | ((uint32_t)(sp.rect[1] + tile_row0) << 16),
-                                               (uint32_t)sp.rect[2] | ((uint32_t)(sp.rect[3] + tile_row0) << 16))
-                                  : make_uint2(0u, 0u);
-        geom.conic_o[i] = make_float4(sp.conic[0], sp.conic[1], sp.conic[2], o.opacity);
-        {   // half extents of the splat's alpha >= 1/255 box, by the function the compositing stage culls with (bit-identical)
-            const SplatCull sc = splat_cull(sp.conic[0], sp.conic[1], sp.conic[2], o.opacity);
-            geom.xyh[i] = make_float4(sp.px, sp.py, sp.visible ? sc.hx : -1.0f, sc.hy);
-        }
-        geom.rgb_invd[i] = make_float4(o.rgb[0], o.rgb[1], o.rgb[2], sp.visible ? 1.0f / sp.depth : 0.f);
-        geom.clamped[i] = o.clampmask;
-        if (want_j) {
-            const float jv[9] = {cj.j0, cj.j1, cj.j2, cj.j3, cj.j4, cj.j5, cj.j6, cj.j7, cj.j8};
-#pragma unroll
-            for (int k = 0; k < 9; ++k) D3GA_DCOL_AT(geom.dcol, i, k, geom.dcol_stride) = jv[k];
-        }
-        visible = sp.visible;
-        r0 = sp.rect[0]; r1 = sp.rect[1] + tile_row0; r2 = sp.rect[2]; r3 = sp.rect[3] + tile_row0;
+        tr = write_geom_records(geom, i, o, !cov3D_precomp, tile_row0, radii, want_j, cj);
     }
 #ifdef D3GA_DIAG
     if (prm.debug & 0x100) return;                                              // diag: no histogram
 #endif
-    // ---- tile histogram (counting-sort pass 1) through the block's LDS window ----
-    const int gx = (prm.W + kTile - 1) / kTile;
-    const TileWindow win = block_tile_window(s_box, visible, r0, r1, r2, r3);   // barriers inside: slabs are dead now
-    const int nvis = __syncthreads_count(visible);
-    if (tid == 0 && nvis) atomicAdd(&counters[D3GA_CNT_VISIBLE], (uint32_t)nvis);
-    const int area = win.area();
-    if (area == 0) return;                                   // uniform
-    if (win.fits()) {
-        for (int k = tid; k < area; k += kBlock) s_cnt[k] = 0;
-        __syncthreads();
-        if (visible)
-            for (int ty = r1; ty < r3; ++ty)
-                for (int tx = r0; tx < r2; ++tx) atomicAdd(&s_cnt[(ty - win.y0) * win.w + (tx - win.x0)], 1u);
-        __syncthreads();
-        const float inv_w = 1.0f / (float)win.w;
-        for (int k = tid; k < area; k += kBlock) {
-            const uint32_t c = s_cnt[k];
-            if (c) atomicAdd(&tile_count[win.tile_of(k, gx, inv_w)], c);
+    tile_histogram(s_box, s_cnt, tr, (prm.W + kTile - 1) / kTile, tile_count, counters);      // (barriers inside: the slabs are dead now)
+}
+
+// The same for KV views of ONE set of Gaussians in one pass (view-batched renders with shared geometry, d3ga.h: n_views): the
+// Gaussian's mean, covariance, opacity and -- the bulk of the kernel's traffic, 12 M bytes -- its SH row are read ONCE; per view the
+// colour (and its direction Jacobian) is formed from the staged row with that view's direction, the projection runs, the records go
+// to the view's section of the batch's buffers and the view's histogram pass follows.  Per view the arithmetic is that of
+// preprocess_kernel (same inlined functions, same order): bit-identical records.  views: KV cameras starting at `view0`.
+template <int KV>
+struct ViewCams { const float *vm[KV], *pm[KV], *cp[KV]; };
+template <bool WANT_J, int KV>
+__device__ __forceinline__ void staged_sh_colour_views(const d3ga_raster_params &prm, const float *__restrict__ means3D,
+                                                       const float *__restrict__ shs, const ViewCams<KV> &cams, float *s_sh,
+                                                       ShColJ (&cj)[KV]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * kBlock + tid;
+    const int M3 = 3 * prm.M;
+    float *slab = s_sh + wave * kShHalfSlab;
+    const int row0 = blockIdx.x * kBlock + wave * 64;
+    const int rows = min(64, prm.P - row0);
+    const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
+    auto eval = [&](const float *row) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < KV; ++v) {
+            float B[16];
+            if (WANT_J) {
+                float dx, dy, dz;
+                sh_view_dir(means3D, i, cams.cp[v], dx, dy, dz);
+                sh_basis(prm.sh_degree, dx, dy, dz, B);
+                cj[v] = sh_accumulate_jacobian(B, dx, dy, dz, row, nb, cj[v]);
+            } else {
+                sh_view_basis(prm, means3D, i, cams.cp[v], B);
+                float acc[3] = {cj[v].a0, cj[v].a1, cj[v].a2};
+                sh_accumulate(B, row, 0, 16, nb, acc);
+                cj[v].a0 = acc[0]; cj[v].a1 = acc[1]; cj[v].a2 = acc[2];
+            }
         }
-    } else if (visible) {                                    // huge footprints: straight to global memory
-        for (int ty = r1; ty < r3; ++ty)
-            for (int tx = r0; tx < r2; ++tx) atomicAdd(&tile_count[ty * gx + tx], 1u);
+    };
+    if (M3 == 48 && rows == 64) {                              // wave-uniform: a full wavefront of full rows
+        static_assert(kShPasses == 2, "two passes");
+        const float *src = shs + (size_t)48 * row0;
+        const ShRegs<kShPassRows> h0 = sh_rows48_load<kShPassRows>(src, lane);
+        const ShRegs<kShPassRows> h1 = sh_rows48_load<kShPassRows>(src + 48 * kShPassRows, lane);
+        __builtin_amdgcn_wave_barrier();
+        sh_rows48_to_slab<kShPassRows>(slab, h0, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (lane / kShPassRows == 0) eval(slab + (lane % kShPassRows) * kShRow);
+        __builtin_amdgcn_wave_barrier();
+        sh_rows48_to_slab<kShPassRows>(slab, h1, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (lane / kShPassRows == 1) eval(slab + (lane % kShPassRows) * kShRow);
+        return;
+    }
+    for (int h = 0; h < kShPasses; ++h) {
+        const int r = min(kShPassRows, rows - kShPassRows * h);
+        __builtin_amdgcn_wave_barrier();
+        if (r > 0) sh_slab_load(slab, shs + (size_t)M3 * (row0 + kShPassRows * h), r, M3, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (i < prm.P && lane / kShPassRows == h) eval(slab + (lane % kShPassRows) * kShRow);
+    }
+}
+
+template <bool WANT_J, int KV>
+__global__ __launch_bounds__(kBlock) void preprocess_views_kernel(
+    d3ga_raster_params prm, const float *__restrict__ means3D, const float *__restrict__ shs,
+    const float *__restrict__ colors_precomp, const float *__restrict__ opacities, const float *__restrict__ scales,
+    const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, ViewCams<KV> cams, GeomBuf geom /* of the first view */,
+    uint32_t *__restrict__ tile_count, uint32_t *__restrict__ counters, int32_t *__restrict__ radii /* of the first view */,
+    int tile_row0, int gyv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_box[4];
+    float *s_sh = reinterpret_cast<float *>(smem);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kBlock + tid;
+    const bool slot = !(prm.tanfovx > 0.f);                     // camera slots: the tangents ride behind every view's position
+    // shared by the views: covariance row and opacity (in flight while the SH rows are staged)
+    float pc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pop = 0.f;
+    const bool pre = cov3D_precomp != nullptr;
+    if (pre && i < prm.P) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pc6[k] = cov3D_precomp[6 * (size_t)i + k];
+        pop = opacities[i];
+    }
+    ShColJ cj[KV];
+#pragma unroll
+    for (int v = 0; v < KV; ++v) cj[v] = ShColJ{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    staged_sh_colour_views<WANT_J, KV>(prm, means3D, shs, cams, s_sh, cj);
+    const int gx = (prm.W + kTile - 1) / kTile;
+#pragma unroll
+    for (int v = 0; v < KV; ++v) {
+        __syncthreads();                                        // the LDS region changes hands: slabs -> window, window -> window
+        TileRect tr = {false, 0, 0, 0, 0};
+        if (i < prm.P) {
+            d3ga_raster_params pv = prm;
+            if (slot) { pv.tanfovx = cams.cp[v][3]; pv.tanfovy = cams.cp[v][4]; }
+            PreLoaded pl;
+            pl.has_sh = true; pl.has_c6 = pre;
+            pl.sh[0] = cj[v].a0; pl.sh[1] = cj[v].a1; pl.sh[2] = cj[v].a2;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pl.c6[k] = pc6[k];
+            pl.op = pop;
+            const PreOut o = preprocess_one(pv, i, means3D, nullptr, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                            cams.vm[v], cams.pm[v], cams.cp[v], pl);
+            tr = write_geom_records(geom_view(geom, prm.P, v), i, o, !cov3D_precomp, tile_row0 + v * gyv, radii + (size_t)prm.P * v, WANT_J, cj[v]);
+        }
+        tile_histogram(s_box, s_cnt, tr, gx, tile_count, counters);
     }
 }
 
@@ -425,6 +543,141 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_kernel(
     }
 }
 
+// R6 for the views of a batch that share their geometry (d3ga.h: n_views without per_view_geometry), ONE pass: thread i walks the kv
+// views of Gaussian i -- per view its accumulator record, rectangle, clamp mask, stored opacity and d(colour)/d(direction) --, sums
+// the gradients of the shared inputs in registers and writes every output ONCE: no read-modify-write of dL/dmeans3D / dL/dcov /
+// dL/dopacity per view, no (P,3) factors through memory, the (P,M,3) SH row formed here (sum_v Y(dir_v) (x) g_v, as
+// sh_grad_from_views_kernel forms it) instead of by a pass of its own.  Same per-view arithmetic as preprocess_bwd_one (cov2d_bwd,
+// project_bwd, the direction term from the forward's Jacobian), views added in ascending order like the per-view launches add them.
+// SH colours need the forward's dcol planes (staged coefficients, forward_only == 0): the launcher falls back to per-view launches
+// otherwise, and for the factored SH output of the camera-sharded exchange.  accum: a later group of a batch of more than kMaxGroup
+// views -- every output is added to.
+constexpr int kMaxGroup = 8;
+struct ViewCamsN { const float *vm[kMaxGroup], *pm[kMaxGroup], *cp[kMaxGroup]; };
+__global__ __launch_bounds__(kBlock) void preprocess_bwd_views_kernel(
+    d3ga_raster_params prm, int kv, const float *__restrict__ means3D, bool sh_path, const float *__restrict__ scales,
+    const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, ViewCamsN cams, GeomBuf geom /* first view of the group */,
+    const float *__restrict__ acc /* first view of the group */, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D /* first view | null */,
+    float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors, float *__restrict__ dL_dcov3D,
+    float *__restrict__ dL_dscales, float *__restrict__ dL_drots, bool accum) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_sh = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * kBlock + tid;
+    const int M3 = 3 * prm.M;
+    const int row0 = blockIdx.x * kBlock + wave * 64;
+    const int rows = min(64, prm.P - row0);
+    float *slab = s_sh + wave * kShSlab;
+    const bool slot = !(prm.tanfovx > 0.f);
+    const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
+    if (i < prm.P) {
+        const V3 mean = ld3(means3D, i);
+        float c6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = (cov3D_precomp ? cov3D_precomp : geom.cov3D)[6 * (size_t)i + k];   // (from scale / rotation: view 0's record -- the same in every view)
+        float gmean[3] = {0.f, 0.f, 0.f}, g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gop = 0.f, gcol[3] = {0.f, 0.f, 0.f};
+        float out[48];
+#pragma unroll
+        for (int k = 0; k < 48; ++k) out[k] = 0.f;
+        for (int v = 0; v < kv; ++v) {
+            const size_t j = (size_t)prm.P * v + i;                          // this view's record
+            const uint2 rc = geom.rect[j];
+            const float4 *ap = reinterpret_cast<const float4 *>(acc + D3GA_ACC_STRIDE * j);
+            const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+            if (prm.acc_self_clearing) {
+                const uint32_t any = (__float_as_uint(a0.x) | __float_as_uint(a0.y) | __float_as_uint(a0.z) | __float_as_uint(a0.w)) |
+                                     (__float_as_uint(a1.x) | __float_as_uint(a1.y) | __float_as_uint(a1.z) | __float_as_uint(a1.w)) |
+                                     (__float_as_uint(a2.x) | __float_as_uint(a2.y) | __float_as_uint(a2.z) | __float_as_uint(a2.w));
+                if (any) {
+                    float4 *wp = const_cast<float4 *>(ap);
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    wp[0] = z; wp[1] = z; wp[2] = z;
+                }
+            }
+            const bool visible = ((rc.y & 0xffffu) > (rc.x & 0xffffu)) && ((rc.y >> 16) > (rc.x >> 16));
+            if (dL_dmeans2D) {                                                // screen-space: per view
+                float *m2 = dL_dmeans2D + 3 * j;
+                m2[0] = visible ? a0.x : 0.f; m2[1] = visible ? a0.y : 0.f; m2[2] = 0.f;
+            }
+            if (!visible) continue;
+            const uint8_t clampmask = geom.clamped[j];
+            const float act_opacity = geom.conic_o[j].w;
+            const float a[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+            const float *vm = cams.vm[v], *pm = cams.pm[v], *cp = cams.cp[v];
+            const float tfx = slot ? cp[3] : prm.tanfovx, tfy = slot ? cp[4] : prm.tanfovy;
+            float gm_v[3] = {0.f, 0.f, 0.f}, g6_v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, aa = 1.0f;
+            cov2d_bwd(mean, c6, vm, prm.W, prm.H, tfx, tfy, a[3], a[4], a[5], g6_v, gm_v, prm.antialiasing != 0, a[6], act_opacity, &aa);
+            project_bwd(mean, pm, a[0], a[1], gm_v);
+            const float z = vm[2] * mean.x + vm[6] * mean.y + vm[10] * mean.z + vm[14];
+            const float gz = -a[10] / (z * z);
+            gm_v[0] += vm[2] * gz; gm_v[1] += vm[6] * gz; gm_v[2] += vm[10] * gz;
+            if (sh_path) {
+                const float gr[3] = {(clampmask & 1) ? 0.f : a[7], (clampmask & 2) ? 0.f : a[8], (clampmask & 4) ? 0.f : a[9]};
+                const V3 d0 = mean - v3(cp[0], cp[1], cp[2]);
+                const float inv = 1.0f / sqrtf(dot(d0, d0));
+                float B[16];
+                sh_basis(prm.sh_degree, d0.x * inv, d0.y * inv, d0.z * inv, B);
+                const float *d = geom.dcol;
+                const float j0 = D3GA_DCOL_AT(d, j, 0, geom.dcol_stride), j1 = D3GA_DCOL_AT(d, j, 1, geom.dcol_stride), j2 = D3GA_DCOL_AT(d, j, 2, geom.dcol_stride);
+                const float j3 = D3GA_DCOL_AT(d, j, 3, geom.dcol_stride), j4 = D3GA_DCOL_AT(d, j, 4, geom.dcol_stride), j5 = D3GA_DCOL_AT(d, j, 5, geom.dcol_stride);
+                const float j6 = D3GA_DCOL_AT(d, j, 6, geom.dcol_stride), j7 = D3GA_DCOL_AT(d, j, 7, geom.dcol_stride), j8 = D3GA_DCOL_AT(d, j, 8, geom.dcol_stride);
+                const V3 gd = v3(j0 * gr[0] + j1 * gr[1] + j2 * gr[2], j3 * gr[0] + j4 * gr[1] + j5 * gr[2], j6 * gr[0] + j7 * gr[1] + j8 * gr[2]);
+                const V3 gm = normalize_bwd(d0, gd);
+                gm_v[0] += gm.x; gm_v[1] += gm.y; gm_v[2] += gm.z;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < nb) { out[3 * k] += B[k] * gr[0]; out[3 * k + 1] += B[k] * gr[1]; out[3 * k + 2] += B[k] * gr[2]; }
+            } else {
+                gcol[0] += a[7]; gcol[1] += a[8]; gcol[2] += a[9];
+            }
+            {
+                const float op = act_opacity / aa, g_op = a[6] * aa;
+                gop += prm.opacity_activation == D3GA_OPACITY_SIGMOID ? g_op * op * (1.0f - op) : g_op;
+            }
+            gmean[0] += gm_v[0]; gmean[1] += gm_v[1]; gmean[2] += gm_v[2];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) g6[k] += g6_v[k];
+        }
+        auto put = [&](float *p, float v) { *p = accum ? *p + v : v; };
+        put(dL_dmeans3D + 3 * (size_t)i, gmean[0]); put(dL_dmeans3D + 3 * (size_t)i + 1, gmean[1]); put(dL_dmeans3D + 3 * (size_t)i + 2, gmean[2]);
+        if (dL_dopacity) put(dL_dopacity + i, gop);
+        if (!sh_path && dL_dcolors) { put(dL_dcolors + 3 * (size_t)i, gcol[0]); put(dL_dcolors + 3 * (size_t)i + 1, gcol[1]); put(dL_dcolors + 3 * (size_t)i + 2, gcol[2]); }
+        if (dL_dcov3D) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) put(dL_dcov3D + 6 * (size_t)i + k, g6[k]);
+        }
+        if (dL_dscales && dL_drots) {
+            const float sc[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+            const float q[4] = {rotations[4 * (size_t)i], rotations[4 * (size_t)i + 1], rotations[4 * (size_t)i + 2], rotations[4 * (size_t)i + 3]};
+            float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+            cov3d_from_scale_rot_bwd(sc, prm.scale_modifier, q, g6, gs, gq);      // (linear in g6: the views' sum goes through once)
+            for (int k = 0; k < 3; ++k) put(dL_dscales + 3 * (size_t)i + k, gs[k]);
+            for (int k = 0; k < 4; ++k) put(dL_drots + 4 * (size_t)i + k, gq[k]);
+        }
+        if (sh_path && dL_dsh) {
+            float *row = slab + lane * kShRow;
+#pragma unroll
+            for (int k = 0; k < 48; ++k)
+                if (k < M3) row[k] = out[k];
+        }
+    }
+    if (sh_path && dL_dsh) {
+        __builtin_amdgcn_wave_barrier();          // the slab is private to the wavefront: program order suffices
+        if (accum) {                              // a later group of a large batch: add to what the earlier groups wrote
+            const int nvec = rows > 0 ? rows * M3 / 4 : 0;
+            float4 *dst = reinterpret_cast<float4 *>(dL_dsh + (size_t)M3 * row0);
+            for (int v = lane; v < nvec; v += 64) {
+                const int e = 4 * v, r = e / M3, c = e - r * M3;
+                const float4 x = *reinterpret_cast<const float4 *>(slab + r * kShRow + c);
+                float4 y = dst[v];
+                y.x += x.x; y.y += x.y; y.z += x.z; y.w += x.w;
+                dst[v] = y;
+            }
+        } else if (M3 == 48 && rows == 64) sh_rows48_store<64>(slab, dL_dsh + (size_t)48 * row0, lane);
+        else if (rows > 0) sh_slab_store(slab, dL_dsh + (size_t)M3 * row0, rows, M3, lane);
+    }
+}
+
 // View-sharded training: the SH gradient of one view is rank-1 per Gaussian,
 //   dL/dsh[i][k][c] = basis_k(normalize(mean_i - campos_v)) * g_v[i][c],      g_v = clamp-masked dL/dcolour,
 // so the ranks exchange the (P,3) factor g_v (all-gather) instead of summing (P,M,3) blocks (all-reduce) and every rank
@@ -529,17 +782,44 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     // a batch of views: one launch per view into ITS records of the batch's buffers (the per-Gaussian stage is a streaming kernel
     // at the copy rate with nothing to gain from a taller grid; what the batch shares is everything downstream)
     const size_t pv = (views > 1 && prm->per_view_geometry) ? (size_t)prm->P : 0;      // records between the views' geometry (0: shared)
-    for (int v = 0; v < views; ++v) {
+    const dim3 grid((prm->P + kBlock - 1) / kBlock), block(kBlock);
+    int v0 = 0;
+    // k cameras of ONE set of Gaussians with staged SH colours: groups of up to four views per pass (preprocess_views_kernel: the
+    // 12 M-byte coefficient row, the mean and the covariance are read once per group instead of once per view)
+    const bool grouped = views > 1 && pv == 0 && shs && prm->M > 0 && (3 * prm->M) % 4 == 0 && 3 * prm->M <= 48;
+#define D3GA_PRE_VIEWS(KVV)                                                                                                        \
+    do {                                                                                                                           \
+        ViewCams<KVV> vc;                                                                                                          \
+        for (int q = 0; q < KVV; ++q) {                                                                                            \
+            vc.vm[q] = viewmatrix + 16 * (size_t)(v0 + q); vc.pm[q] = projmatrix + 16 * (size_t)(v0 + q);                          \
+            vc.cp[q] = campos + (size_t)cam_stride * (v0 + q);                                                                     \
+        }                                                                                                                          \
+        if (want_j) hipLaunchKernelGGL((preprocess_views_kernel<true, KVV>), grid, block, lds, s, *prm, means3D, shs, colors_precomp,  \
+                                       opacities, scales, rotations, cov3D_precomp, vc, geom_view(g, prm->P, v0), bin.tile_count,  \
+                                       bin.counters, radii + (size_t)prm->P * v0, v0 * gyv, gyv);                                  \
+        else hipLaunchKernelGGL((preprocess_views_kernel<false, KVV>), grid, block, lds, s, *prm, means3D, shs, colors_precomp,    \
+                                opacities, scales, rotations, cov3D_precomp, vc, geom_view(g, prm->P, v0), bin.tile_count,         \
+                                bin.counters, radii + (size_t)prm->P * v0, v0 * gyv, gyv);                                         \
+        v0 += KVV;                                                                                                                 \
+    } while (0)
+    while (grouped && views - v0 >= 2) {
+        const int left = views - v0;
+        if (left >= 4 && left != 5) D3GA_PRE_VIEWS(4);          // (5 = 3 + 2: no single view left over)
+        else if (left == 3 || left == 5) D3GA_PRE_VIEWS(3);
+        else D3GA_PRE_VIEWS(2);
+    }
+#undef D3GA_PRE_VIEWS
+    for (int v = v0; v < views; ++v) {
         const GeomBuf gv = geom_view(g, prm->P, v);
         const float *vm = viewmatrix + 16 * (size_t)v, *pm = projmatrix + 16 * (size_t)v, *cp = campos + (size_t)cam_stride * v;
         const float *mv = means3D + 3 * pv * v, *sv = scales ? scales + 3 * pv * v : nullptr, *rq = rotations ? rotations + 4 * pv * v : nullptr;
         const float *cv = cov3D_precomp ? cov3D_precomp + 6 * pv * v : nullptr;
         int32_t *rv = radii + (size_t)prm->P * v;
         if (want_j)
-            hipLaunchKernelGGL(preprocess_kernel<true>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, mv, shs,
+            hipLaunchKernelGGL(preprocess_kernel<true>, grid, block, lds, s, *prm, mv, shs,
                                colors_precomp, opacities, sv, rq, cv, vm, pm, cp, gv, bin.tile_count, bin.counters, rv, v * gyv);
         else
-            hipLaunchKernelGGL(preprocess_kernel<false>, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), lds, s, *prm, mv, shs,
+            hipLaunchKernelGGL(preprocess_kernel<false>, grid, block, lds, s, *prm, mv, shs,
                                colors_precomp, opacities, sv, rq, cv, vm, pm, cp, gv, bin.tile_count, bin.counters, rv, v * gyv);
     }
     return check_launch(s, prm->debug & 0xff);
@@ -594,11 +874,32 @@ extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const f
                            dL_dopacity, dL_dsh, dL_dcolors, dL_dcov3D, dL_dscales, dL_drots, cov3D_precomp, 0);
         return check_launch(s, prm->debug);
     }
-    // a batch of views (d3ga.h: n_views): one launch per view on ITS records; view 0 writes the gradients of the view-independent
-    // inputs, the later ones add to them (launches of one stream: ordered); the SH gradient leaves as per-view (P,3) factors and
-    // the (P,M,3) block is rebuilt ONCE from all of them -- 12 M bytes per Gaussian and batch instead of per view
-    if (shs && !dL_dcolors) return D3GA_E_NULL;
     const int cam_stride = prm->tanfovx > 0.f ? 3 : 5;
+    // k views that SHARE their geometry: one pass over the Gaussians walks the views (preprocess_bwd_views_kernel), up to eight per
+    // launch -- when the SH gradient is wanted as the (P,M,3) block (not as the factors of the camera-sharded exchange) and, for SH
+    // colours, the forward left its direction Jacobian
+    {
+        const bool staged_sh = shs && prm->M > 0 && (3 * prm->M) % 4 == 0 && 3 * prm->M <= 48;
+        const bool looped = !prm->per_view_geometry && (shs ? (dL_dsh != nullptr && staged_sh && D3GA_PRE_DCOL && !prm->forward_only) : true);
+        if (looped) {
+            for (int v0 = 0; v0 < views; v0 += kMaxGroup) {
+                const int kv = views - v0 < kMaxGroup ? views - v0 : kMaxGroup;
+                ViewCamsN vc;
+                for (int q = 0; q < kMaxGroup; ++q) {
+                    const int v = v0 + (q < kv ? q : 0);
+                    vc.vm[q] = viewmatrix + 16 * (size_t)v; vc.pm[q] = projmatrix + 16 * (size_t)v; vc.cp[q] = campos + (size_t)cam_stride * v;
+                }
+                const size_t o = (size_t)prm->P * v0;
+                hipLaunchKernelGGL(preprocess_bwd_views_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), shs ? kShLdsBytes : 0, s, *prm, kv,
+                                   means3D, shs != nullptr, scales, rotations, cov3D_precomp, vc, geom_view(g, prm->P, v0), acc + D3GA_ACC_STRIDE * o,
+                                   dL_dmeans3D, dL_dmeans2D ? dL_dmeans2D + 3 * o : nullptr, dL_dopacity, dL_dsh, dL_dcolors, dL_dcov3D,
+                                   dL_dscales, dL_drots, v0 > 0);
+            }
+            return check_launch(s, prm->debug);
+        }
+    }
+    // otherwise: one launch per view on ITS records; view 0 writes the gradients of the view-independent
+    if (shs && !dL_dcolors) return D3GA_E_NULL;
     const size_t pv = prm->per_view_geometry ? (size_t)prm->P : 0;      // a batch of frames: every view has its own geometry and geometry gradients
     if (prm->factor_rows != 0 && prm->factor_rows < prm->P) return D3GA_E_SIZE;
     const size_t fr = prm->factor_rows > 0 ? (size_t)prm->factor_rows : (size_t)prm->P;      // rows between the views' SH factors

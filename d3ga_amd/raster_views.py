@@ -186,7 +186,9 @@ class _RasterizeViews(torch.autograd.Function):
             grad_colors = torch.zeros((k, 3, prm.H, prm.W), dtype=torch.float32, device=dev)
         grad_colors = _R._f32(grad_colors, dev)
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        acc = torch.empty((k * P, _lib.ACC_STRIDE), dtype=torch.float32, device=dev)
+        # (k P, 16) screen-space accumulator: under rasterizer.set_accumulator_policy("persistent") ONE zeroed buffer per size is kept
+        # and the per-Gaussian backward leaves it all zero again -- no 64 B x k P fill per backward
+        acc, self_clearing = _R._accumulator(k * P, dev)
         from_sr = cov3Ds_precomp is None
         sync, flat, factor = ctx.grad_sync, None, None
         if sync is None:
@@ -218,10 +220,15 @@ class _RasterizeViews(torch.autograd.Function):
                 p2 = RasterParams(**{f: getattr(prm, f) for f, _ in RasterParams._fields_})
                 p2.factor_rows = P + 1
                 prm = p2
+        if self_clearing != bool(prm.acc_self_clearing):
+            p3 = RasterParams(**{f: getattr(prm, f) for f, _ in RasterParams._fields_})      # (ctx.prm may be shared with a retained graph)
+            p3.acc_self_clearing = int(self_clearing)
+            prm = p3
         L = _lib.lib()
         st, pp = stream_handle(), ctypes.byref(prm)          # (prm: the block with factor_rows when the gradients are exchanged)
         tm = _R.stage_timer
-        acc.zero_()
+        if not self_clearing:
+            acc.zero_()
         if ctx.dual:
             tm.stage("composite_bwd", lambda: check(L.d3ga_raster_composite_bwd2(
                 pp, dptr(bg), dptr(bg2), dptr(geom), dptr(colors2), dptr(binning), ctx.cap, dptr(img), dptr(grad_colors),
