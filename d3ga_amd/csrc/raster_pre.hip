@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
 template <int KV>
 struct ViewCams { const float *vm[KV], *pm[KV], *cp[KV]; };
 template <bool WANT_J, int KV>
-__device__ __forceinline__ void staged_sh_colour_views(const d3ga_raster_params &prm, const float *__restrict__ means3D,
+__device__ __forceinline__ void staged_sh_colour_views(const d3ga_raster_params &prm, const float *__restrict__ means3D, size_t pv,
                                                        const float *__restrict__ shs, const ViewCams<KV> &cams, float *s_sh,
                                                        ShColJ (&cj)[KV]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -305,13 +305,14 @@ __device__ __forceinline__ void staged_sh_colour_views(const d3ga_raster_params 
 #pragma unroll
         for (int v = 0; v < KV; ++v) {
             float B[16];
+            const float *mv = means3D + 3 * pv * v;                  // (a batch of frames: every view's own means)
             if (WANT_J) {
                 float dx, dy, dz;
-                sh_view_dir(means3D, i, cams.cp[v], dx, dy, dz);
+                sh_view_dir(mv, i, cams.cp[v], dx, dy, dz);
                 sh_basis(prm.sh_degree, dx, dy, dz, B);
                 cj[v] = sh_accumulate_jacobian(B, dx, dy, dz, row, nb, cj[v]);
             } else {
-                sh_view_basis(prm, means3D, i, cams.cp[v], B);
+                sh_view_basis(prm, mv, i, cams.cp[v], B);
                 float acc[3] = {cj[v].a0, cj[v].a1, cj[v].a2};
                 sh_accumulate(B, row, 0, 16, nb, acc);
                 cj[v].a0 = acc[0]; cj[v].a1 = acc[1]; cj[v].a2 = acc[2];
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_views_kernel(
     const float *__restrict__ colors_precomp, const float *__restrict__ opacities, const float *__restrict__ scales,
     const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, ViewCams<KV> cams, GeomBuf geom /* of the first view */,
     uint32_t *__restrict__ tile_count, uint32_t *__restrict__ counters, int32_t *__restrict__ radii /* of the first view */,
-    int tile_row0, int gyv) {
+    int tile_row0, int gyv, size_t pv /* records between the views' geometry: 0 = k cameras of one set of Gaussians, P = a batch of frames */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_box[4];
     float *s_sh = reinterpret_cast<float *>(smem);
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_views_kernel(
     const bool slot = !(prm.tanfovx > 0.f);                     // camera slots: the tangents ride behind every view's position
     // shared by the views: covariance row and opacity (in flight while the SH rows are staged)
     float pc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pop = 0.f;
-    const bool pre = cov3D_precomp != nullptr;
+    const bool pre = cov3D_precomp != nullptr && pv == 0;
     if (pre && i < prm.P) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) pc6[k] = cov3D_precomp[6 * (size_t)i + k];
@@ -367,22 +368,24 @@ __global__ __launch_bounds__(kBlock) void preprocess_views_kernel(
     ShColJ cj[KV];
 #pragma unroll
     for (int v = 0; v < KV; ++v) cj[v] = ShColJ{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    staged_sh_colour_views<WANT_J, KV>(prm, means3D, shs, cams, s_sh, cj);
+    staged_sh_colour_views<WANT_J, KV>(prm, means3D, pv, shs, cams, s_sh, cj);
     const int gx = (prm.W + kTile - 1) / kTile;
 #pragma unroll
     for (int v = 0; v < KV; ++v) {
         __syncthreads();                                        // the LDS region changes hands: slabs -> window, window -> window
         TileRect tr = {false, 0, 0, 0, 0};
         if (i < prm.P) {
-            d3ga_raster_params pv = prm;
-            if (slot) { pv.tanfovx = cams.cp[v][3]; pv.tanfovy = cams.cp[v][4]; }
+            d3ga_raster_params pvw = prm;
+            if (slot) { pvw.tanfovx = cams.cp[v][3]; pvw.tanfovy = cams.cp[v][4]; }
             PreLoaded pl;
             pl.has_sh = true; pl.has_c6 = pre;
             pl.sh[0] = cj[v].a0; pl.sh[1] = cj[v].a1; pl.sh[2] = cj[v].a2;
 #pragma unroll
             for (int k = 0; k < 6; ++k) pl.c6[k] = pc6[k];
             pl.op = pop;
-            const PreOut o = preprocess_one(pv, i, means3D, nullptr, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+            const size_t og = pv * v;
+            const PreOut o = preprocess_one(pvw, i, means3D + 3 * og, nullptr, colors_precomp, opacities, scales ? scales + 3 * og : nullptr,
+                                            rotations ? rotations + 4 * og : nullptr, cov3D_precomp ? cov3D_precomp + 6 * og : nullptr,
                                             cams.vm[v], cams.pm[v], cams.cp[v], pl);
             tr = write_geom_records(geom_view(geom, prm.P, v), i, o, !cov3D_precomp, tile_row0 + v * gyv, radii + (size_t)prm.P * v, WANT_J, cj[v]);
         }
@@ -559,7 +562,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_views_kernel(
     const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, ViewCamsN cams, GeomBuf geom /* first view of the group */,
     const float *__restrict__ acc /* first view of the group */, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D /* first view | null */,
     float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors, float *__restrict__ dL_dcov3D,
-    float *__restrict__ dL_dscales, float *__restrict__ dL_drots, bool accum) {
+    float *__restrict__ dL_dscales, float *__restrict__ dL_drots, bool accum,
+    size_t pv /* records between the views' geometry AND geometry gradients: 0 = shared (summed), P = a batch of frames (written per view) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_sh = reinterpret_cast<float *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -571,11 +575,28 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_views_kernel(
     const bool slot = !(prm.tanfovx > 0.f);
     const int nb = (prm.sh_degree + 1) * (prm.sh_degree + 1);
     if (i < prm.P) {
-        const V3 mean = ld3(means3D, i);
+        V3 mean = ld3(means3D, i);
         float c6[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) c6[k] = (cov3D_precomp ? cov3D_precomp : geom.cov3D)[6 * (size_t)i + k];   // (from scale / rotation: view 0's record -- the same in every view)
+        for (int k = 0; k < 6; ++k) c6[k] = (cov3D_precomp ? cov3D_precomp : geom.cov3D)[6 * (size_t)i + k];   // (from scale / rotation: view 0's record -- the same in every view of shared geometry)
         float gmean[3] = {0.f, 0.f, 0.f}, g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gop = 0.f, gcol[3] = {0.f, 0.f, 0.f};
+        auto put = [&](float *p, float v, bool add) { *p = add ? *p + v : v; };
+        auto geometry_out = [&](size_t og, const float (&gm)[3], const float (&g)[6], bool vis, bool add) {     // og: record offset of the geometry gradients
+            for (int k = 0; k < 3; ++k) put(dL_dmeans3D + 3 * (og + i) + k, gm[k], add);
+            if (dL_dcov3D)
+                for (int k = 0; k < 6; ++k) put(dL_dcov3D + 6 * (og + i) + k, g[k], add);
+            if (dL_dscales && dL_drots) {
+                float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+                if (vis) {
+                    const float sc[3] = {scales[3 * (og + i)], scales[3 * (og + i) + 1], scales[3 * (og + i) + 2]};
+                    const float q[4] = {rotations[4 * (og + i)], rotations[4 * (og + i) + 1], rotations[4 * (og + i) + 2], rotations[4 * (og + i) + 3]};
+                    cov3d_from_scale_rot_bwd(sc, prm.scale_modifier, q, g, gs, gq);      // (linear in g: a sum over views goes through once)
+                }
+                for (int k = 0; k < 3; ++k) put(dL_dscales + 3 * (og + i) + k, gs[k], add);
+                for (int k = 0; k < 4; ++k) put(dL_drots + 4 * (og + i) + k, gq[k], add);
+            }
+        };
+        const float zero3[3] = {0.f, 0.f, 0.f}, zero6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float out[48];
 #pragma unroll
         for (int k = 0; k < 48; ++k) out[k] = 0.f;
@@ -599,7 +620,15 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_views_kernel(
                 float *m2 = dL_dmeans2D + 3 * j;
                 m2[0] = visible ? a0.x : 0.f; m2[1] = visible ? a0.y : 0.f; m2[2] = 0.f;
             }
-            if (!visible) continue;
+            if (!visible) {
+                if (pv) geometry_out(pv * v, zero3, zero6, false, false);      // a batch of frames: every view's geometry gradients are written
+                continue;
+            }
+            if (pv) {                                                        // this view's own geometry
+                mean = ld3(means3D + 3 * pv * v, i);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) c6[k] = (cov3D_precomp ? cov3D_precomp + 6 * pv * v : geom.cov3D + 6 * (size_t)prm.P * v)[6 * (size_t)i + k];
+            }
             const uint8_t clampmask = geom.clamped[j];
             const float act_opacity = geom.conic_o[j].w;
             const float a[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
@@ -634,26 +663,16 @@ __global__ __launch_bounds__(kBlock) void preprocess_bwd_views_kernel(
                 const float op = act_opacity / aa, g_op = a[6] * aa;
                 gop += prm.opacity_activation == D3GA_OPACITY_SIGMOID ? g_op * op * (1.0f - op) : g_op;
             }
-            gmean[0] += gm_v[0]; gmean[1] += gm_v[1]; gmean[2] += gm_v[2];
+            if (pv) geometry_out(pv * v, gm_v, g6_v, true, false);
+            else {
+                gmean[0] += gm_v[0]; gmean[1] += gm_v[1]; gmean[2] += gm_v[2];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) g6[k] += g6_v[k];
+                for (int k = 0; k < 6; ++k) g6[k] += g6_v[k];
+            }
         }
-        auto put = [&](float *p, float v) { *p = accum ? *p + v : v; };
-        put(dL_dmeans3D + 3 * (size_t)i, gmean[0]); put(dL_dmeans3D + 3 * (size_t)i + 1, gmean[1]); put(dL_dmeans3D + 3 * (size_t)i + 2, gmean[2]);
-        if (dL_dopacity) put(dL_dopacity + i, gop);
-        if (!sh_path && dL_dcolors) { put(dL_dcolors + 3 * (size_t)i, gcol[0]); put(dL_dcolors + 3 * (size_t)i + 1, gcol[1]); put(dL_dcolors + 3 * (size_t)i + 2, gcol[2]); }
-        if (dL_dcov3D) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) put(dL_dcov3D + 6 * (size_t)i + k, g6[k]);
-        }
-        if (dL_dscales && dL_drots) {
-            const float sc[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
-            const float q[4] = {rotations[4 * (size_t)i], rotations[4 * (size_t)i + 1], rotations[4 * (size_t)i + 2], rotations[4 * (size_t)i + 3]};
-            float gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
-            cov3d_from_scale_rot_bwd(sc, prm.scale_modifier, q, g6, gs, gq);      // (linear in g6: the views' sum goes through once)
-            for (int k = 0; k < 3; ++k) put(dL_dscales + 3 * (size_t)i + k, gs[k]);
-            for (int k = 0; k < 4; ++k) put(dL_drots + 4 * (size_t)i + k, gq[k]);
-        }
+        if (!pv) geometry_out(0, gmean, g6, true, accum);
+        if (dL_dopacity) put(dL_dopacity + i, gop, accum);
+        if (!sh_path && dL_dcolors) { put(dL_dcolors + 3 * (size_t)i, gcol[0], accum); put(dL_dcolors + 3 * (size_t)i + 1, gcol[1], accum); put(dL_dcolors + 3 * (size_t)i + 2, gcol[2], accum); }
         if (sh_path && dL_dsh) {
             float *row = slab + lane * kShRow;
 #pragma unroll
@@ -786,7 +805,7 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     int v0 = 0;
     // k cameras of ONE set of Gaussians with staged SH colours: groups of up to four views per pass (preprocess_views_kernel: the
     // 12 M-byte coefficient row, the mean and the covariance are read once per group instead of once per view)
-    const bool grouped = views > 1 && pv == 0 && shs && prm->M > 0 && (3 * prm->M) % 4 == 0 && 3 * prm->M <= 48;
+    const bool grouped = views > 1 && shs && prm->M > 0 && (3 * prm->M) % 4 == 0 && 3 * prm->M <= 48;
 #define D3GA_PRE_VIEWS(KVV)                                                                                                        \
     do {                                                                                                                           \
         ViewCams<KVV> vc;                                                                                                          \
@@ -794,12 +813,12 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
             vc.vm[q] = viewmatrix + 16 * (size_t)(v0 + q); vc.pm[q] = projmatrix + 16 * (size_t)(v0 + q);                          \
             vc.cp[q] = campos + (size_t)cam_stride * (v0 + q);                                                                     \
         }                                                                                                                          \
-        if (want_j) hipLaunchKernelGGL((preprocess_views_kernel<true, KVV>), grid, block, lds, s, *prm, means3D, shs, colors_precomp,  \
-                                       opacities, scales, rotations, cov3D_precomp, vc, geom_view(g, prm->P, v0), bin.tile_count,  \
-                                       bin.counters, radii + (size_t)prm->P * v0, v0 * gyv, gyv);                                  \
-        else hipLaunchKernelGGL((preprocess_views_kernel<false, KVV>), grid, block, lds, s, *prm, means3D, shs, colors_precomp,    \
-                                opacities, scales, rotations, cov3D_precomp, vc, geom_view(g, prm->P, v0), bin.tile_count,         \
-                                bin.counters, radii + (size_t)prm->P * v0, v0 * gyv, gyv);                                         \
+        if (want_j) hipLaunchKernelGGL((preprocess_views_kernel<true, KVV>), grid, block, lds, s, *prm, means3D + 3 * pv * v0, shs, colors_precomp,  \
+                                       opacities, scales ? scales + 3 * pv * v0 : nullptr, rotations ? rotations + 4 * pv * v0 : nullptr, cov3D_precomp ? cov3D_precomp + 6 * pv * v0 : nullptr, vc, geom_view(g, prm->P, v0), bin.tile_count,  \
+                                       bin.counters, radii + (size_t)prm->P * v0, v0 * gyv, gyv, pv);                              \
+        else hipLaunchKernelGGL((preprocess_views_kernel<false, KVV>), grid, block, lds, s, *prm, means3D + 3 * pv * v0, shs, colors_precomp,    \
+                                opacities, scales ? scales + 3 * pv * v0 : nullptr, rotations ? rotations + 4 * pv * v0 : nullptr, cov3D_precomp ? cov3D_precomp + 6 * pv * v0 : nullptr, vc, geom_view(g, prm->P, v0), bin.tile_count,         \
+                                bin.counters, radii + (size_t)prm->P * v0, v0 * gyv, gyv, pv);                                     \
         v0 += KVV;                                                                                                                 \
     } while (0)
     while (grouped && views - v0 >= 2) {
@@ -880,7 +899,8 @@ extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const f
     // colours, the forward left its direction Jacobian
     {
         const bool staged_sh = shs && prm->M > 0 && (3 * prm->M) % 4 == 0 && 3 * prm->M <= 48;
-        const bool looped = !prm->per_view_geometry && (shs ? (dL_dsh != nullptr && staged_sh && D3GA_PRE_DCOL && !prm->forward_only) : true);
+        const bool looped = shs ? (dL_dsh != nullptr && staged_sh && D3GA_PRE_DCOL && !prm->forward_only) : true;
+        const size_t pvl = prm->per_view_geometry ? (size_t)prm->P : 0;
         if (looped) {
             for (int v0 = 0; v0 < views; v0 += kMaxGroup) {
                 const int kv = views - v0 < kMaxGroup ? views - v0 : kMaxGroup;
@@ -889,11 +909,13 @@ extern "C" int d3ga_raster_preprocess_bwd(const d3ga_raster_params *prm, const f
                     const int v = v0 + (q < kv ? q : 0);
                     vc.vm[q] = viewmatrix + 16 * (size_t)v; vc.pm[q] = projmatrix + 16 * (size_t)v; vc.cp[q] = campos + (size_t)cam_stride * v;
                 }
-                const size_t o = (size_t)prm->P * v0;
+                const size_t o = (size_t)prm->P * v0, og = pvl * v0;
                 hipLaunchKernelGGL(preprocess_bwd_views_kernel, dim3((prm->P + kBlock - 1) / kBlock), dim3(kBlock), shs ? kShLdsBytes : 0, s, *prm, kv,
-                                   means3D, shs != nullptr, scales, rotations, cov3D_precomp, vc, geom_view(g, prm->P, v0), acc + D3GA_ACC_STRIDE * o,
-                                   dL_dmeans3D, dL_dmeans2D ? dL_dmeans2D + 3 * o : nullptr, dL_dopacity, dL_dsh, dL_dcolors, dL_dcov3D,
-                                   dL_dscales, dL_drots, v0 > 0);
+                                   means3D + 3 * og, shs != nullptr, scales ? scales + 3 * og : nullptr, rotations ? rotations + 4 * og : nullptr,
+                                   cov3D_precomp ? cov3D_precomp + 6 * og : nullptr, vc, geom_view(g, prm->P, v0), acc + D3GA_ACC_STRIDE * o,
+                                   dL_dmeans3D + 3 * og, dL_dmeans2D ? dL_dmeans2D + 3 * o : nullptr, dL_dopacity, dL_dsh, dL_dcolors,
+                                   dL_dcov3D ? dL_dcov3D + 6 * og : nullptr, dL_dscales ? dL_dscales + 3 * og : nullptr,
+                                   dL_drots ? dL_drots + 4 * og : nullptr, v0 > 0, pvl);
             }
             return check_launch(s, prm->debug);
         }
