@@ -798,8 +798,8 @@ extern "C" int d3ga_raster_preprocess(const d3ga_raster_params *prm, const float
     // (the kernels' `staged` condition, on the host: with it and a backward to follow the forward leaves GeomBuf::dcol)
     const bool want_j = D3GA_PRE_DCOL && shs && prm->M > 0 && (3 * prm->M) % 4 == 0 && 3 * prm->M <= 48 && !prm->forward_only;
     const int cam_stride = prm->tanfovx > 0.f ? 3 : 5;       // camera slots carry the two tangents behind the position
-    // a batch of views: one launch per view into ITS records of the batch's buffers (the per-Gaussian stage is a streaming kernel
-    // at the copy rate with nothing to gain from a taller grid; what the batch shares is everything downstream)
+    // a batch of views writes view v's records at v P + i of the batch's buffers: grouped launches below when the SH row can be
+    // shared, else one launch per view (a streaming kernel at the copy rate gains nothing from a taller grid)
     const size_t pv = (views > 1 && prm->per_view_geometry) ? (size_t)prm->P : 0;      // records between the views' geometry (0: shared)
     const dim3 grid((prm->P + kBlock - 1) / kBlock), block(kBlock);
     int v0 = 0;

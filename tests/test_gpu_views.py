@@ -59,7 +59,11 @@ def _views(inp, batches, leaves, bg, use_sh, from_sr, targets=None):
 
 
 @pytest.mark.parametrize("name,scale_mult,k,use_sh,from_sr", [("T1", 3.0, 3, True, False), ("C1", 1.0, 4, True, False),
-                                                               ("T1", 3.0, 2, False, True), ("T1", 8.0, 5, False, False)])
+                                                               ("T1", 3.0, 2, False, True), ("T1", 8.0, 5, False, False),
+                                                               # the looped per-Gaussian kernels' group splits with SH colours: 2, 3 + 2,
+                                                               # 4 + 3, and 4 + 3 + 2 forward with a SECOND backward group (more than 8 views)
+                                                               ("T1", 3.0, 2, True, False), ("T1", 3.0, 5, True, True),
+                                                               ("T1", 2.0, 7, True, False), ("T1", 2.0, 9, True, False)])
 def test_batched_views_equal_the_single_view_renders(name, scale_mult, k, use_sh, from_sr):
     """Images: bit-identical per view (the same kernels on the same per-view records; only the tile numbering differs).
     Gradients: the sum over the views, formed in another order (float atomics across tiles; the SH block rebuilt from the k
@@ -82,7 +86,7 @@ def test_batched_views_equal_the_single_view_renders(name, scale_mult, k, use_sh
     assert colors.shape == (k, 3, inp["H"], inp["W"]) and radii.shape == (k, inp["means3D"].shape[0])
     for v in range(k):
         assert torch.equal(colors[v], imgs[v]), (v, float((colors[v] - imgs[v]).abs().max()))
-        assert float((colors[v] - bg.view(3, 1, 1)).abs().max()) > 0.05        # something was rendered in every view
+        assert float((colors[v].detach() - bg.view(3, 1, 1)).abs().max()) > 0.05        # something was rendered in every view
     for key in ref:
         a, b = ref[key].grad, mine[key].grad
         scale = float(a.abs().max())
@@ -171,13 +175,12 @@ def test_batched_views_refusals_and_sizes():
     assert L.d3ga_raster_recolor(ctypes.byref(prm), p, None, p, p, p, ctypes.c_void_p(buf.data_ptr() + (1 << 21)), None) == -3      # D3GA_E_CONFIG
 
 
-@pytest.mark.parametrize("use_sh,from_sr", [(True, False), (False, True)])
-def test_batch_of_frames_with_per_view_geometry(use_sh, from_sr):
+@pytest.mark.parametrize("use_sh,from_sr,k", [(True, False, 3), (False, True, 3), (True, True, 5), (True, False, 9)])
+def test_batch_of_frames_with_per_view_geometry(use_sh, from_sr, k):
     """per_view_geometry: the reference's batch holds FRAMES (train.py:218-221) -- the avatar deformed per pose, (k,P,.) geometry, shared
     appearance.  Every image equals the single-view render of (frame v's Gaussians, camera v); the geometry gradients come back per
     frame, the appearance gradients summed over the frames."""
     inp = scene_inputs("T1", scale_mult=3.0)
-    k = 3
     batches = _batches(inp, k)
     bg = torch.tensor([0.9, 0.8, 0.7], device=DEV)
     g = torch.Generator().manual_seed(13)
