@@ -816,10 +816,23 @@ def test_multi_view_gradient_sum_matches_sequential():
     assert rel_err(_np(sh.grad), _np(mean_of_views)) < 1e-5
 
 
+@pytest.fixture
+def sort_where(request):
+    """How the list-driven launches take the lists beyond the per-tile class (raster_bin.hip): the library decides from the mean list
+    length whether the 2049..4096 class rides in the 8192-key launch; the knob forces either way (0: a launch per class, 1: one)."""
+    from d3ga_amd import _lib
+    if os.environ.get("D3GA_KNOBS"):
+        pytest.skip("D3GA_KNOBS set: the knob under test is the caller's")
+    _lib.debug_set("sort_merge", request.param)
+    yield request.param
+    _lib.debug_set("sort_merge")
+
+
+@pytest.mark.parametrize("sort_where", [0, 1], indirect=True)
 @pytest.mark.parametrize("name,scale_mult,min_longest", [("T1", 14.0, 2049), ("C1", 9.0, 4097), ("C1", 30.0, 8193)])
-def test_long_tile_lists_use_the_large_sort_paths(name, scale_mult, min_longest):
-    """Tiles with more than 2048 / 8192 entries go through the 64 KB-LDS and the global-memory sort kernels (driven by
-    device-side work lists); order and image must still match the oracle."""
+def test_long_tile_lists_use_the_large_sort_paths(name, scale_mult, min_longest, sort_where):
+    """Tiles with more than 2048 / 4096 / 8192 entries go through the list-driven sort kernels (48 / 96 KB of LDS, segments beyond;
+    the 2049..4096 class in a launch of its own or inside the 8192-key launch); order and image must still match the oracle."""
     from d3ga_amd import rasterizer as R
     inp = scene_inputs(name, scale_mult=scale_mult)
     bg = torch.tensor([0.0, 0.3, 0.6])
@@ -837,13 +850,15 @@ def test_long_tile_lists_use_the_large_sort_paths(name, scale_mult, min_longest)
     _assert_image(Parity(ctx), _np(color), ocolor)
 
 
-def test_more_than_8192_splats_of_identical_depth_in_one_tile():
+@pytest.mark.parametrize("n", [9000, 3000])
+@pytest.mark.parametrize("sort_where", [0, 1], indirect=True)
+def test_more_than_8192_splats_of_identical_depth_in_one_tile(sort_where, n):
     """The degenerate input of the segmented bucket sort: > 8192 entries of ONE tile share their depth bits (a single bucket
     that exceeds the largest LDS class), so the list falls back to the bitonic network on global memory and the order is
-    decided by the Gaussian index alone."""
+    decided by the Gaussian index alone.  (n = 3000: ONE bucket of the 2049..4096 class -- the O(bucket^2) fix-up of the
+    LDS sort, in the class's own launch and inside the 8192-key launch.)"""
     from d3ga_amd import rasterizer as R
     inp = scene_inputs("T0", scale_mult=1.0)
-    n = 9000
     p = inp["means3D"][:1].repeat(n, 1).contiguous()                 # identical centres: identical depth bits
     cov = torch.tensor([[4e-4, 0, 0, 4e-4, 0, 4e-4]]).repeat(n, 1)
     op = torch.full((n, 1), 0.002)                                   # alpha < 1/255 everywhere: the list is walked, nothing blends
@@ -853,11 +868,11 @@ def test_more_than_8192_splats_of_identical_depth_in_one_tile():
     with torch.no_grad():
         color, radii, _ = rast(means3D=p.to(DEV), means2D=None, opacities=op.to(DEV), colors_precomp=col.to(DEV), cov3D_precomp=cov.to(DEV))
     cnt = R.last_counters()
-    assert cnt["max_tile"] >= 8193, cnt
+    assert cnt["max_tile"] >= (8193 if n > 8192 else 2049), cnt
     start, plist, keys = R.last_tile_lists(inp["W"], inp["H"])
     st = _np(start)
     pl = _np(plist)
-    for t in np.nonzero(np.diff(st) > 8192)[0][:4]:
+    for t in np.nonzero(np.diff(st) > (8192 if n > 8192 else 2048))[0][:4]:
         seg = pl[st[t]:st[t + 1]]
         assert np.array_equal(seg, np.sort(seg))                     # equal depth: ascending index
     assert torch.allclose(color, bg.to(DEV).reshape(3, 1, 1).expand_as(color))

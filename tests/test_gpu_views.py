@@ -14,6 +14,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def _order_bar(from_sr):
+    """Bar of the same-arithmetic comparisons below (max |a - b| / max |a| per leaf): both sides form the same sums, with the float
+    atomics of the compositing backward landing in another order -- as they do from one run of the SAME operator to the next.
+    tools/diag_spread.py measures that spread on these scenes (single-view operator against itself, 30 runs): <= 4e-7 on every
+    leaf when the covariance is given; with (scales, rotations) -- splats without the cage's deformation gradient, some of them
+    needles whose covariance Jacobian cancels heavily -- 5.4e-5 on means3D, 5.5e-5 on scales, 6.4e-5 on rotations.  The 2e-5 of
+    the other same-arithmetic tests would be below the operator's own run-to-run spread there (it failed one run in three)."""
+    return 2e-4 if from_sr else 2e-5
+
+
 def _batches(inp, k, fov_jitter=False):
     from d3ga_amd import synthetic as syn
     out = []
@@ -90,7 +100,7 @@ def test_batched_views_equal_the_single_view_renders(name, scale_mult, k, use_sh
     for key in ref:
         a, b = ref[key].grad, mine[key].grad
         scale = float(a.abs().max())
-        assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (key, float((a - b).abs().max()) / scale)
+        assert scale > 0 and float((a - b).abs().max()) <= _order_bar(from_sr) * scale, (key, float((a - b).abs().max()) / scale)
 
 
 def test_batched_views_with_the_fused_l1_loss():
@@ -210,7 +220,7 @@ def test_batch_of_frames_with_per_view_geometry(use_sh, from_sr, k):
         for n in geo:
             a, b = ref_geo[v][n], mine_geo[n].grad[v]
             scale = float(a.abs().max())
-            assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (v, n, float((a - b).abs().max()) / scale)
+            assert scale > 0 and float((a - b).abs().max()) <= _order_bar(from_sr) * scale, (v, n, float((a - b).abs().max()) / scale)
     for n in shared:
         a, b = shared[n].grad, mine_shared[n].grad
         scale = float(a.abs().max())
