@@ -33,5 +33,27 @@ def main(n=30):
         print(f"use_sh={use_sh} from_sr={from_sr}: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()), flush=True)
 
 
+def frame_spread(n=300, workload="C1"):
+    """the whole bench step (LBS + cage deform + render + fused L1 + backward) against itself: what the eager-against-replay and
+    sharded-against-sequential tests of tests/test_gpu_view_sharded.py compare (bars 1e-5 .. 1e-4 of the largest element)"""
+    import bench
+    frame = bench.Frame(workload, torch.device("cuda"), view_index=0)
+    first, worst = None, {}
+    for _ in range(n):
+        for p in frame.params.values():
+            p.grad = None
+        frame.step()
+        g = {k: p.grad.clone() for k, p in frame.params.items()}
+        if first is None:
+            first = g
+            continue
+        for k in g:
+            worst[k] = max(worst.get(k, 0.0), float((g[k] - first[k]).abs().max()) / float(first[k].abs().max()))
+    print(f"frame {workload} x{n}: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()), flush=True)
+
+
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 30)
+    if len(sys.argv) > 1 and sys.argv[1] == "frame":
+        frame_spread(int(sys.argv[2]) if len(sys.argv) > 2 else 300, sys.argv[3] if len(sys.argv) > 3 else "C1")
+    else:
+        main(int(sys.argv[1]) if len(sys.argv) > 1 else 30)
