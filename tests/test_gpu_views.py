@@ -3,6 +3,7 @@ Gaussians in one grid per stage.  Claim under test: every view's image IS the si
 are the sum over the k single-view backwards -- the single-view operator is the one the oracle tests pin (tests/test_gpu_parity.py),
 and one case here goes to the C oracle directly."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -328,3 +329,115 @@ def test_batched_views_inference_single_view_batch_and_empty_scene():
     assert e_col.shape == (k, 3, inp["H"], inp["W"]) and e_rad.shape == (k, 0)
     assert torch.equal(e_col, bg.view(1, 3, 1, 1).expand_as(e_col))
     e_col.sum().backward()                                  # (nothing to differentiate: must not raise)
+
+
+def _fuzz_case(seed):
+    """-> (tag, from_sr, per_view, geo, k, run_sequential, run_batched): one random case of test_views_fuzz; each run_* renders from fresh
+    leaves and returns (images, gradients: leaf name -> tensor, per-view geometry as (k,P,.))."""
+    from d3ga_amd import rasterizer as R
+    from d3ga_amd.cameras import batch_to_camera
+    from d3ga_amd.raster_views import CameraBatch, rasterize_gaussians_views
+    rng = np.random.default_rng(1000 + seed)
+    name = ("T0", "T1")[int(rng.integers(2))]
+    inp = scene_inputs(name, scale_mult=float(rng.uniform(1.0, 6.0)), seed=int(rng.integers(1, 50)))
+    P0 = inp["means3D"].shape[0]
+    P = int(rng.integers(max(P0 // 3, 70), P0 + 1))
+    k = int(rng.integers(2, 11))
+    use_sh, from_sr, per_view = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(3) == 0)
+    deg = int(rng.integers(0, 4)) if use_sh else 0
+    M = int(rng.choice([m for m in (1, 4, 9, 12, 16) if m >= (deg + 1) ** 2])) if use_sh else 0
+    g = torch.Generator().manual_seed(seed)
+    base = {"means3D": inp["means3D"][:P].clone(), "opacities": inp["opacities"][:P].clone()}
+    base["means3D"][torch.rand(P, generator=g) < 0.05] *= -3.0           # some land behind a camera / outside the frustum
+    if use_sh:
+        base["shs"] = inp["shs"][:P, :M].clone()
+    else:
+        base["rgb"] = inp["rgb"][:P].clone()
+    if from_sr:
+        base["scales"], base["rots"] = inp["scales"][:P].clone(), inp["scene"]["rotation"][:P].clone()
+    else:
+        base["cov6"] = inp["cov6"][:P].clone()
+    geo = ("means3D",) + (("scales", "rots") if from_sr else ("cov6",))
+    batches = _batches(inp, k, fov_jitter=bool(rng.integers(2)))
+    bg = torch.rand(3, generator=g).to(DEV)
+    gpix = torch.randn(k, 3, inp["H"], inp["W"], generator=g).to(DEV)
+    leaf = lambda t: t.to(DEV).contiguous().requires_grad_(True)
+
+    def frame_geo(n, v):          # frame v's own geometry (a batch of frames) or the shared one
+        t = base[n]
+        if not per_view:
+            return t
+        return t * (1.0 + 0.04 * v) if n != "means3D" else t + 0.01 * v
+
+    def single(v, lv):
+        cam = batch_to_camera(batches[v], device=DEV)
+        st = R.GaussianRasterizationSettings(
+            image_height=inp["H"], image_width=inp["W"], tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, scale_modifier=1.0,
+            viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=deg, campos=cam.camera_center,
+            prefiltered=False, debug=False, antialiasing=False)
+        return R.rasterize_gaussians(lv["means3D"], None, lv.get("shs"), lv.get("rgb"), lv["opacities"], lv.get("scales"), lv.get("rots"),
+                                     lv.get("cov6"), st, want_invdepth=False)[0]
+
+    def run_sequential():
+        shared = {n: leaf(t) for n, t in base.items() if not (per_view and n in geo)}
+        per, imgs = [], []
+        for v in range(k):
+            lv = dict(shared)
+            if per_view:
+                lv.update({n: leaf(frame_geo(n, v)) for n in geo})
+            img = single(v, lv)
+            (img * gpix[v]).sum().backward()
+            imgs.append(img.detach())
+            per.append({n: lv[n].grad for n in geo} if per_view else None)
+        grads = {n: t.grad for n, t in shared.items()}
+        if per_view:
+            grads.update({n: torch.stack([per[v][n] for v in range(k)]) for n in geo})
+        torch.cuda.synchronize()
+        return imgs, grads
+
+    def run_batched():
+        mine = {n: leaf(t) for n, t in base.items() if not (per_view and n in geo)}
+        if per_view:
+            mine.update({n: leaf(torch.stack([frame_geo(n, v) for v in range(k)])) for n in geo})
+        cams = CameraBatch(k, inp["W"], inp["H"], device=DEV).set(batches)
+        colors, radii = rasterize_gaussians_views(mine["means3D"], mine.get("shs"), mine.get("rgb"), mine["opacities"], mine.get("scales"),
+                                                  mine.get("rots"), mine.get("cov6"), cams, bg, sh_degree=deg)
+        (colors * gpix).sum().backward()
+        torch.cuda.synchronize()
+        return [colors[v].detach() for v in range(k)], {n: t.grad for n, t in mine.items()}
+
+    return (seed, name, P, k, use_sh, deg, M, from_sr, per_view), from_sr, per_view, geo, k, run_sequential, run_batched
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_VIEWS_FUZZ_N", "8"))))
+def test_views_fuzz(seed):
+    """Random batches through the view-batched operator against the single-view operator, view by view (a campaign:
+    D3GA_VIEWS_FUZZ_N=400): k = 2..10 cameras (every group split of the looped per-Gaussian kernels, a second backward group beyond
+    eight), a ragged number of Gaussians (the last wavefront partly filled: the generic SH staging), SH colours with active degree
+    0..3 at 16 coefficients per Gaussian or fewer (the stride of the rows; 3 M not a multiple of four: the unstaged path) or
+    precomputed colours, covariance given or from (scales, rotations), shared geometry or a batch of frames, cameras with their own
+    field of view, some Gaussians moved behind the cameras.  Images bit-identical.  Gradients: both sides form the same sums in
+    another order, so the bar is 8x what the SEQUENTIAL side differs by from itself -- measured in the test, five more sequential runs
+    -- or _order_bar where that is larger: random scenes with large splats from (scales, rotations) reach 4e-4 of the largest
+    element between two runs of the same operator (tools/diag_fuzz_views.py: needles whose covariance Jacobian cancels), while a
+    wiring error -- a view's gradient dropped, doubled or landed in another view's rows -- is O(1 / k)."""
+    tag, from_sr, per_view, geo, k, run_sequential, run_batched = _fuzz_case(seed)
+    imgs, ref = run_sequential()
+    colors, mine = run_batched()
+    for v in range(k):
+        assert torch.equal(colors[v], imgs[v]), (tag, v, float((colors[v] - imgs[v]).abs().max()))
+    again = [run_sequential()[1] for _ in range(5)]
+    bar = _order_bar(from_sr)
+    for n in ref:
+        views = range(k) if (per_view and n in geo) else (None,)
+        for v in views:
+            pick = (lambda t: t) if v is None else (lambda t: t[v])
+            a, b = pick(ref[n]), pick(mine[n])
+            scale = float(a.abs().max())
+            if scale == 0.0:
+                assert float(b.abs().max()) == 0.0, (tag, n, v)
+                continue
+            own = max(float((a - pick(r[n])).abs().max()) for r in again)
+            allowed = max(bar * scale, 8.0 * own)             # (the spread is heavy-tailed: one needle decides the maximum)
+            assert allowed <= 2e-2 * scale, (tag, n, v, own / scale)                 # (the operator itself: never that loose)
+            assert float((a - b).abs().max()) <= allowed, (tag, n, v, float((a - b).abs().max()) / scale, own / scale)
