@@ -362,6 +362,11 @@ def _fuzz_case(seed):
     bg = torch.rand(3, generator=g).to(DEV)
     gpix = torch.randn(k, 3, inp["H"], inp["W"], generator=g).to(DEV)
     leaf = lambda t: t.to(DEV).contiguous().requires_grad_(True)
+    # what is rendered: the images alone | with the fused L1 loss against targets | the RGB + silhouette pair (constant second colours)
+    mode = ("plain", "l1", "pair")[int(rng.integers(3))]
+    targets = torch.rand(k, 3, inp["H"], inp["W"], generator=g).to(DEV)
+    colors2, bg2 = torch.rand(P, 3, generator=g).to(DEV), torch.rand(3, generator=g).to(DEV)
+    gpix2 = torch.randn(k, 3, inp["H"], inp["W"], generator=g).to(DEV)
 
     def frame_geo(n, v):          # frame v's own geometry (a batch of frames) or the shared one
         t = base[n]
@@ -375,8 +380,14 @@ def _fuzz_case(seed):
             image_height=inp["H"], image_width=inp["W"], tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, scale_modifier=1.0,
             viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=deg, campos=cam.camera_center,
             prefiltered=False, debug=False, antialiasing=False)
-        return R.rasterize_gaussians(lv["means3D"], None, lv.get("shs"), lv.get("rgb"), lv["opacities"], lv.get("scales"), lv.get("rots"),
-                                     lv.get("cov6"), st, want_invdepth=False)[0]
+        args = (lv["means3D"], None, lv.get("shs"), lv.get("rgb"), lv["opacities"], lv.get("scales"), lv.get("rots"), lv.get("cov6"), st)
+        if mode == "l1":
+            out = R.rasterize_gaussians_l1(*args, targets[v].contiguous(), want_invdepth=False)
+            return out[0], out[3]
+        if mode == "pair":
+            out = R.rasterize_gaussians_pair(*args, colors2, bg2, want_invdepth=False)
+            return out[0], out[3]
+        return R.rasterize_gaussians(*args, want_invdepth=False)[0], None
 
     def run_sequential():
         shared = {n: leaf(t) for n, t in base.items() if not (per_view and n in geo)}
@@ -385,9 +396,14 @@ def _fuzz_case(seed):
             lv = dict(shared)
             if per_view:
                 lv.update({n: leaf(frame_geo(n, v)) for n in geo})
-            img = single(v, lv)
-            (img * gpix[v]).sum().backward()
-            imgs.append(img.detach())
+            img, extra = single(v, lv)
+            if mode == "l1":
+                (extra / k).backward()                                  # the batch's loss is the mean over its k images
+            elif mode == "pair":
+                ((img * gpix[v]).sum() + (extra * gpix2[v]).sum()).backward()
+            else:
+                (img * gpix[v]).sum().backward()
+            imgs.append(img.detach() if extra is None else (img.detach(), extra.detach()))
             per.append({n: lv[n].grad for n in geo} if per_view else None)
         grads = {n: t.grad for n, t in shared.items()}
         if per_view:
@@ -400,13 +416,24 @@ def _fuzz_case(seed):
         if per_view:
             mine.update({n: leaf(torch.stack([frame_geo(n, v) for v in range(k)])) for n in geo})
         cams = CameraBatch(k, inp["W"], inp["H"], device=DEV).set(batches)
-        colors, radii = rasterize_gaussians_views(mine["means3D"], mine.get("shs"), mine.get("rgb"), mine["opacities"], mine.get("scales"),
-                                                  mine.get("rots"), mine.get("cov6"), cams, bg, sh_degree=deg)
-        (colors * gpix).sum().backward()
+        out = rasterize_gaussians_views(mine["means3D"], mine.get("shs"), mine.get("rgb"), mine["opacities"], mine.get("scales"),
+                                        mine.get("rots"), mine.get("cov6"), cams, bg, sh_degree=deg,
+                                        l1_targets=targets if mode == "l1" else None, colors2=colors2 if mode == "pair" else None,
+                                        bg2=bg2 if mode == "pair" else None)
+        colors = out[0]
+        if mode == "l1":
+            out[2].backward()
+            imgs = [(colors[v].detach(), out[2].detach()) for v in range(k)]
+        elif mode == "pair":
+            ((colors * gpix).sum() + (out[2] * gpix2).sum()).backward()
+            imgs = [(colors[v].detach(), out[2][v].detach()) for v in range(k)]
+        else:
+            (colors * gpix).sum().backward()
+            imgs = [colors[v].detach() for v in range(k)]
         torch.cuda.synchronize()
-        return [colors[v].detach() for v in range(k)], {n: t.grad for n, t in mine.items()}
+        return imgs, {n: t.grad for n, t in mine.items()}
 
-    return (seed, name, P, k, use_sh, deg, M, from_sr, per_view), from_sr, per_view, geo, k, run_sequential, run_batched
+    return (seed, name, P, k, use_sh, deg, M, from_sr, per_view, mode), from_sr, per_view, geo, k, run_sequential, run_batched
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_VIEWS_FUZZ_N", "8"))))
@@ -416,7 +443,8 @@ def test_views_fuzz(seed):
     eight), a ragged number of Gaussians (the last wavefront partly filled: the generic SH staging), SH colours with active degree
     0..3 at 16 coefficients per Gaussian or fewer (the stride of the rows; 3 M not a multiple of four: the unstaged path) or
     precomputed colours, covariance given or from (scales, rotations), shared geometry or a batch of frames, cameras with their own
-    field of view, some Gaussians moved behind the cameras.  Images bit-identical.  Gradients: both sides form the same sums in
+    field of view, some Gaussians moved behind the cameras; the images alone, with the fused L1 loss, or as the RGB + silhouette
+    pair.  Images bit-identical (the loss to 3e-6).  Gradients: both sides form the same sums in
     another order, so the bar is 8x what the SEQUENTIAL side differs by from itself -- measured in the test, five more sequential runs
     -- or _order_bar where that is larger: random scenes with large splats from (scales, rotations) reach 4e-4 of the largest
     element between two runs of the same operator (tools/diag_fuzz_views.py: needles whose covariance Jacobian cancels), while a
@@ -424,8 +452,17 @@ def test_views_fuzz(seed):
     tag, from_sr, per_view, geo, k, run_sequential, run_batched = _fuzz_case(seed)
     imgs, ref = run_sequential()
     colors, mine = run_batched()
+    mode = tag[-1]
     for v in range(k):
-        assert torch.equal(colors[v], imgs[v]), (tag, v, float((colors[v] - imgs[v]).abs().max()))
+        if mode == "plain":
+            assert torch.equal(colors[v], imgs[v]), (tag, v, float((colors[v] - imgs[v]).abs().max()))
+        else:
+            assert torch.equal(colors[v][0], imgs[v][0]), (tag, v)
+            if mode == "pair":
+                assert torch.equal(colors[v][1], imgs[v][1]), (tag, v, "second image")
+    if mode == "l1":                                                    # the batch's loss = the mean of the views' losses
+        want = float(sum(float(im[1]) for im in imgs)) / k
+        assert abs(float(colors[0][1]) - want) <= 3e-6 * abs(want), (tag, float(colors[0][1]), want)
     again = [run_sequential()[1] for _ in range(5)]
     bar = _order_bar(from_sr)
     for n in ref:
