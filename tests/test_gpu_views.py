@@ -478,3 +478,43 @@ def test_views_fuzz(seed):
             allowed = max(bar * scale, 8.0 * own)             # (the spread is heavy-tailed: one needle decides the maximum)
             assert allowed <= 2e-2 * scale, (tag, n, v, own / scale)                 # (the operator itself: never that loose)
             assert float((a - b).abs().max()) <= allowed, (tag, n, v, float((a - b).abs().max()) / scale, own / scale)
+
+
+def test_batched_capacity_overflow_is_detected_and_retried():
+    """A cold high-water mark and footprints far beyond 4 P duplicates per view: the batched forward overflows its first capacity,
+    reads the count back and runs again -- images and gradients as the single-view operator's; with a static, too small capacity
+    the overflow is flagged (lists truncated), nothing faults."""
+    from d3ga_amd import rasterizer as R
+    inp = scene_inputs("T1", scale_mult=8.0)
+    k = 3
+    batches = _batches(inp, k)
+    bg = torch.tensor([0.2, 0.5, 0.8], device=DEV)
+    gpix = torch.randn(k, 3, inp["H"], inp["W"], generator=torch.Generator().manual_seed(4)).to(DEV)
+    ref = _leaves(inp, False, False)
+    imgs = []
+    for v, b in enumerate(batches):
+        img, _ = _single_view(inp, b, ref, bg, False, False)
+        (img * gpix[v]).sum().backward()
+        imgs.append(img.detach())
+    R._hwm.clear()                                           # the batched call starts from k (4 P + 1024)
+    mine = _leaves(inp, False, False)
+    colors, _ = _views(inp, batches, mine, bg, False, False)
+    cnt = R.last_counters()
+    assert cnt["D"] > k * (4 * inp["means3D"].shape[0] + 1024), "scene too small to exercise the retry"
+    assert not cnt["overflow"]
+    (colors * gpix).sum().backward()
+    torch.cuda.synchronize()
+    for v in range(k):
+        assert torch.equal(colors[v], imgs[v]), v
+    for key in ref:
+        a, b = ref[key].grad, mine[key].grad
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (key, float((a - b).abs().max()) / scale)
+    R.set_capacity_policy("static", 3000)
+    try:
+        with torch.no_grad():
+            _views(inp, batches, {n: t.detach() for n, t in mine.items()}, bg, False, False)
+        torch.cuda.synchronize()
+        assert R.last_counters()["overflow"]
+    finally:
+        R.set_capacity_policy("auto")
