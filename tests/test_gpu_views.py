@@ -518,3 +518,42 @@ def test_batched_capacity_overflow_is_detected_and_retried():
         assert R.last_counters()["overflow"]
     finally:
         R.set_capacity_policy("auto")
+
+
+def test_batched_nan_and_inf_inputs_are_contained():
+    """The containment of tests/test_gpu_parity.py::test_nan_and_inf_inputs_are_contained for a batch of views: a few Gaussians with
+    NaN / Inf positions, covariances or opacities are culled in every view (the looped per-Gaussian kernels walk them view by view):
+    finite images, bit-identical to the single-view renders of the same poisoned inputs, finite gradients for everybody else."""
+    inp = scene_inputs("T1", scale_mult=3.0)
+    k = 4
+    batches = _batches(inp, k, fov_jitter=True)
+    bg = torch.tensor([0.2, 0.3, 0.4], device=DEV)
+    bad = torch.tensor([3, 50, 117, 400, 801], device=DEV)
+    for t, (i, col, val) in zip(("means3D", "means3D", "cov6", "cov6", "opacities"),
+                                ((0, None, "nan"), (1, 2, "inf"), (2, None, "nan"), (3, 0, "inf"), (4, None, "nan"))):
+        x = inp[t]
+        if col is None:
+            x[int(bad[i])] = float(val)
+        else:
+            x[int(bad[i]), col] = float(val)
+    ref = _leaves(inp, True, False)
+    imgs = []
+    for b in batches:
+        img, _ = _single_view(inp, b, ref, bg, True, False)
+        img.sum().backward()
+        imgs.append(img.detach())
+    mine = _leaves(inp, True, False)
+    colors, radii = _views(inp, batches, mine, bg, True, False)
+    colors.sum().backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(colors).all())
+    good = torch.ones(inp["means3D"].shape[0], dtype=torch.bool, device=DEV)
+    good[bad] = False
+    for v in range(k):
+        assert torch.equal(colors[v], imgs[v]), v
+        assert int(radii[v, bad[0]]) == 0 and int(radii[v, bad[2]]) == 0
+    for key in ("means3D", "cov6", "opacities", "shs"):
+        a, b = ref[key].grad[good], mine[key].grad[good]
+        assert bool(torch.isfinite(b).all()), key
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (key, float((a - b).abs().max()) / scale)
