@@ -557,3 +557,33 @@ def test_batched_nan_and_inf_inputs_are_contained():
         assert bool(torch.isfinite(b).all()), key
         scale = float(a.abs().max())
         assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (key, float((a - b).abs().max()) / scale)
+
+
+def test_batched_views_at_full_c3_size():
+    """BASELINE configs[2] through the batched operator: 500k Gaussians, 1920 x 1080, SH degree 3, k = 3 cameras in one grid per stage
+    (1.5 M records, 24 480 tiles, ~5 M duplicates: the list-sort classes and the heavy-tile split of the backward at their real
+    sizes) -- every image bit-identical to the single-view render of that camera, the gradients the sum over the views."""
+    inp = scene_inputs("C3")
+    k = 3
+    batches = _batches(inp, k, fov_jitter=True)
+    bg = torch.tensor([1.0, 1.0, 1.0], device=DEV)
+    g = torch.Generator().manual_seed(8)
+    ref = _leaves(inp, True, False)
+    imgs, seeds = [], []
+    for v, b in enumerate(batches):
+        gp = torch.randn(3, inp["H"], inp["W"], generator=g).to(DEV)
+        img, _ = _single_view(inp, b, ref, bg, True, False)
+        (img * gp).sum().backward()
+        imgs.append(img.detach())
+        seeds.append(gp)
+    mine = _leaves(inp, True, False)
+    colors, radii = _views(inp, batches, mine, bg, True, False)
+    (colors * torch.stack(seeds)).sum().backward()
+    torch.cuda.synchronize()
+    for v in range(k):
+        assert torch.equal(colors[v], imgs[v]), (v, float((colors[v] - imgs[v]).abs().max()))
+        assert int((radii[v] > 0).sum()) > 400_000
+    for key in ref:
+        a, b = ref[key].grad, mine[key].grad
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (key, float((a - b).abs().max()) / scale)
