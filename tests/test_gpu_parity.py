@@ -469,6 +469,47 @@ def test_inference_render_skips_the_backward_lists_and_bad_fov_is_refused():
             R.GaussianRasterizer(st)(**args)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_LBS_FUZZ_N", "6"))))
+def test_lbs_fuzz(seed):
+    """D0 over random shapes against the float64 oracle (a campaign: D3GA_LBS_FUZZ_N=500): 1..4000 cage vertices, K = 1..24
+    influences per vertex (SMPL's dense table as K = J, Goliath's 8, a rigid K = 1) with repeated joints and zero weights among
+    them, 1..60 joints, weights normalised or not, with and without the vertex offsets and the global (Rh, Th); forward to 1e-5,
+    the gradients of template and offsets element-wise."""
+    from d3ga_amd.cage_deform import lbs_cage
+    rng = np.random.default_rng(5000 + seed)
+    V, J = int(rng.integers(1, 4001)), int(rng.integers(1, 61))
+    K = int(rng.choice([1, 2, 3, 4, 8, 24]))
+    g = torch.Generator().manual_seed(seed)
+    template = torch.randn(V, 3, generator=g)
+    delta = 0.1 * torch.randn(V, 3, generator=g) if rng.integers(2) else None
+    A = torch.eye(4).repeat(J, 1, 1)
+    A[:, :3, :3] = torch.linalg.qr(torch.randn(J, 3, 3, generator=g))[0] * (1.0 + 0.2 * torch.rand(J, 1, 1, generator=g))
+    A[:, :3, 3] = torch.randn(J, 3, generator=g)
+    idx = torch.from_numpy(rng.integers(0, J, size=(V, K)).astype(np.int32))
+    w = torch.rand(V, K, generator=g)
+    w[torch.rand(V, K, generator=g) < 0.2] = 0.0
+    if rng.integers(2):
+        w = w / w.sum(1, keepdim=True).clamp_min(1e-6)
+    Rh = torch.linalg.qr(torch.randn(3, 3, generator=g))[0] if rng.integers(2) else None
+    Th = torch.randn(3, generator=g) if (Rh is not None and rng.integers(2)) else None
+    tag = (seed, V, J, K, delta is not None, Rh is not None, Th is not None)
+    t32 = template.to(DEV).requires_grad_(True)
+    d32 = None if delta is None else delta.to(DEV).requires_grad_(True)
+    dv = lambda t: None if t is None else t.to(DEV)
+    out = lbs_cage(t32, d32, A.to(DEV), idx.to(DEV), w.to(DEV), dv(Rh), dv(Th))
+    t64 = template.double().requires_grad_(True)
+    d64 = None if delta is None else delta.double().requires_grad_(True)
+    db = lambda t: None if t is None else t.double()
+    ref = od.lbs_cage(t64, d64, A.double(), idx, w.double(), db(Rh), db(Th))
+    np.testing.assert_allclose(_np(out), _np(ref), rtol=1e-5, atol=1e-5 * float(ref.detach().abs().max()), err_msg=str(tag))
+    gw = torch.randn(V, 3, generator=g)
+    (out * gw.to(DEV)).sum().backward()
+    (ref * gw.double()).sum().backward()
+    assert elementwise_excess(_np(t32.grad), _np(t64.grad)) <= 1.0, tag
+    if delta is not None:
+        assert elementwise_excess(_np(d32.grad), _np(d64.grad)) <= 1.0, tag
+
+
 def test_compute_bary_matches_oracle():
     from d3ga_amd.tetra import compute_bary
     inp = scene_inputs("T1")

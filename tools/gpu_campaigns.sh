@@ -12,5 +12,6 @@ run deform_fuzz   D3GA_DEFORM_FUZZ_N=${N_DEFORM:-2000} timeout 1200 python -m py
 run shard_fuzz    D3GA_SHARD_FUZZ_N=${N_SHARD:-300} timeout 1800 python -m pytest tests -m gpu -q -k exchange_at_the_cut
 run loss_fuzz     D3GA_LOSS_FUZZ_N=${N_LOSS:-400} timeout 1200 python -m pytest tests -m gpu -q -k losses_fuzz
 run views_fuzz    D3GA_VIEWS_FUZZ_N=${N_VIEWS:-1000} timeout 1500 python -m pytest tests -m gpu -q -k views_fuzz
+run lbs_fuzz      D3GA_LBS_FUZZ_N=${N_LBS:-500} timeout 900 python -m pytest tests -m gpu -q -k lbs_fuzz
 run init_fuzz     D3GA_INIT_FUZZ_N=${N_INIT:-400} timeout 1200 python -m pytest tests -m gpu -q -k init_helpers_fuzz
 cat gpurun_out/campaigns.log
