@@ -510,6 +510,45 @@ def test_lbs_fuzz(seed):
         assert elementwise_excess(_np(d32.grad), _np(d64.grad)) <= 1.0, tag
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_FEM_FUZZ_N", "6"))))
+def test_fem_energy_fuzz(seed):
+    """D6 over random meshes against the float64 oracle (D3GA_FEM_FUZZ_N=500): 1..20000 tetrahedra over shared vertices (the
+    vertex gradient is a sum over every tetrahedron around a vertex), rest shapes from near-regular to flat (5 % of the edges' box), deformations from
+    near-identity to compressed, sheared and INVERTED elements (det F < 0: (det F - 1)^2 is smooth there, lib/cage.py:358); energy per
+    tetrahedron to 1e-4 of its scale, the vertex gradient element-wise with the cage-vertex floor of DESIGN sec. 2."""
+    from d3ga_amd.cage_deform import fem_energy
+    rng = np.random.default_rng(7000 + seed)
+    T = int(rng.integers(1, 20001))
+    V = int(rng.integers(max(4, T // 8), T + 6))                          # up to ~32 tetrahedra around a vertex (a cage: 20-30)
+    g = torch.Generator().manual_seed(seed)
+    rest = torch.randn(V, 3, generator=g)
+    tetras = torch.from_numpy(np.stack([rng.permutation(V)[:4] if V < 64 else rng.choice(V, 4, replace=False) for _ in range(T)]).astype(np.int32))
+    c = rest[tetras.long()]
+    Dn = torch.stack([c[:, 3] - c[:, 0], c[:, 2] - c[:, 0], c[:, 1] - c[:, 0]], dim=2)
+    # rest shapes from near-regular down to a volume of 5 % of the edges' box (flatter ones turn float32 rounding into the answer:
+    # det F of such an element is a difference of products 1e3 times its size -- on both sides of any comparison)
+    ok = torch.linalg.det(Dn).abs() > 0.05 * Dn.norm(dim=1).prod(dim=1)
+    tetras, Dn = tetras[ok], Dn[ok]
+    if tetras.shape[0] == 0:
+        pytest.skip("no tetrahedron with a usable rest shape")
+    Dn_inv = torch.linalg.inv(Dn.double()).float()
+    amp = float(rng.choice([0.01, 0.1, 0.5, 1.5]))                       # 1.5: many elements inverted
+    posed = rest @ (torch.eye(3) + amp * torch.randn(3, 3, generator=g)) + amp * 0.3 * torch.randn(V, 3, generator=g)
+    tag = (seed, int(tetras.shape[0]), V, amp)
+    p32 = posed.to(DEV).requires_grad_(True)
+    e = fem_energy(p32, tetras.to(DEV), Dn_inv.to(DEV))
+    p64 = posed.double().requires_grad_(True)
+    e64 = od.fem_energy(p64, tetras, Dn_inv.double())
+    # det F of a sliver multiplies rounding by cond(Dn): hold every energy to 1e-4 of the LARGEST one plus 1e-4 of its own size
+    allow = 1e-4 * e64.detach().abs() + 1e-4 * float(e64.detach().abs().max())
+    assert bool(((e.detach().cpu().double() - e64.detach()).abs() <= allow).all()), tag
+    gw = torch.rand(e64.shape[0], generator=g)
+    (e * gw.to(DEV)).sum().backward()
+    (e64 * gw.double()).sum().backward()
+    ex = elementwise_excess(_np(p32.grad), _np(p64.grad), atol_rel=1e-5)
+    assert ex <= 1.0, (tag, ex)
+
+
 def test_compute_bary_matches_oracle():
     from d3ga_amd.tetra import compute_bary
     inp = scene_inputs("T1")

@@ -13,5 +13,6 @@ run shard_fuzz    D3GA_SHARD_FUZZ_N=${N_SHARD:-300} timeout 1800 python -m pytes
 run loss_fuzz     D3GA_LOSS_FUZZ_N=${N_LOSS:-400} timeout 1200 python -m pytest tests -m gpu -q -k losses_fuzz
 run views_fuzz    D3GA_VIEWS_FUZZ_N=${N_VIEWS:-1000} timeout 1500 python -m pytest tests -m gpu -q -k views_fuzz
 run lbs_fuzz      D3GA_LBS_FUZZ_N=${N_LBS:-500} timeout 900 python -m pytest tests -m gpu -q -k lbs_fuzz
+run fem_fuzz      D3GA_FEM_FUZZ_N=${N_FEM:-600} timeout 1200 python -m pytest tests -m gpu -q -k fem_energy_fuzz
 run init_fuzz     D3GA_INIT_FUZZ_N=${N_INIT:-400} timeout 1200 python -m pytest tests -m gpu -q -k init_helpers_fuzz
 cat gpurun_out/campaigns.log
