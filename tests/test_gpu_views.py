@@ -364,6 +364,7 @@ def _fuzz_case(seed):
     leaf = lambda t: t.to(DEV).contiguous().requires_grad_(True)
     # what is rendered: the images alone | with the fused L1 loss against targets | the RGB + silhouette pair (constant second colours)
     mode = ("plain", "l1", "pair")[int(rng.integers(3))]
+    aa = bool(rng.integers(4) == 0)                                      # branch dr_aa's opacity compensation (preprocess fwd / bwd)
     targets = torch.rand(k, 3, inp["H"], inp["W"], generator=g).to(DEV)
     colors2, bg2 = torch.rand(P, 3, generator=g).to(DEV), torch.rand(3, generator=g).to(DEV)
     gpix2 = torch.randn(k, 3, inp["H"], inp["W"], generator=g).to(DEV)
@@ -379,7 +380,7 @@ def _fuzz_case(seed):
         st = R.GaussianRasterizationSettings(
             image_height=inp["H"], image_width=inp["W"], tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, scale_modifier=1.0,
             viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=deg, campos=cam.camera_center,
-            prefiltered=False, debug=False, antialiasing=False)
+            prefiltered=False, debug=False, antialiasing=aa)
         args = (lv["means3D"], None, lv.get("shs"), lv.get("rgb"), lv["opacities"], lv.get("scales"), lv.get("rots"), lv.get("cov6"), st)
         if mode == "l1":
             out = R.rasterize_gaussians_l1(*args, targets[v].contiguous(), want_invdepth=False)
@@ -417,7 +418,7 @@ def _fuzz_case(seed):
             mine.update({n: leaf(torch.stack([frame_geo(n, v) for v in range(k)])) for n in geo})
         cams = CameraBatch(k, inp["W"], inp["H"], device=DEV).set(batches)
         out = rasterize_gaussians_views(mine["means3D"], mine.get("shs"), mine.get("rgb"), mine["opacities"], mine.get("scales"),
-                                        mine.get("rots"), mine.get("cov6"), cams, bg, sh_degree=deg,
+                                        mine.get("rots"), mine.get("cov6"), cams, bg, sh_degree=deg, antialiasing=aa,
                                         l1_targets=targets if mode == "l1" else None, colors2=colors2 if mode == "pair" else None,
                                         bg2=bg2 if mode == "pair" else None)
         colors = out[0]
@@ -433,7 +434,7 @@ def _fuzz_case(seed):
         torch.cuda.synchronize()
         return imgs, {n: t.grad for n, t in mine.items()}
 
-    return (seed, name, P, k, use_sh, deg, M, from_sr, per_view, mode), from_sr, per_view, geo, k, run_sequential, run_batched
+    return (seed, name, P, k, use_sh, deg, M, from_sr, per_view, aa, mode), from_sr, per_view, geo, k, run_sequential, run_batched
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("D3GA_VIEWS_FUZZ_N", "8"))))
@@ -443,7 +444,7 @@ def test_views_fuzz(seed):
     eight), a ragged number of Gaussians (the last wavefront partly filled: the generic SH staging), SH colours with active degree
     0..3 at 16 coefficients per Gaussian or fewer (the stride of the rows; 3 M not a multiple of four: the unstaged path) or
     precomputed colours, covariance given or from (scales, rotations), shared geometry or a batch of frames, cameras with their own
-    field of view, some Gaussians moved behind the cameras; the images alone, with the fused L1 loss, or as the RGB + silhouette
+    field of view, some Gaussians moved behind the cameras, antialiasing on in a quarter of the cases; the images alone, with the fused L1 loss, or as the RGB + silhouette
     pair.  Images bit-identical (the loss to 3e-6).  Gradients: both sides form the same sums in
     another order, so the bar is 8x what the SEQUENTIAL side differs by from itself -- measured in the test, five more sequential runs
     -- or _order_bar where that is larger: random scenes with large splats from (scales, rotations) reach 4e-4 of the largest
