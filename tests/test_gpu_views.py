@@ -588,3 +588,63 @@ def test_batched_views_at_full_c3_size():
         a, b = ref[key].grad, mine[key].grad
         scale = float(a.abs().max())
         assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale, (key, float((a - b).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("persistent_acc", [False, True])
+def test_captured_batched_step_replays_with_other_cameras(persistent_acc):
+    """The view-batched training step (LBS + cage deform once, k cameras in one grid per stage, mean L1 over the k images, the whole
+    backward -- bench.py: batched_views) as ONE hipGraph: every replay, with the cameras of its CameraBatch rewritten in place and
+    new targets copied into the static buffer, leaves the loss and the gradients of the same step run eagerly; with the
+    accumulator kept between backwards (self-clearing) and allocated per backward."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from d3ga_amd import rasterizer as R
+    from d3ga_amd import synthetic as syn
+    from d3ga_amd.graph import CapturedStep
+    from d3ga_amd.raster_views import CameraBatch
+    from d3ga_amd.renderer import render_views
+    dev = torch.device(DEV)
+    frame = bench.Frame("T1", dev, view_index=0)
+    k, W, H = 3, frame.wl.width, frame.wl.height
+    cams_of = lambda r: [syn.make_batch(W, H, azimuth=0.3 + 0.7 * r + 2 * math.pi * v / 8, camera_id=v, fill=0.8 + 0.05 * v) for v in range(k)]
+    cams = CameraBatch(k, W, H, device=dev).set(cams_of(0))
+    targets = torch.rand(k, 3, H, W, generator=torch.Generator().manual_seed(0)).to(dev)
+    params = list(frame.params.values())
+    one = torch.ones((), device=dev)
+
+    def step():
+        loss = render_views(None, frame.upstream(), frame.bg, targets=targets, cameras=cams)["l1"]
+        loss.backward(one)
+        return loss
+
+    def zero():
+        for p in params:
+            p.grad = None
+    R.set_accumulator_policy("persistent" if persistent_acc else "fresh")
+    try:
+        zero(); step()
+        R.set_capacity_policy("static", int(R.last_counters()["D"] * 2.0) + 4096)
+        zero()
+        graph = CapturedStep(step, params=params, check_every=1)
+        for r in range(1, 5):
+            cams.set(cams_of(r))
+            targets.copy_(torch.rand(k, 3, H, W, generator=torch.Generator().manual_seed(r)).to(dev))
+            loss_g = graph.replay()
+            torch.cuda.synchronize()
+            static = [p.grad for p in params]                        # the graph's own gradient tensors: every replay writes THESE
+            got, lg = [g.clone() for g in static], float(loss_g.detach())
+            zero()
+            le = float(step())
+            torch.cuda.synchronize()
+            assert abs(lg - le) <= 1e-6 * abs(le), (r, lg, le)
+            for p, g in zip(params, got):
+                scale = float(p.grad.abs().max())
+                assert scale > 0 and float((p.grad - g).abs().max()) <= 1e-5 * scale, (r, float((p.grad - g).abs().max()) / scale)
+            for p, g in zip(params, static):        # (give them back: the eager step left tensors of its own in .grad)
+                p.grad = g
+        assert graph.check_overflow()["D"] > 0
+    finally:
+        R.set_capacity_policy("auto")
+        R.set_accumulator_policy("fresh")
