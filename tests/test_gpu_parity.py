@@ -89,11 +89,23 @@ def test_cage_deform_fuzz(seed):
     dbary = 0.05 * torch.randn(P, 4, generator=g)
     fused = bool(seed % 2)
     up_m, up_c = torch.randn(P, 3, generator=g), torch.randn(P, 6, generator=g)
-    # oracle, f64
+    # oracle, f64, on the float32 inputs the product gets (the canonical gradient included: rounding inv(Dm) to float32 alone moves
+    # an ill-conditioned gradient element by more than the bar -- seed 1973 of the 2000-seed campaign: one scale gradient of 0.0386
+    # beside 5.19 in its row, shifted by 1.3e-4)
     L64 = lambda t: t.double().requires_grad_(True)
-    tp64, b64, s64, r64, d64 = L64(tp0), L64(barys), L64(raw_s), L64(rot), L64(dbary)
-    m64, c64 = od.cage_deform(tp64, tetras.long(), tet_id.long(), (b64 + d64) if fused else b64, cg, torch.exp(s64), r64)
-    ((m64 * up_m.double()).sum() + (c64 * up_c.double()).sum()).backward()
+    cg = cg.float().double()
+
+    def oracle(eps, draw=0):
+        """gradients in f64; eps: every float input moved by a random relative eps (one float32 rounding): what the result CANNOT be
+        held to, element by element"""
+        ge = torch.Generator().manual_seed(seed + 77 + 1000 * draw)
+        nz = lambda t: t.double() * (1.0 + eps * (2.0 * torch.rand(t.shape, generator=ge).double() - 1.0))
+        tp64, b64, s64, r64, d64 = (nz(t).requires_grad_(True) for t in (tp0, barys, raw_s, rot, dbary))
+        m64, c64 = od.cage_deform(tp64, tetras.long(), tet_id.long(), (b64 + d64) if fused else b64, nz(cg), torch.exp(s64), r64)
+        ((m64 * up_m.double()).sum() + (c64 * up_c.double()).sum()).backward()
+        return m64, c64, tp64, b64, s64, r64, d64
+    m64, c64, tp64, b64, s64, r64, d64 = oracle(0.0)
+    moved = [oracle(6e-8, d)[2:] for d in range(4)]
     # product
     tp, b, sr, r, db = (_cu(t, True) for t in (tp0, barys, raw_s, rot, dbary))
     if fused:
@@ -104,9 +116,14 @@ def test_cage_deform_fuzz(seed):
     tag = (seed, V, T, P, fused)
     np.testing.assert_allclose(_np(m), m64.detach().numpy(), rtol=1e-4, atol=1e-5, err_msg=str(tag))
     assert rel_err(_np(c), c64.detach().numpy()) < 1e-4, tag
-    for mine, ref, name in ((tp.grad, tp64.grad, "tetpoints"), (b.grad, b64.grad, "barys"), (sr.grad, s64.grad, "scales"),
-                            (r.grad, r64.grad, "rot")) + (((db.grad, d64.grad, "dbary"),) if fused else ()):
-        ex = elementwise_excess(_np(mine), ref.numpy(), atol_rel=1e-5 if name == "tetpoints" else 1e-6)      # (the vertex gradient is a long float32 sum)
+    for j, (mine, ref, name) in enumerate(((tp.grad, tp64.grad, "tetpoints"), (b.grad, b64.grad, "barys"), (sr.grad, s64.grad, "scales"),
+                                           (r.grad, r64.grad, "rot")) + (((db.grad, d64.grad, "dbary"),) if fused else ())):
+        # element-wise bar + 4x what one float32 rounding of the INPUTS moves the element by (four draws, the largest; next to nothing
+        # for all but the ill-conditioned elements)
+        a, b_ = _np(mine).astype(np.float64), ref.numpy()
+        sens = np.max([np.abs(mv[j].grad.numpy() - b_) for mv in moved], axis=0)
+        allow = 1e-3 * np.abs(b_) + (1e-5 if name == "tetpoints" else 1e-6) * np.abs(b_).max() + 4.0 * sens    # (the vertex gradient is a long float32 sum)
+        ex = float((np.abs(a - b_) / allow).max())
         assert ex <= 1.0, (tag, name, ex)
 
 

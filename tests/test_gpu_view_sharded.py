@@ -91,7 +91,11 @@ def test_exchange_at_the_cut_equals_mean_of_per_view_gradients(path, seed):
     for k in args:
         want = 0.5 * (gA[k] + gB[k])
         err = rel_err(got[k].cpu().numpy(), want.cpu().numpy())
-        assert err < 1e-4, (path, seed, k, err)  # float-atomic ordering: ~1e-7 typical, 1.1e-5 seen once in 900; a wiring error is O(1)
+        # float-atomic ordering: ~1e-7 typical with a given covariance (1.1e-5 seen once in 900).  From (scales, rotations) the random
+        # scenes hold needle-shaped splats whose covariance Jacobian cancels: the single-view operator differs from ITSELF by up to
+        # 4e-4 of the largest element between two runs there (tools/diag_fuzz_views.py; 1.7e-4 on `scales` failed 2-3 of 300 seeds at
+        # the 1e-4 bar).  A wiring error is O(1).
+        assert err < (2e-3 if path.endswith("scale_rot") else 1e-4), (path, seed, k, err)
     if path.startswith("sh") and seed == 0:
         assert float(got["shs"].abs().max()) > 0
 
