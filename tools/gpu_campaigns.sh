@@ -8,6 +8,7 @@ run raster_fuzz   D3GA_FUZZ_N=${N_RASTER:-3000} timeout 2400 python -m pytest te
 run raster_fuzz_C1 D3GA_FUZZ_SCENE=C1 D3GA_FUZZ_N=${N_C1:-300} timeout 1800 python -m pytest tests -m gpu -q -k fuzz_ragged
 run pair_fuzz     D3GA_PAIR_FUZZ_N=${N_PAIR:-400} timeout 1200 python -m pytest tests -m gpu -q -k pair_fuzz
 run chain_fuzz    D3GA_CHAIN_FUZZ_N=${N_CHAIN:-3000} timeout 1800 python -m pytest tests -m gpu -q -k chain_fuzz
+run fused_fuzz    D3GA_FUSED_FUZZ_N=${N_FUSED:-600} timeout 1800 python -m pytest tests -m gpu -q -k fused_trunk_fuzz
 run deform_fuzz   D3GA_DEFORM_FUZZ_N=${N_DEFORM:-2000} timeout 1500 python -m pytest tests -m gpu -q -k deform_fuzz
 run shard_fuzz    D3GA_SHARD_FUZZ_N=${N_SHARD:-300} timeout 1800 python -m pytest tests -m gpu -q -k exchange_at_the_cut
 run loss_fuzz     D3GA_LOSS_FUZZ_N=${N_LOSS:-400} timeout 1200 python -m pytest tests -m gpu -q -k losses_fuzz
